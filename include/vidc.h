@@ -1,0 +1,157 @@
+/*
+ * vidc.h -- C-ABI of the MI355X-native vector-ID codec library (libvidc.so).
+ *
+ * Drop-in boundary for the per-inverted-list ID codecs of
+ * facebookresearch/vector_db_id_compression.  Plain pointers and sizes only; no Faiss,
+ * torch or C++ types cross this boundary.  Every entry point names the reference
+ * interface it replaces (file:line under /root/reference).
+ *
+ * Data model: a set of lists is a CSR pair  offsets[nlist+1] (host, uint64) + ids[ntotal].
+ * IDs are faiss::idx_t viewed as uint64 (custom_invlists_impl.cpp:79,159,217,248) or int32
+ * graph rows (altid_impl.cpp:26-37).  "dev" pointers are HIP device pointers valid on the
+ * context's device; everything else is host memory.  Out-buffers are caller-allocated.
+ *
+ * Error convention: every call returns VIDC_OK (0) or a negative vidc_status;
+ * vidc_last_error() returns a thread-local message (replaces FAISS_THROW_IF_NOT /
+ * FaissException, custom_invlists_impl.cpp:87,420-422 and custom_invlists.swig:38-57).
+ * There is NO CPU fallback: without a HIP device vidc_ctx_create fails with VIDC_ERR_NO_DEVICE.
+ */
+#ifndef VIDC_H
+#define VIDC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIDC_VERSION 100
+
+typedef enum {
+    VIDC_OK = 0,
+    VIDC_ERR_INVALID = -1,     /* bad argument */
+    VIDC_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime error at init */
+    VIDC_ERR_HIP = -3,         /* HIP runtime error (message has hipGetErrorString) */
+    VIDC_ERR_DOMAIN = -4,      /* input outside the codec's domain (id >= 2^31, id >= ntotal, list too long) */
+    VIDC_ERR_OVERFLOW = -5,    /* internal arena / mt19937 table exhausted */
+    VIDC_ERR_UNSUPPORTED = -6
+} vidc_status;
+
+const char *vidc_last_error(void);
+int vidc_version(void);
+
+/* ------------------------------------------------------------------ context */
+typedef struct vidc_ctx vidc_ctx;
+/* device < 0 : current HIP device.  Creates the context's own stream. */
+int vidc_ctx_create(int device, vidc_ctx **out);
+void vidc_ctx_destroy(vidc_ctx *ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the own stream. */
+int vidc_ctx_set_stream(vidc_ctx *ctx, void *hip_stream);
+int vidc_ctx_synchronize(vidc_ctx *ctx);
+/* Device memory helpers for hosts without their own allocator (Python uses torch tensors instead). */
+int vidc_dev_alloc(vidc_ctx *ctx, size_t bytes, void **dev_ptr);
+int vidc_dev_free(vidc_ctx *ctx, void *dev_ptr);
+int vidc_copy_h2d(vidc_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+int vidc_copy_d2h(vidc_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+
+/* ------------------------------------------------------- ROC (bits-back ANS) */
+/* Replaces: ANSState (codec.h:13-45), compress/decompress (codec.cpp:123-152),
+ * CompressedIDInvertedListsFenwickTree ctor/get_ids (custom_invlists_impl.cpp:133-223),
+ * ROCNSGGraph ctor/get_neighbors (altid_impl.cpp:103-165).
+ * Bitstreams (head + 32-bit stack words) are bit-identical to codec.cpp. */
+typedef struct vidc_roc vidc_roc;
+
+/* precision_mode for vidc_roc_encode */
+#define VIDC_PREC_REFERENCE (-1) /* ceil(log2((int)max_id)), custom_invlists_impl.cpp:163-164 (pow-2 quirk kept) */
+#define VIDC_PREC_EXACT (-2)     /* bit_width(max_id): lossless for pow-2 max ids (NOT reference-identical) */
+/* precision_mode >= 0 : fixed precision for every list (compress(n,data,state,precision), codec.cpp:123) */
+
+#define VIDC_ROC_WANT_PERM 1u /* keep the sampling permutation (code re-ordering, custom_invlists_impl.cpp:188-193) */
+
+/* Encode every list.  d_ids: device uint64[ntotal].  offsets: host uint64[nlist+1].
+ * Lists may be unsorted and may be empty.  Domain: ids < 2^31 (reference `int max_id`), n <= VIDC_ROC_MAX_LIST. */
+#define VIDC_ROC_MAX_LIST 262144u
+int vidc_roc_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint64_t *d_ids,
+                    int precision_mode, uint32_t flags, vidc_roc **out);
+/* Graph rows: d_rows device int32[N*K], -1 terminated rows (altid_impl.cpp:110-117). */
+int vidc_roc_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_rows, int precision_mode,
+                         uint32_t flags, vidc_roc **out);
+void vidc_roc_destroy(vidc_roc *r);
+
+uint64_t vidc_roc_nlist(const vidc_roc *r);
+uint64_t vidc_roc_ntotal(const vidc_roc *r);
+/* sum over non-empty lists of 8 + 4*nwords  (ANSState::size(), codec.h:42-44; :196-206) */
+uint64_t vidc_roc_compressed_bytes(const vidc_roc *r);
+uint64_t vidc_roc_total_words(const vidc_roc *r);
+/* host copies of per-list metadata (arrays of nlist): any pointer may be NULL */
+int vidc_roc_list_info(const vidc_roc *r, uint32_t *sizes, uint32_t *precisions, uint64_t *heads,
+                       uint32_t *nwords, uint32_t *mt_draws);
+/* stack words of one list, push order (parity export).  cap in words. */
+int vidc_roc_export_words(vidc_ctx *ctx, const vidc_roc *r, uint64_t list_no, uint32_t *words, size_t cap);
+/* sampling permutation for all lists: perm[offsets[l]+i] = input position of the i-th sampled id */
+int vidc_roc_perm(vidc_ctx *ctx, const vidc_roc *r, uint32_t *perm_host);
+const uint32_t *vidc_roc_perm_dev(const vidc_roc *r);
+/* Build from exported streams (decode-only parity tests, on-disk reload).  All host arrays. */
+int vidc_roc_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint32_t *precisions,
+                    const uint64_t *heads, const uint32_t *nwords, const uint32_t *mt_draws,
+                    const uint32_t *words_concat, vidc_roc **out);
+
+/* Decode every list into d_out (device uint64[ntotal], CSR order, each list in sampling order
+ * = the order get_ids returns, codec.cpp:150). */
+int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out);
+/* Decode m selected lists back to back into d_out; out_offsets (host, m+1) receives the packing. */
+int vidc_roc_decode_lists(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *list_nos,
+                          uint64_t *d_out, uint64_t *out_offsets);
+/* Graph flavour: d_out device int32[m*K]; rows padded with -1; counts (host, m) = num edges. */
+int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *nodes, uint32_t K,
+                         int32_t *d_out, uint32_t *counts);
+/* End-state self check of the last decode_all: number of lists whose final ANS state is not the
+ * initial one (head 2^31; SURVEY appendix A invariant).  Lossy reference cases (Q2/Q3) count here. */
+uint64_t vidc_roc_last_decode_nonclean(const vidc_roc *r);
+
+/* -------------------------------------------------------------- packed bits */
+/* Replaces CompressedIDInvertedListsPackedBits (custom_invlists_impl.cpp:64-118) and
+ * CompactBitNSGGraph (altid_impl.cpp:20-51).  LSB-first, little-endian (reader :35-58). */
+typedef struct vidc_packed vidc_packed;
+int vidc_packed_bits_for(uint64_t ntotal); /* :68-70 */
+int vidc_packed_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint64_t *d_ids, int bits,
+                       vidc_packed **out);
+void vidc_packed_destroy(vidc_packed *p);
+uint64_t vidc_packed_compressed_bytes(const vidc_packed *p); /* sum ceil(ls*bits/8), :80,85 */
+int vidc_packed_bits(const vidc_packed *p);
+int vidc_packed_decode_all(vidc_ctx *ctx, const vidc_packed *p, uint64_t *d_out);
+/* m random accesses (get_single_id, :108-113): host arrays of list numbers / offsets -> host ids */
+int vidc_packed_get(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, const uint64_t *list_nos,
+                    const uint64_t *offs, int64_t *ids_out);
+/* byte image of one list (parity against the reference layout) */
+int vidc_packed_export(vidc_ctx *ctx, const vidc_packed *p, uint64_t list_no, uint8_t *bytes, size_t cap);
+
+/* -------------------------------------------------------------- Elias-Fano */
+/* Replaces CompressedIDInvertedListsEliasFano (custom_invlists_impl.cpp:229-339),
+ * EliasFanoNSGGraph (altid_impl.cpp:53-101), succinct::elias_fano builder/select/enumerator
+ * (elias_fano.hpp:22-57,141-145,210-261). */
+typedef struct vidc_ef vidc_ef;
+#define VIDC_EF_WANT_PERM 1u
+int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint64_t *d_ids, uint32_t flags,
+                   vidc_ef **out);
+void vidc_ef_destroy(vidc_ef *e);
+/* (sum low bits + sum high bits) / 8, custom_invlists_impl.cpp:272-282 */
+uint64_t vidc_ef_compressed_bytes(const vidc_ef *e);
+int vidc_ef_list_info(const vidc_ef *e, uint32_t *sizes, uint32_t *low_bits, uint64_t *universes);
+int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out); /* ascending per list, :305-308 */
+int vidc_ef_get(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *list_nos, const uint64_t *offs,
+                int64_t *ids_out); /* ef->select(offset), :314-318 */
+int vidc_ef_perm(vidc_ctx *ctx, const vidc_ef *e, uint32_t *perm_host); /* sort permutation, :324-339 */
+/* word images of one list's low / high streams (64-bit words, LSB-first) */
+int vidc_ef_export(vidc_ctx *ctx, const vidc_ef *e, uint64_t list_no, uint64_t *low, size_t low_cap,
+                   uint64_t *high, size_t high_cap, uint64_t *low_nbits, uint64_t *high_nbits);
+
+/* ------------------------------------------------------ introspection / timing */
+/* Milliseconds spent inside the kernels of the most recent encode / decode call on this context,
+ * measured with hipEvents on the context's stream (used by bench.py for the roofline figure). */
+double vidc_ctx_last_kernel_ms(const vidc_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,177 @@
+"""ctypes binding of libvidc.so (include/vidc.h).  Thin: no compute happens in Python.
+
+The library is hand-written HIP for gfx950; there is no CPU fallback.  If libvidc.so is missing it
+is built with hipcc (build.py); if it cannot be loaded, or no HIP device exists, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvidc.so")
+
+VIDC_PREC_REFERENCE = -1
+VIDC_PREC_EXACT = -2
+VIDC_ROC_WANT_PERM = 1
+VIDC_EF_WANT_PERM = 1
+VIDC_ROC_MAX_LIST = 262144
+
+_lib = None
+
+_vp = C.c_void_p
+_u64 = C.c_uint64
+_u32 = C.c_uint32
+_P = C.POINTER
+
+
+class VidcError(RuntimeError):
+    """Raised for every non-zero vidc_status (mirrors FaissException -> RuntimeError, custom_invlists.swig:38-57)."""
+
+
+def _declare(lib):
+    def f(name, restype, *argtypes):
+        fn = getattr(lib, name)  # AttributeError here = libvidc.so is stale / incomplete: rebuild
+        fn.restype = restype
+        fn.argtypes = list(argtypes)
+
+    f("vidc_last_error", C.c_char_p)
+    f("vidc_version", C.c_int)
+    f("vidc_ctx_create", C.c_int, C.c_int, _P(_vp))
+    f("vidc_ctx_destroy", None, _vp)
+    f("vidc_ctx_set_stream", C.c_int, _vp, _vp)
+    f("vidc_ctx_synchronize", C.c_int, _vp)
+    f("vidc_dev_alloc", C.c_int, _vp, C.c_size_t, _P(_vp))
+    f("vidc_dev_free", C.c_int, _vp, _vp)
+    f("vidc_copy_h2d", C.c_int, _vp, _vp, _vp, C.c_size_t)
+    f("vidc_copy_d2h", C.c_int, _vp, _vp, _vp, C.c_size_t)
+    f("vidc_ctx_last_kernel_ms", C.c_double, _vp)
+    # ROC
+    f("vidc_roc_encode", C.c_int, _vp, _u64, _vp, _vp, C.c_int, _u32, _P(_vp))
+    f("vidc_roc_encode_rows", C.c_int, _vp, _u64, _u32, _vp, C.c_int, _u32, _P(_vp))
+    f("vidc_roc_destroy", None, _vp)
+    f("vidc_roc_nlist", _u64, _vp)
+    f("vidc_roc_ntotal", _u64, _vp)
+    f("vidc_roc_compressed_bytes", _u64, _vp)
+    f("vidc_roc_total_words", _u64, _vp)
+    f("vidc_roc_list_info", C.c_int, _vp, _vp, _vp, _vp, _vp, _vp)
+    f("vidc_roc_export_words", C.c_int, _vp, _vp, _u64, _vp, C.c_size_t)
+    f("vidc_roc_perm", C.c_int, _vp, _vp, _vp)
+    f("vidc_roc_perm_dev", _vp, _vp)
+    f("vidc_roc_import", C.c_int, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _P(_vp))
+    f("vidc_roc_decode_all", C.c_int, _vp, _vp, _vp)
+    f("vidc_roc_decode_lists", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
+    f("vidc_roc_decode_rows", C.c_int, _vp, _vp, _u64, _vp, _u32, _vp, _vp)
+    f("vidc_roc_last_decode_nonclean", _u64, _vp)
+    # packed bits
+    f("vidc_packed_bits_for", C.c_int, _u64)
+    f("vidc_packed_encode", C.c_int, _vp, _u64, _vp, _vp, C.c_int, _P(_vp))
+    f("vidc_packed_destroy", None, _vp)
+    f("vidc_packed_compressed_bytes", _u64, _vp)
+    f("vidc_packed_bits", C.c_int, _vp)
+    f("vidc_packed_decode_all", C.c_int, _vp, _vp, _vp)
+    f("vidc_packed_get", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
+    f("vidc_packed_export", C.c_int, _vp, _vp, _u64, _vp, C.c_size_t)
+    # Elias-Fano
+    f("vidc_ef_encode", C.c_int, _vp, _u64, _vp, _vp, _u32, _P(_vp))
+    f("vidc_ef_destroy", None, _vp)
+    f("vidc_ef_compressed_bytes", _u64, _vp)
+    f("vidc_ef_list_info", C.c_int, _vp, _vp, _vp, _vp)
+    f("vidc_ef_decode_all", C.c_int, _vp, _vp, _vp)
+    f("vidc_ef_get", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
+    f("vidc_ef_perm", C.c_int, _vp, _vp, _vp)
+    f("vidc_ef_export", C.c_int, _vp, _vp, _u64, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp)
+
+
+#: every symbol include/vidc.h declares (checked by the CPU test-suite against the built library)
+EXPORTED_SYMBOLS = [
+    "vidc_last_error", "vidc_version", "vidc_ctx_create", "vidc_ctx_destroy", "vidc_ctx_set_stream",
+    "vidc_ctx_synchronize", "vidc_dev_alloc", "vidc_dev_free", "vidc_copy_h2d", "vidc_copy_d2h",
+    "vidc_ctx_last_kernel_ms",
+    "vidc_roc_encode", "vidc_roc_encode_rows", "vidc_roc_destroy", "vidc_roc_nlist", "vidc_roc_ntotal",
+    "vidc_roc_compressed_bytes", "vidc_roc_total_words", "vidc_roc_list_info", "vidc_roc_export_words",
+    "vidc_roc_perm", "vidc_roc_perm_dev", "vidc_roc_import", "vidc_roc_decode_all", "vidc_roc_decode_lists",
+    "vidc_roc_decode_rows", "vidc_roc_last_decode_nonclean",
+    "vidc_packed_bits_for", "vidc_packed_encode", "vidc_packed_destroy", "vidc_packed_compressed_bytes",
+    "vidc_packed_bits", "vidc_packed_decode_all", "vidc_packed_get", "vidc_packed_export",
+    "vidc_ef_encode", "vidc_ef_destroy", "vidc_ef_compressed_bytes", "vidc_ef_list_info", "vidc_ef_decode_all",
+    "vidc_ef_get", "vidc_ef_perm", "vidc_ef_export",
+]
+
+
+def lib():
+    """The loaded C-ABI library (built on first use)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            _build.build()
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise VidcError(f"vidc status {status}: {lib().vidc_last_error().decode(errors='replace')}")
+
+
+def ptr(x):
+    """Raw address of a numpy array / torch tensor / int / None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        assert x.is_contiguous()
+        return x.data_ptr()
+    raise TypeError(type(x))
+
+
+class Context:
+    """vidc_ctx: one per (process, GPU).  Runs on torch's current stream when asked to."""
+
+    def __init__(self, device=-1):
+        h = _vp()
+        check(lib().vidc_ctx_create(device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().vidc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        check(lib().vidc_ctx_set_stream(self.h, hip_stream))
+
+    def synchronize(self):
+        check(lib().vidc_ctx_synchronize(self.h))
+
+    def last_kernel_ms(self):
+        return float(lib().vidc_ctx_last_kernel_ms(self.h))
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    """Context bound to the current torch device (created lazily, cached per device)."""
+    import torch
+
+    if not torch.cuda.is_available():
+        raise VidcError("no HIP device: vector_db_id_compression_amd needs an MI355X (there is no CPU fallback)")
+    if device is None:
+        device = torch.cuda.current_device()
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

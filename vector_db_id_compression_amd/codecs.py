@@ -1,0 +1,165 @@
+"""Device-resident codec objects over the C-ABI (one object = every list of one index / graph).
+
+IDs live in HBM as torch int64 tensors (faiss::idx_t); list boundaries are a host CSR
+`offsets[nlist+1]`.  All heavy work happens in the HIP kernels behind libvidc.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import VIDC_PREC_EXACT, VIDC_PREC_REFERENCE, check, lib, ptr
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _as_offsets(offsets):
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    assert off.ndim == 1 and off.size >= 1
+    return off
+
+
+def _dev_ids(ids, ntotal):
+    """int64/uint64 CUDA tensor (or numpy array, uploaded) of ntotal ids."""
+    torch = _torch()
+    if isinstance(ids, np.ndarray):
+        ids = torch.from_numpy(np.ascontiguousarray(ids).view(np.int64)).cuda()
+    assert ids.is_cuda, "ids must live on the GPU"
+    assert ids.dtype in (torch.int64, torch.uint64)
+    ids = ids.contiguous()
+    assert ids.numel() == ntotal
+    return ids
+
+
+class RocLists:
+    """ROC-compressed lists (vidc_roc): bit-identical streams to codec.cpp."""
+
+    def __init__(self, handle, ctx, offsets):
+        self.h = handle
+        self.ctx = ctx
+        self.offsets = offsets
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().vidc_roc_destroy(self.h)
+            self.h = None
+
+    # -- construction
+    @classmethod
+    def encode(cls, offsets, ids, precision_mode=VIDC_PREC_REFERENCE, want_perm=False, ctx=None):
+        ctx = ctx or _lib.default_context()
+        off = _as_offsets(offsets)
+        nlist = off.size - 1
+        d_ids = _dev_ids(ids, int(off[-1] - off[0])) if off[-1] > off[0] else None
+        assert off[0] == 0
+        h = C.c_void_p()
+        check(lib().vidc_roc_encode(ctx.h, nlist, ptr(off), ptr(d_ids), int(precision_mode),
+                                    _lib.VIDC_ROC_WANT_PERM if want_perm else 0, C.byref(h)))
+        return cls(h, ctx, off)
+
+    @classmethod
+    def encode_rows(cls, rows, precision_mode=VIDC_PREC_REFERENCE, ctx=None):
+        """rows: int32 CUDA tensor [N, K], -1 terminated (nsg::Graph<int32_t> layout)."""
+        torch = _torch()
+        ctx = ctx or _lib.default_context()
+        if isinstance(rows, np.ndarray):
+            rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).cuda()
+        assert rows.is_cuda and rows.dtype == torch.int32 and rows.dim() == 2
+        rows = rows.contiguous()
+        N, K = rows.shape
+        h = C.c_void_p()
+        check(lib().vidc_roc_encode_rows(ctx.h, N, K, ptr(rows) if N else None, int(precision_mode), 0, C.byref(h)))
+        obj = cls(h, ctx, None)
+        sizes = obj.info()["sizes"]
+        obj.offsets = np.concatenate([[0], np.cumsum(sizes, dtype=np.uint64)]).astype(np.uint64)
+        obj.K = K
+        return obj
+
+    @classmethod
+    def from_streams(cls, offsets, precisions, heads, nwords, words_concat, mt_draws=None, ctx=None):
+        ctx = ctx or _lib.default_context()
+        off = _as_offsets(offsets)
+        nlist = off.size - 1
+        prec = np.ascontiguousarray(precisions, dtype=np.uint32)
+        hd = np.ascontiguousarray(heads, dtype=np.uint64)
+        nw = np.ascontiguousarray(nwords, dtype=np.uint32)
+        wc = np.ascontiguousarray(words_concat, dtype=np.uint32)
+        dr = None if mt_draws is None else np.ascontiguousarray(mt_draws, dtype=np.uint32)
+        h = C.c_void_p()
+        check(lib().vidc_roc_import(ctx.h, nlist, ptr(off), ptr(prec), ptr(hd), ptr(nw), ptr(dr),
+                                    ptr(wc) if wc.size else None, C.byref(h)))
+        return cls(h, ctx, off)
+
+    # -- properties
+    @property
+    def nlist(self):
+        return int(lib().vidc_roc_nlist(self.h))
+
+    @property
+    def ntotal(self):
+        return int(lib().vidc_roc_ntotal(self.h))
+
+    @property
+    def compressed_bytes(self):
+        return int(lib().vidc_roc_compressed_bytes(self.h))
+
+    @property
+    def total_words(self):
+        return int(lib().vidc_roc_total_words(self.h))
+
+    def info(self):
+        n = self.nlist
+        sizes = np.zeros(n, np.uint32)
+        prec = np.zeros(n, np.uint32)
+        heads = np.zeros(n, np.uint64)
+        nwords = np.zeros(n, np.uint32)
+        draws = np.zeros(n, np.uint32)
+        check(lib().vidc_roc_list_info(self.h, ptr(sizes), ptr(prec), ptr(heads), ptr(nwords), ptr(draws)))
+        return dict(sizes=sizes, precision=prec, heads=heads, nwords=nwords, mt_draws=draws)
+
+    def words(self, list_no, nwords=None):
+        if nwords is None:
+            nwords = int(self.info()["nwords"][list_no])
+        w = np.zeros(max(nwords, 1), np.uint32)
+        check(lib().vidc_roc_export_words(self.ctx.h, self.h, list_no, ptr(w), nwords))
+        return w[:nwords]
+
+    def perm(self):
+        p = np.zeros(max(self.ntotal, 1), np.uint32)
+        check(lib().vidc_roc_perm(self.ctx.h, self.h, ptr(p)))
+        return p[: self.ntotal]
+
+    # -- decode
+    def decode_all(self, out=None):
+        torch = _torch()
+        if out is None:
+            out = torch.empty(max(self.ntotal, 1), dtype=torch.int64, device="cuda")
+        check(lib().vidc_roc_decode_all(self.ctx.h, self.h, ptr(out)))
+        return out[: self.ntotal]
+
+    def decode_lists(self, list_nos):
+        torch = _torch()
+        ln = np.ascontiguousarray(list_nos, dtype=np.uint64)
+        sizes = (self.offsets[1:] - self.offsets[:-1])[ln.astype(np.int64)] if ln.size else np.zeros(0, np.uint64)
+        total = int(sizes.sum())
+        out = torch.empty(max(total, 1), dtype=torch.int64, device="cuda")
+        out_off = np.zeros(ln.size + 1, np.uint64)
+        check(lib().vidc_roc_decode_lists(self.ctx.h, self.h, ln.size, ptr(ln), ptr(out), ptr(out_off)))
+        return out[:total], out_off
+
+    def decode_rows(self, nodes, K=None):
+        torch = _torch()
+        K = K or self.K
+        nd = np.ascontiguousarray(nodes, dtype=np.uint64)
+        out = torch.empty((max(nd.size, 1), K), dtype=torch.int32, device="cuda")
+        counts = np.zeros(max(nd.size, 1), np.uint32)
+        check(lib().vidc_roc_decode_rows(self.ctx.h, self.h, nd.size, ptr(nd), K, ptr(out), ptr(counts)))
+        return out[: nd.size], counts[: nd.size]
+
+    @property
+    def last_decode_nonclean(self):
+        return int(lib().vidc_roc_last_decode_nonclean(self.h))

@@ -1,0 +1,163 @@
+// ctx.hip -- context, error channel and raw device-memory helpers of libvidc.
+#include <random>
+
+#include "common.h"
+
+namespace vidc {
+static thread_local std::string g_last_error;
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+int Scratch::get(::vidc_ctx *c, size_t nbytes) {
+    release();
+    ctx = c;
+    if (nbytes == 0) nbytes = 16;
+    // first fit among free blocks that are large enough but not wastefully large
+    int best = -1;
+    for (size_t i = 0; i < c->pool.size(); i++) {
+        PoolBlock &b = c->pool[i];
+        if (!b.in_use && b.bytes >= nbytes && b.bytes <= nbytes * 2 + (1u << 20)) {
+            if (best < 0 || b.bytes < c->pool[best].bytes) best = (int)i;
+        }
+    }
+    if (best >= 0) {
+        c->pool[best].in_use = true;
+        p = c->pool[best].p;
+        bytes = c->pool[best].bytes;
+        return VIDC_OK;
+    }
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, nbytes);
+    if (e != hipSuccess) {
+        // drop cached free blocks and retry once
+        for (auto &b : c->pool)
+            if (!b.in_use && b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+        e = hipMalloc(&q, nbytes);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(e));
+            return VIDC_ERR_HIP;
+        }
+    }
+    c->pool.push_back(PoolBlock{q, nbytes, true});
+    p = q;
+    bytes = nbytes;
+    return VIDC_OK;
+}
+void Scratch::release() {
+    if (ctx && p) {
+        for (auto &b : ctx->pool)
+            if (b.p == p) b.in_use = false;
+    }
+    p = nullptr;
+    bytes = 0;
+}
+}  // namespace vidc
+
+extern "C" {
+
+const char *vidc_last_error(void) { return vidc::g_last_error.c_str(); }
+int vidc_version(void) { return VIDC_VERSION; }
+
+int vidc_ctx_create(int device, vidc_ctx **out) {
+    if (!out) return VIDC_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        vidc::set_error("no HIP device available (%s); libvidc has no CPU fallback",
+                        e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return VIDC_ERR_NO_DEVICE;
+    }
+    if (device < 0) {
+        VIDC_HIP(hipGetDevice(&device));
+    } else {
+        if (device >= count) {
+            vidc::set_error("device %d out of range (%d devices)", device, count);
+            return VIDC_ERR_INVALID;
+        }
+        VIDC_HIP(hipSetDevice(device));
+    }
+    vidc_ctx *c = new vidc_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc((void **)&c->d_mt, VIDC_MT_TABLE * sizeof(uint32_t)) != hipSuccess) {
+        vidc::set_error("context resource creation failed");
+        vidc_ctx_destroy(c);
+        return VIDC_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    // the underflow word source of the reference: std::mt19937 seeded with 1234 (codec.h:16-18)
+    std::mt19937 mt(1234);
+    std::vector<uint32_t> tab(VIDC_MT_TABLE);
+    for (auto &w : tab) w = (uint32_t)mt();
+    if (hipMemcpy(c->d_mt, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        vidc::set_error("mt table upload failed");
+        vidc_ctx_destroy(c);
+        return VIDC_ERR_HIP;
+    }
+    *out = c;
+    return VIDC_OK;
+}
+
+void vidc_ctx_destroy(vidc_ctx *c) {
+    if (!c) return;
+    for (auto &b : c->pool)
+        if (b.p) (void)hipFree(b.p);
+    if (c->d_mt) (void)hipFree(c->d_mt);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int vidc_ctx_set_stream(vidc_ctx *c, void *hip_stream) {
+    if (!c) return VIDC_ERR_INVALID;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return VIDC_OK;
+}
+
+int vidc_ctx_synchronize(vidc_ctx *c) {
+    if (!c) return VIDC_ERR_INVALID;
+    VIDC_HIP(hipStreamSynchronize(c->stream));
+    return VIDC_OK;
+}
+
+int vidc_dev_alloc(vidc_ctx *c, size_t bytes, void **p) {
+    if (!c || !p) return VIDC_ERR_INVALID;
+    VIDC_HIP(hipSetDevice(c->device));
+    VIDC_HIP(hipMalloc(p, bytes ? bytes : 1));
+    return VIDC_OK;
+}
+int vidc_dev_free(vidc_ctx *c, void *p) {
+    if (!c) return VIDC_ERR_INVALID;
+    if (p) VIDC_HIP(hipFree(p));
+    return VIDC_OK;
+}
+int vidc_copy_h2d(vidc_ctx *c, void *d, const void *h, size_t bytes) {
+    if (!c) return VIDC_ERR_INVALID;
+    if (bytes) {
+        VIDC_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+        VIDC_HIP(hipStreamSynchronize(c->stream));
+    }
+    return VIDC_OK;
+}
+int vidc_copy_d2h(vidc_ctx *c, void *h, const void *d, size_t bytes) {
+    if (!c) return VIDC_ERR_INVALID;
+    if (bytes) {
+        VIDC_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+        VIDC_HIP(hipStreamSynchronize(c->stream));
+    }
+    return VIDC_OK;
+}
+
+double vidc_ctx_last_kernel_ms(const vidc_ctx *c) { return c ? c->last_kernel_ms : 0.0; }
+
+}  // extern "C"

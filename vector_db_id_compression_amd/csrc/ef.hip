@@ -1,0 +1,448 @@
+// ef.hip -- Elias-Fano coded lists (CompressedIDInvertedListsEliasFano,
+// custom_invlists_impl.cpp:229-339; EliasFanoNSGGraph, altid_impl.cpp:53-101) following the
+// succinct::elias_fano layout described in elias_fano.hpp:22-57:
+//   l = (m && u/m) ? msb(u/m) : 0          u = universe (= max id), m = count              (:28)
+//   low  stream: m*l bits, element i's low l bits at bit i*l (LSB-first 64-bit words)        (:40-42)
+//   high stream: (m+1) + (u>>l) + 1 bits, bit (x>>l)+i set for the i-th smallest element x   (:29,43)
+// Bandwidth-bound kernels: low words have one owner thread each (no atomics); high bits are set
+// with one atomicOr per element (ascending ids -> neighbouring lanes hit the same 64-bit word);
+// bulk decode walks the high words with a wavefront prefix-scan of popcounts.
+#include <algorithm>
+#include <memory>
+#include <numeric>
+
+#include "bits.h"
+#include "common.h"
+#include "wave.h"
+
+using namespace vidc;
+using namespace vidc::dev;
+
+struct vidc_ef {
+    int device = 0;
+    uint64_t nlist = 0, ntotal = 0;
+    uint64_t total_bits = 0;  // sum of low + high stream lengths in bits
+    std::vector<uint64_t> offsets, low_off, high_off, universe, high_nbits;
+    std::vector<uint32_t> lbits;
+    DevBuf<uint64_t> d_offsets, d_low_off, d_high_off, d_low, d_high, d_universe;
+    DevBuf<uint32_t> d_lbits, d_perm;
+    bool has_perm = false;
+};
+
+namespace {
+
+struct PrepOut {
+    uint64_t max_id;
+    uint32_t unsorted;
+    uint32_t pad;
+};
+
+// one wavefront per list: max id and "is non-decreasing"
+__global__ void __launch_bounds__(64) k_ef_prep(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist,
+                                                PrepOut *outp) {
+    const uint32_t lane = lane_id();
+    for (uint32_t l = blockIdx.x; l < nlist; l += gridDim.x) {
+        const uint64_t off = offsets[l];
+        const uint64_t n = offsets[l + 1] - off;
+        uint64_t mx = 0;
+        bool uns = false;
+        for (uint64_t j = lane; j < n; j += 64) {
+            uint64_t v = ids[off + j];
+            if (j) uns |= ids[off + j - 1] > v;
+            mx = v > mx ? v : mx;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)mx, o, 64);
+            uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(mx >> 32), o, 64);
+            uint64_t w = ((uint64_t)hi << 32) | lo;
+            mx = w > mx ? w : mx;
+        }
+        if (lane == 0) {
+            outp[l].max_id = mx;
+            outp[l].unsorted = ballot(uns) ? 1u : 0u;
+        }
+    }
+}
+
+// wave-level bitonic sort of (key, pos) pairs in global memory; np2 = power of two >= n, padded with ~0
+__global__ void __launch_bounds__(64) k_ef_sort(const uint64_t *ids, const uint64_t *offsets, const uint32_t *lists,
+                                                uint32_t nwork, const uint64_t *key_off, uint64_t *keys,
+                                                uint32_t *kpos, uint64_t *sorted_ids, uint32_t *perm) {
+    const uint32_t lane = lane_id();
+    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const uint32_t l = lists[wi];
+        const uint64_t off = offsets[l];
+        const uint32_t n = (uint32_t)(offsets[l + 1] - off);
+        uint64_t *k = keys + key_off[wi];
+        uint32_t *p = kpos + key_off[wi];
+        const uint32_t np2 = (uint32_t)(key_off[wi + 1] - key_off[wi]);
+        for (uint32_t j = lane; j < np2; j += 64) {
+            k[j] = j < n ? ids[off + j] : ~0ull;
+            p[j] = j < n ? j : 0xffffffffu;
+        }
+        __syncthreads();
+        for (uint32_t kk = 2; kk <= np2; kk <<= 1) {
+            for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = lane; t < (np2 >> 1); t += 64) {
+                    uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));
+                    uint32_t q = i | j;
+                    uint64_t x = k[i], y = k[q];
+                    uint32_t px = p[i], py = p[q];
+                    bool up = ((i & kk) == 0);
+                    bool gt = x > y || (x == y && px > py);  // ties by position: std::sort of (id, code ptr) pairs, :336
+                    if (gt == up) {
+                        k[i] = y; k[q] = x;
+                        p[i] = py; p[q] = px;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (uint32_t j = lane; j < n; j += 64) {
+            sorted_ids[off + j] = k[j];
+            perm[off + j] = p[j];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_iota_perm(const uint64_t *offsets, uint32_t nlist, uint64_t ntotal, uint32_t *perm) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ntotal; g += stride) {
+        const uint32_t l = find_list(offsets, nlist, g);
+        perm[g] = (uint32_t)(g - offsets[l]);
+    }
+}
+
+// low stream: one owner thread per 64-bit word
+__global__ void k_ef_low(const uint64_t *sorted_ids, const uint64_t *offsets, const uint64_t *low_off,
+                         const uint32_t *lbits, uint32_t nlist, uint64_t total_words, uint64_t *low) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total_words; w += stride) {
+        const uint32_t l = find_list(low_off, nlist, w);
+        const uint32_t b = lbits[l];
+        const uint64_t n = offsets[l + 1] - offsets[l];
+        const uint64_t keep = b ? ((1ull << b) - 1ull) : 0ull;
+        low[w] = gather_word<false>(sorted_ids + offsets[l], n, w - low_off[l], b, keep, ~0ull, nullptr);
+    }
+}
+
+// high stream: one thread per element sets bit (x >> l) + i
+__global__ void k_ef_high(const uint64_t *sorted_ids, const uint64_t *offsets, const uint64_t *high_off,
+                          const uint32_t *lbits, uint32_t nlist, uint64_t ntotal, uint64_t *high) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ntotal; g += stride) {
+        const uint32_t l = find_list(offsets, nlist, g);
+        const uint64_t i = g - offsets[l];
+        const uint64_t pos = (sorted_ids[g] >> lbits[l]) + i;
+        atomicOr((unsigned long long *)&high[high_off[l] + (pos >> 6)], 1ull << (pos & 63));
+    }
+}
+
+// bulk decode: one wavefront per list, 64 high words per iteration (select_enumerator, elias_fano.hpp:210-261)
+__global__ void __launch_bounds__(64) k_ef_decode(const uint64_t *low, const uint64_t *high, const uint64_t *offsets,
+                                                  const uint64_t *low_off, const uint64_t *high_off,
+                                                  const uint32_t *lbits, uint32_t nlist, uint64_t *out) {
+    const uint32_t lane = lane_id();
+    for (uint32_t l = blockIdx.x; l < nlist; l += gridDim.x) {
+        const uint64_t off = offsets[l];
+        const uint64_t m = offsets[l + 1] - off;
+        if (!m) continue;
+        const uint32_t b = lbits[l];
+        const uint64_t *lw = low + low_off[l];
+        const uint64_t *hw = high + high_off[l];
+        const uint64_t nhw = high_off[l + 1] - high_off[l];
+        uint64_t done = 0;
+        for (uint64_t w0 = 0; w0 < nhw && done < m; w0 += 64) {
+            const uint64_t wi = w0 + lane;
+            uint64_t word = wi < nhw ? hw[wi] : 0ull;
+            uint32_t c = popc64(word);
+            // inclusive prefix sum over the 64 lanes
+            uint32_t incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+                if (lane >= (uint32_t)o) incl += v;
+            }
+            uint64_t rank = done + (incl - c);
+            while (word && rank < m) {
+                const uint32_t bit = (uint32_t)__builtin_ctzll(word);
+                word &= word - 1;
+                const uint64_t pos = wi * 64 + bit;
+                out[off + rank] = ((pos - rank) << b) | read_bits(lw, rank * b, b);
+                rank++;
+            }
+            done += rl(incl, 63);
+        }
+    }
+}
+
+// random access (ef->select(offset), elias_fano.hpp:141-145): one wavefront per query scans the high words
+__global__ void __launch_bounds__(64) k_ef_get(const uint64_t *low, const uint64_t *high, const uint64_t *low_off,
+                                               const uint64_t *high_off, const uint32_t *lbits, uint64_t m,
+                                               const uint64_t *list_nos, const uint64_t *offs, int64_t *out) {
+    const uint32_t lane = lane_id();
+    for (uint64_t q = blockIdx.x; q < m; q += gridDim.x) {
+        const uint64_t l = list_nos[q];
+        const uint64_t i = offs[q];
+        const uint32_t b = lbits[l];
+        const uint64_t *hw = high + high_off[l];
+        const uint64_t nhw = high_off[l + 1] - high_off[l];
+        uint64_t seen = 0;
+        int64_t res = -1;
+        for (uint64_t w0 = 0; w0 < nhw; w0 += 64) {
+            const uint64_t wi = w0 + lane;
+            const uint64_t word = wi < nhw ? hw[wi] : 0ull;
+            const uint32_t c = popc64(word);
+            uint32_t incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+                if (lane >= (uint32_t)o) incl += v;
+            }
+            const uint32_t tot = rl(incl, 63);
+            if (seen + tot > i) {
+                const uint64_t need = i - seen;  // 0-based inside this chunk
+                const uint64_t hit = ballot((uint64_t)incl > need);
+                const uint32_t wl_ = ff1(hit);
+                // lane wl_ owns the word; k-th set bit inside it
+                const uint32_t before = rl(incl, wl_) - rl(c, wl_);
+                uint32_t k = (uint32_t)need - before;
+                uint32_t wlo = rl((uint32_t)word, wl_), whi = rl((uint32_t)(word >> 32), wl_);
+                uint64_t ww = ((uint64_t)whi << 32) | wlo;
+                for (; k; k--) ww &= ww - 1;
+                const uint64_t pos = (w0 + wl_) * 64 + (uint32_t)__builtin_ctzll(ww);
+                res = (int64_t)(((pos - i) << b) | read_bits(low + low_off[l], i * b, b));
+                break;
+            }
+            seen += tot;
+        }
+        if (lane == 0) out[q] = res;
+    }
+}
+
+inline int msb64(uint64_t x) { return 63 - __builtin_clzll(x); }
+
+}  // namespace
+
+extern "C" {
+
+int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint64_t *d_ids, uint32_t flags,
+                   vidc_ef **out) {
+    if (!ctx || !out || (nlist && !offsets)) return VIDC_ERR_INVALID;
+    *out = nullptr;
+    if (nlist >= 0xffffffffull) return VIDC_ERR_INVALID;
+    VIDC_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<vidc_ef> e(new vidc_ef());
+    e->device = ctx->device;
+    e->nlist = nlist;
+    e->offsets.assign(nlist + 1, 0);
+    if (nlist) e->offsets.assign(offsets, offsets + nlist + 1);
+    e->ntotal = e->offsets[nlist];
+    for (uint64_t l = 0; l < nlist; l++)
+        if (e->offsets[l + 1] < e->offsets[l] || e->offsets[l + 1] - e->offsets[l] > 0xfffffff0ull) {
+            set_error("bad offsets at list %llu", (unsigned long long)l);
+            return VIDC_ERR_INVALID;
+        }
+    if (e->ntotal && !d_ids) return VIDC_ERR_INVALID;
+    VIDC_TRY(e->d_offsets.alloc(nlist + 1));
+    VIDC_HIP(hipMemcpyAsync(e->d_offsets.p, e->offsets.data(), (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    double kernel_ms = 0;
+    auto timed = [&](auto &&fn) -> int {
+        VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+        fn();
+        VIDC_HIP(hipGetLastError());
+        VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+        VIDC_HIP(hipEventSynchronize(ctx->ev1));
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+        kernel_ms += ms;
+        return VIDC_OK;
+    };
+
+    // pass 1: universe (max id) and sortedness per list
+    std::vector<PrepOut> prep(nlist);
+    Scratch s_prep;
+    VIDC_TRY(s_prep.get(ctx, nlist * sizeof(PrepOut)));
+    if (nlist) {
+        VIDC_TRY(timed([&] {
+            hipLaunchKernelGGL(k_ef_prep, dim3((uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 64)), dim3(64),
+                               0, ctx->stream, d_ids, e->d_offsets.p, (uint32_t)nlist, s_prep.as<PrepOut>());
+        }));
+        VIDC_HIP(hipMemcpyAsync(prep.data(), s_prep.p, nlist * sizeof(PrepOut), hipMemcpyDeviceToHost, ctx->stream));
+        VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    // geometry (elias_fano.hpp:28-29)
+    e->lbits.assign(nlist, 0); e->universe.assign(nlist, 0); e->high_nbits.assign(nlist, 0);
+    e->low_off.assign(nlist + 1, 0); e->high_off.assign(nlist + 1, 0);
+    std::vector<uint32_t> unsorted;
+    for (uint64_t l = 0; l < nlist; l++) {
+        uint64_t m = e->offsets[l + 1] - e->offsets[l];
+        uint64_t low_words = 0, high_words = 0;
+        if (m) {  // empty lists have no bitstream object (ef_bitstreams[list_no] stays null, :239-241)
+            uint64_t u = prep[l].max_id;
+            uint32_t lb = (u / m) ? (uint32_t)msb64(u / m) : 0u;
+            uint64_t hb = (m + 1) + (u >> lb) + 1;
+            e->universe[l] = u; e->lbits[l] = lb; e->high_nbits[l] = hb;
+            e->total_bits += m * lb + hb;
+            low_words = (m * lb + 63) / 64 + 1;  // +1 padding word for read_bits
+            high_words = (hb + 63) / 64;
+            if (prep[l].unsorted) unsorted.push_back((uint32_t)l);
+        }
+        e->low_off[l + 1] = e->low_off[l] + low_words;
+        e->high_off[l + 1] = e->high_off[l] + high_words;
+    }
+    VIDC_TRY(e->d_low_off.alloc(nlist + 1)); VIDC_TRY(e->d_high_off.alloc(nlist + 1));
+    VIDC_TRY(e->d_lbits.alloc(nlist ? nlist : 1)); VIDC_TRY(e->d_universe.alloc(nlist ? nlist : 1));
+    VIDC_TRY(e->d_low.alloc(e->low_off[nlist] ? e->low_off[nlist] : 1));
+    VIDC_TRY(e->d_high.alloc(e->high_off[nlist] ? e->high_off[nlist] : 1));
+    VIDC_HIP(hipMemcpyAsync(e->d_low_off.p, e->low_off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(e->d_high_off.p, e->high_off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (nlist) {
+        VIDC_HIP(hipMemcpyAsync(e->d_lbits.p, e->lbits.data(), nlist * 4, hipMemcpyHostToDevice, ctx->stream));
+        VIDC_HIP(hipMemcpyAsync(e->d_universe.p, e->universe.data(), nlist * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    VIDC_HIP(hipMemsetAsync(e->d_high.p, 0, (e->high_off[nlist] ? e->high_off[nlist] : 1) * 8, ctx->stream));
+
+    // pass 2 (only when some list is not ascending): sorted copy + permutation
+    const uint64_t *d_sorted = d_ids;
+    Scratch s_sorted, s_keys, s_kpos, s_key_off, s_lists;
+    const bool want_perm = (flags & VIDC_EF_WANT_PERM) != 0;
+    if (want_perm || !unsorted.empty()) {
+        VIDC_TRY(e->d_perm.alloc(e->ntotal ? e->ntotal : 1));
+        e->has_perm = true;
+        if (e->ntotal) {
+            uint32_t grid = (uint32_t)std::min<uint64_t>((e->ntotal + 255) / 256, (uint64_t)ctx->num_cu * 32);
+            VIDC_TRY(timed([&] {
+                hipLaunchKernelGGL(k_iota_perm, dim3(grid), dim3(256), 0, ctx->stream, e->d_offsets.p, (uint32_t)nlist,
+                                   e->ntotal, e->d_perm.p);
+            }));
+        }
+    }
+    if (!unsorted.empty()) {
+        std::stable_sort(unsorted.begin(), unsorted.end(), [&](uint32_t a, uint32_t b) {
+            return e->offsets[a + 1] - e->offsets[a] > e->offsets[b + 1] - e->offsets[b];
+        });
+        std::vector<uint64_t> key_off(unsorted.size() + 1, 0);
+        for (size_t i = 0; i < unsorted.size(); i++) {
+            uint64_t n = e->offsets[unsorted[i] + 1] - e->offsets[unsorted[i]], p2 = 1;
+            while (p2 < n) p2 <<= 1;
+            key_off[i + 1] = key_off[i] + p2;
+        }
+        VIDC_TRY(s_sorted.get(ctx, e->ntotal * 8));
+        VIDC_HIP(hipMemcpyAsync(s_sorted.p, d_ids, e->ntotal * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        VIDC_TRY(s_keys.get(ctx, key_off.back() * 8));
+        VIDC_TRY(s_kpos.get(ctx, key_off.back() * 4));
+        VIDC_TRY(s_key_off.get(ctx, key_off.size() * 8));
+        VIDC_TRY(s_lists.get(ctx, unsorted.size() * 4));
+        VIDC_HIP(hipMemcpyAsync(s_key_off.p, key_off.data(), key_off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        VIDC_HIP(hipMemcpyAsync(s_lists.p, unsorted.data(), unsorted.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        VIDC_TRY(timed([&] {
+            hipLaunchKernelGGL(k_ef_sort, dim3((uint32_t)unsorted.size()), dim3(64), 0, ctx->stream, d_ids, e->d_offsets.p,
+                               s_lists.as<uint32_t>(), (uint32_t)unsorted.size(), s_key_off.as<uint64_t>(),
+                               s_keys.as<uint64_t>(), s_kpos.as<uint32_t>(), s_sorted.as<uint64_t>(), e->d_perm.p);
+        }));
+        d_sorted = s_sorted.as<uint64_t>();
+    }
+    // pass 3: the two bit streams
+    if (e->ntotal) {
+        uint64_t lw = e->low_off[nlist];
+        uint32_t g1 = (uint32_t)std::min<uint64_t>((lw + 255) / 256, (uint64_t)ctx->num_cu * 32);
+        uint32_t g2 = (uint32_t)std::min<uint64_t>((e->ntotal + 255) / 256, (uint64_t)ctx->num_cu * 32);
+        VIDC_TRY(timed([&] {
+            hipLaunchKernelGGL(k_ef_low, dim3(g1 ? g1 : 1), dim3(256), 0, ctx->stream, d_sorted, e->d_offsets.p,
+                               e->d_low_off.p, e->d_lbits.p, (uint32_t)nlist, lw, e->d_low.p);
+            hipLaunchKernelGGL(k_ef_high, dim3(g2), dim3(256), 0, ctx->stream, d_sorted, e->d_offsets.p, e->d_high_off.p,
+                               e->d_lbits.p, (uint32_t)nlist, e->ntotal, e->d_high.p);
+        }));
+    }
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->last_kernel_ms = kernel_ms;
+    *out = e.release();
+    return VIDC_OK;
+}
+
+void vidc_ef_destroy(vidc_ef *e) { delete e; }
+
+// compressed_ids_size_in_bytes = (sum of low.size() + high.size() in bits) / 8, custom_invlists_impl.cpp:272-282
+uint64_t vidc_ef_compressed_bytes(const vidc_ef *e) { return e ? e->total_bits / 8 : 0; }
+
+int vidc_ef_list_info(const vidc_ef *e, uint32_t *sizes, uint32_t *low_bits, uint64_t *universes) {
+    if (!e) return VIDC_ERR_INVALID;
+    for (uint64_t l = 0; l < e->nlist; l++) {
+        if (sizes) sizes[l] = (uint32_t)(e->offsets[l + 1] - e->offsets[l]);
+        if (low_bits) low_bits[l] = e->lbits[l];
+        if (universes) universes[l] = e->universe[l];
+    }
+    return VIDC_OK;
+}
+
+int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
+    if (!ctx || !e || (e->ntotal && !d_out)) return VIDC_ERR_INVALID;
+    if (!e->ntotal) return VIDC_OK;
+    VIDC_HIP(hipSetDevice(ctx->device));
+    VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_ef_decode, dim3((uint32_t)std::min<uint64_t>(e->nlist, (uint64_t)ctx->num_cu * 64)), dim3(64), 0,
+                       ctx->stream, e->d_low.p, e->d_high.p, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p,
+                       e->d_lbits.p, (uint32_t)e->nlist, d_out);
+    VIDC_HIP(hipGetLastError());
+    VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->last_kernel_ms = ms;
+    return VIDC_OK;
+}
+
+int vidc_ef_get(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *list_nos, const uint64_t *offs,
+                int64_t *ids_out) {
+    if (!ctx || !e || (m && (!list_nos || !offs || !ids_out))) return VIDC_ERR_INVALID;
+    if (!m) return VIDC_OK;
+    for (uint64_t i = 0; i < m; i++) {
+        if (list_nos[i] >= e->nlist || offs[i] >= e->offsets[list_nos[i] + 1] - e->offsets[list_nos[i]]) {
+            set_error("ef get: (list %llu, offset %llu) out of range", (unsigned long long)list_nos[i],
+                      (unsigned long long)offs[i]);
+            return VIDC_ERR_INVALID;
+        }
+    }
+    VIDC_HIP(hipSetDevice(ctx->device));
+    Scratch s_l, s_o, s_r;
+    VIDC_TRY(s_l.get(ctx, m * 8)); VIDC_TRY(s_o.get(ctx, m * 8)); VIDC_TRY(s_r.get(ctx, m * 8));
+    VIDC_HIP(hipMemcpyAsync(s_l.p, list_nos, m * 8, hipMemcpyHostToDevice, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(s_o.p, offs, m * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_ef_get, dim3((uint32_t)std::min<uint64_t>(m, 1u << 20)), dim3(64), 0, ctx->stream, e->d_low.p,
+                       e->d_high.p, e->d_low_off.p, e->d_high_off.p, e->d_lbits.p, m, s_l.as<uint64_t>(),
+                       s_o.as<uint64_t>(), s_r.as<int64_t>());
+    VIDC_HIP(hipGetLastError());
+    VIDC_HIP(hipMemcpyAsync(ids_out, s_r.p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    return VIDC_OK;
+}
+
+int vidc_ef_perm(vidc_ctx *ctx, const vidc_ef *e, uint32_t *perm_host) {
+    if (!ctx || !e || !perm_host) return VIDC_ERR_INVALID;
+    if (!e->has_perm) { set_error("encode was called without VIDC_EF_WANT_PERM"); return VIDC_ERR_INVALID; }
+    return vidc_copy_d2h(ctx, perm_host, e->d_perm.p, e->ntotal * 4);
+}
+
+int vidc_ef_export(vidc_ctx *ctx, const vidc_ef *e, uint64_t list_no, uint64_t *low, size_t low_cap, uint64_t *high,
+                   size_t high_cap, uint64_t *low_nbits, uint64_t *high_nbits) {
+    if (!ctx || !e || list_no >= e->nlist) return VIDC_ERR_INVALID;
+    uint64_t m = e->offsets[list_no + 1] - e->offsets[list_no];
+    uint64_t lb = m * e->lbits[list_no], hb = e->high_nbits[list_no];
+    if (low_nbits) *low_nbits = lb;
+    if (high_nbits) *high_nbits = hb;
+    uint64_t lw = (lb + 63) / 64, hw = (hb + 63) / 64;
+    if (low) {
+        if (lw > low_cap) { set_error("low buffer too small"); return VIDC_ERR_INVALID; }
+        VIDC_TRY(vidc_copy_d2h(ctx, low, e->d_low.p + e->low_off[list_no], lw * 8));
+    }
+    if (high) {
+        if (hw > high_cap) { set_error("high buffer too small"); return VIDC_ERR_INVALID; }
+        VIDC_TRY(vidc_copy_d2h(ctx, high, e->d_high.p + e->high_off[list_no], hw * 8));
+    }
+    return VIDC_OK;
+}
+
+}  // extern "C"

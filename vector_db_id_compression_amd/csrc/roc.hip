@@ -1,0 +1,566 @@
+// roc.hip -- host side of the ROC codec: scheduling of lists onto wavefronts, arenas, compaction,
+// and the vidc_roc_* C-ABI (include/vidc.h).
+#include <algorithm>
+#include <memory>
+#include <numeric>
+
+#include "common.h"
+#include "roc_kernels.h"
+
+using namespace vidc;
+using namespace vidc::dev;
+
+struct vidc_roc {
+    int device = 0;
+    uint64_t nlist = 0, ntotal = 0;
+    bool rows = false;
+    uint32_t K = 0;
+    // host copies of the per-list metadata
+    std::vector<uint64_t> offsets;   // nlist+1
+    std::vector<uint32_t> prec, nwords, draws;
+    std::vector<uint64_t> heads;
+    std::vector<uint64_t> word_off;  // nlist+1
+    uint64_t total_words = 0, compressed_bytes = 0;
+    // device-resident compressed representation
+    DevBuf<uint64_t> d_offsets, d_heads, d_word_off;
+    DevBuf<uint32_t> d_prec, d_nwords, d_draws, d_words, d_perm;
+    mutable uint64_t last_nonclean = 0;
+};
+
+namespace {
+
+constexpr uint32_t TINY_MAX = 64;
+constexpr uint32_t GEN_SMALL_MAX = 1024;   // decoder: fb <= 7 -> 512 B of LDS
+
+inline uint64_t arena_words_for(uint64_t n) { return n * 35 / 32 + 8; }  // <= P+4 bits per step, P <= 31
+
+template <typename T>
+int upload(vidc_ctx *ctx, DevBuf<T> &dst, const std::vector<T> &src) {
+    VIDC_TRY(dst.alloc(src.size()));
+    if (!src.empty())
+        VIDC_HIP(hipMemcpyAsync(dst.p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return VIDC_OK;
+}
+template <typename T>
+int upload_scratch(vidc_ctx *ctx, Scratch &dst, const std::vector<T> &src) {
+    VIDC_TRY(dst.get(ctx, src.size() * sizeof(T)));
+    if (!src.empty())
+        VIDC_HIP(hipMemcpyAsync(dst.p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return VIDC_OK;
+}
+
+struct EventTimer {
+    vidc_ctx *c;
+    explicit EventTimer(vidc_ctx *ctx) : c(ctx) { (void)hipEventRecord(c->ev0, c->stream); }
+    double stop() {
+        (void)hipEventRecord(c->ev1, c->stream);
+        (void)hipEventSynchronize(c->ev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        return ms;
+    }
+};
+
+int check_status(const std::vector<uint32_t> &status, const char *what) {
+    for (size_t l = 0; l < status.size(); l++) {
+        switch (status[l]) {
+            case VIDC_ST_OK: break;
+            case VIDC_ST_DOMAIN:
+                set_error("%s: list %zu holds an id outside [0, 2^31) (reference: int max_id, "
+                          "custom_invlists_impl.cpp:163)", what, l);
+                return VIDC_ERR_DOMAIN;
+            case VIDC_ST_OVERFLOW:
+                set_error("%s: list %zu overflowed its ANS word arena", what, l);
+                return VIDC_ERR_OVERFLOW;
+            case VIDC_ST_MT:
+                set_error("%s: list %zu needed more than %d mt19937 underflow words", what, l, VIDC_MT_TABLE);
+                return VIDC_ERR_OVERFLOW;
+            default:
+                set_error("%s: list %zu finished with status %u", what, l, status[l]);
+                return VIDC_ERR_INVALID;
+        }
+    }
+    return VIDC_OK;
+}
+
+// lists sorted longest first: the hardware dispatches workgroups in order, so this is LPT scheduling
+void sort_desc(std::vector<uint32_t> &wl, const std::vector<uint64_t> &offsets) {
+    std::stable_sort(wl.begin(), wl.end(), [&](uint32_t a, uint32_t b) {
+        return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b];
+    });
+}
+
+int finish_encode(vidc_ctx *ctx, vidc_roc *r, const uint32_t *d_arena, const uint64_t *d_arena_off,
+                  Scratch &d_status_buf, double &kernel_ms) {
+    const uint64_t nlist = r->nlist;
+    std::vector<uint32_t> status(nlist);
+    r->prec.resize(nlist); r->nwords.resize(nlist); r->draws.resize(nlist); r->heads.resize(nlist);
+    if (nlist) {
+        VIDC_HIP(hipMemcpyAsync(status.data(), d_status_buf.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+        VIDC_HIP(hipMemcpyAsync(r->prec.data(), r->d_prec.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+        VIDC_HIP(hipMemcpyAsync(r->nwords.data(), r->d_nwords.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+        VIDC_HIP(hipMemcpyAsync(r->draws.data(), r->d_draws.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+        VIDC_HIP(hipMemcpyAsync(r->heads.data(), r->d_heads.p, nlist * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_TRY(check_status(status, "roc encode"));
+    r->word_off.assign(nlist + 1, 0);
+    r->compressed_bytes = 0;
+    for (uint64_t l = 0; l < nlist; l++) {
+        r->word_off[l + 1] = r->word_off[l] + r->nwords[l];
+        // "let's pretend no memory is used" for empty lists, custom_invlists_impl.cpp:199-201
+        if (r->offsets[l + 1] > r->offsets[l]) r->compressed_bytes += 8 + 4ull * r->nwords[l];
+    }
+    r->total_words = r->word_off[nlist];
+    VIDC_TRY(upload(ctx, r->d_word_off, r->word_off));
+    VIDC_TRY(r->d_words.alloc(r->total_words ? r->total_words : 1));
+    if (nlist) {
+        EventTimer t(ctx);
+        uint32_t grid = (uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 16);
+        hipLaunchKernelGGL(k_roc_compact, dim3(grid), dim3(256), 0, ctx->stream, d_arena, d_arena_off,
+                           r->d_word_off.p, r->d_words.p, (uint32_t)nlist);
+        VIDC_HIP(hipGetLastError());
+        kernel_ms += t.stop();
+    }
+    return VIDC_OK;
+}
+
+int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint64_t *d_ids, bool rows, uint64_t N,
+                uint32_t K, const int32_t *d_rows, int precision_mode, uint32_t flags, vidc_roc **out) {
+    if (!ctx || !out) return VIDC_ERR_INVALID;
+    *out = nullptr;
+    if (precision_mode < VIDC_PREC_EXACT || precision_mode > 32) {
+        set_error("precision_mode %d unsupported (fixed precision must be 0..32)", precision_mode);
+        return VIDC_ERR_INVALID;
+    }
+    if (nlist >= 0xffffffffull) { set_error("too many lists"); return VIDC_ERR_INVALID; }
+    VIDC_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<vidc_roc> r(new vidc_roc());
+    r->device = ctx->device;
+    r->rows = rows;
+    r->K = K;
+    r->nlist = rows ? N : nlist;
+    nlist = r->nlist;
+    double kernel_ms = 0;
+
+    std::vector<uint64_t> arena_off(nlist + 1, 0);
+    std::vector<uint32_t> wl_tiny, wl_c1, wl_c2, wl_c3;
+    if (rows) {
+        if (K == 0 || K > TINY_MAX) {
+            set_error("graph rows: K=%u unsupported (1..64)", K);
+            return VIDC_ERR_UNSUPPORTED;
+        }
+        for (uint64_t l = 0; l < nlist; l++) arena_off[l + 1] = arena_off[l] + arena_words_for(K);
+        wl_tiny.resize(nlist);
+        std::iota(wl_tiny.begin(), wl_tiny.end(), 0u);
+    } else {
+        if (!offsets) return VIDC_ERR_INVALID;
+        r->offsets.assign(offsets, offsets + nlist + 1);
+        for (uint64_t l = 0; l < nlist; l++) {
+            if (offsets[l + 1] < offsets[l]) { set_error("offsets not monotone at list %llu", (unsigned long long)l); return VIDC_ERR_INVALID; }
+            uint64_t n = offsets[l + 1] - offsets[l];
+            if (n > VIDC_ROC_MAX_LIST) {
+                set_error("list %llu has %llu ids; ROC lists are limited to %u (the reference codec is only "
+                          "lossless up to 65536, SURVEY 8a-Q2)", (unsigned long long)l, (unsigned long long)n,
+                          VIDC_ROC_MAX_LIST);
+                return VIDC_ERR_DOMAIN;
+            }
+            arena_off[l + 1] = arena_off[l] + arena_words_for(n);
+            if (n <= TINY_MAX) wl_tiny.push_back((uint32_t)l);
+            else if (n <= 4096) wl_c1.push_back((uint32_t)l);
+            else if (n <= 32768) wl_c2.push_back((uint32_t)l);
+            else wl_c3.push_back((uint32_t)l);
+        }
+        r->ntotal = offsets[nlist];
+        sort_desc(wl_c1, r->offsets); sort_desc(wl_c2, r->offsets); sort_desc(wl_c3, r->offsets);
+    }
+    const uint64_t ntotal_in = rows ? N * K : r->ntotal;
+
+    // persistent outputs
+    VIDC_TRY(r->d_heads.alloc(nlist)); VIDC_TRY(r->d_prec.alloc(nlist));
+    VIDC_TRY(r->d_nwords.alloc(nlist)); VIDC_TRY(r->d_draws.alloc(nlist));
+    const bool want_perm = (flags & VIDC_ROC_WANT_PERM) && !rows;
+    if (want_perm) VIDC_TRY(r->d_perm.alloc(ntotal_in ? ntotal_in : 1));
+    // scratch
+    Scratch s_arena, s_arena_off, s_off, s_status, s_sizes, s_sid, s_wl;
+    VIDC_TRY(s_arena.get(ctx, arena_off[nlist] * 4));
+    VIDC_TRY(upload_scratch(ctx, s_arena_off, arena_off));
+    VIDC_TRY(s_status.get(ctx, nlist * 4));
+    if (nlist) VIDC_HIP(hipMemsetAsync(s_status.p, 0xff, nlist * 4, ctx->stream));
+    if (rows) VIDC_TRY(s_sizes.get(ctx, nlist * 4));
+    else {
+        VIDC_TRY(upload(ctx, r->d_offsets, r->offsets));
+        if (!wl_c1.empty() || !wl_c2.empty() || !wl_c3.empty()) VIDC_TRY(s_sid.get(ctx, ntotal_in * 4));
+    }
+    std::vector<uint32_t> wl_all;
+    wl_all.insert(wl_all.end(), wl_tiny.begin(), wl_tiny.end());
+    wl_all.insert(wl_all.end(), wl_c1.begin(), wl_c1.end());
+    wl_all.insert(wl_all.end(), wl_c2.begin(), wl_c2.end());
+    wl_all.insert(wl_all.end(), wl_c3.begin(), wl_c3.end());
+    VIDC_TRY(upload_scratch(ctx, s_wl, wl_all));
+
+    RocEncArgs a{};
+    a.ids = d_ids; a.rows = d_rows; a.K = K;
+    a.offsets = rows ? nullptr : r->d_offsets.p;
+    a.precision_mode = precision_mode;
+    a.heads = r->d_heads.p; a.prec = r->d_prec.p; a.nwords = r->d_nwords.p; a.draws = r->d_draws.p;
+    a.sizes = s_sizes.as<uint32_t>();
+    a.status = s_status.as<uint32_t>();
+    a.arena = s_arena.as<uint32_t>(); a.arena_off = s_arena_off.as<uint64_t>();
+    a.perm = want_perm ? r->d_perm.p : nullptr;
+    a.sid = s_sid.as<uint32_t>(); a.spos = nullptr; a.skey = nullptr; a.skey_off = nullptr;
+    a.mt = ctx->d_mt;
+
+    auto launch_gen = [&](const uint32_t *d_wl, uint32_t nwork, uint32_t rl_max) -> int {
+        if (!nwork) return VIDC_OK;
+        RocEncArgs b = a;
+        b.worklist = d_wl; b.nwork = nwork;
+        size_t lds = (size_t)64 * rl_max * 12;
+        hipLaunchKernelGGL(k_roc_encode_gen, dim3(nwork), dim3(64), lds, ctx->stream, b, rl_max);
+        VIDC_HIP(hipGetLastError());
+        return VIDC_OK;
+    };
+    {
+        EventTimer t(ctx);
+        const uint32_t *d_wl = s_wl.as<uint32_t>();
+        if (!wl_tiny.empty()) {
+            RocEncArgs b = a;
+            b.worklist = d_wl; b.nwork = (uint32_t)wl_tiny.size();
+            if (rows) hipLaunchKernelGGL(k_roc_encode_tiny<true>, dim3(b.nwork), dim3(64), 0, ctx->stream, b);
+            else hipLaunchKernelGGL(k_roc_encode_tiny<false>, dim3(b.nwork), dim3(64), 0, ctx->stream, b);
+            VIDC_HIP(hipGetLastError());
+        }
+        // longest lists first: they are the critical path
+        size_t base3 = wl_tiny.size() + wl_c1.size() + wl_c2.size();
+        VIDC_TRY(launch_gen(d_wl + base3, (uint32_t)wl_c3.size(), 64));
+        VIDC_TRY(launch_gen(d_wl + wl_tiny.size() + wl_c1.size(), (uint32_t)wl_c2.size(), 8));
+        VIDC_TRY(launch_gen(d_wl + wl_tiny.size(), (uint32_t)wl_c1.size(), 1));
+        kernel_ms += t.stop();
+    }
+
+    // unsorted lists: second pass with sort scratch (Faiss lists are in add order, i.e. normally sorted)
+    if (!rows && nlist) {
+        std::vector<uint32_t> status(nlist);
+        VIDC_HIP(hipMemcpyAsync(status.data(), s_status.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+        VIDC_HIP(hipStreamSynchronize(ctx->stream));
+        std::vector<uint32_t> pend;
+        for (uint64_t l = 0; l < nlist; l++)
+            if (status[l] == VIDC_ST_PENDING_SORT) pend.push_back((uint32_t)l);
+        if (!pend.empty()) {
+            sort_desc(pend, r->offsets);
+            std::vector<uint64_t> skey_off(nlist + 1, 0);
+            uint32_t maxn = 0;
+            {
+                std::vector<uint8_t> is_p(nlist, 0);
+                for (uint32_t l : pend) is_p[l] = 1;
+                for (uint64_t l = 0; l < nlist; l++) {
+                    uint64_t n = r->offsets[l + 1] - r->offsets[l], p2 = 0;
+                    if (is_p[l]) { p2 = 1; while (p2 < n) p2 <<= 1; maxn = std::max<uint32_t>(maxn, (uint32_t)n); }
+                    skey_off[l + 1] = skey_off[l] + p2;
+                }
+            }
+            Scratch s_skey, s_skey_off, s_spos, s_pend;
+            VIDC_TRY(s_skey.get(ctx, skey_off[nlist] * 8));
+            VIDC_TRY(upload_scratch(ctx, s_skey_off, skey_off));
+            VIDC_TRY(s_spos.get(ctx, ntotal_in * 4));
+            VIDC_TRY(upload_scratch(ctx, s_pend, pend));
+            a.skey = s_skey.as<uint64_t>(); a.skey_off = s_skey_off.as<uint64_t>(); a.spos = s_spos.as<uint32_t>();
+            uint32_t rl_max = maxn <= 4096 ? 1 : (maxn <= 32768 ? 8 : 64);
+            EventTimer t(ctx);
+            VIDC_TRY(launch_gen(s_pend.as<uint32_t>(), (uint32_t)pend.size(), rl_max));
+            kernel_ms += t.stop();
+            VIDC_HIP(hipStreamSynchronize(ctx->stream));  // scratch of this scope is released below
+        }
+    }
+    if (rows) {
+        // edge counts define the CSR numbering of the decoded output (altid_impl.h:61 num_outgoing_edges)
+        std::vector<uint32_t> sizes(nlist);
+        if (nlist) VIDC_HIP(hipMemcpyAsync(sizes.data(), s_sizes.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+        VIDC_HIP(hipStreamSynchronize(ctx->stream));
+        r->offsets.assign(nlist + 1, 0);
+        for (uint64_t l = 0; l < nlist; l++) r->offsets[l + 1] = r->offsets[l] + sizes[l];
+        r->ntotal = r->offsets[nlist];
+        VIDC_TRY(upload(ctx, r->d_offsets, r->offsets));
+    }
+    VIDC_TRY(finish_encode(ctx, r.get(), s_arena.as<uint32_t>(), s_arena_off.as<uint64_t>(), s_status, kernel_ms));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->last_kernel_ms = kernel_ms;
+    *out = r.release();
+    return VIDC_OK;
+}
+
+// ---- decode planning: per work item scratch offsets
+struct DecPlan {
+    std::vector<uint32_t> wl;           // tiny | small | big
+    size_t n_tiny = 0, n_small = 0, n_big = 0;
+    std::vector<uint64_t> scratch_off, slots_off;
+    uint64_t scratch_words = 0, slots_words = 0;
+};
+
+void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, DecPlan &p) {
+    std::vector<uint32_t> tiny, small, big;
+    for (uint32_t l : lists) {
+        uint64_t n = r->offsets[l + 1] - r->offsets[l];
+        if (n <= TINY_MAX) tiny.push_back(l);
+        else if (n <= GEN_SMALL_MAX) small.push_back(l);
+        else big.push_back(l);
+    }
+    sort_desc(small, r->offsets);
+    sort_desc(big, r->offsets);
+    p.n_tiny = tiny.size(); p.n_small = small.size(); p.n_big = big.size();
+    p.wl.clear();
+    p.wl.insert(p.wl.end(), tiny.begin(), tiny.end());
+    p.wl.insert(p.wl.end(), small.begin(), small.end());
+    p.wl.insert(p.wl.end(), big.begin(), big.end());
+    p.scratch_off.resize(p.wl.size());
+    p.slots_off.resize(p.wl.size());
+    uint64_t so = 0, sl = 0;
+    for (size_t i = 0; i < p.wl.size(); i++) {
+        uint32_t l = p.wl[i];
+        uint64_t n = r->offsets[l + 1] - r->offsets[l];
+        p.scratch_off[i] = so;
+        so += (uint64_t)r->nwords[l] + 64;
+        p.slots_off[i] = sl;
+        if (n > TINY_MAX) {
+            uint32_t fb = roc_dec_fine_bits((uint32_t)n, r->prec[l] > 32 ? 32 : r->prec[l]);
+            sl += ((uint64_t)1 << fb) * VIDC_DEC_CAP + n;
+        }
+    }
+    p.scratch_words = so;
+    p.slots_words = sl;
+}
+
+int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64_t *out_off_host, uint64_t *d_out,
+                int32_t *d_out_rows, uint32_t K) {
+    VIDC_HIP(hipSetDevice(ctx->device));
+    const size_t nwork = p.wl.size();
+    if (nwork == 0) { ctx->last_kernel_ms = 0; return VIDC_OK; }
+    Scratch s_wl, s_scr_off, s_slots_off, s_scr, s_slots, s_out_off, s_end, s_status;
+    VIDC_TRY(upload_scratch(ctx, s_wl, p.wl));
+    VIDC_TRY(upload_scratch(ctx, s_scr_off, p.scratch_off));
+    VIDC_TRY(upload_scratch(ctx, s_slots_off, p.slots_off));
+    VIDC_TRY(s_scr.get(ctx, p.scratch_words * 4));
+    VIDC_TRY(s_slots.get(ctx, p.slots_words * 4));
+    VIDC_TRY(s_end.get(ctx, r->nlist * 4));
+    VIDC_TRY(s_status.get(ctx, r->nlist * 4));
+    VIDC_HIP(hipMemsetAsync(s_end.p, 0, r->nlist * 4, ctx->stream));
+    VIDC_HIP(hipMemsetAsync(s_status.p, 0, r->nlist * 4, ctx->stream));
+    if (out_off_host) {
+        VIDC_TRY(s_out_off.get(ctx, nwork * 8));
+        VIDC_HIP(hipMemcpyAsync(s_out_off.p, out_off_host, nwork * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    RocDecArgs a{};
+    a.offsets = r->d_offsets.p;
+    a.heads = r->d_heads.p; a.prec = r->d_prec.p; a.nwords = r->d_nwords.p; a.draws = r->d_draws.p;
+    a.words = r->d_words.p; a.word_off = r->d_word_off.p;
+    a.out = d_out; a.out_rows = d_out_rows; a.K = K;
+    a.scratch_words = s_scr.as<uint32_t>();
+    a.slots = s_slots.as<uint32_t>();
+    a.end_state = s_end.as<uint32_t>(); a.status = s_status.as<uint32_t>();
+    a.mt = ctx->d_mt;
+
+    EventTimer t(ctx);
+    auto launch = [&](size_t base, size_t count, int kind) -> int {
+        if (!count) return VIDC_OK;
+        RocDecArgs b = a;
+        b.worklist = s_wl.as<uint32_t>() + base;
+        b.nwork = (uint32_t)count;
+        b.out_off = out_off_host ? s_out_off.as<uint64_t>() + base : nullptr;
+        b.scratch_off = s_scr_off.as<uint64_t>() + base;
+        b.slots_off = s_slots_off.as<uint64_t>() + base;
+        if (kind == 0) {
+            if (d_out_rows) hipLaunchKernelGGL(k_roc_decode_tiny<true>, dim3(b.nwork), dim3(64), 0, ctx->stream, b);
+            else hipLaunchKernelGGL(k_roc_decode_tiny<false>, dim3(b.nwork), dim3(64), 0, ctx->stream, b);
+        } else {
+            uint32_t entries = kind == 1 ? 128u : (1u << VIDC_DEC_MAX_FB);
+            hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), entries * 4, ctx->stream, b, entries);
+        }
+        VIDC_HIP(hipGetLastError());
+        return VIDC_OK;
+    };
+    VIDC_TRY(launch(p.n_tiny + p.n_small, p.n_big, 2));  // longest first
+    VIDC_TRY(launch(p.n_tiny, p.n_small, 1));
+    VIDC_TRY(launch(0, p.n_tiny, 0));
+    ctx->last_kernel_ms = t.stop();
+
+    std::vector<uint32_t> status(r->nlist), endst(r->nlist);
+    VIDC_HIP(hipMemcpyAsync(status.data(), s_status.p, r->nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(endst.data(), s_end.p, r->nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_TRY(check_status(status, "roc decode"));
+    uint64_t bad = 0;
+    for (uint32_t e : endst) bad += e;
+    r->last_nonclean = bad;
+    return VIDC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vidc_roc_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint64_t *d_ids,
+                    int precision_mode, uint32_t flags, vidc_roc **out) {
+    if (nlist && offsets && offsets[nlist] > offsets[0] && !d_ids) return VIDC_ERR_INVALID;
+    return encode_impl(ctx, nlist, offsets, d_ids, false, 0, 0, nullptr, precision_mode, flags, out);
+}
+
+int vidc_roc_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_rows, int precision_mode,
+                         uint32_t flags, vidc_roc **out) {
+    if (N && !d_rows) return VIDC_ERR_INVALID;
+    return encode_impl(ctx, 0, nullptr, nullptr, true, N, K, d_rows, precision_mode, flags, out);
+}
+
+void vidc_roc_destroy(vidc_roc *r) { delete r; }
+
+uint64_t vidc_roc_nlist(const vidc_roc *r) { return r ? r->nlist : 0; }
+uint64_t vidc_roc_ntotal(const vidc_roc *r) { return r ? r->ntotal : 0; }
+uint64_t vidc_roc_compressed_bytes(const vidc_roc *r) { return r ? r->compressed_bytes : 0; }
+uint64_t vidc_roc_total_words(const vidc_roc *r) { return r ? r->total_words : 0; }
+uint64_t vidc_roc_last_decode_nonclean(const vidc_roc *r) { return r ? r->last_nonclean : 0; }
+
+int vidc_roc_list_info(const vidc_roc *r, uint32_t *sizes, uint32_t *precisions, uint64_t *heads,
+                       uint32_t *nwords, uint32_t *mt_draws) {
+    if (!r) return VIDC_ERR_INVALID;
+    for (uint64_t l = 0; l < r->nlist; l++) {
+        if (sizes) sizes[l] = (uint32_t)(r->offsets[l + 1] - r->offsets[l]);
+        if (precisions) precisions[l] = r->prec[l];
+        if (heads) heads[l] = r->heads[l];
+        if (nwords) nwords[l] = r->nwords[l];
+        if (mt_draws) mt_draws[l] = r->draws[l];
+    }
+    return VIDC_OK;
+}
+
+int vidc_roc_export_words(vidc_ctx *ctx, const vidc_roc *r, uint64_t list_no, uint32_t *words, size_t cap) {
+    if (!ctx || !r || list_no >= r->nlist) return VIDC_ERR_INVALID;
+    uint64_t nw = r->nwords[list_no];
+    if (nw > cap) { set_error("export buffer too small (%zu < %llu words)", cap, (unsigned long long)nw); return VIDC_ERR_INVALID; }
+    return vidc_copy_d2h(ctx, words, r->d_words.p + r->word_off[list_no], nw * 4);
+}
+
+int vidc_roc_perm(vidc_ctx *ctx, const vidc_roc *r, uint32_t *perm_host) {
+    if (!ctx || !r || !perm_host) return VIDC_ERR_INVALID;
+    if (!r->d_perm.p) { set_error("encode was called without VIDC_ROC_WANT_PERM"); return VIDC_ERR_INVALID; }
+    return vidc_copy_d2h(ctx, perm_host, r->d_perm.p, r->ntotal * 4);
+}
+const uint32_t *vidc_roc_perm_dev(const vidc_roc *r) { return r ? r->d_perm.p : nullptr; }
+
+int vidc_roc_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint32_t *precisions,
+                    const uint64_t *heads, const uint32_t *nwords, const uint32_t *mt_draws,
+                    const uint32_t *words_concat, vidc_roc **out) {
+    if (!ctx || !out || (nlist && (!offsets || !precisions || !heads || !nwords))) return VIDC_ERR_INVALID;
+    VIDC_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<vidc_roc> r(new vidc_roc());
+    r->device = ctx->device;
+    r->nlist = nlist;
+    r->offsets.assign(offsets, offsets + nlist + 1);
+    r->ntotal = nlist ? offsets[nlist] : 0;
+    if (!nlist) r->offsets.assign(1, 0);
+    r->prec.assign(precisions, precisions + nlist);
+    r->heads.assign(heads, heads + nlist);
+    r->nwords.assign(nwords, nwords + nlist);
+    if (mt_draws) r->draws.assign(mt_draws, mt_draws + nlist); else r->draws.assign(nlist, 0);
+    r->word_off.assign(nlist + 1, 0);
+    for (uint64_t l = 0; l < nlist; l++) {
+        if (r->prec[l] > 32) { set_error("list %llu: precision %u unsupported", (unsigned long long)l, r->prec[l]); return VIDC_ERR_INVALID; }
+        uint64_t n = r->offsets[l + 1] - r->offsets[l];
+        if (n > VIDC_ROC_MAX_LIST) { set_error("list %llu too long", (unsigned long long)l); return VIDC_ERR_DOMAIN; }
+        r->word_off[l + 1] = r->word_off[l] + r->nwords[l];
+        if (n) r->compressed_bytes += 8 + 4ull * r->nwords[l];
+    }
+    r->total_words = r->word_off[nlist];
+    VIDC_TRY(upload(ctx, r->d_offsets, r->offsets));
+    VIDC_TRY(upload(ctx, r->d_prec, r->prec));
+    VIDC_TRY(upload(ctx, r->d_heads, r->heads));
+    VIDC_TRY(upload(ctx, r->d_nwords, r->nwords));
+    VIDC_TRY(upload(ctx, r->d_draws, r->draws));
+    VIDC_TRY(upload(ctx, r->d_word_off, r->word_off));
+    VIDC_TRY(r->d_words.alloc(r->total_words ? r->total_words : 1));
+    if (r->total_words)
+        VIDC_HIP(hipMemcpyAsync(r->d_words.p, words_concat, r->total_words * 4, hipMemcpyHostToDevice, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    *out = r.release();
+    return VIDC_OK;
+}
+
+int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out) {
+    if (!ctx || !r || (r->ntotal && !d_out)) return VIDC_ERR_INVALID;
+    std::vector<uint32_t> all(r->nlist);
+    std::iota(all.begin(), all.end(), 0u);
+    DecPlan p;
+    plan_decode(r, all, p);
+    return decode_impl(ctx, r, p, nullptr, d_out, nullptr, 0);
+}
+
+int vidc_roc_decode_lists(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *list_nos,
+                          uint64_t *d_out, uint64_t *out_offsets) {
+    if (!ctx || !r || (m && !list_nos) || !out_offsets) return VIDC_ERR_INVALID;
+    std::vector<uint32_t> lists(m);
+    std::vector<uint64_t> req_off(m + 1, 0);
+    for (uint64_t i = 0; i < m; i++) {
+        if (list_nos[i] >= r->nlist) { set_error("list number %llu out of range", (unsigned long long)list_nos[i]); return VIDC_ERR_INVALID; }
+        lists[i] = (uint32_t)list_nos[i];
+        req_off[i + 1] = req_off[i] + (r->offsets[lists[i] + 1] - r->offsets[lists[i]]);
+    }
+    std::memcpy(out_offsets, req_off.data(), (m + 1) * 8);
+    // the plan re-orders work items by size: map each item back to its slot in the request.
+    // (a list requested twice is decoded twice)
+    std::vector<uint32_t> item(m);
+    std::iota(item.begin(), item.end(), 0u);
+    DecPlan p;
+    {
+        // plan over request indices: build a temporary roc-like view through index indirection
+        std::vector<uint32_t> tiny, small, big;
+        auto len = [&](uint32_t i) { return r->offsets[lists[i] + 1] - r->offsets[lists[i]]; };
+        for (uint32_t i = 0; i < m; i++) {
+            uint64_t n = len(i);
+            if (n <= TINY_MAX) tiny.push_back(i); else if (n <= GEN_SMALL_MAX) small.push_back(i); else big.push_back(i);
+        }
+        auto by_len = [&](uint32_t x, uint32_t y) { return len(x) > len(y); };
+        std::stable_sort(small.begin(), small.end(), by_len);
+        std::stable_sort(big.begin(), big.end(), by_len);
+        item.clear();
+        item.insert(item.end(), tiny.begin(), tiny.end());
+        item.insert(item.end(), small.begin(), small.end());
+        item.insert(item.end(), big.begin(), big.end());
+        p.n_tiny = tiny.size(); p.n_small = small.size(); p.n_big = big.size();
+        p.wl.resize(m); p.scratch_off.resize(m); p.slots_off.resize(m);
+        uint64_t so = 0, sl = 0;
+        for (size_t k = 0; k < m; k++) {
+            uint32_t l = lists[item[k]];
+            uint64_t n = r->offsets[l + 1] - r->offsets[l];
+            p.wl[k] = l;
+            p.scratch_off[k] = so; so += (uint64_t)r->nwords[l] + 64;
+            p.slots_off[k] = sl;
+            if (n > TINY_MAX) sl += ((uint64_t)1 << roc_dec_fine_bits((uint32_t)n, r->prec[l] > 32 ? 32 : r->prec[l])) * VIDC_DEC_CAP + n;
+        }
+        p.scratch_words = so; p.slots_words = sl;
+    }
+    std::vector<uint64_t> out_off(m);
+    for (size_t k = 0; k < m; k++) out_off[k] = req_off[item[k]];
+    return decode_impl(ctx, r, p, out_off.data(), d_out, nullptr, 0);
+}
+
+int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *nodes, uint32_t K,
+                         int32_t *d_out, uint32_t *counts) {
+    if (!ctx || !r || (m && (!nodes || !d_out))) return VIDC_ERR_INVALID;
+    if (K == 0 || K > TINY_MAX) { set_error("K=%u unsupported", K); return VIDC_ERR_UNSUPPORTED; }
+    DecPlan p;
+    p.wl.resize(m); p.scratch_off.resize(m); p.slots_off.assign(m, 0);
+    std::vector<uint64_t> out_off(m);
+    uint64_t so = 0;
+    for (uint64_t i = 0; i < m; i++) {
+        if (nodes[i] >= r->nlist) { set_error("node %llu out of range", (unsigned long long)nodes[i]); return VIDC_ERR_INVALID; }
+        uint32_t l = (uint32_t)nodes[i];
+        uint64_t n = r->offsets[l + 1] - r->offsets[l];
+        if (n > K) { set_error("node %u has %llu edges > K=%u", l, (unsigned long long)n, K); return VIDC_ERR_INVALID; }
+        if (counts) counts[i] = (uint32_t)n;
+        p.wl[i] = l;
+        p.scratch_off[i] = so; so += (uint64_t)r->nwords[l] + 64;
+        out_off[i] = i * K;
+    }
+    p.n_tiny = m; p.scratch_words = so; p.slots_words = 0;
+    return decode_impl(ctx, r, p, out_off.data(), nullptr, d_out, K);
+}
+
+}  // extern "C"

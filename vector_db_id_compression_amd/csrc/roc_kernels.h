@@ -1,0 +1,537 @@
+// roc_kernels.h -- Random Order Coding (bits-back ANS over a set) encode / decode kernels for gfx950.
+//
+// One inverted list (or one graph row) per 64-lane wavefront; lists are strictly serial inside
+// (every step depends on the 64-bit ANS head) and independent across wavefronts.
+//
+//   encode step i (custom_invlists_impl.cpp:178-192 == codec.cpp:131-137):
+//        k = IDX_pop(n - i)            u64 div/mod by a runtime divisor -> mulhi with per-lane
+//                                      precomputed reciprocals (one 64-bit division per lane per 64 steps)
+//        x = select+remove k-th alive  alive bitmap over the SORTED positions; per-lane inclusive
+//                                      prefix counters (ballot + s_ff1) -> LDS row of prefix counters ->
+//                                      in-word select with v_mbcnt
+//        ID_push(x, P)                 four 16-bit uniform slices
+//   decode step i (codec.cpp:140-152):
+//        x = ID_pop(P); r = #decoded elements < x; IDX_push(r, i + 1); out[n-1-i] = x
+//                                      rank = per-lane coarse prefix counters + LDS fine prefix row +
+//                                      compare against the (<= 16) members of x's fine bucket
+//
+// The order-statistic structures replace the reference's pointer BST (fenwick_tree.h:20-167);
+// the bitstream only depends on rank/select over the set.
+#pragma once
+#include "wave.h"
+
+namespace vidc {
+namespace dev {
+
+// status codes written per list
+#define VIDC_ST_OK 0u
+#define VIDC_ST_PENDING_SORT 1u
+#define VIDC_ST_DOMAIN 2u
+#define VIDC_ST_OVERFLOW 3u
+#define VIDC_ST_MT 4u
+
+struct RocEncArgs {
+    const uint64_t *ids;       // [ntotal] (IVF flavour) or nullptr
+    const int32_t *rows;       // [N*K]   (graph flavour) or nullptr
+    uint32_t K;
+    const uint64_t *offsets;   // [nlist+1] CSR offsets of the OUTPUT numbering (IVF: == input offsets)
+    const uint32_t *worklist;  // list numbers handled by this launch
+    uint32_t nwork;
+    int precision_mode;
+    uint64_t *heads;           // [nlist]
+    uint32_t *prec;            // [nlist]
+    uint32_t *nwords;          // [nlist]
+    uint32_t *draws;           // [nlist]
+    uint32_t *sizes;           // [nlist] (graph flavour: edge counts, altid_impl.h:61)
+    uint32_t *status;          // [nlist]
+    uint32_t *arena;           // worst-case word arena
+    const uint64_t *arena_off; // [nlist+1]
+    uint32_t *perm;            // [ntotal] or nullptr
+    uint32_t *sid;             // [ntotal] scratch: ids of each list in ascending order (u32)
+    uint32_t *spos;            // [ntotal] scratch: input positions in that order (unsorted lists only)
+    uint64_t *skey;            // sort scratch for unsorted lists (pow2-padded) or nullptr
+    const uint64_t *skey_off;  // [nlist+1] or nullptr
+    const uint32_t *mt;
+};
+
+struct RocDecArgs {
+    const uint64_t *offsets;    // [nlist+1] CSR offsets of the stored lists
+    const uint32_t *worklist;   // list numbers handled by this launch
+    const uint64_t *out_off;    // [nwork] output offset per work item (or nullptr: use offsets[list])
+    uint32_t nwork;
+    const uint64_t *heads;
+    const uint32_t *prec;
+    const uint32_t *nwords;
+    const uint32_t *draws;
+    const uint32_t *words;      // compact stream
+    const uint64_t *word_off;   // [nlist+1]
+    uint64_t *out;              // u64 output (IVF flavour) or nullptr
+    int32_t *out_rows;          // int32 rows (graph flavour) or nullptr; row stride K, -1 padded
+    uint32_t K;
+    uint32_t *scratch_words;    // decoder stack re-spill scratch
+    const uint64_t *scratch_off;// [nwork] per work item (relative to work_base)
+    uint32_t *slots;            // fine-bucket member storage
+    const uint64_t *slots_off;  // [nwork] per work item: start of (NF*CAP + n) words
+    uint32_t *end_state;        // [nlist] 0 = clean end state (head == 2^31 and stack == drawn words)
+    uint32_t *status;           // [nlist]
+    const uint32_t *mt;
+};
+
+#define VIDC_DEC_CAP 16u       // members per fine bucket before spilling to the overflow list
+#define VIDC_DEC_MAX_FB 12u    // <= 64 coarse x 64 fine buckets
+
+// fine-bucket bits used by the decoder for a list of n elements with precision P (host + device)
+__host__ __device__ inline uint32_t roc_dec_fine_bits(uint32_t n, uint32_t P) {
+    uint32_t lg = 0;
+    while ((1u << lg) < n) lg++;
+    uint32_t fb = lg > 3u ? lg - 3u : 0u;
+    if (fb > VIDC_DEC_MAX_FB) fb = VIDC_DEC_MAX_FB;
+    if (fb > P) fb = P;
+    return fb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-64-step reciprocals: lane t prepares the divisor d = dmax - t.
+struct Recip {
+    uint32_t m_lo, m_hi;  // floor((2^64 - 1) / d)
+    uint32_t thr;         // d * floor(2^31 / d)
+    uint32_t lq;          // floor(2^31 / d)
+};
+__device__ __forceinline__ void recip_block(Recip &r, uint32_t dmax) {
+    uint32_t t = lane_id();
+    uint32_t d = dmax > t ? dmax - t : 1u;
+    uint64_t m = ~0ull / (uint64_t)d;
+    r.m_lo = (uint32_t)m;
+    r.m_hi = (uint32_t)(m >> 32);
+    r.lq = 0x80000000u / d;
+    r.thr = r.lq * d;
+}
+
+// =============================================================================================
+// TINY lists (n <= 64): the whole set lives in one VGPR, sorted with an in-register bitonic network.
+// =============================================================================================
+template <bool ROWS>
+__global__ void __launch_bounds__(64) k_roc_encode_tiny(RocEncArgs a) {
+    const uint32_t lane = lane_id();
+    for (uint32_t wi = blockIdx.x; wi < a.nwork; wi += gridDim.x) {
+        const uint32_t l = a.worklist[wi];
+        uint32_t n;
+        uint64_t off;
+        uint32_t v = 0xffffffffu;
+        bool bad = false;
+        if (ROWS) {
+            // altid_impl.cpp:110-117: edges up to the first -1
+            int32_t e = lane < a.K ? a.rows[(uint64_t)l * a.K + lane] : -1;
+            uint64_t neg = ballot(e == -1);
+            n = neg ? ff1(neg) : 64u;
+            if (n > a.K) n = a.K;
+            off = (uint64_t)l * a.K;
+            if (lane < n) {
+                v = (uint32_t)e;
+                bad = e < 0;
+            }
+        } else {
+            off = a.offsets[l];
+            n = (uint32_t)(a.offsets[l + 1] - off);
+            if (lane < n) {
+                uint64_t id = a.ids[off + lane];
+                bad = id >= (1ull << 31);  // reference: int max_id (custom_invlists_impl.cpp:163)
+                v = (uint32_t)id;
+            }
+        }
+        if (ROWS) a.sizes[l] = n;
+        if (n == 0) {
+            a.heads[l] = VIDC_RANS_L; a.prec[l] = 0; a.nwords[l] = 0; a.draws[l] = 0; a.status[l] = VIDC_ST_OK;
+            continue;
+        }
+        if (ballot(bad)) {
+            if (lane == 0) a.status[l] = VIDC_ST_DOMAIN;
+            continue;
+        }
+        const uint32_t maxid = wave_max_u32(lane < n ? v : 0u);
+        const uint32_t P = precision_for(maxid, a.precision_mode);
+        const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
+
+        // sort (id, position) ascending: key = id * 64 + position, padding lanes carry ~0
+        uint64_t key = lane < n ? (((uint64_t)v << 6) | lane) : ~0ull;
+#pragma unroll
+        for (uint32_t k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                uint32_t plo = (uint32_t)__shfl_xor((int)(uint32_t)key, (int)j, 64);
+                uint32_t phi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), (int)j, 64);
+                uint64_t other = ((uint64_t)phi << 32) | plo;
+                bool up = ((lane & k) == 0);
+                bool lower = ((lane & j) == 0);
+                bool take_min = (up == lower);
+                uint64_t mn = key < other ? key : other, mx = key < other ? other : key;
+                key = take_min ? mn : mx;
+            }
+        }
+        const uint32_t sid = (uint32_t)(key >> 6);
+        const uint32_t spos = (uint32_t)key & 63u;
+
+        WStack st;
+        uint32_t *arena = a.arena + a.arena_off[l];
+        ws_init_empty(st, arena, (uint32_t)(a.arena_off[l + 1] - a.arena_off[l]), a.mt, VIDC_MT_TABLE);
+        uint64_t head = VIDC_RANS_L;
+        uint64_t alive = n == 64u ? ~0ull : ((1ull << n) - 1ull);
+        Recip rc;
+        recip_block(rc, n);
+        uint32_t pbuf = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t nmax = n - i;
+            const uint64_t magic = rl64(rc.m_lo, rc.m_hi, i);
+            const uint32_t k = ans_idx_pop(head, st, nmax, rl(rc.thr, i), magic);
+            const bool mine = ((alive >> lane) & 1ull) && (mbcnt(alive) == k);
+            const uint32_t b = ff1(ballot(mine));
+            alive &= ~(1ull << b);
+            const uint32_t x = rl(sid, b);
+            ans_id_push(head, st, x, p0, p1);
+            pbuf = wl(rl(spos, b), i, pbuf);
+        }
+        ws_flush(st);
+        if (!ROWS && a.perm && lane < n) a.perm[off + lane] = pbuf;
+        if (lane == 0) {
+            a.heads[l] = head;
+            a.prec[l] = P;
+            a.nwords[l] = st.sp;
+            a.draws[l] = st.draws;
+            a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
+        }
+    }
+}
+
+template <bool ROWS>
+__global__ void __launch_bounds__(64) k_roc_decode_tiny(RocDecArgs a) {
+    const uint32_t lane = lane_id();
+    for (uint32_t wi = blockIdx.x; wi < a.nwork; wi += gridDim.x) {
+        const uint32_t l = a.worklist[wi];
+        const uint32_t n = (uint32_t)(a.offsets[l + 1] - a.offsets[l]);
+        const uint64_t ooff = a.out_off ? a.out_off[wi] : a.offsets[l];
+        if (ROWS) {
+            // pad the row with -1 first (the reference leaves slots >= n untouched, altid_impl.cpp:153-165)
+            if (lane < a.K) a.out_rows[ooff + lane] = -1;
+        }
+        if (n == 0) {
+            if (lane == 0) { a.end_state[l] = 0; a.status[l] = VIDC_ST_OK; }
+            continue;
+        }
+        const uint32_t P = a.prec[l];
+        const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
+        const uint32_t W = a.nwords[l];
+        WStack st;
+        ws_init_loaded(st, a.words + a.word_off[l], W, a.scratch_words + a.scratch_off[wi], W + 64u, a.draws[l], a.mt,
+                       VIDC_MT_TABLE);
+        const uint32_t draws0 = st.draws;
+        uint64_t head = a.heads[l];
+        Recip rc;
+        // decoder divisors grow: nmax = i + 1; lane t prepares d = t + 1  (recip_block counts down from dmax)
+        {
+            uint32_t d = lane + 1u;
+            rc.lq = 0x80000000u / d;
+            rc.thr = 0; rc.m_lo = 0; rc.m_hi = 0;
+        }
+        uint32_t val = 0xffffffffu;  // lane i holds the element decoded at step i
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t x = ans_id_pop(head, st, p0, p1);
+            const uint32_t r = popc64(ballot(lane < i && val < x));  // strictly smaller (fenwick_tree.h:42-94)
+            ans_idx_push(head, st, r, i + 1u, rl(rc.lq, i));
+            val = wl(x, i, val);
+        }
+        if (lane < n) {
+            if (ROWS) a.out_rows[ooff + (n - 1u - lane)] = (int32_t)val;
+            else a.out[ooff + (n - 1u - lane)] = (uint64_t)val;
+        }
+        if (lane == 0) {
+            // clean end: head back at 2^31 and the stack holds exactly the words drawn from mt19937
+            bool clean = (head == VIDC_RANS_L) && (st.sp == st.draws - draws0);
+            a.end_state[l] = clean ? 0u : 1u;
+            a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
+        }
+    }
+}
+
+// =============================================================================================
+// GENERAL lists (n <= 262144)
+// =============================================================================================
+
+// wave-level bitonic sort of npow2 u64 keys in global memory (only taken for unsorted input lists)
+__device__ inline void wave_bitonic_global(uint64_t *keys, uint32_t npow2) {
+    const uint32_t lane = lane_id();
+    for (uint32_t k = 2; k <= npow2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = lane; t < (npow2 >> 1); t += 64) {
+                uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));  // index with bit j clear
+                uint32_t p = i | j;
+                uint64_t x = keys[i], y = keys[p];
+                bool up = ((i & k) == 0);
+                if ((x > y) == up) {
+                    keys[i] = y;
+                    keys[p] = x;
+                }
+            }
+            wave_sync();
+        }
+    }
+}
+
+// LDS layout (dynamic): u64 words[64*RL] | u32 rowpref[64*RL]
+__global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl_max) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *words = (uint64_t *)smem;
+    uint32_t *rowpref = (uint32_t *)(smem + (size_t)64u * rl_max * 8u);
+    const uint32_t lane = lane_id();
+
+    for (uint32_t wi = blockIdx.x; wi < a.nwork; wi += gridDim.x) {
+        const uint32_t l = a.worklist[wi];
+        const uint64_t off = a.offsets[l];
+        const uint32_t n = (uint32_t)(a.offsets[l + 1] - off);
+        if (n == 0) {
+            if (lane == 0) {
+                a.heads[l] = VIDC_RANS_L; a.prec[l] = 0; a.nwords[l] = 0; a.draws[l] = 0; a.status[l] = VIDC_ST_OK;
+            }
+            continue;
+        }
+        // ---- phase 0: stream the list once: domain check, max id, sortedness, u32 copy
+        uint32_t mx = 0;
+        bool bad = false, unsorted = false;
+        for (uint32_t j = lane; j < n; j += 64) {
+            uint64_t id = a.ids[off + j];
+            bad |= id >= (1ull << 31);
+            if (j) unsorted |= a.ids[off + j - 1] >= id;
+            uint32_t v = (uint32_t)id;
+            mx = v > mx ? v : mx;
+            a.sid[off + j] = v;
+        }
+        if (ballot(bad)) {
+            if (lane == 0) a.status[l] = VIDC_ST_DOMAIN;
+            continue;
+        }
+        const bool need_sort = ballot(unsorted) != 0;
+        if (need_sort) {
+            if (!a.skey) {
+                if (lane == 0) a.status[l] = VIDC_ST_PENDING_SORT;
+                continue;
+            }
+            uint64_t *keys = a.skey + a.skey_off[l];
+            const uint32_t np2 = (uint32_t)(a.skey_off[l + 1] - a.skey_off[l]);
+            for (uint32_t j = lane; j < np2; j += 64)
+                keys[j] = j < n ? ((a.ids[off + j] << 32) | j) : ~0ull;  // order (id, position), cf. tuple<id, code ptr>
+            wave_sync();
+            wave_bitonic_global(keys, np2);
+            for (uint32_t j = lane; j < n; j += 64) {
+                uint64_t kk = keys[j];
+                a.sid[off + j] = (uint32_t)(kk >> 32);
+                a.spos[off + j] = (uint32_t)kk;
+            }
+        }
+        const uint32_t maxid = wave_max_u32(mx);
+        const uint32_t P = precision_for(maxid, a.precision_mode);
+        const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
+
+        // ---- phase 1: alive bitmap over sorted positions + two levels of inclusive prefix counters
+        const uint32_t nw = (n + 63u) >> 6;
+        uint32_t RL = 1;
+        while (64u * RL < nw) RL <<= 1;  // words per lane-block
+        const uint32_t rlsh = (uint32_t)__builtin_ctz(RL);
+        for (uint32_t w = lane; w < 64u * RL; w += 64) {
+            uint32_t lo_e = w << 6, hi_e = lo_e + 64u;
+            uint32_t c = w >> rlsh;
+            uint32_t blk_lo = (c << rlsh) << 6;
+            uint32_t cnt_hi = hi_e < n ? hi_e : n;
+            uint32_t cnt_blk = blk_lo < n ? blk_lo : n;
+            rowpref[w] = cnt_hi - cnt_blk;
+            uint32_t in_w = lo_e >= n ? 0u : (n - lo_e >= 64u ? 64u : n - lo_e);
+            words[w] = in_w == 64u ? ~0ull : ((1ull << in_w) - 1ull);
+        }
+        uint32_t P1;  // lane c: alive elements in lane-blocks 0..c
+        {
+            uint64_t e = ((uint64_t)(lane + 1u) << rlsh) << 6;
+            P1 = e < n ? (uint32_t)e : n;
+        }
+        wave_sync();
+
+        // ---- phase 2: the serial chain
+        WStack st;
+        ws_init_empty(st, a.arena + a.arena_off[l], (uint32_t)(a.arena_off[l + 1] - a.arena_off[l]), a.mt,
+                      VIDC_MT_TABLE);
+        uint64_t head = VIDC_RANS_L;
+        Recip rc;
+        uint32_t pbuf = 0;
+        const uint32_t *sid = a.sid + off;
+        const uint32_t *spos = a.spos + off;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t t64 = i & 63u;
+            if (t64 == 0) recip_block(rc, n - i);
+            const uint32_t nmax = n - i;
+            const uint64_t magic = rl64(rc.m_lo, rc.m_hi, t64);
+            uint32_t k = ans_idx_pop(head, st, nmax, rl(rc.thr, t64), magic);
+            // level 1: lane-block
+            const uint32_t c = ff1(ballot(P1 > k));
+            if (c) k -= rl(P1, c - 1u);
+            // level 2: word inside the lane-block
+            uint32_t w = c;
+            uint32_t tsel = 0;
+            uint32_t rowv = 0;
+            if (RL > 1u) {
+                rowv = lane < RL ? rowpref[(c << rlsh) + lane] : 0xffffffffu;
+                tsel = ff1(ballot(rowv > k));
+                if (tsel) k -= rl(rowv, tsel - 1u);
+                w = (c << rlsh) + tsel;
+            }
+            // level 3: bit inside the word
+            const uint64_t W = rfl64(words[w]);
+            const bool mine = ((W >> lane) & 1ull) && (mbcnt(W) == k);
+            const uint32_t b = ff1(ballot(mine));
+            const uint32_t j = (w << 6) + b;
+            const uint32_t x = rfl(sid[j]);
+            // remove
+            if (lane == 0) words[w] = W & ~(1ull << b);
+            if (RL > 1u && lane >= tsel && lane < RL) rowpref[(c << rlsh) + lane] = rowv - 1u;
+            P1 -= (lane >= c) ? 1u : 0u;
+            ans_id_push(head, st, x, p0, p1);
+            if (a.perm) {
+                const uint32_t pos = need_sort ? rfl(spos[j]) : j;
+                pbuf = wl(pos, t64, pbuf);
+                if (t64 == 63u || i == n - 1u) {
+                    if (lane <= t64) a.perm[off + (i - t64) + lane] = pbuf;
+                }
+            }
+        }
+        ws_flush(st);
+        if (lane == 0) {
+            a.heads[l] = head;
+            a.prec[l] = P;
+            a.nwords[l] = st.sp;
+            a.draws[l] = st.draws;
+            a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
+        }
+        wave_sync();
+    }
+}
+
+// LDS layout (dynamic): u32 rowpref[2^fb_max]
+__global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t lds_entries) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *rowpref = (uint32_t *)smem;
+    const uint32_t lane = lane_id();
+
+    for (uint32_t wi = blockIdx.x; wi < a.nwork; wi += gridDim.x) {
+        const uint32_t l = a.worklist[wi];
+        const uint32_t n = (uint32_t)(a.offsets[l + 1] - a.offsets[l]);
+        const uint64_t ooff = a.out_off ? a.out_off[wi] : a.offsets[l];
+        if (n == 0) {
+            if (lane == 0) { a.end_state[l] = 0; a.status[l] = VIDC_ST_OK; }
+            continue;
+        }
+        const uint32_t P = a.prec[l];
+        const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
+        const uint32_t W = a.nwords[l];
+        WStack st;
+        ws_init_loaded(st, a.words + a.word_off[l], W, a.scratch_words + a.scratch_off[wi], W + 64u, a.draws[l], a.mt,
+                       VIDC_MT_TABLE);
+        const uint32_t draws0 = st.draws;
+        uint64_t head = a.heads[l];
+
+        // bucket geometry: fine bucket f = x >> s, coarse c = f >> rb (<= 64 of them), row slot t = f & (RL-1)
+        const uint32_t fb = roc_dec_fine_bits(n, P > 32u ? 32u : P);
+        const uint32_t cb = fb < 6u ? fb : 6u;
+        const uint32_t rb = fb - cb;
+        const uint32_t RL = 1u << rb;
+        const uint32_t s = (P > 32u ? 32u : P) - fb;
+        const uint32_t NF = 1u << fb;
+        for (uint32_t t = lane; t < NF && t < lds_entries; t += 64) rowpref[t] = 0;
+        uint32_t C1 = 0;  // lane c: decoded elements in coarse buckets 0..c
+        uint32_t *slots = a.slots + a.slots_off[wi];
+        uint32_t *ovf = slots + (size_t)NF * VIDC_DEC_CAP;
+        uint32_t novf = 0, novf_vis = 0;
+        uint32_t ring = 0;  // lane t: element decoded at step (block start + t)
+        Recip rc;
+        wave_sync();
+
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t t64 = i & 63u;
+            if (t64 == 0) {
+                // new 64-step block: earlier slot / overflow stores become visible to loads
+                wave_sync();
+                novf_vis = novf;
+                uint32_t d = i + 1u + lane;
+                rc.lq = 0x80000000u / d;
+            }
+            const uint32_t x = ans_id_pop(head, st, p0, p1);
+            const uint32_t f = s >= 32u ? 0u : (x >> s);
+            const uint32_t c = f >> rb;
+            const uint32_t t = f & (RL - 1u);
+            // prefix counts of the buckets below f
+            const uint32_t base1 = c ? rl(C1, c - 1u) : 0u;
+            uint32_t base2 = 0, cnt, rowv = 0;
+            if (rb) {
+                rowv = lane < RL ? rowpref[(c << rb) + lane] : 0u;
+                if (t) base2 = rl(rowv, t - 1u);
+                cnt = rl(rowv, t) - base2;
+            } else {
+                cnt = rl(C1, c) - base1;
+            }
+            // members of bucket f: those stored before this block (visible in memory) ...
+            const bool ring_valid = lane < t64;
+            const bool ring_same = ring_valid && ((s >= 32u ? 0u : (ring >> s)) == f);
+            const uint32_t in_ring = popc64(ballot(ring_same));
+            const uint32_t cnt_vis = cnt - in_ring;
+            const uint32_t m = cnt_vis < VIDC_DEC_CAP ? cnt_vis : VIDC_DEC_CAP;
+            uint32_t y = 0xffffffffu;
+            if (lane < m) y = slots[(size_t)f * VIDC_DEC_CAP + lane];
+            uint32_t within = popc64(ballot(lane < m && y < x));
+            if (cnt_vis > VIDC_DEC_CAP) {  // skewed data: members that did not fit the row
+                for (uint32_t j0 = 0; j0 < novf_vis; j0 += 64) {
+                    uint32_t jj = j0 + lane;
+                    uint32_t z = jj < novf_vis ? ovf[jj] : 0xffffffffu;
+                    bool hit = jj < novf_vis && ((s >= 32u ? 0u : (z >> s)) == f) && z < x;
+                    within += popc64(ballot(hit));
+                }
+            }
+            // ... plus those decoded inside the current block (still in flight to memory)
+            within += popc64(ballot(ring_same && ring < x));
+            const uint32_t r = base1 + base2 + within;
+            ans_idx_push(head, st, r, i + 1u, rl(rc.lq, t64));
+            // insert x
+            if (cnt < VIDC_DEC_CAP) {
+                if (lane == 0) slots[(size_t)f * VIDC_DEC_CAP + cnt] = x;
+            } else {
+                if (lane == 0) ovf[novf] = x;
+                novf++;
+            }
+            C1 += (lane >= c) ? 1u : 0u;
+            if (rb && lane >= t && lane < RL) rowpref[(c << rb) + lane] = rowv + 1u;
+            ring = wl(x, t64, ring);
+            if (t64 == 63u || i == n - 1u) {
+                if (lane <= t64) {
+                    const uint32_t step = (i - t64) + lane;
+                    if (a.out) a.out[ooff + (n - 1u - step)] = (uint64_t)ring;
+                    else a.out_rows[ooff + (n - 1u - step)] = (int32_t)ring;
+                }
+            }
+        }
+        if (lane == 0) {
+            bool clean = (head == VIDC_RANS_L) && (st.sp == st.draws - draws0);
+            a.end_state[l] = clean ? 0u : 1u;
+            a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
+        }
+        wave_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// compaction of the worst-case arena into the CSR stream
+__global__ void k_roc_compact(const uint32_t *arena, const uint64_t *arena_off, const uint64_t *word_off,
+                              uint32_t *words, uint32_t nlist) {
+    for (uint32_t l = blockIdx.x; l < nlist; l += gridDim.x) {
+        const uint32_t *src = arena + arena_off[l];
+        uint32_t *dst = words + word_off[l];
+        uint32_t nw = (uint32_t)(word_off[l + 1] - word_off[l]);
+        for (uint32_t j = threadIdx.x; j < nw; j += blockDim.x) dst[j] = src[j];
+    }
+}
+
+}  // namespace dev
+}  // namespace vidc
