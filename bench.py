@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- IDs encoded+decoded per second on the BASELINE.json workload (MI355X).
+
+A "step" = one pass of the hot path over one batch: ROC-encode every inverted list of the batch, then
+ROC-decode every list (inputs and outputs resident in HBM).  Default workload = BASELINE.json configs[1]
+(S1: 1M uint64 ids in 1024 Zipf(0.75) lists).  With N GPUs every rank owns a shard of the same shape
+(different seed): inverted lists are independent, so there is no data-path collective ("weak" scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(offsets, ids, budget_s=20.0):
+    """Time the CPU codec on this host (rank 0, N=1 only).  Test-infrastructure libraries from oracle/."""
+    from oracle.pyoracle import Oracle, Ref
+
+    try:
+        impl, kind = Ref(), "reference"
+    except Exception:
+        impl, kind = Oracle(), "port"
+    cores = impl.max_threads()
+    ntotal = int(offsets[-1])
+    t0 = time.time()
+    runs = []
+    while True:
+        r = impl.bench_lists(offsets, ids, cores)
+        runs.append(r["t_enc"] + r["t_dec"])
+        if time.time() - t0 > budget_s / 2 or len(runs) >= 5:
+            break
+    t_all = float(np.median(runs))
+    one = impl.bench_lists(offsets, ids, 1)
+    t_one = one["t_enc"] + one["t_dec"]
+    return dict(value=ntotal / t_all, unit="IDs/s (encode+decode)", cores=cores, kind=kind,
+                sample=f"full S1 batch ({ntotal} ids / {offsets.size - 1} lists), median of {len(runs)} runs, "
+                       f"OpenMP schedule(dynamic) over lists",
+                single_thread_value=ntotal / t_one, enc_s=r["t_enc"], dec_s=r["t_dec"],
+                bits_per_id=8.0 * r["bytes"] / ntotal, bad_lists=r["bad_lists"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="s1")
+    ap.add_argument("--codec", default="roc", choices=["roc", "ef", "packed"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from vector_db_id_compression_amd import _lib, synth
+    from vector_db_id_compression_amd.codecs import EfLists, PackedLists, RocLists
+
+    ctx = _lib.default_context(local_rank)
+    wl = synth.workload(args.workload, seed=42 + rank)
+    offsets = wl["offsets"]
+    ids_host = wl["ids"] if isinstance(wl["ids"], np.ndarray) else None
+    d_ids = torch.from_numpy(ids_host.view(np.int64)).cuda() if ids_host is not None else wl["ids"]
+    ntotal = wl["ntotal"]
+    out = torch.empty(ntotal, dtype=torch.int64, device="cuda")
+
+    def step():
+        if args.codec == "roc":
+            r = RocLists.encode(offsets, d_ids, ctx=ctx)
+            t_enc = ctx.phase_ms(0) + ctx.phase_ms(1)
+            r.decode_all(out)
+            t_dec = ctx.phase_ms(2)
+        elif args.codec == "ef":
+            r = EfLists.encode(offsets, d_ids, ctx=ctx)
+            t_enc = ctx.last_kernel_ms()
+            r.decode_all(out)
+            t_dec = ctx.last_kernel_ms()
+        else:
+            r = PackedLists.encode(offsets, d_ids, ctx=ctx)
+            t_enc = ctx.last_kernel_ms()
+            r.decode_all(out)
+            t_dec = ctx.last_kernel_ms()
+        return r, t_enc, t_dec
+
+    for _ in range(args.warmup):
+        r, _, _ = step()
+    # correctness gate inside the bench: every list must come back as the same set of ids
+    verified = None
+    if not args.no_verify:
+        srt = torch.empty_like(out)
+        off_t = torch.from_numpy(offsets.astype(np.int64)).cuda()
+        seg = torch.searchsorted(off_t[1:], torch.arange(ntotal, device="cuda"), right=True)
+        key = seg * (1 << 40) + out
+        srt = torch.sort(key).values & ((1 << 40) - 1)
+        ref = torch.sort(seg * (1 << 40) + d_ids).values & ((1 << 40) - 1)
+        verified = bool(torch.equal(srt, ref))
+        del srt, ref, key, seg
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k_enc = k_dec = 0.0
+    for _ in range(args.steps):
+        r, te, td = step()
+        k_enc += te
+        k_dec += td
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    comp_bytes = r.compressed_bytes
+    c = comp_bytes / ntotal  # compressed bytes per id
+    alg_bytes = (16.0 + 2.0 * c) * ntotal  # enc 8 B read + c written, dec c read + 8 B written
+    kern_s = (k_enc + k_dec) / args.steps / 1e3
+    achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
+
+    if rank == 0:
+        res = {
+            "metric": "IDs encoded+decoded / sec (ROC/ANS, bit-exact vs codec.cpp)" if args.codec == "roc"
+            else f"IDs encoded+decoded / sec ({args.codec})",
+            "value": world * ntotal * args.steps / elapsed,
+            "unit": "IDs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": wl["describe"], "codec": args.codec, "ids_per_gpu": ntotal, "lists_per_gpu": wl["nlist"],
+                       "max_list": wl["max_list"], "median_list": wl["median_list"],
+                       "parallelism": f"lists sharded over {world} GPU(s), no data-path collective"},
+            "bits_per_id": 8.0 * c,
+            "verified_roundtrip": verified,
+            "kernel_ms": {"encode": k_enc / args.steps, "decode": k_dec / args.steps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernels": "k_roc_encode_* + k_roc_compact + k_roc_decode_*" if args.codec == "roc" else args.codec,
+                         "algorithmic_bytes_per_id": 16.0 + 2.0 * c},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.codec == "roc" and ids_host is not None:
+            try:
+                res["cpu_baseline"] = cpu_baseline(offsets, ids_host)
+            except Exception as e:  # the checker libraries are optional at bench time
+                res["cpu_baseline"] = {"value": None, "unit": "IDs/s (encode+decode)", "cores": 0, "kind": "port",
+                                       "sample": f"unavailable: {e}"}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,6 +150,12 @@ int vidc_ef_export(vidc_ctx *ctx, const vidc_ef *e, uint64_t list_no, uint64_t *
 /* Milliseconds spent inside the kernels of the most recent encode / decode call on this context,
  * measured with hipEvents on the context's stream (used by bench.py for the roofline figure). */
 double vidc_ctx_last_kernel_ms(const vidc_ctx *ctx);
+/* Per-phase kernel time (ms, hipEvents) of the most recent call that ran the phase. */
+#define VIDC_PHASE_ROC_ENCODE 0  /* k_roc_encode_tiny + k_roc_encode_gen launches */
+#define VIDC_PHASE_ROC_COMPACT 1 /* k_roc_compact */
+#define VIDC_PHASE_ROC_DECODE 2  /* k_roc_decode_gen + k_roc_decode_tiny launches */
+#define VIDC_PHASE_COUNT 8
+double vidc_ctx_phase_ms(const vidc_ctx *ctx, int phase);
 
 #ifdef __cplusplus
 }

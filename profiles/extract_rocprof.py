@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Turn a rocprofv3 (rocpd sqlite) result database into a small per-kernel CSV summary.
+
+usage: python profiles/extract_rocprof.py gpurun_out/prof_xxx/name_results.db profiles/r01_xxx_kernel_stats.csv
+Durations are nanoseconds as reported by rocprofv3 --kernel-trace --stats (view `top_kernels`).
+"""
+import csv
+import sqlite3
+import sys
+
+
+def main(db_path, out_path):
+    db = sqlite3.connect(db_path)
+    cur = db.cursor()
+    rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    with open(out_path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ns", "avg_ns", "percent"])
+        for name, calls, tot, avg, pct in rows:
+            short = name if len(name) < 160 else name[:157] + "..."
+            w.writerow([short, calls, f"{tot:.0f}", f"{avg:.0f}", f"{pct:.4f}"])
+    print(f"wrote {out_path} ({len(rows)} kernels)")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

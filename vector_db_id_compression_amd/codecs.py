@@ -163,3 +163,136 @@ class RocLists:
     @property
     def last_decode_nonclean(self):
         return int(lib().vidc_roc_last_decode_nonclean(self.h))
+
+
+class PackedLists:
+    """Fixed-width packed ids (vidc_packed): ceil(log2(ntotal+1)) bits per id, LSB-first."""
+
+    def __init__(self, handle, ctx, offsets):
+        self.h = handle
+        self.ctx = ctx
+        self.offsets = offsets
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().vidc_packed_destroy(self.h)
+            self.h = None
+
+    @staticmethod
+    def bits_for(ntotal):
+        return int(lib().vidc_packed_bits_for(int(ntotal)))
+
+    @classmethod
+    def encode(cls, offsets, ids, bits=None, ctx=None):
+        ctx = ctx or _lib.default_context()
+        off = _as_offsets(offsets)
+        ntotal = int(off[-1])
+        if bits is None:
+            bits = cls.bits_for(ntotal)
+        d_ids = _dev_ids(ids, ntotal) if ntotal else None
+        h = C.c_void_p()
+        check(lib().vidc_packed_encode(ctx.h, off.size - 1, ptr(off), ptr(d_ids), int(bits), C.byref(h)))
+        return cls(h, ctx, off)
+
+    @property
+    def ntotal(self):
+        return int(self.offsets[-1])
+
+    @property
+    def bits(self):
+        return int(lib().vidc_packed_bits(self.h))
+
+    @property
+    def compressed_bytes(self):
+        return int(lib().vidc_packed_compressed_bytes(self.h))
+
+    def decode_all(self, out=None):
+        torch = _torch()
+        if out is None:
+            out = torch.empty(max(self.ntotal, 1), dtype=torch.int64, device="cuda")
+        check(lib().vidc_packed_decode_all(self.ctx.h, self.h, ptr(out)))
+        return out[: self.ntotal]
+
+    def get(self, list_nos, offs):
+        ln = np.ascontiguousarray(list_nos, dtype=np.uint64)
+        of = np.ascontiguousarray(offs, dtype=np.uint64)
+        out = np.zeros(max(ln.size, 1), np.int64)
+        check(lib().vidc_packed_get(self.ctx.h, self.h, ln.size, ptr(ln), ptr(of), ptr(out)))
+        return out[: ln.size]
+
+    def export_bytes(self, list_no):
+        n = int(self.offsets[list_no + 1] - self.offsets[list_no])
+        nb = (n * self.bits + 7) // 8
+        buf = np.zeros(max(nb, 1), np.uint8)
+        check(lib().vidc_packed_export(self.ctx.h, self.h, list_no, ptr(buf), nb))
+        return buf[:nb]
+
+
+class EfLists:
+    """Elias-Fano coded lists (vidc_ef), succinct::elias_fano geometry."""
+
+    def __init__(self, handle, ctx, offsets):
+        self.h = handle
+        self.ctx = ctx
+        self.offsets = offsets
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().vidc_ef_destroy(self.h)
+            self.h = None
+
+    @classmethod
+    def encode(cls, offsets, ids, want_perm=False, ctx=None):
+        ctx = ctx or _lib.default_context()
+        off = _as_offsets(offsets)
+        ntotal = int(off[-1])
+        d_ids = _dev_ids(ids, ntotal) if ntotal else None
+        h = C.c_void_p()
+        check(lib().vidc_ef_encode(ctx.h, off.size - 1, ptr(off), ptr(d_ids),
+                                   _lib.VIDC_EF_WANT_PERM if want_perm else 0, C.byref(h)))
+        return cls(h, ctx, off)
+
+    @property
+    def ntotal(self):
+        return int(self.offsets[-1])
+
+    @property
+    def compressed_bytes(self):
+        return int(lib().vidc_ef_compressed_bytes(self.h))
+
+    def info(self):
+        n = self.offsets.size - 1
+        sizes = np.zeros(max(n, 1), np.uint32)
+        lb = np.zeros(max(n, 1), np.uint32)
+        uni = np.zeros(max(n, 1), np.uint64)
+        check(lib().vidc_ef_list_info(self.h, ptr(sizes), ptr(lb), ptr(uni)))
+        return dict(sizes=sizes[:n], low_bits=lb[:n], universe=uni[:n])
+
+    def decode_all(self, out=None):
+        torch = _torch()
+        if out is None:
+            out = torch.empty(max(self.ntotal, 1), dtype=torch.int64, device="cuda")
+        check(lib().vidc_ef_decode_all(self.ctx.h, self.h, ptr(out)))
+        return out[: self.ntotal]
+
+    def get(self, list_nos, offs):
+        ln = np.ascontiguousarray(list_nos, dtype=np.uint64)
+        of = np.ascontiguousarray(offs, dtype=np.uint64)
+        out = np.zeros(max(ln.size, 1), np.int64)
+        check(lib().vidc_ef_get(self.ctx.h, self.h, ln.size, ptr(ln), ptr(of), ptr(out)))
+        return out[: ln.size]
+
+    def perm(self):
+        p = np.zeros(max(self.ntotal, 1), np.uint32)
+        check(lib().vidc_ef_perm(self.ctx.h, self.h, ptr(p)))
+        return p[: self.ntotal]
+
+    def export(self, list_no):
+        """-> (low words, high words, low_nbits, high_nbits) of one list."""
+        lb, hb = C.c_uint64(), C.c_uint64()
+        check(lib().vidc_ef_export(self.ctx.h, self.h, list_no, None, 0, None, 0, C.byref(lb), C.byref(hb)))
+        lw, hw = (lb.value + 63) // 64, (hb.value + 63) // 64
+        low = np.zeros(max(lw, 1), np.uint64)
+        high = np.zeros(max(hw, 1), np.uint64)
+        check(lib().vidc_ef_export(self.ctx.h, self.h, list_no, ptr(low), lw, ptr(high), hw, C.byref(lb), C.byref(hb)))
+        return low[:lw], high[:hw], int(lb.value), int(hb.value)

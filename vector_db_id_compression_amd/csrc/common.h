@@ -98,4 +98,5 @@ struct vidc_ctx {
     uint32_t *d_mt = nullptr;  // VIDC_MT_TABLE words
     int num_cu = 256;
     double last_kernel_ms = 0.0;
+    double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see VIDC_PHASE_* in vidc.h
 };

@@ -159,5 +159,8 @@ int vidc_copy_d2h(vidc_ctx *c, void *h, const void *d, size_t bytes) {
 }
 
 double vidc_ctx_last_kernel_ms(const vidc_ctx *c) { return c ? c->last_kernel_ms : 0.0; }
+double vidc_ctx_phase_ms(const vidc_ctx *c, int phase) {
+    return (c && phase >= 0 && phase < VIDC_PHASE_COUNT) ? c->phase_ms[phase] : 0.0;
+}
 
 }  // extern "C"

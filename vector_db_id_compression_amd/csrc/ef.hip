@@ -58,9 +58,10 @@ __global__ void __launch_bounds__(64) k_ef_prep(const uint64_t *ids, const uint6
             uint64_t w = ((uint64_t)hi << 32) | lo;
             mx = w > mx ? w : mx;
         }
+        const uint64_t any_uns = ballot(uns);  // all lanes vote (not inside the lane-0 branch)
         if (lane == 0) {
             outp[l].max_id = mx;
-            outp[l].unsorted = ballot(uns) ? 1u : 0u;
+            outp[l].unsorted = any_uns ? 1u : 0u;
         }
     }
 }

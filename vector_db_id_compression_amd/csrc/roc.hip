@@ -120,7 +120,9 @@ int finish_encode(vidc_ctx *ctx, vidc_roc *r, const uint32_t *d_arena, const uin
         hipLaunchKernelGGL(k_roc_compact, dim3(grid), dim3(256), 0, ctx->stream, d_arena, d_arena_off,
                            r->d_word_off.p, r->d_words.p, (uint32_t)nlist);
         VIDC_HIP(hipGetLastError());
-        kernel_ms += t.stop();
+        double ms = t.stop();
+        ctx->phase_ms[VIDC_PHASE_ROC_COMPACT] = ms;
+        kernel_ms += ms;
     }
     return VIDC_OK;
 }
@@ -282,6 +284,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         r->ntotal = r->offsets[nlist];
         VIDC_TRY(upload(ctx, r->d_offsets, r->offsets));
     }
+    ctx->phase_ms[VIDC_PHASE_ROC_ENCODE] = kernel_ms;
     VIDC_TRY(finish_encode(ctx, r.get(), s_arena.as<uint32_t>(), s_arena_off.as<uint64_t>(), s_status, kernel_ms));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->last_kernel_ms = kernel_ms;
@@ -382,6 +385,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     VIDC_TRY(launch(p.n_tiny, p.n_small, 1));
     VIDC_TRY(launch(0, p.n_tiny, 0));
     ctx->last_kernel_ms = t.stop();
+    ctx->phase_ms[VIDC_PHASE_ROC_DECODE] = ctx->last_kernel_ms;
 
     std::vector<uint32_t> status(r->nlist), endst(r->nlist);
     VIDC_HIP(hipMemcpyAsync(status.data(), s_status.p, r->nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
