@@ -2,7 +2,7 @@
 """Turn a rocprofv3 (rocpd sqlite) result database into a small per-kernel CSV summary.
 
 usage: python profiles/extract_rocprof.py gpurun_out/prof_xxx/name_results.db profiles/r01_xxx_kernel_stats.csv
-Durations are nanoseconds as reported by rocprofv3 --kernel-trace --stats (view `top_kernels`).
+Durations are MICROSECONDS as stored by rocprofv3 --kernel-trace --stats (view `top_kernels`).
 """
 import csv
 import sqlite3
@@ -15,10 +15,10 @@ def main(db_path, out_path):
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     with open(out_path, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "calls", "total_ns", "avg_ns", "percent"])
+        w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
         for name, calls, tot, avg, pct in rows:
             short = name if len(name) < 160 else name[:157] + "..."
-            w.writerow([short, calls, f"{tot:.0f}", f"{avg:.0f}", f"{pct:.4f}"])
+            w.writerow([short, calls, f"{tot:.1f}", f"{avg:.1f}", f"{pct:.4f}"])
     print(f"wrote {out_path} ({len(rows)} kernels)")
 
 

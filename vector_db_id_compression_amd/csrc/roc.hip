@@ -1,11 +1,13 @@
 // roc.hip -- host side of the ROC codec: scheduling of lists onto wavefronts, arenas, compaction,
 // and the vidc_roc_* C-ABI (include/vidc.h).
 #include <algorithm>
+#include <cstdlib>
 #include <memory>
 #include <numeric>
 
 #include "common.h"
 #include "roc_kernels.h"
+#include "roc_u.h"
 
 using namespace vidc;
 using namespace vidc::dev;
@@ -31,8 +33,23 @@ namespace {
 
 constexpr uint32_t TINY_MAX = 64;
 constexpr uint32_t GEN_SMALL_MAX = 1024;   // decoder: fb <= 7 -> 512 B of LDS
+// Lists longer than this go to the bitmap kernels (one wave per CU, lowest step latency: they are the critical
+// path); shorter ones cost about the same per step in the general kernels, which keep thousands in flight.
+constexpr uint32_t U_MIN_LIST = 4097;
 
 inline uint64_t arena_words_for(uint64_t n) { return n * 35 / 32 + 8; }  // <= P+4 bits per step, P <= 31
+
+// test hook: VIDC_FORCE_GENERAL=1 routes every list through the general (sorted-position / bucket) kernels
+inline bool force_general() {
+    const char *e = getenv("VIDC_FORCE_GENERAL");
+    return e && e[0] == '1';
+}
+
+// kernels that ask for more than 64 KiB of dynamic LDS must opt in
+inline int set_big_lds(const void *fn, size_t bytes) {
+    VIDC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return VIDC_OK;
+}
 
 template <typename T>
 int upload(vidc_ctx *ctx, DevBuf<T> &dst, const std::vector<T> &src) {
@@ -146,7 +163,15 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     double kernel_ms = 0;
 
     std::vector<uint64_t> arena_off(nlist + 1, 0);
-    std::vector<uint32_t> wl_tiny, wl_c1, wl_c2, wl_c3;
+    // work lists: tiny (n <= 64), universe-bitmap kernels (ids < 2^18 / 2^20), general kernels by bitmap depth
+    std::vector<uint32_t> wl_tiny, wl_u18, wl_u20, wl_c1, wl_c2, wl_c3;
+    const bool want_perm = (flags & VIDC_ROC_WANT_PERM) && !rows;
+    const uint64_t ntotal_in = rows ? N * K : (nlist ? offsets[nlist] : 0);
+    // persistent outputs
+    VIDC_TRY(r->d_heads.alloc(nlist)); VIDC_TRY(r->d_prec.alloc(nlist));
+    VIDC_TRY(r->d_nwords.alloc(nlist)); VIDC_TRY(r->d_draws.alloc(nlist));
+    if (want_perm) VIDC_TRY(r->d_perm.alloc(ntotal_in ? ntotal_in : 1));
+    Scratch s_arena, s_arena_off, s_status, s_sizes, s_sid, s_wl, s_maxid, s_flags;
     if (rows) {
         if (K == 0 || K > TINY_MAX) {
             set_error("graph rows: K=%u unsupported (1..64)", K);
@@ -155,9 +180,11 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         for (uint64_t l = 0; l < nlist; l++) arena_off[l + 1] = arena_off[l] + arena_words_for(K);
         wl_tiny.resize(nlist);
         std::iota(wl_tiny.begin(), wl_tiny.end(), 0u);
+        VIDC_TRY(s_sizes.get(ctx, nlist * 4));
     } else {
         if (!offsets) return VIDC_ERR_INVALID;
         r->offsets.assign(offsets, offsets + nlist + 1);
+        bool any_big = false;
         for (uint64_t l = 0; l < nlist; l++) {
             if (offsets[l + 1] < offsets[l]) { set_error("offsets not monotone at list %llu", (unsigned long long)l); return VIDC_ERR_INVALID; }
             uint64_t n = offsets[l + 1] - offsets[l];
@@ -168,37 +195,59 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 return VIDC_ERR_DOMAIN;
             }
             arena_off[l + 1] = arena_off[l] + arena_words_for(n);
-            if (n <= TINY_MAX) wl_tiny.push_back((uint32_t)l);
+            any_big |= n > TINY_MAX;
+        }
+        r->ntotal = offsets[nlist];
+        VIDC_TRY(upload(ctx, r->d_offsets, r->offsets));
+        // classification prepass (one wavefront per list): max id -> precision, sortedness, domain
+        std::vector<uint32_t> maxid(nlist, 0), pflags(nlist, 0);
+        if (any_big) {
+            VIDC_TRY(s_maxid.get(ctx, nlist * 4));
+            VIDC_TRY(s_flags.get(ctx, nlist * 4));
+            EventTimer t(ctx);
+            hipLaunchKernelGGL(k_roc_prepass, dim3((uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 64)),
+                               dim3(64), 0, ctx->stream, d_ids, r->d_offsets.p, (uint32_t)nlist, precision_mode,
+                               s_maxid.as<uint32_t>(), s_flags.as<uint32_t>(), r->d_prec.p);
+            VIDC_HIP(hipGetLastError());
+            kernel_ms += t.stop();
+            VIDC_HIP(hipMemcpyAsync(maxid.data(), s_maxid.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+            VIDC_HIP(hipMemcpyAsync(pflags.data(), s_flags.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+            VIDC_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        // The bitmap kernels own a whole CU's LDS (2^20-bit universe): latency-optimal for long lists, but only
+        // num_cu lists in flight.  With many lists, short ones go to the high-occupancy general kernels.
+        const uint64_t u_min = U_MIN_LIST;
+        for (uint64_t l = 0; l < nlist; l++) {
+            uint64_t n = offsets[l + 1] - offsets[l];
+            if (n <= TINY_MAX) { wl_tiny.push_back((uint32_t)l); continue; }
+            if (pflags[l] & VIDC_PF_DOMAIN) {
+                set_error("roc encode: list %llu holds an id outside [0, 2^31) (reference: int max_id, "
+                          "custom_invlists_impl.cpp:163)", (unsigned long long)l);
+                return VIDC_ERR_DOMAIN;
+            }
+            uint32_t width = maxid[l] ? 32u - (uint32_t)__builtin_clz(maxid[l]) : 0u;  // ids < 2^width
+            // the bitmap kernels need no sort; they cannot report input positions of an unsorted list
+            bool u_ok = !force_general() && !((pflags[l] & VIDC_PF_UNSORTED) && want_perm) &&
+                        (n >= u_min || (pflags[l] & VIDC_PF_UNSORTED));
+            if (u_ok && width <= 18) wl_u18.push_back((uint32_t)l);
+            else if (u_ok && width <= 20) wl_u20.push_back((uint32_t)l);
             else if (n <= 4096) wl_c1.push_back((uint32_t)l);
             else if (n <= 32768) wl_c2.push_back((uint32_t)l);
             else wl_c3.push_back((uint32_t)l);
         }
-        r->ntotal = offsets[nlist];
-        sort_desc(wl_c1, r->offsets); sort_desc(wl_c2, r->offsets); sort_desc(wl_c3, r->offsets);
+        for (auto *w : {&wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3}) sort_desc(*w, r->offsets);
+        if (!wl_c1.empty() || !wl_c2.empty() || !wl_c3.empty()) VIDC_TRY(s_sid.get(ctx, ntotal_in * 4));
     }
-    const uint64_t ntotal_in = rows ? N * K : r->ntotal;
-
-    // persistent outputs
-    VIDC_TRY(r->d_heads.alloc(nlist)); VIDC_TRY(r->d_prec.alloc(nlist));
-    VIDC_TRY(r->d_nwords.alloc(nlist)); VIDC_TRY(r->d_draws.alloc(nlist));
-    const bool want_perm = (flags & VIDC_ROC_WANT_PERM) && !rows;
-    if (want_perm) VIDC_TRY(r->d_perm.alloc(ntotal_in ? ntotal_in : 1));
-    // scratch
-    Scratch s_arena, s_arena_off, s_off, s_status, s_sizes, s_sid, s_wl;
     VIDC_TRY(s_arena.get(ctx, arena_off[nlist] * 4));
     VIDC_TRY(upload_scratch(ctx, s_arena_off, arena_off));
     VIDC_TRY(s_status.get(ctx, nlist * 4));
     if (nlist) VIDC_HIP(hipMemsetAsync(s_status.p, 0xff, nlist * 4, ctx->stream));
-    if (rows) VIDC_TRY(s_sizes.get(ctx, nlist * 4));
-    else {
-        VIDC_TRY(upload(ctx, r->d_offsets, r->offsets));
-        if (!wl_c1.empty() || !wl_c2.empty() || !wl_c3.empty()) VIDC_TRY(s_sid.get(ctx, ntotal_in * 4));
-    }
     std::vector<uint32_t> wl_all;
-    wl_all.insert(wl_all.end(), wl_tiny.begin(), wl_tiny.end());
-    wl_all.insert(wl_all.end(), wl_c1.begin(), wl_c1.end());
-    wl_all.insert(wl_all.end(), wl_c2.begin(), wl_c2.end());
-    wl_all.insert(wl_all.end(), wl_c3.begin(), wl_c3.end());
+    std::vector<size_t> base;
+    for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3}) {
+        base.push_back(wl_all.size());
+        wl_all.insert(wl_all.end(), w->begin(), w->end());
+    }
     VIDC_TRY(upload_scratch(ctx, s_wl, wl_all));
 
     RocEncArgs a{};
@@ -225,6 +274,26 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     {
         EventTimer t(ctx);
         const uint32_t *d_wl = s_wl.as<uint32_t>();
+        // longest lists first: they are the critical path
+        if (!wl_u20.empty()) {
+            RocEncArgs b = a;
+            b.worklist = d_wl + base[2]; b.nwork = (uint32_t)wl_u20.size();
+            VIDC_TRY(set_big_lds((const void *)k_roc_encode_u<20, false>, UGeom<20>::LDS_BYTES));
+            VIDC_TRY(set_big_lds((const void *)k_roc_encode_u<20, true>, UGeom<20>::LDS_BYTES));
+            if (want_perm) hipLaunchKernelGGL((k_roc_encode_u<20, true>), dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, ctx->stream, b);
+            else hipLaunchKernelGGL((k_roc_encode_u<20, false>), dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, ctx->stream, b);
+            VIDC_HIP(hipGetLastError());
+        }
+        VIDC_TRY(launch_gen(d_wl + base[5], (uint32_t)wl_c3.size(), 64));
+        VIDC_TRY(launch_gen(d_wl + base[4], (uint32_t)wl_c2.size(), 8));
+        if (!wl_u18.empty()) {
+            RocEncArgs b = a;
+            b.worklist = d_wl + base[1]; b.nwork = (uint32_t)wl_u18.size();
+            if (want_perm) hipLaunchKernelGGL((k_roc_encode_u<18, true>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->stream, b);
+            else hipLaunchKernelGGL((k_roc_encode_u<18, false>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->stream, b);
+            VIDC_HIP(hipGetLastError());
+        }
+        VIDC_TRY(launch_gen(d_wl + base[3], (uint32_t)wl_c1.size(), 1));
         if (!wl_tiny.empty()) {
             RocEncArgs b = a;
             b.worklist = d_wl; b.nwork = (uint32_t)wl_tiny.size();
@@ -232,20 +301,16 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             else hipLaunchKernelGGL(k_roc_encode_tiny<false>, dim3(b.nwork), dim3(64), 0, ctx->stream, b);
             VIDC_HIP(hipGetLastError());
         }
-        // longest lists first: they are the critical path
-        size_t base3 = wl_tiny.size() + wl_c1.size() + wl_c2.size();
-        VIDC_TRY(launch_gen(d_wl + base3, (uint32_t)wl_c3.size(), 64));
-        VIDC_TRY(launch_gen(d_wl + wl_tiny.size() + wl_c1.size(), (uint32_t)wl_c2.size(), 8));
-        VIDC_TRY(launch_gen(d_wl + wl_tiny.size(), (uint32_t)wl_c1.size(), 1));
         kernel_ms += t.stop();
     }
 
-    // unsorted lists: second pass with sort scratch (Faiss lists are in add order, i.e. normally sorted)
+    // second pass for lists the first pass handed back: unsorted input of the general kernels (Faiss
+    // lists are in add order, i.e. normally sorted) and multiset input of the bitmap kernels
+    std::vector<uint32_t> pend;
     if (!rows && nlist) {
         std::vector<uint32_t> status(nlist);
         VIDC_HIP(hipMemcpyAsync(status.data(), s_status.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
         VIDC_HIP(hipStreamSynchronize(ctx->stream));
-        std::vector<uint32_t> pend;
         for (uint64_t l = 0; l < nlist; l++)
             if (status[l] == VIDC_ST_PENDING_SORT) pend.push_back((uint32_t)l);
         if (!pend.empty()) {
@@ -265,13 +330,32 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             VIDC_TRY(s_skey.get(ctx, skey_off[nlist] * 8));
             VIDC_TRY(upload_scratch(ctx, s_skey_off, skey_off));
             VIDC_TRY(s_spos.get(ctx, ntotal_in * 4));
+            if (!s_sid.p) VIDC_TRY(s_sid.get(ctx, ntotal_in * 4));
             VIDC_TRY(upload_scratch(ctx, s_pend, pend));
+            a.sid = s_sid.as<uint32_t>();
             a.skey = s_skey.as<uint64_t>(); a.skey_off = s_skey_off.as<uint64_t>(); a.spos = s_spos.as<uint32_t>();
             uint32_t rl_max = maxn <= 4096 ? 1 : (maxn <= 32768 ? 8 : 64);
             EventTimer t(ctx);
             VIDC_TRY(launch_gen(s_pend.as<uint32_t>(), (uint32_t)pend.size(), rl_max));
             kernel_ms += t.stop();
             VIDC_HIP(hipStreamSynchronize(ctx->stream));  // scratch of this scope is released below
+        }
+    }
+    // bitmap-kernel lists wrote sampled ids into the perm buffer: turn them into input positions
+    if (want_perm && (!wl_u18.empty() || !wl_u20.empty())) {
+        std::vector<uint8_t> is_p(nlist, 0);
+        for (uint32_t l : pend) is_p[l] = 1;
+        std::vector<uint32_t> ul;
+        for (uint32_t l : wl_u18) if (!is_p[l]) ul.push_back(l);
+        for (uint32_t l : wl_u20) if (!is_p[l]) ul.push_back(l);
+        if (!ul.empty()) {
+            Scratch s_ul;
+            VIDC_TRY(upload_scratch(ctx, s_ul, ul));
+            EventTimer t(ctx);
+            hipLaunchKernelGGL(k_perm_from_order, dim3((uint32_t)ul.size()), dim3(256), 0, ctx->stream, d_ids,
+                               r->d_offsets.p, s_ul.as<uint32_t>(), (uint32_t)ul.size(), r->d_perm.p);
+            VIDC_HIP(hipGetLastError());
+            kernel_ms += t.stop();
         }
     }
     if (rows) {
@@ -292,41 +376,61 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     return VIDC_OK;
 }
 
-// ---- decode planning: per work item scratch offsets
+// ---- decode planning: work items grouped by kernel class, each with private scratch
+enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_GMID, DC_GHUGE, DC_COUNT };
+
 struct DecPlan {
-    std::vector<uint32_t> wl;           // tiny | small | big
-    size_t n_tiny = 0, n_small = 0, n_big = 0;
+    std::vector<uint32_t> wl;        // list numbers, grouped by class, longest first inside a class
+    std::vector<uint32_t> item;      // index of each work item in the caller's request
+    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0};
     std::vector<uint64_t> scratch_off, slots_off;
     uint64_t scratch_words = 0, slots_words = 0;
 };
 
-void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, DecPlan &p) {
-    std::vector<uint32_t> tiny, small, big;
-    for (uint32_t l : lists) {
-        uint64_t n = r->offsets[l + 1] - r->offsets[l];
-        if (n <= TINY_MAX) tiny.push_back(l);
-        else if (n <= GEN_SMALL_MAX) small.push_back(l);
-        else big.push_back(l);
+inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min) {
+    if (n <= TINY_MAX) return DC_TINY;
+    if (!force_general() && n >= u_min) {
+        if (P <= 18) return DC_U18;
+        if (P <= 20) return DC_U20;
     }
-    sort_desc(small, r->offsets);
-    sort_desc(big, r->offsets);
-    p.n_tiny = tiny.size(); p.n_small = small.size(); p.n_big = big.size();
-    p.wl.clear();
-    p.wl.insert(p.wl.end(), tiny.begin(), tiny.end());
-    p.wl.insert(p.wl.end(), small.begin(), small.end());
-    p.wl.insert(p.wl.end(), big.begin(), big.end());
+    if (n <= GEN_SMALL_MAX) return DC_GSMALL;
+    if (n <= 32768) return DC_GMID;
+    return DC_GHUGE;
+}
+
+// lists[i] = list number of request item i (a list may appear more than once)
+void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool rows_flavour, DecPlan &p) {
+    std::vector<uint32_t> cls[DC_COUNT];
+    const uint64_t u_min = U_MIN_LIST;
+    for (uint32_t i = 0; i < lists.size(); i++) {
+        uint32_t l = lists[i];
+        uint64_t n = r->offsets[l + 1] - r->offsets[l];
+        cls[rows_flavour ? DC_TINY : dec_class(n, r->prec[l], u_min)].push_back(i);
+    }
+    auto len = [&](uint32_t i) { return r->offsets[lists[i] + 1] - r->offsets[lists[i]]; };
+    p.wl.clear(); p.item.clear();
+    for (int c = 0; c < DC_COUNT; c++) {
+        if (c != DC_TINY)
+            std::stable_sort(cls[c].begin(), cls[c].end(), [&](uint32_t x, uint32_t y) { return len(x) > len(y); });
+        p.count[c] = cls[c].size();
+        for (uint32_t i : cls[c]) { p.item.push_back(i); p.wl.push_back(lists[i]); }
+    }
     p.scratch_off.resize(p.wl.size());
     p.slots_off.resize(p.wl.size());
     uint64_t so = 0, sl = 0;
-    for (size_t i = 0; i < p.wl.size(); i++) {
-        uint32_t l = p.wl[i];
-        uint64_t n = r->offsets[l + 1] - r->offsets[l];
-        p.scratch_off[i] = so;
-        so += (uint64_t)r->nwords[l] + 64;
-        p.slots_off[i] = sl;
-        if (n > TINY_MAX) {
-            uint32_t fb = roc_dec_fine_bits((uint32_t)n, r->prec[l] > 32 ? 32 : r->prec[l]);
-            sl += ((uint64_t)1 << fb) * VIDC_DEC_CAP + n;
+    size_t k = 0;
+    for (int c = 0; c < DC_COUNT; c++) {
+        for (size_t j = 0; j < p.count[c]; j++, k++) {
+            uint32_t l = p.wl[k];
+            uint64_t n = r->offsets[l + 1] - r->offsets[l];
+            p.scratch_off[k] = so;
+            so += (uint64_t)r->nwords[l] + 64;
+            p.slots_off[k] = sl;
+            if (c == DC_U18 || c == DC_U20) sl += n;  // duplicate side list
+            else if (c >= DC_GSMALL) {
+                uint32_t fb = roc_dec_fine_bits((uint32_t)n, r->prec[l] > 32 ? 32 : r->prec[l]);
+                sl += ((uint64_t)1 << fb) * roc_dec_cap((uint32_t)n) + n;
+            }
         }
     }
     p.scratch_words = so;
@@ -362,28 +466,48 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     a.end_state = s_end.as<uint32_t>(); a.status = s_status.as<uint32_t>();
     a.mt = ctx->d_mt;
 
+    size_t base[DC_COUNT];
+    {
+        size_t acc = 0;
+        for (int c = 0; c < DC_COUNT; c++) { base[c] = acc; acc += p.count[c]; }
+    }
     EventTimer t(ctx);
-    auto launch = [&](size_t base, size_t count, int kind) -> int {
-        if (!count) return VIDC_OK;
+    auto launch = [&](int c) -> int {
+        if (!p.count[c]) return VIDC_OK;
         RocDecArgs b = a;
-        b.worklist = s_wl.as<uint32_t>() + base;
-        b.nwork = (uint32_t)count;
-        b.out_off = out_off_host ? s_out_off.as<uint64_t>() + base : nullptr;
-        b.scratch_off = s_scr_off.as<uint64_t>() + base;
-        b.slots_off = s_slots_off.as<uint64_t>() + base;
-        if (kind == 0) {
-            if (d_out_rows) hipLaunchKernelGGL(k_roc_decode_tiny<true>, dim3(b.nwork), dim3(64), 0, ctx->stream, b);
-            else hipLaunchKernelGGL(k_roc_decode_tiny<false>, dim3(b.nwork), dim3(64), 0, ctx->stream, b);
-        } else {
-            uint32_t entries = kind == 1 ? 128u : (1u << VIDC_DEC_MAX_FB);
-            hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), entries * 4, ctx->stream, b, entries);
+        b.worklist = s_wl.as<uint32_t>() + base[c];
+        b.nwork = (uint32_t)p.count[c];
+        b.out_off = out_off_host ? s_out_off.as<uint64_t>() + base[c] : nullptr;
+        b.scratch_off = s_scr_off.as<uint64_t>() + base[c];
+        b.slots_off = s_slots_off.as<uint64_t>() + base[c];
+        switch (c) {
+            case DC_TINY:
+                if (d_out_rows) hipLaunchKernelGGL(k_roc_decode_tiny<true>, dim3(b.nwork), dim3(64), 0, ctx->stream, b);
+                else hipLaunchKernelGGL(k_roc_decode_tiny<false>, dim3(b.nwork), dim3(64), 0, ctx->stream, b);
+                break;
+            case DC_U18:
+                hipLaunchKernelGGL(k_roc_decode_u<18>, dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->stream, b);
+                break;
+            case DC_U20:
+                VIDC_TRY(set_big_lds((const void *)k_roc_decode_u<20>, UGeom<20>::LDS_BYTES));
+                hipLaunchKernelGGL(k_roc_decode_u<20>, dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, ctx->stream, b);
+                break;
+            case DC_GSMALL:
+                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), 128 * 4, ctx->stream, b, 128u, VIDC_DEC_CAP);
+                break;
+            case DC_GMID:
+                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), (1u << VIDC_DEC_MAX_FB) * 4, ctx->stream, b,
+                                   1u << VIDC_DEC_MAX_FB, VIDC_DEC_CAP);
+                break;
+            default:
+                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), (1u << VIDC_DEC_MAX_FB) * 4, ctx->stream, b,
+                                   1u << VIDC_DEC_MAX_FB, VIDC_DEC_CAP_BIG);
         }
         VIDC_HIP(hipGetLastError());
         return VIDC_OK;
     };
-    VIDC_TRY(launch(p.n_tiny + p.n_small, p.n_big, 2));  // longest first
-    VIDC_TRY(launch(p.n_tiny, p.n_small, 1));
-    VIDC_TRY(launch(0, p.n_tiny, 0));
+    // longest chains first
+    for (int c : {DC_GHUGE, DC_U20, DC_GMID, DC_U18, DC_GSMALL, DC_TINY}) VIDC_TRY(launch(c));
     ctx->last_kernel_ms = t.stop();
     ctx->phase_ms[VIDC_PHASE_ROC_DECODE] = ctx->last_kernel_ms;
 
@@ -492,7 +616,7 @@ int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out) {
     std::vector<uint32_t> all(r->nlist);
     std::iota(all.begin(), all.end(), 0u);
     DecPlan p;
-    plan_decode(r, all, p);
+    plan_decode(r, all, false, p);
     return decode_impl(ctx, r, p, nullptr, d_out, nullptr, 0);
 }
 
@@ -507,41 +631,10 @@ int vidc_roc_decode_lists(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const ui
         req_off[i + 1] = req_off[i] + (r->offsets[lists[i] + 1] - r->offsets[lists[i]]);
     }
     std::memcpy(out_offsets, req_off.data(), (m + 1) * 8);
-    // the plan re-orders work items by size: map each item back to its slot in the request.
-    // (a list requested twice is decoded twice)
-    std::vector<uint32_t> item(m);
-    std::iota(item.begin(), item.end(), 0u);
     DecPlan p;
-    {
-        // plan over request indices: build a temporary roc-like view through index indirection
-        std::vector<uint32_t> tiny, small, big;
-        auto len = [&](uint32_t i) { return r->offsets[lists[i] + 1] - r->offsets[lists[i]]; };
-        for (uint32_t i = 0; i < m; i++) {
-            uint64_t n = len(i);
-            if (n <= TINY_MAX) tiny.push_back(i); else if (n <= GEN_SMALL_MAX) small.push_back(i); else big.push_back(i);
-        }
-        auto by_len = [&](uint32_t x, uint32_t y) { return len(x) > len(y); };
-        std::stable_sort(small.begin(), small.end(), by_len);
-        std::stable_sort(big.begin(), big.end(), by_len);
-        item.clear();
-        item.insert(item.end(), tiny.begin(), tiny.end());
-        item.insert(item.end(), small.begin(), small.end());
-        item.insert(item.end(), big.begin(), big.end());
-        p.n_tiny = tiny.size(); p.n_small = small.size(); p.n_big = big.size();
-        p.wl.resize(m); p.scratch_off.resize(m); p.slots_off.resize(m);
-        uint64_t so = 0, sl = 0;
-        for (size_t k = 0; k < m; k++) {
-            uint32_t l = lists[item[k]];
-            uint64_t n = r->offsets[l + 1] - r->offsets[l];
-            p.wl[k] = l;
-            p.scratch_off[k] = so; so += (uint64_t)r->nwords[l] + 64;
-            p.slots_off[k] = sl;
-            if (n > TINY_MAX) sl += ((uint64_t)1 << roc_dec_fine_bits((uint32_t)n, r->prec[l] > 32 ? 32 : r->prec[l])) * VIDC_DEC_CAP + n;
-        }
-        p.scratch_words = so; p.slots_words = sl;
-    }
+    plan_decode(r, lists, false, p);
     std::vector<uint64_t> out_off(m);
-    for (size_t k = 0; k < m; k++) out_off[k] = req_off[item[k]];
+    for (size_t k = 0; k < m; k++) out_off[k] = req_off[p.item[k]];  // work item k -> its slot in the request
     return decode_impl(ctx, r, p, out_off.data(), d_out, nullptr, 0);
 }
 
@@ -549,21 +642,18 @@ int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uin
                          int32_t *d_out, uint32_t *counts) {
     if (!ctx || !r || (m && (!nodes || !d_out))) return VIDC_ERR_INVALID;
     if (K == 0 || K > TINY_MAX) { set_error("K=%u unsupported", K); return VIDC_ERR_UNSUPPORTED; }
-    DecPlan p;
-    p.wl.resize(m); p.scratch_off.resize(m); p.slots_off.assign(m, 0);
-    std::vector<uint64_t> out_off(m);
-    uint64_t so = 0;
+    std::vector<uint32_t> lists(m);
     for (uint64_t i = 0; i < m; i++) {
         if (nodes[i] >= r->nlist) { set_error("node %llu out of range", (unsigned long long)nodes[i]); return VIDC_ERR_INVALID; }
-        uint32_t l = (uint32_t)nodes[i];
-        uint64_t n = r->offsets[l + 1] - r->offsets[l];
-        if (n > K) { set_error("node %u has %llu edges > K=%u", l, (unsigned long long)n, K); return VIDC_ERR_INVALID; }
+        lists[i] = (uint32_t)nodes[i];
+        uint64_t n = r->offsets[lists[i] + 1] - r->offsets[lists[i]];
+        if (n > K) { set_error("node %u has %llu edges > K=%u", lists[i], (unsigned long long)n, K); return VIDC_ERR_INVALID; }
         if (counts) counts[i] = (uint32_t)n;
-        p.wl[i] = l;
-        p.scratch_off[i] = so; so += (uint64_t)r->nwords[l] + 64;
-        out_off[i] = i * K;
     }
-    p.n_tiny = m; p.scratch_words = so; p.slots_words = 0;
+    DecPlan p;
+    plan_decode(r, lists, true, p);
+    std::vector<uint64_t> out_off(m);
+    for (size_t k = 0; k < m; k++) out_off[k] = (uint64_t)p.item[k] * K;
     return decode_impl(ctx, r, p, out_off.data(), nullptr, d_out, K);
 }
 

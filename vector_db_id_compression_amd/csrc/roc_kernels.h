@@ -77,7 +77,9 @@ struct RocDecArgs {
     const uint32_t *mt;
 };
 
-#define VIDC_DEC_CAP 16u       // members per fine bucket before spilling to the overflow list
+#define VIDC_DEC_CAP 16u       // members per fine bucket before spilling to the overflow list (lists <= 32768)
+#define VIDC_DEC_CAP_BIG 64u   // same for longer lists (average bucket load up to 64)
+__host__ __device__ inline uint32_t roc_dec_cap(uint32_t n) { return n > 32768u ? VIDC_DEC_CAP_BIG : VIDC_DEC_CAP; }
 #define VIDC_DEC_MAX_FB 12u    // <= 64 coarse x 64 fine buckets
 
 // fine-bucket bits used by the decoder for a list of n elements with precision P (host + device)
@@ -180,6 +182,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_tiny(RocEncArgs a) {
         recip_block(rc, n);
         uint32_t pbuf = 0;
         for (uint32_t i = 0; i < n; i++) {
+            ws_prepare(st);
             const uint32_t nmax = n - i;
             const uint64_t magic = rl64(rc.m_lo, rc.m_hi, i);
             const uint32_t k = ans_idx_pop(head, st, nmax, rl(rc.thr, i), magic);
@@ -234,6 +237,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny(RocDecArgs a) {
         }
         uint32_t val = 0xffffffffu;  // lane i holds the element decoded at step i
         for (uint32_t i = 0; i < n; i++) {
+            ws_prepare(st);
             const uint32_t x = ans_id_pop(head, st, p0, p1);
             const uint32_t r = popc64(ballot(lane < i && val < x));  // strictly smaller (fenwick_tree.h:42-94)
             ans_idx_push(head, st, r, i + 1u, rl(rc.lq, i));
@@ -362,6 +366,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
         const uint32_t *sid = a.sid + off;
         const uint32_t *spos = a.spos + off;
         for (uint32_t i = 0; i < n; i++) {
+            ws_prepare(st);
             const uint32_t t64 = i & 63u;
             if (t64 == 0) recip_block(rc, n - i);
             const uint32_t nmax = n - i;
@@ -412,7 +417,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
 }
 
 // LDS layout (dynamic): u32 rowpref[2^fb_max]
-__global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t lds_entries) {
+__global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t lds_entries, uint32_t cap) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *rowpref = (uint32_t *)smem;
     const uint32_t lane = lane_id();
@@ -444,13 +449,14 @@ __global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t ld
         for (uint32_t t = lane; t < NF && t < lds_entries; t += 64) rowpref[t] = 0;
         uint32_t C1 = 0;  // lane c: decoded elements in coarse buckets 0..c
         uint32_t *slots = a.slots + a.slots_off[wi];
-        uint32_t *ovf = slots + (size_t)NF * VIDC_DEC_CAP;
+        uint32_t *ovf = slots + (size_t)NF * cap;
         uint32_t novf = 0, novf_vis = 0;
         uint32_t ring = 0;  // lane t: element decoded at step (block start + t)
         Recip rc;
         wave_sync();
 
         for (uint32_t i = 0; i < n; i++) {
+            ws_prepare(st);
             const uint32_t t64 = i & 63u;
             if (t64 == 0) {
                 // new 64-step block: earlier slot / overflow stores become visible to loads
@@ -478,11 +484,11 @@ __global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t ld
             const bool ring_same = ring_valid && ((s >= 32u ? 0u : (ring >> s)) == f);
             const uint32_t in_ring = popc64(ballot(ring_same));
             const uint32_t cnt_vis = cnt - in_ring;
-            const uint32_t m = cnt_vis < VIDC_DEC_CAP ? cnt_vis : VIDC_DEC_CAP;
+            const uint32_t m = cnt_vis < cap ? cnt_vis : cap;
             uint32_t y = 0xffffffffu;
-            if (lane < m) y = slots[(size_t)f * VIDC_DEC_CAP + lane];
+            if (lane < m) y = slots[(size_t)f * cap + lane];
             uint32_t within = popc64(ballot(lane < m && y < x));
-            if (cnt_vis > VIDC_DEC_CAP) {  // skewed data: members that did not fit the row
+            if (cnt_vis > cap) {  // skewed data: members that did not fit the row
                 for (uint32_t j0 = 0; j0 < novf_vis; j0 += 64) {
                     uint32_t jj = j0 + lane;
                     uint32_t z = jj < novf_vis ? ovf[jj] : 0xffffffffu;
@@ -495,8 +501,8 @@ __global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t ld
             const uint32_t r = base1 + base2 + within;
             ans_idx_push(head, st, r, i + 1u, rl(rc.lq, t64));
             // insert x
-            if (cnt < VIDC_DEC_CAP) {
-                if (lane == 0) slots[(size_t)f * VIDC_DEC_CAP + cnt] = x;
+            if (cnt < cap) {
+                if (lane == 0) slots[(size_t)f * cap + cnt] = x;
             } else {
                 if (lane == 0) ovf[novf] = x;
                 novf++;

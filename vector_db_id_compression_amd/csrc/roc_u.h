@@ -1,0 +1,314 @@
+// roc_u.h -- "universe bitmap" ROC kernels: the latency-optimised path for ids below 2^UB (UB <= 20),
+// i.e. every 1M-vector configuration of the reference's benchmarks (bench_invlists.py on sift1M /
+// deep1M: ids < 10^6 < 2^20).
+//
+// One list per wavefront.  The order-statistic structure over the set is a three-level counting
+// hierarchy over a 2^UB-bit membership bitmap:
+//     level 1   64 per-lane inclusive prefix counters in ONE VGPR          (ballot + s_ff1 / v_readlane)
+//     level 2   64 rows x 64 inclusive prefix counters in 64 VGPRs, row c selected with a wave-uniform
+//               register index (s_set_gpr_idx / v_movrel), i.e. no memory access
+//     level 3   the bitmap words in LDS (2^UB / 8 bytes: 128 KiB for UB = 20, one wave per CU)
+// select(k) (encoder) and rank(x) (decoder) therefore cost ONE LDS round trip per codec step; no sort of
+// the input is needed (ids index the bitmap directly) and the id itself falls out of the select.
+// Duplicate ids cannot be represented: the encoder reports such a list back (it is then encoded by the
+// general kernels), the decoder keeps exact multiset semantics with a side list of duplicates.
+#pragma once
+#include "roc_kernels.h"
+
+namespace vidc {
+namespace dev {
+
+// Level-2 rows: 64 rows x 64 inclusive prefix counters, one counter per lane, TWO rows per VGPR (row c in the
+// low/high 16 bits of register c >> 1; a counter never exceeds 2^14).  32 VGPRs, indexed with a wave-uniform
+// register index (s_set_gpr_idx_on + v_mov): no memory access, no branches.
+typedef uint32_t v32u __attribute__((ext_vector_type(32)));
+__device__ __forceinline__ uint32_t rows_get(const v32u &r, uint32_t c) {
+    return (r[c >> 1] >> ((c & 1u) << 4)) & 0xffffu;
+}
+// per-lane add / subtract on row c; the caller guarantees the 16-bit counter neither overflows nor borrows
+__device__ __forceinline__ void rows_add(v32u &r, uint32_t c, uint32_t v16) { r[c >> 1] += v16 << ((c & 1u) << 4); }
+__device__ __forceinline__ void rows_sub(v32u &r, uint32_t c, uint32_t v16) { r[c >> 1] -= v16 << ((c & 1u) << 4); }
+
+template <int UB>
+struct UGeom {
+    static constexpr uint32_t NW = 1u << (UB - 6);           // 64-bit bitmap words
+    static constexpr uint32_t WPL = NW / 64u;                // words per level-1 block (per lane)
+    static constexpr uint32_t ENT = WPL < 64u ? WPL : 64u;   // level-2 entries per row
+    static constexpr uint32_t G = WPL / ENT;                 // bitmap words per level-2 entry (1 or 4)
+    static constexpr uint32_t LDS_BYTES = NW * 8u;
+    static_assert(UB >= 12 && UB <= 20, "universe bits");
+    static_assert(G == 1 || G == 4, "entry width");
+};
+
+// rows[c] lane t = number of set bits in entries 0..t of level-1 block c; P1 lane c = set bits in blocks 0..c
+template <int UB>
+__device__ __forceinline__ void u_build_counts(const uint64_t *bm, v32u &rows, uint32_t &P1) {
+    using U = UGeom<UB>;
+    const uint32_t lane = lane_id();
+    uint32_t running = 0;
+    P1 = 0;
+#pragma unroll
+    for (int c = 0; c < 32; c++) rows[c] = 0u;
+    for (uint32_t c = 0; c < 64; c++) {
+        uint32_t cnt = 0;
+        if (lane < U::ENT) {
+#pragma unroll
+            for (uint32_t g = 0; g < U::G; g++) cnt += popc64(bm[c * U::WPL + lane * U::G + g]);
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t v = (uint32_t)__shfl_up((int)cnt, o, 64);
+            if (lane >= (uint32_t)o) cnt += v;
+        }
+        rows_add(rows, c, lane < U::ENT ? cnt : 0xffffu);  // padding lanes never win a "> k" vote before a real one
+        running += rl(cnt, 63);
+        P1 = lane == c ? running : P1;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+template <int UB, bool WANT_ORDER>
+__global__ void __launch_bounds__(64) k_roc_encode_u(RocEncArgs a) {
+    using U = UGeom<UB>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *bm = (uint64_t *)smem;
+    uint32_t *bm32 = (uint32_t *)smem;
+    const uint32_t lane = lane_id();
+    const uint32_t wi = blockIdx.x;
+    if (wi >= a.nwork) return;
+    // per-list scalars are read with vector loads: pin them to SGPRs so the whole ANS chain stays scalar
+    const uint32_t l = rfl(a.worklist[wi]);
+    const uint64_t off = rfl64(a.offsets[l]);
+    const uint32_t n = rfl((uint32_t)(a.offsets[l + 1] - off));
+    // ---- membership bitmap
+    {
+        uint4 *z = (uint4 *)smem;
+        for (uint32_t w = lane; w < U::LDS_BYTES / 16u; w += 64) z[w] = make_uint4(0, 0, 0, 0);
+    }
+    wave_sync();
+    bool dup = false;
+    for (uint32_t j = lane; j < n; j += 64) {
+        const uint32_t x = (uint32_t)a.ids[off + j];  // < 2^UB: guaranteed by the host's classification
+        const uint32_t bit = 1u << (x & 31u);
+        const uint32_t old = atomicOr(&bm32[x >> 5], bit);
+        dup |= (old & bit) != 0;
+    }
+    wave_sync();
+    if (ballot(dup)) {  // multiset input: needs the sorted-position kernels
+        if (lane == 0) a.status[l] = VIDC_ST_PENDING_SORT;
+        return;
+    }
+    v32u rows;
+    uint32_t P1;
+    u_build_counts<UB>(bm, rows, P1);
+
+    const uint32_t P = rfl(a.prec[l]);  // written by the prepass
+    const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
+    WStack st;
+    {
+        const uint64_t ao = rfl64(a.arena_off[l]);
+        ws_init_empty(st, a.arena + ao, rfl((uint32_t)(a.arena_off[l + 1] - ao)), a.mt, VIDC_MT_TABLE);
+    }
+    uint64_t head = VIDC_RANS_L;
+    Recip rc;
+    uint32_t obuf = 0;
+    uint32_t *order = WANT_ORDER ? a.perm + off : nullptr;  // sampled ids; k_perm_from_order turns them into positions
+
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        recip_block(rc, n - i0);  // lane t owns the divisor of step i0 + t
+        const uint32_t steps = n - i0 < 64u ? n - i0 : 64u;
+        for (uint32_t t64 = 0; t64 < steps; t64++) {
+            ws_prepare(st);
+            uint32_t k = ans_idx_pop_v(head, st, n - i0 - t64, rl(rc.thr, t64), rc.m_lo, rc.m_hi, t64);
+            // level 1
+            const uint32_t c = ff1(ballot(P1 > k));
+            const uint32_t prev1 = rl(P1, (c - 1u) & 63u);
+            k -= c ? prev1 : 0u;
+            // level 2 (register row)
+            const uint32_t row = rows_get(rows, c);
+            const uint32_t t = ff1(ballot(row > k));
+            const uint32_t prev2 = rl(row, (t - 1u) & 63u);
+            k -= t ? prev2 : 0u;
+            uint32_t wb = c * U::WPL + t * U::G;
+            // level 3 (LDS words)
+            uint64_t W;
+            if (U::G == 1) {
+                W = rfl64(bm[wb]);
+            } else {
+                const uint64_t wv = bm[wb + (lane & 3u)];
+                const uint32_t pc = popc64(wv);
+                const uint32_t q0 = rl(pc, 0), q1 = q0 + rl(pc, 1), q2 = q1 + rl(pc, 2);
+                const bool g0 = k >= q0, g1 = k >= q1, g2 = k >= q2;  // monotone: g2 -> g1 -> g0
+                const uint32_t g = g2 ? 3u : (g1 ? 2u : (g0 ? 1u : 0u));
+                k -= g2 ? q2 : (g1 ? q1 : (g0 ? q0 : 0u));
+                W = rl64((uint32_t)wv, (uint32_t)(wv >> 32), g);
+                wb += g;
+            }
+            const uint32_t b = ff1(ballot(mbcnt(W) == k) & W);
+            const uint32_t x = (wb << 6) | b;
+            // remove x (every lane stores the same word: no exec-mask juggling)
+            P1 -= lane >= c ? 1u : 0u;
+            rows_sub(rows, c, (lane >= t && lane < U::ENT) ? 1u : 0u);  // those counters include x: no borrow
+            bm[wb] = W & ~(1ull << b);
+            ans_id_push(head, st, x, p0, p1);
+            if (WANT_ORDER) obuf = wl(x, t64, obuf);
+        }
+        if (WANT_ORDER) {
+            if (lane < steps) order[i0 + lane] = obuf;
+        }
+    }
+    ws_flush(st);
+    if (lane == 0) {
+        a.heads[l] = head;
+        a.nwords[l] = st.sp;
+        a.draws[l] = st.draws;
+        a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+template <int UB>
+__global__ void __launch_bounds__(64) k_roc_decode_u(RocDecArgs a) {
+    using U = UGeom<UB>;
+    constexpr uint32_t GSH = U::G == 4 ? 2u : 0u;
+    constexpr uint32_t ESH = 6u + GSH;                       // bits of x inside one level-2 entry
+    constexpr uint32_t ENT_SH = U::ENT == 64u ? 6u : (U::ENT == 16u ? 4u : (U::ENT == 32u ? 5u : 0u));
+    static_assert((1u << ENT_SH) == U::ENT, "entries per row must be 16, 32 or 64");
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *bm = (uint64_t *)smem;
+    const uint32_t lane = lane_id();
+    const uint32_t wi = blockIdx.x;
+    if (wi >= a.nwork) return;
+    const uint32_t l = rfl(a.worklist[wi]);
+    const uint32_t n = rfl((uint32_t)(a.offsets[l + 1] - a.offsets[l]));
+    const uint64_t ooff = rfl64(a.out_off ? a.out_off[wi] : a.offsets[l]);
+    {
+        uint4 *z = (uint4 *)smem;
+        for (uint32_t w = lane; w < U::LDS_BYTES / 16u; w += 64) z[w] = make_uint4(0, 0, 0, 0);
+    }
+    const uint32_t P = rfl(a.prec[l]);
+    const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
+    const uint32_t W0 = rfl(a.nwords[l]);
+    WStack st;
+    ws_init_loaded(st, a.words + rfl64(a.word_off[l]), W0, a.scratch_words + rfl64(a.scratch_off[wi]), W0 + 64u,
+                   rfl(a.draws[l]), a.mt, VIDC_MT_TABLE);
+    const uint32_t draws0 = st.draws;
+    uint64_t head = rfl64(a.heads[l]);
+    v32u rows;
+#pragma unroll
+    for (int c = 0; c < 32; c++) rows[c] = 0u;
+    uint32_t P1 = 0;
+    uint32_t *dups = a.slots + rfl64(a.slots_off[wi]);  // capacity n
+    uint32_t ndup = 0;
+    uint32_t ring = 0, lq = 0;
+    wave_sync();
+
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        lq = 0x80000000u / (i0 + 1u + lane);  // lane t owns floor(2^31 / nmax) of step i0 + t
+        const uint32_t steps = n - i0 < 64u ? n - i0 : 64u;
+        for (uint32_t t64 = 0; t64 < steps; t64++) {
+            ws_prepare(st);
+            const uint32_t x = ans_id_pop(head, st, p0, p1);
+            const uint32_t e = x >> ESH;
+            const uint32_t c = e >> ENT_SH, t = e & (U::ENT - 1u);
+            const uint32_t bit = x & 63u;
+            const uint32_t prev1 = rl(P1, (c - 1u) & 63u);
+            const uint32_t row = rows_get(rows, c);
+            const uint32_t prev2 = rl(row, (t - 1u) & 63u);
+            uint32_t r = (c ? prev1 : 0u) + (t ? prev2 : 0u);
+            const uint32_t wb = x >> 6;
+            uint64_t W;
+            if (U::G == 1) {
+                W = rfl64(bm[wb]);
+                r += popc64(W & ((1ull << bit) - 1ull));
+            } else {
+                const uint32_t wsel = wb & 3u;
+                const uint32_t l4 = lane & 3u;
+                const uint64_t wv = bm[(wb & ~3u) + l4];
+                const uint64_t below = l4 < wsel ? ~0ull : (l4 == wsel ? ((1ull << bit) - 1ull) : 0ull);
+                const uint32_t pc = popc64(wv & below);
+                r += rl(pc, 0) + rl(pc, 1) + rl(pc, 2) + rl(pc, 3);
+                W = rl64((uint32_t)wv, (uint32_t)(wv >> 32), wsel);
+            }
+            const bool isdup = (W >> bit) & 1ull;
+            if (__builtin_expect(ndup != 0u, 0)) {  // multiset streams only (reference quirk cases)
+                for (uint32_t j0 = 0; j0 < ndup; j0 += 64) {
+                    const uint32_t jj = j0 + lane;
+                    const uint32_t z = jj < ndup ? dups[jj] : 0xffffffffu;
+                    r += popc64(ballot(jj < ndup && (z >> ESH) == e && z < x));
+                }
+            }
+            ans_idx_push(head, st, r, i0 + t64 + 1u, rl(lq, t64));
+            // insert x
+            P1 += lane >= c ? 1u : 0u;
+            rows_add(rows, c, (lane >= t && lane < U::ENT) ? 1u : 0u);
+            if (__builtin_expect(isdup, 0)) {
+                if (lane == 0) dups[ndup] = x;
+                ndup++;
+                wave_sync();
+            } else {
+                bm[wb] = W | (1ull << bit);  // every lane stores the same word
+            }
+            ring = wl(x, t64, ring);
+        }
+        if (lane < steps) a.out[ooff + (n - 1u - (i0 + lane))] = (uint64_t)ring;
+    }
+    if (lane == 0) {
+        const bool clean = (head == VIDC_RANS_L) && (st.sp == st.draws - draws0);
+        a.end_state[l] = clean ? 0u : 1u;
+        a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// classification prepass: one wavefront per list -> max id, precision, flags
+#define VIDC_PF_UNSORTED 1u  // not strictly ascending (unsorted or duplicates)
+#define VIDC_PF_DOMAIN 2u    // an id >= 2^31
+__global__ void __launch_bounds__(64) k_roc_prepass(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist,
+                                                    int precision_mode, uint32_t *maxid, uint32_t *flags,
+                                                    uint32_t *prec) {
+    const uint32_t lane = lane_id();
+    for (uint32_t l = blockIdx.x; l < nlist; l += gridDim.x) {
+        const uint64_t off = offsets[l];
+        const uint32_t n = (uint32_t)(offsets[l + 1] - off);
+        uint32_t mx = 0;
+        bool bad = false, uns = false;
+        for (uint32_t j = lane; j < n; j += 64) {
+            const uint64_t id = ids[off + j];
+            bad |= id >= (1ull << 31);
+            if (j) uns |= ids[off + j - 1] >= id;
+            const uint32_t v = (uint32_t)id;
+            mx = v > mx ? v : mx;
+        }
+        const uint32_t m = wave_max_u32(mx);
+        const uint32_t f = (ballot(uns) ? VIDC_PF_UNSORTED : 0u) | (ballot(bad) ? VIDC_PF_DOMAIN : 0u);
+        if (lane == 0) {
+            maxid[l] = m;
+            flags[l] = f;
+            prec[l] = n ? precision_for(m, precision_mode) : 0u;
+        }
+    }
+}
+
+// order[] (sampled ids, written by the U encoder into the perm buffer) -> input positions, for lists whose
+// input is strictly ascending: position = index of the id in the list (binary search).
+__global__ void k_perm_from_order(const uint64_t *ids, const uint64_t *offsets, const uint32_t *lists, uint32_t nwork,
+                                  uint32_t *perm) {
+    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const uint32_t l = lists[wi];
+        const uint64_t off = offsets[l];
+        const uint32_t n = (uint32_t)(offsets[l + 1] - off);
+        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+            const uint64_t x = perm[off + j];
+            uint32_t lo = 0, hi = n;
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (ids[off + mid] <= x) lo = mid; else hi = mid;
+            }
+            perm[off + j] = lo;
+        }
+    }
+}
+
+}  // namespace dev
+}  // namespace vidc

@@ -53,6 +53,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // ANS stack: words [0, lo) are in memory, words [lo, sp) in the register ring.
 // Encoder: mem == orig == the list's output arena.  Decoder: orig = stored stream (read-only),
 // mem = private scratch for the (practically never taken) re-spill of pushed words.
+//
+// Hot-path contract: ws_prepare() once per codec step guarantees room for >= 8 pushes and (when the
+// stack holds them) >= 8 pops inside the ring, so ws_push / ws_pop are branch-free ring accesses
+// (a codec step performs at most 5 of either).
 struct WStack {
     uint32_t win;          // per-lane: word (idx) with idx & 63 == lane, lo <= idx < sp
     uint32_t lo, sp;       // wave-uniform, lo multiple of 32, sp - lo <= 64
@@ -82,6 +86,7 @@ __device__ __forceinline__ void ws_init_loaded(WStack &s, const uint32_t *orig, 
     s.win = idx < nwords ? orig[idx] : 0u;
 }
 
+// cold: write the 32 oldest resident words to memory
 __device__ __forceinline__ void ws_spill32(WStack &s) {
     uint32_t rel = (lane_id() - s.lo) & 63u;
     uint32_t idx = s.lo + rel;
@@ -92,29 +97,42 @@ __device__ __forceinline__ void ws_spill32(WStack &s) {
     if (s.dirty > s.lo) s.dirty = s.lo;
     s.lo += 32u;
 }
+// cold: bring the 32 words below the ring back in (their ring slots are free: resident <= 32 here)
+__device__ __forceinline__ void ws_refill32(WStack &s) {
+    uint32_t base = s.lo - 32u;
+    uint32_t rel = (lane_id() - base) & 63u;
+    uint32_t idx = base + rel;
+    if (rel < 32u) s.win = (idx >= s.dirty) ? s.mem[idx] : s.orig[idx];
+    s.lo = base;
+}
+
+__device__ __forceinline__ void ws_prepare(WStack &s) {
+    // one compare on the hot path: resident count outside [8, 56] (a stack that still fits the ring,
+    // lo == 0, never needs a refill and is biased by 8 so that it does not trip the check)
+    const uint32_t res = s.sp - s.lo;
+    const uint32_t biased = res + (s.lo == 0u ? 8u : 0u);
+    if (__builtin_expect(biased - 8u > 48u, 0)) {
+        if (res > 56u) ws_spill32(s);
+        else if (res < 8u && s.lo != 0u) ws_refill32(s);
+    }
+}
 
 __device__ __forceinline__ void ws_push(WStack &s, uint32_t w) {  // codec.h:20-22
-    if (s.sp - s.lo == 64u) ws_spill32(s);
-    s.win = wl(w, s.sp & 63u, s.win);
-    s.sp += 1u;
+    const uint32_t sp = rfl(s.sp);  // keep the stack pointer chain in SGPRs
+    s.win = wl(w, sp & 63u, s.win);
+    s.sp = sp + 1u;
 }
 
 __device__ __forceinline__ uint32_t ws_pop(WStack &s) {  // codec.h:32-40
-    if (s.sp == 0u) {
+    if (__builtin_expect(s.sp == 0u, 0)) {
         uint32_t w = 0u;
         if (s.draws < s.mt_n) w = s.mt[s.draws]; else s.err |= 2u;
         s.draws += 1u;
         return rfl(w);
     }
-    if (s.sp == s.lo) {  // ring empty: refill the 32 words below
-        uint32_t base = s.lo - 32u;
-        uint32_t rel = (lane_id() - base) & 63u;
-        uint32_t idx = base + rel;
-        if (rel < 32u) s.win = (idx >= s.dirty) ? s.mem[idx] : s.orig[idx];
-        s.lo = base;
-    }
-    s.sp -= 1u;
-    return rl(s.win, s.sp & 63u);
+    const uint32_t sp = rfl(s.sp) - 1u;
+    s.sp = sp;
+    return rl(s.win, sp & 63u);
 }
 
 // write every resident word to mem (encoder epilogue)
@@ -130,6 +148,11 @@ __device__ __forceinline__ void ws_flush(WStack &s) {
 // ------------------------------------------------------------------------------- ANS primitives
 // All arguments are wave-uniform.
 
+// v < 2^31 (rans_l) with 32-bit scalar ops: the scalar unit has no ordered 64-bit compare
+__device__ __forceinline__ bool lt_2p31(uint64_t v) {
+    return (((uint32_t)(v >> 32)) | ((uint32_t)v >> 31)) == 0u;
+}
+
 // codec.cpp:65-76 : uniform 2^p push, 0 <= p <= 16.  '+' (not '|'): carries if start >= 2^p.
 __device__ __forceinline__ void ans_u_push(uint64_t &head, WStack &s, uint32_t start, uint32_t p) {
     if ((uint32_t)(head >> 32) >= (0x80000000u >> p)) {
@@ -142,7 +165,7 @@ __device__ __forceinline__ void ans_u_push(uint64_t &head, WStack &s, uint32_t s
 __device__ __forceinline__ uint32_t ans_u_pop(uint64_t &head, WStack &s, uint32_t p) {
     uint32_t sym = (uint32_t)head & ((1u << p) - 1u);
     head >>= p;
-    if (head < VIDC_RANS_L) head = (head << 32) | ws_pop(s);
+    if (lt_2p31(head)) head = (head << 32) | ws_pop(s);
     return sym;
 }
 // codec.cpp:92-105 : four 16-bit slices, low -> high; slice precisions clamp(P - lower, 0, 16).
@@ -167,17 +190,47 @@ __device__ __forceinline__ uint32_t ans_id_pop(uint64_t &head, WStack &s, uint32
 __device__ __forceinline__ uint32_t ans_idx_pop(uint64_t &head, WStack &s, uint32_t nmax, uint32_t thr,
                                                 uint64_t magic) {
     uint64_t h0 = head;
-    if ((uint32_t)(h0 >> 32) >= thr) {  // h0 >= nmax * ((L / nmax) << 32)
+    if (__builtin_expect((uint32_t)(h0 >> 32) >= thr, 0)) {  // h0 >= nmax * ((L / nmax) << 32)
         ws_push(s, (uint32_t)h0);
         h0 >>= 32;
     }
     uint64_t q = __umul64hi(h0, magic);
     uint32_t r = (uint32_t)h0 - (uint32_t)q * nmax;
-    if (r >= nmax) {
-        r -= nmax;
-        q += 1;
+    const uint32_t ge = (uint32_t)(((uint64_t)r - (uint64_t)nmax) >> 63) ^ 1u;  // 1 iff r >= nmax
+    r -= nmax & (0u - ge);
+    q += ge;
+    if (__builtin_expect(lt_2p31(h0), 0)) q = (uint64_t)ws_pop(s) | (q << 32);  // the test is on h0 (codec.cpp:35)
+    head = q;
+    return r;
+}
+// Same, with the reciprocal kept per lane (lane t64 owns the divisor of this step): every lane multiplies the
+// wave-uniform h0 by ITS reciprocal with v_mad_u64_u32 and the owner's product is read back with v_readlane.
+__device__ __forceinline__ uint32_t ans_idx_pop_v(uint64_t &head, WStack &s, uint32_t nmax, uint32_t thr,
+                                                  uint32_t m_lo, uint32_t m_hi, uint32_t t64) {
+    uint64_t h0 = head;
+    const uint32_t h_hi = (uint32_t)(h0 >> 32);
+    if (__builtin_expect(h_hi >= thr || (h_hi | ((uint32_t)h0 >> 31)) == 0u, 0)) {  // rare: renormalisation
+        if (h_hi >= thr) {
+            ws_push(s, (uint32_t)h0);
+            h0 >>= 32;
+        }
+        uint64_t q = h0 / nmax;
+        uint32_t r = (uint32_t)(h0 - q * nmax);
+        if (lt_2p31(h0)) q = (uint64_t)ws_pop(s) | (q << 32);
+        head = q;
+        return rfl(r);
     }
-    if (h0 < VIDC_RANS_L) q = (uint64_t)ws_pop(s) | (q << 32);  // the test is on h0 (codec.cpp:35)
+    const uint32_t a0 = (uint32_t)h0, a1 = h_hi;
+    // mulhi64(h0, m) = a1*m1 + hi(a1*m0) + hi(a0*m1) + carry(lo(a1*m0) + lo(a0*m1) + hi(a0*m0))
+    const uint64_t t0 = (uint64_t)a0 * m_lo;
+    const uint64_t t1 = (uint64_t)a0 * m_hi + (t0 >> 32);
+    const uint64_t t2 = (uint64_t)a1 * m_lo + (uint32_t)t1;
+    const uint64_t qv = (uint64_t)a1 * m_hi + (t1 >> 32) + (t2 >> 32);
+    uint64_t q = rl64((uint32_t)qv, (uint32_t)(qv >> 32), t64);
+    uint32_t r = a0 - (uint32_t)q * nmax;
+    const uint32_t ge = (uint32_t)(((uint64_t)r - (uint64_t)nmax) >> 63) ^ 1u;  // 1 iff r >= nmax
+    r -= nmax & (0u - ge);
+    q += ge;
     head = q;
     return r;
 }
@@ -189,7 +242,7 @@ __device__ __forceinline__ void ans_idx_push(uint64_t &head, WStack &s, uint32_t
         h0 >>= 32;
     }
     uint64_t h = h0 * (uint64_t)nmax + sym;
-    if (h < VIDC_RANS_L) h = (uint64_t)ws_pop(s) | (h << 32);
+    if (__builtin_expect(lt_2p31(h), 0)) h = (uint64_t)ws_pop(s) | (h << 32);
     head = h;
 }
 
