@@ -126,6 +126,18 @@ int vidc_packed_get(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, const uint6
 /* byte image of one list (parity against the reference layout) */
 int vidc_packed_export(vidc_ctx *ctx, const vidc_packed *p, uint64_t list_no, uint8_t *bytes, size_t cap);
 
+/* CompactBitNSGGraph (altid_impl.cpp:20-51): N rows of K int32 (-1 terminated) -> N * stride bytes, sentinel N. */
+typedef struct vidc_compact vidc_compact;
+int vidc_compact_rows_encode(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_rows, vidc_compact **out);
+void vidc_compact_destroy(vidc_compact *c);
+uint32_t vidc_compact_bits(const vidc_compact *c);
+uint32_t vidc_compact_stride(const vidc_compact *c);
+uint64_t vidc_compact_size_in_bytes(const vidc_compact *c);
+/* get_neighbors for m nodes: d_out device int32[m*K] (-1 padded), counts host uint32[m] (may be NULL) */
+int vidc_compact_rows_decode(vidc_ctx *ctx, const vidc_compact *c, uint64_t m, const uint64_t *nodes, int32_t *d_out,
+                             uint32_t *counts);
+int vidc_compact_export_row(vidc_ctx *ctx, const vidc_compact *c, uint64_t node, uint8_t *bytes, size_t cap);
+
 /* -------------------------------------------------------------- Elias-Fano */
 /* Replaces CompressedIDInvertedListsEliasFano (custom_invlists_impl.cpp:229-339),
  * EliasFanoNSGGraph (altid_impl.cpp:53-101), succinct::elias_fano builder/select/enumerator
@@ -142,9 +154,33 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out); /* asc
 int vidc_ef_get(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *list_nos, const uint64_t *offs,
                 int64_t *ids_out); /* ef->select(offset), :314-318 */
 int vidc_ef_perm(vidc_ctx *ctx, const vidc_ef *e, uint32_t *perm_host); /* sort permutation, :324-339 */
+/* EliasFanoNSGGraph (altid_impl.cpp:53-101): rows are counted (-1 terminated), sorted and coded per node. */
+int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_rows, vidc_ef **out);
+/* get_neighbors for m nodes: d_out device int32[m*K] ascending, -1 padded; counts host uint32[m] (may be NULL) */
+int vidc_ef_decode_rows(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *nodes, uint32_t K, int32_t *d_out,
+                        uint32_t *counts);
+/* decode m selected lists back to back (get_ids per touched list, custom_invlists_impl.cpp:508-525) */
+int vidc_ef_decode_lists(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *list_nos, uint64_t *d_out,
+                         uint64_t *out_offsets);
 /* word images of one list's low / high streams (64-bit words, LSB-first) */
 int vidc_ef_export(vidc_ctx *ctx, const vidc_ef *e, uint64_t list_no, uint64_t *low, size_t low_cap,
                    uint64_t *high, size_t high_cap, uint64_t *low_nbits, uint64_t *high_nbits);
+
+/* ------------------------------------------------------------ wavelet tree */
+/* Replaces CompressedIDInvertedListsWaveletTree (custom_invlists_impl.cpp:346-397): one tree over the
+ * sequence list_nos[id]; get_single_id(list, offset) = select(offset + 1, list) (:377-379).
+ * Requires what the reference asserts (:359-360): ids ascending inside every list and ids a permutation
+ * of 0..ntotal-1.  wt_type 0 = plain bitvectors, 1 = sizes reported for rrr_vector<63>-coded levels
+ * (custom_invlists_impl.h:104-113); sdsl itself is absent, so sizes follow the documented layouts. */
+typedef struct vidc_wt vidc_wt;
+int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint64_t *d_ids, int wt_type,
+                  vidc_wt **out);
+void vidc_wt_destroy(vidc_wt *w);
+uint64_t vidc_wt_size_in_bytes(const vidc_wt *w);
+uint32_t vidc_wt_levels(const vidc_wt *w);
+int vidc_wt_select(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint64_t *list_nos, const uint64_t *offs,
+                   int64_t *ids_out);
+int vidc_wt_decode_all(vidc_ctx *ctx, const vidc_wt *w, uint64_t *d_out);
 
 /* ------------------------------------------------------ introspection / timing */
 /* Milliseconds spent inside the kernels of the most recent encode / decode call on this context,

@@ -84,6 +84,24 @@ def _declare(lib):
     f("vidc_ef_get", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
     f("vidc_ef_perm", C.c_int, _vp, _vp, _vp)
     f("vidc_ef_export", C.c_int, _vp, _vp, _u64, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp)
+    f("vidc_ef_encode_rows", C.c_int, _vp, _u64, _u32, _vp, _P(_vp))
+    f("vidc_ef_decode_rows", C.c_int, _vp, _vp, _u64, _vp, _u32, _vp, _vp)
+    f("vidc_ef_decode_lists", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
+    # compact graph rows
+    f("vidc_compact_rows_encode", C.c_int, _vp, _u64, _u32, _vp, _P(_vp))
+    f("vidc_compact_destroy", None, _vp)
+    f("vidc_compact_bits", _u32, _vp)
+    f("vidc_compact_stride", _u32, _vp)
+    f("vidc_compact_size_in_bytes", _u64, _vp)
+    f("vidc_compact_rows_decode", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
+    f("vidc_compact_export_row", C.c_int, _vp, _vp, _u64, _vp, C.c_size_t)
+    # wavelet tree
+    f("vidc_wt_build", C.c_int, _vp, _u64, _vp, _vp, C.c_int, _P(_vp))
+    f("vidc_wt_destroy", None, _vp)
+    f("vidc_wt_size_in_bytes", _u64, _vp)
+    f("vidc_wt_levels", _u32, _vp)
+    f("vidc_wt_select", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
+    f("vidc_wt_decode_all", C.c_int, _vp, _vp, _vp)
 
 
 #: every symbol include/vidc.h declares (checked by the CPU test-suite against the built library)
@@ -99,6 +117,11 @@ EXPORTED_SYMBOLS = [
     "vidc_packed_bits", "vidc_packed_decode_all", "vidc_packed_get", "vidc_packed_export",
     "vidc_ef_encode", "vidc_ef_destroy", "vidc_ef_compressed_bytes", "vidc_ef_list_info", "vidc_ef_decode_all",
     "vidc_ef_get", "vidc_ef_perm", "vidc_ef_export",
+    "vidc_ef_encode_rows", "vidc_ef_decode_rows", "vidc_ef_decode_lists",
+    "vidc_compact_rows_encode", "vidc_compact_destroy", "vidc_compact_bits", "vidc_compact_stride",
+    "vidc_compact_size_in_bytes", "vidc_compact_rows_decode", "vidc_compact_export_row",
+    "vidc_wt_build", "vidc_wt_destroy", "vidc_wt_size_in_bytes", "vidc_wt_levels", "vidc_wt_select",
+    "vidc_wt_decode_all",
 ]
 
 

@@ -287,6 +287,43 @@ class EfLists:
         check(lib().vidc_ef_perm(self.ctx.h, self.h, ptr(p)))
         return p[: self.ntotal]
 
+    @classmethod
+    def encode_rows(cls, rows, ctx=None):
+        """rows: int32 CUDA tensor [N, K], -1 terminated (EliasFanoNSGGraph, altid_impl.cpp:53-90)."""
+        torch = _torch()
+        ctx = ctx or _lib.default_context()
+        if isinstance(rows, np.ndarray):
+            rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).cuda()
+        assert rows.is_cuda and rows.dtype == torch.int32 and rows.dim() == 2
+        rows = rows.contiguous()
+        N, K = rows.shape
+        h = C.c_void_p()
+        check(lib().vidc_ef_encode_rows(ctx.h, N, K, ptr(rows) if N else None, C.byref(h)))
+        obj = cls(h, ctx, np.zeros(N + 1, np.uint64))
+        sizes = obj.info()["sizes"]
+        obj.offsets = np.concatenate([[0], np.cumsum(sizes, dtype=np.uint64)]).astype(np.uint64)
+        obj.K = K
+        return obj
+
+    def decode_rows(self, nodes, K=None):
+        torch = _torch()
+        K = K or self.K
+        nd = np.ascontiguousarray(nodes, dtype=np.uint64)
+        out = torch.empty((max(nd.size, 1), K), dtype=torch.int32, device="cuda")
+        counts = np.zeros(max(nd.size, 1), np.uint32)
+        check(lib().vidc_ef_decode_rows(self.ctx.h, self.h, nd.size, ptr(nd), K, ptr(out), ptr(counts)))
+        return out[: nd.size], counts[: nd.size]
+
+    def decode_lists(self, list_nos):
+        torch = _torch()
+        ln = np.ascontiguousarray(list_nos, dtype=np.uint64)
+        sizes = (self.offsets[1:] - self.offsets[:-1])[ln.astype(np.int64)] if ln.size else np.zeros(0, np.uint64)
+        total = int(sizes.sum())
+        out = torch.empty(max(total, 1), dtype=torch.int64, device="cuda")
+        out_off = np.zeros(ln.size + 1, np.uint64)
+        check(lib().vidc_ef_decode_lists(self.ctx.h, self.h, ln.size, ptr(ln), ptr(out), ptr(out_off)))
+        return out[:total], out_off
+
     def export(self, list_no):
         """-> (low words, high words, low_nbits, high_nbits) of one list."""
         lb, hb = C.c_uint64(), C.c_uint64()
@@ -296,3 +333,103 @@ class EfLists:
         high = np.zeros(max(hw, 1), np.uint64)
         check(lib().vidc_ef_export(self.ctx.h, self.h, list_no, ptr(low), lw, ptr(high), hw, C.byref(lb), C.byref(hb)))
         return low[:lw], high[:hw], int(lb.value), int(hb.value)
+
+
+class CompactRows:
+    """CompactBitNSGGraph storage (vidc_compact): N rows x ceil(K*bits/8) bytes, sentinel N ends a row."""
+
+    def __init__(self, handle, ctx, N, K):
+        self.h, self.ctx, self.N, self.K = handle, ctx, N, K
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().vidc_compact_destroy(self.h)
+            self.h = None
+
+    @classmethod
+    def encode_rows(cls, rows, ctx=None):
+        torch = _torch()
+        ctx = ctx or _lib.default_context()
+        if isinstance(rows, np.ndarray):
+            rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).cuda()
+        assert rows.is_cuda and rows.dtype == torch.int32 and rows.dim() == 2
+        rows = rows.contiguous()
+        N, K = rows.shape
+        h = C.c_void_p()
+        check(lib().vidc_compact_rows_encode(ctx.h, N, K, ptr(rows) if N else None, C.byref(h)))
+        return cls(h, ctx, N, K)
+
+    @property
+    def bits(self):
+        return int(lib().vidc_compact_bits(self.h))
+
+    @property
+    def stride(self):
+        return int(lib().vidc_compact_stride(self.h))
+
+    @property
+    def size_in_bytes(self):
+        return int(lib().vidc_compact_size_in_bytes(self.h))
+
+    def decode_rows(self, nodes):
+        torch = _torch()
+        nd = np.ascontiguousarray(nodes, dtype=np.uint64)
+        out = torch.empty((max(nd.size, 1), self.K), dtype=torch.int32, device="cuda")
+        counts = np.zeros(max(nd.size, 1), np.uint32)
+        check(lib().vidc_compact_rows_decode(self.ctx.h, self.h, nd.size, ptr(nd), ptr(out), ptr(counts)))
+        return out[: nd.size], counts[: nd.size]
+
+    def export_row(self, node):
+        buf = np.zeros(self.stride, np.uint8)
+        check(lib().vidc_compact_export_row(self.ctx.h, self.h, node, ptr(buf), self.stride))
+        return buf
+
+
+class WaveletTreeLists:
+    """Wavelet tree over list_nos[id] (vidc_wt): id = select(offset + 1, list_no)."""
+
+    def __init__(self, handle, ctx, offsets):
+        self.h = handle
+        self.ctx = ctx
+        self.offsets = offsets
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().vidc_wt_destroy(self.h)
+            self.h = None
+
+    @classmethod
+    def build(cls, offsets, ids, wt_type=0, ctx=None):
+        ctx = ctx or _lib.default_context()
+        off = _as_offsets(offsets)
+        ntotal = int(off[-1])
+        d_ids = _dev_ids(ids, ntotal) if ntotal else None
+        h = C.c_void_p()
+        check(lib().vidc_wt_build(ctx.h, off.size - 1, ptr(off), ptr(d_ids), int(wt_type), C.byref(h)))
+        return cls(h, ctx, off)
+
+    @property
+    def ntotal(self):
+        return int(self.offsets[-1])
+
+    @property
+    def size_in_bytes(self):
+        return int(lib().vidc_wt_size_in_bytes(self.h))
+
+    @property
+    def levels(self):
+        return int(lib().vidc_wt_levels(self.h))
+
+    def select(self, list_nos, offs):
+        ln = np.ascontiguousarray(list_nos, dtype=np.uint64)
+        of = np.ascontiguousarray(offs, dtype=np.uint64)
+        out = np.zeros(max(ln.size, 1), np.int64)
+        check(lib().vidc_wt_select(self.ctx.h, self.h, ln.size, ptr(ln), ptr(of), ptr(out)))
+        return out[: ln.size]
+
+    def decode_all(self, out=None):
+        torch = _torch()
+        if out is None:
+            out = torch.empty(max(self.ntotal, 1), dtype=torch.int64, device="cuda")
+        check(lib().vidc_wt_decode_all(self.ctx.h, self.h, ptr(out)))
+        return out[: self.ntotal]

@@ -141,14 +141,23 @@ __global__ void k_ef_high(const uint64_t *sorted_ids, const uint64_t *offsets, c
     }
 }
 
-// bulk decode: one wavefront per list, 64 high words per iteration (select_enumerator, elias_fano.hpp:210-261)
+// bulk decode: one wavefront per list, 64 high words per iteration (select_enumerator, elias_fano.hpp:210-261).
+// worklist == nullptr: every list, output at offsets[l].  Otherwise work item wi decodes list worklist[wi] to
+// out_off[wi] (uint64 output) or to row wi of an int32 [nwork, K] matrix padded with -1 (graph flavour).
 __global__ void __launch_bounds__(64) k_ef_decode(const uint64_t *low, const uint64_t *high, const uint64_t *offsets,
                                                   const uint64_t *low_off, const uint64_t *high_off,
-                                                  const uint32_t *lbits, uint32_t nlist, uint64_t *out) {
+                                                  const uint32_t *lbits, uint32_t nwork, const uint64_t *worklist,
+                                                  const uint64_t *out_off, uint64_t *out, int32_t *out_rows,
+                                                  uint32_t K) {
     const uint32_t lane = lane_id();
-    for (uint32_t l = blockIdx.x; l < nlist; l += gridDim.x) {
-        const uint64_t off = offsets[l];
-        const uint64_t m = offsets[l + 1] - off;
+    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const uint64_t l = worklist ? worklist[wi] : wi;
+        const uint64_t off = out_rows ? (uint64_t)wi * K : (out_off ? out_off[wi] : offsets[l]);
+        const uint64_t m = offsets[l + 1] - offsets[l];
+        if (out_rows) {
+            for (uint32_t j = lane; j < K; j += 64)
+                if (j >= m) out_rows[off + j] = -1;
+        }
         if (!m) continue;
         const uint32_t b = lbits[l];
         const uint64_t *lw = low + low_off[l];
@@ -156,8 +165,8 @@ __global__ void __launch_bounds__(64) k_ef_decode(const uint64_t *low, const uin
         const uint64_t nhw = high_off[l + 1] - high_off[l];
         uint64_t done = 0;
         for (uint64_t w0 = 0; w0 < nhw && done < m; w0 += 64) {
-            const uint64_t wi = w0 + lane;
-            uint64_t word = wi < nhw ? hw[wi] : 0ull;
+            const uint64_t wi64 = w0 + lane;
+            uint64_t word = wi64 < nhw ? hw[wi64] : 0ull;
             uint32_t c = popc64(word);
             // inclusive prefix sum over the 64 lanes
             uint32_t incl = c;
@@ -170,12 +179,46 @@ __global__ void __launch_bounds__(64) k_ef_decode(const uint64_t *low, const uin
             while (word && rank < m) {
                 const uint32_t bit = (uint32_t)__builtin_ctzll(word);
                 word &= word - 1;
-                const uint64_t pos = wi * 64 + bit;
-                out[off + rank] = ((pos - rank) << b) | read_bits(lw, rank * b, b);
+                const uint64_t pos = wi64 * 64 + bit;
+                const uint64_t val = ((pos - rank) << b) | read_bits(lw, rank * b, b);
+                if (out_rows) out_rows[off + rank] = (int32_t)val;
+                else out[off + rank] = val;
                 rank++;
             }
             done += rl(incl, 63);
         }
+    }
+}
+
+// ---- graph rows -> CSR of ascending ids (EliasFanoNSGGraph ctor, altid_impl.cpp:61-76)
+__global__ void __launch_bounds__(64) k_rows_count(const int32_t *rows, uint64_t N, uint32_t K, uint32_t *counts,
+                                                   uint32_t *err) {
+    const uint32_t lane = lane_id();
+    for (uint64_t r = blockIdx.x; r < N; r += gridDim.x) {
+        const int32_t e = lane < K ? rows[r * K + lane] : -1;
+        const uint64_t endm = ballot(e == -1);
+        const uint32_t n = endm ? ff1(endm) : 64u;
+        if (ballot(lane < n && e < 0) && lane == 0) atomicOr(err, 1u);
+        if (lane == 0) counts[r] = n;
+    }
+}
+__global__ void __launch_bounds__(64) k_rows_sorted(const int32_t *rows, uint64_t N, uint32_t K,
+                                                    const uint64_t *offsets, uint64_t *ids) {
+    const uint32_t lane = lane_id();
+    for (uint64_t r = blockIdx.x; r < N; r += gridDim.x) {
+        const uint32_t n = (uint32_t)(offsets[r + 1] - offsets[r]);
+        uint32_t key = lane < n ? (uint32_t)rows[r * K + lane] : 0xffffffffu;
+#pragma unroll
+        for (uint32_t k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                const uint32_t other = (uint32_t)__shfl_xor((int)key, (int)j, 64);
+                const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
+                const uint32_t mn = key < other ? key : other, mx = key < other ? other : key;
+                key = take_min ? mn : mx;
+            }
+        }
+        if (lane < n) ids[offsets[r] + lane] = (uint64_t)key;
     }
 }
 
@@ -386,7 +429,8 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(k_ef_decode, dim3((uint32_t)std::min<uint64_t>(e->nlist, (uint64_t)ctx->num_cu * 64)), dim3(64), 0,
                        ctx->stream, e->d_low.p, e->d_high.p, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p,
-                       e->d_lbits.p, (uint32_t)e->nlist, d_out);
+                       e->d_lbits.p, (uint32_t)e->nlist, (const uint64_t *)nullptr, (const uint64_t *)nullptr, d_out,
+                       (int32_t *)nullptr, 0u);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
@@ -394,6 +438,87 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->last_kernel_ms = ms;
     return VIDC_OK;
+}
+
+static int ef_decode_some(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *list_nos,
+                          const uint64_t *out_off_host, uint64_t *d_out, int32_t *d_rows, uint32_t K) {
+    VIDC_HIP(hipSetDevice(ctx->device));
+    Scratch s_l, s_o;
+    VIDC_TRY(s_l.get(ctx, m * 8));
+    VIDC_HIP(hipMemcpyAsync(s_l.p, list_nos, m * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (out_off_host) {
+        VIDC_TRY(s_o.get(ctx, m * 8));
+        VIDC_HIP(hipMemcpyAsync(s_o.p, out_off_host, m * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_ef_decode, dim3((uint32_t)std::min<uint64_t>(m, (uint64_t)ctx->num_cu * 64)), dim3(64), 0,
+                       ctx->stream, e->d_low.p, e->d_high.p, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p,
+                       e->d_lbits.p, (uint32_t)m, s_l.as<uint64_t>(), out_off_host ? s_o.as<uint64_t>() : nullptr, d_out,
+                       d_rows, K);
+    VIDC_HIP(hipGetLastError());
+    VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->last_kernel_ms = ms;
+    return VIDC_OK;
+}
+
+int vidc_ef_decode_lists(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *list_nos, uint64_t *d_out,
+                         uint64_t *out_offsets) {
+    if (!ctx || !e || (m && !list_nos) || !out_offsets) return VIDC_ERR_INVALID;
+    out_offsets[0] = 0;
+    for (uint64_t i = 0; i < m; i++) {
+        if (list_nos[i] >= e->nlist) { set_error("list number out of range"); return VIDC_ERR_INVALID; }
+        out_offsets[i + 1] = out_offsets[i] + (e->offsets[list_nos[i] + 1] - e->offsets[list_nos[i]]);
+    }
+    if (!m) return VIDC_OK;
+    return ef_decode_some(ctx, e, m, list_nos, out_offsets, d_out, nullptr, 0);
+}
+
+int vidc_ef_decode_rows(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *nodes, uint32_t K, int32_t *d_out,
+                        uint32_t *counts) {
+    if (!ctx || !e || (m && (!nodes || !d_out)) || K == 0) return VIDC_ERR_INVALID;
+    for (uint64_t i = 0; i < m; i++) {
+        if (nodes[i] >= e->nlist) { set_error("node out of range"); return VIDC_ERR_INVALID; }
+        uint64_t n = e->offsets[nodes[i] + 1] - e->offsets[nodes[i]];
+        if (n > K) { set_error("node has more than K edges"); return VIDC_ERR_INVALID; }
+        if (counts) counts[i] = (uint32_t)n;
+    }
+    if (!m) return VIDC_OK;
+    return ef_decode_some(ctx, e, m, nodes, nullptr, nullptr, d_out, K);
+}
+
+int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_rows, vidc_ef **out) {
+    if (!ctx || !out || (N && !d_rows)) return VIDC_ERR_INVALID;
+    *out = nullptr;
+    if (K == 0 || K > 64) { set_error("EF rows: K=%u unsupported (1..64)", K); return VIDC_ERR_UNSUPPORTED; }
+    VIDC_HIP(hipSetDevice(ctx->device));
+    Scratch s_cnt, s_err, s_off, s_ids;
+    VIDC_TRY(s_cnt.get(ctx, N * 4));
+    VIDC_TRY(s_err.get(ctx, 4));
+    VIDC_HIP(hipMemsetAsync(s_err.p, 0, 4, ctx->stream));
+    std::vector<uint32_t> counts(N);
+    std::vector<uint64_t> offsets(N + 1, 0);
+    uint32_t err = 0;
+    if (N) {
+        uint32_t grid = (uint32_t)std::min<uint64_t>(N, (uint64_t)ctx->num_cu * 64);
+        hipLaunchKernelGGL(k_rows_count, dim3(grid), dim3(64), 0, ctx->stream, d_rows, N, K, s_cnt.as<uint32_t>(),
+                           s_err.as<uint32_t>());
+        VIDC_HIP(hipGetLastError());
+        VIDC_HIP(hipMemcpyAsync(counts.data(), s_cnt.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        VIDC_HIP(hipMemcpyAsync(&err, s_err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        VIDC_HIP(hipStreamSynchronize(ctx->stream));
+        if (err) { set_error("EF rows: negative neighbour id before the -1 terminator"); return VIDC_ERR_DOMAIN; }
+        for (uint64_t r = 0; r < N; r++) offsets[r + 1] = offsets[r] + counts[r];
+        VIDC_TRY(s_off.get(ctx, (N + 1) * 8));
+        VIDC_TRY(s_ids.get(ctx, offsets[N] * 8));
+        VIDC_HIP(hipMemcpyAsync(s_off.p, offsets.data(), (N + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_rows_sorted, dim3(grid), dim3(64), 0, ctx->stream, d_rows, N, K, s_off.as<uint64_t>(),
+                           s_ids.as<uint64_t>());
+        VIDC_HIP(hipGetLastError());
+    }
+    return vidc_ef_encode(ctx, N, offsets.data(), s_ids.as<uint64_t>(), 0, out);
 }
 
 int vidc_ef_get(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *list_nos, const uint64_t *offs,

@@ -57,9 +57,139 @@ __global__ void k_packed_get(const uint64_t *words, const uint64_t *word_off, ui
     if (q < m) out[q] = (int64_t)read_bits(words + word_off[list_nos[q]], offs[q] * bits, bits);
 }
 
+// ---- CompactBitNSGGraph (altid_impl.cpp:20-51): row i occupies bytes [i*stride, (i+1)*stride); neighbours are
+// written until the first -1, which is replaced by the sentinel N and ends the row (:28-37).
+// One wavefront per row (K <= 64): lane j owns value j and ORs it into an LDS image of the row (values
+// straddle bytes), which is then written out with coalesced byte stores.
+__global__ void __launch_bounds__(64) k_compact_rows_encode(const int32_t *rows, uint64_t N, uint32_t K, uint32_t bits,
+                                                            uint32_t stride, uint8_t *out, uint32_t *err) {
+    __shared__ uint32_t img[72];  // stride <= ceil(64 * 32 / 8) = 256 bytes (+ spill word)
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t row = blockIdx.x; row < N; row += gridDim.x) {
+        img[lane] = 0;
+        if (lane < 8) img[64 + lane] = 0;
+        __syncthreads();
+        const int32_t e = lane < K ? rows[row * K + lane] : -1;
+        const uint64_t endm = __ballot(e == -1);
+        const uint32_t n = endm ? (uint32_t)__builtin_ctzll(endm) : 64u;  // edges before the first -1
+        const bool bad = lane < n && (e < 0 || (uint64_t)e >= N);
+        if (__ballot(bad) && lane == 0) atomicOr(err, 1u);
+        // values 0..n-1 are neighbours; value n (if n < K) is the sentinel N; nothing after it (:31-36)
+        if (lane <= n && lane < K) {
+            const uint64_t v = lane == n ? N : (uint64_t)(uint32_t)e;
+            const uint32_t pos = lane * bits;
+            const uint64_t sh = v << (pos & 31);
+            atomicOr(&img[pos >> 5], (uint32_t)sh);
+            if ((pos & 31) + bits > 32) atomicOr(&img[(pos >> 5) + 1], (uint32_t)(sh >> 32));
+        }
+        __syncthreads();
+        const uint8_t *b = (const uint8_t *)img;
+        for (uint32_t t = lane; t < stride; t += 64) out[row * stride + t] = b[t];
+        __syncthreads();
+    }
+}
+
+// one wavefront per requested row (K <= 64): lane j reads value j; the row ends at the sentinel N (:43-49)
+__global__ void __launch_bounds__(64) k_compact_rows_decode(const uint8_t *data, uint64_t N, uint32_t K, uint32_t bits,
+                                                            uint32_t stride, uint64_t m, const uint64_t *nodes,
+                                                            int32_t *out, uint32_t *counts) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t q = blockIdx.x; q < m; q += gridDim.x) {
+        const uint8_t *row = data + nodes[q] * stride;
+        uint64_t v = ~0ull;
+        if (lane < K) {
+            const uint32_t pos = lane * bits;
+            uint64_t acc = 0;
+            const uint32_t b0 = pos >> 3;
+            for (uint32_t t = 0; t < 6 && b0 + t < stride; t++) acc |= (uint64_t)row[b0 + t] << (8 * t);
+            v = (acc >> (pos & 7)) & ((1ull << bits) - 1ull);
+        }
+        const uint64_t endm = __ballot(lane < K && v == N);
+        const uint32_t n = endm ? (uint32_t)__builtin_ctzll(endm) : K;
+        if (lane < K) out[q * K + lane] = lane < n ? (int32_t)v : -1;
+        if (lane == 0) counts[q] = n;
+    }
+}
+
 }  // namespace
 
+struct vidc_compact {
+    int device = 0;
+    uint64_t N = 0;
+    uint32_t K = 0, bits = 0, stride = 0;
+    DevBuf<uint8_t> d_data;
+};
+
 extern "C" {
+
+int vidc_compact_rows_encode(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_rows, vidc_compact **out) {
+    if (!ctx || !out || (N && !d_rows)) return VIDC_ERR_INVALID;
+    *out = nullptr;
+    if (K == 0 || K > 64) { set_error("compact rows: K=%u unsupported (1..64)", K); return VIDC_ERR_UNSUPPORTED; }
+    VIDC_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<vidc_compact> c(new vidc_compact());
+    c->device = ctx->device;
+    c->N = N;
+    c->K = K;
+    c->bits = (uint32_t)vidc_packed_bits_for(N);         // while((1 << bits) < N + 1) bits++, altid_impl.cpp:22-23
+    c->stride = (K * c->bits + 7) / 8;                   // :24
+    VIDC_TRY(c->d_data.alloc(N * c->stride + 8));
+    Scratch s_err;
+    VIDC_TRY(s_err.get(ctx, 4));
+    VIDC_HIP(hipMemsetAsync(s_err.p, 0, 4, ctx->stream));
+    VIDC_HIP(hipMemsetAsync(c->d_data.p, 0, N * c->stride + 8, ctx->stream));
+    if (N) {
+        VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+        uint32_t grid = (uint32_t)std::min<uint64_t>(N, (uint64_t)ctx->num_cu * 64);
+        hipLaunchKernelGGL(k_compact_rows_encode, dim3(grid), dim3(64), 0, ctx->stream, d_rows, N, K, c->bits, c->stride,
+                           c->d_data.p, s_err.as<uint32_t>());
+        VIDC_HIP(hipGetLastError());
+        VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    }
+    uint32_t err = 0;
+    VIDC_HIP(hipMemcpyAsync(&err, s_err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    if (N) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+        ctx->last_kernel_ms = ms;
+    }
+    if (err) { set_error("compact rows: neighbour id outside [0, N)"); return VIDC_ERR_DOMAIN; }
+    *out = c.release();
+    return VIDC_OK;
+}
+void vidc_compact_destroy(vidc_compact *c) { delete c; }
+uint32_t vidc_compact_bits(const vidc_compact *c) { return c ? c->bits : 0; }
+uint32_t vidc_compact_stride(const vidc_compact *c) { return c ? c->stride : 0; }
+uint64_t vidc_compact_size_in_bytes(const vidc_compact *c) { return c ? c->N * c->stride : 0; }
+
+int vidc_compact_rows_decode(vidc_ctx *ctx, const vidc_compact *c, uint64_t m, const uint64_t *nodes, int32_t *d_out,
+                             uint32_t *counts) {
+    if (!ctx || !c || (m && (!nodes || !d_out))) return VIDC_ERR_INVALID;
+    if (!m) return VIDC_OK;
+    for (uint64_t i = 0; i < m; i++)
+        if (nodes[i] >= c->N) { set_error("node %llu out of range", (unsigned long long)nodes[i]); return VIDC_ERR_INVALID; }
+    VIDC_HIP(hipSetDevice(ctx->device));
+    Scratch s_n, s_c;
+    VIDC_TRY(s_n.get(ctx, m * 8)); VIDC_TRY(s_c.get(ctx, m * 4));
+    VIDC_HIP(hipMemcpyAsync(s_n.p, nodes, m * 8, hipMemcpyHostToDevice, ctx->stream));
+    VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_compact_rows_decode, dim3((uint32_t)std::min<uint64_t>(m, 1u << 20)), dim3(64), 0, ctx->stream,
+                       c->d_data.p, c->N, c->K, c->bits, c->stride, m, s_n.as<uint64_t>(), d_out, s_c.as<uint32_t>());
+    VIDC_HIP(hipGetLastError());
+    VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    if (counts) VIDC_HIP(hipMemcpyAsync(counts, s_c.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->last_kernel_ms = ms;
+    return VIDC_OK;
+}
+
+int vidc_compact_export_row(vidc_ctx *ctx, const vidc_compact *c, uint64_t node, uint8_t *bytes, size_t cap) {
+    if (!ctx || !c || node >= c->N || cap < c->stride) return VIDC_ERR_INVALID;
+    return vidc_copy_d2h(ctx, bytes, c->d_data.p + node * c->stride, c->stride);
+}
 
 int vidc_packed_bits_for(uint64_t ntotal) {  // custom_invlists_impl.cpp:68-70
     int bits = 0;
