@@ -262,18 +262,27 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     a.sid = s_sid.as<uint32_t>(); a.spos = nullptr; a.skey = nullptr; a.skey_off = nullptr;
     a.mt = ctx->d_mt;
 
+    // The long-list (bitmap) kernels hold one wave per CU; everything else runs concurrently on the auxiliary
+    // stream and fills the remaining wave slots.
+    hipStream_t short_stream = ctx->stream;
     auto launch_gen = [&](const uint32_t *d_wl, uint32_t nwork, uint32_t rl_max) -> int {
         if (!nwork) return VIDC_OK;
         RocEncArgs b = a;
         b.worklist = d_wl; b.nwork = nwork;
         size_t lds = (size_t)64 * rl_max * 12;
-        hipLaunchKernelGGL(k_roc_encode_gen, dim3(nwork), dim3(64), lds, ctx->stream, b, rl_max);
+        hipLaunchKernelGGL(k_roc_encode_gen, dim3(nwork), dim3(64), lds, short_stream, b, rl_max);
         VIDC_HIP(hipGetLastError());
         return VIDC_OK;
     };
     {
         EventTimer t(ctx);
         const uint32_t *d_wl = s_wl.as<uint32_t>();
+        const bool fork = !wl_u18.empty() || !wl_u20.empty();
+        if (fork) {
+            VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+            VIDC_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+            short_stream = ctx->aux_stream;
+        }
         // longest lists first: they are the critical path
         if (!wl_u20.empty()) {
             RocEncArgs b = a;
@@ -297,9 +306,14 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         if (!wl_tiny.empty()) {
             RocEncArgs b = a;
             b.worklist = d_wl; b.nwork = (uint32_t)wl_tiny.size();
-            if (rows) hipLaunchKernelGGL(k_roc_encode_tiny<true>, dim3(b.nwork), dim3(64), 0, ctx->stream, b);
-            else hipLaunchKernelGGL(k_roc_encode_tiny<false>, dim3(b.nwork), dim3(64), 0, ctx->stream, b);
+            if (rows) hipLaunchKernelGGL(k_roc_encode_tiny<true>, dim3(b.nwork), dim3(64), 0, short_stream, b);
+            else hipLaunchKernelGGL(k_roc_encode_tiny<false>, dim3(b.nwork), dim3(64), 0, short_stream, b);
             VIDC_HIP(hipGetLastError());
+        }
+        if (fork) {
+            VIDC_HIP(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+            VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            short_stream = ctx->stream;
         }
         kernel_ms += t.stop();
     }
@@ -472,8 +486,14 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         for (int c = 0; c < DC_COUNT; c++) { base[c] = acc; acc += p.count[c]; }
     }
     EventTimer t(ctx);
+    const bool fork = p.count[DC_U18] || p.count[DC_U20];
+    if (fork) {
+        VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        VIDC_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+    }
     auto launch = [&](int c) -> int {
         if (!p.count[c]) return VIDC_OK;
+        hipStream_t st_ = (fork && c != DC_U18 && c != DC_U20) ? ctx->aux_stream : ctx->stream;
         RocDecArgs b = a;
         b.worklist = s_wl.as<uint32_t>() + base[c];
         b.nwork = (uint32_t)p.count[c];
@@ -482,25 +502,25 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         b.slots_off = s_slots_off.as<uint64_t>() + base[c];
         switch (c) {
             case DC_TINY:
-                if (d_out_rows) hipLaunchKernelGGL(k_roc_decode_tiny<true>, dim3(b.nwork), dim3(64), 0, ctx->stream, b);
-                else hipLaunchKernelGGL(k_roc_decode_tiny<false>, dim3(b.nwork), dim3(64), 0, ctx->stream, b);
+                if (d_out_rows) hipLaunchKernelGGL(k_roc_decode_tiny<true>, dim3(b.nwork), dim3(64), 0, st_, b);
+                else hipLaunchKernelGGL(k_roc_decode_tiny<false>, dim3(b.nwork), dim3(64), 0, st_, b);
                 break;
             case DC_U18:
-                hipLaunchKernelGGL(k_roc_decode_u<18>, dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->stream, b);
+                hipLaunchKernelGGL(k_roc_decode_u<18>, dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, st_, b);
                 break;
             case DC_U20:
                 VIDC_TRY(set_big_lds((const void *)k_roc_decode_u<20>, UGeom<20>::LDS_BYTES));
-                hipLaunchKernelGGL(k_roc_decode_u<20>, dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, ctx->stream, b);
+                hipLaunchKernelGGL(k_roc_decode_u<20>, dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, st_, b);
                 break;
             case DC_GSMALL:
-                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), 128 * 4, ctx->stream, b, 128u, VIDC_DEC_CAP);
+                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), 128 * 4, st_, b, 128u, VIDC_DEC_CAP);
                 break;
             case DC_GMID:
-                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), (1u << VIDC_DEC_MAX_FB) * 4, ctx->stream, b,
+                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), (1u << VIDC_DEC_MAX_FB) * 4, st_, b,
                                    1u << VIDC_DEC_MAX_FB, VIDC_DEC_CAP);
                 break;
             default:
-                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), (1u << VIDC_DEC_MAX_FB) * 4, ctx->stream, b,
+                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), (1u << VIDC_DEC_MAX_FB) * 4, st_, b,
                                    1u << VIDC_DEC_MAX_FB, VIDC_DEC_CAP_BIG);
         }
         VIDC_HIP(hipGetLastError());
@@ -508,6 +528,10 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     };
     // longest chains first
     for (int c : {DC_GHUGE, DC_U20, DC_GMID, DC_U18, DC_GSMALL, DC_TINY}) VIDC_TRY(launch(c));
+    if (fork) {
+        VIDC_HIP(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+        VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    }
     ctx->last_kernel_ms = t.stop();
     ctx->phase_ms[VIDC_PHASE_ROC_DECODE] = ctx->last_kernel_ms;
 

@@ -288,9 +288,10 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
     const uint32_t lane = lane_id();
 
     for (uint32_t wi = blockIdx.x; wi < a.nwork; wi += gridDim.x) {
-        const uint32_t l = a.worklist[wi];
-        const uint64_t off = a.offsets[l];
-        const uint32_t n = (uint32_t)(a.offsets[l + 1] - off);
+        // per-list scalars arrive through vector loads: pin them to SGPRs so the ANS chain stays scalar
+        const uint32_t l = rfl(a.worklist[wi]);
+        const uint64_t off = rfl64(a.offsets[l]);
+        const uint32_t n = rfl((uint32_t)(a.offsets[l + 1] - off));
         if (n == 0) {
             if (lane == 0) {
                 a.heads[l] = VIDC_RANS_L; a.prec[l] = 0; a.nwords[l] = 0; a.draws[l] = 0; a.status[l] = VIDC_ST_OK;
@@ -358,50 +359,54 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
 
         // ---- phase 2: the serial chain
         WStack st;
-        ws_init_empty(st, a.arena + a.arena_off[l], (uint32_t)(a.arena_off[l + 1] - a.arena_off[l]), a.mt,
-                      VIDC_MT_TABLE);
+        {
+            const uint64_t ao = rfl64(a.arena_off[l]);
+            ws_init_empty(st, a.arena + ao, rfl((uint32_t)(a.arena_off[l + 1] - ao)), a.mt, VIDC_MT_TABLE);
+        }
         uint64_t head = VIDC_RANS_L;
         Recip rc;
         uint32_t pbuf = 0;
         const uint32_t *sid = a.sid + off;
         const uint32_t *spos = a.spos + off;
-        for (uint32_t i = 0; i < n; i++) {
-            ws_prepare(st);
-            const uint32_t t64 = i & 63u;
-            if (t64 == 0) recip_block(rc, n - i);
-            const uint32_t nmax = n - i;
-            const uint64_t magic = rl64(rc.m_lo, rc.m_hi, t64);
-            uint32_t k = ans_idx_pop(head, st, nmax, rl(rc.thr, t64), magic);
-            // level 1: lane-block
-            const uint32_t c = ff1(ballot(P1 > k));
-            if (c) k -= rl(P1, c - 1u);
-            // level 2: word inside the lane-block
-            uint32_t w = c;
-            uint32_t tsel = 0;
-            uint32_t rowv = 0;
-            if (RL > 1u) {
-                rowv = lane < RL ? rowpref[(c << rlsh) + lane] : 0xffffffffu;
-                tsel = ff1(ballot(rowv > k));
-                if (tsel) k -= rl(rowv, tsel - 1u);
-                w = (c << rlsh) + tsel;
-            }
-            // level 3: bit inside the word
-            const uint64_t W = rfl64(words[w]);
-            const bool mine = ((W >> lane) & 1ull) && (mbcnt(W) == k);
-            const uint32_t b = ff1(ballot(mine));
-            const uint32_t j = (w << 6) + b;
-            const uint32_t x = rfl(sid[j]);
-            // remove
-            if (lane == 0) words[w] = W & ~(1ull << b);
-            if (RL > 1u && lane >= tsel && lane < RL) rowpref[(c << rlsh) + lane] = rowv - 1u;
-            P1 -= (lane >= c) ? 1u : 0u;
-            ans_id_push(head, st, x, p0, p1);
-            if (a.perm) {
-                const uint32_t pos = need_sort ? rfl(spos[j]) : j;
-                pbuf = wl(pos, t64, pbuf);
-                if (t64 == 63u || i == n - 1u) {
-                    if (lane <= t64) a.perm[off + (i - t64) + lane] = pbuf;
+        const bool want_perm = a.perm != nullptr;
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            recip_block(rc, n - i0);  // lane t owns the divisor of step i0 + t
+            const uint32_t steps = n - i0 < 64u ? n - i0 : 64u;
+            for (uint32_t t64 = 0; t64 < steps; t64++) {
+                ws_prepare(st);
+                uint32_t k = ans_idx_pop_v(head, st, n - i0 - t64, rl(rc.thr, t64), rc.m_lo, rc.m_hi, t64);
+                // level 1: lane-block
+                const uint32_t c = ff1(ballot(P1 > k));
+                const uint32_t prev1 = rl(P1, (c - 1u) & 63u);
+                k -= c ? prev1 : 0u;
+                // level 2: word inside the lane-block
+                uint32_t w = c;
+                uint32_t tsel = 0;
+                uint32_t rowv = 0;
+                if (RL > 1u) {
+                    rowv = lane < RL ? rowpref[(c << rlsh) + lane] : 0xffffffffu;
+                    tsel = ff1(ballot(rowv > k));
+                    const uint32_t prev2 = rl(rowv, (tsel - 1u) & 63u);
+                    k -= tsel ? prev2 : 0u;
+                    w = (c << rlsh) + tsel;
                 }
+                // level 3: bit inside the word
+                const uint64_t W = rfl64(words[w]);
+                const uint32_t b = ff1(ballot(mbcnt(W) == k) & W);
+                const uint32_t j = (w << 6) + b;
+                const uint32_t x = rfl(sid[j]);
+                // remove (every lane stores the same word)
+                words[w] = W & ~(1ull << b);
+                if (RL > 1u && lane >= tsel && lane < RL) rowpref[(c << rlsh) + lane] = rowv - 1u;
+                P1 -= (lane >= c) ? 1u : 0u;
+                ans_id_push(head, st, x, p0, p1);
+                if (want_perm) {
+                    const uint32_t pos = need_sort ? rfl(spos[j]) : j;
+                    pbuf = wl(pos, t64, pbuf);
+                }
+            }
+            if (want_perm) {
+                if (lane < steps) a.perm[off + i0 + lane] = pbuf;
             }
         }
         ws_flush(st);
@@ -423,21 +428,21 @@ __global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t ld
     const uint32_t lane = lane_id();
 
     for (uint32_t wi = blockIdx.x; wi < a.nwork; wi += gridDim.x) {
-        const uint32_t l = a.worklist[wi];
-        const uint32_t n = (uint32_t)(a.offsets[l + 1] - a.offsets[l]);
-        const uint64_t ooff = a.out_off ? a.out_off[wi] : a.offsets[l];
+        const uint32_t l = rfl(a.worklist[wi]);
+        const uint32_t n = rfl((uint32_t)(a.offsets[l + 1] - a.offsets[l]));
+        const uint64_t ooff = rfl64(a.out_off ? a.out_off[wi] : a.offsets[l]);
         if (n == 0) {
             if (lane == 0) { a.end_state[l] = 0; a.status[l] = VIDC_ST_OK; }
             continue;
         }
-        const uint32_t P = a.prec[l];
+        const uint32_t P = rfl(a.prec[l]);
         const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
-        const uint32_t W = a.nwords[l];
+        const uint32_t W = rfl(a.nwords[l]);
         WStack st;
-        ws_init_loaded(st, a.words + a.word_off[l], W, a.scratch_words + a.scratch_off[wi], W + 64u, a.draws[l], a.mt,
-                       VIDC_MT_TABLE);
+        ws_init_loaded(st, a.words + rfl64(a.word_off[l]), W, a.scratch_words + rfl64(a.scratch_off[wi]), W + 64u,
+                       rfl(a.draws[l]), a.mt, VIDC_MT_TABLE);
         const uint32_t draws0 = st.draws;
-        uint64_t head = a.heads[l];
+        uint64_t head = rfl64(a.heads[l]);
 
         // bucket geometry: fine bucket f = x >> s, coarse c = f >> rb (<= 64 of them), row slot t = f & (RL-1)
         const uint32_t fb = roc_dec_fine_bits(n, P > 32u ? 32u : P);
@@ -448,74 +453,73 @@ __global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t ld
         const uint32_t NF = 1u << fb;
         for (uint32_t t = lane; t < NF && t < lds_entries; t += 64) rowpref[t] = 0;
         uint32_t C1 = 0;  // lane c: decoded elements in coarse buckets 0..c
-        uint32_t *slots = a.slots + a.slots_off[wi];
+        uint32_t *slots = a.slots + rfl64(a.slots_off[wi]);
         uint32_t *ovf = slots + (size_t)NF * cap;
         uint32_t novf = 0, novf_vis = 0;
         uint32_t ring = 0;  // lane t: element decoded at step (block start + t)
         Recip rc;
         wave_sync();
 
-        for (uint32_t i = 0; i < n; i++) {
-            ws_prepare(st);
-            const uint32_t t64 = i & 63u;
-            if (t64 == 0) {
-                // new 64-step block: earlier slot / overflow stores become visible to loads
-                wave_sync();
-                novf_vis = novf;
-                uint32_t d = i + 1u + lane;
-                rc.lq = 0x80000000u / d;
-            }
-            const uint32_t x = ans_id_pop(head, st, p0, p1);
-            const uint32_t f = s >= 32u ? 0u : (x >> s);
-            const uint32_t c = f >> rb;
-            const uint32_t t = f & (RL - 1u);
-            // prefix counts of the buckets below f
-            const uint32_t base1 = c ? rl(C1, c - 1u) : 0u;
-            uint32_t base2 = 0, cnt, rowv = 0;
-            if (rb) {
-                rowv = lane < RL ? rowpref[(c << rb) + lane] : 0u;
-                if (t) base2 = rl(rowv, t - 1u);
-                cnt = rl(rowv, t) - base2;
-            } else {
-                cnt = rl(C1, c) - base1;
-            }
-            // members of bucket f: those stored before this block (visible in memory) ...
-            const bool ring_valid = lane < t64;
-            const bool ring_same = ring_valid && ((s >= 32u ? 0u : (ring >> s)) == f);
-            const uint32_t in_ring = popc64(ballot(ring_same));
-            const uint32_t cnt_vis = cnt - in_ring;
-            const uint32_t m = cnt_vis < cap ? cnt_vis : cap;
-            uint32_t y = 0xffffffffu;
-            if (lane < m) y = slots[(size_t)f * cap + lane];
-            uint32_t within = popc64(ballot(lane < m && y < x));
-            if (cnt_vis > cap) {  // skewed data: members that did not fit the row
-                for (uint32_t j0 = 0; j0 < novf_vis; j0 += 64) {
-                    uint32_t jj = j0 + lane;
-                    uint32_t z = jj < novf_vis ? ovf[jj] : 0xffffffffu;
-                    bool hit = jj < novf_vis && ((s >= 32u ? 0u : (z >> s)) == f) && z < x;
-                    within += popc64(ballot(hit));
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            // new 64-step block: earlier slot / overflow stores become visible to loads
+            wave_sync();
+            novf_vis = novf;
+            rc.lq = 0x80000000u / (i0 + 1u + lane);  // lane t owns floor(2^31 / nmax) of step i0 + t
+            const uint32_t steps = n - i0 < 64u ? n - i0 : 64u;
+            for (uint32_t t64 = 0; t64 < steps; t64++) {
+                ws_prepare(st);
+                const uint32_t x = ans_id_pop(head, st, p0, p1);
+                const uint32_t f = s >= 32u ? 0u : (x >> s);
+                const uint32_t c = f >> rb;
+                const uint32_t t = f & (RL - 1u);
+                // prefix counts of the buckets below f
+                const uint32_t prev1 = rl(C1, (c - 1u) & 63u);
+                const uint32_t base1 = c ? prev1 : 0u;
+                uint32_t base2 = 0, cnt, rowv = 0;
+                if (rb) {
+                    rowv = lane < RL ? rowpref[(c << rb) + lane] : 0u;
+                    const uint32_t prev2 = rl(rowv, (t - 1u) & 63u);
+                    base2 = t ? prev2 : 0u;
+                    cnt = rl(rowv, t) - base2;
+                } else {
+                    cnt = rl(C1, c) - base1;
                 }
-            }
-            // ... plus those decoded inside the current block (still in flight to memory)
-            within += popc64(ballot(ring_same && ring < x));
-            const uint32_t r = base1 + base2 + within;
-            ans_idx_push(head, st, r, i + 1u, rl(rc.lq, t64));
-            // insert x
-            if (cnt < cap) {
-                if (lane == 0) slots[(size_t)f * cap + cnt] = x;
-            } else {
-                if (lane == 0) ovf[novf] = x;
-                novf++;
-            }
-            C1 += (lane >= c) ? 1u : 0u;
-            if (rb && lane >= t && lane < RL) rowpref[(c << rb) + lane] = rowv + 1u;
-            ring = wl(x, t64, ring);
-            if (t64 == 63u || i == n - 1u) {
-                if (lane <= t64) {
-                    const uint32_t step = (i - t64) + lane;
-                    if (a.out) a.out[ooff + (n - 1u - step)] = (uint64_t)ring;
-                    else a.out_rows[ooff + (n - 1u - step)] = (int32_t)ring;
+                // members of bucket f: those stored before this block (visible in memory) ...
+                const bool ring_valid = lane < t64;
+                const bool ring_same = ring_valid && ((s >= 32u ? 0u : (ring >> s)) == f);
+                const uint32_t in_ring = popc64(ballot(ring_same));
+                const uint32_t cnt_vis = cnt - in_ring;
+                const uint32_t m = cnt_vis < cap ? cnt_vis : cap;
+                uint32_t y = 0xffffffffu;
+                if (lane < m) y = slots[(size_t)f * cap + lane];
+                uint32_t within = popc64(ballot(lane < m && y < x));
+                if (__builtin_expect(cnt_vis > cap, 0)) {  // skewed data: members that did not fit the row
+                    for (uint32_t j0 = 0; j0 < novf_vis; j0 += 64) {
+                        uint32_t jj = j0 + lane;
+                        uint32_t z = jj < novf_vis ? ovf[jj] : 0xffffffffu;
+                        bool hit = jj < novf_vis && ((s >= 32u ? 0u : (z >> s)) == f) && z < x;
+                        within += popc64(ballot(hit));
+                    }
                 }
+                // ... plus those decoded inside the current block (still in flight to memory)
+                within += popc64(ballot(ring_same && ring < x));
+                const uint32_t r = base1 + base2 + within;
+                ans_idx_push(head, st, r, i0 + t64 + 1u, rl(rc.lq, t64));
+                // insert x
+                if (__builtin_expect(cnt < cap, 1)) {
+                    if (lane == 0) slots[(size_t)f * cap + cnt] = x;
+                } else {
+                    if (lane == 0) ovf[novf] = x;
+                    novf++;
+                }
+                C1 += (lane >= c) ? 1u : 0u;
+                if (rb && lane >= t && lane < RL) rowpref[(c << rb) + lane] = rowv + 1u;
+                ring = wl(x, t64, ring);
+            }
+            if (lane < steps) {
+                const uint32_t step = i0 + lane;
+                if (a.out) a.out[ooff + (n - 1u - step)] = (uint64_t)ring;
+                else a.out_rows[ooff + (n - 1u - step)] = (int32_t)ring;
             }
         }
         if (lane == 0) {
