@@ -44,9 +44,12 @@ class RocLists:
         self.offsets = offsets
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().vidc_roc_destroy(self.h)
-            self.h = None
+        try:  # may run during interpreter shutdown, after module globals are gone
+            if getattr(self, "h", None):
+                lib().vidc_roc_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
     # -- construction
     @classmethod
@@ -174,9 +177,12 @@ class PackedLists:
         self.offsets = offsets
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().vidc_packed_destroy(self.h)
-            self.h = None
+        try:  # may run during interpreter shutdown, after module globals are gone
+            if getattr(self, "h", None):
+                lib().vidc_packed_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
     @staticmethod
     def bits_for(ntotal):
@@ -237,9 +243,12 @@ class EfLists:
         self.offsets = offsets
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().vidc_ef_destroy(self.h)
-            self.h = None
+        try:  # may run during interpreter shutdown, after module globals are gone
+            if getattr(self, "h", None):
+                lib().vidc_ef_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
     @classmethod
     def encode(cls, offsets, ids, want_perm=False, ctx=None):
@@ -342,9 +351,12 @@ class CompactRows:
         self.h, self.ctx, self.N, self.K = handle, ctx, N, K
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().vidc_compact_destroy(self.h)
-            self.h = None
+        try:  # may run during interpreter shutdown, after module globals are gone
+            if getattr(self, "h", None):
+                lib().vidc_compact_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
     @classmethod
     def encode_rows(cls, rows, ctx=None):
@@ -394,9 +406,12 @@ class WaveletTreeLists:
         self.offsets = offsets
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().vidc_wt_destroy(self.h)
-            self.h = None
+        try:  # may run during interpreter shutdown, after module globals are gone
+            if getattr(self, "h", None):
+                lib().vidc_wt_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
     @classmethod
     def build(cls, offsets, ids, wt_type=0, ctx=None):

@@ -27,6 +27,8 @@ struct vidc_roc {
     DevBuf<uint64_t> d_offsets, d_heads, d_word_off;
     DevBuf<uint32_t> d_prec, d_nwords, d_draws, d_words, d_perm;
     mutable uint64_t last_nonclean = 0;
+    // decode_all plan, built on first use (depends only on the immutable metadata)
+    mutable std::shared_ptr<struct DecPlanCache> plan_all;
 };
 
 namespace {
@@ -205,8 +207,8 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             VIDC_TRY(s_maxid.get(ctx, nlist * 4));
             VIDC_TRY(s_flags.get(ctx, nlist * 4));
             EventTimer t(ctx);
-            hipLaunchKernelGGL(k_roc_prepass, dim3((uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 64)),
-                               dim3(64), 0, ctx->stream, d_ids, r->d_offsets.p, (uint32_t)nlist, precision_mode,
+            hipLaunchKernelGGL(k_roc_prepass, dim3((uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 32)),
+                               dim3(256), 0, ctx->stream, d_ids, r->d_offsets.p, (uint32_t)nlist, precision_mode,
                                s_maxid.as<uint32_t>(), s_flags.as<uint32_t>(), r->d_prec.p);
             VIDC_HIP(hipGetLastError());
             kernel_ms += t.stop();
@@ -451,15 +453,33 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     p.slots_words = sl;
 }
 
+}  // namespace
+
+// device copy of a plan, kept with the compressed object for repeated decode_all calls
+struct DecPlanCache {
+    DecPlan plan;
+    DevBuf<uint32_t> d_wl;
+    DevBuf<uint64_t> d_scratch_off, d_slots_off;
+};
+
+namespace {
+
 int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64_t *out_off_host, uint64_t *d_out,
-                int32_t *d_out_rows, uint32_t K) {
+                int32_t *d_out_rows, uint32_t K, const DecPlanCache *cache = nullptr) {
     VIDC_HIP(hipSetDevice(ctx->device));
     const size_t nwork = p.wl.size();
     if (nwork == 0) { ctx->last_kernel_ms = 0; return VIDC_OK; }
-    Scratch s_wl, s_scr_off, s_slots_off, s_scr, s_slots, s_out_off, s_end, s_status;
-    VIDC_TRY(upload_scratch(ctx, s_wl, p.wl));
-    VIDC_TRY(upload_scratch(ctx, s_scr_off, p.scratch_off));
-    VIDC_TRY(upload_scratch(ctx, s_slots_off, p.slots_off));
+    Scratch s_wl, s_scr_off, s_slots_off, s_scr, s_slots, s_out_off, s_end, s_status, s_sum;
+    const uint32_t *d_wl;
+    const uint64_t *d_scr_off, *d_slots_off;
+    if (cache) {
+        d_wl = cache->d_wl.p; d_scr_off = cache->d_scratch_off.p; d_slots_off = cache->d_slots_off.p;
+    } else {
+        VIDC_TRY(upload_scratch(ctx, s_wl, p.wl));
+        VIDC_TRY(upload_scratch(ctx, s_scr_off, p.scratch_off));
+        VIDC_TRY(upload_scratch(ctx, s_slots_off, p.slots_off));
+        d_wl = s_wl.as<uint32_t>(); d_scr_off = s_scr_off.as<uint64_t>(); d_slots_off = s_slots_off.as<uint64_t>();
+    }
     VIDC_TRY(s_scr.get(ctx, p.scratch_words * 4));
     VIDC_TRY(s_slots.get(ctx, p.slots_words * 4));
     VIDC_TRY(s_end.get(ctx, r->nlist * 4));
@@ -495,11 +515,11 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         if (!p.count[c]) return VIDC_OK;
         hipStream_t st_ = (fork && c != DC_U18 && c != DC_U20) ? ctx->aux_stream : ctx->stream;
         RocDecArgs b = a;
-        b.worklist = s_wl.as<uint32_t>() + base[c];
+        b.worklist = d_wl + base[c];
         b.nwork = (uint32_t)p.count[c];
         b.out_off = out_off_host ? s_out_off.as<uint64_t>() + base[c] : nullptr;
-        b.scratch_off = s_scr_off.as<uint64_t>() + base[c];
-        b.slots_off = s_slots_off.as<uint64_t>() + base[c];
+        b.scratch_off = d_scr_off + base[c];
+        b.slots_off = d_slots_off + base[c];
         switch (c) {
             case DC_TINY:
                 if (d_out_rows) hipLaunchKernelGGL(k_roc_decode_tiny<true>, dim3(b.nwork), dim3(64), 0, st_, b);
@@ -535,14 +555,23 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     ctx->last_kernel_ms = t.stop();
     ctx->phase_ms[VIDC_PHASE_ROC_DECODE] = ctx->last_kernel_ms;
 
-    std::vector<uint32_t> status(r->nlist), endst(r->nlist);
-    VIDC_HIP(hipMemcpyAsync(status.data(), s_status.p, r->nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipMemcpyAsync(endst.data(), s_end.p, r->nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // 16-byte summary instead of copying two nlist-sized arrays back
+    VIDC_TRY(s_sum.get(ctx, 16));
+    const unsigned long long init[2] = {~0ull, 0ull};
+    VIDC_HIP(hipMemcpyAsync(s_sum.p, init, 16, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_roc_status_summary, dim3((uint32_t)std::min<uint64_t>((r->nlist + 255) / 256, 1024)), dim3(256),
+                       0, ctx->stream, s_status.as<uint32_t>(), s_end.as<uint32_t>(), (uint32_t)r->nlist,
+                       s_sum.as<unsigned long long>());
+    VIDC_HIP(hipGetLastError());
+    unsigned long long sum[2] = {0, 0};
+    VIDC_HIP(hipMemcpyAsync(sum, s_sum.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
-    VIDC_TRY(check_status(status, "roc decode"));
-    uint64_t bad = 0;
-    for (uint32_t e : endst) bad += e;
-    r->last_nonclean = bad;
+    if (sum[0] != ~0ull) {
+        std::vector<uint32_t> status(r->nlist);
+        VIDC_HIP(hipMemcpy(status.data(), s_status.p, r->nlist * 4, hipMemcpyDeviceToHost));
+        VIDC_TRY(check_status(status, "roc decode"));
+    }
+    r->last_nonclean = sum[1];
     return VIDC_OK;
 }
 
@@ -637,11 +666,18 @@ int vidc_roc_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, cons
 
 int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out) {
     if (!ctx || !r || (r->ntotal && !d_out)) return VIDC_ERR_INVALID;
-    std::vector<uint32_t> all(r->nlist);
-    std::iota(all.begin(), all.end(), 0u);
-    DecPlan p;
-    plan_decode(r, all, false, p);
-    return decode_impl(ctx, r, p, nullptr, d_out, nullptr, 0);
+    if (!r->plan_all) {
+        std::vector<uint32_t> all(r->nlist);
+        std::iota(all.begin(), all.end(), 0u);
+        auto c = std::make_shared<DecPlanCache>();
+        plan_decode(r, all, false, c->plan);
+        VIDC_HIP(hipSetDevice(ctx->device));
+        VIDC_TRY(upload(ctx, c->d_wl, c->plan.wl));
+        VIDC_TRY(upload(ctx, c->d_scratch_off, c->plan.scratch_off));
+        VIDC_TRY(upload(ctx, c->d_slots_off, c->plan.slots_off));
+        r->plan_all = c;
+    }
+    return decode_impl(ctx, r, r->plan_all->plan, nullptr, d_out, nullptr, 0, r->plan_all.get());
 }
 
 int vidc_roc_decode_lists(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *list_nos,

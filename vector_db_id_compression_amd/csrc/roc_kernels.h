@@ -532,6 +532,20 @@ __global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t ld
 }
 
 // ---------------------------------------------------------------------------------------------
+// status summary: out[0] = 1 + smallest list number with a non-OK status (0 = none), out[1] = number of lists
+// whose decode did not end in the initial ANS state
+__global__ void k_roc_status_summary(const uint32_t *status, const uint32_t *end_state, uint32_t nlist,
+                                     unsigned long long *out) {
+    unsigned long long bad = ~0ull, nonclean = 0;
+    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x) {
+        if (status[l] != VIDC_ST_OK && (unsigned long long)l < bad) bad = l;
+        if (end_state) nonclean += end_state[l];
+    }
+    if (bad != ~0ull) atomicMin(&out[0], bad);
+    if (nonclean) atomicAdd(&out[1], nonclean);
+}
+
+// ---------------------------------------------------------------------------------------------
 // compaction of the worst-case arena into the CSR stream
 __global__ void k_roc_compact(const uint32_t *arena, const uint64_t *arena_off, const uint64_t *word_off,
                               uint32_t *words, uint32_t nlist) {

@@ -264,16 +264,17 @@ __global__ void __launch_bounds__(64) k_roc_decode_u(RocDecArgs a) {
 // classification prepass: one wavefront per list -> max id, precision, flags
 #define VIDC_PF_UNSORTED 1u  // not strictly ascending (unsorted or duplicates)
 #define VIDC_PF_DOMAIN 2u    // an id >= 2^31
-__global__ void __launch_bounds__(64) k_roc_prepass(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist,
-                                                    int precision_mode, uint32_t *maxid, uint32_t *flags,
-                                                    uint32_t *prec) {
-    const uint32_t lane = lane_id();
+__global__ void __launch_bounds__(256) k_roc_prepass(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist,
+                                                     int precision_mode, uint32_t *maxid, uint32_t *flags,
+                                                     uint32_t *prec) {
+    __shared__ uint32_t s_max[4], s_flag[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t l = blockIdx.x; l < nlist; l += gridDim.x) {
         const uint64_t off = offsets[l];
         const uint32_t n = (uint32_t)(offsets[l + 1] - off);
         uint32_t mx = 0;
         bool bad = false, uns = false;
-        for (uint32_t j = lane; j < n; j += 64) {
+        for (uint32_t j = threadIdx.x; j < n; j += 256) {
             const uint64_t id = ids[off + j];
             bad |= id >= (1ull << 31);
             if (j) uns |= ids[off + j - 1] >= id;
@@ -282,11 +283,15 @@ __global__ void __launch_bounds__(64) k_roc_prepass(const uint64_t *ids, const u
         }
         const uint32_t m = wave_max_u32(mx);
         const uint32_t f = (ballot(uns) ? VIDC_PF_UNSORTED : 0u) | (ballot(bad) ? VIDC_PF_DOMAIN : 0u);
-        if (lane == 0) {
-            maxid[l] = m;
-            flags[l] = f;
-            prec[l] = n ? precision_for(m, precision_mode) : 0u;
+        if (lane == 0) { s_max[wave] = m; s_flag[wave] = f; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t mm = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+            maxid[l] = mm;
+            flags[l] = s_flag[0] | s_flag[1] | s_flag[2] | s_flag[3];
+            prec[l] = n ? precision_for(mm, precision_mode) : 0u;
         }
+        __syncthreads();
     }
 }
 

@@ -95,6 +95,12 @@ def workload(name, seed=42, device="cuda"):
     elif name == "c5":
         off, ids = make_lists_numpy(10_000_000, 65536, 0.75, seed, cap=65536)
         desc = "10M ids in 65536 Zipf(s=0.75) inverted lists (bigann10M IVF65k shape)"
+    elif name == "uniform_16m":
+        off, ids = make_lists_torch(1 << 24, 1 << 16, 0.0, seed, device=device)
+        desc = "16M ids in 65536 equal-sized lists (256 ids each): throughput regime, no long chain"
+    elif name == "uniform_64m_1k":
+        off, ids = make_lists_torch(1 << 26, 1 << 16, 0.0, seed, device=device)
+        desc = "64M ids in 65536 equal-sized lists (1024 ids each): throughput regime"
     elif name == "s2_64m":
         off, ids = make_lists_torch(1 << 26, 1 << 16, 0.75, seed, cap=65536, device=device)
         desc = "64M ids in 65536 Zipf(s=0.75) lists capped at 65536"
