@@ -42,6 +42,16 @@ TIMED(k_set_gpr_idx, uint32_t w = v; asm volatile(".rept 2048\n s_set_gpr_idx_on
 TIMED(k_mad_u64_dep, uint64_t q = v; asm volatile(".rept 2048\n v_mad_u64_u32 %0, vcc, %1, %1, %0\n .endr" : "+v"(q) : "v"(v) : "vcc"); v += (uint32_t)q;)
 TIMED(k_readfirstlane_dep, asm volatile(".rept 2048\n v_readfirstlane_b32 %0, %1\n s_nop 0\n v_mov_b32 %1, %0\n .endr" : "+s"(s), "+v"(v));)
 
+// clock calibration: 64 * 65536 dependent s_add per launch, timed with hipEvents and s_memtime
+__global__ void __launch_bounds__(64) k_calib(uint64_t *out, uint32_t *buf) {
+    uint32_t s = buf[0];
+    uint64_t t0, t1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0));
+    for (int i = 0; i < 65536; i++) asm volatile(".rept 64\n s_add_u32 %0, %0, 3\n .endr" : "+s"(s));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1));
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = s; }
+}
+
 typedef void (*kern_t)(uint64_t *, uint32_t *);
 struct Item { const char *name; kern_t k; int n; };
 
@@ -69,5 +79,20 @@ int main() {
         printf("%-44s %8.2f memtime-ticks per iteration\n", it.name, (double)h[0] / it.n);
     }
     // wall-clock calibration of the memtime tick: long dependent s_add loop
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_calib, dim3(1), dim3(64), 0, 0, d_out, d_buf);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        uint64_t h[2];
+        hipMemcpy(h, d_out, 16, hipMemcpyDeviceToHost);
+        double n = 64.0 * 65536;
+        printf("calib: %.0f dependent s_add: %.3f ms wall = %.2f ns/instr; %llu memtime ticks = %.2f ticks/instr; tick = %.3f ns\n",
+               n, ms, ms * 1e6 / n, (unsigned long long)h[0], h[0] / n, ms * 1e6 / (double)h[0]);
+    }
     return 0;
 }

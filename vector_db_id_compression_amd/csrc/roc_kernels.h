@@ -98,6 +98,7 @@ struct Recip {
     uint32_t m_lo, m_hi;  // floor((2^64 - 1) / d)
     uint32_t thr;         // d * floor(2^31 / d)
     uint32_t lq;          // floor(2^31 / d)
+    uint32_t d;           // the divisor itself
 };
 __device__ __forceinline__ void recip_block(Recip &r, uint32_t dmax) {
     uint32_t t = lane_id();
@@ -107,6 +108,7 @@ __device__ __forceinline__ void recip_block(Recip &r, uint32_t dmax) {
     r.m_hi = (uint32_t)(m >> 32);
     r.lq = 0x80000000u / d;
     r.thr = r.lq * d;
+    r.d = d;
 }
 
 // =============================================================================================
@@ -374,7 +376,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
             const uint32_t steps = n - i0 < 64u ? n - i0 : 64u;
             for (uint32_t t64 = 0; t64 < steps; t64++) {
                 ws_prepare(st);
-                uint32_t k = ans_idx_pop_v(head, st, n - i0 - t64, rl(rc.thr, t64), rc.m_lo, rc.m_hi, t64);
+                uint32_t k = ans_idx_pop_v(head, st, n - i0 - t64, rl(rc.thr, t64) - 1u, rc.d, rc.m_lo, rc.m_hi, t64);
                 // level 1: lane-block
                 const uint32_t c = ff1(ballot(P1 > k));
                 const uint32_t prev1 = rl(P1, (c - 1u) & 63u);

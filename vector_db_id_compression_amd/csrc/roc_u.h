@@ -42,11 +42,12 @@ struct UGeom {
 
 // rows[c] lane t = number of set bits in entries 0..t of level-1 block c; P1 lane c = set bits in blocks 0..c
 template <int UB>
-__device__ __forceinline__ void u_build_counts(const uint64_t *bm, v32u &rows, uint32_t &P1) {
+__device__ __forceinline__ void u_build_counts(const uint64_t *bm, v32u &rows, uint32_t &P1, uint32_t &P1x) {
     using U = UGeom<UB>;
     const uint32_t lane = lane_id();
     uint32_t running = 0;
     P1 = 0;
+    P1x = 0;
 #pragma unroll
     for (int c = 0; c < 32; c++) rows[c] = 0u;
     for (uint32_t c = 0; c < 64; c++) {
@@ -61,12 +62,19 @@ __device__ __forceinline__ void u_build_counts(const uint64_t *bm, v32u &rows, u
             if (lane >= (uint32_t)o) cnt += v;
         }
         rows_add(rows, c, lane < U::ENT ? cnt : 0xffffu);  // padding lanes never win a "> k" vote before a real one
+        P1x = lane == c ? running : P1x;
         running += rl(cnt, 63);
         P1 = lane == c ? running : P1;
     }
 }
 
 // -------------------------------------------------------------------------------------------------
+#ifdef VIDC_PROF
+#define VIDC_TICK(i) { uint64_t _t = __builtin_readcyclecounter(); prof[i] += _t - tprev; tprev = _t; }
+#else
+#define VIDC_TICK(i)
+#endif
+
 template <int UB, bool WANT_ORDER>
 __global__ void __launch_bounds__(64) k_roc_encode_u(RocEncArgs a) {
     using U = UGeom<UB>;
@@ -99,8 +107,8 @@ __global__ void __launch_bounds__(64) k_roc_encode_u(RocEncArgs a) {
         return;
     }
     v32u rows;
-    uint32_t P1;
-    u_build_counts<UB>(bm, rows, P1);
+    uint32_t P1, P1x;  // lane c: set bits in blocks 0..c (inclusive) / 0..c-1 (exclusive)
+    u_build_counts<UB>(bm, rows, P1, P1x);
 
     const uint32_t P = rfl(a.prec[l]);  // written by the prepass
     const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
@@ -114,50 +122,68 @@ __global__ void __launch_bounds__(64) k_roc_encode_u(RocEncArgs a) {
     uint32_t obuf = 0;
     uint32_t *order = WANT_ORDER ? a.perm + off : nullptr;  // sampled ids; k_perm_from_order turns them into positions
 
+#ifdef VIDC_PROF
+    uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tprev = __builtin_readcyclecounter();
+#endif
     for (uint32_t i0 = 0; i0 < n; i0 += 64) {
         recip_block(rc, n - i0);  // lane t owns the divisor of step i0 + t
         const uint32_t steps = n - i0 < 64u ? n - i0 : 64u;
+        VIDC_TICK(0)
         for (uint32_t t64 = 0; t64 < steps; t64++) {
             ws_prepare(st);
-            uint32_t k = ans_idx_pop_v(head, st, n - i0 - t64, rl(rc.thr, t64), rc.m_lo, rc.m_hi, t64);
+            VIDC_TICK(1)
+            uint32_t k = ans_idx_pop_v(head, st, n - i0 - t64, rl(rc.thr, t64) - 1u, rc.d, rc.m_lo, rc.m_hi, t64);
+            VIDC_TICK(2)
+            // k is a uniform VGPR value: the select arithmetic stays on the VALU (see to_v())
             // level 1
             const uint32_t c = ff1(ballot(P1 > k));
-            const uint32_t prev1 = rl(P1, (c - 1u) & 63u);
-            k -= c ? prev1 : 0u;
+            k -= rl(P1x, c);
             // level 2 (register row)
             const uint32_t row = rows_get(rows, c);
             const uint32_t t = ff1(ballot(row > k));
-            const uint32_t prev2 = rl(row, (t - 1u) & 63u);
-            k -= t ? prev2 : 0u;
+            k -= rl(lane_shr1(row), t);
             uint32_t wb = c * U::WPL + t * U::G;
+            VIDC_TICK(3)
             // level 3 (LDS words)
-            uint64_t W;
+            uint32_t w_lo, w_hi;
             if (U::G == 1) {
-                W = rfl64(bm[wb]);
+                const uint64_t wv = bm[wb];
+                w_lo = rfl((uint32_t)wv);
+                w_hi = rfl((uint32_t)(wv >> 32));
             } else {
                 const uint64_t wv = bm[wb + (lane & 3u)];
                 const uint32_t pc = popc64(wv);
-                const uint32_t q0 = rl(pc, 0), q1 = q0 + rl(pc, 1), q2 = q1 + rl(pc, 2);
-                const bool g0 = k >= q0, g1 = k >= q1, g2 = k >= q2;  // monotone: g2 -> g1 -> g0
-                const uint32_t g = g2 ? 3u : (g1 ? 2u : (g0 ? 1u : 0u));
-                k -= g2 ? q2 : (g1 ? q1 : (g0 ? q0 : 0u));
-                W = rl64((uint32_t)wv, (uint32_t)(wv >> 32), g);
+                const uint32_t incl = prefix4(pc);                       // lanes 0..3
+                const uint32_t g = ff1((ballot(incl > k) & 0xfull) | 8ull);  // first of the 4 words holding bit k
+                k -= rl(incl - pc, g);
+                w_lo = rl((uint32_t)wv, g);
+                w_hi = rl((uint32_t)(wv >> 32), g);
                 wb += g;
             }
+            const uint64_t W = ((uint64_t)w_hi << 32) | w_lo;
             const uint32_t b = ff1(ballot(mbcnt(W) == k) & W);
             const uint32_t x = (wb << 6) | b;
+            VIDC_TICK(4)
             // remove x (every lane stores the same word: no exec-mask juggling)
             P1 -= lane >= c ? 1u : 0u;
+            P1x -= lane > c ? 1u : 0u;
             rows_sub(rows, c, (lane >= t && lane < U::ENT) ? 1u : 0u);  // those counters include x: no borrow
             bm[wb] = W & ~(1ull << b);
+            VIDC_TICK(5)
             ans_id_push(head, st, x, p0, p1);
             if (WANT_ORDER) obuf = wl(x, t64, obuf);
+            VIDC_TICK(6)
         }
         if (WANT_ORDER) {
             if (lane < steps) order[i0 + lane] = obuf;
         }
     }
     ws_flush(st);
+#ifdef VIDC_PROF
+    if (lane == 0)
+        for (int q = 0; q < 8; q++) ((uint64_t *)a.sid)[q] = prof[q];
+#endif
     if (lane == 0) {
         a.heads[l] = head;
         a.nwords[l] = st.sp;

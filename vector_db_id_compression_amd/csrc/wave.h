@@ -31,12 +31,30 @@ __device__ __forceinline__ uint64_t rl64(uint32_t lo, uint32_t hi, uint32_t lane
     return ((uint64_t)rl(hi, lane) << 32) | rl(lo, lane);
 }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+// Keep a wave-uniform value in a VGPR (all lanes equal) and make the compiler treat it as a vector value.
+// A VALU-written SGPR (v_readlane, v_cmp mask) costs ~16 extra cycles when the SCALAR unit consumes it but nothing
+// when a VALU instruction does (tools/ubench_issue.hip), so the select/rank arithmetic is kept on the VALU.
+__device__ __forceinline__ uint32_t to_v(uint32_t x) {
+    uint32_t y;
+    asm volatile("" : "=v"(y) : "0"(x));
+    return y;
+}
 // number of set bits of `mask` strictly below this lane's position
 __device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 __device__ __forceinline__ uint32_t ff1(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
 __device__ __forceinline__ uint32_t popc64(uint64_t m) { return (uint32_t)__builtin_popcountll(m); }
+// value of the previous lane (lane 0 gets 0): DPP wave_shr:1
+__device__ __forceinline__ uint32_t lane_shr1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+}
+// inclusive prefix sum over lanes 0..3 of each 16-lane row (DPP row_shr:1, row_shr:2); other lanes: don't care
+__device__ __forceinline__ uint32_t prefix4(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    return v;
+}
 // single-wave workgroup: orders LDS / global accesses between lanes of the wave
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
@@ -60,6 +78,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 struct WStack {
     uint32_t win;          // per-lane: word (idx) with idx & 63 == lane, lo <= idx < sp
     uint32_t lo, sp;       // wave-uniform, lo multiple of 32, sp - lo <= 64
+    uint32_t sp_min, sp_span;  // hot-path window: no spill/refill needed while sp - sp_min < sp_span
     uint32_t cap;          // capacity of mem in words
     uint32_t dirty;        // decoder: words in [dirty, lo) live in mem, words below in orig
     uint32_t draws;        // mt19937(1234) words consumed (codec.h:32-40)
@@ -70,10 +89,18 @@ struct WStack {
     uint32_t mt_n;
 };
 
+// window of stack pointers for which the ring needs no maintenance: resident count in [8, 56], or anything up
+// to 56 while the whole stack is still resident (lo == 0)
+__device__ __forceinline__ void ws_window(WStack &s) {
+    s.sp_min = s.lo ? s.lo + 8u : 0u;
+    s.sp_span = s.lo ? 49u : 57u;
+}
+
 __device__ __forceinline__ void ws_init_empty(WStack &s, uint32_t *arena, uint32_t cap, const uint32_t *mt,
                                               uint32_t mt_n) {
     s.win = 0; s.lo = 0; s.sp = 0; s.cap = cap; s.dirty = 0; s.draws = 0; s.err = 0;
     s.mem = arena; s.orig = arena; s.mt = mt; s.mt_n = mt_n;
+    ws_window(s);
 }
 
 __device__ __forceinline__ void ws_init_loaded(WStack &s, const uint32_t *orig, uint32_t nwords, uint32_t *scratch,
@@ -84,6 +111,7 @@ __device__ __forceinline__ void ws_init_loaded(WStack &s, const uint32_t *orig, 
     s.lo = nwords ? ((nwords - 1u) & ~31u) : 0u;
     uint32_t idx = s.lo + ((lane_id() - s.lo) & 63u);
     s.win = idx < nwords ? orig[idx] : 0u;
+    ws_window(s);
 }
 
 // cold: write the 32 oldest resident words to memory
@@ -96,6 +124,7 @@ __device__ __forceinline__ void ws_spill32(WStack &s) {
     if (s.lo + 32u > s.cap) s.err |= 1u;
     if (s.dirty > s.lo) s.dirty = s.lo;
     s.lo += 32u;
+    ws_window(s);
 }
 // cold: bring the 32 words below the ring back in (their ring slots are free: resident <= 32 here)
 __device__ __forceinline__ void ws_refill32(WStack &s) {
@@ -104,14 +133,13 @@ __device__ __forceinline__ void ws_refill32(WStack &s) {
     uint32_t idx = base + rel;
     if (rel < 32u) s.win = (idx >= s.dirty) ? s.mem[idx] : s.orig[idx];
     s.lo = base;
+    ws_window(s);
 }
 
 __device__ __forceinline__ void ws_prepare(WStack &s) {
-    // one compare on the hot path: resident count outside [8, 56] (a stack that still fits the ring,
-    // lo == 0, never needs a refill and is biased by 8 so that it does not trip the check)
-    const uint32_t res = s.sp - s.lo;
-    const uint32_t biased = res + (s.lo == 0u ? 8u : 0u);
-    if (__builtin_expect(biased - 8u > 48u, 0)) {
+    // one subtract + one unsigned compare on the hot path
+    if (__builtin_expect(s.sp - s.sp_min >= s.sp_span, 0)) {
+        const uint32_t res = s.sp - s.lo;
         if (res > 56u) ws_spill32(s);
         else if (res < 8u && s.lo != 0u) ws_refill32(s);
     }
@@ -173,8 +201,14 @@ __device__ __forceinline__ uint32_t ans_u_pop(uint64_t &head, WStack &s, uint32_
 __device__ __forceinline__ void ans_id_push(uint64_t &head, WStack &s, uint32_t x, uint32_t p0, uint32_t p1) {
     ans_u_push(head, s, x & 0xffffu, p0);
     ans_u_push(head, s, x >> 16, p1);
-    ans_u_push(head, s, 0u, 0u);
-    ans_u_push(head, s, 0u, 0u);
+    // slices 2 and 3 (precision 0, symbol 0): "if (head >= 2^63) push", twice; after one push head < 2^31, so the
+    // second test can only fire when the first did not.  Only reachable through the carry quirk (x >= 2^P).
+    uint32_t top;
+    asm volatile("s_lshr_b32 %0, %1, 31" : "=s"(top) : "s"((uint32_t)(head >> 32)));
+    if (__builtin_expect(top != 0u, 0)) {
+        ans_u_push(head, s, 0u, 0u);
+        ans_u_push(head, s, 0u, 0u);
+    }
 }
 // codec.cpp:107-121 : slices high -> low
 __device__ __forceinline__ uint32_t ans_id_pop(uint64_t &head, WStack &s, uint32_t p0, uint32_t p1) {
@@ -203,36 +237,38 @@ __device__ __forceinline__ uint32_t ans_idx_pop(uint64_t &head, WStack &s, uint3
     head = q;
     return r;
 }
-// Same, with the reciprocal kept per lane (lane t64 owns the divisor of this step): every lane multiplies the
-// wave-uniform h0 by ITS reciprocal with v_mad_u64_u32 and the owner's product is read back with v_readlane.
-__device__ __forceinline__ uint32_t ans_idx_pop_v(uint64_t &head, WStack &s, uint32_t nmax, uint32_t thr,
-                                                  uint32_t m_lo, uint32_t m_hi, uint32_t t64) {
+// Same, with the reciprocal kept per lane (lane t64 owns the divisor of this step): every lane divides the
+// wave-uniform h0 by ITS divisor d (multiply by its reciprocal with v_mad_u64_u32, remainder and correction on
+// the VALU); only the owner's quotient / remainder are read back.  Returns k as a uniform VGPR value.
+__device__ __forceinline__ uint32_t ans_idx_pop_v(uint64_t &head, WStack &s, uint32_t nmax, uint32_t thrm1,
+                                                  uint32_t d_lane, uint32_t m_lo, uint32_t m_hi, uint32_t t64) {
     uint64_t h0 = head;
     const uint32_t h_hi = (uint32_t)(h0 >> 32);
-    if (__builtin_expect(h_hi >= thr || (h_hi | ((uint32_t)h0 >> 31)) == 0u, 0)) {  // rare: renormalisation
-        if (h_hi >= thr) {
+    // rare renormalisation cases in ONE unsigned compare: h_hi >= thr, or h_hi == 0 (needed for h0 < 2^31)
+    if (__builtin_expect(h_hi - 1u >= thrm1, 0)) {
+        const uint32_t thr = thrm1 + 1u;
+        if (h_hi >= thr) {  // h0 >= nmax * ((L / nmax) << 32)
             ws_push(s, (uint32_t)h0);
             h0 >>= 32;
         }
         uint64_t q = h0 / nmax;
         uint32_t r = (uint32_t)(h0 - q * nmax);
-        if (lt_2p31(h0)) q = (uint64_t)ws_pop(s) | (q << 32);
+        if (lt_2p31(h0)) q = (uint64_t)ws_pop(s) | (q << 32);  // the test is on h0 (codec.cpp:35)
         head = q;
-        return rfl(r);
+        return to_v(rfl(r));
     }
     const uint32_t a0 = (uint32_t)h0, a1 = h_hi;
     // mulhi64(h0, m) = a1*m1 + hi(a1*m0) + hi(a0*m1) + carry(lo(a1*m0) + lo(a0*m1) + hi(a0*m0))
     const uint64_t t0 = (uint64_t)a0 * m_lo;
     const uint64_t t1 = (uint64_t)a0 * m_hi + (t0 >> 32);
     const uint64_t t2 = (uint64_t)a1 * m_lo + (uint32_t)t1;
-    const uint64_t qv = (uint64_t)a1 * m_hi + (t1 >> 32) + (t2 >> 32);
-    uint64_t q = rl64((uint32_t)qv, (uint32_t)(qv >> 32), t64);
-    uint32_t r = a0 - (uint32_t)q * nmax;
-    const uint32_t ge = (uint32_t)(((uint64_t)r - (uint64_t)nmax) >> 63) ^ 1u;  // 1 iff r >= nmax
-    r -= nmax & (0u - ge);
-    q += ge;
-    head = q;
-    return r;
+    uint64_t qv = (uint64_t)a1 * m_hi + (t1 >> 32) + (t2 >> 32);
+    uint32_t rv = a0 - (uint32_t)qv * d_lane;
+    const bool fix = rv >= d_lane;
+    rv = fix ? rv - d_lane : rv;
+    qv = fix ? qv + 1 : qv;
+    head = rl64((uint32_t)qv, (uint32_t)(qv >> 32), t64);
+    return to_v(rl(rv, t64));
 }
 // codec.cpp:44-63 : lq = floor(2^31 / nmax)
 __device__ __forceinline__ void ans_idx_push(uint64_t &head, WStack &s, uint32_t sym, uint32_t nmax, uint32_t lq) {
