@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_u(RocDecArgs a) {
     v32u rows;
 #pragma unroll
     for (int c = 0; c < 32; c++) rows[c] = 0u;
-    uint32_t P1 = 0;
+    uint32_t P1x = 0;  // lane c: decoded elements in blocks 0..c-1 (exclusive prefix)
     uint32_t *dups = a.slots + rfl64(a.slots_off[wi]);  // capacity n
     uint32_t ndup = 0;
     uint32_t ring = 0, lq = 0;
@@ -238,10 +238,9 @@ __global__ void __launch_bounds__(64) k_roc_decode_u(RocDecArgs a) {
             const uint32_t e = x >> ESH;
             const uint32_t c = e >> ENT_SH, t = e & (U::ENT - 1u);
             const uint32_t bit = x & 63u;
-            const uint32_t prev1 = rl(P1, (c - 1u) & 63u);
             const uint32_t row = rows_get(rows, c);
-            const uint32_t prev2 = rl(row, (t - 1u) & 63u);
-            uint32_t r = (c ? prev1 : 0u) + (t ? prev2 : 0u);
+            // the partial ranks are summed on the VALU (uniform VGPR value, see to_v())
+            uint32_t r = to_v(rl(P1x, c)) + rl(lane_shr1(row), t);
             const uint32_t wb = x >> 6;
             uint64_t W;
             if (U::G == 1) {
@@ -252,8 +251,8 @@ __global__ void __launch_bounds__(64) k_roc_decode_u(RocDecArgs a) {
                 const uint32_t l4 = lane & 3u;
                 const uint64_t wv = bm[(wb & ~3u) + l4];
                 const uint64_t below = l4 < wsel ? ~0ull : (l4 == wsel ? ((1ull << bit) - 1ull) : 0ull);
-                const uint32_t pc = popc64(wv & below);
-                r += rl(pc, 0) + rl(pc, 1) + rl(pc, 2) + rl(pc, 3);
+                const uint32_t pc = prefix4(popc64(wv & below));  // lane 3: bits below x in the 4 words
+                r += rl(pc, 3);
                 W = rl64((uint32_t)wv, (uint32_t)(wv >> 32), wsel);
             }
             const bool isdup = (W >> bit) & 1ull;
@@ -264,9 +263,9 @@ __global__ void __launch_bounds__(64) k_roc_decode_u(RocDecArgs a) {
                     r += popc64(ballot(jj < ndup && (z >> ESH) == e && z < x));
                 }
             }
-            ans_idx_push(head, st, r, i0 + t64 + 1u, rl(lq, t64));
+            ans_idx_push(head, st, rfl(r), i0 + t64 + 1u, rl(lq, t64));
             // insert x
-            P1 += lane >= c ? 1u : 0u;
+            P1x += lane > c ? 1u : 0u;
             rows_add(rows, c, (lane >= t && lane < U::ENT) ? 1u : 0u);
             if (__builtin_expect(isdup, 0)) {
                 if (lane == 0) dups[ndup] = x;

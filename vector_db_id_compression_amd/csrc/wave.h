@@ -212,8 +212,12 @@ __device__ __forceinline__ void ans_id_push(uint64_t &head, WStack &s, uint32_t 
 }
 // codec.cpp:107-121 : slices high -> low
 __device__ __forceinline__ uint32_t ans_id_pop(uint64_t &head, WStack &s, uint32_t p0, uint32_t p1) {
-    (void)ans_u_pop(head, s, 0u);
-    (void)ans_u_pop(head, s, 0u);
+    // slices 3 and 2 (precision 0) only test "head < 2^31 -> refill"; a refill makes head >= 2^31, so one test
+    // covers both unless the first refill happened (then the second slice is evaluated normally)
+    if (__builtin_expect(lt_2p31(head), 0)) {
+        (void)ans_u_pop(head, s, 0u);
+        (void)ans_u_pop(head, s, 0u);
+    }
     uint32_t hi = ans_u_pop(head, s, p1);
     uint32_t lo = ans_u_pop(head, s, p0);
     return (hi << 16) | lo;
