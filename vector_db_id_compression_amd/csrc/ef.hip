@@ -12,6 +12,7 @@
 #include <numeric>
 
 #include "bits.h"
+#include "chunks.h"
 #include "common.h"
 #include "wave.h"
 
@@ -26,6 +27,15 @@ struct vidc_ef {
     std::vector<uint32_t> lbits;
     DevBuf<uint64_t> d_offsets, d_low_off, d_high_off, d_low, d_high, d_universe;
     DevBuf<uint32_t> d_lbits, d_perm;
+    DevBuf<Chunk> d_chunks;
+    uint64_t nchunks = 0;
+    // select directory (the role of succinct's darray1): ones before every batch of 64 high words, so that bulk
+    // decode and select work per (list, batch) instead of scanning a list from its start
+    std::vector<uint64_t> batch_off;    // nlist + 1
+    DevBuf<uint64_t> d_batch_off;
+    DevBuf<uint32_t> d_hrank;           // [total batches]
+    DevBuf<Chunk> d_batches;            // (list, batch number) work items of decode_all
+    uint64_t nbatches = 0;
     bool has_perm = false;
 };
 
@@ -37,17 +47,20 @@ struct PrepOut {
     uint32_t pad;
 };
 
-// one wavefront per list: max id and "is non-decreasing"
-__global__ void __launch_bounds__(64) k_ef_prep(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist,
-                                                PrepOut *outp) {
+// one wavefront per chunk: max id and "is non-decreasing" (merged per list with atomics; outp zero-initialised)
+__global__ void __launch_bounds__(64) k_ef_prep(const uint64_t *ids, const uint64_t *offsets, const Chunk *chunks,
+                                                uint64_t nchunks, PrepOut *outp) {
     const uint32_t lane = lane_id();
-    for (uint32_t l = blockIdx.x; l < nlist; l += gridDim.x) {
-        const uint64_t off = offsets[l];
-        const uint64_t n = offsets[l + 1] - off;
+    for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const Chunk ch = chunks[c];
+        const uint64_t off = offsets[ch.list];
+        const uint64_t n = offsets[ch.list + 1] - off;
+        const uint32_t nc = (uint32_t)(n - ch.start < CHUNK_IDS ? n - ch.start : CHUNK_IDS);
         uint64_t mx = 0;
         bool uns = false;
-        for (uint64_t j = lane; j < n; j += 64) {
-            uint64_t v = ids[off + j];
+        for (uint32_t i = lane; i < nc; i += 64) {
+            const uint64_t j = ch.start + i;
+            const uint64_t v = ids[off + j];
             if (j) uns |= ids[off + j - 1] > v;
             mx = v > mx ? v : mx;
         }
@@ -60,8 +73,8 @@ __global__ void __launch_bounds__(64) k_ef_prep(const uint64_t *ids, const uint6
         }
         const uint64_t any_uns = ballot(uns);  // all lanes vote (not inside the lane-0 branch)
         if (lane == 0) {
-            outp[l].max_id = mx;
-            outp[l].unsorted = any_uns ? 1u : 0u;
+            atomicMax((unsigned long long *)&outp[ch.list].max_id, (unsigned long long)mx);
+            if (any_uns) atomicOr(&outp[ch.list].unsorted, 1u);
         }
     }
 }
@@ -116,42 +129,109 @@ __global__ void k_iota_perm(const uint64_t *offsets, uint32_t nlist, uint64_t nt
     }
 }
 
-// low stream: one owner thread per 64-bit word
-__global__ void k_ef_low(const uint64_t *sorted_ids, const uint64_t *offsets, const uint64_t *low_off,
-                         const uint32_t *lbits, uint32_t nlist, uint64_t total_words, uint64_t *low) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total_words; w += stride) {
-        const uint32_t l = find_list(low_off, nlist, w);
-        const uint32_t b = lbits[l];
-        const uint64_t n = offsets[l + 1] - offsets[l];
-        const uint64_t keep = b ? ((1ull << b) - 1ull) : 0ull;
-        low[w] = gather_word<false>(sorted_ids + offsets[l], n, w - low_off[l], b, keep, ~0ull, nullptr);
+// low stream: one wavefront per chunk, one owner lane per 64-bit word (CHUNK_IDS * l is a multiple of 64)
+__global__ void __launch_bounds__(64) k_ef_low(const uint64_t *sorted_ids, const uint64_t *offsets,
+                                               const uint64_t *low_off, const uint32_t *lbits, const Chunk *chunks,
+                                               uint64_t nchunks, uint64_t *low) {
+    const uint32_t lane = lane_id();
+    for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const Chunk ch = chunks[c];
+        const uint32_t b = lbits[ch.list];
+        if (!b) continue;
+        const uint64_t off = offsets[ch.list];
+        const uint64_t n = offsets[ch.list + 1] - off;
+        const uint64_t nc = n - ch.start < CHUNK_IDS ? n - ch.start : CHUNK_IDS;
+        const uint64_t keep = (1ull << b) - 1ull;
+        const uint64_t w0 = (uint64_t)ch.start * b / 64, w1 = ((uint64_t)(ch.start + nc) * b + 63) / 64;
+        uint64_t *dst = low + low_off[ch.list];
+        for (uint64_t w = w0 + lane; w < w1; w += 64)
+            dst[w] = gather_word<false>(sorted_ids + off, n, w, b, keep, ~0ull, nullptr);
     }
 }
 
-// high stream: one thread per element sets bit (x >> l) + i
-__global__ void k_ef_high(const uint64_t *sorted_ids, const uint64_t *offsets, const uint64_t *high_off,
-                          const uint32_t *lbits, uint32_t nlist, uint64_t ntotal, uint64_t *high) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ntotal; g += stride) {
-        const uint32_t l = find_list(offsets, nlist, g);
-        const uint64_t i = g - offsets[l];
-        const uint64_t pos = (sorted_ids[g] >> lbits[l]) + i;
-        atomicOr((unsigned long long *)&high[high_off[l] + (pos >> 6)], 1ull << (pos & 63));
+// high stream: one wavefront per chunk.  Bit positions (x >> l) + i increase strictly with i, so the chunk covers a
+// contiguous bit range that only shares its first and last WORD with neighbouring chunks: the bits are assembled
+// in an LDS window (ds_or) and written with plain stores, global atomics only for the two boundary words.
+#define EF_WIN_WORDS 128u
+__global__ void __launch_bounds__(64) k_ef_high(const uint64_t *sorted_ids, const uint64_t *offsets,
+                                                const uint64_t *high_off, const uint32_t *lbits, const Chunk *chunks,
+                                                uint64_t nchunks, uint64_t *high) {
+    __shared__ unsigned long long win[EF_WIN_WORDS];
+    const uint32_t lane = lane_id();
+    for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const Chunk ch = chunks[c];
+        const uint32_t b = lbits[ch.list];
+        const uint64_t off = offsets[ch.list];
+        const uint64_t n = offsets[ch.list + 1] - off;
+        const uint32_t nc = (uint32_t)(n - ch.start < CHUNK_IDS ? n - ch.start : CHUNK_IDS);
+        unsigned long long *dst = (unsigned long long *)(high + high_off[ch.list]);
+        const uint64_t wf = ((sorted_ids[off + ch.start] >> b) + ch.start) >> 6;
+        const uint64_t wl = ((sorted_ids[off + ch.start + nc - 1] >> b) + (ch.start + nc - 1)) >> 6;
+        uint64_t pos[CHUNK_IDS / 64];
+#pragma unroll
+        for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
+            const uint32_t i = lane + 64 * r;
+            pos[r] = i < nc ? (sorted_ids[off + ch.start + i] >> b) + (ch.start + i) : ~0ull;
+        }
+        for (uint64_t wbase = wf; wbase <= wl; wbase += EF_WIN_WORDS) {
+            win[lane] = 0;
+            win[lane + 64] = 0;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
+                const uint64_t w = pos[r] >> 6;
+                if (pos[r] != ~0ull && w >= wbase && w - wbase < EF_WIN_WORDS)
+                    atomicOr(&win[w - wbase], 1ull << (pos[r] & 63));
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t t = 0; t < 2; t++) {
+                const uint32_t k = lane + 64 * t;
+                const uint64_t w = wbase + k;
+                const unsigned long long v = win[k];
+                if (v && w <= wl) {
+                    if (w == wf || w == wl) atomicOr(&dst[w], v);
+                    else dst[w] = v;
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
-// bulk decode: one wavefront per list, 64 high words per iteration (select_enumerator, elias_fano.hpp:210-261).
-// worklist == nullptr: every list, output at offsets[l].  Otherwise work item wi decodes list worklist[wi] to
-// out_off[wi] (uint64 output) or to row wi of an int32 [nwork, K] matrix padded with -1 (graph flavour).
+// select directory: hrank[item] = number of elements whose high bit lies before batch `b` of list `l`
+// = first j with (x_j >> l) + j >= 4096 * b  (positions increase with j: binary search, no scan)
+__global__ void k_ef_hrank(const uint64_t *sorted_ids, const uint64_t *offsets, const uint32_t *lbits,
+                           const Chunk *batches, uint64_t nbatches, uint32_t *hrank) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < nbatches; it += stride) {
+        const Chunk bt = batches[it];
+        const uint64_t off = offsets[bt.list];
+        const uint64_t n = offsets[bt.list + 1] - off;
+        const uint32_t b = lbits[bt.list];
+        const uint64_t target = (uint64_t)bt.start * 4096ull;
+        uint64_t lo = 0, hi = n;  // first j in [0, n] with pos_j >= target
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if ((sorted_ids[off + mid] >> b) + mid >= target) hi = mid; else lo = mid + 1;
+        }
+        hrank[it] = (uint32_t)lo;
+    }
+}
+
+// bulk decode (select_enumerator, elias_fano.hpp:210-261): one wavefront per batch of 64 high words.
+// items == nullptr: work item wi is list `worklist[wi]` (or wi) decoded batch by batch by one wave (used for
+// the graph rows and short selections); otherwise items[wi] = (list, batch) and every batch is independent.
 __global__ void __launch_bounds__(64) k_ef_decode(const uint64_t *low, const uint64_t *high, const uint64_t *offsets,
                                                   const uint64_t *low_off, const uint64_t *high_off,
-                                                  const uint32_t *lbits, uint32_t nwork, const uint64_t *worklist,
-                                                  const uint64_t *out_off, uint64_t *out, int32_t *out_rows,
-                                                  uint32_t K) {
+                                                  const uint32_t *lbits, const uint64_t *batch_off,
+                                                  const uint32_t *hrank, uint32_t nwork, const Chunk *items,
+                                                  const uint64_t *worklist, const uint64_t *out_off, uint64_t *out,
+                                                  int32_t *out_rows, uint32_t K) {
+    __shared__ uint64_t stage[1024];  // values of one batch, in rank order, for coalesced stores
     const uint32_t lane = lane_id();
     for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const uint64_t l = worklist ? worklist[wi] : wi;
+        const uint64_t l = items ? items[wi].list : (worklist ? worklist[wi] : wi);
         const uint64_t off = out_rows ? (uint64_t)wi * K : (out_off ? out_off[wi] : offsets[l]);
         const uint64_t m = offsets[l + 1] - offsets[l];
         if (out_rows) {
@@ -163,29 +243,42 @@ __global__ void __launch_bounds__(64) k_ef_decode(const uint64_t *low, const uin
         const uint64_t *lw = low + low_off[l];
         const uint64_t *hw = high + high_off[l];
         const uint64_t nhw = high_off[l + 1] - high_off[l];
-        uint64_t done = 0;
-        for (uint64_t w0 = 0; w0 < nhw && done < m; w0 += 64) {
-            const uint64_t wi64 = w0 + lane;
+        const uint64_t nb = batch_off[l + 1] - batch_off[l];
+        const uint64_t b_first = items ? items[wi].start : 0, b_last = items ? b_first + 1 : nb;
+        for (uint64_t bt = b_first; bt < b_last; bt++) {
+            const uint64_t done = hrank[batch_off[l] + bt];
+            if (done >= m) break;
+            const uint64_t wi64 = bt * 64 + lane;
             uint64_t word = wi64 < nhw ? hw[wi64] : 0ull;
             uint32_t c = popc64(word);
-            // inclusive prefix sum over the 64 lanes
-            uint32_t incl = c;
+            uint32_t incl = c;  // inclusive prefix sum over the 64 lanes
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
                 if (lane >= (uint32_t)o) incl += v;
             }
             uint64_t rank = done + (incl - c);
+            const uint32_t tot = rl(incl, 63);
+            const bool staged = tot <= 1024u;  // wave-uniform
             while (word && rank < m) {
                 const uint32_t bit = (uint32_t)__builtin_ctzll(word);
                 word &= word - 1;
                 const uint64_t pos = wi64 * 64 + bit;
                 const uint64_t val = ((pos - rank) << b) | read_bits(lw, rank * b, b);
-                if (out_rows) out_rows[off + rank] = (int32_t)val;
+                if (staged) stage[rank - done] = val;
+                else if (out_rows) out_rows[off + rank] = (int32_t)val;
                 else out[off + rank] = val;
                 rank++;
             }
-            done += rl(incl, 63);
+            if (staged) {
+                __syncthreads();
+                const uint64_t cnt = done + tot < m ? tot : m - done;
+                for (uint32_t t = lane; t < cnt; t += 64) {
+                    if (out_rows) out_rows[off + done + t] = (int32_t)stage[t];
+                    else out[off + done + t] = stage[t];
+                }
+                __syncthreads();
+            }
         }
     }
 }
@@ -222,9 +315,11 @@ __global__ void __launch_bounds__(64) k_rows_sorted(const int32_t *rows, uint64_
     }
 }
 
-// random access (ef->select(offset), elias_fano.hpp:141-145): one wavefront per query scans the high words
+// random access (ef->select(offset), elias_fano.hpp:141-145): one wavefront per query; the select directory
+// gives the batch of 64 high words holding the wanted one, a prefix scan of popcounts finds the word
 __global__ void __launch_bounds__(64) k_ef_get(const uint64_t *low, const uint64_t *high, const uint64_t *low_off,
-                                               const uint64_t *high_off, const uint32_t *lbits, uint64_t m,
+                                               const uint64_t *high_off, const uint32_t *lbits,
+                                               const uint64_t *batch_off, const uint32_t *hrank, uint64_t m,
                                                const uint64_t *list_nos, const uint64_t *offs, int64_t *out) {
     const uint32_t lane = lane_id();
     for (uint64_t q = blockIdx.x; q < m; q += gridDim.x) {
@@ -233,34 +328,33 @@ __global__ void __launch_bounds__(64) k_ef_get(const uint64_t *low, const uint64
         const uint32_t b = lbits[l];
         const uint64_t *hw = high + high_off[l];
         const uint64_t nhw = high_off[l + 1] - high_off[l];
-        uint64_t seen = 0;
-        int64_t res = -1;
-        for (uint64_t w0 = 0; w0 < nhw; w0 += 64) {
-            const uint64_t wi = w0 + lane;
-            const uint64_t word = wi < nhw ? hw[wi] : 0ull;
-            const uint32_t c = popc64(word);
-            uint32_t incl = c;
+        const uint32_t *hr = hrank + batch_off[l];
+        const uint64_t nb = batch_off[l + 1] - batch_off[l];
+        uint64_t lo = 0, hi = nb;  // largest batch with hrank <= i
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (hr[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint64_t w0 = lo * 64;
+        const uint64_t wi = w0 + lane;
+        const uint64_t word = wi < nhw ? hw[wi] : 0ull;
+        const uint32_t c = popc64(word);
+        uint32_t incl = c;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
-                if (lane >= (uint32_t)o) incl += v;
-            }
-            const uint32_t tot = rl(incl, 63);
-            if (seen + tot > i) {
-                const uint64_t need = i - seen;  // 0-based inside this chunk
-                const uint64_t hit = ballot((uint64_t)incl > need);
-                const uint32_t wl_ = ff1(hit);
-                // lane wl_ owns the word; k-th set bit inside it
-                const uint32_t before = rl(incl, wl_) - rl(c, wl_);
-                uint32_t k = (uint32_t)need - before;
-                uint32_t wlo = rl((uint32_t)word, wl_), whi = rl((uint32_t)(word >> 32), wl_);
-                uint64_t ww = ((uint64_t)whi << 32) | wlo;
-                for (; k; k--) ww &= ww - 1;
-                const uint64_t pos = (w0 + wl_) * 64 + (uint32_t)__builtin_ctzll(ww);
-                res = (int64_t)(((pos - i) << b) | read_bits(low + low_off[l], i * b, b));
-                break;
-            }
-            seen += tot;
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+            if (lane >= (uint32_t)o) incl += v;
+        }
+        const uint64_t need = i - hr[lo];  // 0-based inside this batch
+        const uint64_t hit = ballot((uint64_t)incl > need);
+        int64_t res = -1;
+        if (hit) {
+            const uint32_t wl_ = ff1(hit);  // lane wl_ owns the word; k-th set bit inside it
+            uint32_t k = (uint32_t)need - (rl(incl, wl_) - rl(c, wl_));
+            uint64_t ww = rl64((uint32_t)word, (uint32_t)(word >> 32), wl_);
+            for (; k; k--) ww &= ww - 1;
+            const uint64_t pos = (w0 + wl_) * 64 + (uint32_t)__builtin_ctzll(ww);
+            res = (int64_t)(((pos - i) << b) | read_bits(low + low_off[l], i * b, b));
         }
         if (lane == 0) out[q] = res;
     }
@@ -305,14 +399,25 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
         return VIDC_OK;
     };
 
+    {
+        std::vector<Chunk> chunks = build_chunks(e->offsets);
+        e->nchunks = chunks.size();
+        VIDC_TRY(e->d_chunks.alloc(chunks.size() ? chunks.size() : 1));
+        if (!chunks.empty())
+            VIDC_HIP(hipMemcpyAsync(e->d_chunks.p, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice,
+                                    ctx->stream));
+        VIDC_HIP(hipStreamSynchronize(ctx->stream));  // `chunks` is a local host buffer
+    }
+    const uint32_t cgrid = (uint32_t)std::min<uint64_t>(e->nchunks ? e->nchunks : 1, (uint64_t)ctx->num_cu * 256);
     // pass 1: universe (max id) and sortedness per list
     std::vector<PrepOut> prep(nlist);
     Scratch s_prep;
     VIDC_TRY(s_prep.get(ctx, nlist * sizeof(PrepOut)));
     if (nlist) {
+        VIDC_HIP(hipMemsetAsync(s_prep.p, 0, nlist * sizeof(PrepOut), ctx->stream));
         VIDC_TRY(timed([&] {
-            hipLaunchKernelGGL(k_ef_prep, dim3((uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 64)), dim3(64),
-                               0, ctx->stream, d_ids, e->d_offsets.p, (uint32_t)nlist, s_prep.as<PrepOut>());
+            hipLaunchKernelGGL(k_ef_prep, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, e->d_offsets.p, e->d_chunks.p,
+                               e->nchunks, s_prep.as<PrepOut>());
         }));
         VIDC_HIP(hipMemcpyAsync(prep.data(), s_prep.p, nlist * sizeof(PrepOut), hipMemcpyDeviceToHost, ctx->stream));
         VIDC_HIP(hipStreamSynchronize(ctx->stream));
@@ -391,15 +496,39 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     }
     // pass 3: the two bit streams
     if (e->ntotal) {
-        uint64_t lw = e->low_off[nlist];
-        uint32_t g1 = (uint32_t)std::min<uint64_t>((lw + 255) / 256, (uint64_t)ctx->num_cu * 32);
-        uint32_t g2 = (uint32_t)std::min<uint64_t>((e->ntotal + 255) / 256, (uint64_t)ctx->num_cu * 32);
+        VIDC_HIP(hipMemsetAsync(e->d_low.p, 0, (e->low_off[nlist] ? e->low_off[nlist] : 1) * 8, ctx->stream));
         VIDC_TRY(timed([&] {
-            hipLaunchKernelGGL(k_ef_low, dim3(g1 ? g1 : 1), dim3(256), 0, ctx->stream, d_sorted, e->d_offsets.p,
-                               e->d_low_off.p, e->d_lbits.p, (uint32_t)nlist, lw, e->d_low.p);
-            hipLaunchKernelGGL(k_ef_high, dim3(g2), dim3(256), 0, ctx->stream, d_sorted, e->d_offsets.p, e->d_high_off.p,
-                               e->d_lbits.p, (uint32_t)nlist, e->ntotal, e->d_high.p);
+            hipLaunchKernelGGL(k_ef_low, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p, e->d_low_off.p,
+                               e->d_lbits.p, e->d_chunks.p, e->nchunks, e->d_low.p);
+            hipLaunchKernelGGL(k_ef_high, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p,
+                               e->d_high_off.p, e->d_lbits.p, e->d_chunks.p, e->nchunks, e->d_high.p);
         }));
+    }
+    // select directory
+    {
+        e->batch_off.assign(nlist + 1, 0);
+        std::vector<Chunk> batches;
+        for (uint64_t l = 0; l < nlist; l++) {
+            const uint64_t hw = e->high_off[l + 1] - e->high_off[l];
+            const uint64_t nb = (hw + 63) / 64;
+            e->batch_off[l + 1] = e->batch_off[l] + nb;
+            for (uint64_t bt = 0; bt < nb; bt++) batches.push_back(Chunk{(uint32_t)l, (uint32_t)bt});
+        }
+        e->nbatches = batches.size();
+        VIDC_TRY(e->d_batch_off.alloc(nlist + 1));
+        VIDC_TRY(e->d_batches.alloc(e->nbatches ? e->nbatches : 1));
+        VIDC_TRY(e->d_hrank.alloc(e->nbatches ? e->nbatches : 1));
+        VIDC_HIP(hipMemcpyAsync(e->d_batch_off.p, e->batch_off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (e->nbatches) {
+            VIDC_HIP(hipMemcpyAsync(e->d_batches.p, batches.data(), e->nbatches * sizeof(Chunk), hipMemcpyHostToDevice,
+                                    ctx->stream));
+            VIDC_TRY(timed([&] {
+                hipLaunchKernelGGL(k_ef_hrank, dim3((uint32_t)std::min<uint64_t>((e->nbatches + 255) / 256, 4096)), dim3(256),
+                                   0, ctx->stream, d_sorted, e->d_offsets.p, e->d_lbits.p, e->d_batches.p, e->nbatches,
+                                   e->d_hrank.p);
+            }));
+        }
+        VIDC_HIP(hipStreamSynchronize(ctx->stream));  // `batches` is a local host buffer
     }
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->last_kernel_ms = kernel_ms;
@@ -427,10 +556,12 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
     if (!e->ntotal) return VIDC_OK;
     VIDC_HIP(hipSetDevice(ctx->device));
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_ef_decode, dim3((uint32_t)std::min<uint64_t>(e->nlist, (uint64_t)ctx->num_cu * 64)), dim3(64), 0,
-                       ctx->stream, e->d_low.p, e->d_high.p, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p,
-                       e->d_lbits.p, (uint32_t)e->nlist, (const uint64_t *)nullptr, (const uint64_t *)nullptr, d_out,
-                       (int32_t *)nullptr, 0u);
+    if (e->nbatches)
+        hipLaunchKernelGGL(k_ef_decode, dim3((uint32_t)std::min<uint64_t>(e->nbatches, (uint64_t)ctx->num_cu * 256)),
+                           dim3(64), 0, ctx->stream, e->d_low.p, e->d_high.p, e->d_offsets.p, e->d_low_off.p,
+                           e->d_high_off.p, e->d_lbits.p, e->d_batch_off.p, e->d_hrank.p, (uint32_t)e->nbatches,
+                           e->d_batches.p, (const uint64_t *)nullptr, (const uint64_t *)nullptr, d_out,
+                           (int32_t *)nullptr, 0u);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
@@ -453,8 +584,8 @@ static int ef_decode_some(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uin
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(k_ef_decode, dim3((uint32_t)std::min<uint64_t>(m, (uint64_t)ctx->num_cu * 64)), dim3(64), 0,
                        ctx->stream, e->d_low.p, e->d_high.p, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p,
-                       e->d_lbits.p, (uint32_t)m, s_l.as<uint64_t>(), out_off_host ? s_o.as<uint64_t>() : nullptr, d_out,
-                       d_rows, K);
+                       e->d_lbits.p, e->d_batch_off.p, e->d_hrank.p, (uint32_t)m, (const Chunk *)nullptr,
+                       s_l.as<uint64_t>(), out_off_host ? s_o.as<uint64_t>() : nullptr, d_out, d_rows, K);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
@@ -538,8 +669,8 @@ int vidc_ef_get(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *lis
     VIDC_HIP(hipMemcpyAsync(s_l.p, list_nos, m * 8, hipMemcpyHostToDevice, ctx->stream));
     VIDC_HIP(hipMemcpyAsync(s_o.p, offs, m * 8, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_ef_get, dim3((uint32_t)std::min<uint64_t>(m, 1u << 20)), dim3(64), 0, ctx->stream, e->d_low.p,
-                       e->d_high.p, e->d_low_off.p, e->d_high_off.p, e->d_lbits.p, m, s_l.as<uint64_t>(),
-                       s_o.as<uint64_t>(), s_r.as<int64_t>());
+                       e->d_high.p, e->d_low_off.p, e->d_high_off.p, e->d_lbits.p, e->d_batch_off.p, e->d_hrank.p, m,
+                       s_l.as<uint64_t>(), s_o.as<uint64_t>(), s_r.as<int64_t>());
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipMemcpyAsync(ids_out, s_r.p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));

@@ -10,6 +10,7 @@
 #include <memory>
 
 #include "bits.h"
+#include "chunks.h"
 #include "common.h"
 
 using namespace vidc;
@@ -22,32 +23,44 @@ struct vidc_packed {
     uint64_t compressed_bytes = 0, total_words = 0;
     std::vector<uint64_t> offsets, word_off;
     DevBuf<uint64_t> d_offsets, d_word_off, d_words;
+    DevBuf<Chunk> d_chunks;
+    uint64_t nchunks = 0;
 };
 
 namespace {
 
-// one thread per 64-bit output word
-__global__ void k_packed_encode(const uint64_t *ids, const uint64_t *offsets, const uint64_t *word_off,
-                                uint32_t nlist, uint64_t total_words, uint32_t bits, uint64_t id_limit,
-                                uint64_t *words, uint32_t *err) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total_words; w += stride) {
-        const uint32_t l = find_list(word_off, nlist, w);
-        const uint64_t n = offsets[l + 1] - offsets[l];
-        const uint64_t *src = ids + offsets[l];
-        const uint64_t keep = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
-        const uint64_t out = gather_word<true>(src, n, w - word_off[l], bits, keep, id_limit, err);
-        words[w] = out;
+// one wavefront per chunk of CHUNK_IDS ids; each lane owns whole 64-bit output words (no atomics, no search)
+__global__ void __launch_bounds__(64) k_packed_encode(const uint64_t *ids, const uint64_t *offsets,
+                                                      const uint64_t *word_off, const Chunk *chunks, uint64_t nchunks,
+                                                      uint32_t bits, uint64_t id_limit, uint64_t *words, uint32_t *err) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t keep = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+    for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const Chunk ch = chunks[c];
+        const uint64_t off = offsets[ch.list];
+        const uint64_t n = offsets[ch.list + 1] - off;
+        const uint64_t nc = n - ch.start < CHUNK_IDS ? n - ch.start : CHUNK_IDS;
+        const uint64_t w0 = (uint64_t)ch.start * bits / 64;                       // exact: start * bits % 64 == 0
+        const uint64_t w1 = ((uint64_t)(ch.start + nc) * bits + 63) / 64;
+        uint64_t *dst = words + word_off[ch.list];
+        for (uint64_t w = w0 + lane; w < w1; w += 64) dst[w] = gather_word<true>(ids + off, n, w, bits, keep, id_limit, err);
     }
 }
 
-// one thread per id
-__global__ void k_packed_decode(const uint64_t *words, const uint64_t *offsets, const uint64_t *word_off,
-                                uint32_t nlist, uint64_t ntotal, uint32_t bits, uint64_t *out) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ntotal; g += stride) {
-        const uint32_t l = find_list(offsets, nlist, g);
-        out[g] = read_bits(words + word_off[l], (g - offsets[l]) * bits, bits);
+// one wavefront per chunk: lane t decodes ids t, t+64, ... (coalesced 8-byte stores)
+__global__ void __launch_bounds__(64) k_packed_decode(const uint64_t *words, const uint64_t *offsets,
+                                                      const uint64_t *word_off, const Chunk *chunks, uint64_t nchunks,
+                                                      uint32_t bits, uint64_t *out) {
+    const uint32_t lane = threadIdx.x;
+    for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const Chunk ch = chunks[c];
+        const uint64_t off = offsets[ch.list];
+        const uint64_t n = offsets[ch.list + 1] - off;
+        const uint32_t nc = (uint32_t)(n - ch.start < CHUNK_IDS ? n - ch.start : CHUNK_IDS);
+        const uint64_t *src = words + word_off[ch.list];
+        uint64_t *dst = out + off + ch.start;
+#pragma unroll 4
+        for (uint32_t i = lane; i < nc; i += 64) dst[i] = read_bits(src, (uint64_t)(ch.start + i) * bits, bits);
     }
 }
 
@@ -219,6 +232,15 @@ int vidc_packed_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, c
     }
     p->total_words = p->word_off[nlist];
     if (p->ntotal && !d_ids) return VIDC_ERR_INVALID;
+    {
+        std::vector<Chunk> chunks = build_chunks(p->offsets);
+        p->nchunks = chunks.size();
+        VIDC_TRY(p->d_chunks.alloc(chunks.size() ? chunks.size() : 1));
+        if (!chunks.empty())
+            VIDC_HIP(hipMemcpyAsync(p->d_chunks.p, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice,
+                                    ctx->stream));
+        VIDC_HIP(hipStreamSynchronize(ctx->stream));  // `chunks` is a local host buffer
+    }
     VIDC_TRY(p->d_offsets.alloc(nlist + 1));
     VIDC_TRY(p->d_word_off.alloc(nlist + 1));
     VIDC_TRY(p->d_words.alloc(p->total_words ? p->total_words : 1));
@@ -229,13 +251,14 @@ int vidc_packed_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, c
     VIDC_HIP(hipMemsetAsync(s_err.p, 0, 4, ctx->stream));
     if (p->total_words) {
         VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-        uint64_t blocks = (p->total_words + 255) / 256;
-        uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)ctx->num_cu * 32);
+        VIDC_HIP(hipMemsetAsync(p->d_words.p, 0, p->total_words * 8, ctx->stream));  // padding words
+        uint32_t grid = (uint32_t)std::min<uint64_t>(p->nchunks, (uint64_t)ctx->num_cu * 256);
         // ids must fit the field (FAISS_THROW_IF_NOT(ids_in[i] >= 0 && ids_in[i] < ntotal), :87)
         uint64_t limit = ~0ull;
-        hipLaunchKernelGGL(k_packed_encode, dim3(grid), dim3(256), 0, ctx->stream, d_ids, p->d_offsets.p,
-                           p->d_word_off.p, (uint32_t)nlist, p->total_words, (uint32_t)bits, limit, p->d_words.p,
-                           s_err.as<uint32_t>());
+        if (p->nchunks)
+            hipLaunchKernelGGL(k_packed_encode, dim3(grid), dim3(64), 0, ctx->stream, d_ids, p->d_offsets.p,
+                               p->d_word_off.p, p->d_chunks.p, p->nchunks, (uint32_t)bits, limit, p->d_words.p,
+                               s_err.as<uint32_t>());
         VIDC_HIP(hipGetLastError());
         VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     }
@@ -265,10 +288,9 @@ int vidc_packed_decode_all(vidc_ctx *ctx, const vidc_packed *p, uint64_t *d_out)
     if (!p->ntotal) return VIDC_OK;
     VIDC_HIP(hipSetDevice(ctx->device));
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    uint64_t blocks = (p->ntotal + 255) / 256;
-    uint32_t grid = (uint32_t)std::min<uint64_t>(blocks, (uint64_t)ctx->num_cu * 32);
-    hipLaunchKernelGGL(k_packed_decode, dim3(grid), dim3(256), 0, ctx->stream, p->d_words.p, p->d_offsets.p,
-                       p->d_word_off.p, (uint32_t)p->nlist, p->ntotal, (uint32_t)p->bits, d_out);
+    uint32_t grid = (uint32_t)std::min<uint64_t>(p->nchunks, (uint64_t)ctx->num_cu * 256);
+    hipLaunchKernelGGL(k_packed_decode, dim3(grid), dim3(64), 0, ctx->stream, p->d_words.p, p->d_offsets.p,
+                       p->d_word_off.p, p->d_chunks.p, p->nchunks, (uint32_t)p->bits, d_out);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
