@@ -78,7 +78,7 @@ def main():
     from vector_db_id_compression_amd import _lib, synth
     from vector_db_id_compression_amd.codecs import EfLists, PackedLists, RocLists
 
-    ctx = _lib.default_context(local_rank)
+    ctx = _lib.default_context(local_rank)  # bound to torch's current stream
     wl = synth.workload(args.workload, seed=42 + rank)
     offsets = wl["offsets"]
     ids_host = wl["ids"] if isinstance(wl["ids"], np.ndarray) else None

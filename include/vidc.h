@@ -45,8 +45,10 @@ typedef struct vidc_ctx vidc_ctx;
 /* device < 0 : current HIP device.  Creates the context's own stream. */
 int vidc_ctx_create(int device, vidc_ctx **out);
 void vidc_ctx_destroy(vidc_ctx *ctx);
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the own stream. */
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream).  NULL is the legacy default stream (what
+ * torch uses unless told otherwise); vidc_ctx_reset_stream goes back to the context's own stream. */
 int vidc_ctx_set_stream(vidc_ctx *ctx, void *hip_stream);
+int vidc_ctx_reset_stream(vidc_ctx *ctx);
 int vidc_ctx_synchronize(vidc_ctx *ctx);
 /* Device memory helpers for hosts without their own allocator (Python uses torch tensors instead). */
 int vidc_dev_alloc(vidc_ctx *ctx, size_t bytes, void **dev_ptr);

@@ -42,6 +42,7 @@ def _declare(lib):
     f("vidc_ctx_create", C.c_int, C.c_int, _P(_vp))
     f("vidc_ctx_destroy", None, _vp)
     f("vidc_ctx_set_stream", C.c_int, _vp, _vp)
+    f("vidc_ctx_reset_stream", C.c_int, _vp)
     f("vidc_ctx_synchronize", C.c_int, _vp)
     f("vidc_dev_alloc", C.c_int, _vp, C.c_size_t, _P(_vp))
     f("vidc_dev_free", C.c_int, _vp, _vp)
@@ -106,7 +107,7 @@ def _declare(lib):
 
 #: every symbol include/vidc.h declares (checked by the CPU test-suite against the built library)
 EXPORTED_SYMBOLS = [
-    "vidc_last_error", "vidc_version", "vidc_ctx_create", "vidc_ctx_destroy", "vidc_ctx_set_stream",
+    "vidc_last_error", "vidc_version", "vidc_ctx_create", "vidc_ctx_destroy", "vidc_ctx_set_stream", "vidc_ctx_reset_stream",
     "vidc_ctx_synchronize", "vidc_dev_alloc", "vidc_dev_free", "vidc_copy_h2d", "vidc_copy_d2h",
     "vidc_ctx_last_kernel_ms", "vidc_ctx_phase_ms",
     "vidc_roc_encode", "vidc_roc_encode_rows", "vidc_roc_destroy", "vidc_roc_nlist", "vidc_roc_ntotal",
@@ -202,4 +203,7 @@ def default_context(device=None):
         device = torch.cuda.current_device()
     if device not in _default_ctx:
         _default_ctx[device] = Context(device)
-    return _default_ctx[device]
+    ctx = _default_ctx[device]
+    # run on torch's CURRENT stream: tensors produced by torch ops are then ordered before the codec kernels
+    ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+    return ctx

@@ -54,7 +54,7 @@ class RocLists:
     # -- construction
     @classmethod
     def encode(cls, offsets, ids, precision_mode=VIDC_PREC_REFERENCE, want_perm=False, ctx=None):
-        ctx = ctx or _lib.default_context()
+        ctx = _lib.default_context() if ctx is None else ctx
         off = _as_offsets(offsets)
         nlist = off.size - 1
         d_ids = _dev_ids(ids, int(off[-1] - off[0])) if off[-1] > off[0] else None
@@ -68,7 +68,7 @@ class RocLists:
     def encode_rows(cls, rows, precision_mode=VIDC_PREC_REFERENCE, ctx=None):
         """rows: int32 CUDA tensor [N, K], -1 terminated (nsg::Graph<int32_t> layout)."""
         torch = _torch()
-        ctx = ctx or _lib.default_context()
+        ctx = _lib.default_context() if ctx is None else ctx
         if isinstance(rows, np.ndarray):
             rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).cuda()
         assert rows.is_cuda and rows.dtype == torch.int32 and rows.dim() == 2
@@ -84,7 +84,7 @@ class RocLists:
 
     @classmethod
     def from_streams(cls, offsets, precisions, heads, nwords, words_concat, mt_draws=None, ctx=None):
-        ctx = ctx or _lib.default_context()
+        ctx = _lib.default_context() if ctx is None else ctx
         off = _as_offsets(offsets)
         nlist = off.size - 1
         prec = np.ascontiguousarray(precisions, dtype=np.uint32)
@@ -190,7 +190,7 @@ class PackedLists:
 
     @classmethod
     def encode(cls, offsets, ids, bits=None, ctx=None):
-        ctx = ctx or _lib.default_context()
+        ctx = _lib.default_context() if ctx is None else ctx
         off = _as_offsets(offsets)
         ntotal = int(off[-1])
         if bits is None:
@@ -252,7 +252,7 @@ class EfLists:
 
     @classmethod
     def encode(cls, offsets, ids, want_perm=False, ctx=None):
-        ctx = ctx or _lib.default_context()
+        ctx = _lib.default_context() if ctx is None else ctx
         off = _as_offsets(offsets)
         ntotal = int(off[-1])
         d_ids = _dev_ids(ids, ntotal) if ntotal else None
@@ -300,7 +300,7 @@ class EfLists:
     def encode_rows(cls, rows, ctx=None):
         """rows: int32 CUDA tensor [N, K], -1 terminated (EliasFanoNSGGraph, altid_impl.cpp:53-90)."""
         torch = _torch()
-        ctx = ctx or _lib.default_context()
+        ctx = _lib.default_context() if ctx is None else ctx
         if isinstance(rows, np.ndarray):
             rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).cuda()
         assert rows.is_cuda and rows.dtype == torch.int32 and rows.dim() == 2
@@ -361,7 +361,7 @@ class CompactRows:
     @classmethod
     def encode_rows(cls, rows, ctx=None):
         torch = _torch()
-        ctx = ctx or _lib.default_context()
+        ctx = _lib.default_context() if ctx is None else ctx
         if isinstance(rows, np.ndarray):
             rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).cuda()
         assert rows.is_cuda and rows.dtype == torch.int32 and rows.dim() == 2
@@ -415,7 +415,7 @@ class WaveletTreeLists:
 
     @classmethod
     def build(cls, offsets, ids, wt_type=0, ctx=None):
-        ctx = ctx or _lib.default_context()
+        ctx = _lib.default_context() if ctx is None else ctx
         off = _as_offsets(offsets)
         ntotal = int(off[-1])
         d_ids = _dev_ids(ids, ntotal) if ntotal else None

@@ -126,7 +126,13 @@ void vidc_ctx_destroy(vidc_ctx *c) {
 
 int vidc_ctx_set_stream(vidc_ctx *c, void *hip_stream) {
     if (!c) return VIDC_ERR_INVALID;
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = (hipStream_t)hip_stream;  // NULL = legacy default stream
+    return VIDC_OK;
+}
+
+int vidc_ctx_reset_stream(vidc_ctx *c) {
+    if (!c) return VIDC_ERR_INVALID;
+    c->stream = c->own_stream;
     return VIDC_OK;
 }
 
