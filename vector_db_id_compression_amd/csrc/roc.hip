@@ -39,7 +39,7 @@ constexpr uint32_t GEN_SMALL_MAX = 1024;   // decoder: fb <= 7 -> 512 B of LDS
 // path); shorter ones cost about the same per step in the general kernels, which keep thousands in flight.
 constexpr uint32_t U_MIN_LIST = 4097;
 
-inline uint64_t arena_words_for(uint64_t n) { return n * 35 / 32 + 8; }  // <= P+4 bits per step, P <= 31
+inline uint64_t arena_words_for(uint64_t n) { return n * 37 / 32 + 8; }  // <= P+4 bits of growth per step, P <= 32
 
 // test hook: VIDC_FORCE_GENERAL=1 routes every list through the general (sorted-position / bucket) kernels
 inline bool force_general() {
