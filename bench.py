@@ -37,11 +37,11 @@ def cpu_baseline(offsets, ids, budget_s=20.0):
     while True:
         r = impl.bench_lists(offsets, ids, cores)
         runs.append(r["t_enc"] + r["t_dec"])
-        if time.time() - t0 > budget_s / 2 or len(runs) >= 5:
+        if time.time() - t0 > budget_s / 2 or len(runs) >= 41:
             break
     t_all = float(np.median(runs))
-    one = impl.bench_lists(offsets, ids, 1)
-    t_one = one["t_enc"] + one["t_dec"]
+    ones = [impl.bench_lists(offsets, ids, 1) for _ in range(5)]
+    t_one = float(np.median([o["t_enc"] + o["t_dec"] for o in ones]))
     return dict(value=ntotal / t_all, unit="IDs/s (encode+decode)", cores=cores, kind=kind,
                 sample=f"full S1 batch ({ntotal} ids / {offsets.size - 1} lists), median of {len(runs)} runs, "
                        f"OpenMP schedule(dynamic) over lists",
@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--codec", default="roc", choices=["roc", "ef", "packed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short secondary measurements in `extra`")
     args = ap.parse_args()
 
     import torch
@@ -136,6 +137,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    def secondary(workload, codec, steps=3):
+        """Short, untimed-by-the-driver measurement of another regime / codec (reported under `extra` only)."""
+        w2 = synth.workload(workload, seed=1042 + rank)
+        ids2 = torch.from_numpy(w2["ids"].view(np.int64)).cuda() if isinstance(w2["ids"], np.ndarray) else w2["ids"]
+        out2 = torch.empty(w2["ntotal"], dtype=torch.int64, device="cuda")
+        cls = {"roc": RocLists, "ef": EfLists, "packed": PackedLists}[codec]
+        ke = kd = 0.0
+        t_wall = 0.0
+        for it in range(steps + 1):
+            torch.cuda.synchronize()
+            t_a = time.perf_counter()
+            obj = cls.encode(w2["offsets"], ids2, ctx=ctx)
+            e_ms = (ctx.phase_ms(0) + ctx.phase_ms(1)) if codec == "roc" else ctx.last_kernel_ms()
+            obj.decode_all(out2)
+            d_ms = ctx.phase_ms(2) if codec == "roc" else ctx.last_kernel_ms()
+            torch.cuda.synchronize()
+            if it:  # first pass = warm-up
+                t_wall += time.perf_counter() - t_a
+                ke += e_ms
+                kd += d_ms
+        c2 = obj.compressed_bytes / w2["ntotal"]
+        kern = (ke + kd) / steps / 1e3
+        gbs = (16.0 + 2.0 * c2) * w2["ntotal"] / kern / 1e9
+        ok = bool(torch.equal(torch.sort(out2).values, torch.sort(ids2).values))
+        return {"workload": w2["describe"], "codec": codec, "ids_per_s": w2["ntotal"] * steps / t_wall,
+                "kernel_ms": {"encode": ke / steps, "decode": kd / steps}, "bits_per_id": 8.0 * c2,
+                "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "multiset_roundtrip_ok": ok}
+
     comp_bytes = r.compressed_bytes
     c = comp_bytes / ntotal  # compressed bytes per id
     alg_bytes = (16.0 + 2.0 * c) * ntotal  # SURVEY 8(d): enc 8 B read + c written, dec c read + 8 B written
@@ -168,6 +197,17 @@ def main():
                          "kernels": "k_roc_encode_* + k_roc_compact + k_roc_decode_*" if args.codec == "roc" else args.codec,
                          "algorithmic_bytes_per_id": 16.0 + 2.0 * c},
         }
+        if world == 1 and not args.no_extra and args.codec == "roc" and args.workload == "s1":
+            # other regimes of the same kernels, for context only (never part of `value`): many equal lists
+            # (no long serial chain) and the two bandwidth-bound codecs of the same plugin surface
+            try:
+                res["extra"] = {
+                    "roc_many_equal_lists": secondary("uniform_16m", "roc"),
+                    "packed_bits": secondary("uniform_16m", "packed"),
+                    "elias_fano": secondary("uniform_16m", "ef"),
+                }
+            except Exception as e:
+                res["extra"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline and args.codec == "roc" and ids_host is not None:
             try:
                 res["cpu_baseline"] = cpu_baseline(offsets, ids_host)
