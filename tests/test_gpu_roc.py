@@ -205,3 +205,17 @@ def test_full_size_config2_properties(roc):
     # idempotence: encoding the same input twice gives identical streams
     r2 = roc.encode(off, ids)
     assert np.array_equal(r2.info()["heads"], r.info()["heads"]) and r2.total_words == r.total_words
+
+
+def test_save_load_roundtrip(roc, tmp_path):
+    """Flat image of the compressed lists: reload and decode without re-encoding."""
+    rng = np.random.default_rng(9)
+    sizes = [0, 5, 64, 300, 5000]
+    off, ids, lists = _random_lists(rng, sizes)
+    r = roc.encode(off, ids)
+    want = r.decode_all().cpu().numpy()
+    p = str(tmp_path / "roc.npz")
+    r.save(p)
+    r2 = roc.load(p)
+    assert r2.compressed_bytes == r.compressed_bytes
+    assert np.array_equal(r2.decode_all().cpu().numpy(), want)

@@ -97,6 +97,20 @@ class RocLists:
                                     ptr(wc) if wc.size else None, C.byref(h)))
         return cls(h, ctx, off)
 
+    # -- flat on-disk / wire image (the reference keeps compressed lists in memory only)
+    def save(self, path):
+        """{offsets, precision, heads, nwords, mt_draws, words} as one .npz; `load` rebuilds the device object."""
+        info = self.info()
+        nw = info["nwords"]
+        words = np.concatenate([self.words(l, int(nw[l])) for l in range(self.nlist)] + [np.zeros(0, np.uint32)])
+        np.savez(path, offsets=self.offsets, precision=info["precision"], heads=info["heads"], nwords=nw,
+                 mt_draws=info["mt_draws"], words=words)
+
+    @classmethod
+    def load(cls, path, ctx=None):
+        z = np.load(path)
+        return cls.from_streams(z["offsets"], z["precision"], z["heads"], z["nwords"], z["words"], z["mt_draws"], ctx=ctx)
+
     # -- properties
     @property
     def nlist(self):

@@ -20,6 +20,15 @@ def _torch():
     return torch
 
 
+def _assign(x, c, chunk=1 << 16):
+    """argmin_j ||x_i - c_j|| in chunks (keeps the distance matrix small)."""
+    torch = _torch()
+    out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
+    for a in range(0, x.shape[0], chunk):
+        out[a:a + chunk] = torch.cdist(x[a:a + chunk], c).argmin(1)
+    return out
+
+
 def _kmeans(x, k, iters=10, seed=123):
     torch = _torch()
     g = torch.Generator(device="cpu")
@@ -31,8 +40,7 @@ def _kmeans(x, k, iters=10, seed=123):
         reps = (k + c.shape[0] - 1) // c.shape[0]
         c = c.repeat(reps, 1)[:k] + 1e-3 * torch.arange(k, device=x.device, dtype=x.dtype)[:, None]
     for _ in range(iters):
-        d = torch.cdist(x, c)
-        a = d.argmin(1)
+        a = _assign(x, c)
         sums = torch.zeros_like(c).index_add_(0, a, x)
         cnt = torch.bincount(a, minlength=k).to(x.dtype)[:, None]
         c = torch.where(cnt > 0, sums / cnt.clamp(min=1), c)
@@ -57,6 +65,10 @@ class IVFIndex:
     def train(self, xt):
         torch = _torch()
         xt = torch.as_tensor(np.asarray(xt, dtype=np.float32)).cuda()
+        if xt.shape[0] > 200_000:  # like Faiss, train on a subsample
+            g = torch.Generator(device="cpu")
+            g.manual_seed(99)
+            xt = xt[torch.randperm(xt.shape[0], generator=g)[:200_000].to(xt.device)]
         self.centroids = _kmeans(xt, self.nlist)
         if self.M:
             dsub = self.d // self.M
@@ -68,13 +80,13 @@ class IVFIndex:
         if not self.M:
             return x.contiguous().cpu().numpy().view(np.uint8).reshape(x.shape[0], 4 * self.d)
         dsub = self.d // self.M
-        codes = torch.stack([torch.cdist(x[:, m * dsub:(m + 1) * dsub], self.pq[m]).argmin(1) for m in range(self.M)], 1)
+        codes = torch.stack([_assign(x[:, m * dsub:(m + 1) * dsub].contiguous(), self.pq[m]) for m in range(self.M)], 1)
         return codes.to(torch.uint8).cpu().numpy()
 
     def add(self, xb):
         torch = _torch()
         xb = torch.as_tensor(np.asarray(xb, dtype=np.float32)).cuda()
-        assign = torch.cdist(xb, self.centroids).argmin(1).cpu().numpy()
+        assign = _assign(xb, self.centroids).cpu().numpy()
         codes = self._encode(xb)
         ids = np.arange(self.ntotal, self.ntotal + xb.shape[0], dtype=np.int64)
         order = np.argsort(assign, kind="stable")
