@@ -95,8 +95,9 @@ struct vidc_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipStream_t aux_stream = nullptr;            // short-list kernels run here, concurrently with the long-list kernels
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // kernel classes of one call run concurrently: long chains on `stream`, shorter classes on these
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     uint32_t *d_mt = nullptr;  // VIDC_MT_TABLE words
     int num_cu = 256;
     double last_kernel_ms = 0.0;

@@ -87,10 +87,14 @@ int vidc_ctx_create(int device, vidc_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->aux[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->aux[1], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->aux[2], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join[2], hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&c->d_mt, VIDC_MT_TABLE * sizeof(uint32_t)) != hipSuccess) {
         vidc::set_error("context resource creation failed");
         vidc_ctx_destroy(c);
@@ -118,8 +122,10 @@ void vidc_ctx_destroy(vidc_ctx *c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    for (int i = 0; i < 3; i++) {
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+        if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

@@ -264,28 +264,26 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     a.sid = s_sid.as<uint32_t>(); a.spos = nullptr; a.skey = nullptr; a.skey_off = nullptr;
     a.mt = ctx->d_mt;
 
-    // The long-list (bitmap) kernels hold one wave per CU; everything else runs concurrently on the auxiliary
-    // stream and fills the remaining wave slots.
-    hipStream_t short_stream = ctx->stream;
-    auto launch_gen = [&](const uint32_t *d_wl, uint32_t nwork, uint32_t rl_max) -> int {
+    // Kernel classes run concurrently (one stream each): the longest chains on the caller's stream, shorter
+    // classes on the auxiliary streams so that they fill the wave slots the long chains leave idle.
+    auto launch_gen_on = [&](hipStream_t st_, const uint32_t *d_wl, uint32_t nwork, uint32_t rl_max) -> int {
         if (!nwork) return VIDC_OK;
         RocEncArgs b = a;
         b.worklist = d_wl; b.nwork = nwork;
         size_t lds = (size_t)64 * rl_max * 12;
-        hipLaunchKernelGGL(k_roc_encode_gen, dim3(nwork), dim3(64), lds, short_stream, b, rl_max);
+        hipLaunchKernelGGL(k_roc_encode_gen, dim3(nwork), dim3(64), lds, st_, b, rl_max);
         VIDC_HIP(hipGetLastError());
         return VIDC_OK;
+    };
+    auto launch_gen = [&](const uint32_t *d_wl, uint32_t nwork, uint32_t rl_max) -> int {
+        return launch_gen_on(ctx->stream, d_wl, nwork, rl_max);
     };
     {
         EventTimer t(ctx);
         const uint32_t *d_wl = s_wl.as<uint32_t>();
-        const bool fork = !wl_u18.empty() || !wl_u20.empty();
-        if (fork) {
-            VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-            VIDC_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-            short_stream = ctx->aux_stream;
-        }
-        // longest lists first: they are the critical path
+        VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        for (int i = 0; i < 3; i++) VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
+        // main stream: bitmap-20 lists and the deepest general class (the critical paths)
         if (!wl_u20.empty()) {
             RocEncArgs b = a;
             b.worklist = d_wl + base[2]; b.nwork = (uint32_t)wl_u20.size();
@@ -295,27 +293,28 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             else hipLaunchKernelGGL((k_roc_encode_u<20, false>), dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, ctx->stream, b);
             VIDC_HIP(hipGetLastError());
         }
-        VIDC_TRY(launch_gen(d_wl + base[5], (uint32_t)wl_c3.size(), 64));
-        VIDC_TRY(launch_gen(d_wl + base[4], (uint32_t)wl_c2.size(), 8));
+        VIDC_TRY(launch_gen_on(ctx->stream, d_wl + base[5], (uint32_t)wl_c3.size(), 64));
+        // aux 0: mid-size general lists and bitmap-18 lists
+        VIDC_TRY(launch_gen_on(ctx->aux[0], d_wl + base[4], (uint32_t)wl_c2.size(), 8));
         if (!wl_u18.empty()) {
             RocEncArgs b = a;
             b.worklist = d_wl + base[1]; b.nwork = (uint32_t)wl_u18.size();
-            if (want_perm) hipLaunchKernelGGL((k_roc_encode_u<18, true>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->stream, b);
-            else hipLaunchKernelGGL((k_roc_encode_u<18, false>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->stream, b);
+            if (want_perm) hipLaunchKernelGGL((k_roc_encode_u<18, true>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->aux[0], b);
+            else hipLaunchKernelGGL((k_roc_encode_u<18, false>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->aux[0], b);
             VIDC_HIP(hipGetLastError());
         }
-        VIDC_TRY(launch_gen(d_wl + base[3], (uint32_t)wl_c1.size(), 1));
+        // aux 1: short general lists; aux 2: tiny lists
+        VIDC_TRY(launch_gen_on(ctx->aux[1], d_wl + base[3], (uint32_t)wl_c1.size(), 1));
         if (!wl_tiny.empty()) {
             RocEncArgs b = a;
             b.worklist = d_wl; b.nwork = (uint32_t)wl_tiny.size();
-            if (rows) hipLaunchKernelGGL(k_roc_encode_tiny<true>, dim3(b.nwork), dim3(64), 0, short_stream, b);
-            else hipLaunchKernelGGL(k_roc_encode_tiny<false>, dim3(b.nwork), dim3(64), 0, short_stream, b);
+            if (rows) hipLaunchKernelGGL(k_roc_encode_tiny<true>, dim3(b.nwork), dim3(64), 0, ctx->aux[2], b);
+            else hipLaunchKernelGGL(k_roc_encode_tiny<false>, dim3(b.nwork), dim3(64), 0, ctx->aux[2], b);
             VIDC_HIP(hipGetLastError());
         }
-        if (fork) {
-            VIDC_HIP(hipEventRecord(ctx->ev_join, ctx->aux_stream));
-            VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-            short_stream = ctx->stream;
+        for (int i = 0; i < 3; i++) {
+            VIDC_HIP(hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
+            VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
         }
         kernel_ms += t.stop();
     }
@@ -506,14 +505,15 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         for (int c = 0; c < DC_COUNT; c++) { base[c] = acc; acc += p.count[c]; }
     }
     EventTimer t(ctx);
-    const bool fork = p.count[DC_U18] || p.count[DC_U20];
-    if (fork) {
-        VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-        VIDC_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-    }
+    // classes run concurrently: the longest chains on the caller's stream, the rest on the auxiliary streams
+    VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+    for (int i = 0; i < 3; i++) VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
     auto launch = [&](int c) -> int {
         if (!p.count[c]) return VIDC_OK;
-        hipStream_t st_ = (fork && c != DC_U18 && c != DC_U20) ? ctx->aux_stream : ctx->stream;
+        hipStream_t st_ = ctx->stream;
+        if (c == DC_GMID || c == DC_U18) st_ = ctx->aux[0];
+        else if (c == DC_GSMALL) st_ = ctx->aux[1];
+        else if (c == DC_TINY) st_ = ctx->aux[2];
         RocDecArgs b = a;
         b.worklist = d_wl + base[c];
         b.nwork = (uint32_t)p.count[c];
@@ -548,9 +548,9 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     };
     // longest chains first
     for (int c : {DC_GHUGE, DC_U20, DC_GMID, DC_U18, DC_GSMALL, DC_TINY}) VIDC_TRY(launch(c));
-    if (fork) {
-        VIDC_HIP(hipEventRecord(ctx->ev_join, ctx->aux_stream));
-        VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    for (int i = 0; i < 3; i++) {
+        VIDC_HIP(hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
+        VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
     }
     ctx->last_kernel_ms = t.stop();
     ctx->phase_ms[VIDC_PHASE_ROC_DECODE] = ctx->last_kernel_ms;
