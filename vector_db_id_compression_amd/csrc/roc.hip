@@ -1,6 +1,7 @@
 // roc.hip -- host side of the ROC codec: scheduling of lists onto wavefronts, arenas, compaction,
 // and the vidc_roc_* C-ABI (include/vidc.h).
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <memory>
 #include <numeric>
@@ -32,6 +33,24 @@ struct vidc_roc {
 };
 
 namespace {
+
+// VIDC_TRACE=1 prints host-side phase times of encode / decode calls (dev aid)
+struct HostTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    const char *what;
+    explicit HostTrace(const char *w) : what(w) {
+        const char *e = getenv("VIDC_TRACE");
+        on = e && e[0] == '1';
+        t0 = std::chrono::steady_clock::now();
+    }
+    void mark(const char *phase) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[vidc] %s: %-28s %8.3f ms\n", what, phase, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 constexpr uint32_t TINY_MAX = 64;
 constexpr uint32_t GEN_SMALL_MAX = 1024;   // decoder: fb <= 7 -> 512 B of LDS
@@ -102,11 +121,24 @@ int check_status(const std::vector<uint32_t> &status, const char *what) {
     return VIDC_OK;
 }
 
-// lists sorted longest first: the hardware dispatches workgroups in order, so this is LPT scheduling
+// lists sorted longest first: the hardware dispatches workgroups in order, so this is LPT scheduling.
+// Counting sort by length (lengths are bounded by VIDC_ROC_MAX_LIST): O(n), stable.
 void sort_desc(std::vector<uint32_t> &wl, const std::vector<uint64_t> &offsets) {
-    std::stable_sort(wl.begin(), wl.end(), [&](uint32_t a, uint32_t b) {
-        return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b];
-    });
+    if (wl.size() < 2) return;
+    uint64_t maxlen = 0;
+    for (uint32_t l : wl) maxlen = std::max<uint64_t>(maxlen, offsets[l + 1] - offsets[l]);
+    if (maxlen > (1u << 22)) {  // not reachable for ROC lists; keep a comparison sort for safety
+        std::stable_sort(wl.begin(), wl.end(), [&](uint32_t a, uint32_t b) {
+            return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b];
+        });
+        return;
+    }
+    std::vector<uint32_t> start(maxlen + 2, 0);
+    for (uint32_t l : wl) start[maxlen - (offsets[l + 1] - offsets[l]) + 1]++;  // bucket 0 = longest
+    for (size_t i = 1; i < start.size(); i++) start[i] += start[i - 1];
+    std::vector<uint32_t> out(wl.size());
+    for (uint32_t l : wl) out[start[maxlen - (offsets[l + 1] - offsets[l])]++] = l;
+    wl.swap(out);
 }
 
 int finish_encode(vidc_ctx *ctx, vidc_roc *r, const uint32_t *d_arena, const uint64_t *d_arena_off,
@@ -164,6 +196,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     nlist = r->nlist;
     double kernel_ms = 0;
 
+    HostTrace tr("roc encode");
     std::vector<uint64_t> arena_off(nlist + 1, 0);
     // work lists: tiny (n <= 64), universe-bitmap kernels (ids < 2^18 / 2^20), general kernels by bitmap depth
     std::vector<uint32_t> wl_tiny, wl_u18, wl_u20, wl_c1, wl_c2, wl_c3;
@@ -237,7 +270,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             else if (n <= 32768) wl_c2.push_back((uint32_t)l);
             else wl_c3.push_back((uint32_t)l);
         }
+        tr.mark("prepass + classify");
         for (auto *w : {&wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3}) sort_desc(*w, r->offsets);
+        tr.mark("sort work lists");
         if (!wl_c1.empty() || !wl_c2.empty() || !wl_c3.empty()) VIDC_TRY(s_sid.get(ctx, ntotal_in * 4));
     }
     VIDC_TRY(s_arena.get(ctx, arena_off[nlist] * 4));
@@ -264,6 +299,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     a.sid = s_sid.as<uint32_t>(); a.spos = nullptr; a.skey = nullptr; a.skey_off = nullptr;
     a.mt = ctx->d_mt;
 
+    tr.mark("alloc + upload");
     // Kernel classes run concurrently (one stream each): the longest chains on the caller's stream, shorter
     // classes on the auxiliary streams so that they fill the wave slots the long chains leave idle.
     auto launch_gen_on = [&](hipStream_t st_, const uint32_t *d_wl, uint32_t nwork, uint32_t rl_max) -> int {
@@ -319,6 +355,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         kernel_ms += t.stop();
     }
 
+    tr.mark("encode kernels (sync)");
     // second pass for lists the first pass handed back: unsorted input of the general kernels (Faiss
     // lists are in add order, i.e. normally sorted) and multiset input of the bitmap kernels
     std::vector<uint32_t> pend;
@@ -383,9 +420,11 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         r->ntotal = r->offsets[nlist];
         VIDC_TRY(upload(ctx, r->d_offsets, r->offsets));
     }
+    tr.mark("second pass / perm");
     ctx->phase_ms[VIDC_PHASE_ROC_ENCODE] = kernel_ms;
     VIDC_TRY(finish_encode(ctx, r.get(), s_arena.as<uint32_t>(), s_arena_off.as<uint64_t>(), s_status, kernel_ms));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    tr.mark("metadata + compaction");
     ctx->last_kernel_ms = kernel_ms;
     *out = r.release();
     return VIDC_OK;
@@ -425,8 +464,15 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     auto len = [&](uint32_t i) { return r->offsets[lists[i] + 1] - r->offsets[lists[i]]; };
     p.wl.clear(); p.item.clear();
     for (int c = 0; c < DC_COUNT; c++) {
-        if (c != DC_TINY)
-            std::stable_sort(cls[c].begin(), cls[c].end(), [&](uint32_t x, uint32_t y) { return len(x) > len(y); });
+        if (c != DC_TINY && cls[c].size() > 1) {  // counting sort by length, longest first (stable)
+            uint64_t maxlen = 0;
+            for (uint32_t i : cls[c]) maxlen = std::max<uint64_t>(maxlen, len(i));
+            std::vector<uint32_t> start(maxlen + 2, 0), sorted(cls[c].size());
+            for (uint32_t i : cls[c]) start[maxlen - len(i) + 1]++;
+            for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
+            for (uint32_t i : cls[c]) sorted[start[maxlen - len(i)]++] = i;
+            cls[c].swap(sorted);
+        }
         p.count[c] = cls[c].size();
         for (uint32_t i : cls[c]) { p.item.push_back(i); p.wl.push_back(lists[i]); }
     }
