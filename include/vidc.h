@@ -90,6 +90,8 @@ int vidc_roc_list_info(const vidc_roc *r, uint32_t *sizes, uint32_t *precisions,
                        uint32_t *nwords, uint32_t *mt_draws);
 /* stack words of one list, push order (parity export).  cap in words. */
 int vidc_roc_export_words(vidc_ctx *ctx, const vidc_roc *r, uint64_t list_no, uint32_t *words, size_t cap);
+/* the whole compact stream (lists back to back, vidc_roc_total_words() words) in one copy */
+int vidc_roc_export_all_words(vidc_ctx *ctx, const vidc_roc *r, uint32_t *words, size_t cap);
 /* sampling permutation for all lists: perm[offsets[l]+i] = input position of the i-th sampled id */
 int vidc_roc_perm(vidc_ctx *ctx, const vidc_roc *r, uint32_t *perm_host);
 const uint32_t *vidc_roc_perm_dev(const vidc_roc *r);

@@ -71,7 +71,10 @@ def _check_against_oracle(o, r, off, lists, perm, dec):
         if perm is not None:
             assert np.array_equal(perm[a:b], e["perm"]), f"list {l}"
         if dec is not None:
-            assert np.array_equal(dec[a:b], e["order"]), f"list {l}"
+            # what the reference decoder makes of this stream (== the sampling order unless the precision quirk
+            # Q3 makes the list lossy)
+            want = o.roc_decode(e["head"], e["words"], li.size, P, e["mt_draws"])[0]
+            assert np.array_equal(dec[a:b], want), f"list {l}"
 
 
 def test_batch_mixed_sizes_vs_oracle(roc, oracle):
@@ -219,3 +222,75 @@ def test_save_load_roundtrip(roc, tmp_path):
     r2 = roc.load(p)
     assert r2.compressed_bytes == r.compressed_bytes
     assert np.array_equal(r2.decode_all().cpu().numpy(), want)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# lane-per-list kernels (roc_lane.h): lists of 65..1024 strictly ascending ids
+def test_lane_kernels_boundaries_vs_oracle(roc, oracle):
+    """Sizes around every class boundary of the lane-per-list kernels, several universes, one call."""
+    rng = np.random.default_rng(77)
+    sizes = [65, 66, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 767, 768, 769, 1000, 1023, 1024, 1025, 1100]
+    for nbits in (11, 16, 20, 24, 31):
+        sz = [s for s in sizes if s <= (1 << nbits)]
+        off, ids, lists = _random_lists(rng, sz, nbits=nbits)
+        r = roc.encode(off, ids, want_perm=True)
+        dec = r.decode_all().cpu().numpy().view(np.uint64)
+        _check_against_oracle(oracle, r, off, lists, r.perm(), dec)
+
+
+def test_lane_kernels_dense_and_small_precision(roc, oracle):
+    """Dense lists (n close to the universe: tiny precision, many renormalisation pops) and fixed precisions."""
+    rng = np.random.default_rng(78)
+    lists = [np.sort(rng.choice(m, size=n, replace=False)).astype(np.uint64)
+             for n, m in ((65, 66), (100, 101), (128, 200), (300, 301), (1024, 1025), (1000, 1 << 10), (70, 1 << 7))]
+    off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
+    ids = np.concatenate(lists)
+    r = roc.encode(off, ids, want_perm=True)
+    dec = r.decode_all().cpu().numpy().view(np.uint64)
+    _check_against_oracle(oracle, r, off, lists, r.perm(), dec)
+    for P in (12, 17, 32):  # explicit precision (codec.cpp compress(), precision argument)
+        r = roc.encode(off, ids, precision_mode=P, want_perm=True)
+        info = r.info()
+        dec = r.decode_all().cpu().numpy().view(np.uint64)
+        for l, li in enumerate(lists):
+            e = oracle.roc_encode(li, P)
+            assert int(info["heads"][l]) == e["head"] and np.array_equal(r.words(l), e["words"])
+            assert np.array_equal(dec[int(off[l]):int(off[l + 1])], e["order"])
+
+
+def test_lane_decoder_hands_back_skewed_lists(roc, oracle):
+    """All ids of a list in one 1/64 slice of the universe: the lane decoder's bucket row overflows and the list is
+    redone by the wave-per-list kernel (VIDC_ST_RETRY) -- same output."""
+    rng = np.random.default_rng(79)
+    lists = []
+    for n in (70, 300, 900):
+        top = (1 << 20) - 1
+        body = np.sort(rng.choice(4000, size=n - 1, replace=False)).astype(np.uint64) + 5
+        lists.append(np.concatenate([body, [top]]).astype(np.uint64))  # max id sets the precision, the rest is clustered
+    lists.append(np.sort(rng.choice(1 << 20, size=500, replace=False)).astype(np.uint64))  # a clean neighbour
+    off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
+    ids = np.concatenate(lists)
+    r = roc.encode(off, ids, want_perm=True)
+    dec = r.decode_all().cpu().numpy().view(np.uint64)
+    _check_against_oracle(oracle, r, off, lists, r.perm(), dec)
+    assert r.last_decode_nonclean == 0
+    sub, sub_off = r.decode_lists(np.array([2, 3, 0, 2], dtype=np.uint64))  # repeated + mixed retry / clean requests
+    sub = sub.cpu().numpy().view(np.uint64)
+    for i, l in enumerate([2, 3, 0, 2]):
+        assert np.array_equal(sub[int(sub_off[i]):int(sub_off[i + 1])], dec[int(off[l]):int(off[l + 1])])
+
+
+def test_lane_kernels_match_wave_kernels(roc, monkeypatch):
+    """Same streams with and without the lane-per-list kernels (VIDC_NO_LANE test hook) on 3000 ragged lists."""
+    rng = np.random.default_rng(80)
+    sizes = rng.integers(0, 1200, 3000)
+    off, ids, _ = _random_lists(rng, sizes, nbits=22)
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VIDC_NO_LANE", mode)
+        r = roc.encode(off, ids, want_perm=True)
+        info = r.info()
+        got[mode] = (info["heads"], info["nwords"], info["mt_draws"], r.all_words(), r.perm(),
+                     r.decode_all().cpu().numpy().copy())
+    for a, b in zip(got["0"], got["1"]):
+        assert np.array_equal(a, b)

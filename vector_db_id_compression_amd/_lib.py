@@ -60,6 +60,7 @@ def _declare(lib):
     f("vidc_roc_total_words", _u64, _vp)
     f("vidc_roc_list_info", C.c_int, _vp, _vp, _vp, _vp, _vp, _vp)
     f("vidc_roc_export_words", C.c_int, _vp, _vp, _u64, _vp, C.c_size_t)
+    f("vidc_roc_export_all_words", C.c_int, _vp, _vp, _vp, C.c_size_t)
     f("vidc_roc_perm", C.c_int, _vp, _vp, _vp)
     f("vidc_roc_perm_dev", _vp, _vp)
     f("vidc_roc_import", C.c_int, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _P(_vp))
@@ -111,7 +112,7 @@ EXPORTED_SYMBOLS = [
     "vidc_ctx_synchronize", "vidc_dev_alloc", "vidc_dev_free", "vidc_copy_h2d", "vidc_copy_d2h",
     "vidc_ctx_last_kernel_ms", "vidc_ctx_phase_ms",
     "vidc_roc_encode", "vidc_roc_encode_rows", "vidc_roc_destroy", "vidc_roc_nlist", "vidc_roc_ntotal",
-    "vidc_roc_compressed_bytes", "vidc_roc_total_words", "vidc_roc_list_info", "vidc_roc_export_words",
+    "vidc_roc_compressed_bytes", "vidc_roc_total_words", "vidc_roc_list_info", "vidc_roc_export_words", "vidc_roc_export_all_words",
     "vidc_roc_perm", "vidc_roc_perm_dev", "vidc_roc_import", "vidc_roc_decode_all", "vidc_roc_decode_lists",
     "vidc_roc_decode_rows", "vidc_roc_last_decode_nonclean",
     "vidc_packed_bits_for", "vidc_packed_encode", "vidc_packed_destroy", "vidc_packed_compressed_bytes",

@@ -102,7 +102,7 @@ class RocLists:
         """{offsets, precision, heads, nwords, mt_draws, words} as one .npz; `load` rebuilds the device object."""
         info = self.info()
         nw = info["nwords"]
-        words = np.concatenate([self.words(l, int(nw[l])) for l in range(self.nlist)] + [np.zeros(0, np.uint32)])
+        words = self.all_words()
         np.savez(path, offsets=self.offsets, precision=info["precision"], heads=info["heads"], nwords=nw,
                  mt_draws=info["mt_draws"], words=words)
 
@@ -144,6 +144,13 @@ class RocLists:
         w = np.zeros(max(nwords, 1), np.uint32)
         check(lib().vidc_roc_export_words(self.ctx.h, self.h, list_no, ptr(w), nwords))
         return w[:nwords]
+
+    def all_words(self):
+        """the compact stream of every list back to back (word offsets = cumsum of info()['nwords'])"""
+        tw = self.total_words
+        w = np.zeros(max(tw, 1), np.uint32)
+        check(lib().vidc_roc_export_all_words(self.ctx.h, self.h, ptr(w), tw))
+        return w[:tw]
 
     def perm(self):
         p = np.zeros(max(self.ntotal, 1), np.uint32)

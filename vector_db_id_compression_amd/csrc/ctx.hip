@@ -95,7 +95,8 @@ int vidc_ctx_create(int device, vidc_ctx **out) {
         hipEventCreateWithFlags(&c->ev_join[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join[2], hipEventDisableTiming) != hipSuccess ||
-        hipMalloc((void **)&c->d_mt, VIDC_MT_TABLE * sizeof(uint32_t)) != hipSuccess) {
+        hipMalloc((void **)&c->d_mt, VIDC_MT_TABLE * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&c->d_ltab, (VIDC_LANE_TAB + 1) * 16) != hipSuccess) {
         vidc::set_error("context resource creation failed");
         vidc_ctx_destroy(c);
         return VIDC_ERR_HIP;
@@ -110,6 +111,18 @@ int vidc_ctx_create(int device, vidc_ctx **out) {
         vidc_ctx_destroy(c);
         return VIDC_ERR_HIP;
     }
+    // divisor table of the lane-per-list kernels: floor((2^64-1)/d), d*floor(2^31/d), floor(2^31/d)
+    std::vector<uint32_t> lt((VIDC_LANE_TAB + 1) * 4, 0);
+    for (uint32_t d = 1; d <= VIDC_LANE_TAB; d++) {
+        const uint64_t m = ~0ull / d;
+        const uint32_t lq = 0x80000000u / d;
+        lt[4 * d + 0] = (uint32_t)m; lt[4 * d + 1] = (uint32_t)(m >> 32); lt[4 * d + 2] = lq * d; lt[4 * d + 3] = lq;
+    }
+    if (hipMemcpy(c->d_ltab, lt.data(), lt.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        vidc::set_error("divisor table upload failed");
+        vidc_ctx_destroy(c);
+        return VIDC_ERR_HIP;
+    }
     *out = c;
     return VIDC_OK;
 }
@@ -119,6 +132,7 @@ void vidc_ctx_destroy(vidc_ctx *c) {
     for (auto &b : c->pool)
         if (b.p) (void)hipFree(b.p);
     if (c->d_mt) (void)hipFree(c->d_mt);
+    if (c->d_ltab) (void)hipFree(c->d_ltab);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);

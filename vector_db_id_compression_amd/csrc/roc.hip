@@ -9,6 +9,7 @@
 #include "common.h"
 #include "roc_kernels.h"
 #include "roc_u.h"
+#include "roc_lane.h"
 
 using namespace vidc;
 using namespace vidc::dev;
@@ -59,6 +60,13 @@ constexpr uint32_t GEN_SMALL_MAX = 1024;   // decoder: fb <= 7 -> 512 B of LDS
 constexpr uint32_t U_MIN_LIST = 4097;
 
 inline uint64_t arena_words_for(uint64_t n) { return n * 37 / 32 + 8; }  // <= P+4 bits of growth per step, P <= 32
+
+static_assert(VIDC_LANE_MAX == VIDC_LANE_TAB, "divisor table size");
+// test hook: VIDC_NO_LANE=1 keeps short lists on the wave-per-list kernels (A/B and parity checks)
+inline bool no_lane() {
+    const char *e = getenv("VIDC_NO_LANE");
+    return e && e[0] == '1';
+}
 
 // test hook: VIDC_FORCE_GENERAL=1 routes every list through the general (sorted-position / bucket) kernels
 inline bool force_general() {
@@ -199,7 +207,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     HostTrace tr("roc encode");
     std::vector<uint64_t> arena_off(nlist + 1, 0);
     // work lists: tiny (n <= 64), universe-bitmap kernels (ids < 2^18 / 2^20), general kernels by bitmap depth
-    std::vector<uint32_t> wl_tiny, wl_u18, wl_u20, wl_c1, wl_c2, wl_c3;
+    std::vector<uint32_t> wl_tiny, wl_u18, wl_u20, wl_c1, wl_c2, wl_c3, wl_l4, wl_l16;
     const bool want_perm = (flags & VIDC_ROC_WANT_PERM) && !rows;
     const uint64_t ntotal_in = rows ? N * K : (nlist ? offsets[nlist] : 0);
     // persistent outputs
@@ -264,14 +272,17 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             // the bitmap kernels need no sort; they cannot report input positions of an unsorted list
             bool u_ok = !force_general() && !((pflags[l] & VIDC_PF_UNSORTED) && want_perm) &&
                         (n >= u_min || (pflags[l] & VIDC_PF_UNSORTED));
+            const bool lane_ok = !force_general() && !no_lane() && !(pflags[l] & VIDC_PF_UNSORTED) && n <= VIDC_LANE_MAX;
             if (u_ok && width <= 18) wl_u18.push_back((uint32_t)l);
             else if (u_ok && width <= 20) wl_u20.push_back((uint32_t)l);
+            else if (lane_ok && n <= 256) wl_l4.push_back((uint32_t)l);
+            else if (lane_ok) wl_l16.push_back((uint32_t)l);
             else if (n <= 4096) wl_c1.push_back((uint32_t)l);
             else if (n <= 32768) wl_c2.push_back((uint32_t)l);
             else wl_c3.push_back((uint32_t)l);
         }
         tr.mark("prepass + classify");
-        for (auto *w : {&wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3}) sort_desc(*w, r->offsets);
+        for (auto *w : {&wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16}) sort_desc(*w, r->offsets);
         tr.mark("sort work lists");
         if (!wl_c1.empty() || !wl_c2.empty() || !wl_c3.empty()) VIDC_TRY(s_sid.get(ctx, ntotal_in * 4));
     }
@@ -281,7 +292,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     if (nlist) VIDC_HIP(hipMemsetAsync(s_status.p, 0xff, nlist * 4, ctx->stream));
     std::vector<uint32_t> wl_all;
     std::vector<size_t> base;
-    for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3}) {
+    for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16}) {
         base.push_back(wl_all.size());
         wl_all.insert(wl_all.end(), w->begin(), w->end());
     }
@@ -339,8 +350,21 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             else hipLaunchKernelGGL((k_roc_encode_u<18, false>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->aux[0], b);
             VIDC_HIP(hipGetLastError());
         }
-        // aux 1: short general lists; aux 2: tiny lists
+        // aux 1: short general lists and the lane-per-list kernels; aux 2: tiny lists
         VIDC_TRY(launch_gen_on(ctx->aux[1], d_wl + base[3], (uint32_t)wl_c1.size(), 1));
+        for (int cls = 0; cls < 2; cls++) {
+            const std::vector<uint32_t> &w = cls ? wl_l16 : wl_l4;
+            if (w.empty()) continue;
+            RocEncArgs b = a;
+            b.worklist = d_wl + base[6 + cls]; b.nwork = (uint32_t)w.size();
+            const dim3 grid((b.nwork + 63u) / 64u);
+            const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
+            if (cls == 0 && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<4, true>), grid, dim3(64), 0, ctx->aux[1], b, dt);
+            else if (cls == 0) hipLaunchKernelGGL((k_roc_encode_lane<4, false>), grid, dim3(64), 0, ctx->aux[1], b, dt);
+            else if (want_perm) hipLaunchKernelGGL((k_roc_encode_lane<16, true>), grid, dim3(64), 0, ctx->aux[1], b, dt);
+            else hipLaunchKernelGGL((k_roc_encode_lane<16, false>), grid, dim3(64), 0, ctx->aux[1], b, dt);
+            VIDC_HIP(hipGetLastError());
+        }
         if (!wl_tiny.empty()) {
             RocEncArgs b = a;
             b.worklist = d_wl; b.nwork = (uint32_t)wl_tiny.size();
@@ -431,35 +455,37 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
 }
 
 // ---- decode planning: work items grouped by kernel class, each with private scratch
-enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_GMID, DC_GHUGE, DC_COUNT };
+enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_GMID, DC_GHUGE, DC_LANE, DC_COUNT };
 
 struct DecPlan {
     std::vector<uint32_t> wl;        // list numbers, grouped by class, longest first inside a class
     std::vector<uint32_t> item;      // index of each work item in the caller's request
-    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0};
+    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     std::vector<uint64_t> scratch_off, slots_off;
     uint64_t scratch_words = 0, slots_words = 0;
 };
 
-inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min) {
+inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool allow_lane) {
     if (n <= TINY_MAX) return DC_TINY;
     if (!force_general() && n >= u_min) {
         if (P <= 18) return DC_U18;
         if (P <= 20) return DC_U20;
     }
+    if (allow_lane && n <= VIDC_LANE_MAX && !force_general() && !no_lane()) return DC_LANE;
     if (n <= GEN_SMALL_MAX) return DC_GSMALL;
     if (n <= 32768) return DC_GMID;
     return DC_GHUGE;
 }
 
 // lists[i] = list number of request item i (a list may appear more than once)
-void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool rows_flavour, DecPlan &p) {
+void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool rows_flavour, DecPlan &p,
+                 bool allow_lane = true) {
     std::vector<uint32_t> cls[DC_COUNT];
     const uint64_t u_min = U_MIN_LIST;
     for (uint32_t i = 0; i < lists.size(); i++) {
         uint32_t l = lists[i];
         uint64_t n = r->offsets[l + 1] - r->offsets[l];
-        cls[rows_flavour ? DC_TINY : dec_class(n, r->prec[l], u_min)].push_back(i);
+        cls[rows_flavour ? DC_TINY : dec_class(n, r->prec[l], u_min, allow_lane)].push_back(i);
     }
     auto len = [&](uint32_t i) { return r->offsets[lists[i] + 1] - r->offsets[lists[i]]; };
     p.wl.clear(); p.item.clear();
@@ -487,7 +513,11 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             p.scratch_off[k] = so;
             so += (uint64_t)r->nwords[l] + 64;
             p.slots_off[k] = sl;
-            if (c == DC_U18 || c == DC_U20) sl += n;  // duplicate side list
+            if (c == DC_LANE) {
+                sl = (sl + 3) & ~(uint64_t)3;  // rows are read as uint4
+                p.slots_off[k] = sl;
+                sl += 64ull * roc_lane_cap((uint32_t)n);
+            } else if (c == DC_U18 || c == DC_U20) sl += n;  // duplicate side list
             else if (c >= DC_GSMALL) {
                 uint32_t fb = roc_dec_fine_bits((uint32_t)n, r->prec[l] > 32 ? 32 : r->prec[l]);
                 sl += ((uint64_t)1 << fb) * roc_dec_cap((uint32_t)n) + n;
@@ -510,7 +540,7 @@ struct DecPlanCache {
 namespace {
 
 int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64_t *out_off_host, uint64_t *d_out,
-                int32_t *d_out_rows, uint32_t K, const DecPlanCache *cache = nullptr) {
+                int32_t *d_out_rows, uint32_t K, const struct DecPlanCache *cache = nullptr) {
     VIDC_HIP(hipSetDevice(ctx->device));
     const size_t nwork = p.wl.size();
     if (nwork == 0) { ctx->last_kernel_ms = 0; return VIDC_OK; }
@@ -558,7 +588,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         if (!p.count[c]) return VIDC_OK;
         hipStream_t st_ = ctx->stream;
         if (c == DC_GMID || c == DC_U18) st_ = ctx->aux[0];
-        else if (c == DC_GSMALL) st_ = ctx->aux[1];
+        else if (c == DC_GSMALL || c == DC_LANE) st_ = ctx->aux[1];
         else if (c == DC_TINY) st_ = ctx->aux[2];
         RocDecArgs b = a;
         b.worklist = d_wl + base[c];
@@ -581,6 +611,10 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
             case DC_GSMALL:
                 hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), 128 * 4, st_, b, 128u, VIDC_DEC_CAP);
                 break;
+            case DC_LANE:
+                hipLaunchKernelGGL(k_roc_decode_lane, dim3((b.nwork + 63u) / 64u), dim3(64), 0, st_, b,
+                                   (const LaneDiv *)ctx->d_ltab);
+                break;
             case DC_GMID:
                 hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), (1u << VIDC_DEC_MAX_FB) * 4, st_, b,
                                    1u << VIDC_DEC_MAX_FB, VIDC_DEC_CAP);
@@ -593,7 +627,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         return VIDC_OK;
     };
     // longest chains first
-    for (int c : {DC_GHUGE, DC_U20, DC_GMID, DC_U18, DC_GSMALL, DC_TINY}) VIDC_TRY(launch(c));
+    for (int c : {DC_GHUGE, DC_U20, DC_GMID, DC_U18, DC_GSMALL, DC_LANE, DC_TINY}) VIDC_TRY(launch(c));
     for (int i = 0; i < 3; i++) {
         VIDC_HIP(hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
         VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
@@ -602,22 +636,46 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     ctx->phase_ms[VIDC_PHASE_ROC_DECODE] = ctx->last_kernel_ms;
 
     // 16-byte summary instead of copying two nlist-sized arrays back
-    VIDC_TRY(s_sum.get(ctx, 16));
-    const unsigned long long init[2] = {~0ull, 0ull};
-    VIDC_HIP(hipMemcpyAsync(s_sum.p, init, 16, hipMemcpyHostToDevice, ctx->stream));
+    VIDC_TRY(s_sum.get(ctx, 24));
+    const unsigned long long init[3] = {~0ull, 0ull, 0ull};
+    VIDC_HIP(hipMemcpyAsync(s_sum.p, init, 24, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_roc_status_summary, dim3((uint32_t)std::min<uint64_t>((r->nlist + 255) / 256, 1024)), dim3(256),
                        0, ctx->stream, s_status.as<uint32_t>(), s_end.as<uint32_t>(), (uint32_t)r->nlist,
                        s_sum.as<unsigned long long>());
     VIDC_HIP(hipGetLastError());
-    unsigned long long sum[2] = {0, 0};
-    VIDC_HIP(hipMemcpyAsync(sum, s_sum.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long sum[3] = {0, 0, 0};
+    VIDC_HIP(hipMemcpyAsync(sum, s_sum.p, 24, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
-    if (sum[0] != ~0ull) {
+    const double first_ms = ctx->last_kernel_ms;
+    uint64_t nonclean = sum[1];
+    if (sum[0] != ~0ull || sum[2]) {
         std::vector<uint32_t> status(r->nlist);
         VIDC_HIP(hipMemcpy(status.data(), s_status.p, r->nlist * 4, hipMemcpyDeviceToHost));
-        VIDC_TRY(check_status(status, "roc decode"));
+        if (sum[2]) {
+            // lists the lane-per-list decoder handed back (a full bucket row on skewed ids): redo them with the
+            // wave-per-list kernels, into the same output slots
+            std::vector<uint32_t> lists2;
+            std::vector<uint64_t> off2;
+            for (size_t k = base[DC_LANE]; k < base[DC_LANE] + p.count[DC_LANE]; k++) {
+                if (status[p.wl[k]] != VIDC_ST_RETRY) continue;
+                lists2.push_back(p.wl[k]);
+                off2.push_back(out_off_host ? out_off_host[k] : r->offsets[p.wl[k]]);
+            }
+            for (uint32_t l : lists2) status[l] = VIDC_ST_OK;
+            VIDC_TRY(check_status(status, "roc decode"));
+            DecPlan p2;
+            plan_decode(r, lists2, false, p2, false);
+            std::vector<uint64_t> out_off2(lists2.size());
+            for (size_t k = 0; k < lists2.size(); k++) out_off2[k] = off2[p2.item[k]];
+            VIDC_TRY(decode_impl(ctx, r, p2, out_off2.data(), d_out, nullptr, 0));
+            nonclean += r->last_nonclean;
+            ctx->last_kernel_ms += first_ms;
+            ctx->phase_ms[VIDC_PHASE_ROC_DECODE] = ctx->last_kernel_ms;
+        } else {
+            VIDC_TRY(check_status(status, "roc decode"));
+        }
     }
-    r->last_nonclean = sum[1];
+    r->last_nonclean = nonclean;
     return VIDC_OK;
 }
 
@@ -663,6 +721,12 @@ int vidc_roc_export_words(vidc_ctx *ctx, const vidc_roc *r, uint64_t list_no, ui
     uint64_t nw = r->nwords[list_no];
     if (nw > cap) { set_error("export buffer too small (%zu < %llu words)", cap, (unsigned long long)nw); return VIDC_ERR_INVALID; }
     return vidc_copy_d2h(ctx, words, r->d_words.p + r->word_off[list_no], nw * 4);
+}
+
+int vidc_roc_export_all_words(vidc_ctx *ctx, const vidc_roc *r, uint32_t *words, size_t cap) {
+    if (!ctx || !r || (r->total_words && !words)) return VIDC_ERR_INVALID;
+    if (r->total_words > cap) { set_error("export buffer too small (%zu < %llu words)", cap, (unsigned long long)r->total_words); return VIDC_ERR_INVALID; }
+    return vidc_copy_d2h(ctx, words, r->d_words.p, r->total_words * 4);
 }
 
 int vidc_roc_perm(vidc_ctx *ctx, const vidc_roc *r, uint32_t *perm_host) {

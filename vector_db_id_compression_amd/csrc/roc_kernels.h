@@ -534,17 +534,20 @@ __global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t ld
 }
 
 // ---------------------------------------------------------------------------------------------
-// status summary: out[0] = 1 + smallest list number with a non-OK status (0 = none), out[1] = number of lists
-// whose decode did not end in the initial ANS state
+// status summary: out[0] = smallest list number with an error status (~0 = none), out[1] = number of lists
+// whose decode did not end in the initial ANS state, out[2] = number of lists handed back for a retry (status 5)
 __global__ void k_roc_status_summary(const uint32_t *status, const uint32_t *end_state, uint32_t nlist,
                                      unsigned long long *out) {
-    unsigned long long bad = ~0ull, nonclean = 0;
+    unsigned long long bad = ~0ull, nonclean = 0, retry = 0;
     for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x) {
-        if (status[l] != VIDC_ST_OK && (unsigned long long)l < bad) bad = l;
+        const uint32_t s = status[l];
+        if (s == 5u) retry++;  // VIDC_ST_RETRY (roc_lane.h)
+        else if (s != VIDC_ST_OK && (unsigned long long)l < bad) bad = l;
         if (end_state) nonclean += end_state[l];
     }
     if (bad != ~0ull) atomicMin(&out[0], bad);
     if (nonclean) atomicAdd(&out[1], nonclean);
+    if (retry) atomicAdd(&out[2], retry);
 }
 
 // ---------------------------------------------------------------------------------------------

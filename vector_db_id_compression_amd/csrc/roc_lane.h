@@ -1,0 +1,339 @@
+// roc_lane.h -- "one list per LANE" Random Order Coding kernels for short lists (65 .. VIDC_LANE_MAX ids).
+//
+// The wave-per-list kernels of roc_kernels.h spend ~130 wave-wide instructions per codec step on what is almost
+// entirely wave-uniform arithmetic; with tens of thousands of short lists that is the bound (one step of ONE list
+// per ~300 SIMD cycles).  Here every lane runs the serial chain of its own list, so one wave-wide instruction
+// advances 64 lists: the ANS head, stack pointer and divisor are per-lane VGPR values, the order-statistic
+// structure of a list is a private strip of LDS (interleaved by lane: any per-lane index is bank-conflict free),
+// and ANS words go straight to the list's arena / come straight from its stream with per-lane addresses.
+//
+//   encode step (codec.cpp:131-137): k = IDX_pop(n - i) with a table of reciprocals indexed by the divisor,
+//        select+remove the k-th alive position in a 3-level counted bitmap (<= 4 groups x 4 words x 64 bits),
+//        x = ids[position] (the input list is strictly ascending: checked by k_roc_prepass), ID_push(x, P)
+//   decode step (codec.cpp:140-152): x = ID_pop(P); rank of x among the decoded ids through bucket counters
+//        (64 buckets over the top bits, two-level byte counters in LDS) + the members of x's bucket (global
+//        memory, one 64/128-byte row); IDX_push(rank, i + 1)
+//
+// Anything outside the clean domain of these kernels (unsorted or multiset input, bucket overflow on skewed ids,
+// stack underflow in the decoder) is handed back with VIDC_ST_PENDING_SORT / VIDC_ST_RETRY and re-done by the
+// wave-per-list kernels, which handle every case.
+#pragma once
+#include "roc_kernels.h"
+
+namespace vidc {
+namespace dev {
+
+#define VIDC_LANE_MAX 1024u
+#define VIDC_ST_RETRY 5u  // lane decoder: redo this list with the wave-per-list kernel
+
+// entry d of the divisor table (d = 1 .. VIDC_LANE_MAX): x = m_lo, y = m_hi of floor((2^64-1)/d),
+// z = thr = d * floor(2^31/d), w = lq = floor(2^31/d)
+typedef uint4 LaneDiv;
+
+// r-th (0-based) set bit of w; r < popcount(w)
+__device__ __forceinline__ uint32_t lane_select64(uint64_t w, uint32_t r) {
+    uint32_t v = (uint32_t)w;
+    uint32_t c = (uint32_t)__popc(v);
+    uint32_t pos = 0;
+    if (r >= c) { r -= c; v = (uint32_t)(w >> 32); pos = 32; }
+    c = (uint32_t)__popc(v & 0xffffu);
+    if (r >= c) { r -= c; v >>= 16; pos += 16; }
+    c = (uint32_t)__popc(v & 0xffu);
+    if (r >= c) { r -= c; v >>= 8; pos += 8; }
+    c = (uint32_t)__popc(v & 0xfu);
+    if (r >= c) { r -= c; v >>= 4; pos += 4; }
+    c = (uint32_t)__popc(v & 0x3u);
+    if (r >= c) { r -= c; v >>= 2; pos += 2; }
+    c = v & 1u;
+    if (r >= c) pos += 1;
+    return pos;
+}
+
+// per-lane ANS stack in global memory
+struct LStack {
+    uint32_t *mem;       // encoder: the list's arena.  decoder: private scratch for pushed words
+    const uint32_t *orig;  // decoder: the stored stream
+    uint32_t sp, cap, dirty, draws, err;
+    const uint32_t *mt;
+};
+__device__ __forceinline__ void ls_push(LStack &s, uint32_t w) {
+    if (s.sp < s.cap) s.mem[s.sp] = w; else s.err |= 1u;
+    if (s.sp < s.dirty) s.dirty = s.sp;
+    s.sp++;
+}
+__device__ __forceinline__ uint32_t ls_pop(LStack &s) {  // codec.h:32-40
+    if (__builtin_expect(s.sp == 0u, 0)) {
+        uint32_t w = 0;
+        if (s.draws < VIDC_MT_TABLE) w = s.mt[s.draws]; else s.err |= 2u;
+        s.draws++;
+        return w;
+    }
+    s.sp--;
+    return s.sp >= s.dirty ? s.mem[s.sp] : s.orig[s.sp];
+}
+__device__ __forceinline__ bool l_lt_2p31(uint64_t v) { return (v >> 31) == 0; }
+
+// codec.cpp:65-76
+__device__ __forceinline__ void l_u_push(uint64_t &head, LStack &s, uint32_t start, uint32_t p) {
+    if ((uint32_t)(head >> 32) >= (0x80000000u >> p)) {
+        ls_push(s, (uint32_t)head);
+        head >>= 32;
+    }
+    head = (head << p) + start;
+}
+// codec.cpp:78-90
+__device__ __forceinline__ uint32_t l_u_pop(uint64_t &head, LStack &s, uint32_t p) {
+    uint32_t sym = (uint32_t)head & ((1u << p) - 1u);
+    head >>= p;
+    if (l_lt_2p31(head)) head = (head << 32) | ls_pop(s);
+    return sym;
+}
+
+// LDS strip of one lane: u64 bm[NW] | u32 wc[NW/4] (4 byte counters each) | u64 gc (4 u16 counters, NW == 16)
+// element e of lane t lives at base + (e * 64 + t) * size: conflict-free for any per-lane e
+template <int NW>
+struct LaneEncGeom {
+    static constexpr uint32_t BM_BYTES = NW * 64 * 8;
+    static constexpr uint32_t WC_BYTES = (NW / 4) * 64 * 4;
+    static constexpr uint32_t GC_BYTES = NW > 4 ? 64 * 8 : 0;
+    static constexpr uint32_t LDS_BYTES = BM_BYTES + WC_BYTES + GC_BYTES;
+};
+
+template <int NW, bool WANT_PERM>
+__global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const LaneDiv *__restrict__ dtab) {
+    __shared__ __align__(16) unsigned char smem[LaneEncGeom<NW>::LDS_BYTES];
+    uint64_t *bm = (uint64_t *)smem;
+    uint32_t *wc = (uint32_t *)(smem + LaneEncGeom<NW>::BM_BYTES);
+    uint64_t *gc = (uint64_t *)(smem + LaneEncGeom<NW>::BM_BYTES + LaneEncGeom<NW>::WC_BYTES);
+    const uint32_t lane = lane_id();
+    const uint32_t wi = blockIdx.x * 64u + lane;
+    const bool have = wi < a.nwork;
+    const uint32_t l = have ? a.worklist[wi] : 0u;
+    const uint64_t off = have ? a.offsets[l] : 0ull;
+    const uint32_t n = have ? (uint32_t)(a.offsets[l + 1] - off) : 0u;
+    const uint32_t P = have ? a.prec[l] : 0u;  // written by k_roc_prepass
+    const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
+
+    // alive bitmap over the (ascending) input positions + counters
+#pragma unroll
+    for (int g = 0; g < NW / 4; g++) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t w = g * 4 + j;
+            const uint32_t lo_e = w << 6;
+            const uint32_t in_w = lo_e >= n ? 0u : (n - lo_e >= 64u ? 64u : n - lo_e);
+            bm[w * 64 + lane] = in_w == 64u ? ~0ull : ((1ull << in_w) - 1ull);
+            packed |= in_w << (8 * j);
+        }
+        wc[g * 64 + lane] = packed;
+    }
+    if (NW > 4) {
+        uint64_t g4 = 0;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint32_t lo_e = (uint32_t)g << 8;
+            const uint32_t in_g = lo_e >= n ? 0u : (n - lo_e >= 256u ? 256u : n - lo_e);
+            g4 |= (uint64_t)in_g << (16 * g);
+        }
+        gc[lane] = g4;
+    }
+
+    LStack st;
+    {
+        const uint64_t ao = have ? a.arena_off[l] : 0ull;
+        st.mem = a.arena + ao;
+        st.orig = st.mem;
+        st.cap = have ? (uint32_t)(a.arena_off[l + 1] - ao) : 0u;
+        st.sp = 0; st.dirty = 0; st.draws = 0; st.err = 0; st.mt = a.mt;
+    }
+    uint64_t head = VIDC_RANS_L;
+    const uint64_t *ids = a.ids + off;
+    const uint32_t nsteps = wave_max_u32(n);
+
+    for (uint32_t i = 0; i < nsteps; i++) {
+        if (i < n) {
+            // ---- k = IDX_pop(n - i), codec.cpp:21-42
+            const uint32_t d = n - i;
+            const LaneDiv dv = dtab[d];
+            uint64_t h0 = head;
+            if ((uint32_t)(h0 >> 32) >= dv.z) {  // h0 >= nmax * ((L / nmax) << 32)
+                ls_push(st, (uint32_t)h0);
+                h0 >>= 32;
+            }
+            uint64_t q = __umul64hi(h0, ((uint64_t)dv.y << 32) | dv.x);
+            uint32_t k = (uint32_t)h0 - (uint32_t)q * d;
+            if (k >= d) { k -= d; q++; }
+            if (__builtin_expect(l_lt_2p31(h0), 0)) q = (uint64_t)ls_pop(st) | (q << 32);  // test on h0 (codec.cpp:35)
+            head = q;
+
+            // ---- select + remove the k-th alive position
+            uint32_t g = 0;
+            if (NW > 4) {
+                const uint64_t gv = gc[lane];
+                const uint32_t c0 = (uint32_t)gv & 0xffffu, c1 = (uint32_t)(gv >> 16) & 0xffffu,
+                               c2 = (uint32_t)(gv >> 32) & 0xffffu;
+                const uint32_t q0 = c0, q1 = c0 + c1, q2 = q1 + c2;
+                uint32_t base = 0;
+                if (k >= q0) { g = 1; base = q0; }
+                if (k >= q1) { g = 2; base = q1; }
+                if (k >= q2) { g = 3; base = q2; }
+                k -= base;
+                gc[lane] = gv - (1ull << (16u * g));
+            }
+            const uint32_t wv = wc[g * 64 + lane];
+            uint32_t j = 0;
+            {
+                const uint32_t c0 = wv & 0xffu, c1 = (wv >> 8) & 0xffu, c2 = (wv >> 16) & 0xffu;
+                const uint32_t q0 = c0, q1 = c0 + c1, q2 = q1 + c2;
+                uint32_t base = 0;
+                if (k >= q0) { j = 1; base = q0; }
+                if (k >= q1) { j = 2; base = q1; }
+                if (k >= q2) { j = 3; base = q2; }
+                k -= base;
+                wc[g * 64 + lane] = wv - (1u << (8u * j));
+            }
+            const uint32_t w = g * 4u + j;
+            const uint64_t word = bm[w * 64 + lane];
+            const uint32_t b = lane_select64(word, k);
+            bm[w * 64 + lane] = word & ~(1ull << b);
+            const uint32_t pos = (w << 6) + b;
+            const uint32_t x = (uint32_t)ids[pos];
+            if (WANT_PERM) a.perm[off + i] = pos;
+
+            // ---- ID_push(x, P), codec.cpp:92-105
+            l_u_push(head, st, x & 0xffffu, p0);
+            l_u_push(head, st, x >> 16, p1);
+            if (__builtin_expect((uint32_t)(head >> 63) != 0u, 0)) {  // slices 2, 3: precision 0, symbol 0
+                l_u_push(head, st, 0u, 0u);
+                l_u_push(head, st, 0u, 0u);
+            }
+        }
+    }
+    if (have) {
+        a.heads[l] = head;
+        a.nwords[l] = st.sp;
+        a.draws[l] = st.draws;
+        a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// decoder: rank of x among the ids decoded so far.  64 buckets over the top 6 bits of the P-bit universe; LDS per
+// lane: 64 byte counters (4 groups x 16) + 4 u16 group counters; bucket members (u32, unsorted) in a row of
+// `cap` slots in global memory, written in chunks of 4 so that every chunk below ceil(count/4) is fully defined.
+__host__ __device__ inline uint32_t roc_lane_cap(uint32_t n) { return (((n >> 6) * 2u + 12u) + 3u) & ~3u; }
+
+// sum of the bytes j < t (t <= 8) of the 8-byte value v
+__device__ __forceinline__ uint32_t lane_sum_bytes_below(uint64_t v, uint32_t t) {
+    const uint64_t m = (v << 8) << (56u - 8u * (t > 7u ? 7u : t));  // bytes j < min(t, 7) moved to the top, rest dropped
+    uint32_t s = __builtin_amdgcn_sad_u8((uint32_t)m, 0u, 0u);
+    s = __builtin_amdgcn_sad_u8((uint32_t)(m >> 32), 0u, s);
+    if (t > 7u) s += (uint32_t)(v >> 56);
+    return s;
+}
+// sum of the u16 fields j < t (t <= 3) of v
+__device__ __forceinline__ uint32_t lane_sum_u16_below(uint64_t v, uint32_t t) {
+    const uint64_t m = (v << 16) << (48u - 16u * t);
+    uint32_t s = __builtin_amdgcn_sad_u16((uint32_t)m, 0u, 0u);
+    return __builtin_amdgcn_sad_u16((uint32_t)(m >> 32), 0u, s);
+}
+
+struct LaneDecGeom {
+    static constexpr uint32_t CNT_BYTES = 4 * 64 * 16;  // uint4 cnt[4][64]
+    static constexpr uint32_t GRP_BYTES = 64 * 8;       // u64 grp[64]
+    static constexpr uint32_t LDS_BYTES = CNT_BYTES + GRP_BYTES;
+};
+
+__global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const LaneDiv *__restrict__ dtab) {
+    __shared__ __align__(16) unsigned char smem[LaneDecGeom::LDS_BYTES];
+    uint4 *cnt4 = (uint4 *)smem;
+    unsigned char *cnt1 = smem;
+    uint64_t *grp = (uint64_t *)(smem + LaneDecGeom::CNT_BYTES);
+    const uint32_t lane = lane_id();
+    const uint32_t wi = blockIdx.x * 64u + lane;
+    const bool have = wi < a.nwork;
+    const uint32_t l = have ? a.worklist[wi] : 0u;
+    const uint32_t n = have ? (uint32_t)(a.offsets[l + 1] - a.offsets[l]) : 0u;
+    const uint64_t ooff = have ? (a.out_off ? a.out_off[wi] : a.offsets[l]) : 0ull;
+    const uint32_t P = have ? a.prec[l] : 0u;
+    const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
+    const uint32_t bsh = P > 6u ? P - 6u : 0u;
+    const uint32_t cap = roc_lane_cap(n);
+#pragma unroll
+    for (int g = 0; g < 4; g++) cnt4[g * 64 + lane] = make_uint4(0, 0, 0, 0);
+    grp[lane] = 0;
+
+    LStack st;
+    const uint32_t W = have ? a.nwords[l] : 0u;
+    st.orig = a.words + (have ? a.word_off[l] : 0ull);
+    st.mem = a.scratch_words + (have ? a.scratch_off[wi] : 0ull);
+    st.cap = W + 64u; st.sp = W; st.dirty = 0xffffffffu; st.err = 0; st.mt = a.mt;
+    st.draws = have ? a.draws[l] : 0u;
+    const uint32_t draws0 = st.draws;
+    uint64_t head = have ? a.heads[l] : VIDC_RANS_L;
+    uint32_t *slots = a.slots + (have ? a.slots_off[wi] : 0ull);
+    uint32_t n_eff = n;
+    bool retry = false;
+    const uint32_t nsteps = wave_max_u32(n);
+
+    for (uint32_t i = 0; i < nsteps; i++) {
+        const uint32_t lq = dtab[i + 1u].w;  // uniform: floor(2^31 / (i + 1))
+        if (i < n_eff) {
+            // ---- x = ID_pop(P), codec.cpp:107-121 (slices 3, 2 have precision 0: refill test only)
+            if (__builtin_expect(l_lt_2p31(head), 0)) {
+                (void)l_u_pop(head, st, 0u);
+                (void)l_u_pop(head, st, 0u);
+            }
+            const uint32_t hi = l_u_pop(head, st, p1);
+            const uint32_t lo = l_u_pop(head, st, p0);
+            const uint32_t x = (hi << 16) | lo;
+            // ---- rank of x among the decoded ids
+            const uint32_t b = (bsh >= 32u ? 0u : (x >> bsh)) & 63u;
+            const uint32_t g = b >> 4, j = b & 15u;
+            const uint64_t gv = grp[lane];
+            uint32_t r = lane_sum_u16_below(gv, g);
+            const uint4 cv = cnt4[g * 64 + lane];
+            const uint64_t c_lo = ((uint64_t)cv.y << 32) | cv.x, c_hi = ((uint64_t)cv.w << 32) | cv.z;
+            r += lane_sum_bytes_below(c_lo, j < 8u ? j : 8u);
+            r += j > 8u ? lane_sum_bytes_below(c_hi, j - 8u) : 0u;
+            const uint32_t cb = cnt1[(g * 64 + lane) * 16 + j];
+            const uint4 *row4 = (const uint4 *)(slots + (size_t)b * cap);
+            for (uint32_t c = 0; c * 4u < cb; c++) {
+                const uint4 v = row4[c];
+                r += (v.x < x) + (v.y < x) + (v.z < x) + (v.w < x);
+            }
+            // ---- IDX_push(r, i + 1), codec.cpp:44-63
+            {
+                uint64_t h0 = head;
+                if ((uint32_t)(h0 >> 32) >= lq) {
+                    ls_push(st, (uint32_t)h0);
+                    h0 >>= 32;
+                }
+                uint64_t h = h0 * (uint64_t)(i + 1u) + r;
+                if (__builtin_expect(l_lt_2p31(h), 0)) h = (uint64_t)ls_pop(st) | (h << 32);
+                head = h;
+            }
+            // ---- insert x
+            if (__builtin_expect(cb >= cap, 0)) {
+                retry = true;  // skewed ids: this bucket is full -> the wave-per-list kernel redoes the list
+                n_eff = 0;
+            } else {
+                uint32_t *row = slots + (size_t)b * cap;
+                if ((cb & 3u) == 0u) *(uint4 *)(row + cb) = make_uint4(x, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+                else row[cb] = x;
+                cnt1[(g * 64 + lane) * 16 + j] = (unsigned char)(cb + 1u);
+                grp[lane] = gv + (1ull << (16u * g));
+                a.out[ooff + (n - 1u - i)] = (uint64_t)x;
+            }
+        }
+    }
+    if (have) {
+        const bool clean = (head == VIDC_RANS_L) && (st.sp == st.draws - draws0);
+        a.end_state[l] = (clean || retry) ? 0u : 1u;
+        a.status[l] = retry ? VIDC_ST_RETRY : (st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK);
+    }
+}
+
+}  // namespace dev
+}  // namespace vidc
