@@ -162,6 +162,7 @@ int finish_encode(vidc_ctx *ctx, vidc_roc *r, const uint32_t *d_arena, const uin
         VIDC_HIP(hipMemcpyAsync(r->heads.data(), r->d_heads.p, nlist * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    HostTrace tr("roc encode/finish");
     VIDC_TRY(check_status(status, "roc encode"));
     r->word_off.assign(nlist + 1, 0);
     r->compressed_bytes = 0;
@@ -172,7 +173,9 @@ int finish_encode(vidc_ctx *ctx, vidc_roc *r, const uint32_t *d_arena, const uin
     }
     r->total_words = r->word_off[nlist];
     VIDC_TRY(upload(ctx, r->d_word_off, r->word_off));
+    tr.mark("word offsets");
     VIDC_TRY(r->d_words.alloc(r->total_words ? r->total_words : 1));
+    tr.mark("words alloc");
     if (nlist) {
         EventTimer t(ctx);
         uint32_t grid = (uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 16);
@@ -214,6 +217,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     VIDC_TRY(r->d_heads.alloc(nlist)); VIDC_TRY(r->d_prec.alloc(nlist));
     VIDC_TRY(r->d_nwords.alloc(nlist)); VIDC_TRY(r->d_draws.alloc(nlist));
     if (want_perm) VIDC_TRY(r->d_perm.alloc(ntotal_in ? ntotal_in : 1));
+    tr.mark("persistent allocs");
     Scratch s_arena, s_arena_off, s_status, s_sizes, s_sid, s_wl, s_maxid, s_flags;
     if (rows) {
         if (K == 0 || K > TINY_MAX) {
@@ -242,6 +246,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         }
         r->ntotal = offsets[nlist];
         VIDC_TRY(upload(ctx, r->d_offsets, r->offsets));
+        tr.mark("offsets + arena sizes");
         // classification prepass (one wavefront per list): max id -> precision, sortedness, domain
         std::vector<uint32_t> maxid(nlist, 0), pflags(nlist, 0);
         if (any_big) {
@@ -256,10 +261,12 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             VIDC_HIP(hipMemcpyAsync(maxid.data(), s_maxid.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
             VIDC_HIP(hipMemcpyAsync(pflags.data(), s_flags.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
             VIDC_HIP(hipStreamSynchronize(ctx->stream));
+            tr.mark("prepass kernel + d2h");
         }
         // The bitmap kernels own a whole CU's LDS (2^20-bit universe): latency-optimal for long lists, but only
         // num_cu lists in flight.  With many lists, short ones go to the high-occupancy general kernels.
         const uint64_t u_min = U_MIN_LIST;
+        const bool f_general = force_general(), use_lane = !f_general && !no_lane();  // getenv once, not per list
         for (uint64_t l = 0; l < nlist; l++) {
             uint64_t n = offsets[l + 1] - offsets[l];
             if (n <= TINY_MAX) { wl_tiny.push_back((uint32_t)l); continue; }
@@ -270,9 +277,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             }
             uint32_t width = maxid[l] ? 32u - (uint32_t)__builtin_clz(maxid[l]) : 0u;  // ids < 2^width
             // the bitmap kernels need no sort; they cannot report input positions of an unsorted list
-            bool u_ok = !force_general() && !((pflags[l] & VIDC_PF_UNSORTED) && want_perm) &&
+            bool u_ok = !f_general && !((pflags[l] & VIDC_PF_UNSORTED) && want_perm) &&
                         (n >= u_min || (pflags[l] & VIDC_PF_UNSORTED));
-            const bool lane_ok = !force_general() && !no_lane() && !(pflags[l] & VIDC_PF_UNSORTED) && n <= VIDC_LANE_MAX;
+            const bool lane_ok = use_lane && !(pflags[l] & VIDC_PF_UNSORTED) && n <= VIDC_LANE_MAX;
             if (u_ok && width <= 18) wl_u18.push_back((uint32_t)l);
             else if (u_ok && width <= 20) wl_u20.push_back((uint32_t)l);
             else if (lane_ok && n <= 256) wl_l4.push_back((uint32_t)l);
@@ -465,13 +472,13 @@ struct DecPlan {
     uint64_t scratch_words = 0, slots_words = 0;
 };
 
-inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool allow_lane) {
+inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane) {
     if (n <= TINY_MAX) return DC_TINY;
-    if (!force_general() && n >= u_min) {
+    if (!f_general && n >= u_min) {
         if (P <= 18) return DC_U18;
         if (P <= 20) return DC_U20;
     }
-    if (allow_lane && n <= VIDC_LANE_MAX && !force_general() && !no_lane()) return DC_LANE;
+    if (allow_lane && n <= VIDC_LANE_MAX) return DC_LANE;
     if (n <= GEN_SMALL_MAX) return DC_GSMALL;
     if (n <= 32768) return DC_GMID;
     return DC_GHUGE;
@@ -482,10 +489,12 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
                  bool allow_lane = true) {
     std::vector<uint32_t> cls[DC_COUNT];
     const uint64_t u_min = U_MIN_LIST;
+    const bool f_general = force_general();
+    allow_lane = allow_lane && !f_general && !no_lane();
     for (uint32_t i = 0; i < lists.size(); i++) {
         uint32_t l = lists[i];
         uint64_t n = r->offsets[l + 1] - r->offsets[l];
-        cls[rows_flavour ? DC_TINY : dec_class(n, r->prec[l], u_min, allow_lane)].push_back(i);
+        cls[rows_flavour ? DC_TINY : dec_class(n, r->prec[l], u_min, f_general, allow_lane)].push_back(i);
     }
     auto len = [&](uint32_t i) { return r->offsets[lists[i] + 1] - r->offsets[lists[i]]; };
     p.wl.clear(); p.item.clear();
@@ -544,6 +553,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     VIDC_HIP(hipSetDevice(ctx->device));
     const size_t nwork = p.wl.size();
     if (nwork == 0) { ctx->last_kernel_ms = 0; return VIDC_OK; }
+    HostTrace tr("roc decode");
     Scratch s_wl, s_scr_off, s_slots_off, s_scr, s_slots, s_out_off, s_end, s_status, s_sum;
     const uint32_t *d_wl;
     const uint64_t *d_scr_off, *d_slots_off;
@@ -565,6 +575,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         VIDC_TRY(s_out_off.get(ctx, nwork * 8));
         VIDC_HIP(hipMemcpyAsync(s_out_off.p, out_off_host, nwork * 8, hipMemcpyHostToDevice, ctx->stream));
     }
+    tr.mark("scratch + uploads");
     RocDecArgs a{};
     a.offsets = r->d_offsets.p;
     a.heads = r->d_heads.p; a.prec = r->d_prec.p; a.nwords = r->d_nwords.p; a.draws = r->d_draws.p;
@@ -634,6 +645,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     }
     ctx->last_kernel_ms = t.stop();
     ctx->phase_ms[VIDC_PHASE_ROC_DECODE] = ctx->last_kernel_ms;
+    tr.mark("decode kernels (sync)");
 
     // 16-byte summary instead of copying two nlist-sized arrays back
     VIDC_TRY(s_sum.get(ctx, 24));
@@ -646,6 +658,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     unsigned long long sum[3] = {0, 0, 0};
     VIDC_HIP(hipMemcpyAsync(sum, s_sum.p, 24, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    tr.mark("status summary");
     const double first_ms = ctx->last_kernel_ms;
     uint64_t nonclean = sum[1];
     if (sum[0] != ~0ull || sum[2]) {
@@ -777,14 +790,17 @@ int vidc_roc_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, cons
 int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out) {
     if (!ctx || !r || (r->ntotal && !d_out)) return VIDC_ERR_INVALID;
     if (!r->plan_all) {
+        HostTrace tr("roc decode_all");
         std::vector<uint32_t> all(r->nlist);
         std::iota(all.begin(), all.end(), 0u);
         auto c = std::make_shared<DecPlanCache>();
         plan_decode(r, all, false, c->plan);
+        tr.mark("plan");
         VIDC_HIP(hipSetDevice(ctx->device));
         VIDC_TRY(upload(ctx, c->d_wl, c->plan.wl));
         VIDC_TRY(upload(ctx, c->d_scratch_off, c->plan.scratch_off));
         VIDC_TRY(upload(ctx, c->d_slots_off, c->plan.slots_off));
+        tr.mark("plan upload");
         r->plan_all = c;
     }
     return decode_impl(ctx, r, r->plan_all->plan, nullptr, d_out, nullptr, 0, r->plan_all.get());
