@@ -174,7 +174,7 @@ int finish_encode(vidc_ctx *ctx, vidc_roc *r, const uint32_t *d_arena, const uin
     r->total_words = r->word_off[nlist];
     VIDC_TRY(upload(ctx, r->d_word_off, r->word_off));
     tr.mark("word offsets");
-    VIDC_TRY(r->d_words.alloc(r->total_words ? r->total_words : 1));
+    VIDC_TRY(r->d_words.alloc(r->total_words + 4));  // + padding: the lane decoder's look-ahead reads orig[0..1]
     tr.mark("words alloc");
     if (nlist) {
         EventTimer t(ctx);
@@ -375,7 +375,13 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         if (!wl_tiny.empty()) {
             RocEncArgs b = a;
             b.worklist = d_wl; b.nwork = (uint32_t)wl_tiny.size();
-            if (rows) hipLaunchKernelGGL(k_roc_encode_tiny<true>, dim3(b.nwork), dim3(64), 0, ctx->aux[2], b);
+            if (!force_general() && !no_lane()) {  // one list per lane (roc_lane.h)
+                const dim3 grid((b.nwork + 63u) / 64u);
+                const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
+                if (rows && K <= 32) hipLaunchKernelGGL((k_roc_encode_tiny_lane<32, true>), grid, dim3(64), 0, ctx->aux[2], b, dt);
+                else if (rows) hipLaunchKernelGGL((k_roc_encode_tiny_lane<64, true>), grid, dim3(64), 0, ctx->aux[2], b, dt);
+                else hipLaunchKernelGGL((k_roc_encode_tiny_lane<64, false>), grid, dim3(64), 0, ctx->aux[2], b, dt);
+            } else if (rows) hipLaunchKernelGGL(k_roc_encode_tiny<true>, dim3(b.nwork), dim3(64), 0, ctx->aux[2], b);
             else hipLaunchKernelGGL(k_roc_encode_tiny<false>, dim3(b.nwork), dim3(64), 0, ctx->aux[2], b);
             VIDC_HIP(hipGetLastError());
         }
@@ -609,7 +615,12 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         b.slots_off = d_slots_off + base[c];
         switch (c) {
             case DC_TINY:
-                if (d_out_rows) hipLaunchKernelGGL(k_roc_decode_tiny<true>, dim3(b.nwork), dim3(64), 0, st_, b);
+                if (!force_general() && !no_lane()) {  // one list per lane (roc_lane.h)
+                    const dim3 grid((b.nwork + 63u) / 64u);
+                    const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
+                    if (d_out_rows) hipLaunchKernelGGL(k_roc_decode_tiny_lane<true>, grid, dim3(64), 0, st_, b, dt);
+                    else hipLaunchKernelGGL(k_roc_decode_tiny_lane<false>, grid, dim3(64), 0, st_, b, dt);
+                } else if (d_out_rows) hipLaunchKernelGGL(k_roc_decode_tiny<true>, dim3(b.nwork), dim3(64), 0, st_, b);
                 else hipLaunchKernelGGL(k_roc_decode_tiny<false>, dim3(b.nwork), dim3(64), 0, st_, b);
                 break;
             case DC_U18:
@@ -779,7 +790,7 @@ int vidc_roc_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, cons
     VIDC_TRY(upload(ctx, r->d_nwords, r->nwords));
     VIDC_TRY(upload(ctx, r->d_draws, r->draws));
     VIDC_TRY(upload(ctx, r->d_word_off, r->word_off));
-    VIDC_TRY(r->d_words.alloc(r->total_words ? r->total_words : 1));
+    VIDC_TRY(r->d_words.alloc(r->total_words + 4));  // + padding: the lane decoder's look-ahead reads orig[0..1]
     if (r->total_words)
         VIDC_HIP(hipMemcpyAsync(r->d_words.p, words_concat, r->total_words * 4, hipMemcpyHostToDevice, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));

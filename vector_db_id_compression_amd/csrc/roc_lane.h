@@ -335,5 +335,252 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
     }
 }
 
+// ===============================================================================================================
+// TINY lists / graph rows (n <= 64) per lane: the whole codec state of a list is on chip.
+//   encoder: the row is sorted by a compile-time bitonic network over 64 (or 32) registers of the lane (672
+//            min/max pairs for 64 rows at once), the sorted ids go to an LDS strip, the alive set is one u64 mask
+//   decoder: the stream words are copied to an LDS strip (the ANS stack shrinks from its top while the decoded
+//            ids grow down from the end of the same strip), rank = linear scan over the decoded ids
+// No global load sits on the serial chain (the divisor table is copied to LDS), so a step never waits on memory.
+// ===============================================================================================================
+template <int KP>
+__device__ __forceinline__ void lane_bitonic(uint32_t (&r)[KP]) {
+#pragma unroll
+    for (int k = 2; k <= KP; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int e = 0; e < KP; e++) {
+                const int p = e ^ j;
+                if (p > e) {
+                    const uint32_t lo = r[e] < r[p] ? r[e] : r[p], hi = r[e] < r[p] ? r[p] : r[e];
+                    const bool up = (e & k) == 0;
+                    r[e] = up ? lo : hi;
+                    r[p] = up ? hi : lo;
+                }
+            }
+        }
+    }
+}
+
+template <int KP, bool ROWS>
+__global__ void __launch_bounds__(64) k_roc_encode_tiny_lane(RocEncArgs a, const LaneDiv *__restrict__ dtab) {
+    __shared__ uint32_t sid[KP * 64];
+    __shared__ LaneDiv dt[KP + 1];
+    const uint32_t lane = lane_id();
+    const uint32_t wi = blockIdx.x * 64u + lane;
+    const bool have = wi < a.nwork;
+    const uint32_t l = have ? a.worklist[wi] : 0u;
+    for (uint32_t t = lane; t <= (uint32_t)KP; t += 64) dt[t] = dtab[t];
+
+    uint32_t r[KP];
+    uint32_t n = 0;
+    uint64_t off = 0;
+    bool bad = false, unsorted = false;
+    if (ROWS) {
+        // altid_impl.cpp:110-117: edges up to the first -1
+        off = (uint64_t)l * a.K;
+        const int32_t *row = a.rows + off;
+        if ((a.K & 3u) == 0u) {
+#pragma unroll
+            for (int e = 0; e < KP; e += 4) {
+                int4 v = make_int4(-1, -1, -1, -1);
+                if (have && (uint32_t)e < a.K) v = *(const int4 *)(row + e);
+                r[e] = (uint32_t)v.x; r[e + 1] = (uint32_t)v.y; r[e + 2] = (uint32_t)v.z; r[e + 3] = (uint32_t)v.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < KP; e++) r[e] = (have && (uint32_t)e < a.K) ? (uint32_t)row[e] : 0xffffffffu;
+        }
+        n = have ? a.K : 0u;
+#pragma unroll
+        for (int e = KP - 1; e >= 0; e--) n = (r[e] == 0xffffffffu && (uint32_t)e < n) ? (uint32_t)e : n;
+#pragma unroll
+        for (int e = 0; e < KP; e++) {
+            bad |= (uint32_t)e < n && (int32_t)r[e] < 0;
+            r[e] = (uint32_t)e < n ? r[e] : 0xffffffffu;
+        }
+    } else {
+        off = have ? a.offsets[l] : 0ull;
+        n = have ? (uint32_t)(a.offsets[l + 1] - off) : 0u;
+        uint32_t prev = 0;
+#pragma unroll
+        for (int e = 0; e < KP; e++) {
+            uint64_t id = 0;
+            if ((uint32_t)e < n) id = a.ids[off + e];
+            bad |= id >= (1ull << 31);  // reference: int max_id (custom_invlists_impl.cpp:163)
+            const uint32_t v = (uint32_t)id;
+            unsorted |= (uint32_t)e < n && e > 0 && prev >= v;
+            prev = v;
+            r[e] = (uint32_t)e < n ? v : 0xffffffffu;
+        }
+    }
+    uint32_t mx = 0;
+#pragma unroll
+    for (int e = 0; e < KP; e++) mx = ((uint32_t)e < n && r[e] > mx) ? r[e] : mx;
+    const uint32_t P = precision_for(mx, a.precision_mode);
+    const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
+    // graph rows are in no particular order; IVF lists normally ascend (Faiss add order)
+    const bool want_perm = !ROWS && a.perm != nullptr;
+    const bool pending = want_perm && unsorted;  // input positions of an unsorted list: wave-per-list kernel
+    if (ROWS || ballot(unsorted && !pending)) lane_bitonic<KP>(r);
+#pragma unroll
+    for (int e = 0; e < KP; e++) sid[e * 64 + lane] = r[e];
+    if (ROWS && have) a.sizes[l] = n;
+    __syncthreads();
+
+    LStack st;
+    {
+        const uint64_t ao = have ? a.arena_off[l] : 0ull;
+        st.mem = a.arena + ao;
+        st.orig = st.mem;
+        st.cap = have ? (uint32_t)(a.arena_off[l + 1] - ao) : 0u;
+        st.sp = 0; st.dirty = 0; st.draws = 0; st.err = 0; st.mt = a.mt;
+    }
+    uint64_t head = VIDC_RANS_L;
+    uint64_t alive = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+    const uint32_t n_eff = (bad || pending) ? 0u : n;
+    const uint32_t nsteps = wave_max_u32(n_eff);
+    for (uint32_t i = 0; i < nsteps; i++) {
+        if (i < n_eff) {
+            const uint32_t d = n - i;
+            const LaneDiv dv = dt[d];
+            uint64_t h0 = head;
+            if ((uint32_t)(h0 >> 32) >= dv.z) {
+                ls_push(st, (uint32_t)h0);
+                h0 >>= 32;
+            }
+            uint64_t q = __umul64hi(h0, ((uint64_t)dv.y << 32) | dv.x);
+            uint32_t k = (uint32_t)h0 - (uint32_t)q * d;
+            if (k >= d) { k -= d; q++; }
+            if (__builtin_expect(l_lt_2p31(h0), 0)) q = (uint64_t)ls_pop(st) | (q << 32);
+            head = q;
+            const uint32_t pos = lane_select64(alive, k);
+            alive &= ~(1ull << pos);
+            const uint32_t x = sid[pos * 64 + lane];
+            if (want_perm) a.perm[off + i] = pos;
+            l_u_push(head, st, x & 0xffffu, p0);
+            l_u_push(head, st, x >> 16, p1);
+            if (__builtin_expect((uint32_t)(head >> 63) != 0u, 0)) {
+                l_u_push(head, st, 0u, 0u);
+                l_u_push(head, st, 0u, 0u);
+            }
+        }
+    }
+    if (have) {
+        if (bad) {
+            a.status[l] = VIDC_ST_DOMAIN;
+        } else if (pending) {
+            a.status[l] = VIDC_ST_PENDING_SORT;
+        } else {
+            a.heads[l] = head;
+            a.prec[l] = n ? P : 0u;
+            a.nwords[l] = st.sp;
+            a.draws[l] = st.draws;
+            a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
+        }
+    }
+}
+
+#define VIDC_TINY_STRIP 84u  // LDS words per lane of the tiny decoder: >= n + 2 + slack for n <= 64, P <= 32
+
+template <bool ROWS>
+__global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const LaneDiv *__restrict__ dtab) {
+    __shared__ uint32_t buf[VIDC_TINY_STRIP * 64];  // word w of this lane: buf[w * 64 + lane]
+    const uint32_t lane = lane_id();
+    const uint32_t wi = blockIdx.x * 64u + lane;
+    const bool have = wi < a.nwork;
+    const uint32_t l = have ? a.worklist[wi] : 0u;
+    const uint32_t n = have ? (uint32_t)(a.offsets[l + 1] - a.offsets[l]) : 0u;
+    const uint64_t ooff = have ? (a.out_off ? a.out_off[wi] : a.offsets[l]) : 0ull;
+    const uint32_t P = have ? a.prec[l] : 0u;
+    const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
+    const uint32_t W = have ? a.nwords[l] : 0u;
+    const uint32_t *orig = a.words + (have ? a.word_off[l] : 0ull);
+    uint32_t err = (W > VIDC_TINY_STRIP) ? 1u : 0u;
+    const uint32_t Wc = err ? 0u : W;
+    {
+        const uint32_t wmax = wave_max_u32(Wc);
+        for (uint32_t w = 0; w < wmax; w++)
+            if (w < Wc) buf[w * 64 + lane] = orig[w];
+    }
+    uint32_t sp = Wc;
+    uint32_t draws = have ? a.draws[l] : 0u;
+    const uint32_t draws0 = draws;
+    uint64_t head = have ? a.heads[l] : VIDC_RANS_L;
+    const uint32_t n_eff = err ? 0u : n;
+    const uint32_t nsteps = wave_max_u32(n_eff);
+
+    auto pop = [&]() -> uint32_t {  // codec.h:32-40
+        if (__builtin_expect(sp == 0u, 0)) {
+            uint32_t w = 0;
+            if (draws < VIDC_MT_TABLE) w = a.mt[draws]; else err |= 2u;
+            draws++;
+            return w;
+        }
+        sp--;
+        return buf[sp * 64 + lane];
+    };
+    auto u_pop = [&](uint32_t p) -> uint32_t {  // codec.cpp:78-90
+        const uint32_t sym = (uint32_t)head & ((1u << p) - 1u);
+        head >>= p;
+        if (l_lt_2p31(head)) head = (head << 32) | pop();
+        return sym;
+    };
+
+    for (uint32_t i = 0; i < nsteps; i++) {
+        const uint32_t lq = dtab[i + 1u].w;  // uniform: floor(2^31 / (i + 1))
+        if (i < n_eff) {
+            if (__builtin_expect(l_lt_2p31(head), 0)) {
+                (void)u_pop(0u);
+                (void)u_pop(0u);
+            }
+            const uint32_t hi = u_pop(p1);
+            const uint32_t lo = u_pop(p0);
+            const uint32_t x = (hi << 16) | lo;
+            // rank among the i ids decoded so far (strictly smaller, fenwick_tree.h:42-94)
+            uint32_t r = 0;
+            const uint32_t *top = buf + (VIDC_TINY_STRIP - 1u) * 64u + lane;
+            uint32_t e = 0;
+            for (; e + 4u <= i; e += 4u) {
+                const uint32_t v0 = top[-(int)(e * 64u)], v1 = top[-(int)((e + 1u) * 64u)],
+                               v2 = top[-(int)((e + 2u) * 64u)], v3 = top[-(int)((e + 3u) * 64u)];
+                r += (uint32_t)(v0 < x) + (uint32_t)(v1 < x) + (uint32_t)(v2 < x) + (uint32_t)(v3 < x);
+            }
+            for (; e < i; e++) r += (uint32_t)(top[-(int)(e * 64u)] < x);
+            // IDX_push(r, i + 1), codec.cpp:44-63
+            {
+                uint64_t h0 = head;
+                if (__builtin_expect((uint32_t)(h0 >> 32) >= lq, 0)) {
+                    if (sp + i + 1u < VIDC_TINY_STRIP) buf[sp * 64 + lane] = (uint32_t)h0; else err |= 1u;
+                    sp++;
+                    h0 >>= 32;
+                }
+                uint64_t h = h0 * (uint64_t)(i + 1u) + r;
+                if (__builtin_expect(l_lt_2p31(h), 0)) h = (uint64_t)pop() | (h << 32);
+                head = h;
+            }
+            if (sp + i < VIDC_TINY_STRIP) buf[(VIDC_TINY_STRIP - 1u - i) * 64u + lane] = x; else err |= 1u;
+        }
+    }
+    // decoded order == sampling order: out[n-1-i] = id of step i (codec.cpp:150)
+    for (uint32_t i = 0; i < nsteps; i++) {
+        if (i < n_eff) {
+            const uint32_t x = buf[(VIDC_TINY_STRIP - 1u - i) * 64u + lane];
+            if (ROWS) a.out_rows[ooff + (n - 1u - i)] = (int32_t)x;
+            else a.out[ooff + (n - 1u - i)] = (uint64_t)x;
+        }
+    }
+    if (ROWS && have) {
+        // pad the row with -1 (the reference leaves slots >= n untouched, altid_impl.cpp:153-165)
+        for (uint32_t e = n; e < a.K; e++) a.out_rows[ooff + e] = -1;
+    }
+    if (have) {
+        const bool clean = (head == VIDC_RANS_L) && (sp == draws - draws0);
+        a.end_state[l] = (clean || n == 0u) ? 0u : 1u;
+        a.status[l] = err ? ((err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
+    }
+}
+
 }  // namespace dev
 }  // namespace vidc

@@ -107,6 +107,10 @@ def workload(name, seed=42, device="cuda"):
     elif name == "s2":
         off, ids = make_lists_torch(1_000_000_000, 1 << 20, 0.75, seed + 1, cap=65536, device=device)
         desc = "S2: 1B ids in 2^20 Zipf(s=0.75) lists capped at 65536"
+    elif name.startswith("uniform:"):  # "uniform:<nlist>:<ids per list>" (dev sweeps)
+        _, nl, per = name.split(":")
+        off, ids = make_lists_torch(int(nl) * int(per), int(nl), 0.0, seed, device=device)
+        desc = f"{int(nl) * int(per)} ids in {nl} equal-sized lists ({per} ids each)"
     else:
         raise ValueError(name)
     sizes = (off[1:] - off[:-1]).astype(np.int64)
