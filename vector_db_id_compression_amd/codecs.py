@@ -41,7 +41,16 @@ class RocLists:
     def __init__(self, handle, ctx, offsets):
         self.h = handle
         self.ctx = ctx
-        self.offsets = offsets
+        self._offsets = offsets
+
+    @property
+    def offsets(self):
+        """CSR offsets of the decoded output.  Graph objects fetch the edge counts from the device on first use
+        (the per-node metadata stays on the GPU otherwise)."""
+        if self._offsets is None:
+            sizes = self.info()["sizes"]
+            self._offsets = np.concatenate([[0], np.cumsum(sizes, dtype=np.uint64)]).astype(np.uint64)
+        return self._offsets
 
     def __del__(self):
         try:  # may run during interpreter shutdown, after module globals are gone
@@ -77,8 +86,6 @@ class RocLists:
         h = C.c_void_p()
         check(lib().vidc_roc_encode_rows(ctx.h, N, K, ptr(rows) if N else None, int(precision_mode), 0, C.byref(h)))
         obj = cls(h, ctx, None)
-        sizes = obj.info()["sizes"]
-        obj.offsets = np.concatenate([[0], np.cumsum(sizes, dtype=np.uint64)]).astype(np.uint64)
         obj.K = K
         return obj
 
@@ -175,14 +182,16 @@ class RocLists:
         check(lib().vidc_roc_decode_lists(self.ctx.h, self.h, ln.size, ptr(ln), ptr(out), ptr(out_off)))
         return out[:total], out_off
 
-    def decode_rows(self, nodes, K=None):
+    def decode_rows(self, nodes, K=None, want_counts=True):
+        """-> (int32 [m, K] CUDA tensor, -1 padded; edge counts or None).  `want_counts=False` keeps the per-node
+        edge counts on the device (no metadata crosses PCIe)."""
         torch = _torch()
         K = K or self.K
         nd = np.ascontiguousarray(nodes, dtype=np.uint64)
         out = torch.empty((max(nd.size, 1), K), dtype=torch.int32, device="cuda")
-        counts = np.zeros(max(nd.size, 1), np.uint32)
+        counts = np.zeros(max(nd.size, 1), np.uint32) if want_counts else None
         check(lib().vidc_roc_decode_rows(self.ctx.h, self.h, nd.size, ptr(nd), K, ptr(out), ptr(counts)))
-        return out[: nd.size], counts[: nd.size]
+        return out[: nd.size], (counts[: nd.size] if want_counts else None)
 
     @property
     def last_decode_nonclean(self):

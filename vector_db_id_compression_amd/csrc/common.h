@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,22 +35,44 @@ void set_error(const char *fmt, ...);
         if (_s != VIDC_OK) return _s; \
     } while (0)
 
-// Device buffer with explicit lifetime (hipMalloc/hipFree on the owning device).
+// Cached device blocks shared by a context and the objects created through it: steady-state encode / decode calls
+// neither hipMalloc nor hipFree (hipFree synchronises the device).  Blocks go back to the pool when their owner
+// dies and are released when the last holder of the pool (context or object) is gone.
+struct PoolBlockD {
+    void *p;
+    size_t bytes;
+    bool in_use;
+};
+struct DevPool {
+    std::mutex m;
+    std::vector<PoolBlockD> blocks;
+    int device = 0;
+    ~DevPool();
+    int get(size_t nbytes, void **p, size_t *bytes);
+    void put(void *p);
+};
+
+// Device buffer with explicit lifetime: hipMalloc/hipFree on the owning device, or a block of a DevPool.
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    std::shared_ptr<DevPool> pool;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), pool(std::move(o.pool)) { o.p = nullptr; o.n = 0; }
     DevBuf &operator=(DevBuf &&o) noexcept {
-        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        if (this != &o) { release(); p = o.p; n = o.n; pool = std::move(o.pool); o.p = nullptr; o.n = 0; }
         return *this;
     }
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (pool) pool->put(p);
+            else (void)hipFree(p);
+        }
+        pool.reset();
         p = nullptr;
         n = 0;
     }
@@ -59,17 +83,44 @@ struct DevBuf {
         VIDC_HIP(hipMalloc((void **)&p, count * sizeof(T)));
         return VIDC_OK;
     }
+    // from the context's block cache
+    int alloc(size_t count, const std::shared_ptr<DevPool> &from) {
+        release();
+        n = count;
+        size_t got = 0;
+        void *q = nullptr;
+        VIDC_TRY(from->get(count ? count * sizeof(T) : 16, &q, &got));
+        p = (T *)q;
+        pool = from;
+        return VIDC_OK;
+    }
 };
 
 // Scratch buffer borrowed from the context pool (returned on destruction).
 struct Scratch {
-    ::vidc_ctx *ctx = nullptr;
+    std::shared_ptr<DevPool> pool;
     void *p = nullptr;
     size_t bytes = 0;
     Scratch() = default;
     Scratch(const Scratch &) = delete;
     Scratch &operator=(const Scratch &) = delete;
     ~Scratch() { release(); }
+    int get(::vidc_ctx *c, size_t nbytes);
+    void release();
+    template <typename T>
+    T *as() const { return (T *)p; }
+};
+
+// Page-locked host staging borrowed from the context pool: per-list arrays (work lists, offsets, metadata) cross
+// PCIe at DMA speed instead of the pageable-copy path (measured ~1.5 GB/s for 8 MB vectors).
+struct Pinned {
+    ::vidc_ctx *ctx = nullptr;
+    void *p = nullptr;
+    size_t bytes = 0;
+    Pinned() = default;
+    Pinned(const Pinned &) = delete;
+    Pinned &operator=(const Pinned &) = delete;
+    ~Pinned() { release(); }
     int get(::vidc_ctx *c, size_t nbytes);
     void release();
     template <typename T>
@@ -92,7 +143,8 @@ struct PoolBlock {
 };
 
 struct vidc_ctx {
-    std::vector<PoolBlock> pool;
+    std::shared_ptr<vidc::DevPool> dpool;  // device blocks (scratch + the objects created through this context)
+    std::vector<PoolBlock> ppool;          // pinned host blocks
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;

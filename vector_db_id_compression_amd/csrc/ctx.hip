@@ -13,29 +13,32 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
     g_last_error = buf;
 }
-int Scratch::get(::vidc_ctx *c, size_t nbytes) {
-    release();
-    ctx = c;
+DevPool::~DevPool() {
+    for (auto &b : blocks)
+        if (b.p) (void)hipFree(b.p);
+}
+int DevPool::get(size_t nbytes, void **out, size_t *out_bytes) {
+    std::lock_guard<std::mutex> g(m);
     if (nbytes == 0) nbytes = 16;
-    // first fit among free blocks that are large enough but not wastefully large
+    // best fit among free blocks that are large enough but not wastefully large
     int best = -1;
-    for (size_t i = 0; i < c->pool.size(); i++) {
-        PoolBlock &b = c->pool[i];
-        if (!b.in_use && b.bytes >= nbytes && b.bytes <= nbytes * 2 + (1u << 20)) {
-            if (best < 0 || b.bytes < c->pool[best].bytes) best = (int)i;
+    for (size_t i = 0; i < blocks.size(); i++) {
+        PoolBlockD &b = blocks[i];
+        if (!b.in_use && b.p && b.bytes >= nbytes && b.bytes <= nbytes * 2 + (1u << 20)) {
+            if (best < 0 || b.bytes < blocks[best].bytes) best = (int)i;
         }
     }
     if (best >= 0) {
-        c->pool[best].in_use = true;
-        p = c->pool[best].p;
-        bytes = c->pool[best].bytes;
+        blocks[best].in_use = true;
+        *out = blocks[best].p;
+        *out_bytes = blocks[best].bytes;
         return VIDC_OK;
     }
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, nbytes);
     if (e != hipSuccess) {
         // drop cached free blocks and retry once
-        for (auto &b : c->pool)
+        for (auto &b : blocks)
             if (!b.in_use && b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
         e = hipMalloc(&q, nbytes);
         if (e != hipSuccess) {
@@ -43,14 +46,67 @@ int Scratch::get(::vidc_ctx *c, size_t nbytes) {
             return VIDC_ERR_HIP;
         }
     }
-    c->pool.push_back(PoolBlock{q, nbytes, true});
-    p = q;
-    bytes = nbytes;
+    // re-use the record of a dropped block if there is one
+    for (auto &b : blocks)
+        if (!b.p) { b = PoolBlockD{q, nbytes, true}; *out = q; *out_bytes = nbytes; return VIDC_OK; }
+    blocks.push_back(PoolBlockD{q, nbytes, true});
+    *out = q;
+    *out_bytes = nbytes;
     return VIDC_OK;
 }
+void DevPool::put(void *p) {
+    std::lock_guard<std::mutex> g(m);
+    for (auto &b : blocks)
+        if (b.p == p) b.in_use = false;
+}
+int Scratch::get(::vidc_ctx *c, size_t nbytes) {
+    release();
+    pool = c->dpool;
+    return pool->get(nbytes, &p, &bytes);
+}
 void Scratch::release() {
+    if (pool && p) pool->put(p);
+    pool.reset();
+    p = nullptr;
+    bytes = 0;
+}
+int Pinned::get(::vidc_ctx *c, size_t nbytes) {
+    release();
+    ctx = c;
+    if (nbytes == 0) nbytes = 16;
+    int best = -1;
+    for (size_t i = 0; i < c->ppool.size(); i++) {
+        PoolBlock &b = c->ppool[i];
+        if (!b.in_use && b.bytes >= nbytes && b.bytes <= nbytes * 4 + (1u << 20)) {
+            if (best < 0 || b.bytes < c->ppool[best].bytes) best = (int)i;
+        }
+    }
+    if (best >= 0) {
+        c->ppool[best].in_use = true;
+        p = c->ppool[best].p;
+        bytes = c->ppool[best].bytes;
+        return VIDC_OK;
+    }
+    void *q = nullptr;
+    size_t want = nbytes + nbytes / 4;  // list counts drift between calls: leave room for reuse
+    if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) {
+        for (auto &b : c->ppool)
+            if (!b.in_use && b.p) { (void)hipHostFree(b.p); b.p = nullptr; b.bytes = 0; }
+        want = nbytes;
+        hipError_t e = hipHostMalloc(&q, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            return VIDC_ERR_HIP;
+        }
+    }
+    c->ppool.push_back(PoolBlock{q, want, true});
+    p = q;
+    bytes = want;
+    return VIDC_OK;
+}
+void Pinned::release() {
     if (ctx && p) {
-        for (auto &b : ctx->pool)
+        for (auto &b : ctx->ppool)
             if (b.p == p) b.in_use = false;
     }
     p = nullptr;
@@ -84,6 +140,8 @@ int vidc_ctx_create(int device, vidc_ctx **out) {
     }
     vidc_ctx *c = new vidc_ctx();
     c->device = device;
+    c->dpool = std::make_shared<vidc::DevPool>();
+    c->dpool->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -129,8 +187,8 @@ int vidc_ctx_create(int device, vidc_ctx **out) {
 
 void vidc_ctx_destroy(vidc_ctx *c) {
     if (!c) return;
-    for (auto &b : c->pool)
-        if (b.p) (void)hipFree(b.p);
+    for (auto &b : c->ppool)
+        if (b.p) (void)hipHostFree(b.p);
     if (c->d_mt) (void)hipFree(c->d_mt);
     if (c->d_ltab) (void)hipFree(c->d_ltab);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

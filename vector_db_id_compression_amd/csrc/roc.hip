@@ -19,11 +19,15 @@ struct vidc_roc {
     uint64_t nlist = 0, ntotal = 0;
     bool rows = false;
     uint32_t K = 0;
-    // host copies of the per-list metadata
-    std::vector<uint64_t> offsets;   // nlist+1
-    std::vector<uint32_t> prec, nwords, draws;
-    std::vector<uint64_t> heads;
-    std::vector<uint64_t> word_off;  // nlist+1
+    // Host copies of the per-list metadata.  The device arrays are authoritative; the host side is filled lazily
+    // (ensure_meta / ensure_offsets) because with ~10^6 lists or graph nodes the PCIe round trip of these arrays
+    // costs more than the codec kernels.  `offsets` is always valid for IVF objects (it is an input), `prec` holds
+    // the values the decode planner needs (lists above TINY_MAX) as soon as encode returns.
+    mutable std::vector<uint64_t> offsets;   // nlist+1
+    mutable std::vector<uint32_t> prec, nwords, draws;
+    mutable std::vector<uint64_t> heads;
+    mutable std::vector<uint64_t> word_off;  // nlist+1
+    mutable bool meta_host = false, offsets_host = false;
     uint64_t total_words = 0, compressed_bytes = 0;
     // device-resident compressed representation
     DevBuf<uint64_t> d_offsets, d_heads, d_word_off;
@@ -82,7 +86,7 @@ inline int set_big_lds(const void *fn, size_t bytes) {
 
 template <typename T>
 int upload(vidc_ctx *ctx, DevBuf<T> &dst, const std::vector<T> &src) {
-    VIDC_TRY(dst.alloc(src.size()));
+    VIDC_TRY(dst.alloc(src.size(), ctx->dpool));
     if (!src.empty())
         VIDC_HIP(hipMemcpyAsync(dst.p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     return VIDC_OK;
@@ -92,6 +96,58 @@ int upload_scratch(vidc_ctx *ctx, Scratch &dst, const std::vector<T> &src) {
     VIDC_TRY(dst.get(ctx, src.size() * sizeof(T)));
     if (!src.empty())
         VIDC_HIP(hipMemcpyAsync(dst.p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return VIDC_OK;
+}
+
+// device -> host through pinned staging (blocks until the data is there)
+template <typename T>
+int download(vidc_ctx *ctx, std::vector<T> &dst, const T *d_src, size_t count) {
+    dst.resize(count);
+    if (!count) return VIDC_OK;
+    Pinned st;
+    VIDC_TRY(st.get(ctx, count * sizeof(T)));
+    VIDC_HIP(hipMemcpyAsync(st.p, d_src, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    std::memcpy(dst.data(), st.p, count * sizeof(T));
+    return VIDC_OK;
+}
+
+// out[0..n] = exclusive prefix sums of in[0..n) (u32 -> u64), on the stream
+int device_exscan(vidc_ctx *ctx, const uint32_t *d_in, uint32_t n, uint64_t *d_out, Scratch &tmp) {
+    const uint32_t ntiles = n / VIDC_SCAN_TILE + 1u;
+    VIDC_TRY(tmp.get(ctx, (size_t)ntiles * 8));
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(256), 0, ctx->stream, d_in, n, tmp.as<uint64_t>());
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(256), 0, ctx->stream, tmp.as<uint64_t>(), ntiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(256), 0, ctx->stream, d_in, n, tmp.as<uint64_t>(), d_out);
+    VIDC_HIP(hipGetLastError());
+    return VIDC_OK;
+}
+
+// lazy host mirrors of the device-resident metadata (blocking copies; everything was synchronised when the
+// object was built)
+template <typename T>
+int mirror(std::vector<T> &dst, const T *d_src, size_t count) {
+    dst.resize(count);
+    if (count) VIDC_HIP(hipMemcpy(dst.data(), d_src, count * sizeof(T), hipMemcpyDeviceToHost));
+    return VIDC_OK;
+}
+int ensure_offsets(const vidc_roc *r) {
+    if (r->offsets_host) return VIDC_OK;
+    VIDC_HIP(hipSetDevice(r->device));
+    VIDC_TRY(mirror(r->offsets, (const uint64_t *)r->d_offsets.p, r->nlist + 1));
+    r->offsets_host = true;
+    return VIDC_OK;
+}
+int ensure_meta(const vidc_roc *r) {
+    VIDC_TRY(ensure_offsets(r));
+    if (r->meta_host) return VIDC_OK;
+    VIDC_HIP(hipSetDevice(r->device));
+    VIDC_TRY(mirror(r->prec, (const uint32_t *)r->d_prec.p, r->nlist));
+    VIDC_TRY(mirror(r->nwords, (const uint32_t *)r->d_nwords.p, r->nlist));
+    VIDC_TRY(mirror(r->draws, (const uint32_t *)r->d_draws.p, r->nlist));
+    VIDC_TRY(mirror(r->heads, (const uint64_t *)r->d_heads.p, r->nlist));
+    VIDC_TRY(mirror(r->word_off, (const uint64_t *)r->d_word_off.p, r->nlist + 1));
+    r->meta_host = true;
     return VIDC_OK;
 }
 
@@ -149,40 +205,58 @@ void sort_desc(std::vector<uint32_t> &wl, const std::vector<uint64_t> &offsets) 
     wl.swap(out);
 }
 
-int finish_encode(vidc_ctx *ctx, vidc_roc *r, const uint32_t *d_arena, const uint64_t *d_arena_off,
-                  Scratch &d_status_buf, double &kernel_ms) {
+// status check + word offsets + sizes + compaction, all on the device; three u64 come back
+int finish_encode(vidc_ctx *ctx, vidc_roc *r, const uint32_t *d_arena, uint32_t arena_stride, Scratch &d_status_buf,
+                  const uint32_t *d_sizes, uint64_t nonempty_lists, double &kernel_ms) {
     const uint64_t nlist = r->nlist;
-    std::vector<uint32_t> status(nlist);
-    r->prec.resize(nlist); r->nwords.resize(nlist); r->draws.resize(nlist); r->heads.resize(nlist);
+    Scratch s_sum, s_tmp, s_tmp2;
+    Pinned tail;
+    VIDC_TRY(tail.get(ctx, 64));
+    unsigned long long *t = tail.as<unsigned long long>();  // [0..2] status summary, [3] total words, [4] ntotal, [5] non-empty
+    t[0] = ~0ull; t[1] = 0; t[2] = 0; t[3] = 0; t[4] = 0; t[5] = 0;
+    VIDC_TRY(s_sum.get(ctx, 64));
+    VIDC_HIP(hipMemcpyAsync(s_sum.p, t, 48, hipMemcpyHostToDevice, ctx->stream));
+    VIDC_TRY(r->d_word_off.alloc(nlist + 1, ctx->dpool));
     if (nlist) {
-        VIDC_HIP(hipMemcpyAsync(status.data(), d_status_buf.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
-        VIDC_HIP(hipMemcpyAsync(r->prec.data(), r->d_prec.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
-        VIDC_HIP(hipMemcpyAsync(r->nwords.data(), r->d_nwords.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
-        VIDC_HIP(hipMemcpyAsync(r->draws.data(), r->d_draws.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
-        VIDC_HIP(hipMemcpyAsync(r->heads.data(), r->d_heads.p, nlist * 8, hipMemcpyDeviceToHost, ctx->stream));
+        hipLaunchKernelGGL(k_roc_status_summary, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 1024)), dim3(256),
+                           0, ctx->stream, d_status_buf.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t)nlist,
+                           s_sum.as<unsigned long long>());
+        VIDC_TRY(device_exscan(ctx, r->d_nwords.p, (uint32_t)nlist, r->d_word_off.p, s_tmp));
+        if (r->rows) {
+            VIDC_TRY(r->d_offsets.alloc(nlist + 1, ctx->dpool));
+            VIDC_TRY(device_exscan(ctx, d_sizes, (uint32_t)nlist, r->d_offsets.p, s_tmp2));
+            hipLaunchKernelGGL(k_count_nonzero, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 1024)), dim3(256), 0,
+                               ctx->stream, d_sizes, (uint32_t)nlist, s_sum.as<unsigned long long>() + 5);
+            VIDC_HIP(hipMemcpyAsync(t + 4, r->d_offsets.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        VIDC_HIP(hipGetLastError());
+        VIDC_HIP(hipMemcpyAsync(t + 3, r->d_word_off.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        VIDC_HIP(hipMemsetAsync(r->d_word_off.p, 0, 8, ctx->stream));
+        if (r->rows) { VIDC_TRY(r->d_offsets.alloc(1, ctx->dpool)); VIDC_HIP(hipMemsetAsync(r->d_offsets.p, 0, 8, ctx->stream)); }
     }
+    VIDC_HIP(hipMemcpyAsync(t, s_sum.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+    if (r->rows) VIDC_HIP(hipMemcpyAsync(t + 5, s_sum.as<unsigned long long>() + 5, 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
-    HostTrace tr("roc encode/finish");
-    VIDC_TRY(check_status(status, "roc encode"));
-    r->word_off.assign(nlist + 1, 0);
-    r->compressed_bytes = 0;
-    for (uint64_t l = 0; l < nlist; l++) {
-        r->word_off[l + 1] = r->word_off[l] + r->nwords[l];
-        // "let's pretend no memory is used" for empty lists, custom_invlists_impl.cpp:199-201
-        if (r->offsets[l + 1] > r->offsets[l]) r->compressed_bytes += 8 + 4ull * r->nwords[l];
+    if (t[0] != ~0ull) {
+        std::vector<uint32_t> status;
+        VIDC_TRY(download(ctx, status, d_status_buf.as<uint32_t>(), nlist));
+        VIDC_TRY(check_status(status, "roc encode"));
     }
-    r->total_words = r->word_off[nlist];
-    VIDC_TRY(upload(ctx, r->d_word_off, r->word_off));
-    tr.mark("word offsets");
-    VIDC_TRY(r->d_words.alloc(r->total_words + 4));  // + padding: the lane decoder's look-ahead reads orig[0..1]
-    tr.mark("words alloc");
+    r->total_words = t[3];
+    if (r->rows) { r->ntotal = t[4]; nonempty_lists = t[5]; }
+    // ANSState::size() = 8 + 4 * words per non-empty list; "let's pretend no memory is used" for empty ones
+    // (custom_invlists_impl.cpp:196-206).  Empty lists have no words.
+    r->compressed_bytes = 8ull * nonempty_lists + 4ull * r->total_words;
+    VIDC_TRY(r->d_words.alloc(r->total_words + 4, ctx->dpool));  // + padding: the lane decoder's look-ahead reads orig[0..1]
     if (nlist) {
-        EventTimer t(ctx);
+        EventTimer tm(ctx);
         uint32_t grid = (uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 16);
-        hipLaunchKernelGGL(k_roc_compact, dim3(grid), dim3(256), 0, ctx->stream, d_arena, d_arena_off,
+        hipLaunchKernelGGL(k_roc_compact, dim3(grid), dim3(256), 0, ctx->stream, d_arena,
+                           r->rows ? (const uint64_t *)nullptr : (const uint64_t *)r->d_offsets.p, arena_stride,
                            r->d_word_off.p, r->d_words.p, (uint32_t)nlist);
         VIDC_HIP(hipGetLastError());
-        double ms = t.stop();
+        double ms = tm.stop();
         ctx->phase_ms[VIDC_PHASE_ROC_COMPACT] = ms;
         kernel_ms += ms;
     }
@@ -197,7 +271,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         set_error("precision_mode %d unsupported (fixed precision must be 0..32)", precision_mode);
         return VIDC_ERR_INVALID;
     }
-    if (nlist >= 0xffffffffull) { set_error("too many lists"); return VIDC_ERR_INVALID; }
+    if (nlist >= 0xffffffffull || N >= 0xffffffffull) { set_error("too many lists"); return VIDC_ERR_INVALID; }
     VIDC_HIP(hipSetDevice(ctx->device));
     std::unique_ptr<vidc_roc> r(new vidc_roc());
     r->device = ctx->device;
@@ -208,29 +282,33 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     double kernel_ms = 0;
 
     HostTrace tr("roc encode");
-    std::vector<uint64_t> arena_off(nlist + 1, 0);
-    // work lists: tiny (n <= 64), universe-bitmap kernels (ids < 2^18 / 2^20), general kernels by bitmap depth
+    // work lists: tiny (n <= 64), universe-bitmap kernels (ids < 2^18 / 2^20), general kernels by bitmap depth,
+    // lane-per-list kernels
     std::vector<uint32_t> wl_tiny, wl_u18, wl_u20, wl_c1, wl_c2, wl_c3, wl_l4, wl_l16;
     const bool want_perm = (flags & VIDC_ROC_WANT_PERM) && !rows;
     const uint64_t ntotal_in = rows ? N * K : (nlist ? offsets[nlist] : 0);
+    const bool f_general = force_general(), use_lane = !f_general && !no_lane();  // getenv once, not per list
     // persistent outputs
-    VIDC_TRY(r->d_heads.alloc(nlist)); VIDC_TRY(r->d_prec.alloc(nlist));
-    VIDC_TRY(r->d_nwords.alloc(nlist)); VIDC_TRY(r->d_draws.alloc(nlist));
-    if (want_perm) VIDC_TRY(r->d_perm.alloc(ntotal_in ? ntotal_in : 1));
+    VIDC_TRY(r->d_heads.alloc(nlist, ctx->dpool)); VIDC_TRY(r->d_prec.alloc(nlist, ctx->dpool));
+    VIDC_TRY(r->d_nwords.alloc(nlist, ctx->dpool)); VIDC_TRY(r->d_draws.alloc(nlist, ctx->dpool));
+    if (want_perm) VIDC_TRY(r->d_perm.alloc(ntotal_in ? ntotal_in : 1, ctx->dpool));
     tr.mark("persistent allocs");
-    Scratch s_arena, s_arena_off, s_status, s_sizes, s_sid, s_wl, s_maxid, s_flags;
+    Scratch s_arena, s_status, s_sizes, s_sid, s_wl, s_maxid, s_flags, s_sum;
+    Pinned h_wl, h_pre;
+    const uint32_t arena_stride = rows ? (uint32_t)arena_words_for(K) : 0u;
+    uint64_t arena_words = 0, nonempty = 0, ntiny = 0;
     if (rows) {
         if (K == 0 || K > TINY_MAX) {
             set_error("graph rows: K=%u unsupported (1..64)", K);
             return VIDC_ERR_UNSUPPORTED;
         }
-        for (uint64_t l = 0; l < nlist; l++) arena_off[l + 1] = arena_off[l] + arena_words_for(K);
-        wl_tiny.resize(nlist);
-        std::iota(wl_tiny.begin(), wl_tiny.end(), 0u);
+        arena_words = roc_arena_at(nullptr, arena_stride, nlist);
+        ntiny = nlist;  // every row, in order: no work list array (kernels take l = work item)
         VIDC_TRY(s_sizes.get(ctx, nlist * 4));
     } else {
         if (!offsets) return VIDC_ERR_INVALID;
         r->offsets.assign(offsets, offsets + nlist + 1);
+        r->offsets_host = true;
         bool any_big = false;
         for (uint64_t l = 0; l < nlist; l++) {
             if (offsets[l + 1] < offsets[l]) { set_error("offsets not monotone at list %llu", (unsigned long long)l); return VIDC_ERR_INVALID; }
@@ -241,32 +319,53 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                           VIDC_ROC_MAX_LIST);
                 return VIDC_ERR_DOMAIN;
             }
-            arena_off[l + 1] = arena_off[l] + arena_words_for(n);
             any_big |= n > TINY_MAX;
+            nonempty += n != 0;
         }
+        arena_words = roc_arena_at(r->offsets.data(), 0, nlist);
         r->ntotal = offsets[nlist];
-        VIDC_TRY(upload(ctx, r->d_offsets, r->offsets));
-        tr.mark("offsets + arena sizes");
-        // classification prepass (one wavefront per list): max id -> precision, sortedness, domain
-        std::vector<uint32_t> maxid(nlist, 0), pflags(nlist, 0);
+        VIDC_TRY(r->d_offsets.alloc(nlist + 1, ctx->dpool));
+        {
+            Pinned h_off;  // (released after the synchronisation below or at the next one)
+            VIDC_TRY(h_off.get(ctx, (nlist + 1) * 8));
+            std::memcpy(h_off.p, offsets, (nlist + 1) * 8);
+            VIDC_HIP(hipMemcpyAsync(r->d_offsets.p, h_off.p, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+            VIDC_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        tr.mark("offsets");
+        // classification prepass (one workgroup per list): max id -> precision, sortedness, domain
+        const uint32_t *maxid = nullptr, *pflags = nullptr;
         if (any_big) {
             VIDC_TRY(s_maxid.get(ctx, nlist * 4));
             VIDC_TRY(s_flags.get(ctx, nlist * 4));
+            VIDC_TRY(h_pre.get(ctx, nlist * 8));
             EventTimer t(ctx);
             hipLaunchKernelGGL(k_roc_prepass, dim3((uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 32)),
                                dim3(256), 0, ctx->stream, d_ids, r->d_offsets.p, (uint32_t)nlist, precision_mode,
                                s_maxid.as<uint32_t>(), s_flags.as<uint32_t>(), r->d_prec.p);
             VIDC_HIP(hipGetLastError());
             kernel_ms += t.stop();
-            VIDC_HIP(hipMemcpyAsync(maxid.data(), s_maxid.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
-            VIDC_HIP(hipMemcpyAsync(pflags.data(), s_flags.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+            VIDC_HIP(hipMemcpyAsync(h_pre.p, s_maxid.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+            VIDC_HIP(hipMemcpyAsync(h_pre.as<uint32_t>() + nlist, s_flags.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
             VIDC_HIP(hipStreamSynchronize(ctx->stream));
+            maxid = h_pre.as<uint32_t>();
+            pflags = maxid + nlist;
             tr.mark("prepass kernel + d2h");
+            // what the decode planner needs later (kernel class, bucket geometry) is known right here
+            r->prec.resize(nlist);
+            for (uint64_t l = 0; l < nlist; l++) {
+                const uint32_t m = maxid[l];
+                r->prec[l] = offsets[l + 1] == offsets[l] ? 0u
+                             : precision_mode >= 0    ? (uint32_t)precision_mode
+                             : precision_mode == VIDC_PREC_EXACT ? (m ? 32u - (uint32_t)__builtin_clz(m) : 0u)
+                                                                 : (m > 1u ? 32u - (uint32_t)__builtin_clz(m - 1u) : 0u);
+            }
+        } else {
+            r->prec.assign(nlist, 0);  // tiny lists only: the planner does not look at their precision
         }
         // The bitmap kernels own a whole CU's LDS (2^20-bit universe): latency-optimal for long lists, but only
-        // num_cu lists in flight.  With many lists, short ones go to the high-occupancy general kernels.
+        // num_cu lists in flight.  With many lists, short ones go to the high-occupancy kernels.
         const uint64_t u_min = U_MIN_LIST;
-        const bool f_general = force_general(), use_lane = !f_general && !no_lane();  // getenv once, not per list
         for (uint64_t l = 0; l < nlist; l++) {
             uint64_t n = offsets[l + 1] - offsets[l];
             if (n <= TINY_MAX) { wl_tiny.push_back((uint32_t)l); continue; }
@@ -288,22 +387,35 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             else if (n <= 32768) wl_c2.push_back((uint32_t)l);
             else wl_c3.push_back((uint32_t)l);
         }
-        tr.mark("prepass + classify");
+        ntiny = wl_tiny.size();
+        tr.mark("classify");
         for (auto *w : {&wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16}) sort_desc(*w, r->offsets);
         tr.mark("sort work lists");
         if (!wl_c1.empty() || !wl_c2.empty() || !wl_c3.empty()) VIDC_TRY(s_sid.get(ctx, ntotal_in * 4));
     }
-    VIDC_TRY(s_arena.get(ctx, arena_off[nlist] * 4));
-    VIDC_TRY(upload_scratch(ctx, s_arena_off, arena_off));
+    VIDC_TRY(s_arena.get(ctx, arena_words * 4));
     VIDC_TRY(s_status.get(ctx, nlist * 4));
     if (nlist) VIDC_HIP(hipMemsetAsync(s_status.p, 0xff, nlist * 4, ctx->stream));
-    std::vector<uint32_t> wl_all;
     std::vector<size_t> base;
-    for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16}) {
-        base.push_back(wl_all.size());
-        wl_all.insert(wl_all.end(), w->begin(), w->end());
+    const uint32_t *d_wl = nullptr;
+    if (!rows) {
+        size_t total = 0;
+        for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16}) {
+            base.push_back(total);
+            total += w->size();
+        }
+        VIDC_TRY(h_wl.get(ctx, total * 4));
+        size_t k = 0;
+        for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16}) {
+            if (!w->empty()) std::memcpy(h_wl.as<uint32_t>() + k, w->data(), w->size() * 4);
+            k += w->size();
+        }
+        VIDC_TRY(s_wl.get(ctx, total * 4));
+        if (total) VIDC_HIP(hipMemcpyAsync(s_wl.p, h_wl.p, total * 4, hipMemcpyHostToDevice, ctx->stream));
+        d_wl = s_wl.as<uint32_t>();
+    } else {
+        base.assign(8, 0);
     }
-    VIDC_TRY(upload_scratch(ctx, s_wl, wl_all));
 
     RocEncArgs a{};
     a.ids = d_ids; a.rows = d_rows; a.K = K;
@@ -312,7 +424,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     a.heads = r->d_heads.p; a.prec = r->d_prec.p; a.nwords = r->d_nwords.p; a.draws = r->d_draws.p;
     a.sizes = s_sizes.as<uint32_t>();
     a.status = s_status.as<uint32_t>();
-    a.arena = s_arena.as<uint32_t>(); a.arena_off = s_arena_off.as<uint64_t>();
+    a.arena = s_arena.as<uint32_t>(); a.arena_stride = arena_stride;
     a.perm = want_perm ? r->d_perm.p : nullptr;
     a.sid = s_sid.as<uint32_t>(); a.spos = nullptr; a.skey = nullptr; a.skey_off = nullptr;
     a.mt = ctx->d_mt;
@@ -320,21 +432,20 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     tr.mark("alloc + upload");
     // Kernel classes run concurrently (one stream each): the longest chains on the caller's stream, shorter
     // classes on the auxiliary streams so that they fill the wave slots the long chains leave idle.
-    auto launch_gen_on = [&](hipStream_t st_, const uint32_t *d_wl, uint32_t nwork, uint32_t rl_max) -> int {
+    auto launch_gen_on = [&](hipStream_t st_, const uint32_t *wl, uint32_t nwork, uint32_t rl_max) -> int {
         if (!nwork) return VIDC_OK;
         RocEncArgs b = a;
-        b.worklist = d_wl; b.nwork = nwork;
+        b.worklist = wl; b.nwork = nwork;
         size_t lds = (size_t)64 * rl_max * 12;
         hipLaunchKernelGGL(k_roc_encode_gen, dim3(nwork), dim3(64), lds, st_, b, rl_max);
         VIDC_HIP(hipGetLastError());
         return VIDC_OK;
     };
-    auto launch_gen = [&](const uint32_t *d_wl, uint32_t nwork, uint32_t rl_max) -> int {
-        return launch_gen_on(ctx->stream, d_wl, nwork, rl_max);
+    auto launch_gen = [&](const uint32_t *wl, uint32_t nwork, uint32_t rl_max) -> int {
+        return launch_gen_on(ctx->stream, wl, nwork, rl_max);
     };
     {
         EventTimer t(ctx);
-        const uint32_t *d_wl = s_wl.as<uint32_t>();
         VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
         for (int i = 0; i < 3; i++) VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
         // main stream: bitmap-20 lists and the deepest general class (the critical paths)
@@ -372,10 +483,10 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             else hipLaunchKernelGGL((k_roc_encode_lane<16, false>), grid, dim3(64), 0, ctx->aux[1], b, dt);
             VIDC_HIP(hipGetLastError());
         }
-        if (!wl_tiny.empty()) {
+        if (ntiny) {
             RocEncArgs b = a;
-            b.worklist = d_wl; b.nwork = (uint32_t)wl_tiny.size();
-            if (!force_general() && !no_lane()) {  // one list per lane (roc_lane.h)
+            b.worklist = rows ? nullptr : d_wl; b.nwork = (uint32_t)ntiny;
+            if (use_lane) {  // one list per lane (roc_lane.h)
                 const dim3 grid((b.nwork + 63u) / 64u);
                 const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
                 if (rows && K <= 32) hipLaunchKernelGGL((k_roc_encode_tiny_lane<32, true>), grid, dim3(64), 0, ctx->aux[2], b, dt);
@@ -397,11 +508,25 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     // lists are in add order, i.e. normally sorted) and multiset input of the bitmap kernels
     std::vector<uint32_t> pend;
     if (!rows && nlist) {
-        std::vector<uint32_t> status(nlist);
-        VIDC_HIP(hipMemcpyAsync(status.data(), s_status.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+        // how many lists are pending: 32 bytes come back, the status array only if there are any
+        Pinned h_sum;
+        VIDC_TRY(h_sum.get(ctx, 64));
+        unsigned long long *t = h_sum.as<unsigned long long>();
+        t[0] = ~0ull; t[1] = 0; t[2] = 0; t[3] = 0;
+        VIDC_TRY(s_sum.get(ctx, 64));
+        VIDC_HIP(hipMemcpyAsync(s_sum.p, t, 32, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_roc_status_summary, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 1024)), dim3(256),
+                           0, ctx->stream, s_status.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t)nlist,
+                           s_sum.as<unsigned long long>());
+        VIDC_HIP(hipGetLastError());
+        VIDC_HIP(hipMemcpyAsync(t, s_sum.p, 32, hipMemcpyDeviceToHost, ctx->stream));
         VIDC_HIP(hipStreamSynchronize(ctx->stream));
-        for (uint64_t l = 0; l < nlist; l++)
-            if (status[l] == VIDC_ST_PENDING_SORT) pend.push_back((uint32_t)l);
+        if (t[3]) {
+            std::vector<uint32_t> status;
+            VIDC_TRY(download(ctx, status, s_status.as<uint32_t>(), nlist));
+            for (uint64_t l = 0; l < nlist; l++)
+                if (status[l] == VIDC_ST_PENDING_SORT) pend.push_back((uint32_t)l);
+        }
         if (!pend.empty()) {
             sort_desc(pend, r->offsets);
             std::vector<uint64_t> skey_off(nlist + 1, 0);
@@ -424,9 +549,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             a.sid = s_sid.as<uint32_t>();
             a.skey = s_skey.as<uint64_t>(); a.skey_off = s_skey_off.as<uint64_t>(); a.spos = s_spos.as<uint32_t>();
             uint32_t rl_max = maxn <= 4096 ? 1 : (maxn <= 32768 ? 8 : 64);
-            EventTimer t(ctx);
+            EventTimer t2(ctx);
             VIDC_TRY(launch_gen(s_pend.as<uint32_t>(), (uint32_t)pend.size(), rl_max));
-            kernel_ms += t.stop();
+            kernel_ms += t2.stop();
             VIDC_HIP(hipStreamSynchronize(ctx->stream));  // scratch of this scope is released below
         }
     }
@@ -447,19 +572,10 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             kernel_ms += t.stop();
         }
     }
-    if (rows) {
-        // edge counts define the CSR numbering of the decoded output (altid_impl.h:61 num_outgoing_edges)
-        std::vector<uint32_t> sizes(nlist);
-        if (nlist) VIDC_HIP(hipMemcpyAsync(sizes.data(), s_sizes.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
-        VIDC_HIP(hipStreamSynchronize(ctx->stream));
-        r->offsets.assign(nlist + 1, 0);
-        for (uint64_t l = 0; l < nlist; l++) r->offsets[l + 1] = r->offsets[l] + sizes[l];
-        r->ntotal = r->offsets[nlist];
-        VIDC_TRY(upload(ctx, r->d_offsets, r->offsets));
-    }
     tr.mark("second pass / perm");
     ctx->phase_ms[VIDC_PHASE_ROC_ENCODE] = kernel_ms;
-    VIDC_TRY(finish_encode(ctx, r.get(), s_arena.as<uint32_t>(), s_arena_off.as<uint64_t>(), s_status, kernel_ms));
+    VIDC_TRY(finish_encode(ctx, r.get(), s_arena.as<uint32_t>(), arena_stride, s_status, s_sizes.as<uint32_t>(), nonempty,
+                           kernel_ms));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
     tr.mark("metadata + compaction");
     ctx->last_kernel_ms = kernel_ms;
@@ -476,6 +592,7 @@ struct DecPlan {
     size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     std::vector<uint64_t> scratch_off, slots_off;
     uint64_t scratch_words = 0, slots_words = 0;
+    bool lean = false;               // graph rows, lane decoder: item k == request k, no scratch / offset arrays
 };
 
 inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane) {
@@ -493,17 +610,27 @@ inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general
 // lists[i] = list number of request item i (a list may appear more than once)
 void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool rows_flavour, DecPlan &p,
                  bool allow_lane = true) {
-    std::vector<uint32_t> cls[DC_COUNT];
-    const uint64_t u_min = U_MIN_LIST;
     const bool f_general = force_general();
     allow_lane = allow_lane && !f_general && !no_lane();
+    p.wl.clear(); p.item.clear(); p.scratch_off.clear(); p.slots_off.clear();
+    p.scratch_words = 0; p.slots_words = 0;
+    for (int c = 0; c < DC_COUNT; c++) p.count[c] = 0;
+    if (rows_flavour && allow_lane) {
+        // graph rows with the lane-per-row decoder: request order, no scratch, implicit output offsets
+        p.wl = lists;
+        p.count[DC_TINY] = lists.size();
+        p.lean = true;
+        return;
+    }
+    p.lean = false;
+    std::vector<uint32_t> cls[DC_COUNT];
+    const uint64_t u_min = U_MIN_LIST;
     for (uint32_t i = 0; i < lists.size(); i++) {
         uint32_t l = lists[i];
         uint64_t n = r->offsets[l + 1] - r->offsets[l];
         cls[rows_flavour ? DC_TINY : dec_class(n, r->prec[l], u_min, f_general, allow_lane)].push_back(i);
     }
     auto len = [&](uint32_t i) { return r->offsets[lists[i] + 1] - r->offsets[lists[i]]; };
-    p.wl.clear(); p.item.clear();
     for (int c = 0; c < DC_COUNT; c++) {
         if (c != DC_TINY && cls[c].size() > 1) {  // counting sort by length, longest first (stable)
             uint64_t maxlen = 0;
@@ -526,7 +653,8 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             uint32_t l = p.wl[k];
             uint64_t n = r->offsets[l + 1] - r->offsets[l];
             p.scratch_off[k] = so;
-            so += (uint64_t)r->nwords[l] + 64;
+            // re-spill scratch of the decoder stack: the stream never exceeds the encoder's arena bound
+            so += std::max<uint64_t>(arena_words_for(n), r->meta_host ? r->nwords[l] : 0) + 64;
             p.slots_off[k] = sl;
             if (c == DC_LANE) {
                 sl = (sl + 3) & ~(uint64_t)3;  // rows are read as uint4
@@ -561,15 +689,41 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     if (nwork == 0) { ctx->last_kernel_ms = 0; return VIDC_OK; }
     HostTrace tr("roc decode");
     Scratch s_wl, s_scr_off, s_slots_off, s_scr, s_slots, s_out_off, s_end, s_status, s_sum;
+    Pinned h_up;
     const uint32_t *d_wl;
-    const uint64_t *d_scr_off, *d_slots_off;
+    const uint64_t *d_scr_off = nullptr, *d_slots_off = nullptr;
     if (cache) {
         d_wl = cache->d_wl.p; d_scr_off = cache->d_scratch_off.p; d_slots_off = cache->d_slots_off.p;
     } else {
-        VIDC_TRY(upload_scratch(ctx, s_wl, p.wl));
-        VIDC_TRY(upload_scratch(ctx, s_scr_off, p.scratch_off));
-        VIDC_TRY(upload_scratch(ctx, s_slots_off, p.slots_off));
-        d_wl = s_wl.as<uint32_t>(); d_scr_off = s_scr_off.as<uint64_t>(); d_slots_off = s_slots_off.as<uint64_t>();
+        // one pinned staging block for everything that goes up: work list | scratch offsets | slot offsets | out offsets
+        const size_t n8 = p.lean ? 0 : nwork;
+        VIDC_TRY(h_up.get(ctx, nwork * 4 + 8 + n8 * 24));
+        uint32_t *h_wl = h_up.as<uint32_t>();
+        uint64_t *h_64 = (uint64_t *)((char *)h_up.p + ((nwork * 4 + 7) & ~(size_t)7));
+        std::memcpy(h_wl, p.wl.data(), nwork * 4);
+        VIDC_TRY(s_wl.get(ctx, nwork * 4));
+        VIDC_HIP(hipMemcpyAsync(s_wl.p, h_wl, nwork * 4, hipMemcpyHostToDevice, ctx->stream));
+        d_wl = s_wl.as<uint32_t>();
+        if (!p.lean) {
+            std::memcpy(h_64, p.scratch_off.data(), nwork * 8);
+            std::memcpy(h_64 + nwork, p.slots_off.data(), nwork * 8);
+            VIDC_TRY(s_scr_off.get(ctx, nwork * 8));
+            VIDC_TRY(s_slots_off.get(ctx, nwork * 8));
+            VIDC_HIP(hipMemcpyAsync(s_scr_off.p, h_64, nwork * 8, hipMemcpyHostToDevice, ctx->stream));
+            VIDC_HIP(hipMemcpyAsync(s_slots_off.p, h_64 + nwork, nwork * 8, hipMemcpyHostToDevice, ctx->stream));
+            d_scr_off = s_scr_off.as<uint64_t>(); d_slots_off = s_slots_off.as<uint64_t>();
+            if (out_off_host) {
+                std::memcpy(h_64 + 2 * nwork, out_off_host, nwork * 8);
+                VIDC_TRY(s_out_off.get(ctx, nwork * 8));
+                VIDC_HIP(hipMemcpyAsync(s_out_off.p, h_64 + 2 * nwork, nwork * 8, hipMemcpyHostToDevice, ctx->stream));
+            }
+        }
+    }
+    if (cache && out_off_host) {
+        VIDC_TRY(h_up.get(ctx, nwork * 8));
+        std::memcpy(h_up.p, out_off_host, nwork * 8);
+        VIDC_TRY(s_out_off.get(ctx, nwork * 8));
+        VIDC_HIP(hipMemcpyAsync(s_out_off.p, h_up.p, nwork * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     VIDC_TRY(s_scr.get(ctx, p.scratch_words * 4));
     VIDC_TRY(s_slots.get(ctx, p.slots_words * 4));
@@ -577,10 +731,6 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     VIDC_TRY(s_status.get(ctx, r->nlist * 4));
     VIDC_HIP(hipMemsetAsync(s_end.p, 0, r->nlist * 4, ctx->stream));
     VIDC_HIP(hipMemsetAsync(s_status.p, 0, r->nlist * 4, ctx->stream));
-    if (out_off_host) {
-        VIDC_TRY(s_out_off.get(ctx, nwork * 8));
-        VIDC_HIP(hipMemcpyAsync(s_out_off.p, out_off_host, nwork * 8, hipMemcpyHostToDevice, ctx->stream));
-    }
     tr.mark("scratch + uploads");
     RocDecArgs a{};
     a.offsets = r->d_offsets.p;
@@ -610,9 +760,9 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         RocDecArgs b = a;
         b.worklist = d_wl + base[c];
         b.nwork = (uint32_t)p.count[c];
-        b.out_off = out_off_host ? s_out_off.as<uint64_t>() + base[c] : nullptr;
-        b.scratch_off = d_scr_off + base[c];
-        b.slots_off = d_slots_off + base[c];
+        b.out_off = (out_off_host && !p.lean) ? s_out_off.as<uint64_t>() + base[c] : nullptr;
+        b.scratch_off = d_scr_off ? d_scr_off + base[c] : nullptr;
+        b.slots_off = d_slots_off ? d_slots_off + base[c] : nullptr;
         switch (c) {
             case DC_TINY:
                 if (!force_general() && !no_lane()) {  // one list per lane (roc_lane.h)
@@ -659,9 +809,9 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     tr.mark("decode kernels (sync)");
 
     // 16-byte summary instead of copying two nlist-sized arrays back
-    VIDC_TRY(s_sum.get(ctx, 24));
-    const unsigned long long init[3] = {~0ull, 0ull, 0ull};
-    VIDC_HIP(hipMemcpyAsync(s_sum.p, init, 24, hipMemcpyHostToDevice, ctx->stream));
+    VIDC_TRY(s_sum.get(ctx, 32));
+    const unsigned long long init[4] = {~0ull, 0ull, 0ull, 0ull};
+    VIDC_HIP(hipMemcpyAsync(s_sum.p, init, 32, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_roc_status_summary, dim3((uint32_t)std::min<uint64_t>((r->nlist + 255) / 256, 1024)), dim3(256),
                        0, ctx->stream, s_status.as<uint32_t>(), s_end.as<uint32_t>(), (uint32_t)r->nlist,
                        s_sum.as<unsigned long long>());
@@ -730,6 +880,7 @@ uint64_t vidc_roc_last_decode_nonclean(const vidc_roc *r) { return r ? r->last_n
 int vidc_roc_list_info(const vidc_roc *r, uint32_t *sizes, uint32_t *precisions, uint64_t *heads,
                        uint32_t *nwords, uint32_t *mt_draws) {
     if (!r) return VIDC_ERR_INVALID;
+    VIDC_TRY(ensure_meta(r));
     for (uint64_t l = 0; l < r->nlist; l++) {
         if (sizes) sizes[l] = (uint32_t)(r->offsets[l + 1] - r->offsets[l]);
         if (precisions) precisions[l] = r->prec[l];
@@ -742,6 +893,7 @@ int vidc_roc_list_info(const vidc_roc *r, uint32_t *sizes, uint32_t *precisions,
 
 int vidc_roc_export_words(vidc_ctx *ctx, const vidc_roc *r, uint64_t list_no, uint32_t *words, size_t cap) {
     if (!ctx || !r || list_no >= r->nlist) return VIDC_ERR_INVALID;
+    VIDC_TRY(ensure_meta(r));
     uint64_t nw = r->nwords[list_no];
     if (nw > cap) { set_error("export buffer too small (%zu < %llu words)", cap, (unsigned long long)nw); return VIDC_ERR_INVALID; }
     return vidc_copy_d2h(ctx, words, r->d_words.p + r->word_off[list_no], nw * 4);
@@ -790,16 +942,19 @@ int vidc_roc_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, cons
     VIDC_TRY(upload(ctx, r->d_nwords, r->nwords));
     VIDC_TRY(upload(ctx, r->d_draws, r->draws));
     VIDC_TRY(upload(ctx, r->d_word_off, r->word_off));
-    VIDC_TRY(r->d_words.alloc(r->total_words + 4));  // + padding: the lane decoder's look-ahead reads orig[0..1]
+    VIDC_TRY(r->d_words.alloc(r->total_words + 4, ctx->dpool));  // + padding: the lane decoder's look-ahead reads orig[0..1]
     if (r->total_words)
         VIDC_HIP(hipMemcpyAsync(r->d_words.p, words_concat, r->total_words * 4, hipMemcpyHostToDevice, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    r->meta_host = true;
+    r->offsets_host = true;
     *out = r.release();
     return VIDC_OK;
 }
 
 int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out) {
     if (!ctx || !r || (r->ntotal && !d_out)) return VIDC_ERR_INVALID;
+    VIDC_TRY(r->prec.size() == r->nlist ? ensure_offsets(r) : ensure_meta(r));
     if (!r->plan_all) {
         HostTrace tr("roc decode_all");
         std::vector<uint32_t> all(r->nlist);
@@ -820,6 +975,7 @@ int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out) {
 int vidc_roc_decode_lists(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *list_nos,
                           uint64_t *d_out, uint64_t *out_offsets) {
     if (!ctx || !r || (m && !list_nos) || !out_offsets) return VIDC_ERR_INVALID;
+    VIDC_TRY(r->prec.size() == r->nlist ? ensure_offsets(r) : ensure_meta(r));
     std::vector<uint32_t> lists(m);
     std::vector<uint64_t> req_off(m + 1, 0);
     for (uint64_t i = 0; i < m; i++) {
@@ -839,16 +995,21 @@ int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uin
                          int32_t *d_out, uint32_t *counts) {
     if (!ctx || !r || (m && (!nodes || !d_out))) return VIDC_ERR_INVALID;
     if (K == 0 || K > TINY_MAX) { set_error("K=%u unsupported", K); return VIDC_ERR_UNSUPPORTED; }
+    const bool lean = r->rows && K >= r->K && !force_general() && !no_lane();
+    if (!lean || counts) VIDC_TRY(r->prec.size() == r->nlist ? ensure_offsets(r) : ensure_meta(r));
     std::vector<uint32_t> lists(m);
     for (uint64_t i = 0; i < m; i++) {
         if (nodes[i] >= r->nlist) { set_error("node %llu out of range", (unsigned long long)nodes[i]); return VIDC_ERR_INVALID; }
         lists[i] = (uint32_t)nodes[i];
-        uint64_t n = r->offsets[lists[i] + 1] - r->offsets[lists[i]];
-        if (n > K) { set_error("node %u has %llu edges > K=%u", lists[i], (unsigned long long)n, K); return VIDC_ERR_INVALID; }
-        if (counts) counts[i] = (uint32_t)n;
+        if (!lean || counts) {
+            uint64_t n = r->offsets[lists[i] + 1] - r->offsets[lists[i]];
+            if (n > K) { set_error("node %u has %llu edges > K=%u", lists[i], (unsigned long long)n, K); return VIDC_ERR_INVALID; }
+            if (counts) counts[i] = (uint32_t)n;
+        }
     }
     DecPlan p;
-    plan_decode(r, lists, true, p);
+    plan_decode(r, lists, true, p, lean);
+    if (p.lean) return decode_impl(ctx, r, p, nullptr, nullptr, d_out, K);
     std::vector<uint64_t> out_off(m);
     for (size_t k = 0; k < m; k++) out_off[k] = (uint64_t)p.item[k] * K;
     return decode_impl(ctx, r, p, out_off.data(), nullptr, d_out, K);

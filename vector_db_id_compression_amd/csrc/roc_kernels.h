@@ -44,8 +44,8 @@ struct RocEncArgs {
     uint32_t *draws;           // [nlist]
     uint32_t *sizes;           // [nlist] (graph flavour: edge counts, altid_impl.h:61)
     uint32_t *status;          // [nlist]
-    uint32_t *arena;           // worst-case word arena
-    const uint64_t *arena_off; // [nlist+1]
+    uint32_t *arena;           // worst-case word arena; list l owns [arena_at(l), arena_at(l + 1))
+    uint32_t arena_stride;     // graph flavour: words per row
     uint32_t *perm;            // [ntotal] or nullptr
     uint32_t *sid;             // [ntotal] scratch: ids of each list in ascending order (u32)
     uint32_t *spos;            // [ntotal] scratch: input positions in that order (unsorted lists only)
@@ -53,6 +53,17 @@ struct RocEncArgs {
     const uint64_t *skey_off;  // [nlist+1] or nullptr
     const uint32_t *mt;
 };
+
+// Worst-case arena layout in closed form (no per-list offset array to build, upload or read): a list of n ids
+// needs at most n*37/32 + 8 words (<= P + 4 bits of growth per step, P <= 32).
+//   graph rows : l * stride
+//   IVF lists  : floor(offsets[l] * 37 / 32) + 9 * l   (consecutive differences >= floor(n*37/32) + 8)
+__host__ __device__ inline uint64_t roc_arena_at(const uint64_t *offsets, uint32_t stride, uint64_t l) {
+    return offsets ? ((offsets[l] * 37ull) >> 5) + 9ull * l : l * (uint64_t)stride;
+}
+__device__ __forceinline__ uint64_t arena_at(const RocEncArgs &a, uint64_t l) {
+    return roc_arena_at(a.rows ? nullptr : a.offsets, a.arena_stride, l);
+}
 
 struct RocDecArgs {
     const uint64_t *offsets;    // [nlist+1] CSR offsets of the stored lists
@@ -118,7 +129,7 @@ template <bool ROWS>
 __global__ void __launch_bounds__(64) k_roc_encode_tiny(RocEncArgs a) {
     const uint32_t lane = lane_id();
     for (uint32_t wi = blockIdx.x; wi < a.nwork; wi += gridDim.x) {
-        const uint32_t l = a.worklist[wi];
+        const uint32_t l = a.worklist ? a.worklist[wi] : wi;
         uint32_t n;
         uint64_t off;
         uint32_t v = 0xffffffffu;
@@ -176,8 +187,9 @@ __global__ void __launch_bounds__(64) k_roc_encode_tiny(RocEncArgs a) {
         const uint32_t spos = (uint32_t)key & 63u;
 
         WStack st;
-        uint32_t *arena = a.arena + a.arena_off[l];
-        ws_init_empty(st, arena, (uint32_t)(a.arena_off[l + 1] - a.arena_off[l]), a.mt, VIDC_MT_TABLE);
+        const uint64_t ao = arena_at(a, l);
+        uint32_t *arena = a.arena + ao;
+        ws_init_empty(st, arena, (uint32_t)(arena_at(a, l + 1) - ao), a.mt, VIDC_MT_TABLE);
         uint64_t head = VIDC_RANS_L;
         uint64_t alive = n == 64u ? ~0ull : ((1ull << n) - 1ull);
         Recip rc;
@@ -213,7 +225,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny(RocDecArgs a) {
     for (uint32_t wi = blockIdx.x; wi < a.nwork; wi += gridDim.x) {
         const uint32_t l = a.worklist[wi];
         const uint32_t n = (uint32_t)(a.offsets[l + 1] - a.offsets[l]);
-        const uint64_t ooff = a.out_off ? a.out_off[wi] : a.offsets[l];
+        const uint64_t ooff = a.out_off ? a.out_off[wi] : (ROWS ? (uint64_t)wi * a.K : a.offsets[l]);
         if (ROWS) {
             // pad the row with -1 first (the reference leaves slots >= n untouched, altid_impl.cpp:153-165)
             if (lane < a.K) a.out_rows[ooff + lane] = -1;
@@ -362,8 +374,8 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
         // ---- phase 2: the serial chain
         WStack st;
         {
-            const uint64_t ao = rfl64(a.arena_off[l]);
-            ws_init_empty(st, a.arena + ao, rfl((uint32_t)(a.arena_off[l + 1] - ao)), a.mt, VIDC_MT_TABLE);
+            const uint64_t ao = rfl64(arena_at(a, l));
+            ws_init_empty(st, a.arena + ao, rfl((uint32_t)(arena_at(a, l + 1) - ao)), a.mt, VIDC_MT_TABLE);
         }
         uint64_t head = VIDC_RANS_L;
         Recip rc;
@@ -535,27 +547,102 @@ __global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t ld
 
 // ---------------------------------------------------------------------------------------------
 // status summary: out[0] = smallest list number with an error status (~0 = none), out[1] = number of lists
-// whose decode did not end in the initial ANS state, out[2] = number of lists handed back for a retry (status 5)
+// whose decode did not end in the initial ANS state, out[2] = number of lists handed back for a retry (status 5),
+// out[3] = number of lists waiting for the sorting second pass (status 1; also counted as an error in out[0])
 __global__ void k_roc_status_summary(const uint32_t *status, const uint32_t *end_state, uint32_t nlist,
                                      unsigned long long *out) {
-    unsigned long long bad = ~0ull, nonclean = 0, retry = 0;
+    unsigned long long bad = ~0ull, nonclean = 0, retry = 0, pending = 0;
     for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x) {
         const uint32_t s = status[l];
         if (s == 5u) retry++;  // VIDC_ST_RETRY (roc_lane.h)
         else if (s != VIDC_ST_OK && (unsigned long long)l < bad) bad = l;
+        if (s == VIDC_ST_PENDING_SORT) pending++;
         if (end_state) nonclean += end_state[l];
     }
     if (bad != ~0ull) atomicMin(&out[0], bad);
     if (nonclean) atomicAdd(&out[1], nonclean);
     if (retry) atomicAdd(&out[2], retry);
+    if (pending) atomicAdd(&out[3], pending);
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive scan of u32 counts into u64 offsets (out has n + 1 entries): three small launches.  Keeps the per-list
+// word counts / edge counts on the device: with 10^6 lists the host prefix sum + two PCIe crossings of the arrays
+// cost more than the codec kernels.
+#define VIDC_SCAN_TILE 4096u  // elements per block = 256 threads x 16
+__global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t *in, uint32_t n, uint64_t *tile_sums) {
+    __shared__ uint64_t part[4];
+    const uint32_t base = blockIdx.x * VIDC_SCAN_TILE;
+    uint64_t s = 0;
+    for (uint32_t j = threadIdx.x; j < VIDC_SCAN_TILE; j += 256) s += base + j < n ? in[base + j] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor((unsigned long long)s, o, 64);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ void __launch_bounds__(256) k_scan_tiles(uint64_t *tile_sums, uint32_t ntiles) {  // one block, in place
+    __shared__ uint64_t sh[256];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < ntiles; b0 += 256) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint64_t v = i < ntiles ? tile_sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t o = 1; o < 256; o <<= 1) {
+            const uint64_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < ntiles) tile_sums[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += sh[255];
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *in, uint32_t n, const uint64_t *tile_off, uint64_t *out) {
+    __shared__ uint64_t sh[256];
+    const uint32_t base = blockIdx.x * VIDC_SCAN_TILE + threadIdx.x * 16u;
+    uint32_t v[16];
+    uint64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        v[j] = base + j < n ? in[base + j] : 0u;
+        s += v[j];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256; o <<= 1) {
+        const uint64_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint64_t acc = tile_off[blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (base + j <= n) out[base + j] = acc;  // (index n receives the total)
+        acc += v[j];
+    }
+}
+// number of non-zero entries
+__global__ void k_count_nonzero(const uint32_t *in, uint32_t n, unsigned long long *out) {
+    unsigned long long c = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += in[i] != 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63u) == 0 && c) atomicAdd(out, c);
 }
 
 // ---------------------------------------------------------------------------------------------
 // compaction of the worst-case arena into the CSR stream
-__global__ void k_roc_compact(const uint32_t *arena, const uint64_t *arena_off, const uint64_t *word_off,
+__global__ void k_roc_compact(const uint32_t *arena, const uint64_t *offsets, uint32_t stride, const uint64_t *word_off,
                               uint32_t *words, uint32_t nlist) {
     for (uint32_t l = blockIdx.x; l < nlist; l += gridDim.x) {
-        const uint32_t *src = arena + arena_off[l];
+        const uint32_t *src = arena + roc_arena_at(offsets, stride, l);
         uint32_t *dst = words + word_off[l];
         uint32_t nw = (uint32_t)(word_off[l + 1] - word_off[l]);
         for (uint32_t j = threadIdx.x; j < nw; j += blockDim.x) dst[j] = src[j];

@@ -141,10 +141,10 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
 
     LStack st;
     {
-        const uint64_t ao = have ? a.arena_off[l] : 0ull;
+        const uint64_t ao = have ? arena_at(a, l) : 0ull;
         st.mem = a.arena + ao;
         st.orig = st.mem;
-        st.cap = have ? (uint32_t)(a.arena_off[l + 1] - ao) : 0u;
+        st.cap = have ? (uint32_t)(arena_at(a, l + 1) - ao) : 0u;
         st.sp = 0; st.dirty = 0; st.draws = 0; st.err = 0; st.mt = a.mt;
     }
     uint64_t head = VIDC_RANS_L;
@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_tiny_lane(RocEncArgs a, const
     const uint32_t lane = lane_id();
     const uint32_t wi = blockIdx.x * 64u + lane;
     const bool have = wi < a.nwork;
-    const uint32_t l = have ? a.worklist[wi] : 0u;
+    const uint32_t l = have ? (a.worklist ? a.worklist[wi] : wi) : 0u;
     for (uint32_t t = lane; t <= (uint32_t)KP; t += 64) dt[t] = dtab[t];
 
     uint32_t r[KP];
@@ -431,10 +431,10 @@ __global__ void __launch_bounds__(64) k_roc_encode_tiny_lane(RocEncArgs a, const
 
     LStack st;
     {
-        const uint64_t ao = have ? a.arena_off[l] : 0ull;
+        const uint64_t ao = have ? arena_at(a, l) : 0ull;
         st.mem = a.arena + ao;
         st.orig = st.mem;
-        st.cap = have ? (uint32_t)(a.arena_off[l + 1] - ao) : 0u;
+        st.cap = have ? (uint32_t)(arena_at(a, l + 1) - ao) : 0u;
         st.sp = 0; st.dirty = 0; st.draws = 0; st.err = 0; st.mt = a.mt;
     }
     uint64_t head = VIDC_RANS_L;
@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
     const bool have = wi < a.nwork;
     const uint32_t l = have ? a.worklist[wi] : 0u;
     const uint32_t n = have ? (uint32_t)(a.offsets[l + 1] - a.offsets[l]) : 0u;
-    const uint64_t ooff = have ? (a.out_off ? a.out_off[wi] : a.offsets[l]) : 0ull;
+    const uint64_t ooff = have ? (a.out_off ? a.out_off[wi] : (ROWS ? (uint64_t)wi * a.K : a.offsets[l])) : 0ull;
     const uint32_t P = have ? a.prec[l] : 0u;
     const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
     const uint32_t W = have ? a.nwords[l] : 0u;

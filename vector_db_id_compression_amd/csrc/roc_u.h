@@ -114,8 +114,8 @@ __global__ void __launch_bounds__(64) k_roc_encode_u(RocEncArgs a) {
     const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
     WStack st;
     {
-        const uint64_t ao = rfl64(a.arena_off[l]);
-        ws_init_empty(st, a.arena + ao, rfl((uint32_t)(a.arena_off[l + 1] - ao)), a.mt, VIDC_MT_TABLE);
+        const uint64_t ao = rfl64(arena_at(a, l));
+        ws_init_empty(st, a.arena + ao, rfl((uint32_t)(arena_at(a, l + 1) - ao)), a.mt, VIDC_MT_TABLE);
     }
     uint64_t head = VIDC_RANS_L;
     Recip rc;
