@@ -270,7 +270,16 @@ class EfLists:
     def __init__(self, handle, ctx, offsets):
         self.h = handle
         self.ctx = ctx
-        self.offsets = offsets
+        self._offsets = offsets
+        self._nlist = None
+
+    @property
+    def offsets(self):
+        """CSR offsets of the decoded output (graph objects fetch the edge counts from the device on first use)."""
+        if self._offsets is None:
+            sizes = self.info()["sizes"]
+            self._offsets = np.concatenate([[0], np.cumsum(sizes, dtype=np.uint64)]).astype(np.uint64)
+        return self._offsets
 
     def __del__(self):
         try:  # may run during interpreter shutdown, after module globals are gone
@@ -300,7 +309,7 @@ class EfLists:
         return int(lib().vidc_ef_compressed_bytes(self.h))
 
     def info(self):
-        n = self.offsets.size - 1
+        n = self._nlist if self._offsets is None else self._offsets.size - 1
         sizes = np.zeros(max(n, 1), np.uint32)
         lb = np.zeros(max(n, 1), np.uint32)
         uni = np.zeros(max(n, 1), np.uint64)
@@ -338,20 +347,21 @@ class EfLists:
         N, K = rows.shape
         h = C.c_void_p()
         check(lib().vidc_ef_encode_rows(ctx.h, N, K, ptr(rows) if N else None, C.byref(h)))
-        obj = cls(h, ctx, np.zeros(N + 1, np.uint64))
-        sizes = obj.info()["sizes"]
-        obj.offsets = np.concatenate([[0], np.cumsum(sizes, dtype=np.uint64)]).astype(np.uint64)
+        obj = cls(h, ctx, None)
+        obj._nlist = N
         obj.K = K
         return obj
 
-    def decode_rows(self, nodes, K=None):
+    def decode_rows(self, nodes, K=None, want_counts=True):
+        """-> (int32 [m, K] CUDA tensor, -1 padded; edge counts or None).  `want_counts=False` keeps the per-node
+        edge counts on the device."""
         torch = _torch()
         K = K or self.K
         nd = np.ascontiguousarray(nodes, dtype=np.uint64)
         out = torch.empty((max(nd.size, 1), K), dtype=torch.int32, device="cuda")
-        counts = np.zeros(max(nd.size, 1), np.uint32)
+        counts = np.zeros(max(nd.size, 1), np.uint32) if want_counts else None
         check(lib().vidc_ef_decode_rows(self.ctx.h, self.h, nd.size, ptr(nd), K, ptr(out), ptr(counts)))
-        return out[: nd.size], counts[: nd.size]
+        return out[: nd.size], (counts[: nd.size] if want_counts else None)
 
     def decode_lists(self, list_nos):
         torch = _torch()

@@ -14,6 +14,7 @@
 #include "bits.h"
 #include "chunks.h"
 #include "common.h"
+#include "scan.h"
 #include "wave.h"
 
 using namespace vidc;
@@ -23,16 +24,21 @@ struct vidc_ef {
     int device = 0;
     uint64_t nlist = 0, ntotal = 0;
     uint64_t total_bits = 0;  // sum of low + high stream lengths in bits
-    std::vector<uint64_t> offsets, low_off, high_off, universe, high_nbits;
-    std::vector<uint32_t> lbits;
+    bool rows = false;        // built from graph rows (offsets live on the device until somebody asks)
+    uint32_t K = 0;
+    // Host mirrors of the per-list geometry, filled lazily: the device arrays are authoritative (with 10^6 graph
+    // nodes the PCIe crossings of these arrays used to cost 10x the kernels).  `offsets` is always valid for
+    // objects built from host offsets.
+    mutable std::vector<uint64_t> offsets, low_off, high_off, universe, high_nbits;
+    mutable std::vector<uint32_t> lbits;
+    mutable bool offsets_host = false, meta_host = false;
     DevBuf<uint64_t> d_offsets, d_low_off, d_high_off, d_low, d_high, d_universe;
     DevBuf<uint32_t> d_lbits, d_perm;
     DevBuf<Chunk> d_chunks;
     uint64_t nchunks = 0;
     // select directory (the role of succinct's darray1): ones before every batch of 64 high words, so that bulk
     // decode and select work per (list, batch) instead of scanning a list from its start
-    std::vector<uint64_t> batch_off;    // nlist + 1
-    DevBuf<uint64_t> d_batch_off;
+    DevBuf<uint64_t> d_batch_off;       // nlist + 1
     DevBuf<uint32_t> d_hrank;           // [total batches]
     DevBuf<Chunk> d_batches;            // (list, batch number) work items of decode_all
     uint64_t nbatches = 0;
@@ -360,32 +366,96 @@ __global__ void __launch_bounds__(64) k_ef_get(const uint64_t *low, const uint64
     }
 }
 
-inline int msb64(uint64_t x) { return 63 - __builtin_clzll(x); }
+__host__ __device__ inline int msb64(uint64_t x) { return 63 - __builtin_clzll(x); }
+
+// ---- per-list geometry and work-item tables, built on the device
+__global__ void k_ef_count_chunks(const uint64_t *offsets, uint32_t nlist, uint32_t *cnt) {
+    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x)
+        cnt[l] = (uint32_t)((offsets[l + 1] - offsets[l] + CHUNK_IDS - 1) / CHUNK_IDS);
+}
+// items[item_off[l] + c] = (l, c * unit): one wavefront per list
+__global__ void __launch_bounds__(64) k_fill_items(const uint64_t *item_off, uint32_t nlist, uint32_t unit, Chunk *out) {
+    const uint32_t lane = lane_id();
+    for (uint32_t l = blockIdx.x; l < nlist; l += gridDim.x) {
+        const uint64_t o = item_off[l], n = item_off[l + 1] - o;
+        for (uint64_t c = lane; c < n; c += 64) out[o + c] = Chunk{l, (uint32_t)(c * unit)};
+    }
+}
+struct EfTotals {
+    unsigned long long total_bits;
+    unsigned int n_unsorted;
+    unsigned int pad;
+};
+// elias_fano.hpp:28-29 per list; word counts of the two streams and of the select directory
+__global__ void k_ef_geom(const uint64_t *offsets, const PrepOut *prep, uint32_t nlist, uint32_t *lbits,
+                          uint64_t *universe, uint32_t *low_words, uint32_t *high_words, uint32_t *nbatch,
+                          EfTotals *tot) {
+    unsigned long long bits = 0;
+    unsigned int uns = 0;
+    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x) {
+        const uint64_t m = offsets[l + 1] - offsets[l];
+        uint32_t lb = 0, lw = 0, hw = 0;
+        uint64_t u = 0;
+        if (m) {  // empty lists have no bitstream object (ef_bitstreams[list_no] stays null, :239-241)
+            u = prep[l].max_id;
+            lb = (u / m) ? (uint32_t)msb64(u / m) : 0u;
+            const uint64_t hb = (m + 1) + (u >> lb) + 1;
+            bits += m * lb + hb;
+            lw = (uint32_t)((m * lb + 63) / 64 + 1);  // +1 padding word for read_bits
+            hw = (uint32_t)((hb + 63) / 64);
+            uns += prep[l].unsorted ? 1u : 0u;
+        }
+        lbits[l] = lb; universe[l] = u; low_words[l] = lw; high_words[l] = hw; nbatch[l] = (hw + 63u) / 64u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        bits += __shfl_xor(bits, o, 64);
+        uns += (unsigned int)__shfl_xor((int)uns, o, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (bits) atomicAdd(&tot->total_bits, bits);
+        if (uns) atomicAdd(&tot->n_unsorted, uns);
+    }
+}
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint64_t *d_ids, uint32_t flags,
-                   vidc_ef **out) {
-    if (!ctx || !out || (nlist && !offsets)) return VIDC_ERR_INVALID;
-    *out = nullptr;
-    if (nlist >= 0xffffffffull) return VIDC_ERR_INVALID;
-    VIDC_HIP(hipSetDevice(ctx->device));
-    std::unique_ptr<vidc_ef> e(new vidc_ef());
-    e->device = ctx->device;
-    e->nlist = nlist;
-    e->offsets.assign(nlist + 1, 0);
-    if (nlist) e->offsets.assign(offsets, offsets + nlist + 1);
-    e->ntotal = e->offsets[nlist];
-    for (uint64_t l = 0; l < nlist; l++)
-        if (e->offsets[l + 1] < e->offsets[l] || e->offsets[l + 1] - e->offsets[l] > 0xfffffff0ull) {
-            set_error("bad offsets at list %llu", (unsigned long long)l);
-            return VIDC_ERR_INVALID;
-        }
-    if (e->ntotal && !d_ids) return VIDC_ERR_INVALID;
-    VIDC_TRY(e->d_offsets.alloc(nlist + 1));
-    VIDC_HIP(hipMemcpyAsync(e->d_offsets.p, e->offsets.data(), (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+template <typename T>
+int ef_mirror(std::vector<T> &dst, const T *d_src, size_t count) {
+    dst.resize(count);
+    if (count) VIDC_HIP(hipMemcpy(dst.data(), d_src, count * sizeof(T), hipMemcpyDeviceToHost));
+    return VIDC_OK;
+}
+int ef_ensure_offsets(const vidc_ef *e) {
+    if (e->offsets_host) return VIDC_OK;
+    VIDC_HIP(hipSetDevice(e->device));
+    VIDC_TRY(ef_mirror(e->offsets, (const uint64_t *)e->d_offsets.p, e->nlist + 1));
+    e->offsets_host = true;
+    return VIDC_OK;
+}
+int ef_ensure_meta(const vidc_ef *e) {
+    VIDC_TRY(ef_ensure_offsets(e));
+    if (e->meta_host) return VIDC_OK;
+    VIDC_HIP(hipSetDevice(e->device));
+    VIDC_TRY(ef_mirror(e->low_off, (const uint64_t *)e->d_low_off.p, e->nlist + 1));
+    VIDC_TRY(ef_mirror(e->high_off, (const uint64_t *)e->d_high_off.p, e->nlist + 1));
+    VIDC_TRY(ef_mirror(e->universe, (const uint64_t *)e->d_universe.p, e->nlist));
+    VIDC_TRY(ef_mirror(e->lbits, (const uint32_t *)e->d_lbits.p, e->nlist));
+    e->high_nbits.assign(e->nlist, 0);
+    for (uint64_t l = 0; l < e->nlist; l++) {
+        const uint64_t m = e->offsets[l + 1] - e->offsets[l];
+        if (m) e->high_nbits[l] = (m + 1) + (e->universe[l] >> e->lbits[l]) + 1;
+    }
+    e->meta_host = true;
+    return VIDC_OK;
+}
+
+// the part of the encoder shared by the list and the graph-row entry points: e->d_offsets, nlist, ntotal are set
+int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t flags) {
+    const uint64_t nlist = e->nlist;
+    const uint32_t nl32 = (uint32_t)nlist;
     double kernel_ms = 0;
     auto timed = [&](auto &&fn) -> int {
         VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
@@ -398,78 +468,84 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
         kernel_ms += ms;
         return VIDC_OK;
     };
+    const uint32_t lgrid = (uint32_t)std::min<uint64_t>((nlist + 255) / 256 + 1, 2048);
+    const uint32_t wgrid = (uint32_t)std::min<uint64_t>(nlist ? nlist : 1, (uint64_t)ctx->num_cu * 64);
+    Scratch s_cnt, s_coff, s_tmp, s_prep, s_lw, s_hw, s_nb, s_tot, s_tmp2, s_tmp3;
+    Pinned tail;
+    VIDC_TRY(tail.get(ctx, 64));
+    unsigned long long *t = tail.as<unsigned long long>();
 
-    {
-        std::vector<Chunk> chunks = build_chunks(e->offsets);
-        e->nchunks = chunks.size();
-        VIDC_TRY(e->d_chunks.alloc(chunks.size() ? chunks.size() : 1));
-        if (!chunks.empty())
-            VIDC_HIP(hipMemcpyAsync(e->d_chunks.p, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice,
-                                    ctx->stream));
-        VIDC_HIP(hipStreamSynchronize(ctx->stream));  // `chunks` is a local host buffer
-    }
+    // chunk table (one wavefront of the streaming kernels per 512 ids)
+    VIDC_TRY(s_cnt.get(ctx, (nlist + 1) * 4));
+    VIDC_TRY(s_coff.get(ctx, (nlist + 1) * 8));
+    hipLaunchKernelGGL(k_ef_count_chunks, dim3(lgrid), dim3(256), 0, ctx->stream, e->d_offsets.p, nl32, s_cnt.as<uint32_t>());
+    VIDC_TRY(device_exscan(ctx, s_cnt.as<uint32_t>(), nl32, s_coff.as<uint64_t>(), s_tmp));
+    VIDC_HIP(hipMemcpyAsync(t, s_coff.as<uint64_t>() + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    e->nchunks = t[0];
+    VIDC_TRY(e->d_chunks.alloc(e->nchunks ? e->nchunks : 1, ctx->dpool));
+    if (e->nchunks)
+        hipLaunchKernelGGL(k_fill_items, dim3(wgrid), dim3(64), 0, ctx->stream, s_coff.as<uint64_t>(), nl32, CHUNK_IDS,
+                           e->d_chunks.p);
+    VIDC_HIP(hipGetLastError());
     const uint32_t cgrid = (uint32_t)std::min<uint64_t>(e->nchunks ? e->nchunks : 1, (uint64_t)ctx->num_cu * 256);
-    // pass 1: universe (max id) and sortedness per list
-    std::vector<PrepOut> prep(nlist);
-    Scratch s_prep;
-    VIDC_TRY(s_prep.get(ctx, nlist * sizeof(PrepOut)));
-    if (nlist) {
-        VIDC_HIP(hipMemsetAsync(s_prep.p, 0, nlist * sizeof(PrepOut), ctx->stream));
+
+    // pass 1: universe (max id) and sortedness per list, then the geometry (elias_fano.hpp:28-29)
+    VIDC_TRY(s_prep.get(ctx, (nlist + 1) * sizeof(PrepOut)));
+    VIDC_TRY(s_lw.get(ctx, (nlist + 1) * 4)); VIDC_TRY(s_hw.get(ctx, (nlist + 1) * 4)); VIDC_TRY(s_nb.get(ctx, (nlist + 1) * 4));
+    VIDC_TRY(s_tot.get(ctx, sizeof(EfTotals)));
+    VIDC_TRY(e->d_low_off.alloc(nlist + 1, ctx->dpool)); VIDC_TRY(e->d_high_off.alloc(nlist + 1, ctx->dpool));
+    VIDC_TRY(e->d_batch_off.alloc(nlist + 1, ctx->dpool));
+    VIDC_TRY(e->d_lbits.alloc(nlist ? nlist : 1, ctx->dpool)); VIDC_TRY(e->d_universe.alloc(nlist ? nlist : 1, ctx->dpool));
+    VIDC_HIP(hipMemsetAsync(s_prep.p, 0, (nlist + 1) * sizeof(PrepOut), ctx->stream));
+    VIDC_HIP(hipMemsetAsync(s_tot.p, 0, sizeof(EfTotals), ctx->stream));
+    if (e->nchunks)
         VIDC_TRY(timed([&] {
             hipLaunchKernelGGL(k_ef_prep, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, e->d_offsets.p, e->d_chunks.p,
                                e->nchunks, s_prep.as<PrepOut>());
         }));
-        VIDC_HIP(hipMemcpyAsync(prep.data(), s_prep.p, nlist * sizeof(PrepOut), hipMemcpyDeviceToHost, ctx->stream));
-        VIDC_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    // geometry (elias_fano.hpp:28-29)
-    e->lbits.assign(nlist, 0); e->universe.assign(nlist, 0); e->high_nbits.assign(nlist, 0);
-    e->low_off.assign(nlist + 1, 0); e->high_off.assign(nlist + 1, 0);
-    std::vector<uint32_t> unsorted;
-    for (uint64_t l = 0; l < nlist; l++) {
-        uint64_t m = e->offsets[l + 1] - e->offsets[l];
-        uint64_t low_words = 0, high_words = 0;
-        if (m) {  // empty lists have no bitstream object (ef_bitstreams[list_no] stays null, :239-241)
-            uint64_t u = prep[l].max_id;
-            uint32_t lb = (u / m) ? (uint32_t)msb64(u / m) : 0u;
-            uint64_t hb = (m + 1) + (u >> lb) + 1;
-            e->universe[l] = u; e->lbits[l] = lb; e->high_nbits[l] = hb;
-            e->total_bits += m * lb + hb;
-            low_words = (m * lb + 63) / 64 + 1;  // +1 padding word for read_bits
-            high_words = (hb + 63) / 64;
-            if (prep[l].unsorted) unsorted.push_back((uint32_t)l);
-        }
-        e->low_off[l + 1] = e->low_off[l] + low_words;
-        e->high_off[l + 1] = e->high_off[l] + high_words;
-    }
-    VIDC_TRY(e->d_low_off.alloc(nlist + 1)); VIDC_TRY(e->d_high_off.alloc(nlist + 1));
-    VIDC_TRY(e->d_lbits.alloc(nlist ? nlist : 1)); VIDC_TRY(e->d_universe.alloc(nlist ? nlist : 1));
-    VIDC_TRY(e->d_low.alloc(e->low_off[nlist] ? e->low_off[nlist] : 1));
-    VIDC_TRY(e->d_high.alloc(e->high_off[nlist] ? e->high_off[nlist] : 1));
-    VIDC_HIP(hipMemcpyAsync(e->d_low_off.p, e->low_off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    VIDC_HIP(hipMemcpyAsync(e->d_high_off.p, e->high_off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (nlist) {
-        VIDC_HIP(hipMemcpyAsync(e->d_lbits.p, e->lbits.data(), nlist * 4, hipMemcpyHostToDevice, ctx->stream));
-        VIDC_HIP(hipMemcpyAsync(e->d_universe.p, e->universe.data(), nlist * 8, hipMemcpyHostToDevice, ctx->stream));
-    }
-    VIDC_HIP(hipMemsetAsync(e->d_high.p, 0, (e->high_off[nlist] ? e->high_off[nlist] : 1) * 8, ctx->stream));
+    hipLaunchKernelGGL(k_ef_geom, dim3(lgrid), dim3(256), 0, ctx->stream, e->d_offsets.p, s_prep.as<PrepOut>(), nl32,
+                       e->d_lbits.p, e->d_universe.p, s_lw.as<uint32_t>(), s_hw.as<uint32_t>(), s_nb.as<uint32_t>(),
+                       s_tot.as<EfTotals>());
+    VIDC_TRY(device_exscan(ctx, s_lw.as<uint32_t>(), nl32, e->d_low_off.p, s_tmp));
+    VIDC_TRY(device_exscan(ctx, s_hw.as<uint32_t>(), nl32, e->d_high_off.p, s_tmp2));
+    VIDC_TRY(device_exscan(ctx, s_nb.as<uint32_t>(), nl32, e->d_batch_off.p, s_tmp3));
+    VIDC_HIP(hipMemcpyAsync(t + 0, e->d_low_off.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(t + 1, e->d_high_off.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(t + 2, e->d_batch_off.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(t + 3, s_tot.p, sizeof(EfTotals), hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t low_words = t[0], high_words = t[1];
+    e->nbatches = t[2];
+    e->total_bits = t[3];
+    const uint32_t n_unsorted = (uint32_t)(t[4] & 0xffffffffu);
+    VIDC_TRY(e->d_low.alloc(low_words ? low_words : 1, ctx->dpool));
+    VIDC_TRY(e->d_high.alloc(high_words ? high_words : 1, ctx->dpool));
+    VIDC_HIP(hipMemsetAsync(e->d_high.p, 0, (high_words ? high_words : 1) * 8, ctx->stream));
 
     // pass 2 (only when some list is not ascending): sorted copy + permutation
     const uint64_t *d_sorted = d_ids;
     Scratch s_sorted, s_keys, s_kpos, s_key_off, s_lists;
     const bool want_perm = (flags & VIDC_EF_WANT_PERM) != 0;
-    if (want_perm || !unsorted.empty()) {
-        VIDC_TRY(e->d_perm.alloc(e->ntotal ? e->ntotal : 1));
+    if (want_perm || n_unsorted) {
+        VIDC_TRY(e->d_perm.alloc(e->ntotal ? e->ntotal : 1, ctx->dpool));
         e->has_perm = true;
         if (e->ntotal) {
             uint32_t grid = (uint32_t)std::min<uint64_t>((e->ntotal + 255) / 256, (uint64_t)ctx->num_cu * 32);
             VIDC_TRY(timed([&] {
-                hipLaunchKernelGGL(k_iota_perm, dim3(grid), dim3(256), 0, ctx->stream, e->d_offsets.p, (uint32_t)nlist,
-                                   e->ntotal, e->d_perm.p);
+                hipLaunchKernelGGL(k_iota_perm, dim3(grid), dim3(256), 0, ctx->stream, e->d_offsets.p, nl32, e->ntotal,
+                                   e->d_perm.p);
             }));
         }
     }
-    if (!unsorted.empty()) {
+    if (n_unsorted) {
+        // rare (Faiss lists are in add order): the list of unsorted lists is built on the host
+        VIDC_TRY(ef_ensure_offsets(e));
+        std::vector<PrepOut> prep(nlist);
+        VIDC_HIP(hipMemcpy(prep.data(), s_prep.p, nlist * sizeof(PrepOut), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> unsorted;
+        for (uint64_t l = 0; l < nlist; l++)
+            if (e->offsets[l + 1] > e->offsets[l] && prep[l].unsorted) unsorted.push_back((uint32_t)l);
         std::stable_sort(unsorted.begin(), unsorted.end(), [&](uint32_t a, uint32_t b) {
             return e->offsets[a + 1] - e->offsets[a] > e->offsets[b + 1] - e->offsets[b];
         });
@@ -496,7 +572,7 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     }
     // pass 3: the two bit streams
     if (e->ntotal) {
-        VIDC_HIP(hipMemsetAsync(e->d_low.p, 0, (e->low_off[nlist] ? e->low_off[nlist] : 1) * 8, ctx->stream));
+        VIDC_HIP(hipMemsetAsync(e->d_low.p, 0, (low_words ? low_words : 1) * 8, ctx->stream));
         VIDC_TRY(timed([&] {
             hipLaunchKernelGGL(k_ef_low, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p, e->d_low_off.p,
                                e->d_lbits.p, e->d_chunks.p, e->nchunks, e->d_low.p);
@@ -505,33 +581,51 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
         }));
     }
     // select directory
-    {
-        e->batch_off.assign(nlist + 1, 0);
-        std::vector<Chunk> batches;
-        for (uint64_t l = 0; l < nlist; l++) {
-            const uint64_t hw = e->high_off[l + 1] - e->high_off[l];
-            const uint64_t nb = (hw + 63) / 64;
-            e->batch_off[l + 1] = e->batch_off[l] + nb;
-            for (uint64_t bt = 0; bt < nb; bt++) batches.push_back(Chunk{(uint32_t)l, (uint32_t)bt});
-        }
-        e->nbatches = batches.size();
-        VIDC_TRY(e->d_batch_off.alloc(nlist + 1));
-        VIDC_TRY(e->d_batches.alloc(e->nbatches ? e->nbatches : 1));
-        VIDC_TRY(e->d_hrank.alloc(e->nbatches ? e->nbatches : 1));
-        VIDC_HIP(hipMemcpyAsync(e->d_batch_off.p, e->batch_off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        if (e->nbatches) {
-            VIDC_HIP(hipMemcpyAsync(e->d_batches.p, batches.data(), e->nbatches * sizeof(Chunk), hipMemcpyHostToDevice,
-                                    ctx->stream));
-            VIDC_TRY(timed([&] {
-                hipLaunchKernelGGL(k_ef_hrank, dim3((uint32_t)std::min<uint64_t>((e->nbatches + 255) / 256, 4096)), dim3(256),
-                                   0, ctx->stream, d_sorted, e->d_offsets.p, e->d_lbits.p, e->d_batches.p, e->nbatches,
-                                   e->d_hrank.p);
-            }));
-        }
-        VIDC_HIP(hipStreamSynchronize(ctx->stream));  // `batches` is a local host buffer
+    VIDC_TRY(e->d_batches.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
+    VIDC_TRY(e->d_hrank.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
+    if (e->nbatches) {
+        VIDC_TRY(timed([&] {
+            hipLaunchKernelGGL(k_fill_items, dim3(wgrid), dim3(64), 0, ctx->stream, e->d_batch_off.p, nl32, 1u,
+                               e->d_batches.p);
+            hipLaunchKernelGGL(k_ef_hrank, dim3((uint32_t)std::min<uint64_t>((e->nbatches + 255) / 256, 4096)), dim3(256),
+                               0, ctx->stream, d_sorted, e->d_offsets.p, e->d_lbits.p, e->d_batches.p, e->nbatches,
+                               e->d_hrank.p);
+        }));
     }
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->last_kernel_ms = kernel_ms;
+    return VIDC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint64_t *d_ids, uint32_t flags,
+                   vidc_ef **out) {
+    if (!ctx || !out || (nlist && !offsets)) return VIDC_ERR_INVALID;
+    *out = nullptr;
+    if (nlist >= 0xffffffffull) return VIDC_ERR_INVALID;
+    VIDC_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<vidc_ef> e(new vidc_ef());
+    e->device = ctx->device;
+    e->nlist = nlist;
+    e->offsets.assign(nlist + 1, 0);
+    if (nlist) e->offsets.assign(offsets, offsets + nlist + 1);
+    e->offsets_host = true;
+    e->ntotal = e->offsets[nlist];
+    for (uint64_t l = 0; l < nlist; l++)
+        if (e->offsets[l + 1] < e->offsets[l] || e->offsets[l + 1] - e->offsets[l] > 0xfffffff0ull) {
+            set_error("bad offsets at list %llu", (unsigned long long)l);
+            return VIDC_ERR_INVALID;
+        }
+    if (e->ntotal && !d_ids) return VIDC_ERR_INVALID;
+    VIDC_TRY(e->d_offsets.alloc(nlist + 1, ctx->dpool));
+    Pinned h_off;
+    VIDC_TRY(h_off.get(ctx, (nlist + 1) * 8));
+    std::memcpy(h_off.p, e->offsets.data(), (nlist + 1) * 8);
+    VIDC_HIP(hipMemcpyAsync(e->d_offsets.p, h_off.p, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    VIDC_TRY(ef_encode_common(ctx, e.get(), d_ids, flags));
     *out = e.release();
     return VIDC_OK;
 }
@@ -543,6 +637,7 @@ uint64_t vidc_ef_compressed_bytes(const vidc_ef *e) { return e ? e->total_bits /
 
 int vidc_ef_list_info(const vidc_ef *e, uint32_t *sizes, uint32_t *low_bits, uint64_t *universes) {
     if (!e) return VIDC_ERR_INVALID;
+    VIDC_TRY(ef_ensure_meta(e));
     for (uint64_t l = 0; l < e->nlist; l++) {
         if (sizes) sizes[l] = (uint32_t)(e->offsets[l + 1] - e->offsets[l]);
         if (low_bits) low_bits[l] = e->lbits[l];
@@ -572,14 +667,19 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
 }
 
 static int ef_decode_some(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *list_nos,
-                          const uint64_t *out_off_host, uint64_t *d_out, int32_t *d_rows, uint32_t K) {
+                          const uint64_t *out_off_host, uint64_t *d_out, int32_t *d_rows, uint32_t K,
+                          uint32_t *counts_host = nullptr) {
     VIDC_HIP(hipSetDevice(ctx->device));
     Scratch s_l, s_o;
+    Pinned h_up;
+    VIDC_TRY(h_up.get(ctx, m * 16));
     VIDC_TRY(s_l.get(ctx, m * 8));
-    VIDC_HIP(hipMemcpyAsync(s_l.p, list_nos, m * 8, hipMemcpyHostToDevice, ctx->stream));
+    std::memcpy(h_up.p, list_nos, m * 8);
+    VIDC_HIP(hipMemcpyAsync(s_l.p, h_up.p, m * 8, hipMemcpyHostToDevice, ctx->stream));
     if (out_off_host) {
         VIDC_TRY(s_o.get(ctx, m * 8));
-        VIDC_HIP(hipMemcpyAsync(s_o.p, out_off_host, m * 8, hipMemcpyHostToDevice, ctx->stream));
+        std::memcpy(h_up.as<uint64_t>() + m, out_off_host, m * 8);
+        VIDC_HIP(hipMemcpyAsync(s_o.p, h_up.as<uint64_t>() + m, m * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(k_ef_decode, dim3((uint32_t)std::min<uint64_t>(m, (uint64_t)ctx->num_cu * 64)), dim3(64), 0,
@@ -592,12 +692,14 @@ static int ef_decode_some(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uin
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->last_kernel_ms = ms;
+    if (counts_host) VIDC_TRY(fetch_sizes<uint64_t>(ctx, e->d_offsets.p, s_l.as<uint64_t>(), m, counts_host));
     return VIDC_OK;
 }
 
 int vidc_ef_decode_lists(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *list_nos, uint64_t *d_out,
                          uint64_t *out_offsets) {
     if (!ctx || !e || (m && !list_nos) || !out_offsets) return VIDC_ERR_INVALID;
+    VIDC_TRY(ef_ensure_offsets(e));
     out_offsets[0] = 0;
     for (uint64_t i = 0; i < m; i++) {
         if (list_nos[i] >= e->nlist) { set_error("list number out of range"); return VIDC_ERR_INVALID; }
@@ -610,52 +712,62 @@ int vidc_ef_decode_lists(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint
 int vidc_ef_decode_rows(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *nodes, uint32_t K, int32_t *d_out,
                         uint32_t *counts) {
     if (!ctx || !e || (m && (!nodes || !d_out)) || K == 0) return VIDC_ERR_INVALID;
+    // rows of a graph object never exceed its K; edge counts of the requested nodes are gathered on the device
+    const bool lean = e->rows && K >= e->K;
+    if (!lean) VIDC_TRY(ef_ensure_offsets(e));
     for (uint64_t i = 0; i < m; i++) {
         if (nodes[i] >= e->nlist) { set_error("node out of range"); return VIDC_ERR_INVALID; }
+        if (lean) continue;
         uint64_t n = e->offsets[nodes[i] + 1] - e->offsets[nodes[i]];
         if (n > K) { set_error("node has more than K edges"); return VIDC_ERR_INVALID; }
         if (counts) counts[i] = (uint32_t)n;
     }
     if (!m) return VIDC_OK;
-    return ef_decode_some(ctx, e, m, nodes, nullptr, nullptr, d_out, K);
+    return ef_decode_some(ctx, e, m, nodes, nullptr, nullptr, d_out, K, lean ? counts : nullptr);
 }
 
 int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_rows, vidc_ef **out) {
     if (!ctx || !out || (N && !d_rows)) return VIDC_ERR_INVALID;
     *out = nullptr;
     if (K == 0 || K > 64) { set_error("EF rows: K=%u unsupported (1..64)", K); return VIDC_ERR_UNSUPPORTED; }
+    if (N >= 0xffffffffull) return VIDC_ERR_INVALID;
     VIDC_HIP(hipSetDevice(ctx->device));
-    Scratch s_cnt, s_err, s_off, s_ids;
-    VIDC_TRY(s_cnt.get(ctx, N * 4));
+    std::unique_ptr<vidc_ef> e(new vidc_ef());
+    e->device = ctx->device;
+    e->nlist = N;
+    e->rows = true;
+    e->K = K;
+    Scratch s_cnt, s_err, s_ids, s_tmp;
+    Pinned tail;
+    VIDC_TRY(tail.get(ctx, 16));
+    VIDC_TRY(s_cnt.get(ctx, (N + 1) * 4));
     VIDC_TRY(s_err.get(ctx, 4));
+    VIDC_TRY(e->d_offsets.alloc(N + 1, ctx->dpool));
     VIDC_HIP(hipMemsetAsync(s_err.p, 0, 4, ctx->stream));
-    std::vector<uint32_t> counts(N);
-    std::vector<uint64_t> offsets(N + 1, 0);
-    uint32_t err = 0;
-    if (N) {
-        uint32_t grid = (uint32_t)std::min<uint64_t>(N, (uint64_t)ctx->num_cu * 64);
-        hipLaunchKernelGGL(k_rows_count, dim3(grid), dim3(64), 0, ctx->stream, d_rows, N, K, s_cnt.as<uint32_t>(),
-                           s_err.as<uint32_t>());
-        VIDC_HIP(hipGetLastError());
-        VIDC_HIP(hipMemcpyAsync(counts.data(), s_cnt.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-        VIDC_HIP(hipMemcpyAsync(&err, s_err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-        VIDC_HIP(hipStreamSynchronize(ctx->stream));
-        if (err) { set_error("EF rows: negative neighbour id before the -1 terminator"); return VIDC_ERR_DOMAIN; }
-        for (uint64_t r = 0; r < N; r++) offsets[r + 1] = offsets[r] + counts[r];
-        VIDC_TRY(s_off.get(ctx, (N + 1) * 8));
-        VIDC_TRY(s_ids.get(ctx, offsets[N] * 8));
-        VIDC_HIP(hipMemcpyAsync(s_off.p, offsets.data(), (N + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_rows_sorted, dim3(grid), dim3(64), 0, ctx->stream, d_rows, N, K, s_off.as<uint64_t>(),
-                           s_ids.as<uint64_t>());
-        VIDC_HIP(hipGetLastError());
-    }
-    return vidc_ef_encode(ctx, N, offsets.data(), s_ids.as<uint64_t>(), 0, out);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(N ? N : 1, (uint64_t)ctx->num_cu * 64);
+    // edge counts -> CSR offsets, on the device (altid_impl.cpp:61-76 builds one bit stream per node)
+    if (N) hipLaunchKernelGGL(k_rows_count, dim3(grid), dim3(64), 0, ctx->stream, d_rows, N, K, s_cnt.as<uint32_t>(),
+                              s_err.as<uint32_t>());
+    VIDC_TRY(device_exscan(ctx, s_cnt.as<uint32_t>(), (uint32_t)N, e->d_offsets.p, s_tmp));
+    VIDC_HIP(hipMemcpyAsync(tail.p, e->d_offsets.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(tail.as<uint64_t>() + 1, s_err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    if ((uint32_t)tail.as<uint64_t>()[1]) { set_error("EF rows: negative neighbour id before the -1 terminator"); return VIDC_ERR_DOMAIN; }
+    e->ntotal = tail.as<uint64_t>()[0];
+    VIDC_TRY(s_ids.get(ctx, e->ntotal * 8));
+    if (N) hipLaunchKernelGGL(k_rows_sorted, dim3(grid), dim3(64), 0, ctx->stream, d_rows, N, K, e->d_offsets.p,
+                              s_ids.as<uint64_t>());
+    VIDC_HIP(hipGetLastError());
+    VIDC_TRY(ef_encode_common(ctx, e.get(), s_ids.as<uint64_t>(), 0));
+    *out = e.release();
+    return VIDC_OK;
 }
 
 int vidc_ef_get(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *list_nos, const uint64_t *offs,
                 int64_t *ids_out) {
     if (!ctx || !e || (m && (!list_nos || !offs || !ids_out))) return VIDC_ERR_INVALID;
     if (!m) return VIDC_OK;
+    VIDC_TRY(ef_ensure_offsets(e));
     for (uint64_t i = 0; i < m; i++) {
         if (list_nos[i] >= e->nlist || offs[i] >= e->offsets[list_nos[i] + 1] - e->offsets[list_nos[i]]) {
             set_error("ef get: (list %llu, offset %llu) out of range", (unsigned long long)list_nos[i],
@@ -686,6 +798,7 @@ int vidc_ef_perm(vidc_ctx *ctx, const vidc_ef *e, uint32_t *perm_host) {
 int vidc_ef_export(vidc_ctx *ctx, const vidc_ef *e, uint64_t list_no, uint64_t *low, size_t low_cap, uint64_t *high,
                    size_t high_cap, uint64_t *low_nbits, uint64_t *high_nbits) {
     if (!ctx || !e || list_no >= e->nlist) return VIDC_ERR_INVALID;
+    VIDC_TRY(ef_ensure_meta(e));
     uint64_t m = e->offsets[list_no + 1] - e->offsets[list_no];
     uint64_t lb = m * e->lbits[list_no], hb = e->high_nbits[list_no];
     if (low_nbits) *low_nbits = lb;

@@ -10,6 +10,7 @@
 #include "roc_kernels.h"
 #include "roc_u.h"
 #include "roc_lane.h"
+#include "scan.h"
 
 using namespace vidc;
 using namespace vidc::dev;
@@ -109,17 +110,6 @@ int download(vidc_ctx *ctx, std::vector<T> &dst, const T *d_src, size_t count) {
     VIDC_HIP(hipMemcpyAsync(st.p, d_src, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
     std::memcpy(dst.data(), st.p, count * sizeof(T));
-    return VIDC_OK;
-}
-
-// out[0..n] = exclusive prefix sums of in[0..n) (u32 -> u64), on the stream
-int device_exscan(vidc_ctx *ctx, const uint32_t *d_in, uint32_t n, uint64_t *d_out, Scratch &tmp) {
-    const uint32_t ntiles = n / VIDC_SCAN_TILE + 1u;
-    VIDC_TRY(tmp.get(ctx, (size_t)ntiles * 8));
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(256), 0, ctx->stream, d_in, n, tmp.as<uint64_t>());
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(256), 0, ctx->stream, tmp.as<uint64_t>(), ntiles);
-    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(256), 0, ctx->stream, d_in, n, tmp.as<uint64_t>(), d_out);
-    VIDC_HIP(hipGetLastError());
     return VIDC_OK;
 }
 
@@ -996,12 +986,12 @@ int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uin
     if (!ctx || !r || (m && (!nodes || !d_out))) return VIDC_ERR_INVALID;
     if (K == 0 || K > TINY_MAX) { set_error("K=%u unsupported", K); return VIDC_ERR_UNSUPPORTED; }
     const bool lean = r->rows && K >= r->K && !force_general() && !no_lane();
-    if (!lean || counts) VIDC_TRY(r->prec.size() == r->nlist ? ensure_offsets(r) : ensure_meta(r));
+    if (!lean) VIDC_TRY(r->prec.size() == r->nlist ? ensure_offsets(r) : ensure_meta(r));
     std::vector<uint32_t> lists(m);
     for (uint64_t i = 0; i < m; i++) {
         if (nodes[i] >= r->nlist) { set_error("node %llu out of range", (unsigned long long)nodes[i]); return VIDC_ERR_INVALID; }
         lists[i] = (uint32_t)nodes[i];
-        if (!lean || counts) {
+        if (!lean) {
             uint64_t n = r->offsets[lists[i] + 1] - r->offsets[lists[i]];
             if (n > K) { set_error("node %u has %llu edges > K=%u", lists[i], (unsigned long long)n, K); return VIDC_ERR_INVALID; }
             if (counts) counts[i] = (uint32_t)n;
@@ -1009,7 +999,19 @@ int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uin
     }
     DecPlan p;
     plan_decode(r, lists, true, p, lean);
-    if (p.lean) return decode_impl(ctx, r, p, nullptr, nullptr, d_out, K);
+    if (p.lean) {
+        VIDC_TRY(decode_impl(ctx, r, p, nullptr, nullptr, d_out, K));
+        if (counts && m) {  // edge counts of the requested nodes, gathered on the device
+            Scratch s_wl;
+            Pinned h_wl;
+            VIDC_TRY(s_wl.get(ctx, m * 4));
+            VIDC_TRY(h_wl.get(ctx, m * 4));
+            std::memcpy(h_wl.p, lists.data(), m * 4);
+            VIDC_HIP(hipMemcpyAsync(s_wl.p, h_wl.p, m * 4, hipMemcpyHostToDevice, ctx->stream));
+            VIDC_TRY(fetch_sizes<uint32_t>(ctx, r->d_offsets.p, s_wl.as<uint32_t>(), m, counts));
+        }
+        return VIDC_OK;
+    }
     std::vector<uint64_t> out_off(m);
     for (size_t k = 0; k < m; k++) out_off[k] = (uint64_t)p.item[k] * K;
     return decode_impl(ctx, r, p, out_off.data(), nullptr, d_out, K);

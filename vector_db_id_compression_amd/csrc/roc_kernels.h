@@ -566,78 +566,6 @@ __global__ void k_roc_status_summary(const uint32_t *status, const uint32_t *end
 }
 
 // ---------------------------------------------------------------------------------------------
-// exclusive scan of u32 counts into u64 offsets (out has n + 1 entries): three small launches.  Keeps the per-list
-// word counts / edge counts on the device: with 10^6 lists the host prefix sum + two PCIe crossings of the arrays
-// cost more than the codec kernels.
-#define VIDC_SCAN_TILE 4096u  // elements per block = 256 threads x 16
-__global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t *in, uint32_t n, uint64_t *tile_sums) {
-    __shared__ uint64_t part[4];
-    const uint32_t base = blockIdx.x * VIDC_SCAN_TILE;
-    uint64_t s = 0;
-    for (uint32_t j = threadIdx.x; j < VIDC_SCAN_TILE; j += 256) s += base + j < n ? in[base + j] : 0u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor((unsigned long long)s, o, 64);
-    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
-}
-__global__ void __launch_bounds__(256) k_scan_tiles(uint64_t *tile_sums, uint32_t ntiles) {  // one block, in place
-    __shared__ uint64_t sh[256];
-    __shared__ uint64_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t b0 = 0; b0 < ntiles; b0 += 256) {
-        const uint32_t i = b0 + threadIdx.x;
-        const uint64_t v = i < ntiles ? tile_sums[i] : 0;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (uint32_t o = 1; o < 256; o <<= 1) {
-            const uint64_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < ntiles) tile_sums[i] = carry + sh[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry += sh[255];
-        __syncthreads();
-    }
-}
-__global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *in, uint32_t n, const uint64_t *tile_off, uint64_t *out) {
-    __shared__ uint64_t sh[256];
-    const uint32_t base = blockIdx.x * VIDC_SCAN_TILE + threadIdx.x * 16u;
-    uint32_t v[16];
-    uint64_t s = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        v[j] = base + j < n ? in[base + j] : 0u;
-        s += v[j];
-    }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (uint32_t o = 1; o < 256; o <<= 1) {
-        const uint64_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
-    }
-    uint64_t acc = tile_off[blockIdx.x] + sh[threadIdx.x] - s;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        if (base + j <= n) out[base + j] = acc;  // (index n receives the total)
-        acc += v[j];
-    }
-}
-// number of non-zero entries
-__global__ void k_count_nonzero(const uint32_t *in, uint32_t n, unsigned long long *out) {
-    unsigned long long c = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += in[i] != 0u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if ((threadIdx.x & 63u) == 0 && c) atomicAdd(out, c);
-}
-
-// ---------------------------------------------------------------------------------------------
 // compaction of the worst-case arena into the CSR stream
 __global__ void k_roc_compact(const uint32_t *arena, const uint64_t *offsets, uint32_t stride, const uint64_t *word_off,
                               uint32_t *words, uint32_t nlist) {
