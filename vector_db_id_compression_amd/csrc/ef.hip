@@ -289,6 +289,45 @@ __global__ void __launch_bounds__(64) k_ef_decode(const uint64_t *low, const uin
     }
 }
 
+// graph rows (<= 64 edges): one row per LANE.  A row's high stream is 3-4 words and its low stream ~100 bytes, so
+// a wavefront per row (above) leaves the machine mostly idle; here 64 rows advance per instruction.  Values are
+// staged in LDS (element e of row t at stage[e * 65 + t]) and written one row per iteration: contiguous stores.
+__global__ void __launch_bounds__(64) k_ef_decode_rows_lane(const uint64_t *low, const uint64_t *high,
+                                                            const uint64_t *offsets, const uint64_t *low_off,
+                                                            const uint64_t *high_off, const uint32_t *lbits,
+                                                            uint64_t nwork, const uint64_t *worklist, int32_t *out_rows,
+                                                            uint32_t K) {
+    __shared__ uint32_t stage[64 * 65];
+    const uint32_t lane = lane_id();
+    const uint64_t wi = (uint64_t)blockIdx.x * 64u + lane;
+    const bool have = wi < nwork;
+    const uint64_t l = have ? (worklist ? worklist[wi] : wi) : 0;
+    const uint32_t m = have ? (uint32_t)(offsets[l + 1] - offsets[l]) : 0u;
+    const uint32_t b = have ? lbits[l] : 0u;
+    const uint64_t *lw = low + (have ? low_off[l] : 0);
+    const uint64_t *hw = high + (have ? high_off[l] : 0);
+    const uint32_t nhw = have ? (uint32_t)(high_off[l + 1] - high_off[l]) : 0u;
+    uint32_t w = 0, rank = 0;
+    uint64_t word = (m && nhw) ? hw[0] : 0ull;
+    const uint32_t nmax = wave_max_u32(m);
+    for (uint32_t it = 0; it < nmax; it++) {
+        if (rank < m) {
+            while (word == 0ull && w + 1u < nhw) word = hw[++w];
+            const uint32_t bit = (uint32_t)__builtin_ctzll(word);
+            word &= word - 1;
+            const uint64_t pos = (uint64_t)w * 64u + bit;
+            stage[rank * 65u + lane] = (uint32_t)(((pos - rank) << b) | read_bits(lw, (uint64_t)rank * b, b));
+            rank++;
+        }
+    }
+    __syncthreads();
+    const uint64_t wbase = (uint64_t)blockIdx.x * 64u;
+    for (uint32_t rr = 0; rr < 64u && wbase + rr < nwork; rr++) {
+        const uint32_t m_r = rl(m, rr);
+        if (lane < K) out_rows[(wbase + rr) * K + lane] = lane < m_r ? (int32_t)stage[lane * 65u + rr] : -1;
+    }
+}
+
 // ---- graph rows -> CSR of ascending ids (EliasFanoNSGGraph ctor, altid_impl.cpp:61-76)
 __global__ void __launch_bounds__(64) k_rows_count(const int32_t *rows, uint64_t N, uint32_t K, uint32_t *counts,
                                                    uint32_t *err) {
@@ -682,10 +721,15 @@ static int ef_decode_some(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uin
         VIDC_HIP(hipMemcpyAsync(s_o.p, h_up.as<uint64_t>() + m, m * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_ef_decode, dim3((uint32_t)std::min<uint64_t>(m, (uint64_t)ctx->num_cu * 64)), dim3(64), 0,
-                       ctx->stream, e->d_low.p, e->d_high.p, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p,
-                       e->d_lbits.p, e->d_batch_off.p, e->d_hrank.p, (uint32_t)m, (const Chunk *)nullptr,
-                       s_l.as<uint64_t>(), out_off_host ? s_o.as<uint64_t>() : nullptr, d_out, d_rows, K);
+    if (d_rows && e->rows && e->K <= 64 && K >= e->K)  // graph rows: one row per lane
+        hipLaunchKernelGGL(k_ef_decode_rows_lane, dim3((uint32_t)((m + 63) / 64)), dim3(64), 0, ctx->stream, e->d_low.p,
+                           e->d_high.p, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p, e->d_lbits.p, m,
+                           s_l.as<uint64_t>(), d_rows, K);
+    else
+        hipLaunchKernelGGL(k_ef_decode, dim3((uint32_t)std::min<uint64_t>(m, (uint64_t)ctx->num_cu * 64)), dim3(64), 0,
+                           ctx->stream, e->d_low.p, e->d_high.p, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p,
+                           e->d_lbits.p, e->d_batch_off.p, e->d_hrank.p, (uint32_t)m, (const Chunk *)nullptr,
+                           s_l.as<uint64_t>(), out_off_host ? s_o.as<uint64_t>() : nullptr, d_out, d_rows, K);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));

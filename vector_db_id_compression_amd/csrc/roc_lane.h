@@ -483,10 +483,11 @@ __global__ void __launch_bounds__(64) k_roc_encode_tiny_lane(RocEncArgs a, const
 }
 
 #define VIDC_TINY_STRIP 84u  // LDS words per lane of the tiny decoder: >= n + 2 + slack for n <= 64, P <= 32
+#define VIDC_TINY_LD 65u     // word w of lane t at buf[w * 65 + t]: conflict-free per lane AND per row (output phase)
 
 template <bool ROWS>
 __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const LaneDiv *__restrict__ dtab) {
-    __shared__ uint32_t buf[VIDC_TINY_STRIP * 64];  // word w of this lane: buf[w * 64 + lane]
+    __shared__ uint32_t buf[VIDC_TINY_STRIP * VIDC_TINY_LD];
     const uint32_t lane = lane_id();
     const uint32_t wi = blockIdx.x * 64u + lane;
     const bool have = wi < a.nwork;
@@ -502,7 +503,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
     {
         const uint32_t wmax = wave_max_u32(Wc);
         for (uint32_t w = 0; w < wmax; w++)
-            if (w < Wc) buf[w * 64 + lane] = orig[w];
+            if (w < Wc) buf[w * VIDC_TINY_LD + lane] = orig[w];
     }
     uint32_t sp = Wc;
     uint32_t draws = have ? a.draws[l] : 0u;
@@ -519,7 +520,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
             return w;
         }
         sp--;
-        return buf[sp * 64 + lane];
+        return buf[sp * VIDC_TINY_LD + lane];
     };
     auto u_pop = [&](uint32_t p) -> uint32_t {  // codec.cpp:78-90
         const uint32_t sym = (uint32_t)head & ((1u << p) - 1u);
@@ -540,19 +541,19 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
             const uint32_t x = (hi << 16) | lo;
             // rank among the i ids decoded so far (strictly smaller, fenwick_tree.h:42-94)
             uint32_t r = 0;
-            const uint32_t *top = buf + (VIDC_TINY_STRIP - 1u) * 64u + lane;
+            const uint32_t *top = buf + (VIDC_TINY_STRIP - 1u) * VIDC_TINY_LD + lane;
             uint32_t e = 0;
             for (; e + 4u <= i; e += 4u) {
-                const uint32_t v0 = top[-(int)(e * 64u)], v1 = top[-(int)((e + 1u) * 64u)],
-                               v2 = top[-(int)((e + 2u) * 64u)], v3 = top[-(int)((e + 3u) * 64u)];
+                const uint32_t v0 = top[-(int)(e * VIDC_TINY_LD)], v1 = top[-(int)((e + 1u) * VIDC_TINY_LD)],
+                               v2 = top[-(int)((e + 2u) * VIDC_TINY_LD)], v3 = top[-(int)((e + 3u) * VIDC_TINY_LD)];
                 r += (uint32_t)(v0 < x) + (uint32_t)(v1 < x) + (uint32_t)(v2 < x) + (uint32_t)(v3 < x);
             }
-            for (; e < i; e++) r += (uint32_t)(top[-(int)(e * 64u)] < x);
+            for (; e < i; e++) r += (uint32_t)(top[-(int)(e * VIDC_TINY_LD)] < x);
             // IDX_push(r, i + 1), codec.cpp:44-63
             {
                 uint64_t h0 = head;
                 if (__builtin_expect((uint32_t)(h0 >> 32) >= lq, 0)) {
-                    if (sp + i + 1u < VIDC_TINY_STRIP) buf[sp * 64 + lane] = (uint32_t)h0; else err |= 1u;
+                    if (sp + i + 1u < VIDC_TINY_STRIP) buf[sp * VIDC_TINY_LD + lane] = (uint32_t)h0; else err |= 1u;
                     sp++;
                     h0 >>= 32;
                 }
@@ -560,20 +561,27 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
                 if (__builtin_expect(l_lt_2p31(h), 0)) h = (uint64_t)pop() | (h << 32);
                 head = h;
             }
-            if (sp + i < VIDC_TINY_STRIP) buf[(VIDC_TINY_STRIP - 1u - i) * 64u + lane] = x; else err |= 1u;
+            if (sp + i < VIDC_TINY_STRIP) buf[(VIDC_TINY_STRIP - 1u - i) * VIDC_TINY_LD + lane] = x; else err |= 1u;
         }
     }
-    // decoded order == sampling order: out[n-1-i] = id of step i (codec.cpp:150)
-    for (uint32_t i = 0; i < nsteps; i++) {
-        if (i < n_eff) {
-            const uint32_t x = buf[(VIDC_TINY_STRIP - 1u - i) * 64u + lane];
-            if (ROWS) a.out_rows[ooff + (n - 1u - i)] = (int32_t)x;
-            else a.out[ooff + (n - 1u - i)] = (uint64_t)x;
+    __syncthreads();
+    // output, one list per iteration so that the stores are contiguous: decoded order == sampling order, the id
+    // of step i goes to position n-1-i (codec.cpp:150); graph rows are padded with -1 (the reference leaves
+    // slots >= n untouched, altid_impl.cpp:153-165)
+    for (uint32_t rr = 0; rr < 64u; rr++) {
+        const uint32_t n_r = rl(n_eff, rr);
+        const uint32_t have_r = rl(have ? 1u : 0u, rr);
+        if (!have_r) break;  // work items fill the lanes from 0
+        const uint64_t o_r = rl64((uint32_t)ooff, (uint32_t)(ooff >> 32), rr);
+        // position p holds the id of step n-1-p, stored at strip word STRIP-1-(n-1-p) = STRIP-n+p
+        if (ROWS) {
+            if (lane < a.K) {
+                const int32_t v = lane < n_r ? (int32_t)buf[(VIDC_TINY_STRIP - n_r + lane) * VIDC_TINY_LD + rr] : -1;
+                a.out_rows[o_r + lane] = v;
+            }
+        } else if (lane < n_r) {
+            a.out[o_r + lane] = (uint64_t)buf[(VIDC_TINY_STRIP - n_r + lane) * VIDC_TINY_LD + rr];
         }
-    }
-    if (ROWS && have) {
-        // pad the row with -1 (the reference leaves slots >= n untouched, altid_impl.cpp:153-165)
-        for (uint32_t e = n; e < a.K; e++) a.out_rows[ooff + e] = -1;
     }
     if (have) {
         const bool clean = (head == VIDC_RANS_L) && (sp == draws - draws0);
