@@ -1,12 +1,32 @@
+# end-of-round evidence run: tests, smoke, default bench, secondary workloads, rocprofv3 kernel stats
 set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r01d
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/r01d/pytest_gpu.txt
-VIDC_FORCE_GENERAL=1 timeout 900 python -m pytest tests/test_gpu_roc.py -m gpu -q 2>&1 | tail -3 > gpurun_out/r01d/pytest_force_general.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r01d/smoke.txt 2>&1
-timeout 600 python bench.py > gpurun_out/r01d/bench.json 2> gpurun_out/r01d/bench.err
+R=${1:-r01e}
+mkdir -p gpurun_out/$R
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/$R/pytest_gpu.txt
+VIDC_FORCE_GENERAL=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_force_general.txt
+VIDC_NO_LANE=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_no_lane.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/$R/smoke.txt 2>&1
+timeout 600 python bench.py > gpurun_out/$R/bench.json 2> gpurun_out/$R/bench.err
+for w in s1_uniform uniform_16m uniform_64m_1k c5 s2_64m s2; do
+  timeout 900 python bench.py --workload $w --no-cpu-baseline --no-extra --steps 5 --warmup 2 2>/dev/null >> gpurun_out/$R/bench_other.jsonl
+done
+for c in packed ef; do for w in s1 uniform_64m_1k; do
+  timeout 600 python bench.py --workload $w --codec $c --no-cpu-baseline --no-extra --steps 10 --warmup 3 2>/dev/null >> gpurun_out/$R/bench_other.jsonl
+done; done
+timeout 600 python tools/bench_graph.py 1000000 2>/dev/null | tail -1 > gpurun_out/$R/bench_graph.json
 export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/r01d/prof -o s1 -- python bench.py --no-cpu-baseline --no-extra > gpurun_out/r01d/bench_prof.json 2> gpurun_out/r01d/prof.err
-ls -R gpurun_out/r01d/prof | head -20
-cat gpurun_out/r01d/pytest_gpu.txt gpurun_out/r01d/pytest_force_general.txt gpurun_out/r01d/smoke.txt
-cat gpurun_out/r01d/bench.json
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/$R/prof_s1 -o s1 -- python bench.py --no-cpu-baseline --no-extra > /dev/null 2> gpurun_out/$R/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/$R/prof_u16 -o u16 -- python bench.py --workload uniform_16m --no-cpu-baseline --no-extra --steps 5 --warmup 2 > /dev/null 2>> gpurun_out/$R/prof.err
+python profiles/extract_rocprof.py gpurun_out/$R/prof_s1/s1_results.db gpurun_out/$R/bench_s1_kernel_stats.csv
+python profiles/extract_rocprof.py gpurun_out/$R/prof_u16/u16_results.db gpurun_out/$R/bench_uniform16m_kernel_stats.csv
+rm -rf gpurun_out/$R/prof_s1 gpurun_out/$R/prof_u16
+cat gpurun_out/$R/pytest_gpu.txt gpurun_out/$R/pytest_force_general.txt gpurun_out/$R/pytest_no_lane.txt gpurun_out/$R/smoke.txt
+python - <<PY
+import json
+for line in open("gpurun_out/$R/bench_other.jsonl"):
+    d = json.loads(line)
+    print(d["config"]["workload"][:60], d["config"]["codec"], round(d["ms_per_step"], 3), "ms/step", {k: round(v, 3) for k, v in d["kernel_ms"].items()}, round(d["value"] / 1e6, 1), "M IDs/s", "frac", round(d["roofline"]["frac"], 5), "bits", round(d["bits_per_id"], 3), d["verified_roundtrip"])
+PY
+cut -c1-900 gpurun_out/$R/bench.json
+cat gpurun_out/$R/bench_graph.json
