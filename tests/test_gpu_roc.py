@@ -225,8 +225,14 @@ def test_save_load_roundtrip(roc, tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# lane-per-list kernels (roc_lane.h): lists of 65..1024 strictly ascending ids
-def test_lane_kernels_boundaries_vs_oracle(roc, oracle):
+# lane-per-list kernels (roc_lane.h): lists of 65..1024 strictly ascending ids, tiny lists, graph rows.  The library
+# only picks them for calls with thousands of lists; VIDC_FORCE_LANE=1 selects them regardless of the batch size.
+@pytest.fixture
+def force_lane(monkeypatch):
+    monkeypatch.setenv("VIDC_FORCE_LANE", "1")
+
+
+def test_lane_kernels_boundaries_vs_oracle(roc, oracle, force_lane):
     """Sizes around every class boundary of the lane-per-list kernels, several universes, one call."""
     rng = np.random.default_rng(77)
     sizes = [65, 66, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 767, 768, 769, 1000, 1023, 1024, 1025, 1100]
@@ -238,7 +244,7 @@ def test_lane_kernels_boundaries_vs_oracle(roc, oracle):
         _check_against_oracle(oracle, r, off, lists, r.perm(), dec)
 
 
-def test_lane_kernels_dense_and_small_precision(roc, oracle):
+def test_lane_kernels_dense_and_small_precision(roc, oracle, force_lane):
     """Dense lists (n close to the universe: tiny precision, many renormalisation pops) and fixed precisions."""
     rng = np.random.default_rng(78)
     lists = [np.sort(rng.choice(m, size=n, replace=False)).astype(np.uint64)
@@ -258,7 +264,7 @@ def test_lane_kernels_dense_and_small_precision(roc, oracle):
             assert np.array_equal(dec[int(off[l]):int(off[l + 1])], e["order"])
 
 
-def test_lane_decoder_hands_back_skewed_lists(roc, oracle):
+def test_lane_decoder_hands_back_skewed_lists(roc, oracle, force_lane):
     """All ids of a list in one 1/64 slice of the universe: the lane decoder's bucket row overflows and the list is
     redone by the wave-per-list kernel (VIDC_ST_RETRY) -- same output."""
     rng = np.random.default_rng(79)
@@ -281,16 +287,31 @@ def test_lane_decoder_hands_back_skewed_lists(roc, oracle):
 
 
 def test_lane_kernels_match_wave_kernels(roc, monkeypatch):
-    """Same streams with and without the lane-per-list kernels (VIDC_NO_LANE test hook) on 3000 ragged lists."""
+    """Same streams from the two kernel families (VIDC_FORCE_LANE / VIDC_NO_LANE test hooks) on 3000 ragged lists,
+    and from the automatic choice on a batch large enough to take the lane kernels by itself."""
     rng = np.random.default_rng(80)
     sizes = rng.integers(0, 1200, 3000)
     off, ids, _ = _random_lists(rng, sizes, nbits=22)
     got = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("VIDC_NO_LANE", mode)
+        monkeypatch.setenv("VIDC_FORCE_LANE", "1" if mode == "0" else "0")
         r = roc.encode(off, ids, want_perm=True)
         info = r.info()
         got[mode] = (info["heads"], info["nwords"], info["mt_draws"], r.all_words(), r.perm(),
                      r.decode_all().cpu().numpy().copy())
     for a, b in zip(got["0"], got["1"]):
         assert np.array_equal(a, b)
+    # automatic policy: 12000 lists of 65..200 ids and 3000 tiny ones -> lane kernels without any hook
+    monkeypatch.delenv("VIDC_FORCE_LANE")
+    sizes = np.concatenate([rng.integers(65, 200, 12000), rng.integers(0, 64, 3000)])
+    off, ids, _ = _random_lists(rng, sizes, nbits=24)
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VIDC_NO_LANE", mode)
+        r = roc.encode(off, ids)
+        info = r.info()
+        got[mode] = (info["heads"], info["nwords"], r.all_words(), r.decode_all().cpu().numpy().copy())
+    for a, b in zip(got["0"], got["1"]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(np.sort(got["0"][3]), np.sort(ids.view(np.int64)))

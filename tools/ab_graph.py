@@ -14,7 +14,7 @@ ctx = _lib.default_context()
 nodes = np.arange(N, dtype=np.uint64)
 res = {}
 for mode in ("1", "0"):
-    os.environ["VIDC_NO_LANE"] = mode
+    os.environ["VIDC_NO_LANE"] = mode; os.environ["VIDC_FORCE_LANE"] = "0" if mode == "1" else "1"
     for rep in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         g = RocLists.encode_rows(rows)

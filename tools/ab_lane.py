@@ -18,7 +18,7 @@ for name in sys.argv[1:] or ["uniform_16m", "c5", "s1"]:
     out = torch.empty(wl["ntotal"], dtype=torch.int64, device="cuda")
     res = {}
     for mode in ("1", "0"):
-        os.environ["VIDC_NO_LANE"] = mode
+        os.environ["VIDC_NO_LANE"] = mode; os.environ["VIDC_FORCE_LANE"] = "0" if mode == "1" else "1"
         for it in range(3):
             torch.cuda.synchronize()
             t0 = time.perf_counter()

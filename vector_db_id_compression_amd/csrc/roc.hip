@@ -67,10 +67,22 @@ constexpr uint32_t U_MIN_LIST = 4097;
 inline uint64_t arena_words_for(uint64_t n) { return n * 37 / 32 + 8; }  // <= P+4 bits of growth per step, P <= 32
 
 static_assert(VIDC_LANE_MAX == VIDC_LANE_TAB, "divisor table size");
-// test hook: VIDC_NO_LANE=1 keeps short lists on the wave-per-list kernels (A/B and parity checks)
-inline bool no_lane() {
+// Kernel family for short lists.  The lane-per-list kernels advance 64 lists per instruction but every list still
+// pays the full per-step latency, so they only win once a call has enough lists to fill the machine with them
+// (measured crossover ~8 000 lists of 65..1024 ids, ~2 000 tiny lists); smaller calls -- e.g. the few hundred lists
+// a search touches -- keep the latency-optimised wave-per-list kernels.  Test hooks: VIDC_NO_LANE=1 (never),
+// VIDC_FORCE_LANE=1 (always); both families produce the same bits.
+constexpr uint64_t LANE_MIN_LISTS = 8192, LANE_MIN_TINY = 2048;
+enum LanePolicy { LANE_NEVER = 0, LANE_AUTO = 1, LANE_ALWAYS = 2 };
+inline LanePolicy lane_policy() {
     const char *e = getenv("VIDC_NO_LANE");
-    return e && e[0] == '1';
+    if (e && e[0] == '1') return LANE_NEVER;
+    e = getenv("VIDC_FORCE_LANE");
+    if (e && e[0] == '1') return LANE_ALWAYS;
+    return LANE_AUTO;
+}
+inline bool lane_wanted(LanePolicy p, uint64_t nlists, uint64_t min_lists) {
+    return p == LANE_ALWAYS || (p == LANE_AUTO && nlists >= min_lists);
 }
 
 // test hook: VIDC_FORCE_GENERAL=1 routes every list through the general (sorted-position / bucket) kernels
@@ -277,7 +289,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     std::vector<uint32_t> wl_tiny, wl_u18, wl_u20, wl_c1, wl_c2, wl_c3, wl_l4, wl_l16;
     const bool want_perm = (flags & VIDC_ROC_WANT_PERM) && !rows;
     const uint64_t ntotal_in = rows ? N * K : (nlist ? offsets[nlist] : 0);
-    const bool f_general = force_general(), use_lane = !f_general && !no_lane();  // getenv once, not per list
+    const bool f_general = force_general();  // getenv once, not per list
+    const LanePolicy lpol = f_general ? LANE_NEVER : lane_policy();
+    bool use_lane = false, use_lane_tiny = false;
     // persistent outputs
     VIDC_TRY(r->d_heads.alloc(nlist, ctx->dpool)); VIDC_TRY(r->d_prec.alloc(nlist, ctx->dpool));
     VIDC_TRY(r->d_nwords.alloc(nlist, ctx->dpool)); VIDC_TRY(r->d_draws.alloc(nlist, ctx->dpool));
@@ -294,6 +308,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         }
         arena_words = roc_arena_at(nullptr, arena_stride, nlist);
         ntiny = nlist;  // every row, in order: no work list array (kernels take l = work item)
+        use_lane_tiny = lane_wanted(lpol, nlist, LANE_MIN_TINY);
         VIDC_TRY(s_sizes.get(ctx, nlist * 4));
     } else {
         if (!offsets) return VIDC_ERR_INVALID;
@@ -356,6 +371,16 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         // The bitmap kernels own a whole CU's LDS (2^20-bit universe): latency-optimal for long lists, but only
         // num_cu lists in flight.  With many lists, short ones go to the high-occupancy kernels.
         const uint64_t u_min = U_MIN_LIST;
+        {
+            uint64_t n_mid = 0, n_tiny = 0;
+            for (uint64_t l = 0; l < nlist; l++) {
+                const uint64_t n = offsets[l + 1] - offsets[l];
+                n_tiny += n <= TINY_MAX;
+                n_mid += n > TINY_MAX && n <= VIDC_LANE_MAX;
+            }
+            use_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
+            use_lane_tiny = lane_wanted(lpol, n_tiny, LANE_MIN_TINY);
+        }
         for (uint64_t l = 0; l < nlist; l++) {
             uint64_t n = offsets[l + 1] - offsets[l];
             if (n <= TINY_MAX) { wl_tiny.push_back((uint32_t)l); continue; }
@@ -476,7 +501,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         if (ntiny) {
             RocEncArgs b = a;
             b.worklist = rows ? nullptr : d_wl; b.nwork = (uint32_t)ntiny;
-            if (use_lane) {  // one list per lane (roc_lane.h)
+            if (use_lane_tiny) {  // one list per lane (roc_lane.h)
                 const dim3 grid((b.nwork + 63u) / 64u);
                 const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
                 if (rows && K <= 32) hipLaunchKernelGGL((k_roc_encode_tiny_lane<32, true>), grid, dim3(64), 0, ctx->aux[2], b, dt);
@@ -583,9 +608,10 @@ struct DecPlan {
     std::vector<uint64_t> scratch_off, slots_off;
     uint64_t scratch_words = 0, slots_words = 0;
     bool lean = false;               // graph rows, lane decoder: item k == request k, no scratch / offset arrays
+    bool tiny_lane = false;          // DC_TINY items run on the lane-per-list kernel
 };
 
-inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane) {
+inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane) {  // (n > TINY_MAX lists: allow_lane = mid-size policy)
     if (n <= TINY_MAX) return DC_TINY;
     if (!f_general && n >= u_min) {
         if (P <= 18) return DC_U18;
@@ -601,20 +627,32 @@ inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general
 void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool rows_flavour, DecPlan &p,
                  bool allow_lane = true) {
     const bool f_general = force_general();
-    allow_lane = allow_lane && !f_general && !no_lane();
+    const LanePolicy lpol = (allow_lane && !f_general) ? lane_policy() : LANE_NEVER;
     p.wl.clear(); p.item.clear(); p.scratch_off.clear(); p.slots_off.clear();
     p.scratch_words = 0; p.slots_words = 0;
     for (int c = 0; c < DC_COUNT; c++) p.count[c] = 0;
-    if (rows_flavour && allow_lane) {
+    p.tiny_lane = false;
+    if (rows_flavour && lane_wanted(lpol, lists.size(), LANE_MIN_TINY)) {
         // graph rows with the lane-per-row decoder: request order, no scratch, implicit output offsets
         p.wl = lists;
         p.count[DC_TINY] = lists.size();
         p.lean = true;
+        p.tiny_lane = true;
         return;
     }
     p.lean = false;
     std::vector<uint32_t> cls[DC_COUNT];
     const uint64_t u_min = U_MIN_LIST;
+    {
+        uint64_t n_mid = 0, n_tiny = 0;
+        for (uint32_t l : lists) {
+            const uint64_t n = r->offsets[l + 1] - r->offsets[l];
+            n_tiny += n <= TINY_MAX;
+            n_mid += n > TINY_MAX && n <= VIDC_LANE_MAX;
+        }
+        allow_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
+        p.tiny_lane = lane_wanted(lpol, rows_flavour ? lists.size() : n_tiny, LANE_MIN_TINY);
+    }
     for (uint32_t i = 0; i < lists.size(); i++) {
         uint32_t l = lists[i];
         uint64_t n = r->offsets[l + 1] - r->offsets[l];
@@ -755,7 +793,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         b.slots_off = d_slots_off ? d_slots_off + base[c] : nullptr;
         switch (c) {
             case DC_TINY:
-                if (!force_general() && !no_lane()) {  // one list per lane (roc_lane.h)
+                if (p.tiny_lane) {  // one list per lane (roc_lane.h)
                     const dim3 grid((b.nwork + 63u) / 64u);
                     const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
                     if (d_out_rows) hipLaunchKernelGGL(k_roc_decode_tiny_lane<true>, grid, dim3(64), 0, st_, b, dt);
@@ -985,7 +1023,7 @@ int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uin
                          int32_t *d_out, uint32_t *counts) {
     if (!ctx || !r || (m && (!nodes || !d_out))) return VIDC_ERR_INVALID;
     if (K == 0 || K > TINY_MAX) { set_error("K=%u unsupported", K); return VIDC_ERR_UNSUPPORTED; }
-    const bool lean = r->rows && K >= r->K && !force_general() && !no_lane();
+    const bool lean = r->rows && K >= r->K && !force_general() && lane_wanted(lane_policy(), m, LANE_MIN_TINY);
     if (!lean) VIDC_TRY(r->prec.size() == r->nlist ? ensure_offsets(r) : ensure_meta(r));
     std::vector<uint32_t> lists(m);
     for (uint64_t i = 0; i < m; i++) {
