@@ -264,3 +264,30 @@ def test_sharded_lists_single_rank_gpu():
     full = sh.codec.decode_all().cpu().numpy()
     for i, l in enumerate(req):
         assert np.array_equal(out[int(roff[i]):int(roff[i + 1])], full[int(off[l]):int(off[l + 1])])
+
+
+@pytest.mark.parametrize("N,K", [(4096, 64), (8193, 32), (5000, 50)])
+def test_graph_codecs_device_side_offsets(N, K, monkeypatch):
+    """Edge counts -> CSR offsets are scanned on the device for the ROC and Elias-Fano graph objects; rows decoded by the
+    lane-per-row kernels (forced) and by the wave-per-row kernels must both give back the neighbour SETS."""
+    from vector_db_id_compression_amd import synth
+    from vector_db_id_compression_amd.codecs import EfLists, RocLists
+
+    rows = synth.make_graph_rows(N, K, seed=N, dmin=1)
+    deg = (rows >= 0).sum(1)
+    nodes = np.arange(N, dtype=np.uint64)
+    want = np.sort(np.where(rows >= 0, rows, np.iinfo(np.int32).max), axis=1)
+    for force in ("1", "0"):
+        monkeypatch.setenv("VIDC_FORCE_LANE", force)
+        monkeypatch.setenv("VIDC_NO_LANE", "0" if force == "1" else "1")
+        for cls in (RocLists, EfLists):
+            g = cls.encode_rows(rows)
+            dec, cnt = g.decode_rows(nodes, K)
+            assert np.array_equal(cnt, deg)
+            got = dec.cpu().numpy()
+            assert ((got >= 0).sum(1) == deg).all()
+            if cls is EfLists or rows.max() & (rows.max() - 1):  # ROC is lossy for a pow-2 max id (SURVEY Q3)
+                assert np.array_equal(np.sort(np.where(got >= 0, got, np.iinfo(np.int32).max), axis=1), want)
+            assert np.array_equal(np.diff(g.offsets.astype(np.int64)), deg)
+            sub, c2 = g.decode_rows(np.array([N - 1, 0, N // 2], dtype=np.uint64), K, want_counts=False)
+            assert c2 is None and np.array_equal(sub.cpu().numpy(), got[[N - 1, 0, N // 2]])

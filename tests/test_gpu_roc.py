@@ -315,3 +315,26 @@ def test_lane_kernels_match_wave_kernels(roc, monkeypatch):
     for a, b in zip(got["0"], got["1"]):
         assert np.array_equal(a, b)
     assert np.array_equal(np.sort(got["0"][3]), np.sort(ids.view(np.int64)))
+
+
+@pytest.mark.parametrize("nlist", [4096, 8192, 12289])
+def test_device_metadata_matches_host_view(roc, nlist):
+    """Word offsets, sizes and totals are computed on the device (exclusive scans over a multiple of the scan tile,
+    a multiple plus one, ...): they must agree with what the per-list metadata says."""
+    rng = np.random.default_rng(nlist)
+    sizes = rng.integers(0, 40, nlist)
+    sizes[rng.integers(0, nlist, 8)] = rng.integers(65, 300, 8)
+    off, ids, lists = _random_lists(rng, sizes, nbits=21)
+    r = roc.encode(off, ids)
+    info = r.info()
+    nw = info["nwords"].astype(np.uint64)
+    assert r.total_words == int(nw.sum())
+    assert r.compressed_bytes == int((8 + 4 * nw[sizes > 0]).sum())  # custom_invlists_impl.cpp:196-206
+    words = r.all_words()
+    woff = np.concatenate([[0], np.cumsum(nw)]).astype(np.int64)
+    for l in (0, 1, nlist // 2, nlist - 2, nlist - 1):
+        assert np.array_equal(r.words(l), words[woff[l]:woff[l + 1]])
+    dec = r.decode_all().cpu().numpy().view(np.uint64)
+    for l in (0, nlist // 3, nlist - 1):
+        assert np.array_equal(np.sort(dec[int(off[l]):int(off[l + 1])]), lists[l])
+    assert r.last_decode_nonclean == 0
