@@ -165,6 +165,31 @@ def main():
                 "kernel_ms": {"encode": ke / steps, "decode": kd / steps}, "bits_per_id": 8.0 * c2,
                 "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "multiset_roundtrip_ok": ok}
 
+    def secondary_graph(N=262144, K=64, steps=3):
+        """BASELINE configs[3] shape (NSG adjacency rows, -1 terminated) through the ROC and Elias-Fano graph codecs."""
+        rows = torch.from_numpy(synth.make_graph_rows(N, K, seed=1044 + rank)).cuda()
+        nodes = np.arange(N, dtype=np.uint64)
+        edges = int((rows >= 0).sum().item())
+        res = {"workload": f"{N} graph nodes x K={K} int32 rows ({edges} edges)"}
+        for name, cls in (("roc", RocLists), ("elias_fano", EfLists)):
+            t_wall = ke = kd = 0.0
+            for it in range(steps + 1):
+                torch.cuda.synchronize()
+                t_a = time.perf_counter()
+                g = cls.encode_rows(rows, ctx=ctx)
+                e_ms = ctx.last_kernel_ms()
+                dec, _ = g.decode_rows(nodes, K, want_counts=False)
+                d_ms = ctx.last_kernel_ms()
+                torch.cuda.synchronize()
+                if it:
+                    t_wall += time.perf_counter() - t_a
+                    ke += e_ms
+                    kd += d_ms
+            ok = bool(((dec >= 0).sum() == edges).item())
+            res[name] = {"edges_per_s": edges * steps / t_wall, "kernel_ms": {"encode": ke / steps, "decode": kd / steps},
+                         "bits_per_edge": 8.0 * g.compressed_bytes / edges, "edge_count_ok": ok}
+        return res
+
     comp_bytes = r.compressed_bytes
     c = comp_bytes / ntotal  # compressed bytes per id
     alg_bytes = (16.0 + 2.0 * c) * ntotal  # SURVEY 8(d): enc 8 B read + c written, dec c read + 8 B written
@@ -205,6 +230,7 @@ def main():
                     "roc_many_equal_lists": secondary("uniform_16m", "roc"),
                     "packed_bits": secondary("uniform_16m", "packed"),
                     "elias_fano": secondary("uniform_16m", "ef"),
+                    "graph_rows": secondary_graph(),
                 }
             except Exception as e:
                 res["extra"] = {"error": str(e)}
