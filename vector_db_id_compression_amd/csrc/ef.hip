@@ -205,6 +205,91 @@ __global__ void __launch_bounds__(64) k_ef_high(const uint64_t *sorted_ids, cons
     }
 }
 
+// ---- single-pass encoder for ascending lists (the normal case: Faiss lists are in add order, graph rows are sorted
+// by k_rows_sorted).  The universe of an ascending list is its last element, so the ids are streamed from HBM once:
+// k_ef_prep_last reads one id per list, k_ef_lowhigh writes both bit streams per chunk and checks the order on the
+// way; any violation raises `unsorted` and the caller redoes the object with the three-pass path below.
+__global__ void k_ef_prep_last(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist, PrepOut *outp) {
+    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x) {
+        const uint64_t n = offsets[l + 1] - offsets[l];
+        outp[l].max_id = n ? ids[offsets[l + 1] - 1] : 0ull;
+        outp[l].unsorted = 0;
+    }
+}
+__global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, const uint64_t *offsets,
+                                                   const uint64_t *low_off, const uint64_t *high_off,
+                                                   const uint32_t *lbits, const uint64_t *universe, const Chunk *chunks,
+                                                   uint64_t nchunks, uint64_t *low, uint64_t *high, uint32_t *unsorted) {
+    __shared__ unsigned long long win[EF_WIN_WORDS];
+    const uint32_t lane = lane_id();
+    for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const Chunk ch = chunks[c];
+        const uint32_t b = lbits[ch.list];
+        const uint64_t off = offsets[ch.list];
+        const uint64_t n = offsets[ch.list + 1] - off;
+        const uint64_t u = universe[ch.list];
+        const uint32_t nc = (uint32_t)(n - ch.start < CHUNK_IDS ? n - ch.start : CHUNK_IDS);
+        const uint64_t *src = sorted_ids + off;
+        unsigned long long *dst = (unsigned long long *)(high + high_off[ch.list]);
+        uint64_t pos[CHUNK_IDS / 64];
+        bool bad = false;
+        uint64_t carry = ch.start ? src[ch.start - 1] : 0ull;  // the id before this chunk (order check)
+#pragma unroll
+        for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
+            const uint32_t i = lane + 64 * r;
+            const uint64_t v = i < nc ? src[ch.start + i] : ~0ull;
+            // predecessor = previous lane's id (lane 0: the last id of the previous 64-group)
+            uint32_t plo = (uint32_t)__shfl_up((int)(uint32_t)v, 1, 64), phi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1, 64);
+            const uint64_t prev = lane ? (((uint64_t)phi << 32) | plo) : carry;
+            carry = rl64((uint32_t)v, (uint32_t)(v >> 32), 63);
+            pos[r] = ~0ull;
+            if (i < nc) {
+                bad |= v > u || prev > v;
+                pos[r] = v > u ? ~0ull : (v >> b) + (ch.start + i);
+            }
+        }
+        if (ballot(bad)) {
+            if (lane == 0) atomicOr(unsorted, 1u);
+            continue;  // the object is rebuilt by the general path
+        }
+        // high stream: positions increase strictly, the chunk covers a contiguous bit range (see k_ef_high)
+        const uint64_t wf = ((src[ch.start] >> b) + ch.start) >> 6;
+        const uint64_t wl = ((src[ch.start + nc - 1] >> b) + (ch.start + nc - 1)) >> 6;
+        for (uint64_t wbase = wf; wbase <= wl; wbase += EF_WIN_WORDS) {
+            win[lane] = 0;
+            win[lane + 64] = 0;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
+                const uint64_t w = pos[r] >> 6;
+                if (pos[r] != ~0ull && w >= wbase && w - wbase < EF_WIN_WORDS)
+                    atomicOr(&win[w - wbase], 1ull << (pos[r] & 63));
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t t = 0; t < 2; t++) {
+                const uint32_t k = lane + 64 * t;
+                const uint64_t w = wbase + k;
+                const unsigned long long v = win[k];
+                if (v && w <= wl) {
+                    if (w == wf || w == wl) atomicOr(&dst[w], v);
+                    else dst[w] = v;
+                }
+            }
+            __syncthreads();
+        }
+        // low stream: one owner lane per 64-bit word (the ids were just read: cache hits)
+        if (b) {
+            const uint64_t keep = (1ull << b) - 1ull;
+            const uint64_t w0 = ((uint64_t)ch.start * b) >> 6, w1 = ((uint64_t)(ch.start + nc) * b + 63) >> 6;
+            const uint32_t m22 = bits_rcp22(b);
+            uint64_t *ldst = low + low_off[ch.list];
+            for (uint64_t w = w0 + lane; w < w1; w += 64)
+                ldst[w] = gather_word_chunk<false>(src, n, ch.start, w0, w, b, m22, keep, ~0ull, nullptr);
+        }
+    }
+}
+
 // select directory: hrank[item] = number of elements whose high bit lies before batch `b` of list `l`
 // = first j with (x_j >> l) + j >= 4096 * b  (positions increase with j: binary search, no scan)
 __global__ void k_ef_hrank(const uint64_t *sorted_ids, const uint64_t *offsets, const uint32_t *lbits,
@@ -492,7 +577,8 @@ int ef_ensure_meta(const vidc_ef *e) {
 }
 
 // the part of the encoder shared by the list and the graph-row entry points: e->d_offsets, nlist, ntotal are set
-int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t flags) {
+// assume_sorted: single-pass encoder; *retry is raised when some list turned out not to be ascending
+int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t flags, bool assume_sorted, bool *retry) {
     const uint64_t nlist = e->nlist;
     const uint32_t nl32 = (uint32_t)nlist;
     double kernel_ms = 0;
@@ -540,8 +626,12 @@ int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t 
     VIDC_HIP(hipMemsetAsync(s_tot.p, 0, sizeof(EfTotals), ctx->stream));
     if (e->nchunks)
         VIDC_TRY(timed([&] {
-            hipLaunchKernelGGL(k_ef_prep, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, e->d_offsets.p, e->d_chunks.p,
-                               e->nchunks, s_prep.as<PrepOut>());
+            if (assume_sorted)
+                hipLaunchKernelGGL(k_ef_prep_last, dim3(lgrid), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
+                                   s_prep.as<PrepOut>());
+            else
+                hipLaunchKernelGGL(k_ef_prep, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, e->d_offsets.p,
+                                   e->d_chunks.p, e->nchunks, s_prep.as<PrepOut>());
         }));
     hipLaunchKernelGGL(k_ef_geom, dim3(lgrid), dim3(256), 0, ctx->stream, e->d_offsets.p, s_prep.as<PrepOut>(), nl32,
                        e->d_lbits.p, e->d_universe.p, s_lw.as<uint32_t>(), s_hw.as<uint32_t>(), s_nb.as<uint32_t>(),
@@ -612,12 +702,27 @@ int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t 
     // pass 3: the two bit streams
     if (e->ntotal) {
         VIDC_HIP(hipMemsetAsync(e->d_low.p, 0, (low_words ? low_words : 1) * 8, ctx->stream));
-        VIDC_TRY(timed([&] {
-            hipLaunchKernelGGL(k_ef_low, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p, e->d_low_off.p,
-                               e->d_lbits.p, e->d_chunks.p, e->nchunks, e->d_low.p);
-            hipLaunchKernelGGL(k_ef_high, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p,
-                               e->d_high_off.p, e->d_lbits.p, e->d_chunks.p, e->nchunks, e->d_high.p);
-        }));
+        if (assume_sorted) {
+            VIDC_HIP(hipMemsetAsync(s_tot.p, 0, sizeof(EfTotals), ctx->stream));
+            VIDC_TRY(timed([&] {
+                hipLaunchKernelGGL(k_ef_lowhigh, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p,
+                                   e->d_low_off.p, e->d_high_off.p, e->d_lbits.p, e->d_universe.p, e->d_chunks.p,
+                                   e->nchunks, e->d_low.p, e->d_high.p, &s_tot.as<EfTotals>()->n_unsorted);
+            }));
+            VIDC_HIP(hipMemcpyAsync(t, s_tot.p, sizeof(EfTotals), hipMemcpyDeviceToHost, ctx->stream));
+            VIDC_HIP(hipStreamSynchronize(ctx->stream));
+            if ((uint32_t)(t[1] & 0xffffffffu)) {
+                *retry = true;
+                return VIDC_OK;
+            }
+        } else {
+            VIDC_TRY(timed([&] {
+                hipLaunchKernelGGL(k_ef_low, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p,
+                                   e->d_low_off.p, e->d_lbits.p, e->d_chunks.p, e->nchunks, e->d_low.p);
+                hipLaunchKernelGGL(k_ef_high, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p,
+                                   e->d_high_off.p, e->d_lbits.p, e->d_chunks.p, e->nchunks, e->d_high.p);
+            }));
+        }
     }
     // select directory
     VIDC_TRY(e->d_batches.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
@@ -664,7 +769,13 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     VIDC_TRY(h_off.get(ctx, (nlist + 1) * 8));
     std::memcpy(h_off.p, e->offsets.data(), (nlist + 1) * 8);
     VIDC_HIP(hipMemcpyAsync(e->d_offsets.p, h_off.p, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    VIDC_TRY(ef_encode_common(ctx, e.get(), d_ids, flags));
+    bool retry = false;
+    VIDC_TRY(ef_encode_common(ctx, e.get(), d_ids, flags, true, &retry));
+    if (retry) {  // some list is not ascending: general three-pass encoder with the sort
+        e->total_bits = 0;
+        e->has_perm = false;
+        VIDC_TRY(ef_encode_common(ctx, e.get(), d_ids, flags, false, &retry));
+    }
     *out = e.release();
     return VIDC_OK;
 }
@@ -802,7 +913,9 @@ int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_
     if (N) hipLaunchKernelGGL(k_rows_sorted, dim3(grid), dim3(64), 0, ctx->stream, d_rows, N, K, e->d_offsets.p,
                               s_ids.as<uint64_t>());
     VIDC_HIP(hipGetLastError());
-    VIDC_TRY(ef_encode_common(ctx, e.get(), s_ids.as<uint64_t>(), 0));
+    bool retry = false;
+    VIDC_TRY(ef_encode_common(ctx, e.get(), s_ids.as<uint64_t>(), 0, true, &retry));
+    if (retry) { set_error("EF rows: internal error (sorted rows reported unsorted)"); return VIDC_ERR_INVALID; }
     *out = e.release();
     return VIDC_OK;
 }
