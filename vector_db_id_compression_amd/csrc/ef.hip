@@ -221,6 +221,7 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
                                                    const uint32_t *lbits, const uint64_t *universe, const Chunk *chunks,
                                                    uint64_t nchunks, uint64_t *low, uint64_t *high, uint32_t *unsorted) {
     __shared__ unsigned long long win[EF_WIN_WORDS];
+    __shared__ unsigned long long img[CHUNK_IDS + 8];  // low words of the chunk (CHUNK_IDS * l / 64 <= CHUNK_IDS)
     const uint32_t lane = lane_id();
     for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const Chunk ch = chunks[c];
@@ -231,30 +232,45 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
         const uint32_t nc = (uint32_t)(n - ch.start < CHUNK_IDS ? n - ch.start : CHUNK_IDS);
         const uint64_t *src = sorted_ids + off;
         unsigned long long *dst = (unsigned long long *)(high + high_off[ch.list]);
-        uint64_t pos[CHUNK_IDS / 64];
-        bool bad = false;
-        uint64_t carry = ch.start ? src[ch.start - 1] : 0ull;  // the id before this chunk (order check)
+        // the chunk's ids: eight independent coalesced loads per lane
+        uint64_t v[CHUNK_IDS / 64];
+        const uint64_t before = ch.start ? src[ch.start - 1] : 0ull;  // the id before this chunk (order check)
 #pragma unroll
         for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
             const uint32_t i = lane + 64 * r;
-            const uint64_t v = i < nc ? src[ch.start + i] : ~0ull;
+            v[r] = i < nc ? src[ch.start + i] : ~0ull;
+        }
+        const uint32_t nlw = (uint32_t)(((uint64_t)nc * b + 63) >> 6);
+        for (uint32_t w = lane; w < nlw + 1u; w += 64) img[w] = 0;
+        uint64_t pos[CHUNK_IDS / 64];
+        bool bad = false;
+        uint64_t carry = before;
+#pragma unroll
+        for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
+            const uint32_t i = lane + 64 * r;
             // predecessor = previous lane's id (lane 0: the last id of the previous 64-group)
-            uint32_t plo = (uint32_t)__shfl_up((int)(uint32_t)v, 1, 64), phi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1, 64);
+            uint32_t plo = (uint32_t)__shfl_up((int)(uint32_t)v[r], 1, 64), phi = (uint32_t)__shfl_up((int)(uint32_t)(v[r] >> 32), 1, 64);
             const uint64_t prev = lane ? (((uint64_t)phi << 32) | plo) : carry;
-            carry = rl64((uint32_t)v, (uint32_t)(v >> 32), 63);
+            carry = rl64((uint32_t)v[r], (uint32_t)(v[r] >> 32), 63);
             pos[r] = ~0ull;
             if (i < nc) {
-                bad |= v > u || prev > v;
-                pos[r] = v > u ? ~0ull : (v >> b) + (ch.start + i);
+                bad |= v[r] > u || prev > v[r];
+                pos[r] = v[r] > u ? ~0ull : (v[r] >> b) + (ch.start + i);
             }
         }
         if (ballot(bad)) {
             if (lane == 0) atomicOr(unsorted, 1u);
+            __syncthreads();
             continue;  // the object is rebuilt by the general path
         }
         // high stream: positions increase strictly, the chunk covers a contiguous bit range (see k_ef_high)
-        const uint64_t wf = ((src[ch.start] >> b) + ch.start) >> 6;
-        const uint64_t wl = ((src[ch.start + nc - 1] >> b) + (ch.start + nc - 1)) >> 6;
+        const uint64_t first = rl64((uint32_t)pos[0], (uint32_t)(pos[0] >> 32), 0);
+        const uint32_t lr = (nc - 1u) >> 6, ll = (nc - 1u) & 63u;  // register / lane holding the last id
+        uint64_t last = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < CHUNK_IDS / 64; r++)
+            if (r == lr) last = rl64((uint32_t)pos[r], (uint32_t)(pos[r] >> 32), ll);
+        const uint64_t wf = first >> 6, wl = last >> 6;
         for (uint64_t wbase = wf; wbase <= wl; wbase += EF_WIN_WORDS) {
             win[lane] = 0;
             win[lane + 64] = 0;
@@ -265,27 +281,35 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
                 if (pos[r] != ~0ull && w >= wbase && w - wbase < EF_WIN_WORDS)
                     atomicOr(&win[w - wbase], 1ull << (pos[r] & 63));
             }
+            if (wbase == wf && b) {  // low stream: OR the l low bits of every id into the LDS image of the chunk's words
+                const uint64_t keep = (1ull << b) - 1ull;
+#pragma unroll
+                for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
+                    const uint32_t i = lane + 64 * r;
+                    if (i < nc) {
+                        const uint64_t x = v[r] & keep;
+                        const uint32_t p = i * b, sh = p & 63u;
+                        atomicOr(&img[p >> 6], x << sh);
+                        if (sh + b > 64u) atomicOr(&img[(p >> 6) + 1u], x >> (64u - sh));
+                    }
+                }
+            }
             __syncthreads();
 #pragma unroll
             for (uint32_t t = 0; t < 2; t++) {
                 const uint32_t k = lane + 64 * t;
                 const uint64_t w = wbase + k;
-                const unsigned long long v = win[k];
-                if (v && w <= wl) {
-                    if (w == wf || w == wl) atomicOr(&dst[w], v);
-                    else dst[w] = v;
+                const unsigned long long hv = win[k];
+                if (hv && w <= wl) {
+                    if (w == wf || w == wl) atomicOr(&dst[w], hv);
+                    else dst[w] = hv;
                 }
             }
+            if (wbase == wf && b) {
+                uint64_t *ldst = low + low_off[ch.list] + (((uint64_t)ch.start * b) >> 6);
+                for (uint32_t w = lane; w < nlw; w += 64) ldst[w] = img[w];
+            }
             __syncthreads();
-        }
-        // low stream: one owner lane per 64-bit word (the ids were just read: cache hits)
-        if (b) {
-            const uint64_t keep = (1ull << b) - 1ull;
-            const uint64_t w0 = ((uint64_t)ch.start * b) >> 6, w1 = ((uint64_t)(ch.start + nc) * b + 63) >> 6;
-            const uint32_t m22 = bits_rcp22(b);
-            uint64_t *ldst = low + low_off[ch.list];
-            for (uint64_t w = w0 + lane; w < w1; w += 64)
-                ldst[w] = gather_word_chunk<false>(src, n, ch.start, w0, w, b, m22, keep, ~0ull, nullptr);
         }
     }
 }
@@ -312,14 +336,19 @@ __global__ void k_ef_hrank(const uint64_t *sorted_ids, const uint64_t *offsets, 
 
 // bulk decode (select_enumerator, elias_fano.hpp:210-261): one wavefront per batch of 64 high words.
 // items == nullptr: work item wi is list `worklist[wi]` (or wi) decoded batch by batch by one wave (used for
-// the graph rows and short selections); otherwise items[wi] = (list, batch) and every batch is independent.
+// short selections); otherwise items[wi] = (list, batch) and every batch is independent.
+// Per batch: lane t popcounts high word t, a prefix scan gives every set bit its rank, the bit positions are
+// TRANSPOSED through LDS (pos[rank]) and the values are then produced rank-major: lane r reads pos[r], the low bits
+// of element r (both words unconditionally, eight elements per lane in flight) and stores out[r] -- every global
+// access is coalesced and independent of the others.
+#define EF_BATCH_BITS 4096u
 __global__ void __launch_bounds__(64) k_ef_decode(const uint64_t *low, const uint64_t *high, const uint64_t *offsets,
                                                   const uint64_t *low_off, const uint64_t *high_off,
                                                   const uint32_t *lbits, const uint64_t *batch_off,
                                                   const uint32_t *hrank, uint32_t nwork, const Chunk *items,
                                                   const uint64_t *worklist, const uint64_t *out_off, uint64_t *out,
                                                   int32_t *out_rows, uint32_t K) {
-    __shared__ uint64_t stage[1024];  // values of one batch, in rank order, for coalesced stores
+    __shared__ uint16_t spos[EF_BATCH_BITS];  // bit position (inside the batch) of the element with in-batch rank r
     const uint32_t lane = lane_id();
     for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
         const uint64_t l = items ? items[wi].list : (worklist ? worklist[wi] : wi);
@@ -331,6 +360,7 @@ __global__ void __launch_bounds__(64) k_ef_decode(const uint64_t *low, const uin
         }
         if (!m) continue;
         const uint32_t b = lbits[l];
+        const uint64_t keep = b ? ((b >= 64 ? 0ull : (1ull << b)) - 1ull) : 0ull;
         const uint64_t *lw = low + low_off[l];
         const uint64_t *hw = high + high_off[l];
         const uint64_t nhw = high_off[l + 1] - high_off[l];
@@ -341,35 +371,46 @@ __global__ void __launch_bounds__(64) k_ef_decode(const uint64_t *low, const uin
             if (done >= m) break;
             const uint64_t wi64 = bt * 64 + lane;
             uint64_t word = wi64 < nhw ? hw[wi64] : 0ull;
-            uint32_t c = popc64(word);
+            const uint32_t c = popc64(word);
             uint32_t incl = c;  // inclusive prefix sum over the 64 lanes
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
                 if (lane >= (uint32_t)o) incl += v;
             }
-            uint64_t rank = done + (incl - c);
-            const uint32_t tot = rl(incl, 63);
-            const bool staged = tot <= 1024u;  // wave-uniform
-            while (word && rank < m) {
+            const uint32_t tot0 = rl(incl, 63);
+            const uint32_t tot = (uint32_t)(done + tot0 <= m ? tot0 : m - done);  // elements of this batch
+            uint32_t r = incl - c;
+            while (word) {  // transpose: position of every set bit, indexed by its rank inside the batch
                 const uint32_t bit = (uint32_t)__builtin_ctzll(word);
                 word &= word - 1;
-                const uint64_t pos = wi64 * 64 + bit;
-                const uint64_t val = ((pos - rank) << b) | read_bits(lw, rank * b, b);
-                if (staged) stage[rank - done] = val;
-                else if (out_rows) out_rows[off + rank] = (int32_t)val;
-                else out[off + rank] = val;
-                rank++;
+                spos[r++] = (uint16_t)(lane * 64u + bit);
             }
-            if (staged) {
-                __syncthreads();
-                const uint64_t cnt = done + tot < m ? tot : m - done;
-                for (uint32_t t = lane; t < cnt; t += 64) {
-                    if (out_rows) out_rows[off + done + t] = (int32_t)stage[t];
-                    else out[off + done + t] = stage[t];
+            __syncthreads();
+            const uint64_t pbase = bt * EF_BATCH_BITS;
+            for (uint32_t r0 = 0; r0 < tot; r0 += 512) {
+                uint64_t a[8], bw[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {  // low bits: both words, unconditionally (a padding word follows)
+                    const uint32_t rr = r0 + lane + 64 * k;
+                    const uint64_t bp = (done + (rr < tot ? rr : 0u)) * b;
+                    a[k] = b ? lw[bp >> 6] : 0ull;
+                    bw[k] = b ? lw[(bp >> 6) + 1] : 0ull;
                 }
-                __syncthreads();
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {
+                    const uint32_t rr = r0 + lane + 64 * k;
+                    if (rr < tot) {
+                        const uint64_t rank = done + rr;
+                        const uint32_t sh = (uint32_t)((rank * b) & 63);
+                        const uint64_t lo = ((a[k] >> sh) | (sh ? bw[k] << (64 - sh) : 0ull)) & keep;
+                        const uint64_t val = ((pbase + spos[rr] - rank) << b) | lo;
+                        if (out_rows) out_rows[off + rank] = (int32_t)val;
+                        else out[off + rank] = val;
+                    }
+                }
             }
+            __syncthreads();
         }
     }
 }
