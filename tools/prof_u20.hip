@@ -13,7 +13,8 @@ int main() {
     std::vector<uint64_t> ids;
     { std::mt19937_64 g(1); std::vector<uint64_t> all(1 << 20); for (size_t i = 0; i < all.size(); i++) all[i] = i;
       std::shuffle(all.begin(), all.end(), g); ids.assign(all.begin(), all.begin() + n); std::sort(ids.begin(), ids.end()); }
-    uint64_t offs[2] = {0, n}, aoff[2] = {0, (uint64_t)n * 35 / 32 + 8};
+    uint64_t offs[2] = {0, n}, aoff[2] = {0, roc_arena_at(nullptr, 0, 0)};
+    aoff[1] = ((uint64_t)n * 37 >> 5) + 9;  // closed-form arena layout (roc_arena_at)
     uint32_t wl[1] = {0}, prec[1] = {20};
     uint64_t *d_ids, *d_off, *d_aoff, *d_heads, *d_prof; uint32_t *d_wl, *d_prec, *d_nw, *d_dr, *d_st, *d_arena, *d_mt;
     CK(hipMalloc(&d_ids, n * 8)); CK(hipMalloc(&d_off, 16)); CK(hipMalloc(&d_aoff, 16)); CK(hipMalloc(&d_heads, 8));
@@ -24,7 +25,7 @@ int main() {
     CK(hipMemcpy(d_prec, prec, 4, hipMemcpyHostToDevice)); CK(hipMemset(d_mt, 0, 4096));
     RocEncArgs a{};
     a.ids = d_ids; a.offsets = d_off; a.worklist = d_wl; a.nwork = 1; a.heads = d_heads; a.prec = d_prec; a.nwords = d_nw;
-    a.draws = d_dr; a.status = d_st; a.arena = d_arena; a.arena_off = d_aoff; a.sid = (uint32_t *)d_prof; a.mt = d_mt;
+    a.draws = d_dr; a.status = d_st; a.arena = d_arena; a.arena_stride = 0; a.sid = (uint32_t *)d_prof; a.mt = d_mt;
     CK(hipFuncSetAttribute((const void *)k_roc_encode_u<20, false>, hipFuncAttributeMaxDynamicSharedMemorySize, UGeom<20>::LDS_BYTES));
     for (int rep = 0; rep < 2; rep++) {
         hipLaunchKernelGGL((k_roc_encode_u<20, false>), dim3(1), dim3(64), UGeom<20>::LDS_BYTES, 0, a);
