@@ -15,6 +15,17 @@
  * vidc_last_error() returns a thread-local message (replaces FAISS_THROW_IF_NOT /
  * FaissException, custom_invlists_impl.cpp:87,420-422 and custom_invlists.swig:38-57).
  * There is NO CPU fallback: without a HIP device vidc_ctx_create fails with VIDC_ERR_NO_DEVICE.
+ *
+ * Residency: compressed objects live on the device, including their per-list metadata (offsets, word counts,
+ * precisions, ...).  Sizes come back as scalars; the *_list_info / *_export_* calls copy the per-list arrays to the
+ * host on first use.  Device memory of objects and scratch comes from a block cache shared by the context and the
+ * objects created through it (steady-state calls neither hipMalloc nor hipFree); objects may be destroyed before
+ * or after their context.
+ *
+ * Environment (test hooks, read per call): VIDC_NO_LANE=1 / VIDC_FORCE_LANE=1 never / always use the
+ * lane-per-list ROC kernels (default: only for calls with thousands of short lists), VIDC_FORCE_GENERAL=1 routes
+ * every list through the general wave-per-list kernels, VIDC_TRACE=1 prints host-side phase times.  The bit
+ * streams do not depend on any of them.
  */
 #ifndef VIDC_H
 #define VIDC_H
@@ -85,7 +96,8 @@ uint64_t vidc_roc_ntotal(const vidc_roc *r);
 /* sum over non-empty lists of 8 + 4*nwords  (ANSState::size(), codec.h:42-44; :196-206) */
 uint64_t vidc_roc_compressed_bytes(const vidc_roc *r);
 uint64_t vidc_roc_total_words(const vidc_roc *r);
-/* host copies of per-list metadata (arrays of nlist): any pointer may be NULL */
+/* host copies of per-list metadata (arrays of nlist): any pointer may be NULL.  The metadata lives on the device;
+ * the first call copies it to the host (blocking). */
 int vidc_roc_list_info(const vidc_roc *r, uint32_t *sizes, uint32_t *precisions, uint64_t *heads,
                        uint32_t *nwords, uint32_t *mt_draws);
 /* stack words of one list, push order (parity export).  cap in words. */
