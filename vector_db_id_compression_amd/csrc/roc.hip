@@ -59,7 +59,7 @@ struct HostTrace {
 };
 
 constexpr uint32_t TINY_MAX = 64;
-constexpr uint32_t GEN_SMALL_MAX = 1024;   // decoder: fb <= 7 -> 512 B of LDS
+constexpr uint32_t GEN_SMALL_MAX = 4096;   // decoder: fb <= 9 -> 2 KiB of LDS (full occupancy)
 // Lists longer than this go to the bitmap kernels (one wave per CU, lowest step latency: they are the critical
 // path); shorter ones cost about the same per step in the general kernels, which keep thousands in flight.
 constexpr uint32_t U_MIN_LIST = 4097;
@@ -599,12 +599,14 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
 }
 
 // ---- decode planning: work items grouped by kernel class, each with private scratch
-enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_GMID, DC_GHUGE, DC_LANE, DC_COUNT };
+// general decoder classes by LDS footprint of the fine prefix rows (2^fb u32, fb = lg(n) - 3): occupancy, not
+// arithmetic, bounds the general decoder when a batch has many mid-size lists
+enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_COUNT };
 
 struct DecPlan {
     std::vector<uint32_t> wl;        // list numbers, grouped by class, longest first inside a class
     std::vector<uint32_t> item;      // index of each work item in the caller's request
-    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<uint64_t> scratch_off, slots_off;
     uint64_t scratch_words = 0, slots_words = 0;
     bool lean = false;               // graph rows, lane decoder: item k == request k, no scratch / offset arrays
@@ -619,6 +621,8 @@ inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general
     }
     if (allow_lane && n <= VIDC_LANE_MAX) return DC_LANE;
     if (n <= GEN_SMALL_MAX) return DC_GSMALL;
+    if (n <= 8192) return DC_G8K;
+    if (n <= 16384) return DC_G16K;
     if (n <= 32768) return DC_GMID;
     return DC_GHUGE;
 }
@@ -782,7 +786,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     auto launch = [&](int c) -> int {
         if (!p.count[c]) return VIDC_OK;
         hipStream_t st_ = ctx->stream;
-        if (c == DC_GMID || c == DC_U18) st_ = ctx->aux[0];
+        if (c == DC_GMID || c == DC_G16K || c == DC_G8K || c == DC_U18) st_ = ctx->aux[0];
         else if (c == DC_GSMALL || c == DC_LANE) st_ = ctx->aux[1];
         else if (c == DC_TINY) st_ = ctx->aux[2];
         RocDecArgs b = a;
@@ -809,11 +813,17 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 hipLaunchKernelGGL(k_roc_decode_u<20>, dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, st_, b);
                 break;
             case DC_GSMALL:
-                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), 128 * 4, st_, b, 128u, VIDC_DEC_CAP);
+                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), 512 * 4, st_, b, 512u, VIDC_DEC_CAP);
                 break;
             case DC_LANE:
                 hipLaunchKernelGGL(k_roc_decode_lane, dim3((b.nwork + 63u) / 64u), dim3(64), 0, st_, b,
                                    (const LaneDiv *)ctx->d_ltab);
+                break;
+            case DC_G8K:
+                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), 1024 * 4, st_, b, 1024u, VIDC_DEC_CAP);
+                break;
+            case DC_G16K:
+                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), 2048 * 4, st_, b, 2048u, VIDC_DEC_CAP);
                 break;
             case DC_GMID:
                 hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), (1u << VIDC_DEC_MAX_FB) * 4, st_, b,
@@ -827,7 +837,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         return VIDC_OK;
     };
     // longest chains first
-    for (int c : {DC_GHUGE, DC_U20, DC_GMID, DC_U18, DC_GSMALL, DC_LANE, DC_TINY}) VIDC_TRY(launch(c));
+    for (int c : {DC_GHUGE, DC_U20, DC_GMID, DC_G16K, DC_G8K, DC_U18, DC_GSMALL, DC_LANE, DC_TINY}) VIDC_TRY(launch(c));
     for (int i = 0; i < 3; i++) {
         VIDC_HIP(hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
         VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
