@@ -178,7 +178,7 @@ def main():
                 t_a = time.perf_counter()
                 g = cls.encode_rows(rows, ctx=ctx)
                 e_ms = ctx.last_kernel_ms()
-                dec, _ = g.decode_rows(nodes, K, want_counts=False)
+                dec, _ = g.decode_rows(None, K, want_counts=False)
                 d_ms = ctx.last_kernel_ms()
                 torch.cuda.synchronize()
                 if it:

@@ -118,7 +118,8 @@ int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out);
 /* Decode m selected lists back to back into d_out; out_offsets (host, m+1) receives the packing. */
 int vidc_roc_decode_lists(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *list_nos,
                           uint64_t *d_out, uint64_t *out_offsets);
-/* Graph flavour: d_out device int32[m*K]; rows padded with -1; counts (host, m) = num edges. */
+/* Graph flavour: d_out device int32[m*K]; rows padded with -1; counts (host, m, may be NULL) = num edges.
+ * nodes == NULL selects nodes 0..m-1 (no index array is built or uploaded). */
 int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *nodes, uint32_t K,
                          int32_t *d_out, uint32_t *counts);
 /* End-state self check of the last decode_all: number of lists whose final ANS state is not the
@@ -172,7 +173,8 @@ int vidc_ef_get(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *lis
 int vidc_ef_perm(vidc_ctx *ctx, const vidc_ef *e, uint32_t *perm_host); /* sort permutation, :324-339 */
 /* EliasFanoNSGGraph (altid_impl.cpp:53-101): rows are counted (-1 terminated), sorted and coded per node. */
 int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_rows, vidc_ef **out);
-/* get_neighbors for m nodes: d_out device int32[m*K] ascending, -1 padded; counts host uint32[m] (may be NULL) */
+/* get_neighbors for m nodes: d_out device int32[m*K] ascending, -1 padded; counts host uint32[m] (may be NULL);
+ * nodes == NULL selects nodes 0..m-1 */
 int vidc_ef_decode_rows(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *nodes, uint32_t K, int32_t *d_out,
                         uint32_t *counts);
 /* decode m selected lists back to back (get_ids per touched list, custom_invlists_impl.cpp:508-525) */

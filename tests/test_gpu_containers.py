@@ -291,3 +291,5 @@ def test_graph_codecs_device_side_offsets(N, K, monkeypatch):
             assert np.array_equal(np.diff(g.offsets.astype(np.int64)), deg)
             sub, c2 = g.decode_rows(np.array([N - 1, 0, N // 2], dtype=np.uint64), K, want_counts=False)
             assert c2 is None and np.array_equal(sub.cpu().numpy(), got[[N - 1, 0, N // 2]])
+            every, c3 = g.decode_rows(None, K)  # nodes == NULL: all rows in order, no index array
+            assert np.array_equal(every.cpu().numpy(), got) and np.array_equal(c3, deg)

@@ -1,0 +1,15 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out/s2p
+W=${1:-s2}
+timeout 900 rocprofv3 --kernel-trace -d gpurun_out/s2p/prof -o s2 -- python bench.py --workload $W --no-cpu-baseline --no-extra --no-verify --steps 2 --warmup 1 > /dev/null 2> gpurun_out/s2p/err.txt
+python - <<'PY'
+import sqlite3, glob, re
+db = sqlite3.connect(glob.glob("gpurun_out/s2p/prof/*results.db")[0])
+cur = db.cursor()
+tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+kd = [t for t in tabs if "kernel_dispatch" in t and "rocpd" in t][0] if any("kernel_dispatch" in t for t in tabs) else None
+print([t for t in tabs if "kernel" in t][:10])
+rows = list(cur.execute("select name, count(*), sum(duration), avg(duration), min(start), max(end) from kernels group by name order by sum(duration) desc")) if "kernels" in tabs else []
+for r in rows[:14]:
+    m = re.search(r"(k_\w+(<[^>]*>)?)", r[0]); print((m.group(1) if m else r[0][:40]).ljust(34), "calls", r[1], "total_ms", round(r[2]/1e6,2), "avg_ms", round(r[3]/1e6,3))
+PY
+rm -rf gpurun_out/s2p/prof

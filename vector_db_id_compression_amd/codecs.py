@@ -187,11 +187,15 @@ class RocLists:
         edge counts on the device (no metadata crosses PCIe)."""
         torch = _torch()
         K = K or self.K
-        nd = np.ascontiguousarray(nodes, dtype=np.uint64)
-        out = torch.empty((max(nd.size, 1), K), dtype=torch.int32, device="cuda")
-        counts = np.zeros(max(nd.size, 1), np.uint32) if want_counts else None
-        check(lib().vidc_roc_decode_rows(self.ctx.h, self.h, nd.size, ptr(nd), K, ptr(out), ptr(counts)))
-        return out[: nd.size], (counts[: nd.size] if want_counts else None)
+        if nodes is None:  # every node, in order: no index array at all
+            nd, m = None, self.nlist
+        else:
+            nd = np.ascontiguousarray(nodes, dtype=np.uint64)
+            m = nd.size
+        out = torch.empty((max(m, 1), K), dtype=torch.int32, device="cuda")
+        counts = np.zeros(max(m, 1), np.uint32) if want_counts else None
+        check(lib().vidc_roc_decode_rows(self.ctx.h, self.h, m, ptr(nd), K, ptr(out), ptr(counts)))
+        return out[:m], (counts[:m] if want_counts else None)
 
     @property
     def last_decode_nonclean(self):
@@ -357,11 +361,15 @@ class EfLists:
         edge counts on the device."""
         torch = _torch()
         K = K or self.K
-        nd = np.ascontiguousarray(nodes, dtype=np.uint64)
-        out = torch.empty((max(nd.size, 1), K), dtype=torch.int32, device="cuda")
-        counts = np.zeros(max(nd.size, 1), np.uint32) if want_counts else None
-        check(lib().vidc_ef_decode_rows(self.ctx.h, self.h, nd.size, ptr(nd), K, ptr(out), ptr(counts)))
-        return out[: nd.size], (counts[: nd.size] if want_counts else None)
+        if nodes is None:  # every node, in order
+            nd, m = None, self._nlist if self._offsets is None else self._offsets.size - 1
+        else:
+            nd = np.ascontiguousarray(nodes, dtype=np.uint64)
+            m = nd.size
+        out = torch.empty((max(m, 1), K), dtype=torch.int32, device="cuda")
+        counts = np.zeros(max(m, 1), np.uint32) if want_counts else None
+        check(lib().vidc_ef_decode_rows(self.ctx.h, self.h, m, ptr(nd), K, ptr(out), ptr(counts)))
+        return out[:m], (counts[:m] if want_counts else None)
 
     def decode_lists(self, list_nos):
         torch = _torch()

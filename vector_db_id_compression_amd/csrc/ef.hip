@@ -864,9 +864,13 @@ static int ef_decode_some(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uin
     Scratch s_l, s_o;
     Pinned h_up;
     VIDC_TRY(h_up.get(ctx, m * 16));
-    VIDC_TRY(s_l.get(ctx, m * 8));
-    std::memcpy(h_up.p, list_nos, m * 8);
-    VIDC_HIP(hipMemcpyAsync(s_l.p, h_up.p, m * 8, hipMemcpyHostToDevice, ctx->stream));
+    const uint64_t *d_l = nullptr;  // list_nos == NULL: lists 0..m-1, no index array
+    if (list_nos) {
+        VIDC_TRY(s_l.get(ctx, m * 8));
+        std::memcpy(h_up.p, list_nos, m * 8);
+        VIDC_HIP(hipMemcpyAsync(s_l.p, h_up.p, m * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_l = s_l.as<uint64_t>();
+    }
     if (out_off_host) {
         VIDC_TRY(s_o.get(ctx, m * 8));
         std::memcpy(h_up.as<uint64_t>() + m, out_off_host, m * 8);
@@ -876,19 +880,19 @@ static int ef_decode_some(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uin
     if (d_rows && e->rows && e->K <= 64 && K >= e->K)  // graph rows: one row per lane
         hipLaunchKernelGGL(k_ef_decode_rows_lane, dim3((uint32_t)((m + 63) / 64)), dim3(64), 0, ctx->stream, e->d_low.p,
                            e->d_high.p, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p, e->d_lbits.p, m,
-                           s_l.as<uint64_t>(), d_rows, K);
+                           d_l, d_rows, K);
     else
         hipLaunchKernelGGL(k_ef_decode, dim3((uint32_t)std::min<uint64_t>(m, (uint64_t)ctx->num_cu * 64)), dim3(64), 0,
                            ctx->stream, e->d_low.p, e->d_high.p, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p,
                            e->d_lbits.p, e->d_batch_off.p, e->d_hrank.p, (uint32_t)m, (const Chunk *)nullptr,
-                           s_l.as<uint64_t>(), out_off_host ? s_o.as<uint64_t>() : nullptr, d_out, d_rows, K);
+                           d_l, out_off_host ? s_o.as<uint64_t>() : nullptr, d_out, d_rows, K);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->last_kernel_ms = ms;
-    if (counts_host) VIDC_TRY(fetch_sizes<uint64_t>(ctx, e->d_offsets.p, s_l.as<uint64_t>(), m, counts_host));
+    if (counts_host) VIDC_TRY(fetch_sizes<uint64_t>(ctx, e->d_offsets.p, d_l, m, counts_host));
     return VIDC_OK;
 }
 
@@ -907,14 +911,16 @@ int vidc_ef_decode_lists(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint
 
 int vidc_ef_decode_rows(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *nodes, uint32_t K, int32_t *d_out,
                         uint32_t *counts) {
-    if (!ctx || !e || (m && (!nodes || !d_out)) || K == 0) return VIDC_ERR_INVALID;
+    if (!ctx || !e || (m && !d_out) || K == 0) return VIDC_ERR_INVALID;
+    if (!nodes && m > e->nlist) { set_error("nodes == NULL selects nodes 0..m-1: m exceeds the node count"); return VIDC_ERR_INVALID; }
     // rows of a graph object never exceed its K; edge counts of the requested nodes are gathered on the device
     const bool lean = e->rows && K >= e->K;
     if (!lean) VIDC_TRY(ef_ensure_offsets(e));
-    for (uint64_t i = 0; i < m; i++) {
-        if (nodes[i] >= e->nlist) { set_error("node out of range"); return VIDC_ERR_INVALID; }
+    for (uint64_t i = 0; i < m && (nodes || !lean); i++) {
+        const uint64_t node = nodes ? nodes[i] : i;
+        if (node >= e->nlist) { set_error("node out of range"); return VIDC_ERR_INVALID; }
         if (lean) continue;
-        uint64_t n = e->offsets[nodes[i] + 1] - e->offsets[nodes[i]];
+        uint64_t n = e->offsets[node + 1] - e->offsets[node];
         if (n > K) { set_error("node has more than K edges"); return VIDC_ERR_INVALID; }
         if (counts) counts[i] = (uint32_t)n;
     }

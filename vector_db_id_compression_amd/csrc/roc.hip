@@ -611,6 +611,7 @@ struct DecPlan {
     uint64_t scratch_words = 0, slots_words = 0;
     bool lean = false;               // graph rows, lane decoder: item k == request k, no scratch / offset arrays
     bool tiny_lane = false;          // DC_TINY items run on the lane-per-list kernel
+    uint64_t implicit = 0;           // lean plan without a work list: items are rows 0..implicit-1
 };
 
 inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane) {  // (n > TINY_MAX lists: allow_lane = mid-size policy)
@@ -717,7 +718,7 @@ namespace {
 int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64_t *out_off_host, uint64_t *d_out,
                 int32_t *d_out_rows, uint32_t K, const struct DecPlanCache *cache = nullptr) {
     VIDC_HIP(hipSetDevice(ctx->device));
-    const size_t nwork = p.wl.size();
+    const size_t nwork = p.implicit ? (size_t)p.implicit : p.wl.size();
     if (nwork == 0) { ctx->last_kernel_ms = 0; return VIDC_OK; }
     HostTrace tr("roc decode");
     Scratch s_wl, s_scr_off, s_slots_off, s_scr, s_slots, s_out_off, s_end, s_status, s_sum;
@@ -726,6 +727,8 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     const uint64_t *d_scr_off = nullptr, *d_slots_off = nullptr;
     if (cache) {
         d_wl = cache->d_wl.p; d_scr_off = cache->d_scratch_off.p; d_slots_off = cache->d_slots_off.p;
+    } else if (p.implicit) {
+        d_wl = nullptr;
     } else {
         // one pinned staging block for everything that goes up: work list | scratch offsets | slot offsets | out offsets
         const size_t n8 = p.lean ? 0 : nwork;
@@ -790,7 +793,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         else if (c == DC_GSMALL || c == DC_LANE) st_ = ctx->aux[1];
         else if (c == DC_TINY) st_ = ctx->aux[2];
         RocDecArgs b = a;
-        b.worklist = d_wl + base[c];
+        b.worklist = d_wl ? d_wl + base[c] : nullptr;
         b.nwork = (uint32_t)p.count[c];
         b.out_off = (out_off_host && !p.lean) ? s_out_off.as<uint64_t>() + base[c] : nullptr;
         b.scratch_off = d_scr_off ? d_scr_off + base[c] : nullptr;
@@ -1031,14 +1034,24 @@ int vidc_roc_decode_lists(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const ui
 
 int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *nodes, uint32_t K,
                          int32_t *d_out, uint32_t *counts) {
-    if (!ctx || !r || (m && (!nodes || !d_out))) return VIDC_ERR_INVALID;
+    if (!ctx || !r || (m && !d_out)) return VIDC_ERR_INVALID;
     if (K == 0 || K > TINY_MAX) { set_error("K=%u unsupported", K); return VIDC_ERR_UNSUPPORTED; }
+    if (!nodes && m > r->nlist) { set_error("nodes == NULL selects nodes 0..m-1: m=%llu > %llu nodes", (unsigned long long)m, (unsigned long long)r->nlist); return VIDC_ERR_INVALID; }
     const bool lean = r->rows && K >= r->K && !force_general() && lane_wanted(lane_policy(), m, LANE_MIN_TINY);
+    if (lean && !nodes) {  // rows 0..m-1 of a graph object: nothing proportional to m is built on or leaves the host
+        DecPlan p;
+        p.lean = true; p.tiny_lane = true; p.implicit = m;
+        p.count[DC_TINY] = m;
+        VIDC_TRY(decode_impl(ctx, r, p, nullptr, nullptr, d_out, K));
+        if (counts) VIDC_TRY(fetch_sizes<uint32_t>(ctx, r->d_offsets.p, (const uint32_t *)nullptr, m, counts));
+        return VIDC_OK;
+    }
     if (!lean) VIDC_TRY(r->prec.size() == r->nlist ? ensure_offsets(r) : ensure_meta(r));
     std::vector<uint32_t> lists(m);
     for (uint64_t i = 0; i < m; i++) {
-        if (nodes[i] >= r->nlist) { set_error("node %llu out of range", (unsigned long long)nodes[i]); return VIDC_ERR_INVALID; }
-        lists[i] = (uint32_t)nodes[i];
+        const uint64_t node = nodes ? nodes[i] : i;
+        if (node >= r->nlist) { set_error("node %llu out of range", (unsigned long long)node); return VIDC_ERR_INVALID; }
+        lists[i] = (uint32_t)node;
         if (!lean) {
             uint64_t n = r->offsets[lists[i] + 1] - r->offsets[lists[i]];
             if (n > K) { set_error("node %u has %llu edges > K=%u", lists[i], (unsigned long long)n, K); return VIDC_ERR_INVALID; }

@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
     const uint32_t lane = lane_id();
     const uint32_t wi = blockIdx.x * 64u + lane;
     const bool have = wi < a.nwork;
-    const uint32_t l = have ? a.worklist[wi] : 0u;
+    const uint32_t l = have ? (a.worklist ? a.worklist[wi] : wi) : 0u;
     const uint32_t n = have ? (uint32_t)(a.offsets[l + 1] - a.offsets[l]) : 0u;
     const uint64_t ooff = have ? (a.out_off ? a.out_off[wi] : (ROWS ? (uint64_t)wi * a.K : a.offsets[l])) : 0ull;
     const uint32_t P = have ? a.prec[l] : 0u;

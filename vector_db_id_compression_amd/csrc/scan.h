@@ -82,7 +82,10 @@ __global__ void k_count_nonzero(const uint32_t *in, uint32_t n, unsigned long lo
 template <typename I>
 __global__ void k_gather_sizes(const uint64_t *offsets, const I *idx, uint64_t m, uint32_t *sizes) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x)
-        sizes[i] = (uint32_t)(offsets[idx[i] + 1] - offsets[idx[i]]);
+    {
+        const uint64_t l = idx ? (uint64_t)idx[i] : i;  // no index array: lists 0..m-1
+        sizes[i] = (uint32_t)(offsets[l + 1] - offsets[l]);
+    }
 }
 // host copy of the sizes of the requested lists, computed on the device (no nlist-sized array crosses PCIe)
 template <typename I>
