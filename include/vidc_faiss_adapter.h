@@ -20,6 +20,7 @@
 #include <faiss/invlists/InvertedLists.h>
 
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "vidc.h"
@@ -57,6 +58,7 @@ struct DeviceLists {
 /* replaces CompressedIDInvertedListsFenwickTree (custom_invlists_impl.cpp:133-223) */
 struct ROCInvertedLists : faiss::ReadOnlyInvertedLists {
     DeviceLists dev;
+    mutable std::mutex ctx_mu;  // a vidc_ctx serves one host thread at a time; Faiss calls get_ids from OpenMP threads
     vidc_roc* roc = nullptr;
     std::vector<std::vector<uint8_t>> codes_all;
     size_t compressed_ids_size_in_bytes = 0, overhead_in_bytes = 0;
@@ -86,6 +88,7 @@ struct ROCInvertedLists : faiss::ReadOnlyInvertedLists {
         size_t n = list_size(l);
         if (n == 0) return nullptr;
         auto* out = new faiss::idx_t[n];
+        std::lock_guard<std::mutex> guard(ctx_mu);
         void* d = nullptr;
         uint64_t off[2], ln = l;
         VIDC_FAISS_CHECK(vidc_dev_alloc(dev.ctx, n * 8, &d));
@@ -101,6 +104,7 @@ struct ROCInvertedLists : faiss::ReadOnlyInvertedLists {
 /* replaces ROCNSGGraph (altid_impl.cpp:103-165) */
 struct ROCNSGGraph : faiss::nsg::Graph<int32_t> {
     vidc_ctx* ctx = nullptr;
+    mutable std::mutex ctx_mu;  // get_neighbors may be called from several search threads
     vidc_roc* roc = nullptr;
     void* d_row = nullptr;
     explicit ROCNSGGraph(const faiss::nsg::Graph<int32_t>& g) : faiss::nsg::Graph<int32_t>(g.data, g.N, g.K) {
@@ -120,6 +124,7 @@ struct ROCNSGGraph : faiss::nsg::Graph<int32_t> {
         vidc_ctx_destroy(ctx);
     }
     size_t get_neighbors(int i, int32_t* neighbors) const override {
+        std::lock_guard<std::mutex> guard(ctx_mu);
         uint64_t node = (uint64_t)i;
         uint32_t count = 0;
         VIDC_FAISS_CHECK(vidc_roc_decode_rows(ctx, roc, 1, &node, K, (int32_t*)d_row, &count));

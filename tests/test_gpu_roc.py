@@ -338,3 +338,44 @@ def test_device_metadata_matches_host_view(roc, nlist):
     for l in (0, nlist // 3, nlist - 1):
         assert np.array_equal(np.sort(dec[int(off[l]):int(off[l + 1])]), lists[l])
     assert r.last_decode_nonclean == 0
+
+
+def test_concurrent_decode_from_two_contexts(roc):
+    """One compressed object decoded by two host threads, each with its own context (the reference calls get_ids
+    from OpenMP threads, custom_invlists_impl.cpp:467,508): lazy host mirrors and the cached decode plan are shared."""
+    import threading
+
+    import torch
+
+    from vector_db_id_compression_amd import _lib
+
+    rng = np.random.default_rng(91)
+    sizes = rng.integers(0, 900, 400)
+    off, ids, lists = _random_lists(rng, sizes, nbits=21)
+    r = roc.encode(off, ids)  # encoded through the default context
+    ctxs = [_lib.Context(0), _lib.Context(0)]
+    outs = [torch.empty(int(off[-1]), dtype=torch.int64, device="cuda") for _ in ctxs]
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                _lib.check(_lib.lib().vidc_roc_decode_all(ctxs[i].h, r.h, _lib.ptr(outs[i])))
+                sel = np.array([3, 7, 399, 3], dtype=np.uint64)
+                tmp = torch.empty(int(sizes[[3, 7, 399, 3]].sum()) + 1, dtype=torch.int64, device="cuda")
+                oo = np.zeros(5, np.uint64)
+                _lib.check(_lib.lib().vidc_roc_decode_lists(ctxs[i].h, r.h, 4, _lib.ptr(sel), _lib.ptr(tmp), _lib.ptr(oo)))
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    torch.cuda.synchronize()
+    a, b = outs[0].cpu().numpy().view(np.uint64), outs[1].cpu().numpy().view(np.uint64)
+    assert np.array_equal(a, b)
+    for l in (0, 5, 399):
+        assert np.array_equal(np.sort(a[int(off[l]):int(off[l + 1])]), lists[l])
+    for c in ctxs:
+        c.close()

@@ -9,6 +9,7 @@
 // bulk decode walks the high words with a wavefront prefix-scan of popcounts.
 #include <algorithm>
 #include <memory>
+#include <mutex>
 #include <numeric>
 
 #include "bits.h"
@@ -32,6 +33,7 @@ struct vidc_ef {
     mutable std::vector<uint64_t> offsets, low_off, high_off, universe, high_nbits;
     mutable std::vector<uint32_t> lbits;
     mutable bool offsets_host = false, meta_host = false;
+    mutable std::mutex mu;  // guards the lazy host mirrors
     DevBuf<uint64_t> d_offsets, d_low_off, d_high_off, d_low, d_high, d_universe;
     DevBuf<uint32_t> d_lbits, d_perm;
     DevBuf<Chunk> d_chunks;
@@ -593,15 +595,20 @@ int ef_mirror(std::vector<T> &dst, const T *d_src, size_t count) {
     if (count) VIDC_HIP(hipMemcpy(dst.data(), d_src, count * sizeof(T), hipMemcpyDeviceToHost));
     return VIDC_OK;
 }
-int ef_ensure_offsets(const vidc_ef *e) {
+int ef_ensure_offsets_locked(const vidc_ef *e) {
     if (e->offsets_host) return VIDC_OK;
     VIDC_HIP(hipSetDevice(e->device));
     VIDC_TRY(ef_mirror(e->offsets, (const uint64_t *)e->d_offsets.p, e->nlist + 1));
     e->offsets_host = true;
     return VIDC_OK;
 }
+int ef_ensure_offsets(const vidc_ef *e) {
+    std::lock_guard<std::mutex> g(e->mu);
+    return ef_ensure_offsets_locked(e);
+}
 int ef_ensure_meta(const vidc_ef *e) {
-    VIDC_TRY(ef_ensure_offsets(e));
+    std::lock_guard<std::mutex> g(e->mu);
+    VIDC_TRY(ef_ensure_offsets_locked(e));
     if (e->meta_host) return VIDC_OK;
     VIDC_HIP(hipSetDevice(e->device));
     VIDC_TRY(ef_mirror(e->low_off, (const uint64_t *)e->d_low_off.p, e->nlist + 1));

@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <numeric>
 
 #include "common.h"
@@ -29,6 +30,7 @@ struct vidc_roc {
     mutable std::vector<uint64_t> heads;
     mutable std::vector<uint64_t> word_off;  // nlist+1
     mutable bool meta_host = false, offsets_host = false;
+    mutable std::mutex mu;  // guards the lazy host mirrors and the cached decode plan (objects are otherwise immutable)
     uint64_t total_words = 0, compressed_bytes = 0;
     // device-resident compressed representation
     DevBuf<uint64_t> d_offsets, d_heads, d_word_off;
@@ -133,15 +135,20 @@ int mirror(std::vector<T> &dst, const T *d_src, size_t count) {
     if (count) VIDC_HIP(hipMemcpy(dst.data(), d_src, count * sizeof(T), hipMemcpyDeviceToHost));
     return VIDC_OK;
 }
-int ensure_offsets(const vidc_roc *r) {
+int ensure_offsets_locked(const vidc_roc *r) {
     if (r->offsets_host) return VIDC_OK;
     VIDC_HIP(hipSetDevice(r->device));
     VIDC_TRY(mirror(r->offsets, (const uint64_t *)r->d_offsets.p, r->nlist + 1));
     r->offsets_host = true;
     return VIDC_OK;
 }
+int ensure_offsets(const vidc_roc *r) {
+    std::lock_guard<std::mutex> g(r->mu);
+    return ensure_offsets_locked(r);
+}
 int ensure_meta(const vidc_roc *r) {
-    VIDC_TRY(ensure_offsets(r));
+    std::lock_guard<std::mutex> g(r->mu);
+    VIDC_TRY(ensure_offsets_locked(r));
     if (r->meta_host) return VIDC_OK;
     VIDC_HIP(hipSetDevice(r->device));
     VIDC_TRY(mirror(r->prec, (const uint32_t *)r->d_prec.p, r->nlist));
@@ -996,7 +1003,12 @@ int vidc_roc_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, cons
 int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out) {
     if (!ctx || !r || (r->ntotal && !d_out)) return VIDC_ERR_INVALID;
     VIDC_TRY(r->prec.size() == r->nlist ? ensure_offsets(r) : ensure_meta(r));
-    if (!r->plan_all) {
+    std::shared_ptr<DecPlanCache> plan;
+    {
+        std::lock_guard<std::mutex> g(r->mu);
+        plan = r->plan_all;
+    }
+    if (!plan) {
         HostTrace tr("roc decode_all");
         std::vector<uint32_t> all(r->nlist);
         std::iota(all.begin(), all.end(), 0u);
@@ -1008,9 +1020,12 @@ int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out) {
         VIDC_TRY(upload(ctx, c->d_scratch_off, c->plan.scratch_off));
         VIDC_TRY(upload(ctx, c->d_slots_off, c->plan.slots_off));
         tr.mark("plan upload");
-        r->plan_all = c;
+        VIDC_HIP(hipStreamSynchronize(ctx->stream));  // another context may use the cached plan next
+        std::lock_guard<std::mutex> g(r->mu);
+        if (!r->plan_all) r->plan_all = c;
+        plan = r->plan_all;
     }
-    return decode_impl(ctx, r, r->plan_all->plan, nullptr, d_out, nullptr, 0, r->plan_all.get());
+    return decode_impl(ctx, r, plan->plan, nullptr, d_out, nullptr, 0, plan.get());
 }
 
 int vidc_roc_decode_lists(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *list_nos,
