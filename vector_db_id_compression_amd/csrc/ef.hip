@@ -54,6 +54,12 @@ struct PrepOut {
     uint32_t unsorted;
     uint32_t pad;
 };
+__host__ __device__ inline int msb64(uint64_t x) { return 63 - __builtin_clzll(x); }
+struct EfTotals {
+    unsigned long long total_bits;
+    unsigned int n_unsorted;
+    unsigned int pad;
+};
 
 // one wavefront per chunk: max id and "is non-decreasing" (merged per list with atomics; outp zero-initialised)
 __global__ void __launch_bounds__(64) k_ef_prep(const uint64_t *ids, const uint64_t *offsets, const Chunk *chunks,
@@ -456,35 +462,111 @@ __global__ void __launch_bounds__(64) k_ef_decode_rows_lane(const uint64_t *low,
     }
 }
 
-// ---- graph rows -> CSR of ascending ids (EliasFanoNSGGraph ctor, altid_impl.cpp:61-76)
-__global__ void __launch_bounds__(64) k_rows_count(const int32_t *rows, uint64_t N, uint32_t K, uint32_t *counts,
-                                                   uint32_t *err) {
-    const uint32_t lane = lane_id();
-    for (uint64_t r = blockIdx.x; r < N; r += gridDim.x) {
-        const int32_t e = lane < K ? rows[r * K + lane] : -1;
-        const uint64_t endm = ballot(e == -1);
-        const uint32_t n = endm ? ff1(endm) : 64u;
-        if (ballot(lane < n && e < 0) && lane == 0) atomicOr(err, 1u);
-        if (lane == 0) counts[r] = n;
-    }
-}
-__global__ void __launch_bounds__(64) k_rows_sorted(const int32_t *rows, uint64_t N, uint32_t K,
-                                                    const uint64_t *offsets, uint64_t *ids) {
-    const uint32_t lane = lane_id();
-    for (uint64_t r = blockIdx.x; r < N; r += gridDim.x) {
-        const uint32_t n = (uint32_t)(offsets[r + 1] - offsets[r]);
-        uint32_t key = lane < n ? (uint32_t)rows[r * K + lane] : 0xffffffffu;
+// ---- graph rows, one row per LANE (EliasFanoNSGGraph ctor, altid_impl.cpp:61-76): the row is read as int32 (no
+// u64 copy of the graph), sorted by the lane's own register network, and both bit streams are written by the lane.
+template <int KP>
+__device__ __forceinline__ uint32_t ef_load_row(const int32_t *rows, uint64_t row, uint32_t K, bool have, uint32_t (&r)[KP],
+                                                bool &bad) {
+    const int32_t *src = rows + row * K;
+    if ((K & 3u) == 0u) {
 #pragma unroll
-        for (uint32_t k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                const uint32_t other = (uint32_t)__shfl_xor((int)key, (int)j, 64);
-                const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
-                const uint32_t mn = key < other ? key : other, mx = key < other ? other : key;
-                key = take_min ? mn : mx;
-            }
+        for (int e = 0; e < KP; e += 4) {
+            int4 v = make_int4(-1, -1, -1, -1);
+            if (have && (uint32_t)e < K) v = *(const int4 *)(src + e);
+            r[e] = (uint32_t)v.x; r[e + 1] = (uint32_t)v.y; r[e + 2] = (uint32_t)v.z; r[e + 3] = (uint32_t)v.w;
         }
-        if (lane < n) ids[offsets[r] + lane] = (uint64_t)key;
+    } else {
+#pragma unroll
+        for (int e = 0; e < KP; e++) r[e] = (have && (uint32_t)e < K) ? (uint32_t)src[e] : 0xffffffffu;
+    }
+    uint32_t n = have ? K : 0u;
+#pragma unroll
+    for (int e = KP - 1; e >= 0; e--) n = (r[e] == 0xffffffffu && (uint32_t)e < n) ? (uint32_t)e : n;
+#pragma unroll
+    for (int e = 0; e < KP; e++) {
+        bad |= (uint32_t)e < n && (int32_t)r[e] < 0;
+        r[e] = (uint32_t)e < n ? r[e] : 0xffffffffu;
+    }
+    return n;
+}
+
+template <int KP>
+__global__ void __launch_bounds__(64) k_ef_rows_geom_lane(const int32_t *rows, uint64_t N, uint32_t K, uint32_t *sizes,
+                                                          uint32_t *lbits, uint64_t *universe, uint32_t *low_words,
+                                                          uint32_t *high_words, uint32_t *nbatch, EfTotals *tot,
+                                                          uint32_t *err) {
+    const uint32_t lane = lane_id();
+    const uint64_t row = (uint64_t)blockIdx.x * 64u + lane;
+    const bool have = row < N;
+    uint32_t r[KP];
+    bool bad = false;
+    const uint32_t n = ef_load_row<KP>(rows, row, K, have, r, bad);
+    uint32_t u = 0;
+#pragma unroll
+    for (int e = 0; e < KP; e++) u = ((uint32_t)e < n && r[e] > u) ? r[e] : u;
+    uint32_t lb = 0, lw = 0, hw = 0;
+    unsigned long long bits = 0;
+    if (n) {  // elias_fano.hpp:28-29; empty rows have no bitstream object
+        lb = (u / n) ? (uint32_t)msb64(u / n) : 0u;
+        const uint32_t hb = (n + 1u) + (u >> lb) + 1u;
+        bits = (unsigned long long)n * lb + hb;
+        lw = (n * lb + 63u) / 64u + 1u;  // +1 padding word for read_bits
+        hw = (hb + 63u) / 64u;
+    }
+    if (have) {
+        sizes[row] = n; lbits[row] = lb; universe[row] = u; low_words[row] = lw; high_words[row] = hw;
+        nbatch[row] = (hw + 63u) / 64u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bits += __shfl_xor(bits, o, 64);
+    if (lane == 0 && bits) atomicAdd(&tot->total_bits, bits);
+    if (ballot(bad) && lane == 0) atomicOr(err, 1u);
+}
+
+template <int KP>
+__global__ void __launch_bounds__(64) k_ef_rows_write_lane(const int32_t *rows, uint64_t N, uint32_t K,
+                                                           const uint32_t *lbits, const uint64_t *low_off,
+                                                           const uint64_t *high_off, uint64_t *low, uint64_t *high) {
+    const uint32_t lane = lane_id();
+    const uint64_t row = (uint64_t)blockIdx.x * 64u + lane;
+    const bool have = row < N;
+    uint32_t r[KP];
+    bool bad = false;
+    const uint32_t n = ef_load_row<KP>(rows, row, K, have, r, bad);
+    lane_bitonic<KP>(r);  // padding (0xffffffff) sorts to the end
+    const uint32_t lb = have ? lbits[row] : 0u;
+    uint64_t *lw = low + (have ? low_off[row] : 0);
+    uint64_t *hw = high + (have ? high_off[row] : 0);
+    // low stream: l bits per element, LSB-first (elias_fano.hpp:40-42); the streams were zeroed beforehand
+    const uint64_t keep = lb ? ((1ull << lb) - 1ull) : 0ull;
+    uint64_t acc = 0, hacc = 0;
+    uint32_t sh = 0, w = 0, hwi = 0;
+#pragma unroll
+    for (int e = 0; e < KP; e++) {
+        if ((uint32_t)e < n) {
+            const uint64_t v = r[e] & keep;
+            acc |= v << sh;
+            if (lb && sh + lb >= 64u) {
+                lw[w++] = acc;
+                acc = sh + lb > 64u ? v >> (64u - sh) : 0ull;
+                sh = sh + lb - 64u;
+            } else {
+                sh += lb;
+            }
+            // high stream: bit (x >> l) + e (elias_fano.hpp:43); positions increase strictly
+            const uint32_t pos = (r[e] >> lb) + (uint32_t)e;
+            const uint32_t pw = pos >> 6;
+            if (pw != hwi) {
+                if (hacc) hw[hwi] = hacc;
+                hacc = 0;
+                hwi = pw;
+            }
+            hacc |= 1ull << (pos & 63u);
+        }
+    }
+    if (n) {
+        if (sh) lw[w] = acc;
+        if (hacc) hw[hwi] = hacc;
     }
 }
 
@@ -533,7 +615,6 @@ __global__ void __launch_bounds__(64) k_ef_get(const uint64_t *low, const uint64
     }
 }
 
-__host__ __device__ inline int msb64(uint64_t x) { return 63 - __builtin_clzll(x); }
 
 // ---- per-list geometry and work-item tables, built on the device
 __global__ void k_ef_count_chunks(const uint64_t *offsets, uint32_t nlist, uint32_t *cnt) {
@@ -548,11 +629,6 @@ __global__ void __launch_bounds__(64) k_fill_items(const uint64_t *item_off, uin
         for (uint64_t c = lane; c < n; c += 64) out[o + c] = Chunk{l, (uint32_t)(c * unit)};
     }
 }
-struct EfTotals {
-    unsigned long long total_bits;
-    unsigned int n_unsorted;
-    unsigned int pad;
-};
 // elias_fano.hpp:28-29 per list; word counts of the two streams and of the select directory
 __global__ void k_ef_geom(const uint64_t *offsets, const PrepOut *prep, uint32_t nlist, uint32_t *lbits,
                           uint64_t *universe, uint32_t *low_words, uint32_t *high_words, uint32_t *nbatch,
@@ -946,30 +1022,85 @@ int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_
     e->nlist = N;
     e->rows = true;
     e->K = K;
-    Scratch s_cnt, s_err, s_ids, s_tmp;
+    const uint32_t n32 = (uint32_t)N;
+    Scratch s_cnt, s_lw, s_hw, s_nb, s_tot, s_t0, s_t1, s_t2, s_t3;
     Pinned tail;
-    VIDC_TRY(tail.get(ctx, 16));
-    VIDC_TRY(s_cnt.get(ctx, (N + 1) * 4));
-    VIDC_TRY(s_err.get(ctx, 4));
+    VIDC_TRY(tail.get(ctx, 64));
+    unsigned long long *t = tail.as<unsigned long long>();
+    VIDC_TRY(s_cnt.get(ctx, (N + 1) * 4)); VIDC_TRY(s_lw.get(ctx, (N + 1) * 4));
+    VIDC_TRY(s_hw.get(ctx, (N + 1) * 4)); VIDC_TRY(s_nb.get(ctx, (N + 1) * 4));
+    VIDC_TRY(s_tot.get(ctx, 32));  // EfTotals + error flag
     VIDC_TRY(e->d_offsets.alloc(N + 1, ctx->dpool));
-    VIDC_HIP(hipMemsetAsync(s_err.p, 0, 4, ctx->stream));
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(N ? N : 1, (uint64_t)ctx->num_cu * 64);
-    // edge counts -> CSR offsets, on the device (altid_impl.cpp:61-76 builds one bit stream per node)
-    if (N) hipLaunchKernelGGL(k_rows_count, dim3(grid), dim3(64), 0, ctx->stream, d_rows, N, K, s_cnt.as<uint32_t>(),
-                              s_err.as<uint32_t>());
-    VIDC_TRY(device_exscan(ctx, s_cnt.as<uint32_t>(), (uint32_t)N, e->d_offsets.p, s_tmp));
-    VIDC_HIP(hipMemcpyAsync(tail.p, e->d_offsets.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipMemcpyAsync(tail.as<uint64_t>() + 1, s_err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_TRY(e->d_low_off.alloc(N + 1, ctx->dpool)); VIDC_TRY(e->d_high_off.alloc(N + 1, ctx->dpool));
+    VIDC_TRY(e->d_batch_off.alloc(N + 1, ctx->dpool));
+    VIDC_TRY(e->d_lbits.alloc(N ? N : 1, ctx->dpool)); VIDC_TRY(e->d_universe.alloc(N ? N : 1, ctx->dpool));
+    VIDC_HIP(hipMemsetAsync(s_tot.p, 0, 32, ctx->stream));
+    double kernel_ms = 0;
+    auto timed = [&](auto &&fn) -> int {
+        VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+        fn();
+        VIDC_HIP(hipGetLastError());
+        VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+        VIDC_HIP(hipEventSynchronize(ctx->ev1));
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+        kernel_ms += ms;
+        return VIDC_OK;
+    };
+    const dim3 lgrid((uint32_t)((N + 63) / 64));
+    EfTotals *d_tot = s_tot.as<EfTotals>();
+    uint32_t *d_err = (uint32_t *)((char *)s_tot.p + 16);
+    // pass 1 (one row per lane): edge count, universe, geometry
+    if (N)
+        VIDC_TRY(timed([&] {
+            if (K <= 32)
+                hipLaunchKernelGGL(k_ef_rows_geom_lane<32>, lgrid, dim3(64), 0, ctx->stream, d_rows, N, K, s_cnt.as<uint32_t>(),
+                                   e->d_lbits.p, e->d_universe.p, s_lw.as<uint32_t>(), s_hw.as<uint32_t>(),
+                                   s_nb.as<uint32_t>(), d_tot, d_err);
+            else
+                hipLaunchKernelGGL(k_ef_rows_geom_lane<64>, lgrid, dim3(64), 0, ctx->stream, d_rows, N, K, s_cnt.as<uint32_t>(),
+                                   e->d_lbits.p, e->d_universe.p, s_lw.as<uint32_t>(), s_hw.as<uint32_t>(),
+                                   s_nb.as<uint32_t>(), d_tot, d_err);
+        }));
+    VIDC_TRY(device_exscan(ctx, s_cnt.as<uint32_t>(), n32, e->d_offsets.p, s_t0));
+    VIDC_TRY(device_exscan(ctx, s_lw.as<uint32_t>(), n32, e->d_low_off.p, s_t1));
+    VIDC_TRY(device_exscan(ctx, s_hw.as<uint32_t>(), n32, e->d_high_off.p, s_t2));
+    VIDC_TRY(device_exscan(ctx, s_nb.as<uint32_t>(), n32, e->d_batch_off.p, s_t3));
+    VIDC_HIP(hipMemcpyAsync(t + 0, e->d_offsets.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(t + 1, e->d_low_off.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(t + 2, e->d_high_off.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(t + 3, e->d_batch_off.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(t + 4, s_tot.p, 32, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
-    if ((uint32_t)tail.as<uint64_t>()[1]) { set_error("EF rows: negative neighbour id before the -1 terminator"); return VIDC_ERR_DOMAIN; }
-    e->ntotal = tail.as<uint64_t>()[0];
-    VIDC_TRY(s_ids.get(ctx, e->ntotal * 8));
-    if (N) hipLaunchKernelGGL(k_rows_sorted, dim3(grid), dim3(64), 0, ctx->stream, d_rows, N, K, e->d_offsets.p,
-                              s_ids.as<uint64_t>());
-    VIDC_HIP(hipGetLastError());
-    bool retry = false;
-    VIDC_TRY(ef_encode_common(ctx, e.get(), s_ids.as<uint64_t>(), 0, true, &retry));
-    if (retry) { set_error("EF rows: internal error (sorted rows reported unsorted)"); return VIDC_ERR_INVALID; }
+    if ((uint32_t)(t[6] & 0xffffffffu)) { set_error("EF rows: negative neighbour id before the -1 terminator"); return VIDC_ERR_DOMAIN; }
+    e->ntotal = t[0];
+    const uint64_t low_words = t[1], high_words = t[2];
+    e->nbatches = t[3];
+    e->total_bits = t[4];
+    VIDC_TRY(e->d_low.alloc(low_words ? low_words : 1, ctx->dpool));
+    VIDC_TRY(e->d_high.alloc(high_words ? high_words : 1, ctx->dpool));
+    VIDC_TRY(e->d_chunks.alloc(1, ctx->dpool));  // chunk table: encoder-only, not needed for rows
+    VIDC_TRY(e->d_batches.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
+    VIDC_TRY(e->d_hrank.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
+    VIDC_HIP(hipMemsetAsync(e->d_low.p, 0, (low_words ? low_words : 1) * 8, ctx->stream));
+    VIDC_HIP(hipMemsetAsync(e->d_high.p, 0, (high_words ? high_words : 1) * 8, ctx->stream));
+    // a row's high stream is a handful of words: one batch per row, no element before it
+    VIDC_HIP(hipMemsetAsync(e->d_hrank.p, 0, (e->nbatches ? e->nbatches : 1) * 4, ctx->stream));
+    if (N)
+        VIDC_TRY(timed([&] {
+            // pass 2 (one row per lane): sort the row in registers, write both streams
+            if (K <= 32)
+                hipLaunchKernelGGL(k_ef_rows_write_lane<32>, lgrid, dim3(64), 0, ctx->stream, d_rows, N, K, e->d_lbits.p,
+                                   e->d_low_off.p, e->d_high_off.p, e->d_low.p, e->d_high.p);
+            else
+                hipLaunchKernelGGL(k_ef_rows_write_lane<64>, lgrid, dim3(64), 0, ctx->stream, d_rows, N, K, e->d_lbits.p,
+                                   e->d_low_off.p, e->d_high_off.p, e->d_low.p, e->d_high.p);
+            if (e->nbatches)
+                hipLaunchKernelGGL(k_fill_items, dim3((uint32_t)std::min<uint64_t>(N, (uint64_t)ctx->num_cu * 64)), dim3(64), 0,
+                                   ctx->stream, e->d_batch_off.p, n32, 1u, e->d_batches.p);
+        }));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->last_kernel_ms = kernel_ms;
     *out = e.release();
     return VIDC_OK;
 }

@@ -343,26 +343,6 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
 //            ids grow down from the end of the same strip), rank = linear scan over the decoded ids
 // No global load sits on the serial chain (the divisor table is copied to LDS), so a step never waits on memory.
 // ===============================================================================================================
-template <int KP>
-__device__ __forceinline__ void lane_bitonic(uint32_t (&r)[KP]) {
-#pragma unroll
-    for (int k = 2; k <= KP; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-#pragma unroll
-            for (int e = 0; e < KP; e++) {
-                const int p = e ^ j;
-                if (p > e) {
-                    const uint32_t lo = r[e] < r[p] ? r[e] : r[p], hi = r[e] < r[p] ? r[p] : r[e];
-                    const bool up = (e & k) == 0;
-                    r[e] = up ? lo : hi;
-                    r[p] = up ? hi : lo;
-                }
-            }
-        }
-    }
-}
-
 template <int KP, bool ROWS>
 __global__ void __launch_bounds__(64) k_roc_encode_tiny_lane(RocEncArgs a, const LaneDiv *__restrict__ dtab) {
     __shared__ uint32_t sid[KP * 64];

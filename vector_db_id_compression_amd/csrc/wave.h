@@ -55,6 +55,28 @@ __device__ __forceinline__ uint32_t prefix4(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
     return v;
 }
+// ascending sort of KP values held in KP registers OF ONE LANE (compile-time bitonic network: every lane sorts its own
+// row, 64 rows per wavefront; KP = 64: 672 min/max pairs)
+template <int KP>
+__device__ __forceinline__ void lane_bitonic(uint32_t (&r)[KP]) {
+#pragma unroll
+    for (int k = 2; k <= KP; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int e = 0; e < KP; e++) {
+                const int p = e ^ j;
+                if (p > e) {
+                    const uint32_t lo = r[e] < r[p] ? r[e] : r[p], hi = r[e] < r[p] ? r[p] : r[e];
+                    const bool up = (e & k) == 0;
+                    r[e] = up ? lo : hi;
+                    r[p] = up ? hi : lo;
+                }
+            }
+        }
+    }
+}
+
 // single-wave workgroup: orders LDS / global accesses between lanes of the wave
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
