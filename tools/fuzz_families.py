@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the ROC kernel families (dev tool, run through gpurun): random batches -- list sizes 0..1500,
+universes 2^7..2^31, dense lists, explicit precisions below / above what the ids need (the reference's carry quirk),
+unsorted lists, duplicates -- encoded and decoded by the lane-per-list kernels (VIDC_FORCE_LANE), the wave-per-list
+kernels (VIDC_NO_LANE) and the general kernels only (VIDC_FORCE_GENERAL); streams, permutations and decoded arrays
+must be identical, and a sample of lists is checked against the CPU oracle."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.pyoracle import Oracle  # noqa: E402  (dev tool: the checker)
+from vector_db_id_compression_amd.codecs import RocLists  # noqa: E402
+
+MODES = {"lane": {"VIDC_FORCE_LANE": "1", "VIDC_NO_LANE": "0", "VIDC_FORCE_GENERAL": "0"},
+         "wave": {"VIDC_FORCE_LANE": "0", "VIDC_NO_LANE": "1", "VIDC_FORCE_GENERAL": "0"},
+         "general": {"VIDC_FORCE_LANE": "0", "VIDC_NO_LANE": "1", "VIDC_FORCE_GENERAL": "1"}}
+
+
+def make_batch(rng):
+    nbits = int(rng.integers(7, 32))
+    nlist = int(rng.integers(1, 200))
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        sizes = rng.integers(0, 70, nlist)
+    elif kind == 1:
+        sizes = rng.integers(60, 1100, nlist)
+    elif kind == 2:
+        sizes = rng.integers(0, 1500, nlist)
+    else:
+        sizes = np.minimum(rng.geometric(0.01, nlist), 5000)
+    sizes = np.minimum(sizes, 1 << nbits)
+    lists = []
+    for s in sizes:
+        s = int(s)
+        if rng.random() < 0.1 and s > 2:  # dense list: nearly the whole universe [0, s + few)
+            li = rng.choice(s + int(rng.integers(1, 4)), size=s, replace=False)
+        elif rng.random() < 0.05 and s > 2:  # duplicates
+            li = rng.integers(0, 1 << nbits, size=s)
+        else:
+            li = rng.choice(1 << nbits, size=s, replace=False) if (1 << nbits) < 4 * max(s, 1) else np.unique(rng.integers(0, 1 << nbits, size=s))
+        li = np.sort(li).astype(np.uint64)
+        if rng.random() < 0.15:
+            rng.shuffle(li)
+        lists.append(li)
+    off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
+    ids = np.concatenate(lists) if lists else np.zeros(0, np.uint64)
+    mode = -1
+    r = rng.random()
+    if r < 0.15:
+        mode = -2
+    elif r < 0.4:
+        mode = int(rng.integers(max(nbits - 3, 0), min(nbits + 3, 32) + 1))
+    return off, ids, lists, mode
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
+    rng = np.random.default_rng(seed)
+    orc = Oracle()
+    t0 = time.time()
+    nb = nl = 0
+    while time.time() - t0 < budget:
+        off, ids, lists, mode = make_batch(rng)
+        want_perm = bool(rng.random() < 0.5)
+        got = {}
+        for name, env in MODES.items():
+            os.environ.update(env)
+            r = RocLists.encode(off, ids, precision_mode=mode, want_perm=want_perm)
+            info = r.info()
+            dec = r.decode_all().cpu().numpy().copy()
+            got[name] = (info["heads"], info["nwords"], info["precision"], info["mt_draws"], r.all_words(), dec,
+                         r.perm() if want_perm else np.zeros(0))
+            nonclean = r.last_decode_nonclean
+        for name in ("wave", "general"):
+            for a, b in zip(got["lane"], got[name]):
+                if not np.array_equal(a, b):
+                    print("MISMATCH lane vs", name, "seed", seed, "batch", nb, "mode", mode, flush=True)
+                    np.savez("gpurun_out/fuzz_fail.npz", off=off, ids=ids, mode=mode)
+                    sys.exit(1)
+        # a few lists against the CPU oracle (stream + what the reference decoder makes of it)
+        heads, nwords, prec, draws, words, dec, _ = got["lane"]
+        woff = np.concatenate([[0], np.cumsum(nwords.astype(np.int64))])
+        for l in rng.choice(len(lists), size=min(6, len(lists)), replace=False):
+            li = lists[int(l)]
+            if li.size == 0:
+                continue
+            P = int(prec[l])
+            e = orc.roc_encode(li, P)
+            assert int(heads[l]) == e["head"], (seed, nb, l)
+            assert np.array_equal(words[woff[l]:woff[l + 1]], e["words"]), (seed, nb, l)
+            ref = orc.roc_decode(e["head"], e["words"], li.size, P, e["mt_draws"])[0]
+            assert np.array_equal(dec[int(off[l]):int(off[l + 1])].view(np.uint64), ref), (seed, nb, l)
+        nb += 1
+        nl += len(lists)
+    print(f"fuzz ok: seed {seed}, {nb} batches, {nl} lists, three kernel families identical, oracle samples identical", flush=True)
+
+
+if __name__ == "__main__":
+    main()
