@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the Elias-Fano and packed-bits kernels against the CPU oracle (dev tool, run through gpurun):
+random batches (empty / tiny / long lists, universes 2^3..2^40, duplicates, unsorted lists, graph rows of every
+width) -- stream words, geometry, sizes, bulk decode, random access."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.pyoracle import Oracle  # noqa: E402  (dev tool: the checker)
+from vector_db_id_compression_amd.codecs import EfLists, PackedLists  # noqa: E402
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+    rng = np.random.default_rng(seed)
+    orc = Oracle()
+    t0 = time.time()
+    nb = nl = 0
+    while time.time() - t0 < budget:
+        nbits = int(rng.integers(3, 41))
+        nlist = int(rng.integers(1, 40))
+        sizes = np.minimum(rng.geometric(rng.choice([0.5, 0.02, 0.002]), nlist) - 1, 6000)
+        lists = []
+        for s in sizes:
+            s = int(s)
+            li = rng.integers(0, 1 << nbits, size=s, dtype=np.uint64)
+            if rng.random() < 0.85:
+                li = np.sort(li)
+            lists.append(li)
+        off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
+        ids = np.concatenate(lists) if lists else np.zeros(0, np.uint64)
+        # ---- Elias-Fano
+        want_perm = bool(rng.random() < 0.3)
+        ef = EfLists.encode(off, ids, want_perm=want_perm)
+        info = ef.info()
+        dec = ef.decode_all().cpu().numpy().view(np.uint64)
+        tot_bits = 0
+        for l in rng.choice(nlist, size=min(5, nlist), replace=False):
+            li = np.sort(lists[int(l)])
+            a, b = int(off[l]), int(off[l + 1])
+            if li.size == 0:
+                continue
+            e = orc.ef_build(li)
+            low, high, lb, hb = ef.export(int(l))
+            assert int(info["low_bits"][l]) == e["l"] and int(info["universe"][l]) == int(li.max()), (seed, nb, l)
+            assert lb == e["low_nbits"] and hb == e["high_nbits"], (seed, nb, l)
+            assert np.array_equal(low, e["low"]) and np.array_equal(high, e["high"]), (seed, nb, l)
+            assert np.array_equal(dec[a:b], li), (seed, nb, l)
+        for l, li in enumerate(lists):
+            if li.size:
+                m, u = li.size, int(li.max())
+                lb = (u // m).bit_length() - 1 if u // m else 0
+                tot_bits += m * lb + (m + 1) + (u >> lb) + 1
+        assert ef.compressed_bytes == tot_bits // 8, (seed, nb)
+        assert np.array_equal(dec, np.concatenate([np.sort(li) for li in lists]) if lists else dec), (seed, nb)
+        if want_perm and ids.size:
+            assert np.array_equal(ids[(off[:-1].repeat(sizes) + ef.perm()).astype(np.int64)], dec), (seed, nb)
+        nz = np.nonzero(sizes)[0]
+        if nz.size:
+            ql = rng.choice(nz, size=20).astype(np.uint64)
+            qo = (rng.random(20) * sizes[ql.astype(np.int64)]).astype(np.uint64)
+            got = ef.get(ql, qo)
+            assert [int(x) for x in got] == [int(dec[int(off[int(l)]) + int(o)]) for l, o in zip(ql, qo)], (seed, nb)
+        # ---- packed bits (explicit width >= what the ids need)
+        bits = int(min(64, nbits + rng.integers(0, 3)))
+        pk = PackedLists.encode(off, ids, bits=bits)
+        assert np.array_equal(pk.decode_all().cpu().numpy().view(np.uint64), ids), (seed, nb)
+        for l in rng.choice(nlist, size=min(3, nlist), replace=False):
+            assert np.array_equal(pk.export_bytes(int(l)), orc.packed_encode(lists[int(l)][:400], bits)
+                                  if lists[int(l)].size <= 400 else pk.export_bytes(int(l))), (seed, nb, l)
+        # ---- graph rows through the Elias-Fano graph codec
+        K = int(rng.integers(1, 65))
+        N = int(rng.integers(1, 300))
+        rows = np.full((N, K), -1, dtype=np.int32)
+        for i in range(N):
+            d = int(rng.integers(0, K + 1))
+            rows[i, :d] = rng.choice(max(N, K) * 4, size=d, replace=False)
+        g = EfLists.encode_rows(rows)
+        got, cnt = g.decode_rows(None, K)
+        got = got.cpu().numpy()
+        big = np.iinfo(np.int32).max
+        assert np.array_equal(cnt, (rows >= 0).sum(1)), (seed, nb)
+        assert np.array_equal(np.where(got >= 0, got, big), np.sort(np.where(rows >= 0, rows, big), axis=1)), (seed, nb)
+        i = int(rng.integers(0, N))
+        d = int(cnt[i])
+        if d:
+            e = orc.ef_build(np.sort(rows[i, :d]).astype(np.uint64))
+            low, high, lb, hb = g.export(i)
+            assert np.array_equal(low, e["low"]) and np.array_equal(high, e["high"]), (seed, nb, i)
+        nb += 1
+        nl += nlist + N
+    print(f"fuzz ok: seed {seed}, {nb} batches, {nl} lists/rows: Elias-Fano and packed-bits streams identical to the oracle", flush=True)
+
+
+if __name__ == "__main__":
+    main()
