@@ -196,6 +196,20 @@ def main():
     kern_s = (k_enc + k_dec) / args.steps / 1e3
     achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
 
+    # HBM-side traffic of one step from the PMC counters: collected offline (rocprofv3 cannot wrap its own caller),
+    # separate FETCH_SIZE / WRITE_SIZE passes of this very command (tools/pmc_s1.sh -> profiles/pmc_traffic_s1.json)
+    traffic = None
+    traffic_note = None
+    if args.codec == "roc" and args.workload == "s1":
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_s1.json")) as f:
+                pt = json.load(f)
+            traffic = 1024.0 * (pt["fetch_KiB_per_step"] + pt["write_KiB_per_step"])
+            traffic_note = ("bytes per step, FETCH_SIZE + WRITE_SIZE summed over the ROC kernels of a step (rocprofv3 --pmc, "
+                            "separate passes, raw counters: gfx950 counts wide coalesced reads at half their bytes)")
+        except Exception:
+            pass
+
     if rank == 0:
         res = {
             "metric": "IDs encoded+decoded / sec (ROC/ANS, bit-exact vs codec.cpp)" if args.codec == "roc"
@@ -218,7 +232,8 @@ def main():
             "verified_roundtrip": verified,
             "kernel_ms": {"encode": k_enc / args.steps, "decode": k_dec / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "algorithmic_bytes_per_step": alg_bytes,
                          "kernels": "k_roc_encode_* + k_roc_compact + k_roc_decode_*" if args.codec == "roc" else args.codec,
                          "algorithmic_bytes_per_id": 16.0 + 2.0 * c},
         }
