@@ -26,3 +26,24 @@ inline std::vector<Chunk> build_chunks(const std::vector<uint64_t> &offsets) {
 }
 
 }  // namespace vidc
+
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+namespace {
+// the same table built on the device (no host array, no PCIe crossing): chunks per list -> exclusive scan (scan.h)
+// -> one wavefront per list fills its items
+__global__ void k_count_chunks(const uint64_t *offsets, uint32_t nlist, uint32_t *cnt) {
+    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x)
+        cnt[l] = (uint32_t)((offsets[l + 1] - offsets[l] + vidc::CHUNK_IDS - 1) / vidc::CHUNK_IDS);
+}
+// items[item_off[l] + c] = (l, c * unit): one wavefront per list
+__global__ void __launch_bounds__(64) k_fill_items(const uint64_t *item_off, uint32_t nlist, uint32_t unit, vidc::Chunk *out) {
+    const uint32_t lane = (threadIdx.x & 63u);
+    for (uint32_t l = blockIdx.x; l < nlist; l += gridDim.x) {
+        const uint64_t o = item_off[l], n = item_off[l + 1] - o;
+        for (uint64_t c = lane; c < n; c += 64) out[o + c] = vidc::Chunk{l, (uint32_t)(c * unit)};
+    }
+}
+}  // namespace
+#endif
+

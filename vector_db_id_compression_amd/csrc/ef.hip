@@ -617,18 +617,6 @@ __global__ void __launch_bounds__(64) k_ef_get(const uint64_t *low, const uint64
 
 
 // ---- per-list geometry and work-item tables, built on the device
-__global__ void k_ef_count_chunks(const uint64_t *offsets, uint32_t nlist, uint32_t *cnt) {
-    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x)
-        cnt[l] = (uint32_t)((offsets[l + 1] - offsets[l] + CHUNK_IDS - 1) / CHUNK_IDS);
-}
-// items[item_off[l] + c] = (l, c * unit): one wavefront per list
-__global__ void __launch_bounds__(64) k_fill_items(const uint64_t *item_off, uint32_t nlist, uint32_t unit, Chunk *out) {
-    const uint32_t lane = lane_id();
-    for (uint32_t l = blockIdx.x; l < nlist; l += gridDim.x) {
-        const uint64_t o = item_off[l], n = item_off[l + 1] - o;
-        for (uint64_t c = lane; c < n; c += 64) out[o + c] = Chunk{l, (uint32_t)(c * unit)};
-    }
-}
 // elias_fano.hpp:28-29 per list; word counts of the two streams and of the select directory
 __global__ void k_ef_geom(const uint64_t *offsets, const PrepOut *prep, uint32_t nlist, uint32_t *lbits,
                           uint64_t *universe, uint32_t *low_words, uint32_t *high_words, uint32_t *nbatch,
@@ -727,7 +715,7 @@ int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t 
     // chunk table (one wavefront of the streaming kernels per 512 ids)
     VIDC_TRY(s_cnt.get(ctx, (nlist + 1) * 4));
     VIDC_TRY(s_coff.get(ctx, (nlist + 1) * 8));
-    hipLaunchKernelGGL(k_ef_count_chunks, dim3(lgrid), dim3(256), 0, ctx->stream, e->d_offsets.p, nl32, s_cnt.as<uint32_t>());
+    hipLaunchKernelGGL(k_count_chunks, dim3(lgrid), dim3(256), 0, ctx->stream, e->d_offsets.p, nl32, s_cnt.as<uint32_t>());
     VIDC_TRY(device_exscan(ctx, s_cnt.as<uint32_t>(), nl32, s_coff.as<uint64_t>(), s_tmp));
     VIDC_HIP(hipMemcpyAsync(t, s_coff.as<uint64_t>() + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));

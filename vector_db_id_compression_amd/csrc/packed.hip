@@ -12,6 +12,7 @@
 #include "bits.h"
 #include "chunks.h"
 #include "common.h"
+#include "scan.h"
 
 using namespace vidc;
 using namespace vidc::dev;
@@ -277,20 +278,34 @@ int vidc_packed_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, c
     }
     p->total_words = p->word_off[nlist];
     if (p->ntotal && !d_ids) return VIDC_ERR_INVALID;
+    // offsets / word offsets through pinned staging; chunk table built on the device
+    Pinned h_up;
+    Scratch s_cnt, s_coff, s_tmp;
+    VIDC_TRY(h_up.get(ctx, (nlist + 1) * 16 + 16));
+    uint64_t *h64 = h_up.as<uint64_t>();
+    std::memcpy(h64, p->offsets.data(), (nlist + 1) * 8);
+    std::memcpy(h64 + nlist + 1, p->word_off.data(), (nlist + 1) * 8);
+    VIDC_TRY(p->d_offsets.alloc(nlist + 1, ctx->dpool));
+    VIDC_TRY(p->d_word_off.alloc(nlist + 1, ctx->dpool));
+    VIDC_TRY(p->d_words.alloc(p->total_words ? p->total_words : 1, ctx->dpool));
+    VIDC_HIP(hipMemcpyAsync(p->d_offsets.p, h64, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(p->d_word_off.p, h64 + nlist + 1, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     {
-        std::vector<Chunk> chunks = build_chunks(p->offsets);
-        p->nchunks = chunks.size();
-        VIDC_TRY(p->d_chunks.alloc(chunks.size() ? chunks.size() : 1));
-        if (!chunks.empty())
-            VIDC_HIP(hipMemcpyAsync(p->d_chunks.p, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice,
-                                    ctx->stream));
-        VIDC_HIP(hipStreamSynchronize(ctx->stream));  // `chunks` is a local host buffer
+        const uint32_t nl32 = (uint32_t)nlist;
+        VIDC_TRY(s_cnt.get(ctx, (nlist + 1) * 4));
+        VIDC_TRY(s_coff.get(ctx, (nlist + 1) * 8));
+        hipLaunchKernelGGL(k_count_chunks, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256 + 1, 2048)), dim3(256), 0,
+                           ctx->stream, p->d_offsets.p, nl32, s_cnt.as<uint32_t>());
+        VIDC_TRY(device_exscan(ctx, s_cnt.as<uint32_t>(), nl32, s_coff.as<uint64_t>(), s_tmp));
+        VIDC_HIP(hipMemcpyAsync(h64 + 2 * nlist + 2, s_coff.as<uint64_t>() + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
+        VIDC_HIP(hipStreamSynchronize(ctx->stream));
+        p->nchunks = h64[2 * nlist + 2];
+        VIDC_TRY(p->d_chunks.alloc(p->nchunks ? p->nchunks : 1, ctx->dpool));
+        if (p->nchunks)
+            hipLaunchKernelGGL(k_fill_items, dim3((uint32_t)std::min<uint64_t>(nlist ? nlist : 1, (uint64_t)ctx->num_cu * 64)),
+                               dim3(64), 0, ctx->stream, s_coff.as<uint64_t>(), nl32, CHUNK_IDS, p->d_chunks.p);
+        VIDC_HIP(hipGetLastError());
     }
-    VIDC_TRY(p->d_offsets.alloc(nlist + 1));
-    VIDC_TRY(p->d_word_off.alloc(nlist + 1));
-    VIDC_TRY(p->d_words.alloc(p->total_words ? p->total_words : 1));
-    VIDC_HIP(hipMemcpyAsync(p->d_offsets.p, p->offsets.data(), (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    VIDC_HIP(hipMemcpyAsync(p->d_word_off.p, p->word_off.data(), (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     Scratch s_err;
     VIDC_TRY(s_err.get(ctx, 4));
     VIDC_HIP(hipMemsetAsync(s_err.p, 0, 4, ctx->stream));
