@@ -150,7 +150,8 @@ void vidc_compact_destroy(vidc_compact *c);
 uint32_t vidc_compact_bits(const vidc_compact *c);
 uint32_t vidc_compact_stride(const vidc_compact *c);
 uint64_t vidc_compact_size_in_bytes(const vidc_compact *c);
-/* get_neighbors for m nodes: d_out device int32[m*K] (-1 padded), counts host uint32[m] (may be NULL) */
+/* get_neighbors for m nodes: d_out device int32[m*K] (-1 padded), counts host uint32[m] (may be NULL);
+ * nodes == NULL selects nodes 0..m-1 */
 int vidc_compact_rows_decode(vidc_ctx *ctx, const vidc_compact *c, uint64_t m, const uint64_t *nodes, int32_t *d_out,
                              uint32_t *counts);
 int vidc_compact_export_row(vidc_ctx *ctx, const vidc_compact *c, uint64_t node, uint8_t *bytes, size_t cap);

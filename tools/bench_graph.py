@@ -19,7 +19,7 @@ for name, cls in [("roc", RocLists), ("elias-fano", EfLists), ("compact", Compac
         g = cls.encode_rows(rows)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         k_enc = ctx.last_kernel_ms()
-        dec, cnt = g.decode_rows(nodes) if name == "compact" else g.decode_rows(None, 64)
+        dec, cnt = g.decode_rows(None, 64)
         torch.cuda.synchronize(); t2 = time.perf_counter()
         k_dec = ctx.last_kernel_ms()
     size = g.compressed_bytes if name != "compact" else g.size_in_bytes

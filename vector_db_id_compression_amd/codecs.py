@@ -431,13 +431,18 @@ class CompactRows:
     def size_in_bytes(self):
         return int(lib().vidc_compact_size_in_bytes(self.h))
 
-    def decode_rows(self, nodes):
+    def decode_rows(self, nodes, K=None, want_counts=True):
+        """nodes=None: every node in order (no index array)."""
         torch = _torch()
-        nd = np.ascontiguousarray(nodes, dtype=np.uint64)
-        out = torch.empty((max(nd.size, 1), self.K), dtype=torch.int32, device="cuda")
-        counts = np.zeros(max(nd.size, 1), np.uint32)
-        check(lib().vidc_compact_rows_decode(self.ctx.h, self.h, nd.size, ptr(nd), ptr(out), ptr(counts)))
-        return out[: nd.size], counts[: nd.size]
+        if nodes is None:
+            nd, m = None, self.N
+        else:
+            nd = np.ascontiguousarray(nodes, dtype=np.uint64)
+            m = nd.size
+        out = torch.empty((max(m, 1), self.K), dtype=torch.int32, device="cuda")
+        counts = np.zeros(max(m, 1), np.uint32) if want_counts else None
+        check(lib().vidc_compact_rows_decode(self.ctx.h, self.h, m, ptr(nd), ptr(out), ptr(counts)))
+        return out[:m], (counts[:m] if want_counts else None)
 
     def export_row(self, node):
         buf = np.zeros(self.stride, np.uint8)

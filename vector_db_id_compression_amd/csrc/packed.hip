@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(64) k_compact_rows_decode(const uint8_t *data,
                                                             int32_t *out, uint32_t *counts) {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint64_t q = blockIdx.x; q < m; q += gridDim.x) {
-        const uint8_t *row = data + nodes[q] * stride;
+        const uint8_t *row = data + (nodes ? nodes[q] : q) * stride;
         uint64_t v = ~0ull;
         if (lane < K) {
             const uint32_t pos = lane * bits;
@@ -192,7 +192,7 @@ int vidc_compact_rows_encode(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_
     c->K = K;
     c->bits = (uint32_t)vidc_packed_bits_for(N);         // while((1 << bits) < N + 1) bits++, altid_impl.cpp:22-23
     c->stride = (K * c->bits + 7) / 8;                   // :24
-    VIDC_TRY(c->d_data.alloc(N * c->stride + 8));
+    VIDC_TRY(c->d_data.alloc(N * c->stride + 8, ctx->dpool));
     Scratch s_err;
     VIDC_TRY(s_err.get(ctx, 4));
     VIDC_HIP(hipMemsetAsync(s_err.p, 0, 4, ctx->stream));
@@ -224,21 +224,31 @@ uint64_t vidc_compact_size_in_bytes(const vidc_compact *c) { return c ? c->N * c
 
 int vidc_compact_rows_decode(vidc_ctx *ctx, const vidc_compact *c, uint64_t m, const uint64_t *nodes, int32_t *d_out,
                              uint32_t *counts) {
-    if (!ctx || !c || (m && (!nodes || !d_out))) return VIDC_ERR_INVALID;
+    if (!ctx || !c || (m && !d_out)) return VIDC_ERR_INVALID;
     if (!m) return VIDC_OK;
-    for (uint64_t i = 0; i < m; i++)
+    if (!nodes && m > c->N) { set_error("nodes == NULL selects nodes 0..m-1: m exceeds the node count"); return VIDC_ERR_INVALID; }
+    for (uint64_t i = 0; nodes && i < m; i++)
         if (nodes[i] >= c->N) { set_error("node %llu out of range", (unsigned long long)nodes[i]); return VIDC_ERR_INVALID; }
     VIDC_HIP(hipSetDevice(ctx->device));
     Scratch s_n, s_c;
-    VIDC_TRY(s_n.get(ctx, m * 8)); VIDC_TRY(s_c.get(ctx, m * 4));
-    VIDC_HIP(hipMemcpyAsync(s_n.p, nodes, m * 8, hipMemcpyHostToDevice, ctx->stream));
+    Pinned h_io;
+    VIDC_TRY(s_c.get(ctx, m * 4));
+    VIDC_TRY(h_io.get(ctx, m * 8));
+    const uint64_t *d_nodes = nullptr;  // nodes == NULL: rows 0..m-1, no index array
+    if (nodes) {
+        VIDC_TRY(s_n.get(ctx, m * 8));
+        std::memcpy(h_io.p, nodes, m * 8);
+        VIDC_HIP(hipMemcpyAsync(s_n.p, h_io.p, m * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_nodes = s_n.as<uint64_t>();
+    }
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(k_compact_rows_decode, dim3((uint32_t)std::min<uint64_t>(m, 1u << 20)), dim3(64), 0, ctx->stream,
-                       c->d_data.p, c->N, c->K, c->bits, c->stride, m, s_n.as<uint64_t>(), d_out, s_c.as<uint32_t>());
+                       c->d_data.p, c->N, c->K, c->bits, c->stride, m, d_nodes, d_out, s_c.as<uint32_t>());
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    if (counts) VIDC_HIP(hipMemcpyAsync(counts, s_c.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (counts) VIDC_HIP(hipMemcpyAsync(h_io.p, s_c.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    if (counts) std::memcpy(counts, h_io.p, m * 4);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->last_kernel_ms = ms;
