@@ -335,3 +335,30 @@ def test_graph_rows_edge_shapes(K, monkeypatch, oracle):
                 e = oracle.roc_encode(ids, P)
                 ref = oracle.roc_decode(e["head"], e["words"], d, P, e["mt_draws"])[0]
                 assert np.array_equal(got[i, :d].astype(np.uint64), ref), (cls.__name__, i)
+
+
+def test_empty_graph_and_list_objects():
+    """Zero nodes / zero lists / all-empty rows through every codec (scan kernels with n = 0, zero-sized streams)."""
+    from vector_db_id_compression_amd.codecs import CompactRows, EfLists, PackedLists, RocLists
+
+    for K in (4, 64):
+        rows0 = np.zeros((0, K), dtype=np.int32)
+        rows_e = np.full((5, K), -1, dtype=np.int32)
+        for cls in (RocLists, EfLists, CompactRows):
+            g = cls.encode_rows(rows_e)  # five nodes without edges
+            got, cnt = g.decode_rows(None, K)
+            assert np.array_equal(cnt, np.zeros(5, np.uint32)) and (got.cpu().numpy() == -1).all(), cls.__name__
+            got, cnt = g.decode_rows(np.array([4, 0], dtype=np.uint64), K)
+            assert (got.cpu().numpy() == -1).all() and got.shape == (2, K)
+            if cls is not CompactRows:
+                assert g.compressed_bytes == 0  # empty lists have no bitstream object (:199-201, :239-241)
+            if cls is RocLists or cls is EfLists:
+                g0 = cls.encode_rows(rows0)
+                got0, cnt0 = g0.decode_rows(None, K)
+                assert got0.shape[0] == 0 and cnt0.size == 0
+    off0 = np.array([0], dtype=np.uint64)
+    for cls in (EfLists, PackedLists):
+        o = cls.encode(off0, np.zeros(0, np.uint64))
+        assert o.compressed_bytes == 0 and o.decode_all().numel() == 0
+        o = cls.encode(np.array([0, 0, 0, 0], dtype=np.uint64), np.zeros(0, np.uint64))
+        assert o.compressed_bytes == 0 and o.decode_all().numel() == 0
