@@ -279,6 +279,26 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
         for (uint32_t r = 0; r < CHUNK_IDS / 64; r++)
             if (r == lr) last = rl64((uint32_t)pos[r], (uint32_t)(pos[r] >> 32), ll);
         const uint64_t wf = first >> 6, wl = last >> 6;
+        // Word ownership instead of global atomics on the two boundary words: a high word belongs to the chunk that
+        // holds its first element.  This chunk skips word wf when the id before the chunk already lies in it, and
+        // adds to word wl the bits of the (at most 63) ids after the chunk that still fall into it.
+        const bool own_first = !(ch.start && (((before >> b) + (ch.start - 1)) >> 6) == wf && before <= u);
+        uint64_t tail_bits = 0;
+        {
+            const uint64_t j = (uint64_t)ch.start + nc + lane;
+            if (j < n) {
+                const uint64_t vn = src[j];
+                const uint64_t pn = (vn >> b) + j;
+                if (vn <= u && (pn >> 6) == wl) tail_bits = 1ull << (pn & 63);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)tail_bits, o, 64);
+                const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(tail_bits >> 32), o, 64);
+                tail_bits |= ((uint64_t)hi << 32) | lo;
+            }
+        }
+        uint32_t *win32 = (uint32_t *)win;  // 32-bit LDS atomics (the 64-bit ones run at half rate)
         for (uint64_t wbase = wf; wbase <= wl; wbase += EF_WIN_WORDS) {
             win[lane] = 0;
             win[lane + 64] = 0;
@@ -287,7 +307,7 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
             for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
                 const uint64_t w = pos[r] >> 6;
                 if (pos[r] != ~0ull && w >= wbase && w - wbase < EF_WIN_WORDS)
-                    atomicOr(&win[w - wbase], 1ull << (pos[r] & 63));
+                    atomicOr(&win32[(uint32_t)(pos[r] - wbase * 64u) >> 5], 1u << (pos[r] & 31));
             }
             if (wbase == wf && b) {  // low stream: OR the l low bits of every id into the LDS image of the chunk's words
                 const uint64_t keep = (1ull << b) - 1ull;
@@ -307,11 +327,9 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
             for (uint32_t t = 0; t < 2; t++) {
                 const uint32_t k = lane + 64 * t;
                 const uint64_t w = wbase + k;
-                const unsigned long long hv = win[k];
-                if (hv && w <= wl) {
-                    if (w == wf || w == wl) atomicOr(&dst[w], hv);
-                    else dst[w] = hv;
-                }
+                unsigned long long hv = win[k];
+                if (w == wl) hv |= tail_bits;
+                if (hv && w <= wl && (w != wf || own_first)) dst[w] = hv;  // (the stream was zeroed: empty words stay)
             }
             if (wbase == wf && b) {
                 uint64_t *ldst = low + low_off[ch.list] + (((uint64_t)ch.start * b) >> 6);
