@@ -242,7 +242,8 @@ __device__ __forceinline__ uint32_t lane_sum_u16_below(uint64_t v, uint32_t t) {
 struct LaneDecGeom {
     static constexpr uint32_t CNT_BYTES = 4 * 64 * 16;  // uint4 cnt[4][64]
     static constexpr uint32_t GRP_BYTES = 64 * 8;       // u64 grp[64]
-    static constexpr uint32_t LDS_BYTES = CNT_BYTES + GRP_BYTES;
+    static constexpr uint32_t RING_BYTES = 8 * 64 * 4;  // u32 oring[8][64]
+    static constexpr uint32_t LDS_BYTES = CNT_BYTES + GRP_BYTES + RING_BYTES;
 };
 
 __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const LaneDiv *__restrict__ dtab) {
@@ -250,6 +251,9 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
     uint4 *cnt4 = (uint4 *)smem;
     unsigned char *cnt1 = smem;
     uint64_t *grp = (uint64_t *)(smem + LaneDecGeom::CNT_BYTES);
+    // decoded ids wait in an 8-deep LDS ring and leave 8 at a time: the 8 stores of a lane hit one or two 64-byte
+    // lines back to back, so a line is completed in L2 instead of being written back to HBM partially up to 8 times
+    uint32_t *oring = (uint32_t *)(smem + LaneDecGeom::CNT_BYTES + LaneDecGeom::GRP_BYTES);
     const uint32_t lane = lane_id();
     const uint32_t wi = blockIdx.x * 64u + lane;
     const bool have = wi < a.nwork;
@@ -324,7 +328,16 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
                 else row[cb] = x;
                 cnt1[(g * 64 + lane) * 16 + j] = (unsigned char)(cb + 1u);
                 grp[lane] = gv + (1ull << (16u * g));
-                a.out[ooff + (n - 1u - i)] = (uint64_t)x;
+                oring[(i & 7u) * 64u + lane] = x;
+            }
+        }
+        if ((i & 7u) == 7u || i + 1u == nsteps) {  // uniform: flush the ring (steps s0 .. i)
+            const uint32_t s0 = i & ~7u;
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) {
+                const uint32_t sstep = s0 + k;
+                // (lists handed back for a retry are rewritten as a whole: whatever they store here is harmless)
+                if (sstep <= i && sstep < n) a.out[ooff + (n - 1u - sstep)] = (uint64_t)oring[k * 64u + lane];
             }
         }
     }
