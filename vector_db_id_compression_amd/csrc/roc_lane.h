@@ -73,8 +73,63 @@ __device__ __forceinline__ uint32_t ls_pop(LStack &s) {  // codec.h:32-40
 }
 __device__ __forceinline__ bool l_lt_2p31(uint64_t v) { return (v >> 31) == 0; }
 
+// Encoder stack of the mid-size lane kernels: pushed words wait in a 32-deep LDS ring per lane and are stored 16 at
+// a time, back to back.  Single 4-byte stores, one every step or two, left every 64-byte arena
+// line partially written for so long that it went to HBM several times (WRITE_SIZE 7x the stream size).
+#define VIDC_PRING 32u
+struct LEStack {
+    uint32_t *mem;   // the list's arena
+    uint32_t *ring;  // LDS: entry e of this lane at ring[e * 64]
+    uint32_t sp, sp_mem, cap, draws, err;  // words [sp_mem, sp) are in the ring
+    const uint32_t *mt;
+};
+__device__ __forceinline__ void ls_push(LEStack &s, uint32_t w) {
+    s.ring[(s.sp & (VIDC_PRING - 1u)) * 64u] = w;
+    s.sp++;
+}
+__device__ __forceinline__ uint32_t ls_pop(LEStack &s) {  // codec.h:32-40 (rare in the encoder)
+    if (s.sp > s.sp_mem) {
+        s.sp--;
+        return s.ring[(s.sp & (VIDC_PRING - 1u)) * 64u];
+    }
+    if (s.sp == 0u) {
+        uint32_t w = 0;
+        if (s.draws < VIDC_MT_TABLE) w = s.mt[s.draws]; else s.err |= 2u;
+        s.draws++;
+        return w;
+    }
+    s.sp--;
+    s.sp_mem = s.sp;
+    return s.mem[s.sp];
+}
+// per lane: once 16 words are pending, store them as one run (a full 64-byte line, or the tails of two)
+__device__ __forceinline__ void le_drain16(LEStack &s) {
+    if (s.sp - s.sp_mem >= 16u) {
+        if (s.sp_mem + 16u <= s.cap) {
+#pragma unroll
+            for (uint32_t j = 0; j < 16u; j++) s.mem[s.sp_mem + j] = s.ring[((s.sp_mem + j) & (VIDC_PRING - 1u)) * 64u];
+        } else {
+            s.err |= 1u;
+        }
+        s.sp_mem += 16u;
+    }
+}
+// wave-uniform call: every lane stores its pending words
+__device__ __forceinline__ void le_flush(LEStack &s) {
+    const uint32_t cnt = s.sp - s.sp_mem;
+    const uint32_t maxc = wave_max_u32(cnt);
+    for (uint32_t j = 0; j < maxc; j++) {
+        if (j < cnt) {
+            const uint32_t idx = s.sp_mem + j;
+            if (idx < s.cap) s.mem[idx] = s.ring[(idx & (VIDC_PRING - 1u)) * 64u]; else s.err |= 1u;
+        }
+    }
+    s.sp_mem = s.sp;
+}
+
 // codec.cpp:65-76
-__device__ __forceinline__ void l_u_push(uint64_t &head, LStack &s, uint32_t start, uint32_t p) {
+template <typename Stack>
+__device__ __forceinline__ void l_u_push(uint64_t &head, Stack &s, uint32_t start, uint32_t p) {
     if ((uint32_t)(head >> 32) >= (0x80000000u >> p)) {
         ls_push(s, (uint32_t)head);
         head >>= 32;
@@ -96,7 +151,8 @@ struct LaneEncGeom {
     static constexpr uint32_t BM_BYTES = NW * 64 * 8;
     static constexpr uint32_t WC_BYTES = (NW / 4) * 64 * 4;
     static constexpr uint32_t GC_BYTES = NW > 4 ? 64 * 8 : 0;
-    static constexpr uint32_t LDS_BYTES = BM_BYTES + WC_BYTES + GC_BYTES;
+    static constexpr uint32_t RING_BYTES = VIDC_PRING * 64 * 4;
+    static constexpr uint32_t LDS_BYTES = BM_BYTES + WC_BYTES + GC_BYTES + RING_BYTES;
 };
 
 template <int NW, bool WANT_PERM>
@@ -139,13 +195,13 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
         gc[lane] = g4;
     }
 
-    LStack st;
+    LEStack st;
     {
         const uint64_t ao = have ? arena_at(a, l) : 0ull;
         st.mem = a.arena + ao;
-        st.orig = st.mem;
+        st.ring = (uint32_t *)(smem + LaneEncGeom<NW>::BM_BYTES + LaneEncGeom<NW>::WC_BYTES + LaneEncGeom<NW>::GC_BYTES) + lane;
         st.cap = have ? (uint32_t)(arena_at(a, l + 1) - ao) : 0u;
-        st.sp = 0; st.dirty = 0; st.draws = 0; st.err = 0; st.mt = a.mt;
+        st.sp = 0; st.sp_mem = 0; st.draws = 0; st.err = 0; st.mt = a.mt;
     }
     uint64_t head = VIDC_RANS_L;
     const uint64_t *ids = a.ids + off;
@@ -209,7 +265,9 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
                 l_u_push(head, st, 0u, 0u);
             }
         }
+        le_drain16(st);  // at most 5 words per step: the ring (32) never overflows
     }
+    le_flush(st);
     if (have) {
         a.heads[l] = head;
         a.nwords[l] = st.sp;
