@@ -142,6 +142,13 @@ int vidc_packed_get(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, const uint6
                     const uint64_t *offs, int64_t *ids_out);
 /* byte image of one list (parity against the reference layout) */
 int vidc_packed_export(vidc_ctx *ctx, const vidc_packed *p, uint64_t list_no, uint8_t *bytes, size_t cap);
+/* Flat image {offsets, bits, words} for saving / shipping an object without re-encoding (the reference keeps compressed
+ * lists in memory only): words = the device layout, every list starts on a 64-bit word and is followed by one padding
+ * word. */
+uint64_t vidc_packed_total_words(const vidc_packed *p);
+int vidc_packed_export_all(vidc_ctx *ctx, const vidc_packed *p, uint64_t *words, size_t cap);
+int vidc_packed_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, int bits, const uint64_t *words,
+                       uint64_t nwords, vidc_packed **out);
 
 /* CompactBitNSGGraph (altid_impl.cpp:20-51): N rows of K int32 (-1 terminated) -> N * stride bytes, sentinel N. */
 typedef struct vidc_compact vidc_compact;
@@ -184,6 +191,13 @@ int vidc_ef_decode_lists(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint
 /* word images of one list's low / high streams (64-bit words, LSB-first) */
 int vidc_ef_export(vidc_ctx *ctx, const vidc_ef *e, uint64_t list_no, uint64_t *low, size_t low_cap,
                    uint64_t *high, size_t high_cap, uint64_t *low_nbits, uint64_t *high_nbits);
+/* Flat image {offsets, l[], universe[], low[], high[]}: stream offsets follow from (count, l, universe) per list
+ * (elias_fano.hpp:28-29); the select directory is rebuilt from the high stream on import. */
+int vidc_ef_stream_words(const vidc_ef *e, uint64_t *low_words, uint64_t *high_words);
+int vidc_ef_export_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *low, size_t low_cap, uint64_t *high, size_t high_cap);
+int vidc_ef_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint32_t *lbits,
+                   const uint64_t *universe, const uint64_t *low, uint64_t n_low, const uint64_t *high, uint64_t n_high,
+                   vidc_ef **out);
 
 /* ------------------------------------------------------------ wavelet tree */
 /* Replaces CompressedIDInvertedListsWaveletTree (custom_invlists_impl.cpp:346-397): one tree over the

@@ -131,3 +131,45 @@ def test_full_size_properties():
     assert 10.7 < 8.0 * ef.compressed_bytes / ids.size < 11.0  # 10.844 bit/id
     pk = PackedLists.encode(off, ids)
     assert pk.bits == 20 and np.array_equal(pk.decode_all().cpu().numpy().view(np.uint64), ids)
+
+
+def test_save_load_roundtrip(tmp_path):
+    """Flat images of Elias-Fano / packed-bits objects (lists and graph rows): load rebuilds an object that decodes,
+    selects and reports sizes exactly like the original (the select directory is rebuilt from the high stream)."""
+    from vector_db_id_compression_amd import synth
+    from vector_db_id_compression_amd.codecs import EfLists, PackedLists
+
+    rng = np.random.default_rng(5)
+    sizes = [0, 1, 3, 64, 65, 700, 0, 9000, 4097, 2]
+    off, ids, lists = _lists(rng, sizes, nbits=26)
+    ef = EfLists.encode(off, ids)
+    ef.save(tmp_path / "ef.npz")
+    ef2 = EfLists.load(tmp_path / "ef.npz")
+    assert ef2.compressed_bytes == ef.compressed_bytes
+    assert np.array_equal(ef2.decode_all().cpu().numpy(), ef.decode_all().cpu().numpy())
+    ql = np.array([3, 7, 7, 8, 1, 9], dtype=np.uint64)
+    qo = np.array([63, 0, 8999, 4096, 0, 1], dtype=np.uint64)
+    assert np.array_equal(ef2.get(ql, qo), ef.get(ql, qo))
+    d, o = ef2.decode_lists(np.array([7, 4, 7], dtype=np.uint64))
+    assert np.array_equal(d.cpu().numpy().view(np.uint64)[: sizes[7]], np.sort(lists[7]))
+    for l in (3, 7):
+        for a, b in zip(ef.export(l), ef2.export(l)):
+            assert np.array_equal(a, b)
+
+    rows = synth.make_graph_rows(3000, 32, seed=9, dmin=0)
+    g = EfLists.encode_rows(rows)
+    g.save(tmp_path / "efg.npz")
+    g2 = EfLists.load(tmp_path / "efg.npz")
+    a, ca = g.decode_rows(None, 32)
+    b, cb = g2.decode_rows(None, 32)
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy()) and np.array_equal(ca, cb)
+
+    perm = rng.permutation(int(off[-1])).astype(np.uint64)
+    pk = PackedLists.encode(off, perm)
+    pk.save(tmp_path / "pk.npz")
+    pk2 = PackedLists.load(tmp_path / "pk.npz")
+    assert pk2.bits == pk.bits and pk2.compressed_bytes == pk.compressed_bytes
+    assert np.array_equal(pk2.decode_all().cpu().numpy().view(np.uint64), perm)
+    assert np.array_equal(pk2.get(ql, qo), pk.get(ql, qo))
+    for l in (3, 7, 9):
+        assert np.array_equal(pk2.export_bytes(l), pk.export_bytes(l))

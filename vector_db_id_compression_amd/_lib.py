@@ -77,6 +77,9 @@ def _declare(lib):
     f("vidc_packed_decode_all", C.c_int, _vp, _vp, _vp)
     f("vidc_packed_get", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
     f("vidc_packed_export", C.c_int, _vp, _vp, _u64, _vp, C.c_size_t)
+    f("vidc_packed_total_words", _u64, _vp)
+    f("vidc_packed_export_all", C.c_int, _vp, _vp, _vp, C.c_size_t)
+    f("vidc_packed_import", C.c_int, _vp, _u64, _vp, C.c_int, _vp, _u64, _P(_vp))
     # Elias-Fano
     f("vidc_ef_encode", C.c_int, _vp, _u64, _vp, _vp, _u32, _P(_vp))
     f("vidc_ef_destroy", None, _vp)
@@ -86,6 +89,9 @@ def _declare(lib):
     f("vidc_ef_get", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
     f("vidc_ef_perm", C.c_int, _vp, _vp, _vp)
     f("vidc_ef_export", C.c_int, _vp, _vp, _u64, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp)
+    f("vidc_ef_stream_words", C.c_int, _vp, _vp, _vp)
+    f("vidc_ef_export_all", C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t)
+    f("vidc_ef_import", C.c_int, _vp, _u64, _vp, _vp, _vp, _vp, _u64, _vp, _u64, _P(_vp))
     f("vidc_ef_encode_rows", C.c_int, _vp, _u64, _u32, _vp, _P(_vp))
     f("vidc_ef_decode_rows", C.c_int, _vp, _vp, _u64, _vp, _u32, _vp, _vp)
     f("vidc_ef_decode_lists", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
@@ -116,9 +122,9 @@ EXPORTED_SYMBOLS = [
     "vidc_roc_perm", "vidc_roc_perm_dev", "vidc_roc_import", "vidc_roc_decode_all", "vidc_roc_decode_lists",
     "vidc_roc_decode_rows", "vidc_roc_last_decode_nonclean",
     "vidc_packed_bits_for", "vidc_packed_encode", "vidc_packed_destroy", "vidc_packed_compressed_bytes",
-    "vidc_packed_bits", "vidc_packed_decode_all", "vidc_packed_get", "vidc_packed_export",
+    "vidc_packed_bits", "vidc_packed_decode_all", "vidc_packed_get", "vidc_packed_export", "vidc_packed_total_words", "vidc_packed_export_all", "vidc_packed_import",
     "vidc_ef_encode", "vidc_ef_destroy", "vidc_ef_compressed_bytes", "vidc_ef_list_info", "vidc_ef_decode_all",
-    "vidc_ef_get", "vidc_ef_perm", "vidc_ef_export",
+    "vidc_ef_get", "vidc_ef_perm", "vidc_ef_export", "vidc_ef_stream_words", "vidc_ef_export_all", "vidc_ef_import",
     "vidc_ef_encode_rows", "vidc_ef_decode_rows", "vidc_ef_decode_lists",
     "vidc_compact_rows_encode", "vidc_compact_destroy", "vidc_compact_bits", "vidc_compact_stride",
     "vidc_compact_size_in_bytes", "vidc_compact_rows_decode", "vidc_compact_export_row",

@@ -260,6 +260,24 @@ class PackedLists:
         check(lib().vidc_packed_get(self.ctx.h, self.h, ln.size, ptr(ln), ptr(of), ptr(out)))
         return out[: ln.size]
 
+    # -- flat on-disk / wire image (the reference keeps compressed lists in memory only)
+    def save(self, path):
+        tw = int(lib().vidc_packed_total_words(self.h))
+        words = np.zeros(max(tw, 1), np.uint64)
+        check(lib().vidc_packed_export_all(self.ctx.h, self.h, ptr(words), tw))
+        np.savez(path, offsets=self.offsets, bits=np.int64(self.bits), words=words[:tw])
+
+    @classmethod
+    def load(cls, path, ctx=None):
+        ctx = _lib.default_context() if ctx is None else ctx
+        z = np.load(path)
+        off = _as_offsets(z["offsets"])
+        words = np.ascontiguousarray(z["words"], dtype=np.uint64)
+        h = C.c_void_p()
+        check(lib().vidc_packed_import(ctx.h, off.size - 1, ptr(off), int(z["bits"]), ptr(words) if words.size else None,
+                                       words.size, C.byref(h)))
+        return cls(h, ctx, off)
+
     def export_bytes(self, list_no):
         n = int(self.offsets[list_no + 1] - self.offsets[list_no])
         nb = (n * self.bits + 7) // 8
@@ -380,6 +398,33 @@ class EfLists:
         out_off = np.zeros(ln.size + 1, np.uint64)
         check(lib().vidc_ef_decode_lists(self.ctx.h, self.h, ln.size, ptr(ln), ptr(out), ptr(out_off)))
         return out[:total], out_off
+
+    # -- flat on-disk / wire image (the reference keeps compressed lists in memory only)
+    def save(self, path):
+        lw, hw = C.c_uint64(), C.c_uint64()
+        check(lib().vidc_ef_stream_words(self.h, C.byref(lw), C.byref(hw)))
+        low, high = np.zeros(lw.value, np.uint64), np.zeros(hw.value, np.uint64)
+        check(lib().vidc_ef_export_all(self.ctx.h, self.h, ptr(low), low.size, ptr(high), high.size))
+        info = self.info()
+        np.savez(path, offsets=self.offsets, low_bits=info["low_bits"], universe=info["universe"], low=low, high=high,
+                 K=np.int64(getattr(self, "K", 0)))
+
+    @classmethod
+    def load(cls, path, ctx=None):
+        ctx = _lib.default_context() if ctx is None else ctx
+        z = np.load(path)
+        off = _as_offsets(z["offsets"])
+        lb = np.ascontiguousarray(z["low_bits"], dtype=np.uint32)
+        uni = np.ascontiguousarray(z["universe"], dtype=np.uint64)
+        low = np.ascontiguousarray(z["low"], dtype=np.uint64)
+        high = np.ascontiguousarray(z["high"], dtype=np.uint64)
+        h = C.c_void_p()
+        check(lib().vidc_ef_import(ctx.h, off.size - 1, ptr(off), ptr(lb) if lb.size else None, ptr(uni) if uni.size else None,
+                                   ptr(low), low.size, ptr(high), high.size, C.byref(h)))
+        obj = cls(h, ctx, off)
+        if int(z["K"]):
+            obj.K = int(z["K"])
+        return obj
 
     def export(self, list_no):
         """-> (low words, high words, low_nbits, high_nbits) of one list."""

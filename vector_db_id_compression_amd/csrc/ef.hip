@@ -340,6 +340,27 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
     }
 }
 
+// the same directory rebuilt from the high stream alone (import of a saved object): one wavefront per list,
+// running popcount over its batches of 64 words
+__global__ void __launch_bounds__(64) k_ef_hrank_from_high(const uint64_t *high, const uint64_t *high_off,
+                                                           const uint64_t *batch_off, uint32_t nlist, uint32_t *hrank) {
+    const uint32_t lane = lane_id();
+    for (uint32_t l = blockIdx.x; l < nlist; l += gridDim.x) {
+        const uint64_t *hw = high + high_off[l];
+        const uint64_t nhw = high_off[l + 1] - high_off[l];
+        const uint64_t nb = batch_off[l + 1] - batch_off[l];
+        uint32_t run = 0;
+        for (uint64_t bt = 0; bt < nb; bt++) {
+            if (lane == 0) hrank[batch_off[l] + bt] = run;
+            const uint64_t w = bt * 64 + lane;
+            uint32_t c = w < nhw ? popc64(hw[w]) : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
+            run += c;
+        }
+    }
+}
+
 // select directory: hrank[item] = number of elements whose high bit lies before batch `b` of list `l`
 // = first j with (x_j >> l) + j >= 4096 * b  (positions increase with j: binary search, no scan)
 __global__ void k_ef_hrank(const uint64_t *sorted_ids, const uint64_t *offsets, const uint32_t *lbits,
@@ -1160,6 +1181,92 @@ int vidc_ef_export(vidc_ctx *ctx, const vidc_ef *e, uint64_t list_no, uint64_t *
         if (hw > high_cap) { set_error("high buffer too small"); return VIDC_ERR_INVALID; }
         VIDC_TRY(vidc_copy_d2h(ctx, high, e->d_high.p + e->high_off[list_no], hw * 8));
     }
+    return VIDC_OK;
+}
+
+// ---- flat image of the object (the reference keeps compressed lists in memory only):
+// {offsets, l[], universe[], low[], high[]}; stream offsets follow from (count, l, universe) per list
+int vidc_ef_stream_words(const vidc_ef *e, uint64_t *low_words, uint64_t *high_words) {
+    if (!e) return VIDC_ERR_INVALID;
+    if (low_words) *low_words = e->d_low.n;
+    if (high_words) *high_words = e->d_high.n;
+    return VIDC_OK;
+}
+int vidc_ef_export_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *low, size_t low_cap, uint64_t *high, size_t high_cap) {
+    if (!ctx || !e || !low || !high) return VIDC_ERR_INVALID;
+    if (e->d_low.n > low_cap || e->d_high.n > high_cap) { set_error("export buffers too small"); return VIDC_ERR_INVALID; }
+    VIDC_TRY(vidc_copy_d2h(ctx, low, e->d_low.p, e->d_low.n * 8));
+    return vidc_copy_d2h(ctx, high, e->d_high.p, e->d_high.n * 8);
+}
+int vidc_ef_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint32_t *lbits,
+                   const uint64_t *universe, const uint64_t *low, uint64_t n_low, const uint64_t *high, uint64_t n_high,
+                   vidc_ef **out) {
+    if (!ctx || !out || (nlist && (!offsets || !lbits || !universe))) return VIDC_ERR_INVALID;
+    *out = nullptr;
+    if (nlist >= 0xffffffffull) return VIDC_ERR_INVALID;
+    VIDC_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<vidc_ef> e(new vidc_ef());
+    e->device = ctx->device;
+    e->nlist = nlist;
+    e->offsets.assign(nlist + 1, 0);
+    if (nlist) e->offsets.assign(offsets, offsets + nlist + 1);
+    e->ntotal = e->offsets[nlist];
+    e->lbits.assign(lbits, lbits + nlist);
+    e->universe.assign(universe, universe + nlist);
+    e->high_nbits.assign(nlist, 0);
+    e->low_off.assign(nlist + 1, 0);
+    e->high_off.assign(nlist + 1, 0);
+    std::vector<uint64_t> batch_off(nlist + 1, 0);
+    for (uint64_t l = 0; l < nlist; l++) {
+        if (e->offsets[l + 1] < e->offsets[l] || lbits[l] > 63) { set_error("ef import: bad geometry at list %llu", (unsigned long long)l); return VIDC_ERR_INVALID; }
+        const uint64_t m = e->offsets[l + 1] - e->offsets[l];
+        uint64_t lw = 0, hw = 0;
+        if (m) {
+            const uint64_t hb = (m + 1) + (universe[l] >> lbits[l]) + 1;
+            e->high_nbits[l] = hb;
+            e->total_bits += m * lbits[l] + hb;
+            lw = (m * lbits[l] + 63) / 64 + 1;
+            hw = (hb + 63) / 64;
+        }
+        e->low_off[l + 1] = e->low_off[l] + lw;
+        e->high_off[l + 1] = e->high_off[l] + hw;
+        batch_off[l + 1] = batch_off[l] + (hw + 63) / 64;
+    }
+    e->offsets_host = e->meta_host = true;
+    const uint64_t need_low = e->low_off[nlist] ? e->low_off[nlist] : 1, need_high = e->high_off[nlist] ? e->high_off[nlist] : 1;
+    if (n_low != need_low || n_high != need_high || !low || !high) {
+        set_error("ef import: streams of %llu / %llu words given, the geometry needs %llu / %llu", (unsigned long long)n_low,
+                  (unsigned long long)n_high, (unsigned long long)need_low, (unsigned long long)need_high);
+        return VIDC_ERR_INVALID;
+    }
+    e->nbatches = batch_off[nlist];
+    VIDC_TRY(e->d_offsets.alloc(nlist + 1, ctx->dpool)); VIDC_TRY(e->d_low_off.alloc(nlist + 1, ctx->dpool));
+    VIDC_TRY(e->d_high_off.alloc(nlist + 1, ctx->dpool)); VIDC_TRY(e->d_batch_off.alloc(nlist + 1, ctx->dpool));
+    VIDC_TRY(e->d_lbits.alloc(nlist ? nlist : 1, ctx->dpool)); VIDC_TRY(e->d_universe.alloc(nlist ? nlist : 1, ctx->dpool));
+    VIDC_TRY(e->d_low.alloc(need_low, ctx->dpool)); VIDC_TRY(e->d_high.alloc(need_high, ctx->dpool));
+    VIDC_TRY(e->d_chunks.alloc(1, ctx->dpool));  // encoder-only table
+    VIDC_TRY(e->d_batches.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
+    VIDC_TRY(e->d_hrank.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
+    VIDC_TRY(vidc_copy_h2d(ctx, e->d_offsets.p, e->offsets.data(), (nlist + 1) * 8));
+    VIDC_TRY(vidc_copy_h2d(ctx, e->d_low_off.p, e->low_off.data(), (nlist + 1) * 8));
+    VIDC_TRY(vidc_copy_h2d(ctx, e->d_high_off.p, e->high_off.data(), (nlist + 1) * 8));
+    VIDC_TRY(vidc_copy_h2d(ctx, e->d_batch_off.p, batch_off.data(), (nlist + 1) * 8));
+    if (nlist) {
+        VIDC_TRY(vidc_copy_h2d(ctx, e->d_lbits.p, e->lbits.data(), nlist * 4));
+        VIDC_TRY(vidc_copy_h2d(ctx, e->d_universe.p, e->universe.data(), nlist * 8));
+    }
+    VIDC_TRY(vidc_copy_h2d(ctx, e->d_low.p, low, n_low * 8));
+    VIDC_TRY(vidc_copy_h2d(ctx, e->d_high.p, high, n_high * 8));
+    if (e->nbatches) {
+        const uint32_t wgrid = (uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 64);
+        hipLaunchKernelGGL(k_fill_items, dim3(wgrid), dim3(64), 0, ctx->stream, e->d_batch_off.p, (uint32_t)nlist, 1u,
+                           e->d_batches.p);
+        hipLaunchKernelGGL(k_ef_hrank_from_high, dim3(wgrid), dim3(64), 0, ctx->stream, e->d_high.p, e->d_high_off.p,
+                           e->d_batch_off.p, (uint32_t)nlist, e->d_hrank.p);
+        VIDC_HIP(hipGetLastError());
+    }
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    *out = e.release();
     return VIDC_OK;
 }
 

@@ -266,13 +266,8 @@ int vidc_packed_bits_for(uint64_t ntotal) {  // custom_invlists_impl.cpp:68-70
     return bits;
 }
 
-int vidc_packed_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint64_t *d_ids, int bits,
-                       vidc_packed **out) {
-    if (!ctx || !out || (nlist && !offsets) || bits < 0 || bits > 64) return VIDC_ERR_INVALID;
-    *out = nullptr;
-    if (nlist >= 0xffffffffull) return VIDC_ERR_INVALID;
-    VIDC_HIP(hipSetDevice(ctx->device));
-    std::unique_ptr<vidc_packed> p(new vidc_packed());
+// geometry, offsets / word offsets on the device, chunk table (shared by encode and import)
+static int packed_setup(vidc_ctx *ctx, vidc_packed *p, uint64_t nlist, const uint64_t *offsets, int bits) {
     p->device = ctx->device;
     p->nlist = nlist;
     p->bits = bits;
@@ -287,7 +282,6 @@ int vidc_packed_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, c
         p->word_off[l + 1] = p->word_off[l] + (n * bits + 63) / 64 + 1;  // +1: read_bits may touch the next word
     }
     p->total_words = p->word_off[nlist];
-    if (p->ntotal && !d_ids) return VIDC_ERR_INVALID;
     // offsets / word offsets through pinned staging; chunk table built on the device
     Pinned h_up;
     Scratch s_cnt, s_coff, s_tmp;
@@ -300,22 +294,33 @@ int vidc_packed_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, c
     VIDC_TRY(p->d_words.alloc(p->total_words ? p->total_words : 1, ctx->dpool));
     VIDC_HIP(hipMemcpyAsync(p->d_offsets.p, h64, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     VIDC_HIP(hipMemcpyAsync(p->d_word_off.p, h64 + nlist + 1, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    {
-        const uint32_t nl32 = (uint32_t)nlist;
-        VIDC_TRY(s_cnt.get(ctx, (nlist + 1) * 4));
-        VIDC_TRY(s_coff.get(ctx, (nlist + 1) * 8));
-        hipLaunchKernelGGL(k_count_chunks, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256 + 1, 2048)), dim3(256), 0,
-                           ctx->stream, p->d_offsets.p, nl32, s_cnt.as<uint32_t>());
-        VIDC_TRY(device_exscan(ctx, s_cnt.as<uint32_t>(), nl32, s_coff.as<uint64_t>(), s_tmp));
-        VIDC_HIP(hipMemcpyAsync(h64 + 2 * nlist + 2, s_coff.as<uint64_t>() + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
-        VIDC_HIP(hipStreamSynchronize(ctx->stream));
-        p->nchunks = h64[2 * nlist + 2];
-        VIDC_TRY(p->d_chunks.alloc(p->nchunks ? p->nchunks : 1, ctx->dpool));
-        if (p->nchunks)
-            hipLaunchKernelGGL(k_fill_items, dim3((uint32_t)std::min<uint64_t>(nlist ? nlist : 1, (uint64_t)ctx->num_cu * 64)),
-                               dim3(64), 0, ctx->stream, s_coff.as<uint64_t>(), nl32, CHUNK_IDS, p->d_chunks.p);
-        VIDC_HIP(hipGetLastError());
-    }
+    const uint32_t nl32 = (uint32_t)nlist;
+    VIDC_TRY(s_cnt.get(ctx, (nlist + 1) * 4));
+    VIDC_TRY(s_coff.get(ctx, (nlist + 1) * 8));
+    hipLaunchKernelGGL(k_count_chunks, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256 + 1, 2048)), dim3(256), 0,
+                       ctx->stream, p->d_offsets.p, nl32, s_cnt.as<uint32_t>());
+    VIDC_TRY(device_exscan(ctx, s_cnt.as<uint32_t>(), nl32, s_coff.as<uint64_t>(), s_tmp));
+    VIDC_HIP(hipMemcpyAsync(h64 + 2 * nlist + 2, s_coff.as<uint64_t>() + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    p->nchunks = h64[2 * nlist + 2];
+    VIDC_TRY(p->d_chunks.alloc(p->nchunks ? p->nchunks : 1, ctx->dpool));
+    if (p->nchunks)
+        hipLaunchKernelGGL(k_fill_items, dim3((uint32_t)std::min<uint64_t>(nlist ? nlist : 1, (uint64_t)ctx->num_cu * 64)),
+                           dim3(64), 0, ctx->stream, s_coff.as<uint64_t>(), nl32, CHUNK_IDS, p->d_chunks.p);
+    VIDC_HIP(hipGetLastError());
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));  // scratch of this scope is released on return
+    return VIDC_OK;
+}
+
+int vidc_packed_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint64_t *d_ids, int bits,
+                       vidc_packed **out) {
+    if (!ctx || !out || (nlist && !offsets) || bits < 0 || bits > 64) return VIDC_ERR_INVALID;
+    *out = nullptr;
+    if (nlist >= 0xffffffffull) return VIDC_ERR_INVALID;
+    VIDC_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<vidc_packed> p(new vidc_packed());
+    VIDC_TRY(packed_setup(ctx, p.get(), nlist, offsets, bits));
+    if (p->ntotal && !d_ids) return VIDC_ERR_INVALID;
     Scratch s_err;
     VIDC_TRY(s_err.get(ctx, 4));
     VIDC_HIP(hipMemsetAsync(s_err.p, 0, 4, ctx->stream));
@@ -345,6 +350,32 @@ int vidc_packed_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, c
                   "ids_in[i] < ntotal), custom_invlists_impl.cpp:87)", bits);
         return VIDC_ERR_DOMAIN;
     }
+    *out = p.release();
+    return VIDC_OK;
+}
+
+// ---- flat image of the object (the reference keeps compressed lists in memory only): {offsets, bits, words}, words =
+// the device layout (every list starts on a 64-bit word, one padding word follows it)
+uint64_t vidc_packed_total_words(const vidc_packed *p) { return p ? p->total_words : 0; }
+int vidc_packed_export_all(vidc_ctx *ctx, const vidc_packed *p, uint64_t *words, size_t cap) {
+    if (!ctx || !p || (p->total_words && !words)) return VIDC_ERR_INVALID;
+    if (p->total_words > cap) { set_error("export buffer too small"); return VIDC_ERR_INVALID; }
+    return vidc_copy_d2h(ctx, words, p->d_words.p, p->total_words * 8);
+}
+int vidc_packed_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, int bits, const uint64_t *words,
+                       uint64_t nwords, vidc_packed **out) {
+    if (!ctx || !out || (nlist && !offsets) || bits < 0 || bits > 64) return VIDC_ERR_INVALID;
+    *out = nullptr;
+    if (nlist >= 0xffffffffull) return VIDC_ERR_INVALID;
+    VIDC_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<vidc_packed> p(new vidc_packed());
+    VIDC_TRY(packed_setup(ctx, p.get(), nlist, offsets, bits));
+    if (nwords != p->total_words || (nwords && !words)) {
+        set_error("packed import: %llu words given, the offsets need %llu", (unsigned long long)nwords,
+                  (unsigned long long)p->total_words);
+        return VIDC_ERR_INVALID;
+    }
+    if (nwords) VIDC_TRY(vidc_copy_h2d(ctx, p->d_words.p, words, nwords * 8));
     *out = p.release();
     return VIDC_OK;
 }
