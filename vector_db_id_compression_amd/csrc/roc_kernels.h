@@ -408,11 +408,14 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
                 const uint64_t W = rfl64(words[w]);
                 const uint32_t b = ff1(ballot(mbcnt(W) == k) & W);
                 const uint32_t j = (w << 6) + b;
-                const uint32_t x = rfl(sid[j]);
-                // remove (every lane stores the same word)
+                const uint32_t xv = sid[j];  // the only global load on the chain: issued first, consumed last
+                __builtin_amdgcn_sched_barrier(0);
+                // remove (every lane stores the same word): runs in the shadow of the load
                 words[w] = W & ~(1ull << b);
                 if (RL > 1u && lane >= tsel && lane < RL) rowpref[(c << rlsh) + lane] = rowv - 1u;
                 P1 -= (lane >= c) ? 1u : 0u;
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t x = rfl(xv);
                 ans_id_push(head, st, x, p0, p1);
                 if (want_perm) {
                     const uint32_t pos = need_sort ? rfl(spos[j]) : j;
