@@ -225,7 +225,7 @@ def test_save_load_roundtrip(roc, tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# lane-per-list kernels (roc_lane.h): lists of 65..1024 strictly ascending ids, tiny lists, graph rows.  The library
+# lane-per-list kernels (roc_lane.h): lists of 65..4096 strictly ascending ids, tiny lists, graph rows.  The library
 # only picks them for calls with thousands of lists; VIDC_FORCE_LANE=1 selects them regardless of the batch size.
 @pytest.fixture
 def force_lane(monkeypatch):
@@ -235,7 +235,8 @@ def force_lane(monkeypatch):
 def test_lane_kernels_boundaries_vs_oracle(roc, oracle, force_lane):
     """Sizes around every class boundary of the lane-per-list kernels, several universes, one call."""
     rng = np.random.default_rng(77)
-    sizes = [65, 66, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 767, 768, 769, 1000, 1023, 1024, 1025, 1100]
+    sizes = [65, 66, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 767, 768, 769, 1000, 1023, 1024, 1025, 1100,
+             1279, 1280, 1281, 2047, 2048, 2049, 3071, 3072, 3073, 3840, 4000, 4095, 4096, 4097, 4200]
     for nbits in (11, 16, 20, 24, 31):
         sz = [s for s in sizes if s <= (1 << nbits)]
         off, ids, lists = _random_lists(rng, sz, nbits=nbits)
@@ -248,7 +249,8 @@ def test_lane_kernels_dense_and_small_precision(roc, oracle, force_lane):
     """Dense lists (n close to the universe: tiny precision, many renormalisation pops) and fixed precisions."""
     rng = np.random.default_rng(78)
     lists = [np.sort(rng.choice(m, size=n, replace=False)).astype(np.uint64)
-             for n, m in ((65, 66), (100, 101), (128, 200), (300, 301), (1024, 1025), (1000, 1 << 10), (70, 1 << 7))]
+             for n, m in ((65, 66), (100, 101), (128, 200), (300, 301), (1024, 1025), (1000, 1 << 10), (70, 1 << 7),
+                          (1025, 1026), (2500, 2501), (4096, 4097), (4096, 5000), (3000, 1 << 12))]
     off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
     ids = np.concatenate(lists)
     r = roc.encode(off, ids, want_perm=True)
@@ -261,28 +263,32 @@ def test_lane_kernels_dense_and_small_precision(roc, oracle, force_lane):
         for l, li in enumerate(lists):
             e = oracle.roc_encode(li, P)
             assert int(info["heads"][l]) == e["head"] and np.array_equal(r.words(l), e["words"])
-            assert np.array_equal(dec[int(off[l]):int(off[l + 1])], e["order"])
+            # the reference decoder's view of the stream (P = 12 is one bit short for the lists holding id 4096: Q3)
+            want = oracle.roc_decode(e["head"], e["words"], li.size, P, e["mt_draws"])[0]
+            assert np.array_equal(dec[int(off[l]):int(off[l + 1])], want)
 
 
 def test_lane_decoder_hands_back_skewed_lists(roc, oracle, force_lane):
-    """All ids of a list in one 1/64 slice of the universe: the lane decoder's bucket row overflows and the list is
-    redone by the wave-per-list kernel (VIDC_ST_RETRY) -- same output."""
+    """All ids of a list in one 1/64 (1/256) slice of the universe: the lane decoder's bucket row overflows and the
+    list is redone by the wave-per-list kernel (VIDC_ST_RETRY) -- same output."""
     rng = np.random.default_rng(79)
     lists = []
-    for n in (70, 300, 900):
+    for n in (70, 300, 900, 1500, 3900):
         top = (1 << 20) - 1
         body = np.sort(rng.choice(4000, size=n - 1, replace=False)).astype(np.uint64) + 5
         lists.append(np.concatenate([body, [top]]).astype(np.uint64))  # max id sets the precision, the rest is clustered
     lists.append(np.sort(rng.choice(1 << 20, size=500, replace=False)).astype(np.uint64))  # a clean neighbour
+    lists.append(np.sort(rng.choice(1 << 20, size=2000, replace=False)).astype(np.uint64))  # a clean 256-bucket list
     off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
     ids = np.concatenate(lists)
     r = roc.encode(off, ids, want_perm=True)
     dec = r.decode_all().cpu().numpy().view(np.uint64)
     _check_against_oracle(oracle, r, off, lists, r.perm(), dec)
     assert r.last_decode_nonclean == 0
-    sub, sub_off = r.decode_lists(np.array([2, 3, 0, 2], dtype=np.uint64))  # repeated + mixed retry / clean requests
+    req = [2, 5, 0, 2, 4, 6, 3]
+    sub, sub_off = r.decode_lists(np.array(req, dtype=np.uint64))  # repeated + mixed retry / clean requests
     sub = sub.cpu().numpy().view(np.uint64)
-    for i, l in enumerate([2, 3, 0, 2]):
+    for i, l in enumerate(req):
         assert np.array_equal(sub[int(sub_off[i]):int(sub_off[i + 1])], dec[int(off[l]):int(off[l + 1])])
 
 
@@ -290,7 +296,7 @@ def test_lane_kernels_match_wave_kernels(roc, monkeypatch):
     """Same streams from the two kernel families (VIDC_FORCE_LANE / VIDC_NO_LANE test hooks) on 3000 ragged lists,
     and from the automatic choice on a batch large enough to take the lane kernels by itself."""
     rng = np.random.default_rng(80)
-    sizes = rng.integers(0, 1200, 3000)
+    sizes = np.concatenate([rng.integers(0, 1200, 3000), rng.integers(1025, 4200, 300)])
     off, ids, _ = _random_lists(rng, sizes, nbits=22)
     got = {}
     for mode in ("0", "1"):

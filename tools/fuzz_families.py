@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential fuzz of the ROC kernel families (dev tool, run through gpurun): random batches -- list sizes 0..1500,
+"""Differential fuzz of the ROC kernel families (dev tool, run through gpurun): random batches -- list sizes 0..4300,
 universes 2^7..2^31, dense lists, explicit precisions below / above what the ids need (the reference's carry quirk),
 unsorted lists, duplicates -- encoded and decoded by the lane-per-list kernels (VIDC_FORCE_LANE), the wave-per-list
 kernels (VIDC_NO_LANE) and the general kernels only (VIDC_FORCE_GENERAL); streams, permutations and decoded arrays
@@ -22,15 +22,18 @@ MODES = {"lane": {"VIDC_FORCE_LANE": "1", "VIDC_NO_LANE": "0", "VIDC_FORCE_GENER
 def make_batch(rng):
     nbits = int(rng.integers(7, 32))
     nlist = int(rng.integers(1, 200))
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 5)
     if kind == 0:
         sizes = rng.integers(0, 70, nlist)
     elif kind == 1:
         sizes = rng.integers(60, 1100, nlist)
     elif kind == 2:
         sizes = rng.integers(0, 1500, nlist)
-    else:
+    elif kind == 3:
         sizes = np.minimum(rng.geometric(0.01, nlist), 5000)
+    else:  # the 1025..4096 lane class and its boundaries
+        nlist = min(nlist, 40)
+        sizes = rng.integers(900, 4300, nlist)
     sizes = np.minimum(sizes, 1 << nbits)
     lists = []
     for s in sizes:
@@ -69,9 +72,14 @@ def main():
         got = {}
         for name, env in MODES.items():
             os.environ.update(env)
-            r = RocLists.encode(off, ids, precision_mode=mode, want_perm=want_perm)
-            info = r.info()
-            dec = r.decode_all().cpu().numpy().copy()
+            try:
+                r = RocLists.encode(off, ids, precision_mode=mode, want_perm=want_perm)
+                info = r.info()
+                dec = r.decode_all().cpu().numpy().copy()
+            except Exception as ex:
+                print("ERROR in family", name, "seed", seed, "batch", nb, "mode", mode, ":", ex, flush=True)
+                np.savez("gpurun_out/fuzz_fail.npz", off=off, ids=ids, mode=mode)
+                sys.exit(1)
             got[name] = (info["heads"], info["nwords"], info["precision"], info["mt_draws"], r.all_words(), dec,
                          r.perm() if want_perm else np.zeros(0))
             nonclean = r.last_decode_nonclean

@@ -132,8 +132,8 @@ struct Pinned {
 // mt19937(1234) words available to the kernels for ANS stack underflow (codec.h:16-18,32-40).
 // The reference draws 0 or 1 word per list in every valid case.
 #define VIDC_MT_TABLE 1024
-// largest divisor of the lane-per-list kernels' reciprocal table (== VIDC_LANE_MAX in roc_lane.h)
-#define VIDC_LANE_TAB 1024
+// largest divisor of the lane-per-list kernels' reciprocal table (== VIDC_LANE_MAX64 in roc_lane.h)
+#define VIDC_LANE_TAB 4096
 
 // Scratch blocks are cached per context so steady-state encode/decode calls do not hipMalloc.
 struct PoolBlock {
@@ -153,7 +153,7 @@ struct vidc_ctx {
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     uint32_t *d_mt = nullptr;  // VIDC_MT_TABLE words
-    void *d_ltab = nullptr;    // divisor table of the lane-per-list kernels (roc_lane.h), VIDC_LANE_MAX + 1 entries
+    void *d_ltab = nullptr;    // divisor table of the lane-per-list kernels (roc_lane.h), VIDC_LANE_TAB + 1 entries
     int num_cu = 256;
     double last_kernel_ms = 0.0;
     double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see VIDC_PHASE_* in vidc.h

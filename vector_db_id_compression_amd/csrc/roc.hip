@@ -68,13 +68,13 @@ constexpr uint32_t U_MIN_LIST = 4097;
 
 inline uint64_t arena_words_for(uint64_t n) { return n * 37 / 32 + 8; }  // <= P+4 bits of growth per step, P <= 32
 
-static_assert(VIDC_LANE_MAX == VIDC_LANE_TAB, "divisor table size");
+static_assert(VIDC_LANE_MAX64 == VIDC_LANE_TAB, "divisor table size");
 // Kernel family for short lists.  The lane-per-list kernels advance 64 lists per instruction but every list still
 // pays the full per-step latency, so they only win once a call has enough lists to fill the machine with them
 // (measured crossover ~8 000 lists of 65..1024 ids, ~2 000 tiny lists); smaller calls -- e.g. the few hundred lists
 // a search touches -- keep the latency-optimised wave-per-list kernels.  Test hooks: VIDC_NO_LANE=1 (never),
 // VIDC_FORCE_LANE=1 (always); both families produce the same bits.
-constexpr uint64_t LANE_MIN_LISTS = 8192, LANE_MIN_TINY = 2048;
+constexpr uint64_t LANE_MIN_LISTS = 8192, LANE_MIN_LISTS64 = 8192, LANE_MIN_TINY = 2048;  // 64: lists of 1025..4096 ids
 enum LanePolicy { LANE_NEVER = 0, LANE_AUTO = 1, LANE_ALWAYS = 2 };
 inline LanePolicy lane_policy() {
     const char *e = getenv("VIDC_NO_LANE");
@@ -293,12 +293,12 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     HostTrace tr("roc encode");
     // work lists: tiny (n <= 64), universe-bitmap kernels (ids < 2^18 / 2^20), general kernels by bitmap depth,
     // lane-per-list kernels
-    std::vector<uint32_t> wl_tiny, wl_u18, wl_u20, wl_c1, wl_c2, wl_c3, wl_l4, wl_l16;
+    std::vector<uint32_t> wl_tiny, wl_u18, wl_u20, wl_c1, wl_c2, wl_c3, wl_l4, wl_l16, wl_l64;
     const bool want_perm = (flags & VIDC_ROC_WANT_PERM) && !rows;
     const uint64_t ntotal_in = rows ? N * K : (nlist ? offsets[nlist] : 0);
     const bool f_general = force_general();  // getenv once, not per list
     const LanePolicy lpol = f_general ? LANE_NEVER : lane_policy();
-    bool use_lane = false, use_lane_tiny = false;
+    bool use_lane = false, use_lane64 = false, use_lane_tiny = false;
     // persistent outputs
     VIDC_TRY(r->d_heads.alloc(nlist, ctx->dpool)); VIDC_TRY(r->d_prec.alloc(nlist, ctx->dpool));
     VIDC_TRY(r->d_nwords.alloc(nlist, ctx->dpool)); VIDC_TRY(r->d_draws.alloc(nlist, ctx->dpool));
@@ -379,13 +379,15 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         // num_cu lists in flight.  With many lists, short ones go to the high-occupancy kernels.
         const uint64_t u_min = U_MIN_LIST;
         {
-            uint64_t n_mid = 0, n_tiny = 0;
+            uint64_t n_mid = 0, n_mid64 = 0, n_tiny = 0;
             for (uint64_t l = 0; l < nlist; l++) {
                 const uint64_t n = offsets[l + 1] - offsets[l];
                 n_tiny += n <= TINY_MAX;
                 n_mid += n > TINY_MAX && n <= VIDC_LANE_MAX;
+                n_mid64 += n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64;
             }
             use_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
+            use_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
             use_lane_tiny = lane_wanted(lpol, n_tiny, LANE_MIN_TINY);
         }
         for (uint64_t l = 0; l < nlist; l++) {
@@ -400,18 +402,20 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             // the bitmap kernels need no sort; they cannot report input positions of an unsorted list
             bool u_ok = !f_general && !((pflags[l] & VIDC_PF_UNSORTED) && want_perm) &&
                         (n >= u_min || (pflags[l] & VIDC_PF_UNSORTED));
-            const bool lane_ok = use_lane && !(pflags[l] & VIDC_PF_UNSORTED) && n <= VIDC_LANE_MAX;
+            const bool lane_ok = !(pflags[l] & VIDC_PF_UNSORTED) &&
+                                 ((use_lane && n <= VIDC_LANE_MAX) || (use_lane64 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64));
             if (u_ok && width <= 18) wl_u18.push_back((uint32_t)l);
             else if (u_ok && width <= 20) wl_u20.push_back((uint32_t)l);
             else if (lane_ok && n <= 256) wl_l4.push_back((uint32_t)l);
-            else if (lane_ok) wl_l16.push_back((uint32_t)l);
+            else if (lane_ok && n <= VIDC_LANE_MAX) wl_l16.push_back((uint32_t)l);
+            else if (lane_ok) wl_l64.push_back((uint32_t)l);
             else if (n <= 4096) wl_c1.push_back((uint32_t)l);
             else if (n <= 32768) wl_c2.push_back((uint32_t)l);
             else wl_c3.push_back((uint32_t)l);
         }
         ntiny = wl_tiny.size();
         tr.mark("classify");
-        for (auto *w : {&wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16}) sort_desc(*w, r->offsets);
+        for (auto *w : {&wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64}) sort_desc(*w, r->offsets);
         tr.mark("sort work lists");
         if (!wl_c1.empty() || !wl_c2.empty() || !wl_c3.empty()) VIDC_TRY(s_sid.get(ctx, ntotal_in * 4));
     }
@@ -422,13 +426,13 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     const uint32_t *d_wl = nullptr;
     if (!rows) {
         size_t total = 0;
-        for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16}) {
+        for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64}) {
             base.push_back(total);
             total += w->size();
         }
         VIDC_TRY(h_wl.get(ctx, total * 4));
         size_t k = 0;
-        for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16}) {
+        for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64}) {
             if (!w->empty()) std::memcpy(h_wl.as<uint32_t>() + k, w->data(), w->size() * 4);
             k += w->size();
         }
@@ -436,7 +440,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         if (total) VIDC_HIP(hipMemcpyAsync(s_wl.p, h_wl.p, total * 4, hipMemcpyHostToDevice, ctx->stream));
         d_wl = s_wl.as<uint32_t>();
     } else {
-        base.assign(8, 0);
+        base.assign(9, 0);
     }
 
     RocEncArgs a{};
@@ -480,7 +484,17 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             else hipLaunchKernelGGL((k_roc_encode_u<20, false>), dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, ctx->stream, b);
             VIDC_HIP(hipGetLastError());
         }
-        VIDC_TRY(launch_gen_on(ctx->stream, d_wl + base[5], (uint32_t)wl_c3.size(), 64));
+        // the deepest class: prefix rows sized for its longest list (first of the work list).  With the fixed
+        // 48 KiB layout a CU held 3 of these chains; lists up to 65 536 ids need 12 KiB (S2 encode 152 -> see DESIGN)
+        {
+            uint32_t rl3 = 64;
+            if (!wl_c3.empty()) {
+                const uint64_t nmax3 = r->offsets[wl_c3[0] + 1] - r->offsets[wl_c3[0]];
+                rl3 = 16;
+                while ((uint64_t)64 * 64 * rl3 < nmax3) rl3 <<= 1;
+            }
+            VIDC_TRY(launch_gen_on(ctx->stream, d_wl + base[5], (uint32_t)wl_c3.size(), rl3));
+        }
         // aux 0: mid-size general lists and bitmap-18 lists
         VIDC_TRY(launch_gen_on(ctx->aux[0], d_wl + base[4], (uint32_t)wl_c2.size(), 8));
         if (!wl_u18.empty()) {
@@ -492,14 +506,16 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         }
         // aux 1: short general lists and the lane-per-list kernels; aux 2: tiny lists
         VIDC_TRY(launch_gen_on(ctx->aux[1], d_wl + base[3], (uint32_t)wl_c1.size(), 1));
-        for (int cls = 0; cls < 2; cls++) {
-            const std::vector<uint32_t> &w = cls ? wl_l16 : wl_l4;
+        for (int cls = 2; cls >= 0; cls--) {  // longest chains first
+            const std::vector<uint32_t> &w = cls == 2 ? wl_l64 : (cls ? wl_l16 : wl_l4);
             if (w.empty()) continue;
             RocEncArgs b = a;
             b.worklist = d_wl + base[6 + cls]; b.nwork = (uint32_t)w.size();
             const dim3 grid((b.nwork + 63u) / 64u);
             const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
-            if (cls == 0 && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<4, true>), grid, dim3(64), 0, ctx->aux[1], b, dt);
+            if (cls == 2 && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<64, true>), grid, dim3(64), 0, ctx->aux[1], b, dt);
+            else if (cls == 2) hipLaunchKernelGGL((k_roc_encode_lane<64, false>), grid, dim3(64), 0, ctx->aux[1], b, dt);
+            else if (cls == 0 && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<4, true>), grid, dim3(64), 0, ctx->aux[1], b, dt);
             else if (cls == 0) hipLaunchKernelGGL((k_roc_encode_lane<4, false>), grid, dim3(64), 0, ctx->aux[1], b, dt);
             else if (want_perm) hipLaunchKernelGGL((k_roc_encode_lane<16, true>), grid, dim3(64), 0, ctx->aux[1], b, dt);
             else hipLaunchKernelGGL((k_roc_encode_lane<16, false>), grid, dim3(64), 0, ctx->aux[1], b, dt);
@@ -570,7 +586,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             VIDC_TRY(upload_scratch(ctx, s_pend, pend));
             a.sid = s_sid.as<uint32_t>();
             a.skey = s_skey.as<uint64_t>(); a.skey_off = s_skey_off.as<uint64_t>(); a.spos = s_spos.as<uint32_t>();
-            uint32_t rl_max = maxn <= 4096 ? 1 : (maxn <= 32768 ? 8 : 64);
+            uint32_t rl_max = maxn <= 4096 ? 1 : (maxn <= 32768 ? 8 : (maxn <= 65536 ? 16 : 64));
             EventTimer t2(ctx);
             VIDC_TRY(launch_gen(s_pend.as<uint32_t>(), (uint32_t)pend.size(), rl_max));
             kernel_ms += t2.stop();
@@ -608,12 +624,13 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
 // ---- decode planning: work items grouped by kernel class, each with private scratch
 // general decoder classes by LDS footprint of the fine prefix rows (2^fb u32, fb = lg(n) - 3): occupancy, not
 // arithmetic, bounds the general decoder when a batch has many mid-size lists
-enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_COUNT };
+enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_COUNT };
 
 struct DecPlan {
     std::vector<uint32_t> wl;        // list numbers, grouped by class, longest first inside a class
     std::vector<uint32_t> item;      // index of each work item in the caller's request
-    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t sum_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<uint64_t> scratch_off, slots_off;
     uint64_t scratch_words = 0, slots_words = 0;
     bool lean = false;               // graph rows, lane decoder: item k == request k, no scratch / offset arrays
@@ -621,13 +638,14 @@ struct DecPlan {
     uint64_t implicit = 0;           // lean plan without a work list: items are rows 0..implicit-1
 };
 
-inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane) {  // (n > TINY_MAX lists: allow_lane = mid-size policy)
+inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane, bool allow_lane64) {  // (allow_lane*: mid-size policies)
     if (n <= TINY_MAX) return DC_TINY;
     if (!f_general && n >= u_min) {
         if (P <= 18) return DC_U18;
         if (P <= 20) return DC_U20;
     }
     if (allow_lane && n <= VIDC_LANE_MAX) return DC_LANE;
+    if (allow_lane64 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64) return DC_LANE64;
     if (n <= GEN_SMALL_MAX) return DC_GSMALL;
     if (n <= 8192) return DC_G8K;
     if (n <= 16384) return DC_G16K;
@@ -642,7 +660,7 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     const LanePolicy lpol = (allow_lane && !f_general) ? lane_policy() : LANE_NEVER;
     p.wl.clear(); p.item.clear(); p.scratch_off.clear(); p.slots_off.clear();
     p.scratch_words = 0; p.slots_words = 0;
-    for (int c = 0; c < DC_COUNT; c++) p.count[c] = 0;
+    for (int c = 0; c < DC_COUNT; c++) { p.count[c] = 0; p.sum_n[c] = 0; p.max_n[c] = 0; }
     p.tiny_lane = false;
     if (rows_flavour && lane_wanted(lpol, lists.size(), LANE_MIN_TINY)) {
         // graph rows with the lane-per-row decoder: request order, no scratch, implicit output offsets
@@ -655,20 +673,23 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     p.lean = false;
     std::vector<uint32_t> cls[DC_COUNT];
     const uint64_t u_min = U_MIN_LIST;
+    bool allow_lane64 = false;
     {
-        uint64_t n_mid = 0, n_tiny = 0;
+        uint64_t n_mid = 0, n_mid64 = 0, n_tiny = 0;
         for (uint32_t l : lists) {
             const uint64_t n = r->offsets[l + 1] - r->offsets[l];
             n_tiny += n <= TINY_MAX;
             n_mid += n > TINY_MAX && n <= VIDC_LANE_MAX;
+            n_mid64 += n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64;
         }
         allow_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
+        allow_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
         p.tiny_lane = lane_wanted(lpol, rows_flavour ? lists.size() : n_tiny, LANE_MIN_TINY);
     }
     for (uint32_t i = 0; i < lists.size(); i++) {
         uint32_t l = lists[i];
         uint64_t n = r->offsets[l + 1] - r->offsets[l];
-        cls[rows_flavour ? DC_TINY : dec_class(n, r->prec[l], u_min, f_general, allow_lane)].push_back(i);
+        cls[rows_flavour ? DC_TINY : dec_class(n, r->prec[l], u_min, f_general, allow_lane, allow_lane64)].push_back(i);
     }
     auto len = [&](uint32_t i) { return r->offsets[lists[i] + 1] - r->offsets[lists[i]]; };
     for (int c = 0; c < DC_COUNT; c++) {
@@ -682,7 +703,11 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             cls[c].swap(sorted);
         }
         p.count[c] = cls[c].size();
-        for (uint32_t i : cls[c]) { p.item.push_back(i); p.wl.push_back(lists[i]); }
+        for (uint32_t i : cls[c]) {
+            p.item.push_back(i); p.wl.push_back(lists[i]);
+            p.sum_n[c] += len(i);
+            p.max_n[c] = std::max<uint64_t>(p.max_n[c], len(i));
+        }
     }
     p.scratch_off.resize(p.wl.size());
     p.slots_off.resize(p.wl.size());
@@ -693,13 +718,17 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             uint32_t l = p.wl[k];
             uint64_t n = r->offsets[l + 1] - r->offsets[l];
             p.scratch_off[k] = so;
-            // re-spill scratch of the decoder stack: the stream never exceeds the encoder's arena bound
-            so += std::max<uint64_t>(arena_words_for(n), r->meta_host ? r->nwords[l] : 0) + 64;
+            // re-spill scratch of the decoder stack (== roc_dec_stack_cap in the kernels)
+            so += roc_dec_stack_cap((uint32_t)n, r->meta_host ? r->nwords[l] : 0u);
             p.slots_off[k] = sl;
             if (c == DC_LANE) {
                 sl = (sl + 3) & ~(uint64_t)3;  // rows are read as uint4
                 p.slots_off[k] = sl;
                 sl += 64ull * roc_lane_cap((uint32_t)n);
+            } else if (c == DC_LANE64) {
+                sl = (sl + 3) & ~(uint64_t)3;
+                p.slots_off[k] = sl;
+                sl += 256ull * roc_lane_cap_nb<256>((uint32_t)n);
             } else if (c == DC_U18 || c == DC_U20) sl += n;  // duplicate side list
             else if (c >= DC_GSMALL) {
                 uint32_t fb = roc_dec_fine_bits((uint32_t)n, r->prec[l] > 32 ? 32 : r->prec[l]);
@@ -793,12 +822,37 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     // classes run concurrently: the longest chains on the caller's stream, the rest on the auxiliary streams
     VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     for (int i = 0; i < 3; i++) VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
+    // Stream assignment: a class's kernel lasts about max(its longest chain, its share of the machine); classes are
+    // taken longest first and each goes to the stream that frees up first (LPT over 3 streams).  A fixed
+    // assignment left three general classes back to back on one stream on S2 (70 + 45 + 18 ms) while the
+    // others had drained.
+    int order[DC_COUNT];
+    hipStream_t stream_of[DC_COUNT];
+    {
+        double est[DC_COUNT];
+        for (int c = 0; c < DC_COUNT; c++) {
+            order[c] = c;
+            const bool u = c == DC_U18 || c == DC_U20, lane = c == DC_LANE || c == DC_LANE64;
+            const double step_us = u ? 0.4 : (lane ? 2.5 : (c == DC_TINY ? 0.5 : 1.0));       // one chain step
+            const double rate = u ? 0.6e3 : (lane ? 10e3 : (c == DC_TINY ? 30e3 : 4e3));       // steps / us, all CUs
+            est[c] = std::max((double)p.max_n[c] * step_us, (double)p.sum_n[c] / rate);
+        }
+        std::sort(order, order + DC_COUNT, [&](int x, int y) { return est[x] > est[y]; });
+        // three streams: a 4th one did not run concurrently (HIP maps streams onto 4 hardware queues and the
+        // process has other streams; the kernels of aux[2] started when the main stream's had finished)
+        double load[3] = {0, 0, 0};
+        for (int k = 0; k < DC_COUNT; k++) {
+            const int c = order[k];
+            int best = 0;
+            for (int q = 1; q < 3; q++)
+                if (load[q] < load[best]) best = q;
+            stream_of[c] = best == 0 ? ctx->stream : ctx->aux[best - 1];
+            load[best] += est[c] + 1.0;
+        }
+    }
     auto launch = [&](int c) -> int {
         if (!p.count[c]) return VIDC_OK;
-        hipStream_t st_ = ctx->stream;
-        if (c == DC_GMID || c == DC_G16K || c == DC_G8K || c == DC_U18) st_ = ctx->aux[0];
-        else if (c == DC_GSMALL || c == DC_LANE) st_ = ctx->aux[1];
-        else if (c == DC_TINY) st_ = ctx->aux[2];
+        hipStream_t st_ = stream_of[c];
         RocDecArgs b = a;
         b.worklist = d_wl ? d_wl + base[c] : nullptr;
         b.nwork = (uint32_t)p.count[c];
@@ -826,7 +880,11 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), 512 * 4, st_, b, 512u, VIDC_DEC_CAP);
                 break;
             case DC_LANE:
-                hipLaunchKernelGGL(k_roc_decode_lane, dim3((b.nwork + 63u) / 64u), dim3(64), 0, st_, b,
+                hipLaunchKernelGGL(k_roc_decode_lane<64>, dim3((b.nwork + 63u) / 64u), dim3(64), 0, st_, b,
+                                   (const LaneDiv *)ctx->d_ltab);
+                break;
+            case DC_LANE64:
+                hipLaunchKernelGGL(k_roc_decode_lane<256>, dim3((b.nwork + 63u) / 64u), dim3(64), 0, st_, b,
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
             case DC_G8K:
@@ -846,8 +904,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         VIDC_HIP(hipGetLastError());
         return VIDC_OK;
     };
-    // longest chains first
-    for (int c : {DC_GHUGE, DC_U20, DC_GMID, DC_G16K, DC_G8K, DC_U18, DC_GSMALL, DC_LANE, DC_TINY}) VIDC_TRY(launch(c));
+    for (int k = 0; k < DC_COUNT; k++) VIDC_TRY(launch(order[k]));  // longest first
     for (int i = 0; i < 3; i++) {
         VIDC_HIP(hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
         VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
@@ -878,7 +935,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
             // wave-per-list kernels, into the same output slots
             std::vector<uint32_t> lists2;
             std::vector<uint64_t> off2;
-            for (size_t k = base[DC_LANE]; k < base[DC_LANE] + p.count[DC_LANE]; k++) {
+            for (size_t k = base[DC_LANE]; k < base[DC_LANE] + p.count[DC_LANE] + p.count[DC_LANE64]; k++) {  // both lane classes
                 if (status[p.wl[k]] != VIDC_ST_RETRY) continue;
                 lists2.push_back(p.wl[k]);
                 off2.push_back(out_off_host ? out_off_host[k] : r->offsets[p.wl[k]]);

@@ -61,6 +61,13 @@ struct RocEncArgs {
 __host__ __device__ inline uint64_t roc_arena_at(const uint64_t *offsets, uint32_t stride, uint64_t l) {
     return offsets ? ((offsets[l] * 37ull) >> 5) + 9ull * l : l * (uint64_t)stride;
 }
+// capacity of a decoder's private stack scratch (plan_decode allots exactly this): the decoder pushes at most
+// ~log2(n) bits per step, so streams of the encoder never outgrow the encoder's own arena bound; a stream whose
+// precision is far below log2(n) (reference quirk domain) GROWS while it is decoded and needs that room
+__host__ __device__ inline uint32_t roc_dec_stack_cap(uint32_t n, uint32_t W) {
+    const uint32_t a = (uint32_t)(((uint64_t)n * 37ull) >> 5) + 8u;
+    return (a > W ? a : W) + 64u;
+}
 __device__ __forceinline__ uint64_t arena_at(const RocEncArgs &a, uint64_t l) {
     return roc_arena_at(a.rows ? nullptr : a.offsets, a.arena_stride, l);
 }
@@ -238,7 +245,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny(RocDecArgs a) {
         const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
         const uint32_t W = a.nwords[l];
         WStack st;
-        ws_init_loaded(st, a.words + a.word_off[l], W, a.scratch_words + a.scratch_off[wi], W + 64u, a.draws[l], a.mt,
+        ws_init_loaded(st, a.words + a.word_off[l], W, a.scratch_words + a.scratch_off[wi], roc_dec_stack_cap(n, W), a.draws[l], a.mt,
                        VIDC_MT_TABLE);
         const uint32_t draws0 = st.draws;
         uint64_t head = a.heads[l];
@@ -456,7 +463,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t ld
         const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
         const uint32_t W = rfl(a.nwords[l]);
         WStack st;
-        ws_init_loaded(st, a.words + rfl64(a.word_off[l]), W, a.scratch_words + rfl64(a.scratch_off[wi]), W + 64u,
+        ws_init_loaded(st, a.words + rfl64(a.word_off[l]), W, a.scratch_words + rfl64(a.scratch_off[wi]), roc_dec_stack_cap(n, W),
                        rfl(a.draws[l]), a.mt, VIDC_MT_TABLE);
         const uint32_t draws0 = st.draws;
         uint64_t head = rfl64(a.heads[l]);

@@ -1,4 +1,4 @@
-// roc_lane.h -- "one list per LANE" Random Order Coding kernels for short lists (65 .. VIDC_LANE_MAX ids).
+// roc_lane.h -- "one list per LANE" Random Order Coding kernels for short lists (65 .. VIDC_LANE_MAX64 ids).
 //
 // The wave-per-list kernels of roc_kernels.h spend ~130 wave-wide instructions per codec step on what is almost
 // entirely wave-uniform arithmetic; with tens of thousands of short lists that is the bound (one step of ONE list
@@ -23,10 +23,11 @@
 namespace vidc {
 namespace dev {
 
-#define VIDC_LANE_MAX 1024u
+#define VIDC_LANE_MAX 1024u    // NW = 16 encoder / 64-bucket decoder
+#define VIDC_LANE_MAX64 4096u  // NW = 64 encoder / 256-bucket decoder (the divisor table ends here)
 #define VIDC_ST_RETRY 5u  // lane decoder: redo this list with the wave-per-list kernel
 
-// entry d of the divisor table (d = 1 .. VIDC_LANE_MAX): x = m_lo, y = m_hi of floor((2^64-1)/d),
+// entry d of the divisor table (d = 1 .. VIDC_LANE_MAX64): x = m_lo, y = m_hi of floor((2^64-1)/d),
 // z = thr = d * floor(2^31/d), w = lq = floor(2^31/d)
 typedef uint4 LaneDiv;
 
@@ -144,16 +145,31 @@ __device__ __forceinline__ uint32_t l_u_pop(uint64_t &head, LStack &s, uint32_t 
     return sym;
 }
 
-// LDS strip of one lane: u64 bm[NW] | u32 wc[NW/4] (4 byte counters each) | u64 gc (4 u16 counters, NW == 16)
+// LDS strip of one lane: u64 bm[NW] | u32 wc[NW/4] (4 byte counters each) | u64 gc[NW/16] (4 u16 group counters each,
+// NW >= 16) | u64 sc (4 u16 super-group counters, NW == 64)
 // element e of lane t lives at base + (e * 64 + t) * size: conflict-free for any per-lane e
 template <int NW>
 struct LaneEncGeom {
+    static_assert(NW == 4 || NW == 16 || NW == 64, "1, 2 or 3 counter levels above the words");
     static constexpr uint32_t BM_BYTES = NW * 64 * 8;
     static constexpr uint32_t WC_BYTES = (NW / 4) * 64 * 4;
-    static constexpr uint32_t GC_BYTES = NW > 4 ? 64 * 8 : 0;
+    static constexpr uint32_t GC_BYTES = NW > 4 ? (NW / 16) * 64 * 8 : 0;
+    static constexpr uint32_t SC_BYTES = NW > 16 ? 64 * 8 : 0;
     static constexpr uint32_t RING_BYTES = VIDC_PRING * 64 * 4;
-    static constexpr uint32_t LDS_BYTES = BM_BYTES + WC_BYTES + GC_BYTES + RING_BYTES;
+    static constexpr uint32_t LDS_BYTES = BM_BYTES + WC_BYTES + GC_BYTES + SC_BYTES + RING_BYTES;
 };
+
+// 4 u16 counters in v: the field f holding the k-th element (k < total), k reduced to its rank inside the field
+__device__ __forceinline__ uint32_t lane_pick4_u16(uint64_t v, uint32_t &k) {
+    const uint32_t c0 = (uint32_t)v & 0xffffu, c1 = (uint32_t)(v >> 16) & 0xffffu, c2 = (uint32_t)(v >> 32) & 0xffffu;
+    const uint32_t q0 = c0, q1 = c0 + c1, q2 = q1 + c2;
+    uint32_t f = 0, base = 0;
+    if (k >= q0) { f = 1; base = q0; }
+    if (k >= q1) { f = 2; base = q1; }
+    if (k >= q2) { f = 3; base = q2; }
+    k -= base;
+    return f;
+}
 
 template <int NW, bool WANT_PERM>
 __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const LaneDiv *__restrict__ dtab) {
@@ -161,6 +177,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
     uint64_t *bm = (uint64_t *)smem;
     uint32_t *wc = (uint32_t *)(smem + LaneEncGeom<NW>::BM_BYTES);
     uint64_t *gc = (uint64_t *)(smem + LaneEncGeom<NW>::BM_BYTES + LaneEncGeom<NW>::WC_BYTES);
+    uint64_t *sc = (uint64_t *)(smem + LaneEncGeom<NW>::BM_BYTES + LaneEncGeom<NW>::WC_BYTES + LaneEncGeom<NW>::GC_BYTES);
     const uint32_t lane = lane_id();
     const uint32_t wi = blockIdx.x * 64u + lane;
     const bool have = wi < a.nwork;
@@ -185,21 +202,34 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
         wc[g * 64 + lane] = packed;
     }
     if (NW > 4) {
-        uint64_t g4 = 0;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const uint32_t lo_e = (uint32_t)g << 8;
-            const uint32_t in_g = lo_e >= n ? 0u : (n - lo_e >= 256u ? 256u : n - lo_e);
-            g4 |= (uint64_t)in_g << (16 * g);
+        for (int q = 0; q < NW / 16; q++) {
+            uint64_t g4 = 0;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const uint32_t lo_e = (uint32_t)(q * 4 + g) << 8;
+                const uint32_t in_g = lo_e >= n ? 0u : (n - lo_e >= 256u ? 256u : n - lo_e);
+                g4 |= (uint64_t)in_g << (16 * g);
+            }
+            gc[q * 64 + lane] = g4;
         }
-        gc[lane] = g4;
+    }
+    if (NW > 16) {
+        uint64_t s4 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t lo_e = (uint32_t)q << 10;
+            const uint32_t in_s = lo_e >= n ? 0u : (n - lo_e >= 1024u ? 1024u : n - lo_e);
+            s4 |= (uint64_t)in_s << (16 * q);
+        }
+        sc[lane] = s4;
     }
 
     LEStack st;
     {
         const uint64_t ao = have ? arena_at(a, l) : 0ull;
         st.mem = a.arena + ao;
-        st.ring = (uint32_t *)(smem + LaneEncGeom<NW>::BM_BYTES + LaneEncGeom<NW>::WC_BYTES + LaneEncGeom<NW>::GC_BYTES) + lane;
+        st.ring = (uint32_t *)(smem + LaneEncGeom<NW>::BM_BYTES + LaneEncGeom<NW>::WC_BYTES + LaneEncGeom<NW>::GC_BYTES + LaneEncGeom<NW>::SC_BYTES) + lane;
         st.cap = have ? (uint32_t)(arena_at(a, l + 1) - ao) : 0u;
         st.sp = 0; st.sp_mem = 0; st.draws = 0; st.err = 0; st.mt = a.mt;
     }
@@ -224,18 +254,18 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
             head = q;
 
             // ---- select + remove the k-th alive position
-            uint32_t g = 0;
+            uint32_t g = 0;  // group of 4 words (256 positions) holding the k-th alive position
             if (NW > 4) {
-                const uint64_t gv = gc[lane];
-                const uint32_t c0 = (uint32_t)gv & 0xffffu, c1 = (uint32_t)(gv >> 16) & 0xffffu,
-                               c2 = (uint32_t)(gv >> 32) & 0xffffu;
-                const uint32_t q0 = c0, q1 = c0 + c1, q2 = q1 + c2;
-                uint32_t base = 0;
-                if (k >= q0) { g = 1; base = q0; }
-                if (k >= q1) { g = 2; base = q1; }
-                if (k >= q2) { g = 3; base = q2; }
-                k -= base;
-                gc[lane] = gv - (1ull << (16u * g));
+                uint32_t q = 0;
+                if (NW > 16) {
+                    const uint64_t sv = sc[lane];
+                    q = lane_pick4_u16(sv, k);
+                    sc[lane] = sv - (1ull << (16u * q));
+                }
+                const uint64_t gv = gc[q * 64 + lane];
+                const uint32_t f = lane_pick4_u16(gv, k);
+                gc[q * 64 + lane] = gv - (1ull << (16u * f));
+                g = q * 4u + f;
             }
             const uint32_t wv = wc[g * 64 + lane];
             uint32_t j = 0;
@@ -277,10 +307,15 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// decoder: rank of x among the ids decoded so far.  64 buckets over the top 6 bits of the P-bit universe; LDS per
-// lane: 64 byte counters (4 groups x 16) + 4 u16 group counters; bucket members (u32, unsorted) in a row of
-// `cap` slots in global memory, written in chunks of 4 so that every chunk below ceil(count/4) is fully defined.
-__host__ __device__ inline uint32_t roc_lane_cap(uint32_t n) { return (((n >> 6) * 2u + 12u) + 3u) & ~3u; }
+// decoder: rank of x among the ids decoded so far.  NB = 64 (lists up to 1024 ids) or 256 (up to 4096) buckets over
+// the top 6 / 8 bits of the P-bit universe; LDS per lane: NB byte counters (groups of 16) + u16 group counters (4 per
+// u64) + for NB = 256 4 u16 super-group counters; bucket members (u32, unsorted) in a row of `cap` slots in global
+// memory, written in chunks of 4 so that every chunk below ceil(count/4) is fully defined.
+template <int NB>
+__host__ __device__ inline uint32_t roc_lane_cap_nb(uint32_t n) {
+    return (((n / (uint32_t)NB) * 2u + 12u) + 3u) & ~3u;
+}
+__host__ __device__ inline uint32_t roc_lane_cap(uint32_t n) { return roc_lane_cap_nb<64>(n); }
 
 // sum of the bytes j < t (t <= 8) of the 8-byte value v
 __device__ __forceinline__ uint32_t lane_sum_bytes_below(uint64_t v, uint32_t t) {
@@ -297,21 +332,29 @@ __device__ __forceinline__ uint32_t lane_sum_u16_below(uint64_t v, uint32_t t) {
     return __builtin_amdgcn_sad_u16((uint32_t)(m >> 32), 0u, s);
 }
 
+template <int NB>
 struct LaneDecGeom {
-    static constexpr uint32_t CNT_BYTES = 4 * 64 * 16;  // uint4 cnt[4][64]
-    static constexpr uint32_t GRP_BYTES = 64 * 8;       // u64 grp[64]
-    static constexpr uint32_t RING_BYTES = 8 * 64 * 4;  // u32 oring[8][64]
-    static constexpr uint32_t LDS_BYTES = CNT_BYTES + GRP_BYTES + RING_BYTES;
+    static_assert(NB == 64 || NB == 256, "2 or 3 counter levels");
+    static constexpr uint32_t NG = NB / 16;                   // groups of 16 byte counters
+    static constexpr uint32_t CNT_BYTES = NG * 64 * 16;       // uint4 cnt[NG][64]
+    static constexpr uint32_t GRP_BYTES = (NG / 4) * 64 * 8;  // u64 grp[NG/4][64]
+    static constexpr uint32_t SUP_BYTES = NB > 64 ? 64 * 8 : 0;
+    static constexpr uint32_t RING_BYTES = 8 * 64 * 4;        // u32 oring[8][64]
+    static constexpr uint32_t LDS_BYTES = CNT_BYTES + GRP_BYTES + SUP_BYTES + RING_BYTES;
+    static constexpr uint32_t BITS = NB == 64 ? 6u : 8u;
 };
 
+template <int NB>
 __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const LaneDiv *__restrict__ dtab) {
-    __shared__ __align__(16) unsigned char smem[LaneDecGeom::LDS_BYTES];
+    using G = LaneDecGeom<NB>;
+    __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
     uint4 *cnt4 = (uint4 *)smem;
     unsigned char *cnt1 = smem;
-    uint64_t *grp = (uint64_t *)(smem + LaneDecGeom::CNT_BYTES);
+    uint64_t *grp = (uint64_t *)(smem + G::CNT_BYTES);
+    uint64_t *sup = (uint64_t *)(smem + G::CNT_BYTES + G::GRP_BYTES);
     // decoded ids wait in an 8-deep LDS ring and leave 8 at a time: the 8 stores of a lane hit one or two 64-byte
     // lines back to back, so a line is completed in L2 instead of being written back to HBM partially up to 8 times
-    uint32_t *oring = (uint32_t *)(smem + LaneDecGeom::CNT_BYTES + LaneDecGeom::GRP_BYTES);
+    uint32_t *oring = (uint32_t *)(smem + G::CNT_BYTES + G::GRP_BYTES + G::SUP_BYTES);
     const uint32_t lane = lane_id();
     const uint32_t wi = blockIdx.x * 64u + lane;
     const bool have = wi < a.nwork;
@@ -320,17 +363,19 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
     const uint64_t ooff = have ? (a.out_off ? a.out_off[wi] : a.offsets[l]) : 0ull;
     const uint32_t P = have ? a.prec[l] : 0u;
     const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
-    const uint32_t bsh = P > 6u ? P - 6u : 0u;
-    const uint32_t cap = roc_lane_cap(n);
+    const uint32_t bsh = P > G::BITS ? P - G::BITS : 0u;
+    const uint32_t cap = roc_lane_cap_nb<NB>(n);
 #pragma unroll
-    for (int g = 0; g < 4; g++) cnt4[g * 64 + lane] = make_uint4(0, 0, 0, 0);
-    grp[lane] = 0;
+    for (int g = 0; g < (int)G::NG; g++) cnt4[g * 64 + lane] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < (int)G::NG / 4; q++) grp[q * 64 + lane] = 0;
+    if (NB > 64) sup[lane] = 0;
 
     LStack st;
     const uint32_t W = have ? a.nwords[l] : 0u;
     st.orig = a.words + (have ? a.word_off[l] : 0ull);
     st.mem = a.scratch_words + (have ? a.scratch_off[wi] : 0ull);
-    st.cap = W + 64u; st.sp = W; st.dirty = 0xffffffffu; st.err = 0; st.mt = a.mt;
+    st.cap = roc_dec_stack_cap(n, W); st.sp = W; st.dirty = 0xffffffffu; st.err = 0; st.mt = a.mt;
     st.draws = have ? a.draws[l] : 0u;
     const uint32_t draws0 = st.draws;
     uint64_t head = have ? a.heads[l] : VIDC_RANS_L;
@@ -351,10 +396,17 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
             const uint32_t lo = l_u_pop(head, st, p0);
             const uint32_t x = (hi << 16) | lo;
             // ---- rank of x among the decoded ids
-            const uint32_t b = (bsh >= 32u ? 0u : (x >> bsh)) & 63u;
-            const uint32_t g = b >> 4, j = b & 15u;
-            const uint64_t gv = grp[lane];
-            uint32_t r = lane_sum_u16_below(gv, g);
+            const uint32_t b = (bsh >= 32u ? 0u : (x >> bsh)) & (uint32_t)(NB - 1);
+            const uint32_t g = b >> 4, j = b & 15u;  // group of 16 buckets, bucket inside the group
+            const uint32_t q = g >> 2;               // super-group (0 for NB = 64)
+            uint32_t r = 0;
+            uint64_t sv = 0;
+            if (NB > 64) {
+                sv = sup[lane];
+                r = lane_sum_u16_below(sv, q);
+            }
+            const uint64_t gv = grp[q * 64 + lane];
+            r += lane_sum_u16_below(gv, g & 3u);
             const uint4 cv = cnt4[g * 64 + lane];
             const uint64_t c_lo = ((uint64_t)cv.y << 32) | cv.x, c_hi = ((uint64_t)cv.w << 32) | cv.z;
             r += lane_sum_bytes_below(c_lo, j < 8u ? j : 8u);
@@ -385,7 +437,8 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
                 if ((cb & 3u) == 0u) *(uint4 *)(row + cb) = make_uint4(x, 0xffffffffu, 0xffffffffu, 0xffffffffu);
                 else row[cb] = x;
                 cnt1[(g * 64 + lane) * 16 + j] = (unsigned char)(cb + 1u);
-                grp[lane] = gv + (1ull << (16u * g));
+                grp[q * 64 + lane] = gv + (1ull << (16u * (g & 3u)));
+                if (NB > 64) sup[lane] = sv + (1ull << (16u * q));
                 oring[(i & 7u) * 64u + lane] = x;
             }
         }

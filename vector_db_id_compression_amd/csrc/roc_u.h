@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_u(RocDecArgs a) {
     const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
     const uint32_t W0 = rfl(a.nwords[l]);
     WStack st;
-    ws_init_loaded(st, a.words + rfl64(a.word_off[l]), W0, a.scratch_words + rfl64(a.scratch_off[wi]), W0 + 64u,
+    ws_init_loaded(st, a.words + rfl64(a.word_off[l]), W0, a.scratch_words + rfl64(a.scratch_off[wi]), roc_dec_stack_cap(n, W0),
                    rfl(a.draws[l]), a.mt, VIDC_MT_TABLE);
     const uint32_t draws0 = st.draws;
     uint64_t head = rfl64(a.heads[l]);
