@@ -38,6 +38,8 @@ struct vidc_roc {
     mutable uint64_t last_nonclean = 0;
     // decode_all plan, built on first use (depends only on the immutable metadata)
     mutable std::shared_ptr<struct DecPlanCache> plan_all;
+    // the same plan without its device arrays, built by the encoder while its kernels run (the host would only wait)
+    mutable std::shared_ptr<struct DecPlanCache> plan_ahead;
 };
 
 namespace {
@@ -271,6 +273,10 @@ int finish_encode(vidc_ctx *ctx, vidc_roc *r, const uint32_t *d_arena, uint32_t 
     }
     return VIDC_OK;
 }
+
+// decode_all plan of a freshly encoded object (defined with the planner below)
+std::shared_ptr<DecPlanCache> plan_ahead_build(const vidc_roc *r);
+constexpr uint64_t PLAN_AHEAD_MIN_LISTS = 4096;
 
 int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint64_t *d_ids, bool rows, uint64_t N,
                 uint32_t K, const int32_t *d_rows, int precision_mode, uint32_t flags, vidc_roc **out) {
@@ -538,6 +544,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             VIDC_HIP(hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
             VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
         }
+        // the kernels are in flight and the host has nothing to do until they finish: plan the decode of the whole
+        // object now (7 ms per million lists that decode_all would otherwise spend on its critical path)
+        if (!rows && nlist >= PLAN_AHEAD_MIN_LISTS && r->prec.size() == nlist) r->plan_ahead = plan_ahead_build(r.get());
         kernel_ms += t.stop();
     }
 
@@ -833,8 +842,9 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         for (int c = 0; c < DC_COUNT; c++) {
             order[c] = c;
             const bool u = c == DC_U18 || c == DC_U20, lane = c == DC_LANE || c == DC_LANE64;
-            const double step_us = u ? 0.4 : (lane ? 2.5 : (c == DC_TINY ? 0.5 : 1.0));       // one chain step
-            const double rate = u ? 0.6e3 : (lane ? 10e3 : (c == DC_TINY ? 30e3 : 4e3));       // steps / us, all CUs
+            // (constants fitted to the S2 timeline: general kernels ~2.5 G steps/s while they share the machine)
+            const double step_us = u ? 0.4 : (lane ? 2.5 : (c == DC_TINY ? 0.5 : 1.2));       // one chain step
+            const double rate = u ? 0.6e3 : (lane ? 16e3 : (c == DC_TINY ? 30e3 : 2.5e3));     // steps / us, all CUs
             est[c] = std::max((double)p.max_n[c] * step_us, (double)p.sum_n[c] / rate);
         }
         std::sort(order, order + DC_COUNT, [&](int x, int y) { return est[x] > est[y]; });
@@ -877,7 +887,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 hipLaunchKernelGGL(k_roc_decode_u<20>, dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, st_, b);
                 break;
             case DC_GSMALL:
-                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), 512 * 4, st_, b, 512u, VIDC_DEC_CAP);
+                hipLaunchKernelGGL(k_roc_decode_gen<uint16_t>, dim3(b.nwork), dim3(64), 512 * 2, st_, b, 512u, VIDC_DEC_CAP);
                 break;
             case DC_LANE:
                 hipLaunchKernelGGL(k_roc_decode_lane<64>, dim3((b.nwork + 63u) / 64u), dim3(64), 0, st_, b,
@@ -888,18 +898,22 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
             case DC_G8K:
-                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), 1024 * 4, st_, b, 1024u, VIDC_DEC_CAP);
+                hipLaunchKernelGGL(k_roc_decode_gen<uint16_t>, dim3(b.nwork), dim3(64), 1024 * 2, st_, b, 1024u, VIDC_DEC_CAP);
                 break;
             case DC_G16K:
-                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), 2048 * 4, st_, b, 2048u, VIDC_DEC_CAP);
+                hipLaunchKernelGGL(k_roc_decode_gen<uint16_t>, dim3(b.nwork), dim3(64), 2048 * 2, st_, b, 2048u, VIDC_DEC_CAP);
                 break;
             case DC_GMID:
-                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), (1u << VIDC_DEC_MAX_FB) * 4, st_, b,
+                hipLaunchKernelGGL(k_roc_decode_gen<uint16_t>, dim3(b.nwork), dim3(64), (1u << VIDC_DEC_MAX_FB) * 2, st_, b,
                                    1u << VIDC_DEC_MAX_FB, VIDC_DEC_CAP);
                 break;
-            default:
-                hipLaunchKernelGGL(k_roc_decode_gen, dim3(b.nwork), dim3(64), (1u << VIDC_DEC_MAX_FB) * 4, st_, b,
-                                   1u << VIDC_DEC_MAX_FB, VIDC_DEC_CAP_BIG);
+            default:  // DC_GHUGE: 16-bit row counters unless the class holds a list beyond 65 536 ids
+                if (p.max_n[DC_GHUGE] <= 65536)
+                    hipLaunchKernelGGL(k_roc_decode_gen<uint16_t>, dim3(b.nwork), dim3(64), (1u << VIDC_DEC_MAX_FB) * 2, st_,
+                                       b, 1u << VIDC_DEC_MAX_FB, VIDC_DEC_CAP_BIG);
+                else
+                    hipLaunchKernelGGL(k_roc_decode_gen<uint32_t>, dim3(b.nwork), dim3(64), (1u << VIDC_DEC_MAX_FB) * 4, st_,
+                                       b, 1u << VIDC_DEC_MAX_FB, VIDC_DEC_CAP_BIG);
         }
         VIDC_HIP(hipGetLastError());
         return VIDC_OK;
@@ -1057,6 +1071,16 @@ int vidc_roc_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, cons
     return VIDC_OK;
 }
 
+namespace {
+std::shared_ptr<DecPlanCache> plan_ahead_build(const vidc_roc *r) {
+    std::vector<uint32_t> all(r->nlist);
+    std::iota(all.begin(), all.end(), 0u);
+    auto c = std::make_shared<DecPlanCache>();
+    plan_decode(r, all, false, c->plan);
+    return c;
+}
+}  // namespace
+
 int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out) {
     if (!ctx || !r || (r->ntotal && !d_out)) return VIDC_ERR_INVALID;
     VIDC_TRY(r->prec.size() == r->nlist ? ensure_offsets(r) : ensure_meta(r));
@@ -1067,10 +1091,12 @@ int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out) {
     }
     if (!plan) {
         HostTrace tr("roc decode_all");
-        std::vector<uint32_t> all(r->nlist);
-        std::iota(all.begin(), all.end(), 0u);
-        auto c = std::make_shared<DecPlanCache>();
-        plan_decode(r, all, false, c->plan);
+        std::shared_ptr<DecPlanCache> c;
+        {
+            std::lock_guard<std::mutex> g(r->mu);
+            c = std::move(r->plan_ahead);
+        }
+        if (!c) c = plan_ahead_build(r);
         tr.mark("plan");
         VIDC_HIP(hipSetDevice(ctx->device));
         VIDC_TRY(upload(ctx, c->d_wl, c->plan.wl));

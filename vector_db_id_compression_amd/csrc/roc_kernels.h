@@ -446,9 +446,14 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
 }
 
 // LDS layout (dynamic): u32 rowpref[2^fb_max]
+// CT = counter type of the fine prefix rows: uint16_t for lists up to 65 536 ids (a counter is only read while
+// fewer than n ids are decoded, so it never exceeds 65 535 when it matters; the wrap at the last insert is never
+// read), uint32_t beyond.  Halves the LDS footprint: with 16 KiB per list the two deepest classes of S2 (7 + 10
+// lists per CU) did not fit a CU's LDS together and the second one ran at a third of its occupancy.
+template <typename CT>
 __global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t lds_entries, uint32_t cap) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *rowpref = (uint32_t *)smem;
+    CT *rowpref = (CT *)smem;
     const uint32_t lane = lane_id();
 
     for (uint32_t wi = blockIdx.x; wi < a.nwork; wi += gridDim.x) {
@@ -501,7 +506,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t ld
                 const uint32_t base1 = c ? prev1 : 0u;
                 uint32_t base2 = 0, cnt, rowv = 0;
                 if (rb) {
-                    rowv = lane < RL ? rowpref[(c << rb) + lane] : 0u;
+                    rowv = lane < RL ? (uint32_t)rowpref[(c << rb) + lane] : 0u;
                     const uint32_t prev2 = rl(rowv, (t - 1u) & 63u);
                     base2 = t ? prev2 : 0u;
                     cnt = rl(rowv, t) - base2;
@@ -537,7 +542,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t ld
                     novf++;
                 }
                 C1 += (lane >= c) ? 1u : 0u;
-                if (rb && lane >= t && lane < RL) rowpref[(c << rb) + lane] = rowv + 1u;
+                if (rb && lane >= t && lane < RL) rowpref[(c << rb) + lane] = (CT)(rowv + 1u);
                 ring = wl(x, t64, ring);
             }
             if (lane < steps) {
