@@ -45,6 +45,25 @@ struct vidc_ef {
     DevBuf<Chunk> d_batches;            // (list, batch number) work items of decode_all
     uint64_t nbatches = 0;
     bool has_perm = false;
+    // decode_all acceleration records (one per batch), built on the first bulk decode and kept (guarded by mu)
+    mutable DevBuf<struct EfRec> d_recs;
+    mutable bool recs_ready = false;
+    mutable uint32_t recs_max_cnt = 0;  // largest element count of a batch: sizes the decode kernel's LDS table
+};
+
+// Everything a wavefront needs to decode one batch of 64 high words, in one 48-byte record: with the CSR arrays
+// alone a wavefront walks batch item -> list header (8 arrays) -> directory entry -> high word -> low words, five
+// dependent memory round trips for ~10 KiB of payload, and the kernel is latency x occupancy bound.
+struct EfRec {
+    uint64_t out_pos;   // offsets[l] + done: where the batch's first element goes
+    uint64_t low_base;  // word offset of the list's low stream
+    uint64_t hw_base;   // word offset of the batch's first high word
+    uint32_t done;      // elements of the list before this batch (select directory entry)
+    uint32_t cnt;       // elements of this batch
+    uint32_t nw;        // high words of this batch (<= 64)
+    uint32_t b;         // low bits per element
+    uint32_t bt;        // batch number inside the list
+    uint32_t pad;
 };
 
 namespace {
@@ -459,6 +478,110 @@ __global__ void __launch_bounds__(64) k_ef_decode(const uint64_t *low, const uin
             }
             __syncthreads();
         }
+    }
+}
+
+// one thread per batch: the record of EfRec from the CSR arrays (coalesced over batches, off every decode's path)
+__global__ void k_ef_build_recs(const uint64_t *offsets, const uint64_t *low_off, const uint64_t *high_off,
+                                const uint32_t *lbits, const uint64_t *batch_off, const uint32_t *hrank,
+                                const Chunk *items, uint64_t nbatches, EfRec *recs, unsigned int *max_cnt) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned int mx = 0;
+    for (uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < nbatches; it += stride) {
+        const uint64_t l = items[it].list, bt = items[it].start;
+        const uint64_t m = offsets[l + 1] - offsets[l];
+        const uint64_t nhw = high_off[l + 1] - high_off[l];
+        const uint64_t nb = batch_off[l + 1] - batch_off[l];
+        const uint64_t done = hrank[batch_off[l] + bt];
+        const uint64_t next = bt + 1 < nb ? (uint64_t)hrank[batch_off[l] + bt + 1] : m;
+        EfRec r;
+        r.out_pos = offsets[l] + done;
+        r.low_base = low_off[l];
+        r.hw_base = high_off[l] + bt * 64;
+        r.done = (uint32_t)done;
+        r.cnt = done >= m ? 0u : (uint32_t)((next < m ? next : m) - done);
+        r.nw = (uint32_t)(bt * 64 >= nhw ? 0 : (nhw - bt * 64 < 64 ? nhw - bt * 64 : 64));
+        r.b = lbits[l];
+        r.bt = (uint32_t)bt;
+        r.pad = 0;
+        recs[it] = r;
+        mx = r.cnt > mx ? r.cnt : mx;
+    }
+    if (mx) atomicMax(max_cnt, mx);
+}
+
+// decode_all with batch records: record -> {high word, low words of the first 512 elements} -> stores.  The low
+// words of rank-major element r only depend on `done` (in the record), not on the high word, so both loads leave
+// together; two dependent round trips instead of five.
+__global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const uint64_t *high, const EfRec *recs,
+                                                      uint32_t nwork, uint64_t *out) {
+    extern __shared__ uint16_t spos[];  // max elements per batch of this object (<= EF_BATCH_BITS) entries
+    const uint32_t lane = lane_id();
+    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        // the record as 12 dwords through one vector load, broadcast to SGPRs
+        const uint32_t *rp = (const uint32_t *)(recs + wi);
+        const uint32_t rv = lane < 12u ? rp[lane] : 0u;
+        const uint64_t out_pos = ((uint64_t)rl(rv, 1) << 32) | rl(rv, 0);
+        const uint64_t low_base = ((uint64_t)rl(rv, 3) << 32) | rl(rv, 2);
+        const uint64_t hw_base = ((uint64_t)rl(rv, 5) << 32) | rl(rv, 4);
+        const uint32_t done = rl(rv, 6), tot = rl(rv, 7), nw = rl(rv, 8), b = rl(rv, 9), bt = rl(rv, 10);
+        if (!tot) continue;
+        const uint64_t keep = b ? ((b >= 64 ? 0ull : (1ull << b)) - 1ull) : 0ull;
+        const uint64_t *lw = low + low_base;
+        uint64_t word = lane < nw ? high[hw_base + lane] : 0ull;
+        uint64_t a[8], bw[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {  // both words, unconditionally (a padding word follows every stream)
+            const uint32_t rr = lane + 64 * k;
+            const uint64_t bp = ((uint64_t)done + (rr < tot ? rr : 0u)) * b;
+            a[k] = b ? lw[bp >> 6] : 0ull;
+            bw[k] = b ? lw[(bp >> 6) + 1] : 0ull;
+        }
+        const uint32_t c = popc64(word);
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+            if (lane >= (uint32_t)o) incl += v;
+        }
+        uint32_t r = incl - c;
+        {   // transpose: position of every set bit, indexed by its rank inside the batch (32-bit halves: one
+            // v_ffbl + two ALU ops per bit instead of the 64-bit sequence)
+            uint32_t h0 = (uint32_t)word, h1 = (uint32_t)(word >> 32);
+            const uint32_t p0 = lane * 64u;
+            while (h0) {
+                spos[r++] = (uint16_t)(p0 + (uint32_t)__builtin_ctz(h0));
+                h0 &= h0 - 1u;
+            }
+            while (h1) {
+                spos[r++] = (uint16_t)(p0 + 32u + (uint32_t)__builtin_ctz(h1));
+                h1 &= h1 - 1u;
+            }
+        }
+        __syncthreads();
+        const uint64_t pbase = (uint64_t)bt * EF_BATCH_BITS;
+        for (uint32_t r0 = 0; r0 < tot; r0 += 512) {
+            if (r0) {
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {
+                    const uint32_t rr = r0 + lane + 64 * k;
+                    const uint64_t bp = ((uint64_t)done + (rr < tot ? rr : 0u)) * b;
+                    a[k] = b ? lw[bp >> 6] : 0ull;
+                    bw[k] = b ? lw[(bp >> 6) + 1] : 0ull;
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t rr = r0 + lane + 64 * k;
+                if (rr < tot) {
+                    const uint64_t rank = (uint64_t)done + rr;
+                    const uint32_t sh = (uint32_t)((rank * b) & 63);
+                    const uint64_t lo = ((a[k] >> sh) | (sh ? bw[k] << (64 - sh) : 0ull)) & keep;
+                    out[out_pos + rr] = ((pbase + spos[rr] - rank) << b) | lo;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -951,13 +1074,30 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
     if (!ctx || !e || (e->ntotal && !d_out)) return VIDC_ERR_INVALID;
     if (!e->ntotal) return VIDC_OK;
     VIDC_HIP(hipSetDevice(ctx->device));
+    if (e->nbatches) {  // batch records: built once per object, on its first bulk decode
+        std::lock_guard<std::mutex> g(e->mu);
+        if (!e->recs_ready) {
+            VIDC_TRY(e->d_recs.alloc(e->nbatches, ctx->dpool));
+            Scratch s_mx;
+            Pinned h_mx;
+            VIDC_TRY(s_mx.get(ctx, 16));
+            VIDC_TRY(h_mx.get(ctx, 16));
+            VIDC_HIP(hipMemsetAsync(s_mx.p, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_ef_build_recs, dim3((uint32_t)std::min<uint64_t>((e->nbatches + 255) / 256, 4096)),
+                               dim3(256), 0, ctx->stream, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p, e->d_lbits.p,
+                               e->d_batch_off.p, e->d_hrank.p, e->d_batches.p, e->nbatches, e->d_recs.p,
+                               s_mx.as<unsigned int>());
+            VIDC_HIP(hipGetLastError());
+            VIDC_HIP(hipMemcpyAsync(h_mx.p, s_mx.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            VIDC_HIP(hipStreamSynchronize(ctx->stream));  // another context may use the records next
+            e->recs_max_cnt = *h_mx.as<unsigned int>();
+            e->recs_ready = true;
+        }
+    }
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     if (e->nbatches)
-        hipLaunchKernelGGL(k_ef_decode, dim3((uint32_t)std::min<uint64_t>(e->nbatches, (uint64_t)ctx->num_cu * 256)),
-                           dim3(64), 0, ctx->stream, e->d_low.p, e->d_high.p, e->d_offsets.p, e->d_low_off.p,
-                           e->d_high_off.p, e->d_lbits.p, e->d_batch_off.p, e->d_hrank.p, (uint32_t)e->nbatches,
-                           e->d_batches.p, (const uint64_t *)nullptr, (const uint64_t *)nullptr, d_out,
-                           (int32_t *)nullptr, 0u);
+        hipLaunchKernelGGL(k_ef_decode_rec, dim3((uint32_t)std::min<uint64_t>(e->nbatches, (uint64_t)ctx->num_cu * 256)),
+                           dim3(64), std::min<uint32_t>(EF_BATCH_BITS, (e->recs_max_cnt + 63u) & ~63u) * 2, ctx->stream, e->d_low.p, e->d_high.p, e->d_recs.p, (uint32_t)e->nbatches, d_out);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
