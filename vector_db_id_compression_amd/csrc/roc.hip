@@ -501,8 +501,14 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             }
             VIDC_TRY(launch_gen_on(ctx->stream, d_wl + base[5], (uint32_t)wl_c3.size(), rl3));
         }
-        // aux 0: mid-size general lists and bitmap-18 lists
-        VIDC_TRY(launch_gen_on(ctx->aux[0], d_wl + base[4], (uint32_t)wl_c2.size(), 8));
+        // The lane-per-list kernels and the throughput-bound general classes must not share the machine: on S2 the
+        // 64-word lane class took 69 ms next to the 26 316-list general class (49 ms) -- 9 ms and ~35 ms when each
+        // has the CUs to itself (the lane strips take 141 KiB of a CU's LDS, the general waves the issue slots).
+        // With lane classes in the call they go first on aux 1 and the general classes queue behind them; the long
+        // chains on the main stream overlap with all of it.
+        const bool lanes_present = !wl_l4.empty() || !wl_l16.empty() || !wl_l64.empty();
+        // aux 0: mid-size general lists (calls without lane classes) and bitmap-18 lists
+        if (!lanes_present) VIDC_TRY(launch_gen_on(ctx->aux[0], d_wl + base[4], (uint32_t)wl_c2.size(), 8));
         if (!wl_u18.empty()) {
             RocEncArgs b = a;
             b.worklist = d_wl + base[1]; b.nwork = (uint32_t)wl_u18.size();
@@ -510,8 +516,8 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             else hipLaunchKernelGGL((k_roc_encode_u<18, false>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->aux[0], b);
             VIDC_HIP(hipGetLastError());
         }
-        // aux 1: short general lists and the lane-per-list kernels; aux 2: tiny lists
-        VIDC_TRY(launch_gen_on(ctx->aux[1], d_wl + base[3], (uint32_t)wl_c1.size(), 1));
+        // aux 1: the lane-per-list kernels, then the general classes; aux 2: tiny lists
+        if (!lanes_present) VIDC_TRY(launch_gen_on(ctx->aux[1], d_wl + base[3], (uint32_t)wl_c1.size(), 1));
         for (int cls = 2; cls >= 0; cls--) {  // longest chains first
             const std::vector<uint32_t> &w = cls == 2 ? wl_l64 : (cls ? wl_l16 : wl_l4);
             if (w.empty()) continue;
@@ -519,13 +525,31 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             b.worklist = d_wl + base[6 + cls]; b.nwork = (uint32_t)w.size();
             const dim3 grid((b.nwork + 63u) / 64u);
             const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
-            if (cls == 2 && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<64, true>), grid, dim3(64), 0, ctx->aux[1], b, dt);
-            else if (cls == 2) hipLaunchKernelGGL((k_roc_encode_lane<64, false>), grid, dim3(64), 0, ctx->aux[1], b, dt);
+            if (cls == 2) {
+                // lists are sorted longest first: the leading wavefronts need the 64-word strips (46.5 KiB of LDS,
+                // 3 per CU), everything from the first wavefront whose longest list has <= 2048 ids the 32-word
+                // ones (27.5 KiB, 5 per CU)
+                uint32_t n_big = 0;
+                while (n_big < b.nwork && r->offsets[w[n_big] + 1] - r->offsets[w[n_big]] > 2048) n_big++;
+                n_big = std::min<uint32_t>(b.nwork, (n_big + 63u) & ~63u);
+                RocEncArgs b2 = b;
+                b2.worklist = b.worklist + n_big; b2.nwork = b.nwork - n_big;
+                b.nwork = n_big;
+                const dim3 g1((b.nwork + 63u) / 64u), g2((b2.nwork + 63u) / 64u);
+                if (b.nwork && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<64, true>), g1, dim3(64), 0, ctx->aux[1], b, dt);
+                else if (b.nwork) hipLaunchKernelGGL((k_roc_encode_lane<64, false>), g1, dim3(64), 0, ctx->aux[1], b, dt);
+                if (b2.nwork && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<32, true>), g2, dim3(64), 0, ctx->aux[1], b2, dt);
+                else if (b2.nwork) hipLaunchKernelGGL((k_roc_encode_lane<32, false>), g2, dim3(64), 0, ctx->aux[1], b2, dt);
+            }
             else if (cls == 0 && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<4, true>), grid, dim3(64), 0, ctx->aux[1], b, dt);
             else if (cls == 0) hipLaunchKernelGGL((k_roc_encode_lane<4, false>), grid, dim3(64), 0, ctx->aux[1], b, dt);
             else if (want_perm) hipLaunchKernelGGL((k_roc_encode_lane<16, true>), grid, dim3(64), 0, ctx->aux[1], b, dt);
             else hipLaunchKernelGGL((k_roc_encode_lane<16, false>), grid, dim3(64), 0, ctx->aux[1], b, dt);
             VIDC_HIP(hipGetLastError());
+        }
+        if (lanes_present) {
+            VIDC_TRY(launch_gen_on(ctx->aux[1], d_wl + base[4], (uint32_t)wl_c2.size(), 8));
+            VIDC_TRY(launch_gen_on(ctx->aux[1], d_wl + base[3], (uint32_t)wl_c1.size(), 1));
         }
         if (ntiny) {
             RocEncArgs b = a;

@@ -150,7 +150,7 @@ __device__ __forceinline__ uint32_t l_u_pop(uint64_t &head, LStack &s, uint32_t 
 // element e of lane t lives at base + (e * 64 + t) * size: conflict-free for any per-lane e
 template <int NW>
 struct LaneEncGeom {
-    static_assert(NW == 4 || NW == 16 || NW == 64, "1, 2 or 3 counter levels above the words");
+    static_assert(NW == 4 || NW == 16 || NW == 32 || NW == 64, "1, 2 or 3 counter levels above the words");
     static constexpr uint32_t BM_BYTES = NW * 64 * 8;
     static constexpr uint32_t WC_BYTES = (NW / 4) * 64 * 4;
     static constexpr uint32_t GC_BYTES = NW > 4 ? (NW / 16) * 64 * 8 : 0;
