@@ -61,6 +61,11 @@ void vidc_ctx_destroy(vidc_ctx *ctx);
 int vidc_ctx_set_stream(vidc_ctx *ctx, void *hip_stream);
 int vidc_ctx_reset_stream(vidc_ctx *ctx);
 int vidc_ctx_synchronize(vidc_ctx *ctx);
+/* A context caches the device and pinned-host blocks its calls used (steady-state encode / decode calls neither
+ * allocate nor free; a 10^9-id decode leaves several GB of scratch behind).  vidc_ctx_trim synchronises the
+ * context's stream and releases every cached block that is not in use; *freed_bytes (optional) = device + pinned
+ * bytes returned to the driver.  Blocks held by live objects are untouched. */
+int vidc_ctx_trim(vidc_ctx *ctx, uint64_t *freed_bytes);
 /* Device memory helpers for hosts without their own allocator (Python uses torch tensors instead). */
 int vidc_dev_alloc(vidc_ctx *ctx, size_t bytes, void **dev_ptr);
 int vidc_dev_free(vidc_ctx *ctx, void *dev_ptr);

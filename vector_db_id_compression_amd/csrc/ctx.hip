@@ -220,6 +220,32 @@ int vidc_ctx_synchronize(vidc_ctx *c) {
     return VIDC_OK;
 }
 
+int vidc_ctx_trim(vidc_ctx *c, uint64_t *freed_bytes) {
+    if (!c) return VIDC_ERR_INVALID;
+    VIDC_HIP(hipSetDevice(c->device));
+    VIDC_HIP(hipStreamSynchronize(c->stream));
+    uint64_t freed = 0;
+    if (c->dpool) {
+        std::lock_guard<std::mutex> g(c->dpool->m);
+        for (auto &b : c->dpool->blocks)
+            if (!b.in_use && b.p) {
+                (void)hipFree(b.p);
+                freed += b.bytes;
+                b.p = nullptr;
+                b.bytes = 0;
+            }
+    }
+    for (auto &b : c->ppool)
+        if (!b.in_use && b.p) {
+            (void)hipHostFree(b.p);
+            freed += b.bytes;
+            b.p = nullptr;
+            b.bytes = 0;
+        }
+    if (freed_bytes) *freed_bytes = freed;
+    return VIDC_OK;
+}
+
 int vidc_dev_alloc(vidc_ctx *c, size_t bytes, void **p) {
     if (!c || !p) return VIDC_ERR_INVALID;
     VIDC_HIP(hipSetDevice(c->device));
