@@ -119,6 +119,33 @@ def test_elias_fano_edge_universes(oracle):
         assert np.array_equal(low, e["low"]) and np.array_equal(high, e["high"])
 
 
+def test_elias_fano_narrow_and_wide_encoders_agree(oracle):
+    """Objects whose ids all fit 32 bits take the 32-bit single-pass encoder; one id beyond 2^32 anywhere switches
+    the object to the 64-bit kernel.  Both must write the same streams for the lists they share."""
+    from vector_db_id_compression_amd.codecs import EfLists
+
+    rng = np.random.default_rng(321)
+    sizes = [1, 2, 63, 64, 65, 511, 512, 513, 1024, 1500, 5000, 70000]
+    lists = [np.sort(rng.choice(1 << 31, size=n, replace=False).astype(np.uint64) * np.uint64(2) + np.uint64(1))
+             for n in sizes]  # odd ids up to 2^32 - 1
+    lists.append(np.arange(3000, dtype=np.uint64))              # dense: l = 0, no low stream
+    lists.append(np.array([0xffffffff], dtype=np.uint64))       # the largest narrow id
+    wide = lists + [np.array([7, 1 << 32, (1 << 45) + 3], dtype=np.uint64)]
+    got = []
+    for ls in (lists, wide):
+        off = np.concatenate([[0], np.cumsum([c.size for c in ls])]).astype(np.uint64)
+        ef = EfLists.encode(off, np.concatenate(ls))
+        assert np.array_equal(ef.decode_all().cpu().numpy().view(np.uint64), np.concatenate(ls))
+        got.append([ef.export(l) for l in range(len(lists))])
+    for l, c in enumerate(lists):
+        (lo_a, hi_a, lb_a, hb_a), (lo_b, hi_b, lb_b, hb_b) = got[0][l], got[1][l]
+        assert (lb_a, hb_a) == (lb_b, hb_b) and np.array_equal(lo_a, lo_b) and np.array_equal(hi_a, hi_b), f"list {l}"
+        if c.size <= 5000:
+            e = oracle.ef_build(c)
+            assert (lb_a, hb_a) == (e["low_nbits"], e["high_nbits"])
+            assert np.array_equal(lo_a, e["low"]) and np.array_equal(hi_a, e["high"]), f"list {l}"
+
+
 def test_full_size_properties():
     """Config-2 shape at full size: EF and packed round-trip every id, sizes match SURVEY 6."""
     from vector_db_id_compression_amd import synth
