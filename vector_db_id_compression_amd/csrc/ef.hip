@@ -49,6 +49,7 @@ struct vidc_ef {
     mutable DevBuf<struct EfRec> d_recs;
     mutable bool recs_ready = false;
     mutable uint32_t recs_max_cnt = 0;  // largest element count of a batch: sizes the decode kernel's LDS table
+    bool narrow = false;  // every id < 2^32 and every list < 2^30 ids (known from the encoder): 32-bit decode kernel
 };
 
 // Everything a wavefront needs to decode one batch of 64 high words, in one 48-byte record: with the CSR arrays
@@ -707,6 +708,78 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
     }
 }
 
+// the same for objects whose ids fit 32 bits: low bits come as 32-bit word pairs and the value is assembled in one
+// register (the 64-bit version reads 16 bytes of low words per element and does two-register shifts)
+__global__ void __launch_bounds__(64) k_ef_decode_rec32(const uint64_t *low, const uint64_t *high, const EfRec *recs,
+                                                        uint32_t nwork, uint64_t *out) {
+    extern __shared__ uint16_t spos[];
+    const uint32_t lane = lane_id();
+    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const uint32_t *rp = (const uint32_t *)(recs + wi);
+        const uint32_t rv = lane < 12u ? rp[lane] : 0u;
+        const uint64_t out_pos = ((uint64_t)rl(rv, 1) << 32) | rl(rv, 0);
+        const uint64_t low_base = ((uint64_t)rl(rv, 3) << 32) | rl(rv, 2);
+        const uint64_t hw_base = ((uint64_t)rl(rv, 5) << 32) | rl(rv, 4);
+        const uint32_t done = rl(rv, 6), tot = rl(rv, 7), nw = rl(rv, 8), b = rl(rv, 9), bt = rl(rv, 10);
+        if (!tot) continue;
+        const uint32_t keep = b ? ((b >= 32u ? 0u : (1u << b)) - 1u) : 0u;
+        const uint32_t *lw = (const uint32_t *)(low + low_base);
+        uint64_t word = lane < nw ? high[hw_base + lane] : 0ull;
+        uint32_t a[8], bw[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {  // both halves, unconditionally (a padding word follows every stream)
+            const uint32_t rr = lane + 64 * k;
+            const uint64_t bp = ((uint64_t)done + (rr < tot ? rr : 0u)) * b;
+            a[k] = b ? lw[bp >> 5] : 0u;
+            bw[k] = b ? lw[(bp >> 5) + 1] : 0u;
+        }
+        const uint32_t c = popc64(word);
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+            if (lane >= (uint32_t)o) incl += v;
+        }
+        uint32_t r = incl - c;
+        {
+            uint32_t h0 = (uint32_t)word, h1 = (uint32_t)(word >> 32);
+            const uint32_t p0 = lane * 64u;
+            while (h0) {
+                spos[r++] = (uint16_t)(p0 + (uint32_t)__builtin_ctz(h0));
+                h0 &= h0 - 1u;
+            }
+            while (h1) {
+                spos[r++] = (uint16_t)(p0 + 32u + (uint32_t)__builtin_ctz(h1));
+                h1 &= h1 - 1u;
+            }
+        }
+        __syncthreads();
+        const uint32_t pbase = bt * EF_BATCH_BITS;
+        for (uint32_t r0 = 0; r0 < tot; r0 += 512) {
+            if (r0) {
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {
+                    const uint32_t rr = r0 + lane + 64 * k;
+                    const uint64_t bp = ((uint64_t)done + (rr < tot ? rr : 0u)) * b;
+                    a[k] = b ? lw[bp >> 5] : 0u;
+                    bw[k] = b ? lw[(bp >> 5) + 1] : 0u;
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t rr = r0 + lane + 64 * k;
+                if (rr < tot) {
+                    const uint32_t rank = done + rr;
+                    const uint32_t sh = (uint32_t)(((uint64_t)rank * b) & 31u);
+                    const uint32_t lo = ((a[k] >> sh) | (sh ? bw[k] << (32u - sh) : 0u)) & keep;
+                    out[out_pos + rr] = (uint64_t)(((pbase + spos[rr] - rank) << b) | lo);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // graph rows (<= 64 edges): one row per LANE.  A row's high stream is 3-4 words and its low stream ~100 bytes, so
 // a wavefront per row (above) leaves the machine mostly idle; here 64 rows advance per instruction.  Values are
 // staged in LDS (element e of row t at stage[e * 65 + t]) and written one row per iteration: contiguous stores.
@@ -1048,6 +1121,7 @@ int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t 
     e->total_bits = t[3];
     const uint32_t n_unsorted = (uint32_t)(t[4] & 0xffffffffu);
     const bool wide_ids = (t[4] >> 32) != 0;
+    e->narrow = !wide_ids;
     VIDC_TRY(e->d_low.alloc(low_words ? low_words : 1, ctx->dpool));
     VIDC_TRY(e->d_high.alloc(high_words ? high_words : 1, ctx->dpool));
     VIDC_HIP(hipMemsetAsync(e->d_high.p, 0, (high_words ? high_words : 1) * 8, ctx->stream));
@@ -1226,7 +1300,11 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
         }
     }
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    if (e->nbatches)
+    if (e->nbatches && e->narrow)
+        hipLaunchKernelGGL(k_ef_decode_rec32, dim3((uint32_t)std::min<uint64_t>(e->nbatches, (uint64_t)ctx->num_cu * 256)),
+                           dim3(64), std::min<uint32_t>(EF_BATCH_BITS, (e->recs_max_cnt + 63u) & ~63u) * 2, ctx->stream,
+                           e->d_low.p, e->d_high.p, e->d_recs.p, (uint32_t)e->nbatches, d_out);
+    else if (e->nbatches)
         hipLaunchKernelGGL(k_ef_decode_rec, dim3((uint32_t)std::min<uint64_t>(e->nbatches, (uint64_t)ctx->num_cu * 256)),
                            dim3(64), std::min<uint32_t>(EF_BATCH_BITS, (e->recs_max_cnt + 63u) & ~63u) * 2, ctx->stream, e->d_low.p, e->d_high.p, e->d_recs.p, (uint32_t)e->nbatches, d_out);
     VIDC_HIP(hipGetLastError());
