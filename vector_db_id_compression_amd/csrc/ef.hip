@@ -482,6 +482,12 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *sorted_ids,
     }
 }
 
+// the padding word behind every non-empty list's low stream: the only low words the encoder kernels do not write
+__global__ void k_ef_zero_low_pads(const uint64_t *low_off, uint32_t nlist, uint64_t *low) {
+    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x)
+        if (low_off[l + 1] > low_off[l]) low[low_off[l + 1] - 1] = 0ull;
+}
+
 // the same directory rebuilt from the high stream alone (import of a saved object): one wavefront per list,
 // running popcount over its batches of 64 words
 __global__ void __launch_bounds__(64) k_ef_hrank_from_high(const uint64_t *high, const uint64_t *high_off,
@@ -1175,7 +1181,9 @@ int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t 
     }
     // pass 3: the two bit streams
     if (e->ntotal) {
-        VIDC_HIP(hipMemsetAsync(e->d_low.p, 0, (low_words ? low_words : 1) * 8, ctx->stream));
+        // (a memset of the whole low stream -- 2 bytes per id -- cost more than the geometry kernels together)
+        hipLaunchKernelGGL(k_ef_zero_low_pads, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 2048)), dim3(256), 0,
+                           ctx->stream, e->d_low_off.p, (uint32_t)nlist, e->d_low.p);
         if (assume_sorted) {
             VIDC_HIP(hipMemsetAsync(s_tot.p, 0, sizeof(EfTotals), ctx->stream));
             VIDC_TRY(timed([&] {

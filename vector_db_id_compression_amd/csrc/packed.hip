@@ -77,6 +77,13 @@ __global__ void __launch_bounds__(64) k_packed_encode(const uint64_t *ids, const
     }
 }
 
+// the padding word behind every list (the only words the encoder's chunks do not write): zeroing the whole stream
+// first cost a quarter of the encode time
+__global__ void k_packed_zero_pads(const uint64_t *word_off, uint32_t nlist, uint64_t *words) {
+    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x)
+        words[word_off[l + 1] - 1] = 0ull;
+}
+
 // one wavefront per chunk: lane t decodes ids t, t+64, ... (coalesced 8-byte stores).  Both words an id can touch
 // are loaded unconditionally for all 8 ids of the lane before anything is consumed (16 independent loads in flight
 // per lane; a padding word follows every list): a conditional second load costs a second memory round trip per id.
@@ -326,7 +333,8 @@ int vidc_packed_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, c
     VIDC_HIP(hipMemsetAsync(s_err.p, 0, 4, ctx->stream));
     if (p->total_words) {
         VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-        VIDC_HIP(hipMemsetAsync(p->d_words.p, 0, p->total_words * 8, ctx->stream));  // padding words
+        hipLaunchKernelGGL(k_packed_zero_pads, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 2048)), dim3(256), 0,
+                           ctx->stream, p->d_word_off.p, (uint32_t)nlist, p->d_words.p);
         uint32_t grid = (uint32_t)std::min<uint64_t>(p->nchunks, (uint64_t)ctx->num_cu * 256);
         // ids must fit the field (FAISS_THROW_IF_NOT(ids_in[i] >= 0 && ids_in[i] < ntotal), :87)
         uint64_t limit = ~0ull;
