@@ -149,6 +149,7 @@ int vidc_ctx_create(int device, vidc_ctx **out) {
         hipStreamCreateWithFlags(&c->aux[1], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->aux[2], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        [&] { for (auto &ev : c->tev) if (hipEventCreate(&ev) != hipSuccess) return true; return false; }() ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join[1], hipEventDisableTiming) != hipSuccess ||
@@ -193,6 +194,7 @@ void vidc_ctx_destroy(vidc_ctx *c) {
     if (c->d_ltab) (void)hipFree(c->d_ltab);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto &ev : c->tev) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (int i = 0; i < 3; i++) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);

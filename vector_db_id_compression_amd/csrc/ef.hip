@@ -1060,15 +1060,13 @@ int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t 
     const uint64_t nlist = e->nlist;
     const uint32_t nl32 = (uint32_t)nlist;
     double kernel_ms = 0;
+    bool check_unsorted = false;
+    VidcPhaseTimer pt(ctx);  // phases are timed without a host synchronisation each
     auto timed = [&](auto &&fn) -> int {
-        VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+        pt.begin();
         fn();
         VIDC_HIP(hipGetLastError());
-        VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-        VIDC_HIP(hipEventSynchronize(ctx->ev1));
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-        kernel_ms += ms;
+        pt.end();
         return VIDC_OK;
     };
     const uint32_t lgrid = (uint32_t)std::min<uint64_t>((nlist + 255) / 256 + 1, 2048);
@@ -1196,12 +1194,10 @@ int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t 
                                        e->d_low_off.p, e->d_high_off.p, e->d_lbits.p, e->d_universe.p, e->d_chunks.p,
                                        e->nchunks, e->d_low.p, e->d_high.p, &s_tot.as<EfTotals>()->n_unsorted);
             }));
+            // the "some list was not ascending" flag comes back with the final synchronisation (the directory
+            // kernels below are cheap and simply wasted in that rare case)
             VIDC_HIP(hipMemcpyAsync(t, s_tot.p, sizeof(EfTotals), hipMemcpyDeviceToHost, ctx->stream));
-            VIDC_HIP(hipStreamSynchronize(ctx->stream));
-            if ((uint32_t)(t[1] & 0xffffffffu)) {
-                *retry = true;
-                return VIDC_OK;
-            }
+            check_unsorted = true;
         } else {
             VIDC_TRY(timed([&] {
                 hipLaunchKernelGGL(k_ef_low, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p,
@@ -1224,7 +1220,9 @@ int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t 
         }));
     }
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    kernel_ms += pt.collect();
     ctx->last_kernel_ms = kernel_ms;
+    if (check_unsorted && (uint32_t)(t[1] & 0xffffffffu)) *retry = true;
     return VIDC_OK;
 }
 
