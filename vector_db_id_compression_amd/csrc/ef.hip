@@ -642,9 +642,14 @@ __global__ void k_ef_build_recs(const uint64_t *offsets, const uint64_t *low_off
 // decode_all with batch records: record -> {high word, low words of the first 512 elements} -> stores.  The low
 // words of rank-major element r only depend on `done` (in the record), not on the high word, so both loads leave
 // together; two dependent round trips instead of five.
+// LW = uint64_t: any ids.  LW = uint32_t: objects whose ids fit 32 bits -- low bits come as 32-bit word pairs and the
+// value is assembled in one register (the 64-bit version reads 16 bytes of low words per element and does
+// two-register shifts: 0.19 vs 0.13 ms per 64 M ids).
+template <typename LW>
 __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const uint64_t *high, const EfRec *recs,
                                                       uint32_t nwork, uint64_t *out) {
     extern __shared__ uint16_t spos[];  // max elements per batch of this object (<= EF_BATCH_BITS) entries
+    constexpr uint32_t WB = sizeof(LW) * 8u, WSH = sizeof(LW) == 8 ? 6u : 5u;
     const uint32_t lane = lane_id();
     for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
         // the record as 12 dwords through one vector load, broadcast to SGPRs
@@ -655,16 +660,16 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
         const uint64_t hw_base = ((uint64_t)rl(rv, 5) << 32) | rl(rv, 4);
         const uint32_t done = rl(rv, 6), tot = rl(rv, 7), nw = rl(rv, 8), b = rl(rv, 9), bt = rl(rv, 10);
         if (!tot) continue;
-        const uint64_t keep = b ? ((b >= 64 ? 0ull : (1ull << b)) - 1ull) : 0ull;
-        const uint64_t *lw = low + low_base;
+        const LW keep = b ? (LW)(((b >= WB ? (LW)0 : ((LW)1 << b))) - (LW)1) : (LW)0;
+        const LW *lw = (const LW *)(low + low_base);
         uint64_t word = lane < nw ? high[hw_base + lane] : 0ull;
-        uint64_t a[8], bw[8];
+        LW a[8], bw[8];
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {  // both words, unconditionally (a padding word follows every stream)
             const uint32_t rr = lane + 64 * k;
             const uint64_t bp = ((uint64_t)done + (rr < tot ? rr : 0u)) * b;
-            a[k] = b ? lw[bp >> 6] : 0ull;
-            bw[k] = b ? lw[(bp >> 6) + 1] : 0ull;
+            a[k] = b ? lw[bp >> WSH] : (LW)0;
+            bw[k] = b ? lw[(bp >> WSH) + 1] : (LW)0;
         }
         const uint32_t c = popc64(word);
         uint32_t incl = c;
@@ -688,87 +693,15 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
             }
         }
         __syncthreads();
-        const uint64_t pbase = (uint64_t)bt * EF_BATCH_BITS;
+        const LW pbase = (LW)bt * EF_BATCH_BITS;
         for (uint32_t r0 = 0; r0 < tot; r0 += 512) {
             if (r0) {
 #pragma unroll
                 for (uint32_t k = 0; k < 8; k++) {
                     const uint32_t rr = r0 + lane + 64 * k;
                     const uint64_t bp = ((uint64_t)done + (rr < tot ? rr : 0u)) * b;
-                    a[k] = b ? lw[bp >> 6] : 0ull;
-                    bw[k] = b ? lw[(bp >> 6) + 1] : 0ull;
-                }
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                const uint32_t rr = r0 + lane + 64 * k;
-                if (rr < tot) {
-                    const uint64_t rank = (uint64_t)done + rr;
-                    const uint32_t sh = (uint32_t)((rank * b) & 63);
-                    const uint64_t lo = ((a[k] >> sh) | (sh ? bw[k] << (64 - sh) : 0ull)) & keep;
-                    out[out_pos + rr] = ((pbase + spos[rr] - rank) << b) | lo;
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// the same for objects whose ids fit 32 bits: low bits come as 32-bit word pairs and the value is assembled in one
-// register (the 64-bit version reads 16 bytes of low words per element and does two-register shifts)
-__global__ void __launch_bounds__(64) k_ef_decode_rec32(const uint64_t *low, const uint64_t *high, const EfRec *recs,
-                                                        uint32_t nwork, uint64_t *out) {
-    extern __shared__ uint16_t spos[];
-    const uint32_t lane = lane_id();
-    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const uint32_t *rp = (const uint32_t *)(recs + wi);
-        const uint32_t rv = lane < 12u ? rp[lane] : 0u;
-        const uint64_t out_pos = ((uint64_t)rl(rv, 1) << 32) | rl(rv, 0);
-        const uint64_t low_base = ((uint64_t)rl(rv, 3) << 32) | rl(rv, 2);
-        const uint64_t hw_base = ((uint64_t)rl(rv, 5) << 32) | rl(rv, 4);
-        const uint32_t done = rl(rv, 6), tot = rl(rv, 7), nw = rl(rv, 8), b = rl(rv, 9), bt = rl(rv, 10);
-        if (!tot) continue;
-        const uint32_t keep = b ? ((b >= 32u ? 0u : (1u << b)) - 1u) : 0u;
-        const uint32_t *lw = (const uint32_t *)(low + low_base);
-        uint64_t word = lane < nw ? high[hw_base + lane] : 0ull;
-        uint32_t a[8], bw[8];
-#pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {  // both halves, unconditionally (a padding word follows every stream)
-            const uint32_t rr = lane + 64 * k;
-            const uint64_t bp = ((uint64_t)done + (rr < tot ? rr : 0u)) * b;
-            a[k] = b ? lw[bp >> 5] : 0u;
-            bw[k] = b ? lw[(bp >> 5) + 1] : 0u;
-        }
-        const uint32_t c = popc64(word);
-        uint32_t incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
-            if (lane >= (uint32_t)o) incl += v;
-        }
-        uint32_t r = incl - c;
-        {
-            uint32_t h0 = (uint32_t)word, h1 = (uint32_t)(word >> 32);
-            const uint32_t p0 = lane * 64u;
-            while (h0) {
-                spos[r++] = (uint16_t)(p0 + (uint32_t)__builtin_ctz(h0));
-                h0 &= h0 - 1u;
-            }
-            while (h1) {
-                spos[r++] = (uint16_t)(p0 + 32u + (uint32_t)__builtin_ctz(h1));
-                h1 &= h1 - 1u;
-            }
-        }
-        __syncthreads();
-        const uint32_t pbase = bt * EF_BATCH_BITS;
-        for (uint32_t r0 = 0; r0 < tot; r0 += 512) {
-            if (r0) {
-#pragma unroll
-                for (uint32_t k = 0; k < 8; k++) {
-                    const uint32_t rr = r0 + lane + 64 * k;
-                    const uint64_t bp = ((uint64_t)done + (rr < tot ? rr : 0u)) * b;
-                    a[k] = b ? lw[bp >> 5] : 0u;
-                    bw[k] = b ? lw[(bp >> 5) + 1] : 0u;
+                    a[k] = b ? lw[bp >> WSH] : (LW)0;
+                    bw[k] = b ? lw[(bp >> WSH) + 1] : (LW)0;
                 }
             }
 #pragma unroll
@@ -776,9 +709,9 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec32(const uint64_t *low, con
                 const uint32_t rr = r0 + lane + 64 * k;
                 if (rr < tot) {
                     const uint32_t rank = done + rr;
-                    const uint32_t sh = (uint32_t)(((uint64_t)rank * b) & 31u);
-                    const uint32_t lo = ((a[k] >> sh) | (sh ? bw[k] << (32u - sh) : 0u)) & keep;
-                    out[out_pos + rr] = (uint64_t)(((pbase + spos[rr] - rank) << b) | lo);
+                    const uint32_t sh = (uint32_t)(((uint64_t)rank * b) & (WB - 1u));
+                    const LW lo = (LW)((a[k] >> sh) | (sh ? (LW)(bw[k] << (WB - sh)) : (LW)0)) & keep;
+                    out[out_pos + rr] = (uint64_t)((LW)((LW)(pbase + spos[rr] - rank) << b) | lo);
                 }
             }
         }
@@ -1307,11 +1240,11 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
     }
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     if (e->nbatches && e->narrow)
-        hipLaunchKernelGGL(k_ef_decode_rec32, dim3((uint32_t)std::min<uint64_t>(e->nbatches, (uint64_t)ctx->num_cu * 256)),
+        hipLaunchKernelGGL(k_ef_decode_rec<uint32_t>, dim3((uint32_t)std::min<uint64_t>(e->nbatches, (uint64_t)ctx->num_cu * 256)),
                            dim3(64), std::min<uint32_t>(EF_BATCH_BITS, (e->recs_max_cnt + 63u) & ~63u) * 2, ctx->stream,
                            e->d_low.p, e->d_high.p, e->d_recs.p, (uint32_t)e->nbatches, d_out);
     else if (e->nbatches)
-        hipLaunchKernelGGL(k_ef_decode_rec, dim3((uint32_t)std::min<uint64_t>(e->nbatches, (uint64_t)ctx->num_cu * 256)),
+        hipLaunchKernelGGL(k_ef_decode_rec<uint64_t>, dim3((uint32_t)std::min<uint64_t>(e->nbatches, (uint64_t)ctx->num_cu * 256)),
                            dim3(64), std::min<uint32_t>(EF_BATCH_BITS, (e->recs_max_cnt + 63u) & ~63u) * 2, ctx->stream, e->d_low.p, e->d_high.p, e->d_recs.p, (uint32_t)e->nbatches, d_out);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
