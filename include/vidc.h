@@ -24,8 +24,9 @@
  *
  * Environment (test hooks, read per call): VIDC_NO_LANE=1 / VIDC_FORCE_LANE=1 never / always use the
  * lane-per-list ROC kernels (default: only for calls with thousands of short lists), VIDC_FORCE_GENERAL=1 routes
- * every list through the general wave-per-list kernels, VIDC_TRACE=1 prints host-side phase times.  The bit
- * streams do not depend on any of them.
+ * every list through the general wave-per-list kernels, VIDC_HOST_THREADS=n caps the host threads used to plan calls
+ * with >= 131072 lists (default 8), VIDC_TRACE=1 prints host-side phase times.  The bit streams do not depend on
+ * any of them.
  */
 #ifndef VIDC_H
 #define VIDC_H

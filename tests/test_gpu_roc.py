@@ -323,6 +323,29 @@ def test_lane_kernels_match_wave_kernels(roc, monkeypatch):
     assert np.array_equal(np.sort(got["0"][3]), np.sort(ids.view(np.int64)))
 
 
+def test_threaded_host_planning_matches_single_thread(roc, monkeypatch):
+    """Calls with >= 131072 lists classify and sort their work lists on several host threads (VIDC_HOST_THREADS=1
+    forces one): same streams, same decode, and a sample of lists against the oracle."""
+    rng = np.random.default_rng(91)
+    sizes = np.concatenate([rng.integers(0, 40, 120000), rng.integers(65, 300, 20000), rng.integers(1025, 2300, 300),
+                            [5000, 9000, 40000]])
+    rng.shuffle(sizes)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    gaps = rng.integers(1, 400, int(off[-1])).astype(np.uint64)  # strictly ascending ids per list: running gap sums
+    cs = np.cumsum(gaps)
+    first = np.repeat(np.concatenate([[0], cs])[off[:-1].astype(np.int64)], sizes)
+    ids = (cs - first).astype(np.uint64)
+    got = []
+    for threads in ("1", "8"):
+        monkeypatch.setenv("VIDC_HOST_THREADS", threads)
+        r = roc.encode(off, ids, precision_mode=-2)  # bit_width(max id): lossless also when a max id is a power of two
+        info = r.info()
+        got.append((info["heads"], info["nwords"], info["precision"], r.all_words(), r.decode_all().cpu().numpy().copy()))
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(np.sort(got[1][4].view(np.uint64)), np.sort(ids))
+
+
 @pytest.mark.parametrize("nlist", [4096, 8192, 12289])
 def test_device_metadata_matches_host_view(roc, nlist):
     """Word offsets, sizes and totals are computed on the device (exclusive scans over a multiple of the scan tile,

@@ -6,6 +6,7 @@
 #include <memory>
 #include <mutex>
 #include <numeric>
+#include <thread>
 
 #include "common.h"
 #include "roc_kernels.h"
@@ -196,6 +197,30 @@ int check_status(const std::vector<uint32_t> &status, const char *what) {
     return VIDC_OK;
 }
 
+// Host loops over the lists of a call (classification, work-list sorts): with 10^6 lists they are the host's
+// critical path between the prepass and the first encode kernel (7 ms single-threaded), so they are split over a few
+// threads.  f(begin, end, part) for `parts` contiguous ranges; small calls stay on the calling thread.
+constexpr uint64_t PAR_MIN_LISTS = 131072;
+inline unsigned par_parts(uint64_t n) {
+    if (n < PAR_MIN_LISTS) return 1;
+    const char *e = getenv("VIDC_HOST_THREADS");  // test hook: 1 = single-threaded host loops
+    const unsigned cap = e && e[0] ? (unsigned)std::max(1, atoi(e)) : 8u;
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(cap, hw ? hw : 1u));
+}
+template <class F>
+void par_ranges(uint64_t n, unsigned parts, F &&f) {
+    if (parts <= 1 || n == 0) { f((uint64_t)0, n, 0u); return; }
+    std::vector<std::thread> th;
+    const uint64_t per = (n + parts - 1) / parts;
+    for (unsigned t = 1; t < parts; t++) {
+        const uint64_t a = std::min<uint64_t>(n, t * per), b = std::min<uint64_t>(n, a + per);
+        th.emplace_back([&f, a, b, t] { f(a, b, t); });
+    }
+    f((uint64_t)0, std::min<uint64_t>(n, per), 0u);
+    for (auto &x : th) x.join();
+}
+
 // lists sorted longest first: the hardware dispatches workgroups in order, so this is LPT scheduling.
 // Counting sort by length (lengths are bounded by VIDC_ROC_MAX_LIST): O(n), stable.
 void sort_desc(std::vector<uint32_t> &wl, const std::vector<uint64_t> &offsets) {
@@ -208,10 +233,32 @@ void sort_desc(std::vector<uint32_t> &wl, const std::vector<uint64_t> &offsets) 
         });
         return;
     }
+    std::vector<uint32_t> out(wl.size());
+    const unsigned parts = maxlen <= 65536 ? par_parts(wl.size()) : 1;
+    if (parts > 1) {  // the same stable counting sort, histogram and scatter per contiguous part of the work list
+        const size_t nb = maxlen + 1;
+        std::vector<uint32_t> hist((size_t)parts * nb, 0);
+        par_ranges(wl.size(), parts, [&](uint64_t a, uint64_t b, unsigned t) {
+            uint32_t *h = &hist[(size_t)t * nb];
+            for (uint64_t i = a; i < b; i++) h[maxlen - (offsets[wl[i] + 1] - offsets[wl[i]])]++;
+        });
+        uint32_t run = 0;  // bucket-major, part-minor: equal lengths keep their work-list order
+        for (size_t k = 0; k < nb; k++)
+            for (unsigned t = 0; t < parts; t++) {
+                const uint32_t c = hist[(size_t)t * nb + k];
+                hist[(size_t)t * nb + k] = run;
+                run += c;
+            }
+        par_ranges(wl.size(), parts, [&](uint64_t a, uint64_t b, unsigned t) {
+            uint32_t *h = &hist[(size_t)t * nb];
+            for (uint64_t i = a; i < b; i++) out[h[maxlen - (offsets[wl[i] + 1] - offsets[wl[i]])]++] = wl[i];
+        });
+        wl.swap(out);
+        return;
+    }
     std::vector<uint32_t> start(maxlen + 2, 0);
     for (uint32_t l : wl) start[maxlen - (offsets[l + 1] - offsets[l]) + 1]++;  // bucket 0 = longest
     for (size_t i = 1; i < start.size(); i++) start[i] += start[i - 1];
-    std::vector<uint32_t> out(wl.size());
     for (uint32_t l : wl) out[start[maxlen - (offsets[l + 1] - offsets[l])]++] = l;
     wl.swap(out);
 }
@@ -371,13 +418,15 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             tr.mark("prepass kernel + d2h");
             // what the decode planner needs later (kernel class, bucket geometry) is known right here
             r->prec.resize(nlist);
-            for (uint64_t l = 0; l < nlist; l++) {
-                const uint32_t m = maxid[l];
-                r->prec[l] = offsets[l + 1] == offsets[l] ? 0u
-                             : precision_mode >= 0    ? (uint32_t)precision_mode
-                             : precision_mode == VIDC_PREC_EXACT ? (m ? 32u - (uint32_t)__builtin_clz(m) : 0u)
-                                                                 : (m > 1u ? 32u - (uint32_t)__builtin_clz(m - 1u) : 0u);
-            }
+            par_ranges(nlist, par_parts(nlist), [&](uint64_t la, uint64_t lb, unsigned) {
+                for (uint64_t l = la; l < lb; l++) {
+                    const uint32_t m = maxid[l];
+                    r->prec[l] = offsets[l + 1] == offsets[l] ? 0u
+                                 : precision_mode >= 0    ? (uint32_t)precision_mode
+                                 : precision_mode == VIDC_PREC_EXACT ? (m ? 32u - (uint32_t)__builtin_clz(m) : 0u)
+                                                                     : (m > 1u ? 32u - (uint32_t)__builtin_clz(m - 1u) : 0u);
+                }
+            });
         } else {
             r->prec.assign(nlist, 0);  // tiny lists only: the planner does not look at their precision
         }
@@ -386,42 +435,89 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         const uint64_t u_min = U_MIN_LIST;
         {
             uint64_t n_mid = 0, n_mid64 = 0, n_tiny = 0;
-            for (uint64_t l = 0; l < nlist; l++) {
-                const uint64_t n = offsets[l + 1] - offsets[l];
-                n_tiny += n <= TINY_MAX;
-                n_mid += n > TINY_MAX && n <= VIDC_LANE_MAX;
-                n_mid64 += n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64;
+            {
+                const unsigned parts = par_parts(nlist);
+                std::vector<uint64_t> cnt(3 * (size_t)parts, 0);
+                par_ranges(nlist, parts, [&](uint64_t la, uint64_t lb, unsigned t) {
+                    uint64_t a = 0, b = 0, c = 0;
+                    for (uint64_t l = la; l < lb; l++) {
+                        const uint64_t n = offsets[l + 1] - offsets[l];
+                        a += n <= TINY_MAX;
+                        b += n > TINY_MAX && n <= VIDC_LANE_MAX;
+                        c += n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64;
+                    }
+                    cnt[3 * t] = a; cnt[3 * t + 1] = b; cnt[3 * t + 2] = c;
+                });
+                for (unsigned t = 0; t < parts; t++) { n_tiny += cnt[3 * t]; n_mid += cnt[3 * t + 1]; n_mid64 += cnt[3 * t + 2]; }
             }
             use_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
             use_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
             use_lane_tiny = lane_wanted(lpol, n_tiny, LANE_MIN_TINY);
         }
-        for (uint64_t l = 0; l < nlist; l++) {
-            uint64_t n = offsets[l + 1] - offsets[l];
-            if (n <= TINY_MAX) { wl_tiny.push_back((uint32_t)l); continue; }
-            if (pflags[l] & VIDC_PF_DOMAIN) {
-                set_error("roc encode: list %llu holds an id outside [0, 2^31) (reference: int max_id, "
-                          "custom_invlists_impl.cpp:163)", (unsigned long long)l);
-                return VIDC_ERR_DOMAIN;
+        {
+            // per-thread work lists (contiguous list ranges), concatenated in range order: the same lists in the
+            // same order as a single pass
+            enum { W_TINY = 0, W_U18, W_U20, W_C1, W_C2, W_C3, W_L4, W_L16, W_L64, W_COUNT };
+            const unsigned parts = par_parts(nlist);
+            std::vector<std::vector<uint32_t>> part_wl((size_t)parts * W_COUNT);
+            std::vector<int64_t> bad_list(parts, -1);
+            par_ranges(nlist, parts, [&](uint64_t la, uint64_t lb, unsigned tpart) {
+                std::vector<uint32_t> *w = &part_wl[(size_t)tpart * W_COUNT];
+                for (uint64_t l = la; l < lb; l++) {
+                    const uint64_t n = offsets[l + 1] - offsets[l];
+                    if (n <= TINY_MAX) { w[W_TINY].push_back((uint32_t)l); continue; }
+                    if (pflags[l] & VIDC_PF_DOMAIN) {
+                        if (bad_list[tpart] < 0) bad_list[tpart] = (int64_t)l;
+                        continue;
+                    }
+                    const uint32_t width = maxid[l] ? 32u - (uint32_t)__builtin_clz(maxid[l]) : 0u;  // ids < 2^width
+                    // the bitmap kernels need no sort; they cannot report input positions of an unsorted list
+                    const bool u_ok = !f_general && !((pflags[l] & VIDC_PF_UNSORTED) && want_perm) &&
+                                      (n >= u_min || (pflags[l] & VIDC_PF_UNSORTED));
+                    const bool lane_ok = !(pflags[l] & VIDC_PF_UNSORTED) &&
+                                         ((use_lane && n <= VIDC_LANE_MAX) ||
+                                          (use_lane64 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64));
+                    const int cls = (u_ok && width <= 18) ? W_U18
+                                    : (u_ok && width <= 20) ? W_U20
+                                    : (lane_ok && n <= 256) ? W_L4
+                                    : (lane_ok && n <= VIDC_LANE_MAX) ? W_L16
+                                    : lane_ok ? W_L64
+                                    : n <= 4096 ? W_C1
+                                    : n <= 32768 ? W_C2 : W_C3;
+                    w[cls].push_back((uint32_t)l);
+                }
+            });
+            for (unsigned t = 0; t < parts; t++)
+                if (bad_list[t] >= 0) {  // the first offending list, as a single pass would report it
+                    set_error("roc encode: list %llu holds an id outside [0, 2^31) (reference: int max_id, "
+                              "custom_invlists_impl.cpp:163)", (unsigned long long)bad_list[t]);
+                    return VIDC_ERR_DOMAIN;
+                }
+            std::vector<uint32_t> *dst[W_COUNT] = {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64};
+            for (int c = 0; c < W_COUNT; c++) {
+                size_t tot = 0;
+                for (unsigned t = 0; t < parts; t++) tot += part_wl[(size_t)t * W_COUNT + c].size();
+                dst[c]->reserve(tot);
+                for (unsigned t = 0; t < parts; t++) {
+                    const auto &v = part_wl[(size_t)t * W_COUNT + c];
+                    dst[c]->insert(dst[c]->end(), v.begin(), v.end());
+                }
             }
-            uint32_t width = maxid[l] ? 32u - (uint32_t)__builtin_clz(maxid[l]) : 0u;  // ids < 2^width
-            // the bitmap kernels need no sort; they cannot report input positions of an unsorted list
-            bool u_ok = !f_general && !((pflags[l] & VIDC_PF_UNSORTED) && want_perm) &&
-                        (n >= u_min || (pflags[l] & VIDC_PF_UNSORTED));
-            const bool lane_ok = !(pflags[l] & VIDC_PF_UNSORTED) &&
-                                 ((use_lane && n <= VIDC_LANE_MAX) || (use_lane64 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64));
-            if (u_ok && width <= 18) wl_u18.push_back((uint32_t)l);
-            else if (u_ok && width <= 20) wl_u20.push_back((uint32_t)l);
-            else if (lane_ok && n <= 256) wl_l4.push_back((uint32_t)l);
-            else if (lane_ok && n <= VIDC_LANE_MAX) wl_l16.push_back((uint32_t)l);
-            else if (lane_ok) wl_l64.push_back((uint32_t)l);
-            else if (n <= 4096) wl_c1.push_back((uint32_t)l);
-            else if (n <= 32768) wl_c2.push_back((uint32_t)l);
-            else wl_c3.push_back((uint32_t)l);
         }
         ntiny = wl_tiny.size();
         tr.mark("classify");
-        for (auto *w : {&wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64}) sort_desc(*w, r->offsets);
+        {
+            std::vector<uint32_t> *ws[8] = {&wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64};
+            if (par_parts(nlist) > 1) {  // one thread per class (independent vectors, read-only offsets)
+                std::vector<std::thread> th;
+                for (int c = 1; c < 8; c++)
+                    if (ws[c]->size() > 1) th.emplace_back([&, c] { sort_desc(*ws[c], r->offsets); });
+                sort_desc(*ws[0], r->offsets);
+                for (auto &x : th) x.join();
+            } else {
+                for (auto *w : ws) sort_desc(*w, r->offsets);
+            }
+        }
         tr.mark("sort work lists");
         if (!wl_c1.empty() || !wl_c2.empty() || !wl_c3.empty()) VIDC_TRY(s_sid.get(ctx, ntotal_in * 4));
     }
