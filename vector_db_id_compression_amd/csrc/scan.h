@@ -1,4 +1,5 @@
-// scan.h -- device exclusive scan of u32 counts into u64 offsets (out has n + 1 entries), three small launches.
+// scan.h -- device exclusive scan of u32 counts into u64 offsets (out has n + 1 entries): one launch up to 8192
+// elements, three small launches beyond.
 // Keeps per-list counts (ANS words, edges, chunk / batch counts) on the device: with 10^6 lists the host prefix sum
 // plus two PCIe crossings of the arrays cost more than the codec kernels.  Included by several translation units:
 // everything here has internal linkage.
@@ -69,6 +70,40 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *in, uint32_t
         acc += v[j];
     }
 }
+// up to 8192 elements: one block, one launch (the three-launch version costs ~17 us whatever n is and an Elias-Fano
+// encode runs four scans; beyond a few elements per thread the single block is latency-bound and loses)
+#define VIDC_SCAN_SMALL_MAX 8192u
+__global__ void __launch_bounds__(1024) k_scan_small(const uint32_t *in, uint32_t n, uint64_t *out) {
+    __shared__ uint64_t wsum[16];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t E = (n + 1023u) / 1024u;  // consecutive elements per thread
+    const uint32_t base = t * E;
+    uint64_t s = 0;
+    for (uint32_t j = 0; j < E; j++) s += base + j < n ? in[base + j] : 0u;
+    uint64_t incl = s;  // inclusive scan inside the wavefront
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t v = __shfl_up((unsigned long long)incl, o, 64);
+        if (lane >= (uint32_t)o) incl += v;
+    }
+    if (lane == 63u) wsum[wave] = incl;
+    __syncthreads();
+    uint64_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; w++) {
+        before += w < wave ? wsum[w] : 0;
+        total += wsum[w];
+    }
+    uint64_t acc = before + incl - s;
+    for (uint32_t j = 0; j < E; j++) {
+        if (base + j < n) {
+            out[base + j] = acc;
+            acc += in[base + j];
+        }
+    }
+    if (t == 0) out[n] = total;
+}
+
 // number of non-zero entries
 __global__ void k_count_nonzero(const uint32_t *in, uint32_t n, unsigned long long *out) {
     unsigned long long c = 0;
@@ -106,6 +141,11 @@ inline int fetch_sizes(::vidc_ctx *ctx, const uint64_t *d_offsets, const I *d_id
 
 // out[0..n] = exclusive prefix sums of in[0..n) on the context's stream (tmp: scratch for the tile sums)
 inline int device_exscan(::vidc_ctx *ctx, const uint32_t *d_in, uint32_t n, uint64_t *d_out, Scratch &tmp) {
+    if (n <= VIDC_SCAN_SMALL_MAX) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, d_in, n, d_out);
+        VIDC_HIP(hipGetLastError());
+        return VIDC_OK;
+    }
     const uint32_t ntiles = n / VIDC_SCAN_TILE + 1u;
     VIDC_TRY(tmp.get(ctx, (size_t)ntiles * 8));
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(256), 0, ctx->stream, d_in, n, tmp.as<uint64_t>());
