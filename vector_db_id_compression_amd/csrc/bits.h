@@ -48,31 +48,5 @@ __device__ __forceinline__ uint64_t gather_word(const uint64_t *src, uint64_t n,
     return out;
 }
 
-// Same word, for callers that work on chunks of a list starting at a word boundary (chunk start * bits % 64 == 0):
-// the first id touching word w is chunk_start + floor((w - w_chunk) * 64 / bits), a 16-bit numerator divided through
-// the exact reciprocal m22 = ceil(2^22 / bits) instead of a 64-bit division per word.
-__device__ __forceinline__ uint32_t bits_rcp22(uint32_t bits) { return ((1u << 22) + bits - 1u) / bits; }
-template <bool CHECK>
-__device__ __forceinline__ uint64_t gather_word_chunk(const uint64_t *src, uint64_t n, uint64_t chunk_start,
-                                                      uint64_t w_chunk, uint64_t w_in_list, uint32_t bits, uint32_t m22,
-                                                      uint64_t keep_mask, uint64_t id_limit, uint32_t *err) {
-    uint64_t out = 0;
-    if (!bits) return 0;
-    const uint64_t bit0 = w_in_list * 64;
-    const uint32_t rel = (uint32_t)(w_in_list - w_chunk) * 64u;  // < 2^16 for chunks of 512 ids, bits <= 64
-    uint64_t i = chunk_start + ((rel * m22) >> 22);
-    uint64_t pos = i * bits;
-    for (; i < n && pos < bit0 + 64; i++, pos += bits) {
-        uint64_t v = src[i];
-        if (CHECK) {
-            if (v >= id_limit || (bits < 64 && (v >> bits))) atomicOr(err, 1u);
-        }
-        v &= keep_mask;
-        if (pos >= bit0) out |= v << (pos - bit0);
-        else out |= v >> (bit0 - pos);
-    }
-    return out;
-}
-
 }  // namespace dev
 }  // namespace vidc
