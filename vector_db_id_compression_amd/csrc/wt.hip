@@ -192,6 +192,35 @@ __global__ void k_wt_decode_all(const uint64_t *bits, const uint32_t *rank, cons
     }
 }
 
+// get_ids for every list as L stable partitions of the id sequence (the build's own passes, run on ids instead of
+// symbols): at level l the element at position i of node p goes to the zeros / ones part of its node, one rank per
+// element instead of the select (binary search over the rank directory + word scan) the per-id walk needs per level.
+// in == nullptr: level 0 (position i holds id i, prefix 0).  LAST: the final order is the answer (u64 ids).
+struct WtItem {
+    uint32_t id, pref;
+};
+template <bool LAST>
+__global__ void k_wt_decode_level(const WtItem *in, WtItem *out, uint64_t *out_ids, const uint64_t *bits,
+                                  const uint32_t *rank, const uint64_t *C, uint64_t ntotal, uint32_t nlist, uint32_t L,
+                                  uint32_t level) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t sh = L - level;  // symbols of one node share their top `level` bits
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ntotal; i += stride) {
+        const WtItem it = in ? in[i] : WtItem{(uint32_t)i, 0u};
+        const uint64_t p = it.pref;
+        uint64_t s_lo = sh >= 32 ? 0 : (p << sh), s_hi = sh >= 32 ? nlist : ((p + 1) << sh);
+        if (s_lo > nlist) s_lo = nlist;
+        if (s_hi > nlist) s_hi = nlist;
+        const uint64_t ns = C[s_lo], ne = C[s_hi];
+        const uint64_t r_ns = rank1(bits, rank, ns), r_i = rank1(bits, rank, i), r_ne = rank1(bits, rank, ne);
+        const bool bit = (bits[i >> 6] >> (i & 63)) & 1ull;
+        const uint64_t zeros_in_node = (ne - ns) - (r_ne - r_ns);
+        const uint64_t dst = bit ? ns + zeros_in_node + (r_i - r_ns) : ns + ((i - ns) - (r_i - r_ns));
+        if (LAST) out_ids[dst] = it.id;
+        else out[dst] = WtItem{it.id, (uint32_t)((p << 1) | (bit ? 1u : 0u))};
+    }
+}
+
 // size of an RRR-63 coded bitvector (sdsl::rrr_vector<63>): 6-bit class + ceil(log2 C(63, class)) offset bits
 // per 63-bit block, plus a 64-bit pointer and rank sample every 32 blocks (the layout sdsl documents)
 __global__ void k_wt_rrr_bits(const uint64_t *bits, uint64_t nbits, const uint8_t *offbits, unsigned long long *total) {
@@ -338,9 +367,38 @@ int vidc_wt_decode_all(vidc_ctx *ctx, const vidc_wt *w, uint64_t *d_out) {
     if (!w->ntotal) return VIDC_OK;
     VIDC_HIP(hipSetDevice(ctx->device));
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((w->ntotal + 127) / 128, (uint64_t)ctx->num_cu * 64);
-    hipLaunchKernelGGL(k_wt_decode_all, dim3(grid), dim3(128), 0, ctx->stream, w->d_bits.p, w->d_rank.p, w->d_C.p,
-                       w->words_per_level, w->blocks_per_level, (uint32_t)w->nlist, w->L, w->ntotal, d_out);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((w->ntotal + 255) / 256, (uint64_t)ctx->num_cu * 32);
+    if (w->L == 0) {  // one list: ids 0..ntotal-1 in order (the per-id kernel handles it)
+        hipLaunchKernelGGL(k_wt_decode_all, dim3(grid), dim3(128), 0, ctx->stream, w->d_bits.p, w->d_rank.p, w->d_C.p,
+                           w->words_per_level, w->blocks_per_level, (uint32_t)w->nlist, w->L, w->ntotal, d_out);
+    } else {
+        Scratch s_a, s_b;  // ping-pong (id, symbol prefix) arrays
+        if (w->L > 1) {
+            VIDC_TRY(s_a.get(ctx, w->ntotal * sizeof(WtItem)));
+            if (w->L > 2) VIDC_TRY(s_b.get(ctx, w->ntotal * sizeof(WtItem)));
+        }
+        const WtItem *in = nullptr;
+        for (uint32_t level = 0; level < w->L; level++) {
+            const uint64_t *b = w->d_bits.p + (uint64_t)level * w->words_per_level;
+            const uint32_t *r = w->d_rank.p + (uint64_t)level * (w->blocks_per_level + 1);
+            if (level + 1 == w->L) {
+                hipLaunchKernelGGL(k_wt_decode_level<true>, dim3(grid), dim3(256), 0, ctx->stream, in, (WtItem *)nullptr,
+                                   d_out, b, r, w->d_C.p, w->ntotal, (uint32_t)w->nlist, w->L, level);
+            } else {
+                WtItem *out = (level & 1u) ? s_b.as<WtItem>() : s_a.as<WtItem>();
+                hipLaunchKernelGGL(k_wt_decode_level<false>, dim3(grid), dim3(256), 0, ctx->stream, in, out,
+                                   (uint64_t *)nullptr, b, r, w->d_C.p, w->ntotal, (uint32_t)w->nlist, w->L, level);
+                in = out;
+            }
+        }
+        VIDC_HIP(hipGetLastError());
+        VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+        VIDC_HIP(hipStreamSynchronize(ctx->stream));  // the scratch of this scope goes back to the pool below
+        float ms2 = 0;
+        (void)hipEventElapsedTime(&ms2, ctx->ev0, ctx->ev1);
+        ctx->last_kernel_ms = ms2;
+        return VIDC_OK;
+    }
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
