@@ -155,25 +155,38 @@ __global__ void __launch_bounds__(64) k_compact_rows_encode(const int32_t *rows,
     }
 }
 
-// one wavefront per requested row (K <= 64): lane j reads value j; the row ends at the sentinel N (:43-49)
+// one wavefront per requested row (K <= 64): lane j reads value j; the row ends at the sentinel N (:43-49).
+// Four rows per iteration: a field (<= 32 bits) lies inside the two aligned dwords around its
+// first byte, so every lane issues 2 dword loads per row (not 6 byte loads), all 8 loads of the four rows before
+// anything is consumed.  (The buffer ends with 8 padding bytes.)
 __global__ void __launch_bounds__(64) k_compact_rows_decode(const uint8_t *data, uint64_t N, uint32_t K, uint32_t bits,
                                                             uint32_t stride, uint64_t m, const uint64_t *nodes,
                                                             int32_t *out, uint32_t *counts) {
     const uint32_t lane = threadIdx.x & 63u;
-    for (uint64_t q = blockIdx.x; q < m; q += gridDim.x) {
-        const uint8_t *row = data + (nodes ? nodes[q] : q) * stride;
-        uint64_t v = ~0ull;
-        if (lane < K) {
-            const uint32_t pos = lane * bits;
-            uint64_t acc = 0;
-            const uint32_t b0 = pos >> 3;
-            for (uint32_t t = 0; t < 6 && b0 + t < stride; t++) acc |= (uint64_t)row[b0 + t] << (8 * t);
-            v = (acc >> (pos & 7)) & ((1ull << bits) - 1ull);
+    const uint64_t mask = (1ull << bits) - 1ull;
+    const uint32_t pos = lane * bits;
+    for (uint64_t q0 = (uint64_t)blockIdx.x * 4u; q0 < m; q0 += (uint64_t)gridDim.x * 4u) {
+        uint32_t w0[4], w1[4], sh[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint64_t q = q0 + j < m ? q0 + j : q0;
+            const uint8_t *p = data + (nodes ? nodes[q] : q) * stride + (pos >> 3);
+            const uintptr_t a = (uintptr_t)p;
+            const uint32_t *w = (const uint32_t *)(a & ~(uintptr_t)3);
+            sh[j] = (uint32_t)(a & 3u) * 8u + (pos & 7u);
+            w0[j] = lane < K ? w[0] : 0u;
+            w1[j] = lane < K ? w[1] : 0u;
         }
-        const uint64_t endm = __ballot(lane < K && v == N);
-        const uint32_t n = endm ? (uint32_t)__builtin_ctzll(endm) : K;
-        if (lane < K) out[q * K + lane] = lane < n ? (int32_t)v : -1;
-        if (lane == 0) counts[q] = n;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint64_t q = q0 + j;
+            if (q >= m) break;
+            const uint64_t v = lane < K ? ((((uint64_t)w1[j] << 32) | w0[j]) >> sh[j]) & mask : ~0ull;
+            const uint64_t endm = __ballot(lane < K && v == N);
+            const uint32_t n = endm ? (uint32_t)__builtin_ctzll(endm) : K;
+            if (lane < K) out[q * K + lane] = lane < n ? (int32_t)v : -1;
+            if (lane == 0) counts[q] = n;
+        }
     }
 }
 
@@ -249,7 +262,7 @@ int vidc_compact_rows_decode(vidc_ctx *ctx, const vidc_compact *c, uint64_t m, c
         d_nodes = s_n.as<uint64_t>();
     }
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_compact_rows_decode, dim3((uint32_t)std::min<uint64_t>(m, 1u << 20)), dim3(64), 0, ctx->stream,
+    hipLaunchKernelGGL(k_compact_rows_decode, dim3((uint32_t)std::min<uint64_t>((m + 3) / 4, (uint64_t)ctx->num_cu * 256)), dim3(64), 0, ctx->stream,
                        c->d_data.p, c->N, c->K, c->bits, c->stride, m, d_nodes, d_out, s_c.as<uint32_t>());
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
