@@ -44,6 +44,26 @@ __global__ void __launch_bounds__(64) k_fill_items(const uint64_t *item_off, uin
         for (uint64_t c = lane; c < n; c += 64) out[o + c] = vidc::Chunk{l, (uint32_t)(c * unit)};
     }
 }
+// the same with one THREAD per list: for objects whose lists hold one or two items each (graph rows: one batch per
+// row) a wavefront per list is 10^6 workgroups writing 8 bytes
+__global__ void k_fill_items_flat(const uint64_t *item_off, uint32_t nlist, uint32_t unit, vidc::Chunk *out) {
+    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x) {
+        const uint64_t o = item_off[l], n = item_off[l + 1] - o;
+        for (uint64_t c = 0; c < n; c++) out[o + c] = vidc::Chunk{l, (uint32_t)(c * unit)};
+    }
+}
+// items of every list, by whichever kernel fits: lists with at most ~2 items each -> thread per list
+inline void launch_fill_items(hipStream_t st, const uint64_t *item_off, uint32_t nlist, uint32_t unit, vidc::Chunk *out,
+                              uint64_t total_items, uint32_t num_cu) {
+    if (!nlist) return;
+    if (total_items <= 2ull * nlist) {
+        const uint32_t grid = (nlist + 255u) / 256u < num_cu * 16u ? (nlist + 255u) / 256u : num_cu * 16u;
+        hipLaunchKernelGGL(k_fill_items_flat, dim3(grid), dim3(256), 0, st, item_off, nlist, unit, out);
+    } else {
+        const uint32_t grid = nlist < num_cu * 64u ? nlist : num_cu * 64u;
+        hipLaunchKernelGGL(k_fill_items, dim3(grid), dim3(64), 0, st, item_off, nlist, unit, out);
+    }
+}
 }  // namespace
 #endif
 

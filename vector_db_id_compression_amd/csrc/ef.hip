@@ -1003,7 +1003,6 @@ int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t 
         return VIDC_OK;
     };
     const uint32_t lgrid = (uint32_t)std::min<uint64_t>((nlist + 255) / 256 + 1, 2048);
-    const uint32_t wgrid = (uint32_t)std::min<uint64_t>(nlist ? nlist : 1, (uint64_t)ctx->num_cu * 64);
     Scratch s_cnt, s_coff, s_tmp, s_prep, s_lw, s_hw, s_nb, s_tot, s_tmp2, s_tmp3;
     Pinned tail;
     VIDC_TRY(tail.get(ctx, 64));
@@ -1019,8 +1018,7 @@ int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t 
     e->nchunks = t[0];
     VIDC_TRY(e->d_chunks.alloc(e->nchunks ? e->nchunks : 1, ctx->dpool));
     if (e->nchunks)
-        hipLaunchKernelGGL(k_fill_items, dim3(wgrid), dim3(64), 0, ctx->stream, s_coff.as<uint64_t>(), nl32, CHUNK_IDS,
-                           e->d_chunks.p);
+        launch_fill_items(ctx->stream, s_coff.as<uint64_t>(), nl32, CHUNK_IDS, e->d_chunks.p, e->nchunks, (uint32_t)ctx->num_cu);
     VIDC_HIP(hipGetLastError());
     const uint32_t cgrid = (uint32_t)std::min<uint64_t>(e->nchunks ? e->nchunks : 1, (uint64_t)ctx->num_cu * 256);
 
@@ -1145,8 +1143,7 @@ int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t 
     VIDC_TRY(e->d_hrank.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
     if (e->nbatches) {
         VIDC_TRY(timed([&] {
-            hipLaunchKernelGGL(k_fill_items, dim3(wgrid), dim3(64), 0, ctx->stream, e->d_batch_off.p, nl32, 1u,
-                               e->d_batches.p);
+            launch_fill_items(ctx->stream, e->d_batch_off.p, nl32, 1u, e->d_batches.p, e->nbatches, (uint32_t)ctx->num_cu);
             hipLaunchKernelGGL(k_ef_hrank, dim3((uint32_t)std::min<uint64_t>((e->nbatches + 255) / 256, 4096)), dim3(256),
                                0, ctx->stream, d_sorted, e->d_offsets.p, e->d_lbits.p, e->d_batches.p, e->nbatches,
                                e->d_hrank.p);
@@ -1411,8 +1408,7 @@ int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_
                 hipLaunchKernelGGL(k_ef_rows_write_lane<64>, lgrid, dim3(64), 0, ctx->stream, d_rows, N, K, e->d_lbits.p,
                                    e->d_low_off.p, e->d_high_off.p, e->d_low.p, e->d_high.p);
             if (e->nbatches)
-                hipLaunchKernelGGL(k_fill_items, dim3((uint32_t)std::min<uint64_t>(N, (uint64_t)ctx->num_cu * 64)), dim3(64), 0,
-                                   ctx->stream, e->d_batch_off.p, n32, 1u, e->d_batches.p);
+                launch_fill_items(ctx->stream, e->d_batch_off.p, n32, 1u, e->d_batches.p, e->nbatches, (uint32_t)ctx->num_cu);
         }));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
     ctx->last_kernel_ms = kernel_ms;
@@ -1547,8 +1543,7 @@ int vidc_ef_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     VIDC_TRY(vidc_copy_h2d(ctx, e->d_high.p, high, n_high * 8));
     if (e->nbatches) {
         const uint32_t wgrid = (uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 64);
-        hipLaunchKernelGGL(k_fill_items, dim3(wgrid), dim3(64), 0, ctx->stream, e->d_batch_off.p, (uint32_t)nlist, 1u,
-                           e->d_batches.p);
+        launch_fill_items(ctx->stream, e->d_batch_off.p, (uint32_t)nlist, 1u, e->d_batches.p, e->nbatches, (uint32_t)ctx->num_cu);
         hipLaunchKernelGGL(k_ef_hrank_from_high, dim3(wgrid), dim3(64), 0, ctx->stream, e->d_high.p, e->d_high_off.p,
                            e->d_batch_off.p, (uint32_t)nlist, e->d_hrank.p);
         VIDC_HIP(hipGetLastError());

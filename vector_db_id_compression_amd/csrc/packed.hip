@@ -325,8 +325,7 @@ static int packed_setup(vidc_ctx *ctx, vidc_packed *p, uint64_t nlist, const uin
     p->nchunks = h64[2 * nlist + 2];
     VIDC_TRY(p->d_chunks.alloc(p->nchunks ? p->nchunks : 1, ctx->dpool));
     if (p->nchunks)
-        hipLaunchKernelGGL(k_fill_items, dim3((uint32_t)std::min<uint64_t>(nlist ? nlist : 1, (uint64_t)ctx->num_cu * 64)),
-                           dim3(64), 0, ctx->stream, s_coff.as<uint64_t>(), nl32, CHUNK_IDS, p->d_chunks.p);
+        launch_fill_items(ctx->stream, s_coff.as<uint64_t>(), nl32, CHUNK_IDS, p->d_chunks.p, p->nchunks, (uint32_t)ctx->num_cu);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipStreamSynchronize(ctx->stream));  // scratch of this scope is released on return
     return VIDC_OK;

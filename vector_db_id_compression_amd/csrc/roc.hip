@@ -283,7 +283,7 @@ int finish_encode(vidc_ctx *ctx, vidc_roc *r, const uint32_t *d_arena, uint32_t 
         if (r->rows) {
             VIDC_TRY(r->d_offsets.alloc(nlist + 1, ctx->dpool));
             VIDC_TRY(device_exscan(ctx, d_sizes, (uint32_t)nlist, r->d_offsets.p, s_tmp2));
-            hipLaunchKernelGGL(k_count_nonzero, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 1024)), dim3(256), 0,
+            hipLaunchKernelGGL(k_count_nonzero, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 64)), dim3(256), 0,
                                ctx->stream, d_sizes, (uint32_t)nlist, s_sum.as<unsigned long long>() + 5);
             VIDC_HIP(hipMemcpyAsync(t + 4, r->d_offsets.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
         }
@@ -309,10 +309,16 @@ int finish_encode(vidc_ctx *ctx, vidc_roc *r, const uint32_t *d_arena, uint32_t 
     VIDC_TRY(r->d_words.alloc(r->total_words + 4, ctx->dpool));  // + padding: the lane decoder's look-ahead reads orig[0..1]
     if (nlist) {
         EventTimer tm(ctx);
-        uint32_t grid = (uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 16);
-        hipLaunchKernelGGL(k_roc_compact, dim3(grid), dim3(256), 0, ctx->stream, d_arena,
-                           r->rows ? (const uint64_t *)nullptr : (const uint64_t *)r->d_offsets.p, arena_stride,
-                           r->d_word_off.p, r->d_words.p, (uint32_t)nlist);
+        const uint64_t *d_off = r->rows ? (const uint64_t *)nullptr : (const uint64_t *)r->d_offsets.p;
+        if (r->total_words / nlist < 64) {  // graph rows / tiny lists (a few dozen words each): one wavefront per 64 lists
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((nlist + 63) / 64, (uint64_t)ctx->num_cu * 64);
+            hipLaunchKernelGGL(k_roc_compact_groups, dim3(grid), dim3(64), 0, ctx->stream, d_arena, d_off, arena_stride,
+                               r->d_word_off.p, r->d_words.p, (uint32_t)nlist);
+        } else {
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 16);
+            hipLaunchKernelGGL(k_roc_compact, dim3(grid), dim3(256), 0, ctx->stream, d_arena, d_off, arena_stride,
+                               r->d_word_off.p, r->d_words.p, (uint32_t)nlist);
+        }
         VIDC_HIP(hipGetLastError());
         double ms = tm.stop();
         ctx->phase_ms[VIDC_PHASE_ROC_COMPACT] = ms;

@@ -592,5 +592,36 @@ __global__ void k_roc_compact(const uint32_t *arena, const uint64_t *offsets, ui
     }
 }
 
+// The same for many short lists / graph rows (a few dozen words each): one wavefront per 64 consecutive lists, lane
+// per OUTPUT word (the group's words are contiguous in `words`), the owning list found by a binary search over the
+// group's 65 word offsets in LDS.  A workgroup per 34-word row spent its time on launch and header loads: the
+// compaction of 10^6 graph rows took as long as their encode kernel.
+__global__ void __launch_bounds__(64) k_roc_compact_groups(const uint32_t *arena, const uint64_t *offsets, uint32_t stride,
+                                                           const uint64_t *word_off, uint32_t *words, uint32_t nlist) {
+    __shared__ uint64_t wo[65];
+    __shared__ uint64_t ao[64];
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t g0 = blockIdx.x * 64u; g0 < nlist; g0 += gridDim.x * 64u) {
+        const uint32_t cnt = nlist - g0 < 64u ? nlist - g0 : 64u;
+        if (lane < cnt) {
+            wo[lane] = word_off[g0 + lane];
+            ao[lane] = roc_arena_at(offsets, stride, g0 + lane);
+        }
+        if (lane == 0) wo[cnt] = word_off[g0 + cnt];
+        __syncthreads();
+        const uint64_t w_begin = wo[0], total = wo[cnt] - w_begin;
+        for (uint64_t k = lane; k < total; k += 64) {
+            const uint64_t g = w_begin + k;
+            uint32_t lo = 0, hi = cnt;  // largest r with wo[r] <= g
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (wo[mid] <= g) lo = mid; else hi = mid;
+            }
+            words[g] = arena[ao[lo] + (g - wo[lo])];
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace dev
 }  // namespace vidc
