@@ -134,6 +134,16 @@ struct Pinned {
 #define VIDC_MT_TABLE 1024
 // largest divisor of the lane-per-list kernels' reciprocal table (== VIDC_LANE_MAX64 in roc_lane.h)
 #define VIDC_LANE_TAB 4096
+// one entry of the chain kernels' divisor table (roc_u2.h: U2Div)
+inline void u2_div_entry(uint32_t d, uint32_t out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (d == 0) return;
+    const uint64_t m = ~0ull / (uint64_t)d;
+    out[0] = (uint32_t)m;
+    out[1] = (uint32_t)(m >> 32);
+    out[2] = d >= 2u ? (uint32_t)(0x100000000ull / d) : 0xffffffffu;
+    out[3] = d >= 2u ? (0x80000000u / (d - 1u)) * (d - 1u) - 1u : 0u;
+}
 
 // Scratch blocks are cached per context so steady-state encode/decode calls do not hipMalloc.
 struct PoolBlock {
@@ -154,6 +164,7 @@ struct vidc_ctx {
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     uint32_t *d_mt = nullptr;  // VIDC_MT_TABLE words
+    void *d_u2tab = nullptr;   // per-divisor constants of the hand-scheduled chain kernels (roc_u2.h), VIDC_ROC_MAX_LIST + 1 entries
     void *d_ltab = nullptr;    // divisor table of the lane-per-list kernels (roc_lane.h), VIDC_LANE_TAB + 1 entries
     int num_cu = 256;
     double last_kernel_ms = 0.0;

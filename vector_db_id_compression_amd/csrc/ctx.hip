@@ -182,6 +182,17 @@ int vidc_ctx_create(int device, vidc_ctx **out) {
         vidc_ctx_destroy(c);
         return VIDC_ERR_HIP;
     }
+    {
+        // divisor table of the chain kernels (roc_u2.h): one 16-byte entry per possible list length
+        std::vector<uint32_t> ut(((size_t)VIDC_ROC_MAX_LIST + 1) * 4);
+        for (uint32_t d = 0; d <= VIDC_ROC_MAX_LIST; d++) u2_div_entry(d, &ut[(size_t)d * 4]);
+        if (hipMalloc(&c->d_u2tab, ut.size() * 4) != hipSuccess ||
+            hipMemcpy(c->d_u2tab, ut.data(), ut.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            vidc::set_error("divisor table upload failed");
+            vidc_ctx_destroy(c);
+            return VIDC_ERR_HIP;
+        }
+    }
     *out = c;
     return VIDC_OK;
 }
@@ -192,6 +203,7 @@ void vidc_ctx_destroy(vidc_ctx *c) {
         if (b.p) (void)hipHostFree(b.p);
     if (c->d_mt) (void)hipFree(c->d_mt);
     if (c->d_ltab) (void)hipFree(c->d_ltab);
+    if (c->d_u2tab) (void)hipFree(c->d_u2tab);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto &ev : c->tev) if (ev) (void)hipEventDestroy(ev);

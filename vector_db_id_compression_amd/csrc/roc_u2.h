@@ -1,0 +1,562 @@
+// roc_u2.h -- hand-scheduled "universe bitmap" ROC chain kernels (round 2): the latency-critical path of the
+// BASELINE configuration (one 52 114-id list = 52 114 dependent codec steps on ONE wavefront).
+//
+// Same bitstream as roc_u.h / codec.cpp:21-152; what changed is the shape of the step:
+//
+//  * head' = ID_push(q, x) is B(q) + c(x): every renormalisation decision of the two 16-bit slices depends on
+//    q = head div nmax alone, and x only adds c(x) = x_lo * 2^p1 + x_hi (or x_hi when the second slice renormalises)
+//    below the low zero bits of B.  The 64-bit division of the NEXT index pop therefore runs on B while the select is
+//    in flight (all lanes divide B by THEIR divisor with per-lane 64-bit reciprocals), and only a 21-bit fix-up
+//    (r_B + c(x)) divmod nmax' -- mul_hi by a 32-bit reciprocal, one multiply-add, one min -- sits between two selects.
+//  * order statistics: ONE exclusive prefix counter per level, stored in REVERSED lane order (lane L <-> block 63 - L),
+//    so that "counter <= k" is true from the wanted lane upwards: v_cmp + s_ff1 + v_readlane gives both the index and
+//    the amount to subtract (the inclusive / exclusive counter pairs and the DPP shift of roc_u.h are gone); level-2
+//    rows are 64 unpacked VGPRs read with s_set_gpr_idx.
+//  * the steady-state loop is one asm statement with a fixed register map (below).  A lone wavefront issues one
+//    instruction every 4 cycles whatever its type (tools/ubench_issue.hip) and a scalar instruction issued less than
+//    ~16 cycles after a VALU instruction that wrote an SGPR / VCC stalls for the difference (tools/ubench_sel*.hip);
+//    the body is ordered so that those windows and the LDS round trip hold independent vector work (the division of
+//    B, counter updates, the removal of the previous id from the bitmap).
+//  * renormalisation is branch-free (s_cselect + unconditional ring write + stack-pointer add of the condition).
+//
+// Anything rare (index-pop renormalisation, stack underflow, nmax <= 2, ring spills) leaves the asm loop at a step
+// boundary and runs one generic C++ step (u2_slow_step) on the same data structures.
+// Lists the fast path cannot represent (precision > 20, an id >= 2^precision, duplicates) are handed back to the
+// general kernels through VIDC_ST_PENDING_SORT like roc_u.h does for multisets.
+#pragma once
+#include "roc_u.h"
+
+namespace vidc {
+namespace dev {
+
+template <int UB>
+struct U2Geom {
+    static_assert(UB == 18 || UB == 20, "universe bits");
+    static constexpr uint32_t GSH = UB == 20 ? 2u : 0u;   // log2(bitmap words per level-2 entry)
+    static constexpr uint32_t G = 1u << GSH;
+    static constexpr uint32_t ESH = 6u + GSH;             // id bits below the entry index
+    static constexpr uint32_t NE = 4096u;                 // 64 blocks x 64 entries
+    static constexpr uint32_t BITMAP_BYTES = NE * G * 8u;
+    static constexpr uint32_t LDS_BYTES = BITMAP_BYTES + 16u;  // + a dummy word: target of the "no pending removal" store
+};
+
+// LDS word index of id x: entries are stored in REVERSED order (entry e' = e ^ 4095), words inside an entry ascending
+template <int UB>
+__device__ __forceinline__ uint32_t u2_word_of(uint32_t x) {
+    using U = U2Geom<UB>;
+    return (((x >> U::ESH) ^ (U::NE - 1u)) << U::GSH) | ((x >> 6) & (U::G - 1u));
+}
+
+// Per-divisor constants (16 bytes, table built once per context, vidc_ctx::d_u2tab, VIDC_ROC_MAX_LIST + 1 entries):
+//   x = floor((2^64 - 1) / d) low, y = high, z = floor(2^32 / d) (d >= 2), w = (d - 1) * floor(2^31 / (d - 1)) - 1
+// (w is the index-pop renormalisation threshold of the NEXT step, whose divisor is d - 1).  Entry 0 is all zero.
+typedef uint4 U2Div;  // filled by u2_div_entry (common.h)
+
+// exclusive counters in reversed lane order, see the header comment.  rows: ra = rows 0..31, rb = rows 32..63.
+template <int UB>
+__device__ __forceinline__ void u2_build_counts(const uint64_t *bm, uint32_t &E1, v32u &ra, v32u &rb) {
+    using U = U2Geom<UB>;
+    const uint32_t lane = lane_id();
+    uint32_t running = 0;
+    E1 = 0;
+#pragma unroll
+    for (int L1 = 63; L1 >= 0; L1--) {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < U::G; g++) cnt += popc64(bm[((uint32_t)L1 * 64u + lane) * U::G + g]);
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)inc, o, 64);
+            if (lane >= (uint32_t)o) inc += v;
+        }
+        const uint32_t tot = rl(inc, 63);
+        const uint32_t row = tot - inc;  // elements of this block in entries with a LARGER lane index (smaller ids)
+        if (L1 < 32) ra[L1] = row; else rb[L1 - 32] = row;
+        E1 = lane == (uint32_t)L1 ? running : E1;
+        running += tot;
+    }
+}
+
+// Row L1 of the level-2 counters by register index.  A C++ subscript with a run-time index would make the compiler
+// keep both vectors in scratch memory around every asm statement; the rows stay pinned to v64..v127 instead.
+__device__ __forceinline__ uint32_t u2_row_get(v32u &ra, v32u &rb, uint32_t L1) {
+    uint32_t v;
+    asm volatile("s_set_gpr_idx_on %3, gpr_idx(SRC0)\n\tv_mov_b32 %0, v64\n\ts_set_gpr_idx_off"
+                 : "=v"(v), "+{v[64:95]}"(ra), "+{v[96:127]}"(rb) : "s"(L1));
+    return v;
+}
+__device__ __forceinline__ void u2_row_set(v32u &ra, v32u &rb, uint32_t L1, uint32_t v) {
+    asm volatile("s_set_gpr_idx_on %2, gpr_idx(DST)\n\tv_mov_b32 v64, %3\n\ts_set_gpr_idx_off"
+                 : "+{v[64:95]}"(ra), "+{v[96:127]}"(rb) : "s"(L1), "v"(v));
+}
+
+// one generic encode step on the reversed structures (rare path): codec.cpp:131-137
+template <int UB>
+__device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uint32_t nmax, uint32_t &E1, v32u &ra, v32u &rb,
+                                              uint64_t *bm, uint32_t p0, uint32_t p1) {
+    using U = U2Geom<UB>;
+    const uint32_t lane = lane_id();
+    ws_prepare(st);
+    const uint32_t lq = 0x80000000u / nmax;
+    uint32_t k = ans_idx_pop(head, st, nmax, lq * nmax, ~0ull / (uint64_t)nmax);
+    const uint32_t L1 = ff1(ballot(E1 <= k));
+    k -= rl(E1, L1);
+    uint32_t row = u2_row_get(ra, rb, L1);
+    const uint32_t L2 = ff1(ballot(row <= k));
+    k -= rl(row, L2);
+    const uint32_t e = L1 * 64u + L2;
+    uint32_t g = 0;
+    uint64_t W = rfl64(bm[e * U::G]);
+    for (; g + 1u < U::G; g++) {
+        const uint32_t pc = popc64(W);
+        if (k < pc) break;
+        k -= pc;
+        W = rfl64(bm[e * U::G + g + 1u]);
+    }
+    const uint32_t b = ff1(ballot(mbcnt(W) == k) & W);
+    const uint32_t x = ((e ^ (U::NE - 1u)) << U::ESH) | (g << 6) | b;
+    E1 -= lane < L1 ? 1u : 0u;
+    row -= lane < L2 ? 1u : 0u;
+    u2_row_set(ra, rb, L1, row);
+    bm[e * U::G + g] = W & ~(1ull << b);
+    wave_sync();
+    ans_id_push(head, st, x, p0, p1);
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The encode loop.  One asm statement runs a list from a plain ANS state to the next rare event.  Register map
+// (pinned through the operand constraints of U2_ENC_ASM):
+//   v2  lane id          v3  (lane & 3) * 8 [G = 4] / 0     v4  E1 (level 1)     v5  ANS stack ring   v6  order ring
+//   v7  m_lo  v8  m_hi  v9  d  v10 m32  v11 thrs  v29 -d    (per lane: lane j owns divisor D0 - j)   v54:57 next block
+//   v12 k     v13 row   v14 x_hi  v15 x_lo  v16 s  v17 q^  v18 r  v19 r - d  v20:21 {qf, 0}  v52 k per lane
+//   v22:23 bit mask  v24:25 new word  v26 its address  v27 tmp  v28 LDS address  v30:31 loaded word(s)  v58 tmp
+//   v32 popcount  v33 v34 prefix  v35 exclusive prefix  v49 mbcnt
+//   v36:37 {ph, 0}  v38:39 U  v40:41 {U.lo, 0}  v42:43 W  v44:45 Z  v46:47 q^ of B (per lane)  v48 r of B (per lane)
+//   v50:51 q = q^ + qf (per lane)           v64..v127 level-2 rows
+//   s40 x      s41 mul    s42 k      s43 L1    s44 L2    s45 entry   s46 x base  s47 g     s48 b     s49 E1[L1]
+//   s50:51 q   s52:53 a   s54:55 A   s56:57 b  s58:59 B  s60 sp      s61 lo      s62 slot of the second push
+//   s63 row[L2]  s64 excl[g]  s65 word address  s66:67 word  s68 tmp  s69 t (lane of the current divisor)
+//   s70 t_end  s71 limit  s72 tmp  s73 T0 = 2^(31-p0)  s74 T1 = 2^(31-p1)  s75 2^p1  s76 p0  s77 p1
+//   s78:81 carry scratch  s82:83 mask scratch  s85 D0 (divisor of lane 0)
+//   s86 fast steps left from lane 0 of the block  s87 order base  s88:89 order pointer  s90:91 arena pointer
+//   s92 arena capacity  s93 error flags  s94:95 divisor table  s96:97 saved exec  s98 s99 tmp
+// Invariant at label 1 (top of step i, divisor lane t = s69):
+//   head_i = B + c(x_{i-1}) with c = x_lo * mul + x_hi; lanes hold (v46:47, v48) = (q^, r) with B = q^ d_lane + r,
+//   0 <= r < 2 d_lane; the bit of x_{i-1} is still set in the bitmap (word s66:67 at address s65; it is cleared in
+//   the first window of the step).
+// Blocks: lanes 0..62 of a block serve as "current" divisor, lane t + 1 as the next one; after lane 62 the constants
+// of the next 64 divisors (prefetched from the table one block ahead) are installed and lane 63's division result
+// moves to lane 0.  The order ring (v6) is indexed by t and flushed at block ends and on exit.
+#ifdef U2_PROF  // dev builds (tools/chain_u2.hip -DU2_PROF): cycles per section, accumulated per lane-uniform VGPR
+#define U2P(i) "s_memtime s[96:97]\n s_waitcnt lgkmcnt(0)\n s_sub_u32 s99, s96, s98\n s_mov_b32 s98, s96\n v_add_u32 v" #i ", s99, v" #i "\n"
+#define U2P_OPERANDS , "+{v130}"(prof[0]), "+{v131}"(prof[1]), "+{v132}"(prof[2]), "+{v133}"(prof[3]), "+{v134}"(prof[4]), "+{v135}"(prof[5]), \
+    "+{v136}"(prof[6]), "+{v137}"(prof[7]), "+{v138}"(prof[8]), "+{v139}"(prof[9]), "+{v140}"(prof[10]), "+{v141}"(prof[11]), "+{v142}"(prof[12]), "+{v143}"(prof[13])
+#else
+#define U2P(i) ""
+#define U2P_OPERANDS
+#endif
+#define U2_DIV \
+    "v_mul_hi_u32 v36, s58, v7\n"                      /* B div d (all lanes): mulhi64(B, m) */ \
+    "v_mad_u64_u32 v[38:39], s[78:79], s58, v8, v[36:37]\n" \
+    "v_mov_b32 v40, v38\n" \
+    "v_mad_u64_u32 v[42:43], s[78:79], s59, v7, v[40:41]\n" \
+    "v_add_co_u32_e64 v44, s[78:79], v39, v43\n" \
+    "v_addc_co_u32_e64 v45, s[80:81], 0, 0, s[78:79]\n" \
+    "v_mad_u64_u32 v[46:47], s[78:79], s59, v8, v[44:45]\n"
+#define U2_DIV_REM \
+    "v_mul_lo_u32 v48, v46, v9\n" \
+    "v_sub_u32 v48, s58, v48\n"                        /* r_B in [0, 2d) */
+// constants of the block whose lane 0 divides by s85: v54:57 -> v7 v8 v10 v11, d, -d; prefetch of the block after it
+#define U2_INSTALL \
+    "v_mov_b32 v7, v54\n v_mov_b32 v8, v55\n v_mov_b32 v10, v56\n v_mov_b32 v11, v57\n" \
+    "v_sub_u32 v9, s85, v2\n" \
+    "v_max_i32 v9, 1, v9\n" \
+    "v_sub_u32 v29, 0, v9\n" \
+    "s_sub_u32 s68, s85, 63\n" \
+    "v_sub_u32 v58, s68, v2\n" \
+    "v_max_i32 v58, 0, v58\n" \
+    "v_lshlrev_b32 v58, 4, v58\n" \
+    "global_load_dwordx4 v[54:57], v58, s[94:95]\n"
+#define U2_ENC_ENTRY \
+    "v_sub_u32 v58, s85, v2\n" \
+    "v_max_i32 v58, 0, v58\n" \
+    "v_lshlrev_b32 v58, 4, v58\n" \
+    "global_load_dwordx4 v[54:57], v58, s[94:95]\n" \
+    "s_waitcnt vmcnt(0)\n" \
+    U2_INSTALL U2_DIV U2_DIV_REM \
+    "s_mov_b32 s69, 0\n" \
+    "s_min_u32 s70, s86, 63\n"
+
+#define U2_ENC_TOP \
+    "1:\n" U2P(130) U2P(131) \
+    "v_lshrrev_b32_e64 v14, 16, s40\n"                 /* x_hi */ \
+    "v_bfe_u32 v15, s40, 0, 16\n"                      /* x_lo */ \
+    "v_add_u32 v16, v48, v14\n"                        /* s = r_B + x_hi */ \
+    "v_mad_u32_u24 v16, v15, s41, v16\n"               /*   + x_lo * mul */ \
+    "v_mul_hi_u32 v17, v16, v10\n"                     /* q^ = mulhi(s, 2^32 / d) */ \
+    "v_mad_i32_i24 v18, v17, v29, v16\n"               /* r = s - q^ d in [0, 2d) */ \
+    "v_sub_u32 v19, v18, v9\n" \
+    "v_min_u32 v52, v18, v19\n"                        /* k (of this lane's divisor) */ \
+    "v_ashrrev_i32 v27, 31, v19\n"                     /* -1 if r < d */ \
+    "v_add3_u32 v20, v17, v27, 1\n"                    /* qf = q^ + (r >= d) */ \
+    "v_readlane_b32 s42, v52, s69\n"                   /* k of the step */ \
+    "v_add_co_u32_e64 v50, s[78:79], v46, v20\n"       /* q = head div d (per lane) */ \
+    "v_addc_co_u32_e64 v51, s[78:79], 0, v47, s[78:79]\n" \
+    "v_mov_b32 v12, s42\n" U2P(132) \
+    "v_cmp_le_u32 vcc, v4, v12\n"                      /* level 1 */ \
+    "v_lshlrev_b64 v[22:23], s40, 1\n"                 /* removal of x_{i-1} from the bitmap */ \
+    "v_bfi_b32 v24, v22, 0, s66\n" \
+    "v_readlane_b32 s50, v50, s69\n" \
+    "v_readlane_b32 s51, v51, s69\n" \
+    U2P(133) \
+    "v_bfi_b32 v25, v23, 0, s67\n" \
+    "v_mov_b32 v26, s65\n" \
+    "ds_write_b64 v26, v[24:25]\n" \
+    "s_ff1_i32_b64 s43, vcc\n" \
+    "s_set_gpr_idx_on s43, gpr_idx(SRC0)\n" \
+    "v_mov_b32 v13, v64\n"                             /* row L1 */ \
+    "s_set_gpr_idx_off\n" U2P(134) \
+    "s_and_b32 m0, s60, 63\n"                          /* slice 0 (codec.cpp:65-76), branch-free */ \
+    "s_cmp_ge_u32 s51, s73\n" \
+    "v_writelane_b32 v5, s50, m0\n" \
+    "s_cselect_b32 s52, s51, s50\n" \
+    "s_cselect_b32 s53, 0, s51\n" \
+    "s_addc_u32 s60, s60, 0\n" \
+    "s_lshl_b64 s[54:55], s[52:53], s76\n" U2P(135) \
+    "v_readlane_b32 s49, v4, s43\n" \
+    "v_subrev_u32 v27, s43, v2\n"                      /* lane - L1 */ \
+    "v_subrev_u32 v12, s49, v12\n" \
+    "v_cmp_le_u32 vcc, v13, v12\n"                     /* level 2 */ \
+    "v_ashrrev_i32 v27, 31, v27\n" \
+    "v_add_u32 v4, v4, v27\n"                          /* E1 -= 1 in lanes below L1 */ \
+    "s_ff1_i32_b64 s44, vcc\n" \
+    "s_lshl_b32 s45, s43, 6\n" \
+    "s_or_b32 s45, s45, s44\n" U2P(136)
+
+#define U2_ENC_MID_G4 \
+    "v_lshl_add_u32 v28, s45, 5, v3\n" \
+    "ds_read_b64 v[30:31], v28\n"
+#define U2_ENC_MID_G1 \
+    "v_lshlrev_b32_e64 v28, 3, s45\n" \
+    "ds_read_b64 v[30:31], v28\n"
+
+#define U2_ENC_SLICE1(XSH) \
+    "s_and_b32 s62, s60, 63\n"                         /* slice 1 */ \
+    "s_cmp_ge_u32 s55, s74\n" \
+    "s_cselect_b32 s41, 0, s75\n" \
+    "s_cselect_b32 s56, s55, s54\n" \
+    "s_cselect_b32 s57, 0, s55\n" \
+    "s_addc_u32 s60, s60, 0\n" \
+    "s_lshl_b64 s[58:59], s[56:57], s77\n"             /* B */ \
+    "s_xor_b32 s46, s45, 0xfff\n" \
+    "s_lshl_b32 s46, s46, " XSH "\n"                   /* id bits of the entry */ \
+    "v_readlane_b32 s63, v13, s44\n" \
+    "v_subrev_u32 v59, s44, v2\n"                      /* lane - L2 */ \
+    "v_subrev_u32 v12, s63, v12\n" \
+    "v_mul_hi_u32 v36, s58, v7\n"                      /* B div d (all lanes): mulhi64(B, m) */ \
+    "v_mad_u64_u32 v[38:39], s[78:79], s58, v8, v[36:37]\n" \
+    "v_mov_b32 v40, v38\n" \
+    "v_mad_u64_u32 v[42:43], s[78:79], s59, v7, v[40:41]\n"
+
+#define U2_ENC_L3_G4 \
+    "s_waitcnt lgkmcnt(0)\n" U2P(137) \
+    "v_bcnt_u32_b32 v32, v30, 0\n" \
+    "v_bcnt_u32_b32 v32, v31, v32\n" \
+    "v_add_co_u32_e64 v44, s[78:79], v39, v43\n" \
+    "v_addc_co_u32_e64 v45, s[80:81], 0, 0, s[78:79]\n" \
+    "v_add_u32_dpp v33, v32, v32 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+    "v_mad_u64_u32 v[46:47], s[78:79], s59, v8, v[44:45]\n" \
+    "v_ashrrev_i32 v59, 31, v59\n" \
+    "v_add_u32_dpp v34, v33, v33 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+    "v_cmp_gt_u32 vcc, v34, v12\n"                     /* word of the entry */ \
+    "v_sub_u32 v35, v34, v32\n" U2P(138) \
+    "v_mul_lo_u32 v48, v46, v9\n" \
+    "v_add_u32 v13, v13, v59\n"                        /* row -= 1 in lanes below L2 */ \
+    "s_ff1_i32_b64 s47, vcc\n" \
+    "s_lshl_b32 s68, s47, 6\n" \
+    "s_or_b32 s46, s46, s68\n" \
+    "s_lshl_b32 s65, s45, 2\n" \
+    "s_add_u32 s65, s65, s47\n" \
+    "s_lshl_b32 s65, s65, 3\n" \
+    "v_readlane_b32 s64, v35, s47\n" \
+    "v_readlane_b32 s66, v30, s47\n" \
+    "v_readlane_b32 s67, v31, s47\n" \
+    "v_subrev_u32 v12, s64, v12\n" U2P(139)
+#define U2_ENC_L3_G1 \
+    "s_lshl_b32 s65, s45, 3\n" \
+    "v_add_co_u32_e64 v44, s[78:79], v39, v43\n" \
+    "v_addc_co_u32_e64 v45, s[80:81], 0, 0, s[78:79]\n" \
+    "v_ashrrev_i32 v59, 31, v59\n" \
+    "v_mad_u64_u32 v[46:47], s[78:79], s59, v8, v[44:45]\n" \
+    "v_add_u32 v13, v13, v59\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "v_readfirstlane_b32 s66, v30\n" \
+    "v_readfirstlane_b32 s67, v31\n" \
+    "v_mul_lo_u32 v48, v46, v9\n"
+
+#define U2_ENC_BOT(ORDER) \
+    "v_mbcnt_lo_u32_b32 v49, s66, 0\n" \
+    "v_mbcnt_hi_u32_b32 v49, s67, v49\n" \
+    "v_cmp_eq_u32 vcc, v49, v12\n"                     /* bit of the word */ \
+    "v_sub_u32 v48, s58, v48\n"                        /* r_B in [0, 2d) */ \
+    "s_and_b64 s[82:83], vcc, s[66:67]\n" \
+    "s_ff1_i32_b64 s48, s[82:83]\n" \
+    "s_or_b32 s40, s46, s48\n"                         /* x */ U2P(140) \
+    "s_mov_b32 m0, s62\n" \
+    "s_and_b32 s68, s40, 0xffff\n" \
+    "s_or_b32 s68, s68, s54\n" \
+    "v_writelane_b32 v5, s68, m0\n"                    /* word of the second slice (kept only if it renormalised) */ \
+    ORDER U2P(141) \
+    "s_set_gpr_idx_on s43, gpr_idx(DST)\n" \
+    "v_mov_b32 v64, v13\n" \
+    "s_set_gpr_idx_off\n" U2P(142) \
+    "s_lshr_b32 s68, s58, 31\n"                        /* next index pop must not renormalise (U2_SAFE_HI) */ \
+    "s_add_u32 s68, s68, s59\n" \
+    "s_add_u32 s68, s68, -1\n" \
+    "s_cmp_ge_u32 s68, 0x7ff80000\n" \
+    "s_cselect_b32 s71, 0, s70\n" \
+    "s_sub_u32 s68, s60, s61\n"                        /* ring nearly full */ \
+    "s_cmp_ge_u32 s68, 62\n" \
+    "s_cselect_b32 s71, 0, s71\n" \
+    "s_add_u32 s69, s69, 1\n" U2P(143) \
+    "s_cmp_lt_u32 s69, s71\n" \
+    "s_cbranch_scc1 1b\n"
+#define U2_ENC_ORDER \
+    "s_mov_b32 m0, s69\n" \
+    "s_nop 0\n" \
+    "v_writelane_b32 v6, s40, m0\n"
+
+// store order-ring lanes [0, s72) at order[s87 ...]; s87 += s72
+#define U2_ORDER_FLUSH \
+    "v_cmp_gt_u32 vcc, s72, v2\n" \
+    "v_add_u32 v58, s87, v2\n" \
+    "v_lshlrev_b32 v58, 2, v58\n" \
+    "s_and_saveexec_b64 s[96:97], vcc\n" \
+    "global_store_dword v58, v6, s[88:89]\n" \
+    "s_mov_b64 exec, s[96:97]\n" \
+    "s_add_u32 s87, s87, s72\n"
+
+// what the fast loop falls into: ring spill, block change, and the decision to go on
+#define U2_ENC_OUTER(FLUSH) \
+    "s_lshr_b32 s68, s58, 31\n"                        /* the index-pop test of the next step */ \
+    "s_add_u32 s68, s68, s59\n" \
+    "s_add_u32 s68, s68, -1\n" \
+    "s_cmp_ge_u32 s68, 0x7ff80000\n" \
+    "s_cselect_b32 s99, 1, 0\n" \
+    "s_sub_u32 s68, s60, s61\n" \
+    "s_cmp_lt_u32 s68, 62\n" \
+    "s_cbranch_scc1 3f\n" \
+    "v_subrev_u32 v27, s61, v2\n"                      /* spill the 32 oldest ring words (ws_spill32) */ \
+    "v_and_b32 v27, 63, v27\n" \
+    "v_add_u32 v58, s61, v27\n" \
+    "v_cmp_gt_u32 vcc, 32, v27\n" \
+    "v_cmp_gt_u32 s[96:97], s92, v58\n" \
+    "v_lshlrev_b32 v58, 2, v58\n" \
+    "s_and_b64 vcc, vcc, s[96:97]\n" \
+    "s_and_saveexec_b64 s[96:97], vcc\n" \
+    "global_store_dword v58, v5, s[90:91]\n" \
+    "s_mov_b64 exec, s[96:97]\n" \
+    "s_add_u32 s61, s61, 32\n" \
+    "s_cmp_gt_u32 s61, s92\n" \
+    "s_cselect_b32 s68, 1, 0\n" \
+    "s_or_b32 s93, s93, s68\n" \
+    "3:\n" \
+    "s_cmp_lt_u32 s69, 63\n" \
+    "s_cbranch_scc1 5f\n" \
+    "s_waitcnt vmcnt(0)\n"                             /* block change: the prefetched constants have landed; waiting */ \
+    "s_mov_b32 s72, 63\n"                              /* here, before the ring store, keeps the store's latency off the chain */ \
+    FLUSH \
+    "s_sub_u32 s85, s85, 63\n" \
+    "s_sub_u32 s86, s86, 63\n" \
+    "v_readlane_b32 s68, v46, 63\n" \
+    "v_readlane_b32 s72, v47, 63\n" \
+    "v_readlane_b32 s98, v48, 63\n" \
+    "s_nop 3\n" \
+    "v_writelane_b32 v46, s68, 0\n" \
+    "v_writelane_b32 v47, s72, 0\n" \
+    "v_writelane_b32 v48, s98, 0\n" \
+    U2_INSTALL \
+    "s_mov_b32 s69, 0\n" \
+    "s_min_u32 s70, s86, 63\n" \
+    "5:\n" \
+    "s_cmp_ge_u32 s69, s70\n"                          /* no fast step left (nmax <= 2 next) */ \
+    "s_cbranch_scc1 9f\n" \
+    "s_cmp_eq_u32 s99, 0\n" \
+    "s_cbranch_scc1 1b\n" \
+    "9:\n" \
+    "s_mov_b32 s72, s69\n" \
+    FLUSH \
+    "s_waitcnt vmcnt(0)\n"
+
+// The index pop of a step renormalises when head_hi >= nmax * floor(2^31 / nmax) (push) or head < 2^31 (refill)
+// (codec.cpp:27-35).  nmax * floor(2^31 / nmax) > 2^31 - nmax >= 2^31 - 2^18, so with t = head_hi + (head_lo >> 31) - 1
+// (0xffffffff exactly when head < 2^31) "t < 2^31 - 2^19" is a sufficient test for the fast path that needs no
+// per-divisor constant; the few extra heads it rejects take the generic step.  Heads in [2^31, 2^32) are common (3 % of
+// the steps of a 20-bit list: every fourth renormalisation of the second slice leaves one) and stay on the fast path.
+#define U2_SAFE_HI 0x7ff80000u
+__device__ __forceinline__ bool u2_needs_generic(uint64_t head) {
+    return (uint32_t)(head >> 32) + ((uint32_t)head >> 31) - 1u >= U2_SAFE_HI;
+}
+template <int UB, bool WANT_ORDER>
+__global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div *__restrict__ dtab) {
+    using U = U2Geom<UB>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *bm = (uint64_t *)smem;
+    uint32_t *bm32 = (uint32_t *)smem;
+    const uint32_t lane = lane_id();
+    const uint32_t wi = blockIdx.x;
+    if (wi >= a.nwork) return;
+#ifdef U2_PROF2
+    const uint64_t tk0 = __builtin_readcyclecounter();
+#endif
+    const uint32_t l = rfl(a.worklist[wi]);
+    const uint64_t off = rfl64(a.offsets[l]);
+    const uint32_t n = rfl((uint32_t)(a.offsets[l + 1] - off));
+    {
+        uint4 *z = (uint4 *)smem;
+        for (uint32_t w = lane; w < U::LDS_BYTES / 16u; w += 64) z[w] = make_uint4(0, 0, 0, 0);
+    }
+    wave_sync();
+    bool dup = false;
+    uint32_t mx = 0;
+    for (uint32_t j0 = 0; j0 < n; j0 += 512u) {  // 8 loads per lane in flight (one per iteration made this loop 1.2 ms of S1)
+        uint64_t v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            const uint32_t j = j0 + u * 64u + lane;
+            v[u] = j < n ? __builtin_nontemporal_load(&a.ids[off + j]) : ~0ull;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            if (v[u] == ~0ull) continue;
+            const uint32_t x = (uint32_t)v[u];  // < 2^UB: guaranteed by the host's classification
+            const uint32_t bit = 1u << (x & 31u);
+            const uint32_t old = atomicOr(&bm32[u2_word_of<UB>(x) * 2u + ((x >> 5) & 1u)], bit);
+            dup |= (old & bit) != 0;
+            mx = x > mx ? x : mx;
+        }
+    }
+    wave_sync();
+    const uint32_t P = rfl(a.prec[l]);  // written by the prepass
+    const uint32_t maxid = wave_max_u32(mx);
+    // multisets, precisions above 20 bits and ids that do not fit the precision (reference carry quirk) take the
+    // general kernels
+    if (ballot(dup) || P > 20u || (maxid >> P) != 0u) {
+        if (lane == 0) a.status[l] = VIDC_ST_PENDING_SORT;
+        return;
+    }
+    uint32_t E1;
+    v32u ra, rb;
+    u2_build_counts<UB>(bm, E1, ra, rb);
+
+    const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? P - 16u : 0u;
+    WStack st;
+    {
+        const uint64_t ao = rfl64(arena_at(a, l));
+        ws_init_empty(st, a.arena + ao, rfl((uint32_t)(arena_at(a, l + 1) - ao)), a.mt, VIDC_MT_TABLE);
+    }
+    uint64_t head = VIDC_RANS_L;
+    uint32_t obuf = 0, obase = 0;
+    uint32_t *order = WANT_ORDER ? a.perm + off : nullptr;  // sampled ids; k_perm_from_order turns them into positions
+    const uint32_t T0 = 0x80000000u >> p0, T1 = 0x80000000u >> p1, MULN = 1u << p1;
+    const uint32_t l3off = U::G == 4u ? (lane & 3u) * 8u : 0u;
+
+#ifdef U2_PROF
+    uint32_t prof[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+#ifdef U2_PROF2
+    uint64_t prof2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    prof2[2] = __builtin_readcyclecounter();
+#endif
+    uint32_t nmax = n;  // divisor of the next step
+    while (nmax) {
+        if (st.sp - st.lo >= 62u) ws_spill32(st);
+        // generic step: the last two (the fix-up reciprocal needs nmax' >= 2) and index pops that renormalise
+        if (nmax < 3u || u2_needs_generic(head)) {
+            const uint32_t x = u2_slow_step<UB>(head, st, nmax, E1, ra, rb, bm, p0, p1);
+            if (WANT_ORDER) {
+                if (lane == 0) order[obase] = x;
+                obase++;
+            }
+            nmax--;
+            continue;
+        }
+        uint32_t s_x = 0, s_mul = 0, s_t = 0, s_waddr = U::BITMAP_BYTES, s_D0 = rfl(nmax), s_left = rfl(nmax - 2u);
+        uint64_t s_w = 0, s_B = rfl64(head);
+        uint64_t z0 = 0, z1 = 0, z2 = 0;  // {value, 0} register pairs: the odd halves stay 0
+        uint64_t qh = 0;
+        uint32_t rr = 0;
+        st.sp = rfl(st.sp);
+        st.lo = rfl(st.lo);
+        st.err = rfl(st.err);
+        obase = rfl(obase);
+#ifdef U2_PROF2
+        const uint64_t tp0 = __builtin_readcyclecounter();
+#endif
+        // clang-format off
+#define U2_ENC_ASM(BODY)                                                                                                  \
+        asm volatile(BODY                                                                                                 \
+            : "+{v4}"(E1), "+{v5}"(st.win), "+{v6}"(obuf), "+{v[64:95]}"(ra), "+{v[96:127]}"(rb),                          \
+              "+{v[46:47]}"(qh), "+{v48}"(rr), "+{s40}"(s_x), "+{s41}"(s_mul), "+{s[58:59]}"(s_B), "+{s60}"(st.sp),          \
+              "+{s61}"(st.lo), "+{s65}"(s_waddr), "+{s[66:67]}"(s_w), "+{s69}"(s_t), "+{s85}"(s_D0), "+{s86}"(s_left),       \
+              "+{s87}"(obase), "+{s93}"(st.err), "+{v[20:21]}"(z0), "+{v[36:37]}"(z1), "+{v[40:41]}"(z2) U2P_OPERANDS       \
+            : "{v2}"(lane), "{v3}"(l3off), "{s73}"(T0), "{s74}"(T1), "{s75}"(MULN), "{s76}"(p0), "{s77}"(p1),                \
+              "{s[88:89]}"(order), "{s[90:91]}"(st.mem), "{s92}"(st.cap), "{s[94:95]}"(dtab)                                \
+            : "memory", "vcc", "scc", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",  \
+              "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v38", "v39",\
+              "v42", "v43", "v44", "v45", "v49", "v50", "v51", "v52", "v54", "v55", "v56", "v57", "v58", "v59",                     \
+              "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57",\
+              "s62", "s63", "s64", "s68", "s70", "s71", "s72", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s96",       \
+              "s97", "s98", "s99")
+        if (U::G == 4u) {
+            if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT(U2_ENC_ORDER) U2_ENC_OUTER(U2_ORDER_FLUSH));
+            else U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT("") U2_ENC_OUTER(""));
+        } else {
+            if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT(U2_ENC_ORDER) U2_ENC_OUTER(U2_ORDER_FLUSH));
+            else U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT("") U2_ENC_OUTER(""));
+        }
+#undef U2_ENC_ASM
+        // clang-format on
+#ifdef U2_PROF2
+        prof2[0] += __builtin_readcyclecounter() - tp0;
+        prof2[1] += 1;
+        prof2[4] += s_t == 63u;
+        prof2[5] += st.sp - st.lo >= 62u;
+        prof2[6] += u2_needs_generic(s_B);
+        prof2[7] += s_t;
+#endif
+        // ---- back to the plain state.  head = B + c(x); x's bit leaves the bitmap; slices 2 and 3 of ID_push
+        // (precision 0: "if head >= 2^63 push", codec.cpp:92-105) can only fire on the way out
+        head = s_B + (uint64_t)((s_x & 0xffffu) * s_mul + (s_x >> 16));
+        bm[s_waddr >> 3] = s_w & ~(1ull << (s_x & 63u));
+        ws_window(st);
+        if (__builtin_expect((head >> 63) != 0ull, 0)) {
+            ws_prepare(st);
+            ans_u_push(head, st, 0u, 0u);
+            ans_u_push(head, st, 0u, 0u);
+        }
+        nmax = s_D0 - s_t;
+    }
+#ifdef U2_PROF2
+    prof2[3] = __builtin_readcyclecounter() - prof2[2];
+    prof2[2] -= tk0;
+    if (lane == 0)
+        for (int q = 0; q < 8; q++) ((uint64_t *)a.sid)[q] = prof2[q];
+#endif
+    ws_flush(st);
+#ifdef U2_PROF
+    if (lane == 0)
+        for (int q = 0; q < 14; q++) a.sid[q] = prof[q];
+#endif
+    if (lane == 0) {
+        a.heads[l] = head;
+        a.nwords[l] = st.sp;
+        a.draws[l] = st.draws;
+        a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
+    }
+}
+
+}  // namespace dev
+}  // namespace vidc
