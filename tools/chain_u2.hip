@@ -19,7 +19,7 @@ static void u2_div_entry_local(uint32_t d, uint32_t out[4]) {  // == u2_div_entr
     const uint64_t m = ~0ull / (uint64_t)d;
     out[0] = (uint32_t)m; out[1] = (uint32_t)(m >> 32);
     out[2] = d >= 2u ? (uint32_t)(0x100000000ull / d) : 0xffffffffu;
-    out[3] = d >= 2u ? (0x80000000u / (d - 1u)) * (d - 1u) - 1u : 0u;
+    out[3] = 0x80000000u / d;
 }
 template <int UB>
 int run(uint32_t n, uint32_t seed, uint32_t P) {
@@ -65,9 +65,51 @@ int run(uint32_t n, uint32_t seed, uint32_t P) {
     }
     bool same = r[0].head == r[1].head && r[0].nw == r[1].nw && r[0].words == r[1].words && r[0].order == r[1].order && r[0].st == 0 && r[1].st == 0;
     size_t fd = 0; while (fd < n && r[0].order[fd] == r[1].order[fd]) fd++;
-    printf("UB=%d n=%u P=%u seed=%u: old %.1f ns/step, new %.1f ns/step; status %u/%u head %llx/%llx words %u/%u first order diff at %zu -> %s\n",
+    printf("UB=%d n=%u P=%u seed=%u: ENCODE old %.1f ns/step, new %.1f ns/step; status %u/%u head %llx/%llx words %u/%u first order diff at %zu -> %s\n",
            UB, n, P, seed, r[0].ms * 1e6 / n, r[1].ms * 1e6 / n, r[0].st, r[1].st, (unsigned long long)r[0].head,
            (unsigned long long)r[1].head, r[0].nw, r[1].nw, fd, same ? "IDENTICAL" : "MISMATCH");
+    // ---- decode the (old-kernel) stream with both decoders
+    bool dsame = true;
+    {
+        const uint32_t W0 = r[0].nw;
+        CK(hipMemcpy(d_arena, r[0].words.data(), (size_t)W0 * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_heads, &r[0].head, 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_nw, &W0, 4, hipMemcpyHostToDevice));
+        uint64_t woff[2] = {0, W0}, zero64 = 0, *d_woff, *d_out, *d_z; uint32_t *d_scr, *d_slots, *d_end;
+        const uint32_t cap = roc_dec_stack_cap(n, W0);
+        CK(hipMalloc(&d_woff, 16)); CK(hipMalloc(&d_out, (size_t)n * 8 + 64)); CK(hipMalloc(&d_z, 8)); CK(hipMalloc(&d_scr, (size_t)cap * 4 + 64));
+        CK(hipMalloc(&d_slots, (size_t)n * 4 + 64)); CK(hipMalloc(&d_end, 4));
+        CK(hipMemcpy(d_woff, woff, 16, hipMemcpyHostToDevice)); CK(hipMemcpy(d_z, &zero64, 8, hipMemcpyHostToDevice));
+        RocDecArgs b{};
+        b.offsets = d_off; b.worklist = d_wl; b.out_off = nullptr; b.nwork = 1; b.heads = d_heads; b.prec = d_prec; b.nwords = d_nw; b.draws = d_dr;
+        b.words = d_arena; b.word_off = d_woff; b.out = d_out; b.out_rows = nullptr; b.K = 0; b.scratch_words = d_scr; b.scratch_off = d_z;
+        b.slots = d_slots; b.slots_off = d_z; b.end_state = d_end; b.status = d_st; b.mt = d_mt;
+        CK(hipFuncSetAttribute((const void *)k_roc_decode_u<UB>, hipFuncAttributeMaxDynamicSharedMemorySize, UGeom<UB>::LDS_BYTES));
+        CK(hipFuncSetAttribute((const void *)k_roc_decode_u2<UB>, hipFuncAttributeMaxDynamicSharedMemorySize, U2Geom<UB>::LDS_BYTES));
+        std::vector<uint64_t> outv[2]; float dms[2]; uint32_t dst[2], dend[2];
+        for (int which = 0; which < 2; which++) {
+            for (int rep = 0; rep < 2; rep++) {
+                CK(hipMemset(d_out, 0xee, (size_t)n * 8)); CK(hipMemset(d_st, 0xff, 4)); CK(hipMemset(d_end, 0xff, 4));
+                CK(hipEventRecord(e0, 0));
+                if (which == 0) hipLaunchKernelGGL((k_roc_decode_u<UB>), dim3(1), dim3(64), UGeom<UB>::LDS_BYTES, 0, b);
+                else hipLaunchKernelGGL((k_roc_decode_u2<UB>), dim3(1), dim3(64), U2Geom<UB>::LDS_BYTES, 0, b, (const U2Div *)d_tab);
+                CK(hipEventRecord(e1, 0));
+                CK(hipDeviceSynchronize());
+                CK(hipEventElapsedTime(&dms[which], e0, e1));
+            }
+#ifdef U2_PROF2
+            if (which == 1) { uint32_t dbg[4]; CK(hipMemcpy(dbg, d_slots, 16, hipMemcpyDeviceToHost)); printf("   decode dbg: slow steps %u, asm entries %u, bits %u, n %u\n", dbg[0], dbg[1], dbg[2], dbg[3]); }
+#endif
+            outv[which].resize(n);
+            CK(hipMemcpy(outv[which].data(), d_out, (size_t)n * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(&dst[which], d_st, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&dend[which], d_end, 4, hipMemcpyDeviceToHost));
+        }
+        size_t dd = 0; while (dd < n && outv[0][dd] == outv[1][dd]) dd++;
+        size_t od = 0; while (od < n && outv[1][od] == r[0].order[od]) od++;
+        dsame = dd == n && dst[0] == 0 && dst[1] == 0 && dend[0] == dend[1];
+        printf("                         DECODE old %.1f ns/step, new %.1f ns/step; status %u/%u end state %u/%u first diff old/new at %zu, new/encoder order at %zu -> %s\n",
+               dms[0] * 1e6 / n, dms[1] * 1e6 / n, dst[0], dst[1], dend[0], dend[1], dd, od, dsame ? "IDENTICAL" : "MISMATCH");
+    }
+    same = same && dsame;
 #ifdef U2_PROF2
     { uint64_t q[8]; CK(hipMemcpy(q, d_prof, 64, hipMemcpyDeviceToHost)); printf("  exits: t==63 %llu, ring %llu, headcheck %llu, sum of t %llu\n", (unsigned long long)q[4], (unsigned long long)q[5], (unsigned long long)q[6], (unsigned long long)q[7]);
       printf("  setup %.0f ticks (%.1f us), chain phase %.1f ticks/step, inside asm %.1f ticks/step over %llu asm entries\n", (double)q[2], q[2] * 0.000417,

@@ -142,7 +142,7 @@ inline void u2_div_entry(uint32_t d, uint32_t out[4]) {
     out[0] = (uint32_t)m;
     out[1] = (uint32_t)(m >> 32);
     out[2] = d >= 2u ? (uint32_t)(0x100000000ull / d) : 0xffffffffu;
-    out[3] = d >= 2u ? (0x80000000u / (d - 1u)) * (d - 1u) - 1u : 0u;
+    out[3] = 0x80000000u / d;
 }
 
 // Scratch blocks are cached per context so steady-state encode/decode calls do not hipMalloc.

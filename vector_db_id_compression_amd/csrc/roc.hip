@@ -11,6 +11,7 @@
 #include "common.h"
 #include "roc_kernels.h"
 #include "roc_u.h"
+#include "roc_u2.h"
 #include "roc_lane.h"
 #include "scan.h"
 
@@ -88,6 +89,12 @@ inline LanePolicy lane_policy() {
 }
 inline bool lane_wanted(LanePolicy p, uint64_t nlists, uint64_t min_lists) {
     return p == LANE_ALWAYS || (p == LANE_AUTO && nlists >= min_lists);
+}
+
+// test hook: VIDC_OLD_U=1 keeps the round-1 bitmap kernels (roc_u.h) instead of the hand-scheduled ones (roc_u2.h)
+inline bool old_u_kernels() {
+    const char *e = getenv("VIDC_OLD_U");
+    return e && e[0] == '1';
 }
 
 // test hook: VIDC_FORCE_GENERAL=1 routes every list through the general (sorted-position / bucket) kernels
@@ -586,10 +593,18 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         if (!wl_u20.empty()) {
             RocEncArgs b = a;
             b.worklist = d_wl + base[2]; b.nwork = (uint32_t)wl_u20.size();
-            VIDC_TRY(set_big_lds((const void *)k_roc_encode_u<20, false>, UGeom<20>::LDS_BYTES));
-            VIDC_TRY(set_big_lds((const void *)k_roc_encode_u<20, true>, UGeom<20>::LDS_BYTES));
-            if (want_perm) hipLaunchKernelGGL((k_roc_encode_u<20, true>), dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, ctx->stream, b);
-            else hipLaunchKernelGGL((k_roc_encode_u<20, false>), dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, ctx->stream, b);
+            const U2Div *dt = (const U2Div *)ctx->d_u2tab;
+            if (old_u_kernels()) {
+                VIDC_TRY(set_big_lds((const void *)k_roc_encode_u<20, false>, UGeom<20>::LDS_BYTES));
+                VIDC_TRY(set_big_lds((const void *)k_roc_encode_u<20, true>, UGeom<20>::LDS_BYTES));
+                if (want_perm) hipLaunchKernelGGL((k_roc_encode_u<20, true>), dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, ctx->stream, b);
+                else hipLaunchKernelGGL((k_roc_encode_u<20, false>), dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, ctx->stream, b);
+            } else {
+                VIDC_TRY(set_big_lds((const void *)k_roc_encode_u2<20, false>, U2Geom<20>::LDS_BYTES));
+                VIDC_TRY(set_big_lds((const void *)k_roc_encode_u2<20, true>, U2Geom<20>::LDS_BYTES));
+                if (want_perm) hipLaunchKernelGGL((k_roc_encode_u2<20, true>), dim3(b.nwork), dim3(64), U2Geom<20>::LDS_BYTES, ctx->stream, b, dt);
+                else hipLaunchKernelGGL((k_roc_encode_u2<20, false>), dim3(b.nwork), dim3(64), U2Geom<20>::LDS_BYTES, ctx->stream, b, dt);
+            }
             VIDC_HIP(hipGetLastError());
         }
         // the deepest class: prefix rows sized for its longest list (first of the work list).  With the fixed
@@ -614,8 +629,12 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         if (!wl_u18.empty()) {
             RocEncArgs b = a;
             b.worklist = d_wl + base[1]; b.nwork = (uint32_t)wl_u18.size();
-            if (want_perm) hipLaunchKernelGGL((k_roc_encode_u<18, true>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->aux[0], b);
-            else hipLaunchKernelGGL((k_roc_encode_u<18, false>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->aux[0], b);
+            const U2Div *dt = (const U2Div *)ctx->d_u2tab;
+            if (old_u_kernels()) {
+                if (want_perm) hipLaunchKernelGGL((k_roc_encode_u<18, true>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->aux[0], b);
+                else hipLaunchKernelGGL((k_roc_encode_u<18, false>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->aux[0], b);
+            } else if (want_perm) hipLaunchKernelGGL((k_roc_encode_u2<18, true>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, ctx->aux[0], b, dt);
+            else hipLaunchKernelGGL((k_roc_encode_u2<18, false>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, ctx->aux[0], b, dt);
             VIDC_HIP(hipGetLastError());
         }
         // aux 1: the lane-per-list kernels, then the general classes; aux 2: tiny lists
@@ -1006,11 +1025,19 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 else hipLaunchKernelGGL(k_roc_decode_tiny<false>, dim3(b.nwork), dim3(64), 0, st_, b);
                 break;
             case DC_U18:
-                hipLaunchKernelGGL(k_roc_decode_u<18>, dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, st_, b);
+                if (old_u_kernels()) hipLaunchKernelGGL(k_roc_decode_u<18>, dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, st_, b);
+                else hipLaunchKernelGGL(k_roc_decode_u2<18>, dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, st_, b,
+                                        (const U2Div *)ctx->d_u2tab);
                 break;
             case DC_U20:
-                VIDC_TRY(set_big_lds((const void *)k_roc_decode_u<20>, UGeom<20>::LDS_BYTES));
-                hipLaunchKernelGGL(k_roc_decode_u<20>, dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, st_, b);
+                if (old_u_kernels()) {
+                    VIDC_TRY(set_big_lds((const void *)k_roc_decode_u<20>, UGeom<20>::LDS_BYTES));
+                    hipLaunchKernelGGL(k_roc_decode_u<20>, dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, st_, b);
+                } else {
+                    VIDC_TRY(set_big_lds((const void *)k_roc_decode_u2<20>, U2Geom<20>::LDS_BYTES));
+                    hipLaunchKernelGGL(k_roc_decode_u2<20>, dim3(b.nwork), dim3(64), U2Geom<20>::LDS_BYTES, st_, b,
+                                       (const U2Div *)ctx->d_u2tab);
+                }
                 break;
             case DC_GSMALL:
                 hipLaunchKernelGGL(k_roc_decode_gen<uint16_t>, dim3(b.nwork), dim3(64), 512 * 2, st_, b, 512u, VIDC_DEC_CAP);

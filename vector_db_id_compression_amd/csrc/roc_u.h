@@ -201,14 +201,14 @@ __global__ void __launch_bounds__(64) k_roc_encode_u(RocEncArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// (a device function: the round-2 kernel of roc_u2.h falls back to it for streams that decode to a multiset)
 template <int UB>
-__global__ void __launch_bounds__(64) k_roc_decode_u(RocDecArgs a) {
+__device__ __forceinline__ void roc_decode_u_body(const RocDecArgs &a, unsigned char *smem) {
     using U = UGeom<UB>;
     constexpr uint32_t GSH = U::G == 4 ? 2u : 0u;
     constexpr uint32_t ESH = 6u + GSH;                       // bits of x inside one level-2 entry
     constexpr uint32_t ENT_SH = U::ENT == 64u ? 6u : (U::ENT == 16u ? 4u : (U::ENT == 32u ? 5u : 0u));
     static_assert((1u << ENT_SH) == U::ENT, "entries per row must be 16, 32 or 64");
-    extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *bm = (uint64_t *)smem;
     const uint32_t lane = lane_id();
     const uint32_t wi = blockIdx.x;
@@ -291,6 +291,12 @@ __global__ void __launch_bounds__(64) k_roc_decode_u(RocDecArgs a) {
         a.end_state[l] = clean ? 0u : 1u;
         a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
     }
+}
+
+template <int UB>
+__global__ void __launch_bounds__(64) k_roc_decode_u(RocDecArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    roc_decode_u_body<UB>(a, smem);
 }
 
 // -------------------------------------------------------------------------------------------------

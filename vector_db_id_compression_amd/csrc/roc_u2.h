@@ -48,8 +48,7 @@ __device__ __forceinline__ uint32_t u2_word_of(uint32_t x) {
 }
 
 // Per-divisor constants (16 bytes, table built once per context, vidc_ctx::d_u2tab, VIDC_ROC_MAX_LIST + 1 entries):
-//   x = floor((2^64 - 1) / d) low, y = high, z = floor(2^32 / d) (d >= 2), w = (d - 1) * floor(2^31 / (d - 1)) - 1
-// (w is the index-pop renormalisation threshold of the NEXT step, whose divisor is d - 1).  Entry 0 is all zero.
+//   x = floor((2^64 - 1) / d) low, y = high, z = floor(2^32 / d) (d >= 2), w = floor(2^31 / d).  Entry 0 is all zero.
 typedef uint4 U2Div;  // filled by u2_div_entry (common.h)
 
 // exclusive counters in reversed lane order, see the header comment.  rows: ra = rows 0..31, rb = rows 32..63.
@@ -554,6 +553,325 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
         a.heads[l] = head;
         a.nwords[l] = st.sp;
         a.draws[l] = st.draws;
+        a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
+    }
+}
+
+
+// ===============================================================================================================
+// Decode (codec.cpp:140-152): step i pops x (two 16-bit slices, high first), ranks it among the ids decoded so far,
+// pushes the rank as a uniform index over nmax = i + 1 and stores out[n - 1 - i] = x.
+//
+// head' = H * nmax + r with H (the head after the two slice pops, renormalised for the index push) independent of the
+// rank r: the push renormalisation, the 64 x 32 multiply and all insertions run in the shadow of the LDS read; r joins with
+// one 64-bit add, and the next id is a bit field of that sum.  The set is a bitmap over the id universe with the same
+// reversed exclusive counters as the encoder (rank = E1[L1] + row[L1][L2] + set bits below x inside its entry).
+// Multiset streams (reference quirk regimes) cannot be represented by a bitmap: the number of set bits is compared with
+// n at the end and such a list is decoded again by the round-1 kernel body, which keeps a side list of duplicates.
+//
+// Register map (decode):
+//   v2 lane  v3 (lane & 3) * 8  v4 E1  v5 stack ring  v6:7 {output ring, 0}  v10 lq = floor(2^31 / nmax) per lane (nmax = N0 + lane)
+//   v13 row  v26 address / v27 bit of the insertion  v28 LDS address  v30:31 word(s)  v32..v37 popcount temporaries
+//   v54:57 table entry of the next block  v58 v59 tmp  v64..v127 level-2 rows
+//   s40 x  s43 L1  s44 L2  s45 entry  s46 x_hi  s47 g  s48 b  s49 E1[L1]  s50:51 H  s52:53 H * nmax  s58:59 head  s60 sp
+//   s61 lo  s62 lq  s63 row[L2]  s64 below  s65 tmp  s66:67 mask below b  s68 tmp  s69 t  s70 t_end  s71 limit  s72 tmp
+//   s73 2^p1 - 1  s74 2^p0 - 1  s75 nmax  s76 p0  s77 p1  s85 N0  s86 steps left at lane 0  s87 output index of lane 0
+//   s88:89 output pointer  s94:95 divisor table  s96:97 saved exec  s98 s99 tmp
+#define U2_DEC_INSTALL \
+    "v_mov_b32 v10, v57\n" \
+    "s_add_u32 s68, s85, 64\n" \
+    "v_add_u32 v58, s68, v2\n" \
+    "v_min_u32 v58, 0x40000, v58\n" \
+    "v_lshlrev_b32 v58, 4, v58\n" \
+    "global_load_dwordx4 v[54:57], v58, s[94:95]\n"
+#define U2_DEC_ENTRY \
+    "v_add_u32 v58, s85, v2\n" \
+    "v_min_u32 v58, 0x40000, v58\n" \
+    "v_lshlrev_b32 v58, 4, v58\n" \
+    "global_load_dwordx4 v[54:57], v58, s[94:95]\n" \
+    "s_waitcnt vmcnt(0)\n" \
+    U2_DEC_INSTALL \
+    "s_mov_b32 s69, 0\n" \
+    "s_mov_b32 s75, s85\n" \
+    "s_min_u32 s70, s86, 64\n"
+
+#define U2_DEC_TOP \
+    "1:\n" \
+    "s_and_b32 s46, s58, s73\n"                        /* slice 1: x_hi (codec.cpp:78-90) */ \
+    "s_lshr_b64 s[58:59], s[58:59], s77\n" \
+    "s_lshr_b32 s68, s58, 31\n" \
+    "s_or_b32 s68, s68, s59\n" \
+    "s_cbranch_scc0 20f\n"                             /* head < 2^31: refill */ \
+    "21:\n" \
+    "s_and_b32 s40, s58, s74\n"                        /* slice 0: x_lo */ \
+    "s_lshr_b64 s[58:59], s[58:59], s76\n" \
+    "s_lshr_b32 s68, s58, 31\n" \
+    "s_or_b32 s68, s68, s59\n" \
+    "s_cbranch_scc0 22f\n" \
+    "23:\n" \
+    "s_lshl_b32 s46, s46, 16\n" \
+    "s_or_b32 s40, s40, s46\n"                         /* x */
+#define U2_DEC_IDX_G4 \
+    "s_lshr_b32 s45, s40, 8\n" \
+    "s_xor_b32 s45, s45, 0xfff\n"                      /* entry (reversed) */ \
+    "v_lshl_add_u32 v28, s45, 5, v3\n" \
+    "ds_read_b64 v[30:31], v28\n" \
+    "s_bfe_u32 s47, s40, 0x20006\n"                    /* g */ \
+    "s_bfe_u32 s65, s40, 0x30005\n"                    /* 32-bit half of the entry holding x */ \
+    "s_lshl_b32 s68, s45, 3\n" \
+    "s_or_b32 s65, s65, s68\n" \
+    "s_lshl_b32 s65, s65, 2\n"
+#define U2_DEC_IDX_G1 \
+    "s_lshr_b32 s45, s40, 6\n" \
+    "s_xor_b32 s45, s45, 0xfff\n" \
+    "v_lshlrev_b32_e64 v28, 3, s45\n" \
+    "ds_read_b64 v[30:31], v28\n" \
+    "s_bfe_u32 s65, s40, 0x10005\n" \
+    "s_lshl_b32 s68, s45, 1\n" \
+    "s_or_b32 s65, s65, s68\n" \
+    "s_lshl_b32 s65, s65, 2\n"
+#define U2_DEC_MID \
+    "s_lshr_b32 s43, s45, 6\n"                         /* L1 */ \
+    "s_and_b32 s44, s45, 63\n"                         /* L2 */ \
+    "s_set_gpr_idx_on s43, gpr_idx(SRC0)\n" \
+    "v_mov_b32 v13, v64\n" \
+    "s_set_gpr_idx_off\n" \
+    "s_and_b32 s48, s40, 63\n"                         /* b */ \
+    "s_bfm_b64 s[66:67], s48, 0\n"                     /* bits below b */ \
+    "v_mov_b32 v26, s65\n"                             /* insertion of x: after the read in LDS order */ \
+    "v_lshlrev_b32_e64 v27, s40, 1\n" \
+    "s_mov_b64 exec, 1\n" \
+    "ds_or_b32 v26, v27\n" \
+    "s_mov_b64 exec, -1\n" \
+    "v_readlane_b32 s49, v4, s43\n"                    /* E1[L1] */ \
+    "v_readlane_b32 s63, v13, s44\n"                   /* row[L2] */ \
+    "v_readlane_b32 s62, v10, s69\n"                   /* lq of this step */ \
+    "v_subrev_u32 v58, s43, v2\n" \
+    "v_subrev_u32 v59, s44, v2\n" \
+    "v_ashrrev_i32 v58, 31, v58\n" \
+    "v_ashrrev_i32 v59, 31, v59\n" \
+    "v_sub_u32 v4, v4, v58\n"                          /* E1 += 1 in lanes below L1 */ \
+    "v_sub_u32 v13, v13, v59\n"                        /* row += 1 in lanes below L2 */ \
+    "s_and_b32 m0, s60, 63\n"                          /* index push, first half (codec.cpp:44-63): renormalise H */ \
+    "s_cmp_ge_u32 s59, s62\n" \
+    "v_writelane_b32 v5, s58, m0\n" \
+    "s_cselect_b32 s50, s59, s58\n" \
+    "s_cselect_b32 s51, 0, s59\n" \
+    "s_addc_u32 s60, s60, 0\n" \
+    "s_mul_i32 s52, s50, s75\n"                        /* H * nmax */ \
+    "s_mul_hi_u32 s53, s50, s75\n" \
+    "s_mul_i32 s68, s51, s75\n" \
+    "s_add_u32 s53, s53, s68\n" \
+    "s_mov_b32 m0, s69\n" \
+    "s_add_u32 s72, s49, s63\n" \
+    "v_writelane_b32 v6, s40, m0\n"                    /* output ring */ \
+    "s_set_gpr_idx_on s43, gpr_idx(DST)\n" \
+    "v_mov_b32 v64, v13\n" \
+    "s_set_gpr_idx_off\n"
+#define U2_DEC_RANK_G4 \
+    "s_waitcnt lgkmcnt(1)\n" \
+    "v_bcnt_u32_b32 v32, v30, 0\n" \
+    "v_bcnt_u32_b32 v32, v31, v32\n"                   /* set bits of the lane's word */ \
+    "v_and_b32 v33, s66, v30\n" \
+    "v_and_b32 v34, s67, v31\n" \
+    "v_add_u32_dpp v35, v32, v32 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+    "v_bcnt_u32_b32 v33, v33, 0\n" \
+    "v_bcnt_u32_b32 v33, v34, v33\n"                   /* ... below b */ \
+    "v_add_u32_dpp v36, v35, v35 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+    "v_sub_u32 v33, v33, v32\n" \
+    "v_add_u32 v37, v36, v33\n"                        /* lane g: bits of the entry below x */ \
+    "s_nop 0\n" \
+    "v_readlane_b32 s64, v37, s47\n"
+#define U2_DEC_RANK_G1 \
+    "s_waitcnt lgkmcnt(1)\n" \
+    "v_and_b32 v33, s66, v30\n" \
+    "v_and_b32 v34, s67, v31\n" \
+    "v_bcnt_u32_b32 v33, v33, 0\n" \
+    "v_bcnt_u32_b32 v37, v34, v33\n" \
+    "s_nop 0\n" \
+    "v_readfirstlane_b32 s64, v37\n"
+#define U2_DEC_BOT \
+    "s_sub_u32 s68, s60, s61\n"                        /* ring: two pops and one push must fit the next step */ \
+    "s_add_u32 s68, s68, -2\n" \
+    "s_add_u32 s69, s69, 1\n" \
+    "s_add_u32 s75, s75, 1\n" \
+    "s_add_u32 s72, s72, s64\n"                        /* rank */ \
+    "s_add_u32 s58, s52, s72\n"                        /* head' = H * nmax + rank */ \
+    "s_addc_u32 s59, s53, 0\n" \
+    "s_cmp_gt_u32 s68, 59\n" \
+    "s_cselect_b32 s71, 0, s70\n" \
+    "s_lshr_b32 s68, s58, 31\n"                        /* head' < 2^31: the push refills (generic code) */ \
+    "s_or_b32 s68, s68, s59\n" \
+    "s_cselect_b32 s71, s71, 0\n" \
+    "s_cmp_lt_u32 s69, s71\n" \
+    "s_cbranch_scc1 1b\n" \
+    "s_branch 2f\n" \
+    "20:\n"                                            /* refills: head = (head << 32) | pop (codec.cpp:83-87) */ \
+    "s_sub_u32 s60, s60, 1\n" \
+    "s_and_b32 s68, s60, 63\n" \
+    "s_mov_b32 s59, s58\n" \
+    "v_readlane_b32 s58, v5, s68\n" \
+    "s_branch 21b\n" \
+    "22:\n" \
+    "s_sub_u32 s60, s60, 1\n" \
+    "s_and_b32 s68, s60, 63\n" \
+    "s_mov_b32 s59, s58\n" \
+    "v_readlane_b32 s58, v5, s68\n" \
+    "s_branch 23b\n" \
+    "2:\n"
+// store output-ring lanes [0, s72) at out[s87 - lane]; s87 -= s72
+#define U2_DEC_FLUSH \
+    "v_cmp_gt_u32 vcc, s72, v2\n" \
+    "v_sub_u32 v58, s87, v2\n" \
+    "v_lshlrev_b32 v58, 3, v58\n" \
+    "s_and_saveexec_b64 s[96:97], vcc\n" \
+    "global_store_dwordx2 v58, v[6:7], s[88:89]\n" \
+    "s_mov_b64 exec, s[96:97]\n" \
+    "s_sub_u32 s87, s87, s72\n"
+#define U2_DEC_OUTER \
+    "s_lshr_b32 s68, s58, 31\n" \
+    "s_or_b32 s68, s68, s59\n" \
+    "s_cselect_b32 s99, 0, 1\n"                        /* head < 2^31 */ \
+    "s_sub_u32 s68, s60, s61\n" \
+    "s_add_u32 s68, s68, -2\n" \
+    "s_cmp_gt_u32 s68, 59\n" \
+    "s_cselect_b32 s99, 1, s99\n"                      /* ring needs the host code */ \
+    "s_cmp_lt_u32 s69, 64\n" \
+    "s_cbranch_scc1 5f\n" \
+    "s_waitcnt vmcnt(0)\n"                             /* block change */ \
+    "s_mov_b32 s72, 64\n" \
+    U2_DEC_FLUSH \
+    "s_add_u32 s85, s85, 64\n" \
+    "s_sub_u32 s86, s86, 64\n" \
+    U2_DEC_INSTALL \
+    "s_mov_b32 s69, 0\n" \
+    "s_min_u32 s70, s86, 64\n" \
+    "5:\n" \
+    "s_cmp_ge_u32 s69, s70\n" \
+    "s_cbranch_scc1 9f\n" \
+    "s_cmp_eq_u32 s99, 0\n" \
+    "s_cbranch_scc1 1b\n" \
+    "9:\n" \
+    "s_mov_b32 s72, s69\n" \
+    U2_DEC_FLUSH \
+    "s_waitcnt vmcnt(0)\n"
+
+// one generic decode step on the reversed structures (rare path): codec.cpp:144-150
+template <int UB>
+__device__ __forceinline__ uint32_t u2_slow_dec_step(uint64_t &head, WStack &st, uint32_t nmax, uint32_t &E1, v32u &ra, v32u &rb,
+                                                     uint64_t *bm, uint32_t p0, uint32_t p1) {
+    using U = U2Geom<UB>;
+    const uint32_t lane = lane_id();
+    ws_prepare(st);
+    const uint32_t x = ans_id_pop(head, st, p0, p1);
+    const uint32_t e = (x >> U::ESH) ^ (U::NE - 1u);
+    const uint32_t L1 = e >> 6, L2 = e & 63u, g = (x >> 6) & (U::G - 1u), b = x & 63u;
+    uint32_t row = u2_row_get(ra, rb, L1);
+    uint32_t r = rl(E1, L1) + rl(row, L2);
+    for (uint32_t j = 0; j < g; j++) r += popc64(rfl64(bm[e * U::G + j]));
+    const uint64_t W = rfl64(bm[e * U::G + g]);
+    r += popc64(W & ((1ull << b) - 1ull));
+    ans_idx_push(head, st, r, nmax, 0x80000000u / nmax);
+    E1 += lane < L1 ? 1u : 0u;
+    row += lane < L2 ? 1u : 0u;
+    u2_row_set(ra, rb, L1, row);
+    bm[e * U::G + g] = W | (1ull << b);
+    wave_sync();
+    return x;
+}
+
+template <int UB>
+__global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div *__restrict__ dtab) {
+    using U = U2Geom<UB>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *bm = (uint64_t *)smem;
+    const uint32_t lane = lane_id();
+    const uint32_t wi = blockIdx.x;
+    if (wi >= a.nwork) return;
+    const uint32_t l = rfl(a.worklist[wi]);
+    const uint32_t n = rfl((uint32_t)(a.offsets[l + 1] - a.offsets[l]));
+    const uint64_t ooff = rfl64(a.out_off ? a.out_off[wi] : a.offsets[l]);
+    {
+        uint4 *z = (uint4 *)smem;
+        for (uint32_t w = lane; w < U::LDS_BYTES / 16u; w += 64) z[w] = make_uint4(0, 0, 0, 0);
+    }
+    const uint32_t P = rfl(a.prec[l]);
+    const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
+    const uint32_t W0 = rfl(a.nwords[l]);
+    WStack st;
+    ws_init_loaded(st, a.words + rfl64(a.word_off[l]), W0, a.scratch_words + rfl64(a.scratch_off[wi]), roc_dec_stack_cap(n, W0),
+                   rfl(a.draws[l]), a.mt, VIDC_MT_TABLE);
+    const uint32_t draws0 = st.draws;
+    uint64_t head = rfl64(a.heads[l]);
+    uint32_t E1 = 0;
+    v32u ra, rb;
+#pragma unroll
+    for (int c = 0; c < 32; c++) { ra[c] = 0u; rb[c] = 0u; }
+    const uint32_t l3off = U::G == 4u ? (lane & 3u) * 8u : 0u;
+    const uint32_t M1 = (1u << p1) - 1u, M0 = (1u << p0) - 1u;
+    uint64_t *out = a.out + ooff;
+    wave_sync();
+
+#ifdef U2_PROF2
+    uint32_t dbg[4] = {0, 0, 0, 0};
+#define U2_DBG(k) dbg[k]++
+#else
+#define U2_DBG(k)
+#endif
+    uint32_t i = 0;  // ids decoded so far
+    while (i < n) {
+        ws_prepare(st);
+        if (lt_2p31(head) || st.sp - st.lo < 2u || st.sp - st.lo > 61u) {  // generic step
+            U2_DBG(0);
+            const uint32_t x = u2_slow_dec_step<UB>(head, st, i + 1u, E1, ra, rb, bm, p0, p1);
+            if (lane == 0) out[n - 1u - i] = (uint64_t)x;
+            i++;
+            continue;
+        }
+        U2_DBG(1);
+        uint32_t s_t = 0, s_N0 = rfl(i + 1u), s_left = rfl(n - i), s_oidx = rfl(n - 1u - i);
+        uint64_t s_h = rfl64(head), oring = 0;
+        st.sp = rfl(st.sp);
+        st.lo = rfl(st.lo);
+        // clang-format off
+#define U2_DEC_ASM(BODY)                                                                                                  \
+        asm volatile(BODY                                                                                                 \
+            : "+{v4}"(E1), "+{v5}"(st.win), "+{v[6:7]}"(oring), "+{v[64:95]}"(ra), "+{v[96:127]}"(rb),                     \
+              "+{s[58:59]}"(s_h), "+{s60}"(st.sp), "+{s69}"(s_t), "+{s85}"(s_N0), "+{s86}"(s_left), "+{s87}"(s_oidx)        \
+            : "{v2}"(lane), "{v3}"(l3off), "{s61}"(st.lo), "{s73}"(M1), "{s74}"(M0), "{s76}"(p0), "{s77}"(p1),               \
+              "{s[88:89]}"(out), "{s[94:95]}"(dtab)                                                                        \
+            : "memory", "vcc", "scc", "v10", "v13", "v26", "v27", "v28", "v30", "v31", "v32", "v33", "v34", "v35", "v36",     \
+              "v37", "v54", "v55", "v56", "v57", "v58", "v59", "s40", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",\
+              "s51", "s52", "s53", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s70", "s71", "s72", "s75", "s96", "s97",\
+              "s98", "s99")
+        if (U::G == 4u) U2_DEC_ASM(U2_DEC_ENTRY U2_DEC_TOP U2_DEC_IDX_G4 U2_DEC_MID U2_DEC_RANK_G4 U2_DEC_BOT U2_DEC_OUTER);
+        else U2_DEC_ASM(U2_DEC_ENTRY U2_DEC_TOP U2_DEC_IDX_G1 U2_DEC_MID U2_DEC_RANK_G1 U2_DEC_BOT U2_DEC_OUTER);
+#undef U2_DEC_ASM
+        // clang-format on
+        head = s_h;
+        ws_window(st);
+        if (__builtin_expect(lt_2p31(head), 0)) {  // second half of the last index push (codec.cpp:59-61)
+            ws_prepare(st);
+            head = (uint64_t)ws_pop(st) | (head << 32);
+        }
+        i = s_N0 + s_t - 1u;
+    }
+    // a bitmap holds every id once: streams that decode to a multiset are decoded again with the side-list kernel body
+    uint32_t bits = 0;
+    for (uint32_t w = lane; w < U::BITMAP_BYTES / 8u; w += 64) bits += popc64(bm[w]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bits += (uint32_t)__shfl_xor((int)bits, o, 64);
+#ifdef U2_PROF2
+    if (lane == 0) { a.slots[0] = dbg[0]; a.slots[1] = dbg[1]; a.slots[2] = rfl(bits); a.slots[3] = n; }
+#endif
+    if (rfl(bits) != n) {
+        wave_sync();
+        roc_decode_u_body<UB>(a, smem);
+        return;
+    }
+    if (lane == 0) {
+        const bool clean = (head == VIDC_RANS_L) && (st.sp == st.draws - draws0);
+        a.end_state[l] = clean ? 0u : 1u;
         a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
     }
 }
