@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- IDs encoded+decoded per second on the BASELINE.json workload (MI355X).
 
-A "step" = one pass of the hot path over one batch: ROC-encode every inverted list of the batch, then
+A "step" = one pass of the hot path over one batch: ROC-encode every inverted list of the batch the way the container
+does (stream + the sampling permutation the vector codes are reordered by, custom_invlists_impl.cpp:188-193), then
 ROC-decode every list (inputs and outputs resident in HBM).  Default workload = BASELINE.json configs[1]
 (S1: 1M uint64 ids in 1024 Zipf(0.75) lists).  With N GPUs every rank owns a shard of the same shape
 (different seed): inverted lists are independent, so there is no data-path collective ("weak" scaling).
+
+`--sharded` (with `--workload c5`) is the strong-scaling form of BASELINE.json configs[4]: ONE 65 536-list index,
+lists partitioned over the ranks by total length (sharding.ShardedInvLists), every rank encodes + decodes its shard,
+then a search-shaped request (nq * nprobe touched lists) is decoded by the owners and gathered on rank 0 over
+RCCL send/recv; the line reports the per-rank time spread and the gather time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -49,6 +55,94 @@ def cpu_baseline(offsets, ids, budget_s=20.0):
                 bits_per_id=8.0 * r["bytes"] / ntotal, bad_lists=r["bad_lists"])
 
 
+def sharded_main(args, ctx, dist, rank, world):
+    """Strong scaling of one index (BASELINE configs[4] shape): shard, encode + decode per rank, search-shaped gather."""
+    import torch
+
+    from vector_db_id_compression_amd import synth
+    from vector_db_id_compression_amd.codecs import RocLists
+    from vector_db_id_compression_amd.sharding import ShardedInvLists
+
+    wl = synth.workload(args.workload if args.workload != "s1" else "c5", seed=42)  # the SAME index on every rank
+    offsets, ids_host = wl["offsets"], wl["ids"]
+    want_perm = not args.no_perm
+    t_sh = time.perf_counter()
+    sh = ShardedInvLists(offsets, ids_host, rank, world, lambda o, i: (o, torch.from_numpy(np.ascontiguousarray(i).view(np.int64)).cuda()),
+                         device="cuda")
+    loc_off, loc_ids = sh.codec  # (the "codec" slot holds the raw shard until the first timed encode)
+    t_sh = time.perf_counter() - t_sh
+    out = torch.empty(int(loc_off[-1]), dtype=torch.int64, device="cuda")
+    rng = np.random.default_rng(7)
+    nq, nprobe = 1000, 16
+    req = rng.integers(0, wl["nlist"], size=nq * nprobe).astype(np.int64)  # lists a batch of searches touched
+
+    def step():
+        sh.codec = RocLists.encode(loc_off, loc_ids, ctx=ctx, want_perm=want_perm)
+        ke = ctx.phase_ms(0) + ctx.phase_ms(1)
+        sh.codec.decode_all(out)
+        return ke, ctx.phase_ms(2)
+
+    for _ in range(args.warmup):
+        step()
+        sh.gather_ids(req, dst=0)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k_enc = k_dec = t_codec = t_gather = 0.0
+    for _ in range(args.steps):
+        ta = time.perf_counter()
+        ke, kd = step()
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        got, goff = sh.gather_ids(req, dst=0)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        k_enc += ke
+        k_dec += kd
+        t_codec += tb - ta
+        t_gather += tc - tb
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = torch.tensor([t_codec / args.steps, t_gather / args.steps, float(loc_off[-1]), k_enc / args.steps, k_dec / args.steps],
+                            dtype=torch.float64, device="cuda")
+    allr = [per_rank.clone() for _ in range(world)]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.all_gather(allr, per_rank)
+    if rank == 0:
+        # the gathered ids are the decoded lists in request order: check them against the index itself (as sets per list)
+        sizes = (offsets[1:] - offsets[:-1]).astype(np.int64)
+        ok = int(goff[-1]) == int(sizes[req].sum())
+        for i in rng.integers(0, req.size, size=64):
+            l = int(req[i])
+            a = np.sort(got[int(goff[i]):int(goff[i + 1])].cpu().numpy().astype(np.uint64))
+            ok = ok and np.array_equal(a, np.sort(np.asarray(ids_host[int(offsets[l]):int(offsets[l + 1])]).astype(np.uint64)))
+        rows = [x.cpu().numpy() for x in allr]
+        codec_ms = [1e3 * float(x[0]) for x in rows]
+        res = {
+            "metric": "IDs encoded+decoded / sec (ROC/ANS, bit-exact vs codec.cpp), one index sharded over the GPUs",
+            "value": wl["ntotal"] * args.steps / elapsed, "unit": "IDs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": wl["describe"], "codec": "roc", "nlist": wl["nlist"], "max_list": wl["max_list"],
+                       "median_list": wl["median_list"], "container_path": "stream + sampling permutation" if want_perm else "stream only",
+                       "parallelism": f"{wl['nlist']} lists partitioned over {world} GPU(s) by total length (LPT); per step: "
+                                      f"encode + decode of the shard, then the {nq * nprobe} lists of {nq} searches x nprobe {nprobe} "
+                                      f"decoded by their owners and gathered on rank 0 (send/recv, {int(goff[-1]) * 8} bytes)"},
+            "per_rank": {"ids": [int(x[2]) for x in rows], "codec_ms": codec_ms, "gather_ms": [1e3 * float(x[1]) for x in rows],
+                         "kernel_ms_encode": [float(x[3]) for x in rows], "kernel_ms_decode": [float(x[4]) for x in rows],
+                         "codec_ms_spread": max(codec_ms) - min(codec_ms)},
+            "shard_setup_s": t_sh, "gather_verified": bool(ok),
+        }
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +153,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short secondary measurements in `extra`")
+    ap.add_argument("--no-s2", action="store_true", help="skip the 1 B-id workload in `extra` (takes ~1 min)")
+    ap.add_argument("--sharded", action="store_true", help="strong scaling: one index sharded over the ranks + gather")
+    ap.add_argument("--no-perm", action="store_true", help="encode the streams only (no sampling permutation)")
     args = ap.parse_args()
 
     import torch
@@ -80,6 +177,9 @@ def main():
     from vector_db_id_compression_amd.codecs import EfLists, PackedLists, RocLists
 
     ctx = _lib.default_context(local_rank)  # bound to torch's current stream
+    if args.sharded:
+        return sharded_main(args, ctx, dist, rank, world)
+    want_perm = not args.no_perm
     wl = synth.workload(args.workload, seed=42 + rank)
     offsets = wl["offsets"]
     ids_host = wl["ids"] if isinstance(wl["ids"], np.ndarray) else None
@@ -89,7 +189,7 @@ def main():
 
     def step():
         if args.codec == "roc":
-            r = RocLists.encode(offsets, d_ids, ctx=ctx)
+            r = RocLists.encode(offsets, d_ids, ctx=ctx, want_perm=want_perm)
             t_enc = ctx.phase_ms(0) + ctx.phase_ms(1)
             r.decode_all(out)
             t_dec = ctx.phase_ms(2)
@@ -137,18 +237,39 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    def secondary(workload, codec, steps=3):
+    def chain_floor(w2, ids2):
+        """The longest list of the workload encoded + decoded ALONE: its serial chain (one dependent codec step per id)
+        bounds any schedule of the batch from below."""
+        sizes = (w2["offsets"][1:] - w2["offsets"][:-1]).astype(np.int64)
+        l = int(np.argmax(sizes))
+        a, b = int(w2["offsets"][l]), int(w2["offsets"][l + 1])
+        one = ids2[a:b].contiguous()
+        off1 = np.array([0, b - a], dtype=np.uint64)
+        o1 = torch.empty(b - a, dtype=torch.int64, device="cuda")
+        e = d = 0.0
+        for it in range(4):
+            obj = RocLists.encode(off1, one, ctx=ctx, want_perm=want_perm)
+            e_ms = ctx.phase_ms(0)
+            obj.decode_all(o1)
+            if it:
+                e += e_ms
+                d += ctx.phase_ms(2)
+        return {"list": l, "ids": b - a, "encode_ms": e / 3, "decode_ms": d / 3,
+                "us_per_step": {"encode": 1e3 * e / 3 / (b - a), "decode": 1e3 * d / 3 / (b - a)}}
+
+    def secondary(workload, codec, steps=3, floor=False):
         """Short, untimed-by-the-driver measurement of another regime / codec (reported under `extra` only)."""
         w2 = synth.workload(workload, seed=1042 + rank)
         ids2 = torch.from_numpy(w2["ids"].view(np.int64)).cuda() if isinstance(w2["ids"], np.ndarray) else w2["ids"]
         out2 = torch.empty(w2["ntotal"], dtype=torch.int64, device="cuda")
         cls = {"roc": RocLists, "ef": EfLists, "packed": PackedLists}[codec]
+        kw = {"want_perm": want_perm} if codec == "roc" else {}
         ke = kd = 0.0
         t_wall = 0.0
         for it in range(steps + 1):
             torch.cuda.synchronize()
             t_a = time.perf_counter()
-            obj = cls.encode(w2["offsets"], ids2, ctx=ctx)
+            obj = cls.encode(w2["offsets"], ids2, ctx=ctx, **kw)
             e_ms = (ctx.phase_ms(0) + ctx.phase_ms(1)) if codec == "roc" else ctx.last_kernel_ms()
             obj.decode_all(out2)
             d_ms = ctx.phase_ms(2) if codec == "roc" else ctx.last_kernel_ms()
@@ -161,9 +282,21 @@ def main():
         kern = (ke + kd) / steps / 1e3
         gbs = (16.0 + 2.0 * c2) * w2["ntotal"] / kern / 1e9
         ok = bool(torch.equal(torch.sort(out2).values, torch.sort(ids2).values))
-        return {"workload": w2["describe"], "codec": codec, "ids_per_s": w2["ntotal"] * steps / t_wall,
-                "kernel_ms": {"encode": ke / steps, "decode": kd / steps}, "bits_per_id": 8.0 * c2,
-                "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "multiset_roundtrip_ok": ok}
+        res2 = {"workload": w2["describe"], "codec": codec, "nlist": w2["nlist"], "max_list": w2["max_list"],
+                "median_list": w2["median_list"], "ids_per_s": w2["ntotal"] * steps / t_wall,
+                "ms_per_step": 1e3 * t_wall / steps, "kernel_ms": {"encode": ke / steps, "decode": kd / steps},
+                "bits_per_id": 8.0 * c2, "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+                "multiset_roundtrip_ok": ok}
+        if floor:
+            del out2
+            cf = chain_floor(w2, ids2)
+            cf["chain_floor_ms"] = cf["encode_ms"] + cf["decode_ms"]
+            cf["share_of_kernel_time"] = cf["chain_floor_ms"] / ((ke + kd) / steps)
+            cf["note"] = ("the longest list alone: every codec step consumes the ANS head of the previous one, so no "
+                          "schedule of this batch runs faster than this chain (under load its steps are slower: its one "
+                          "global load per step misses L2)")
+            res2["chain_floor"] = cf
+        return res2
 
     def secondary_graph(N=262144, K=64, steps=3):
         """BASELINE configs[3] shape (NSG adjacency rows, -1 terminated) through the ROC and Elias-Fano graph codecs."""
@@ -227,7 +360,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["describe"], "codec": args.codec, "ids_per_gpu": ntotal, "lists_per_gpu": wl["nlist"],
                        "max_list": wl["max_list"], "median_list": wl["median_list"],
-                       "parallelism": f"lists sharded over {world} GPU(s), no data-path collective"},
+                       "parallelism": f"lists sharded over {world} GPU(s), no data-path collective",
+                       "container_path": "stream + sampling permutation" if want_perm else "stream only"},
             "bits_per_id": 8.0 * c,
             "verified_roundtrip": verified,
             "kernel_ms": {"encode": k_enc / args.steps, "decode": k_dec / args.steps},
@@ -246,9 +380,24 @@ def main():
                     "packed_bits": secondary("uniform_16m", "packed"),
                     "elias_fano": secondary("uniform_16m", "ef"),
                     "graph_rows": secondary_graph(),
+                    "c5": secondary("c5", "roc", floor=True),
                 }
+                if not args.no_s2:  # BASELINE north_star's roofline workload: 1 B ids on one GPU
+                    torch.cuda.empty_cache()
+                    res["extra"]["s2"] = secondary("s2", "roc", steps=2, floor=True)
             except Exception as e:
                 res["extra"] = {"error": str(e)}
+        if world == 1 and args.codec == "roc":
+            try:
+                cf = chain_floor(wl, d_ids)
+                cf["chain_floor_ms"] = cf["encode_ms"] + cf["decode_ms"]
+                cf["share_of_kernel_time"] = cf["chain_floor_ms"] / (1e3 * kern_s)
+                res["roofline"]["chain_floor"] = cf
+                res["roofline"]["note"] = ("latency bound, not bandwidth bound: the batch cannot finish before its longest list's "
+                                           "chain of dependent codec steps (chain_floor); frac is reported against the HBM peak as "
+                                           "the contract asks")
+            except Exception as e:
+                res["roofline"]["chain_floor"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline and args.codec == "roc" and ids_host is not None:
             try:
                 res["cpu_baseline"] = cpu_baseline(offsets, ids_host)

@@ -118,6 +118,9 @@ size_t rc_bench_lists(size_t nlist, const uint64_t* offsets, const uint64_t* ids
                       double* t_enc, double* t_dec, uint64_t* sum_bytes) {
     std::vector<ANSState> states(nlist);
     std::vector<int> prec(nlist, 0);
+    // the container always produces the sampling permutation (the vector codes are reordered by it,
+    // custom_invlists_impl.cpp:188-193): the timed encode fills it like the GPU path of bench.py does
+    std::vector<uint32_t> perm(offsets[nlist] ? offsets[nlist] : 1);
     (void)threads;
     auto t0 = std::chrono::steady_clock::now();
 #pragma omp parallel for schedule(dynamic) num_threads(threads)
@@ -127,7 +130,7 @@ size_t rc_bench_lists(size_t nlist, const uint64_t* offsets, const uint64_t* ids
         const uint64_t* p = ids + offsets[l];
         int max_id = (int)*std::max_element(p, p + n);
         prec[l] = (int)(uint64_t)std::ceil(std::log2(max_id));
-        container_encode(n, p, prec[l], (uint32_t)(l * 2654435761u + 1u), states[l], nullptr, nullptr);
+        container_encode(n, p, prec[l], (uint32_t)(l * 2654435761u + 1u), states[l], nullptr, perm.data() + offsets[l]);
     }
     auto t1 = std::chrono::steady_clock::now();
     uint64_t bytes = 0;

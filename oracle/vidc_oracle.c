@@ -410,6 +410,8 @@ size_t vo_roc_bench_lists(size_t nlist, const uint64_t *offsets, const uint64_t 
                           double *t_enc, double *t_dec, uint64_t *sum_bytes) {
     vo_ans_state *sts = (vo_ans_state *)malloc(nlist * sizeof(vo_ans_state));
     int *prec = (int *)malloc(nlist * sizeof(int));
+    /* the container always produces the sampling permutation (custom_invlists_impl.cpp:188-193) */
+    uint32_t *perm = (uint32_t *)malloc((size_t)(offsets[nlist] ? offsets[nlist] : 1) * sizeof(uint32_t));
     (void)threads;
     double t0 = now_s();
 #ifdef _OPENMP
@@ -424,7 +426,7 @@ size_t vo_roc_bench_lists(size_t nlist, const uint64_t *offsets, const uint64_t 
         uint64_t mx = 0;
         for (size_t i = 0; i < n; i++) mx = p[i] > mx ? p[i] : mx;
         prec[l] = vo_precision_from_max_id((int32_t)mx);
-        vo_roc_encode(n, p, prec[l], &sts[l], NULL, NULL);
+        vo_roc_encode(n, p, prec[l], &sts[l], NULL, perm + offsets[l]);
     }
     double t1 = now_s();
     uint64_t bytes = 0;
@@ -465,6 +467,7 @@ size_t vo_roc_bench_lists(size_t nlist, const uint64_t *offsets, const uint64_t 
     for (size_t l = 0; l < nlist; l++) vo_ans_free(&sts[l]);
     free(sts);
     free(prec);
+    free(perm);
     *t_enc = t1 - t0;
     *t_dec = t3 - t2;
     *sum_bytes = bytes;
