@@ -143,6 +143,10 @@ void vidc_packed_destroy(vidc_packed *p);
 uint64_t vidc_packed_compressed_bytes(const vidc_packed *p); /* sum ceil(ls*bits/8), :80,85 */
 int vidc_packed_bits(const vidc_packed *p);
 int vidc_packed_decode_all(vidc_ctx *ctx, const vidc_packed *p, uint64_t *d_out);
+/* decode m selected lists back to back into d_out (get_ids per touched list, :96-105 / the loop :508-525);
+ * out_offsets: host uint64[m + 1] */
+int vidc_packed_decode_lists(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, const uint64_t *list_nos, uint64_t *d_out,
+                             uint64_t *out_offsets);
 /* m random accesses (get_single_id, :108-113): host arrays of list numbers / offsets -> host ids */
 int vidc_packed_get(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, const uint64_t *list_nos,
                     const uint64_t *offs, int64_t *ids_out);
@@ -220,6 +224,9 @@ uint32_t vidc_wt_levels(const vidc_wt *w);
 int vidc_wt_select(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint64_t *list_nos, const uint64_t *offs,
                    int64_t *ids_out);
 int vidc_wt_decode_all(vidc_ctx *ctx, const vidc_wt *w, uint64_t *d_out);
+/* get_ids of m selected lists back to back (custom_invlists_impl.cpp:381-392 per list); out_offsets: host uint64[m + 1] */
+int vidc_wt_decode_lists(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint64_t *list_nos, uint64_t *d_out,
+                         uint64_t *out_offsets);
 
 /* ------------------------------------------------------ introspection / timing */
 /* Milliseconds spent inside the kernels of the most recent encode / decode call on this context,

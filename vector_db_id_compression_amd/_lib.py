@@ -76,6 +76,7 @@ def _declare(lib):
     f("vidc_packed_compressed_bytes", _u64, _vp)
     f("vidc_packed_bits", C.c_int, _vp)
     f("vidc_packed_decode_all", C.c_int, _vp, _vp, _vp)
+    f("vidc_packed_decode_lists", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
     f("vidc_packed_get", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
     f("vidc_packed_export", C.c_int, _vp, _vp, _u64, _vp, C.c_size_t)
     f("vidc_packed_total_words", _u64, _vp)
@@ -111,6 +112,7 @@ def _declare(lib):
     f("vidc_wt_levels", _u32, _vp)
     f("vidc_wt_select", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
     f("vidc_wt_decode_all", C.c_int, _vp, _vp, _vp)
+    f("vidc_wt_decode_lists", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
 
 
 #: every symbol include/vidc.h declares (checked by the CPU test-suite against the built library)
@@ -123,14 +125,14 @@ EXPORTED_SYMBOLS = [
     "vidc_roc_perm", "vidc_roc_perm_dev", "vidc_roc_import", "vidc_roc_decode_all", "vidc_roc_decode_lists",
     "vidc_roc_decode_rows", "vidc_roc_last_decode_nonclean",
     "vidc_packed_bits_for", "vidc_packed_encode", "vidc_packed_destroy", "vidc_packed_compressed_bytes",
-    "vidc_packed_bits", "vidc_packed_decode_all", "vidc_packed_get", "vidc_packed_export", "vidc_packed_total_words", "vidc_packed_export_all", "vidc_packed_import",
+    "vidc_packed_bits", "vidc_packed_decode_all", "vidc_packed_decode_lists", "vidc_packed_get", "vidc_packed_export", "vidc_packed_total_words", "vidc_packed_export_all", "vidc_packed_import",
     "vidc_ef_encode", "vidc_ef_destroy", "vidc_ef_compressed_bytes", "vidc_ef_list_info", "vidc_ef_decode_all",
     "vidc_ef_get", "vidc_ef_perm", "vidc_ef_export", "vidc_ef_stream_words", "vidc_ef_export_all", "vidc_ef_import",
     "vidc_ef_encode_rows", "vidc_ef_decode_rows", "vidc_ef_decode_lists",
     "vidc_compact_rows_encode", "vidc_compact_destroy", "vidc_compact_bits", "vidc_compact_stride",
     "vidc_compact_size_in_bytes", "vidc_compact_rows_decode", "vidc_compact_export_row",
     "vidc_wt_build", "vidc_wt_destroy", "vidc_wt_size_in_bytes", "vidc_wt_levels", "vidc_wt_select",
-    "vidc_wt_decode_all",
+    "vidc_wt_decode_all", "vidc_wt_decode_lists",
 ]
 
 
@@ -138,8 +140,7 @@ def lib():
     """The loaded C-ABI library (built on first use)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            _build.build()
+        _build.build()  # returns at once unless a source is newer than the library (no stale kernels after an edit)
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
     return _lib

@@ -253,6 +253,17 @@ class PackedLists:
         check(lib().vidc_packed_decode_all(self.ctx.h, self.h, ptr(out)))
         return out[: self.ntotal]
 
+    def decode_lists(self, list_nos):
+        """Decode the requested lists back to back (work proportional to their sizes) -> (int64 CUDA tensor, offsets)."""
+        torch = _torch()
+        ln = np.ascontiguousarray(list_nos, dtype=np.uint64)
+        sizes = (self.offsets[1:] - self.offsets[:-1])[ln.astype(np.int64)] if ln.size else np.zeros(0, np.uint64)
+        total = int(sizes.sum())
+        out = torch.empty(max(total, 1), dtype=torch.int64, device="cuda")
+        out_off = np.zeros(ln.size + 1, np.uint64)
+        check(lib().vidc_packed_decode_lists(self.ctx.h, self.h, ln.size, ptr(ln), ptr(out), ptr(out_off)))
+        return out[:total], out_off
+
     def get(self, list_nos, offs):
         ln = np.ascontiguousarray(list_nos, dtype=np.uint64)
         of = np.ascontiguousarray(offs, dtype=np.uint64)
@@ -532,6 +543,17 @@ class WaveletTreeLists:
     @property
     def levels(self):
         return int(lib().vidc_wt_levels(self.h))
+
+    def decode_lists(self, list_nos):
+        """Decode the requested lists back to back (work proportional to their sizes) -> (int64 CUDA tensor, offsets)."""
+        torch = _torch()
+        ln = np.ascontiguousarray(list_nos, dtype=np.uint64)
+        sizes = (self.offsets[1:] - self.offsets[:-1])[ln.astype(np.int64)] if ln.size else np.zeros(0, np.uint64)
+        total = int(sizes.sum())
+        out = torch.empty(max(total, 1), dtype=torch.int64, device="cuda")
+        out_off = np.zeros(ln.size + 1, np.uint64)
+        check(lib().vidc_wt_decode_lists(self.ctx.h, self.h, ln.size, ptr(ln), ptr(out), ptr(out_off)))
+        return out[:total], out_off
 
     def select(self, list_nos, offs):
         ln = np.ascontiguousarray(list_nos, dtype=np.uint64)

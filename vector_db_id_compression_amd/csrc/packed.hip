@@ -117,6 +117,43 @@ __global__ void __launch_bounds__(64) k_packed_decode(const uint64_t *words, con
     }
 }
 
+// the same for a request of lists (get_ids of the lists a search touched, custom_invlists_impl.cpp:96-105 per list): one
+// wavefront per (request item, chunk); item i's ids go to out + out_off[i]
+struct PackedItem {
+    uint32_t item;
+    uint32_t start;
+};
+__global__ void __launch_bounds__(64) k_packed_decode_lists(const uint64_t *words, const uint64_t *offsets,
+                                                            const uint64_t *word_off, const uint64_t *list_nos,
+                                                            const uint64_t *out_off, const PackedItem *items,
+                                                            uint64_t nitems, uint32_t bits, uint64_t *out) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t keep = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+    for (uint64_t c = blockIdx.x; c < nitems; c += gridDim.x) {
+        const PackedItem it = items[c];
+        const uint64_t l = list_nos[it.item];
+        const uint64_t n = offsets[l + 1] - offsets[l];
+        const uint32_t nc = (uint32_t)(n - it.start < CHUNK_IDS ? n - it.start : CHUNK_IDS);
+        const uint64_t *src = words + word_off[l];
+        uint64_t *dst = out + out_off[it.item] + it.start;
+        uint64_t a[CHUNK_IDS / 64], b[CHUNK_IDS / 64];
+#pragma unroll
+        for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
+            const uint32_t i = lane + 64 * r;
+            const uint64_t pos = (uint64_t)(it.start + (i < nc ? i : 0u)) * bits;
+            a[r] = src[pos >> 6];
+            b[r] = src[(pos >> 6) + 1];
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
+            const uint32_t i = lane + 64 * r;
+            const uint32_t sh = (uint32_t)(((uint64_t)(it.start + i) * bits) & 63);
+            const uint64_t v = (a[r] >> sh) | (sh ? b[r] << (64 - sh) : 0ull);
+            if (i < nc) dst[i] = v & keep;
+        }
+    }
+}
+
 __global__ void k_packed_get(const uint64_t *words, const uint64_t *word_off, uint32_t bits, uint64_t m,
                              const uint64_t *list_nos, const uint64_t *offs, int64_t *out) {
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -415,6 +452,40 @@ int vidc_packed_decode_all(vidc_ctx *ctx, const vidc_packed *p, uint64_t *d_out)
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->last_kernel_ms = ms;
+    return VIDC_OK;
+}
+
+int vidc_packed_decode_lists(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, const uint64_t *list_nos, uint64_t *d_out,
+                             uint64_t *out_offsets) {
+    if (!ctx || !p || (m && !list_nos) || !out_offsets) return VIDC_ERR_INVALID;
+    out_offsets[0] = 0;
+    std::vector<PackedItem> items;
+    for (uint64_t i = 0; i < m; i++) {
+        if (list_nos[i] >= p->nlist) { set_error("list number out of range"); return VIDC_ERR_INVALID; }
+        const uint64_t n = p->offsets[list_nos[i] + 1] - p->offsets[list_nos[i]];
+        out_offsets[i + 1] = out_offsets[i] + n;
+        for (uint64_t s = 0; s < n; s += CHUNK_IDS) items.push_back(PackedItem{(uint32_t)i, (uint32_t)s});
+    }
+    ctx->last_kernel_ms = 0;
+    if (items.empty()) return VIDC_OK;
+    if (!d_out) return VIDC_ERR_INVALID;
+    VIDC_HIP(hipSetDevice(ctx->device));
+    Scratch s_l, s_o, s_i;
+    VIDC_TRY(s_l.get(ctx, m * 8)); VIDC_TRY(s_o.get(ctx, (m + 1) * 8)); VIDC_TRY(s_i.get(ctx, items.size() * sizeof(PackedItem)));
+    VIDC_HIP(hipMemcpyAsync(s_l.p, list_nos, m * 8, hipMemcpyHostToDevice, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(s_o.p, out_offsets, (m + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(s_i.p, items.data(), items.size() * sizeof(PackedItem), hipMemcpyHostToDevice, ctx->stream));
+    VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(items.size(), (uint64_t)ctx->num_cu * 256);
+    hipLaunchKernelGGL(k_packed_decode_lists, dim3(grid), dim3(64), 0, ctx->stream, p->d_words.p, p->d_offsets.p,
+                       p->d_word_off.p, s_l.as<uint64_t>(), s_o.as<uint64_t>(), s_i.as<PackedItem>(), (uint64_t)items.size(),
+                       (uint32_t)p->bits, d_out);
+    VIDC_HIP(hipGetLastError());
+    VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));  // the staging vectors above are pageable host memory
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->last_kernel_ms = ms;

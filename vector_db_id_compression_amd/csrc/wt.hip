@@ -170,6 +170,34 @@ __global__ void k_wt_select(const uint64_t *bits, const uint32_t *rank, const ui
     }
 }
 
+// get_ids of the requested lists (custom_invlists_impl.cpp:381-392 loops get_single_id): one thread per output slot,
+// its request item found in the m + 1 output offsets
+__global__ void k_wt_decode_lists(const uint64_t *bits, const uint32_t *rank, const uint64_t *C, uint64_t words_per_level,
+                                  uint64_t blocks_per_level, uint32_t L, uint64_t m, const uint64_t *list_nos,
+                                  const uint64_t *out_off, uint64_t total, uint64_t *out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        uint64_t lo = 0, hi = m;  // largest i with out_off[i] <= g
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (out_off[mid] <= g) lo = mid; else hi = mid;
+        }
+        const uint32_t c = (uint32_t)list_nos[lo];
+        uint64_t pos = g - out_off[lo];
+        for (int level = (int)L - 1; level >= 0; level--) {
+            const uint32_t sh = L - (uint32_t)level;
+            const uint64_t p = sh >= 32 ? 0 : (uint64_t)(c >> sh);
+            const uint64_t ns = C[sh >= 32 ? 0 : (p << sh)];
+            const bool bit = (c >> (L - 1u - (uint32_t)level)) & 1u;
+            const uint64_t *b = bits + (uint64_t)level * words_per_level;
+            const uint32_t *r = rank + (uint64_t)level * (blocks_per_level + 1);
+            const uint64_t r_ns = rank1(b, r, ns);
+            pos = select_bit(b, r, blocks_per_level, words_per_level, (bit ? r_ns : ns - r_ns) + pos, bit) - ns;
+        }
+        out[g] = pos;
+    }
+}
+
 // get_ids for every list (custom_invlists_impl.cpp:381-392 loops get_single_id)
 __global__ void k_wt_decode_all(const uint64_t *bits, const uint32_t *rank, const uint64_t *C, uint64_t words_per_level,
                                 uint64_t blocks_per_level, uint32_t nlist, uint32_t L, uint64_t ntotal,
@@ -359,6 +387,36 @@ int vidc_wt_select(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint64_t *
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipMemcpyAsync(ids_out, s_r.p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    return VIDC_OK;
+}
+
+int vidc_wt_decode_lists(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint64_t *list_nos, uint64_t *d_out,
+                         uint64_t *out_offsets) {
+    if (!ctx || !w || (m && !list_nos) || !out_offsets) return VIDC_ERR_INVALID;
+    out_offsets[0] = 0;
+    for (uint64_t i = 0; i < m; i++) {
+        if (list_nos[i] >= w->nlist) { set_error("list number out of range"); return VIDC_ERR_INVALID; }
+        out_offsets[i + 1] = out_offsets[i] + (w->offsets[list_nos[i] + 1] - w->offsets[list_nos[i]]);
+    }
+    const uint64_t total = out_offsets[m];
+    ctx->last_kernel_ms = 0;
+    if (!total) return VIDC_OK;
+    if (!d_out) return VIDC_ERR_INVALID;
+    VIDC_HIP(hipSetDevice(ctx->device));
+    Scratch s_l, s_o;
+    VIDC_TRY(s_l.get(ctx, m * 8)); VIDC_TRY(s_o.get(ctx, (m + 1) * 8));
+    VIDC_HIP(hipMemcpyAsync(s_l.p, list_nos, m * 8, hipMemcpyHostToDevice, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(s_o.p, out_offsets, (m + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_wt_decode_lists, dim3((uint32_t)std::min<uint64_t>((total + 127) / 128, 1u << 16)), dim3(128), 0,
+                       ctx->stream, w->d_bits.p, w->d_rank.p, w->d_C.p, w->words_per_level, w->blocks_per_level, w->L, m,
+                       s_l.as<uint64_t>(), s_o.as<uint64_t>(), total, d_out);
+    VIDC_HIP(hipGetLastError());
+    VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->last_kernel_ms = ms;
     return VIDC_OK;
 }
 

@@ -103,13 +103,7 @@ class CompressedIDInvertedListsPackedBits(InvertedListsArrayCodes):
         return self._c.decode_all()
 
     def decode_lists(self, list_nos):
-        torch = _torch()
-        full = self._c.decode_all()
-        ln = np.asarray(list_nos, dtype=np.int64)
-        sizes = (self._offsets[1:] - self._offsets[:-1])[ln].astype(np.int64)
-        out_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
-        parts = [full[int(self._offsets[l]):int(self._offsets[l + 1])] for l in ln]
-        return (torch.cat(parts) if parts else full[:0]), out_off
+        return self._c.decode_lists(np.asarray(list_nos, dtype=np.uint64))  # work ~ the requested lists (:96-105)
 
     def get_single_ids(self, list_nos, offsets):
         return self._c.get(list_nos, offsets)
@@ -186,14 +180,7 @@ class CompressedIDInvertedListsWaveletTree(InvertedListsArrayCodes):
         return self._c.decode_all()
 
     def decode_lists(self, list_nos):
-        torch = _torch()
-        ln = np.asarray(list_nos, dtype=np.int64)
-        sizes = (self._offsets[1:] - self._offsets[:-1])[ln].astype(np.int64)
-        out_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
-        qs_l = np.repeat(ln, sizes).astype(np.uint64)
-        qs_o = (np.arange(int(sizes.sum())) - np.repeat(out_off[:-1].astype(np.int64), sizes)).astype(np.uint64)
-        ids = self._c.select(qs_l, qs_o)  # get_ids loops get_single_id (:381-392)
-        return torch.from_numpy(ids).cuda(), out_off
+        return self._c.decode_lists(np.asarray(list_nos, dtype=np.uint64))  # get_ids loops get_single_id (:381-392)
 
     def get_single_ids(self, list_nos, offsets):
         return self._c.select(list_nos, offsets)
