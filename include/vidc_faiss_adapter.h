@@ -1,26 +1,41 @@
 /*
- * vidc_faiss_adapter.h -- OPTIONAL C++ adapter that puts libvidc behind faiss::InvertedLists / faiss::nsg::Graph.
+ * vidc_faiss_adapter.h -- C++ adapter that puts libvidc behind faiss::InvertedLists / faiss::nsg::Graph.
  *
- * Compiles only where the Faiss headers are installed (they are not in the build image of this repository, so this
- * header is exercised by no test here; INTEGRATION.md walks through it).  It is what a maintainer of the reference
- * adds next to custom_invlists_impl.h / altid_impl.h so that bench_invlists.py and graph_dynamic_bench_invlists.py
- * can select the GPU codecs through the same SWIG modules:
- *     %include "vidc_faiss_adapter.h"     (custom_invlists.swig:61, altid.swig)
+ * What a maintainer of the reference adds next to custom_invlists_impl.h / altid_impl.h so that bench_invlists.py,
+ * search_ivf_qinco.py and graph_dynamic_bench_invlists.py select the GPU codecs through the same SWIG modules
+ * (`%include "vidc_faiss_adapter.h"` in custom_invlists.swig:61 / altid.swig; the harness dictionaries then name these
+ * classes).  One class per reference class, same constructor argument, same public size attributes:
+ *
+ *   reference (custom_invlists_impl.h / altid_impl.h)            here
+ *   CompressedIDInvertedListsFenwickTree  (.cpp:133-223)          vidc_faiss::ROCInvertedLists
+ *   CompressedIDInvertedListsEliasFano    (.cpp:229-339)          vidc_faiss::EliasFanoInvertedLists
+ *   CompressedIDInvertedListsPackedBits   (.cpp:64-118)           vidc_faiss::PackedBitsInvertedLists
+ *   CompressedIDInvertedListsWaveletTree  (.cpp:346-397)          vidc_faiss::WaveletTreeInvertedLists
+ *   CompactBitNSGGraph / EliasFanoNSGGraph / ROCNSGGraph          vidc_faiss::CompactBitNSGGraph / EliasFanoNSGGraph / ROCNSGGraph
+ *   (altid_impl.cpp:20-165)
+ *   search_IVF_defer_id_decoding          (.cpp:407-526)          vidc_faiss::search_IVF_defer_id_decoding: the OpenMP loop
+ *                                                                 over touched lists (:508-525) is ONE vidc_*_decode_lists call
+ *
+ * Needs the Faiss headers, include/vidc.h and -lvidc.  Faiss is not installed in this repository's build image: the
+ * header is compiled and exercised there against the interface shim of tests/faiss_shim (tests/test_boundary.py,
+ * tests/adapter_smoke.cpp); against a real Faiss nothing else changes.
+ *
+ * Threading: Faiss calls get_ids / get_single_id / get_neighbors concurrently from OpenMP threads
+ * (custom_invlists_impl.cpp:467,508).  A vidc_ctx serves one host thread, so every thread gets its own context
+ * (thread_local, created on first use) with a device staging buffer that grows to the largest request and is reused:
+ * no allocation, no lock on the per-call path.  Compressed objects are immutable and shared.
  */
 #pragma once
-#if defined(__has_include)
-#if __has_include(<faiss/invlists/InvertedLists.h>) && __has_include(<faiss/impl/NSG.h>)
-#define VIDC_HAVE_FAISS 1
-#endif
-#endif
-
-#ifdef VIDC_HAVE_FAISS
+#include <faiss/IndexIVF.h>
 #include <faiss/impl/FaissAssert.h>
 #include <faiss/impl/NSG.h>
+#include <faiss/invlists/DirectMap.h>
 #include <faiss/invlists/InvertedLists.h>
 
+#include <cmath>
 #include <cstring>
-#include <mutex>
+#include <memory>
+#include <unordered_map>
 #include <vector>
 
 #include "vidc.h"
@@ -29,109 +44,389 @@ namespace vidc_faiss {
 
 #define VIDC_FAISS_CHECK(expr) FAISS_THROW_IF_NOT_MSG((expr) == VIDC_OK, vidc_last_error())
 
-/* common part: CSR of the source lists on the device (custom_invlists_impl.cpp:156-160 borrows ids the same way) */
-struct DeviceLists {
-    vidc_ctx* ctx = nullptr;
-    std::vector<uint64_t> offsets;
-    void* d_ids = nullptr;
-    explicit DeviceLists(const faiss::InvertedLists& il) : offsets(il.nlist + 1, 0) {
-        VIDC_FAISS_CHECK(vidc_ctx_create(-1, &ctx));
-        for (size_t l = 0; l < il.nlist; l++) offsets[l + 1] = offsets[l] + il.list_size(l);
+/* per-thread context + pooled device staging */
+struct ThreadCtx {
+    vidc_ctx* h = nullptr;
+    void* d_buf = nullptr;
+    size_t cap = 0;
+    vidc_ctx* ctx() {
+        if (!h) VIDC_FAISS_CHECK(vidc_ctx_create(-1, &h));
+        return h;
+    }
+    void* staging(size_t bytes) {
+        if (bytes > cap) {
+            if (d_buf) vidc_dev_free(ctx(), d_buf);
+            d_buf = nullptr;
+            cap = 0;
+            size_t want = bytes < (1u << 16) ? (1u << 16) : bytes + bytes / 2;
+            VIDC_FAISS_CHECK(vidc_dev_alloc(ctx(), want, &d_buf));
+            cap = want;
+        }
+        return d_buf;
+    }
+    ~ThreadCtx() {
+        if (h) {
+            if (d_buf) vidc_dev_free(h, d_buf);
+            vidc_ctx_destroy(h);
+        }
+    }
+};
+inline ThreadCtx& thread_ctx() {
+    thread_local ThreadCtx c;
+    return c;
+}
+
+/* RAII device copy of a host array (constructor-time uploads) */
+struct DeviceArray {
+    vidc_ctx* ctx;
+    void* p = nullptr;
+    DeviceArray(vidc_ctx* c, const void* host, size_t bytes) : ctx(c) {
+        if (!bytes) return;
+        VIDC_FAISS_CHECK(vidc_dev_alloc(ctx, bytes, &p));
+        int st = vidc_copy_h2d(ctx, p, host, bytes);
+        if (st != VIDC_OK) {
+            vidc_dev_free(ctx, p);
+            p = nullptr;
+            VIDC_FAISS_CHECK(st);
+        }
+    }
+    ~DeviceArray() {
+        if (p) vidc_dev_free(ctx, p);
+    }
+    DeviceArray(const DeviceArray&) = delete;
+    DeviceArray& operator=(const DeviceArray&) = delete;
+};
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * InvertedListsArrayCodes (custom_invlists_impl.h:22-33): CSR of the list sizes + the vector codes, optionally
+ * re-ordered; plus the batched decode every subclass provides for the deferred search.                          */
+struct CompressedInvertedLists : faiss::ReadOnlyInvertedLists {
+    std::vector<uint64_t> offsets;                /* [nlist + 1] */
+    std::vector<std::vector<uint8_t>> codes_all;  /* per list, in the container's order */
+    size_t compressed_ids_size_in_bytes = 0, overhead_in_bytes = 0, codes_size_in_bytes = 0;
+
+    explicit CompressedInvertedLists(const faiss::InvertedLists& il)
+            : faiss::ReadOnlyInvertedLists(il.nlist, il.code_size), offsets(il.nlist + 1, 0), codes_all(il.nlist) {
+        for (size_t l = 0; l < nlist; l++) offsets[l + 1] = offsets[l] + il.list_size(l);
+    }
+    /* ids of every list back to back (borrowed like custom_invlists_impl.cpp:156-160) */
+    static std::vector<uint64_t> gather_ids(const faiss::InvertedLists& il, const std::vector<uint64_t>& offsets) {
         std::vector<uint64_t> ids(offsets.back());
         for (size_t l = 0; l < il.nlist; l++) {
+            size_t n = il.list_size(l);
+            if (!n) continue;
             faiss::InvertedLists::ScopedIds s(&il, l);
-            if (il.list_size(l)) std::memcpy(ids.data() + offsets[l], s.get(), il.list_size(l) * 8);
+            std::memcpy(ids.data() + offsets[l], s.get(), n * 8);
         }
-        VIDC_FAISS_CHECK(vidc_dev_alloc(ctx, ids.size() * 8, &d_ids));
-        VIDC_FAISS_CHECK(vidc_copy_h2d(ctx, d_ids, ids.data(), ids.size() * 8));
+        return ids;
     }
-    void drop_ids() {
-        if (d_ids) vidc_dev_free(ctx, d_ids);
-        d_ids = nullptr;
-    }
-    ~DeviceLists() {
-        drop_ids();
-        vidc_ctx_destroy(ctx);
-    }
-};
-
-/* replaces CompressedIDInvertedListsFenwickTree (custom_invlists_impl.cpp:133-223) */
-struct ROCInvertedLists : faiss::ReadOnlyInvertedLists {
-    DeviceLists dev;
-    mutable std::mutex ctx_mu;  // a vidc_ctx serves one host thread at a time; Faiss calls get_ids from OpenMP threads
-    vidc_roc* roc = nullptr;
-    std::vector<std::vector<uint8_t>> codes_all;
-    size_t compressed_ids_size_in_bytes = 0, overhead_in_bytes = 0;
-
-    explicit ROCInvertedLists(const faiss::InvertedLists& il)
-            : faiss::ReadOnlyInvertedLists(il.nlist, il.code_size), dev(il), codes_all(il.nlist) {
-        VIDC_FAISS_CHECK(vidc_roc_encode(dev.ctx, nlist, dev.offsets.data(), (const uint64_t*)dev.d_ids,
-                                         VIDC_PREC_REFERENCE, VIDC_ROC_WANT_PERM, &roc));
-        dev.drop_ids();
-        compressed_ids_size_in_bytes = vidc_roc_compressed_bytes(roc);
-        std::vector<uint32_t> perm(dev.offsets.back());
-        VIDC_FAISS_CHECK(vidc_roc_perm(dev.ctx, roc, perm.data()));
-        for (size_t l = 0; l < nlist; l++) { /* codes follow the sampling order (:188-193) */
-            faiss::InvertedLists::ScopedCodes c(&il, l);
+    /* codes_all[l][i] = source code at position perm[offsets[l] + i] of list l (identity when perm == nullptr) */
+    void store_codes(const faiss::InvertedLists& il, const uint32_t* perm) {
+        for (size_t l = 0; l < nlist; l++) {
             size_t n = il.list_size(l);
             codes_all[l].resize(n * code_size);
-            for (size_t i = 0; i < n; i++)
-                std::memcpy(&codes_all[l][i * code_size], c.get() + (size_t)perm[dev.offsets[l] + i] * code_size,
-                            code_size);
+            if (!n || !code_size) continue;
+            faiss::InvertedLists::ScopedCodes c(&il, l);
+            for (size_t i = 0; i < n; i++) {
+                size_t src = perm ? perm[offsets[l] + i] : i;
+                std::memcpy(&codes_all[l][i * code_size], c.get() + src * code_size, code_size);
+            }
         }
     }
-    ~ROCInvertedLists() override { vidc_roc_destroy(roc); }
+    /* the reference adds the size of ALL code arrays once per non-empty list (custom_invlists_impl.cpp:203-205) */
+    void reference_codes_accounting() {
+        size_t total = 0, nonempty = 0;
+        for (auto& c : codes_all) {
+            total += c.size();
+            nonempty += !c.empty() || code_size == 0;
+        }
+        nonempty = 0;
+        for (size_t l = 0; l < nlist; l++) nonempty += offsets[l + 1] > offsets[l];
+        codes_size_in_bytes = nonempty * total;
+    }
 
-    size_t list_size(size_t l) const override { return dev.offsets[l + 1] - dev.offsets[l]; }
+    size_t list_size(size_t l) const override { return offsets[l + 1] - offsets[l]; }
     const uint8_t* get_codes(size_t l) const override { return codes_all[l].data(); }
-    const faiss::idx_t* get_ids(size_t l) const override { /* :210-219 */
+    void release_ids(size_t, const faiss::idx_t* ids) const override { delete[] ids; } /* :116-118,221-223,320-322,395-397 */
+
+    /* decode m lists into device memory d_out (lists back to back), offsets of the lists in out_off[m + 1] */
+    virtual int decode_lists_device(vidc_ctx* ctx, uint64_t m, const uint64_t* list_nos, uint64_t* d_out,
+                                    uint64_t* out_off) const = 0;
+
+    /* get_ids: new idx_t[list_size], nullptr for an empty list (:212-214,294-296) */
+    const faiss::idx_t* get_ids(size_t l) const override {
         size_t n = list_size(l);
         if (n == 0) return nullptr;
-        auto* out = new faiss::idx_t[n];
-        std::lock_guard<std::mutex> guard(ctx_mu);
-        void* d = nullptr;
+        std::unique_ptr<faiss::idx_t[]> out(new faiss::idx_t[n]);
+        ThreadCtx& t = thread_ctx();
         uint64_t off[2], ln = l;
-        VIDC_FAISS_CHECK(vidc_dev_alloc(dev.ctx, n * 8, &d));
-        int st = vidc_roc_decode_lists(dev.ctx, roc, 1, &ln, (uint64_t*)d, off);
-        if (st == VIDC_OK) st = vidc_copy_d2h(dev.ctx, out, d, n * 8);
-        vidc_dev_free(dev.ctx, d);
-        VIDC_FAISS_CHECK(st);
-        return out;
+        uint64_t* d = (uint64_t*)t.staging(n * 8);
+        VIDC_FAISS_CHECK(decode_lists_device(t.ctx(), 1, &ln, d, off));
+        VIDC_FAISS_CHECK(vidc_copy_d2h(t.ctx(), out.get(), d, n * 8));
+        return out.release();
     }
-    void release_ids(size_t, const faiss::idx_t* ids) const override { delete[] ids; } /* :221-223 */
+    /* the lists a batch of searches touched, decoded by ONE call (replaces the loop :508-525); host result */
+    void decode_lists_host(uint64_t m, const uint64_t* list_nos, std::vector<faiss::idx_t>& ids,
+                           std::vector<uint64_t>& out_off) const {
+        out_off.assign(m + 1, 0);
+        size_t total = 0;
+        for (uint64_t i = 0; i < m; i++) total += list_size(list_nos[i]);
+        ids.resize(total);
+        if (!total) return;
+        ThreadCtx& t = thread_ctx();
+        uint64_t* d = (uint64_t*)t.staging(total * 8);
+        VIDC_FAISS_CHECK(decode_lists_device(t.ctx(), m, list_nos, d, out_off.data()));
+        VIDC_FAISS_CHECK(vidc_copy_d2h(t.ctx(), ids.data(), d, total * 8));
+    }
 };
 
-/* replaces ROCNSGGraph (altid_impl.cpp:103-165) */
-struct ROCNSGGraph : faiss::nsg::Graph<int32_t> {
-    vidc_ctx* ctx = nullptr;
-    mutable std::mutex ctx_mu;  // get_neighbors may be called from several search threads
+/* CompressedIDInvertedListsFenwickTree (custom_invlists_impl.cpp:133-223): ROC / bits-back ANS */
+struct ROCInvertedLists : CompressedInvertedLists {
     vidc_roc* roc = nullptr;
-    void* d_row = nullptr;
-    explicit ROCNSGGraph(const faiss::nsg::Graph<int32_t>& g) : faiss::nsg::Graph<int32_t>(g.data, g.N, g.K) {
-        VIDC_FAISS_CHECK(vidc_ctx_create(-1, &ctx));
-        void* d = nullptr;
-        VIDC_FAISS_CHECK(vidc_dev_alloc(ctx, (size_t)N * K * 4, &d));
-        VIDC_FAISS_CHECK(vidc_copy_h2d(ctx, d, g.data, (size_t)N * K * 4));
-        int st = vidc_roc_encode_rows(ctx, N, K, (const int32_t*)d, VIDC_PREC_REFERENCE, 0, &roc);
-        vidc_dev_free(ctx, d);
-        VIDC_FAISS_CHECK(st);
-        VIDC_FAISS_CHECK(vidc_dev_alloc(ctx, (size_t)K * 4, &d_row));
-        data = nullptr; /* altid_impl.cpp:150 */
+    std::vector<uint64_t> id_symbol_precision; /* custom_invlists_impl.h:61 */
+
+    explicit ROCInvertedLists(const faiss::InvertedLists& il) : CompressedInvertedLists(il) {
+        vidc_ctx* ctx = thread_ctx().ctx();
+        {
+            std::vector<uint64_t> ids = gather_ids(il, offsets);
+            DeviceArray d_ids(ctx, ids.data(), ids.size() * 8);
+            VIDC_FAISS_CHECK(vidc_roc_encode(ctx, nlist, offsets.data(), (const uint64_t*)d_ids.p, VIDC_PREC_REFERENCE,
+                                             VIDC_ROC_WANT_PERM, &roc));
+        }
+        compressed_ids_size_in_bytes = vidc_roc_compressed_bytes(roc); /* :196-206 */
+        std::vector<uint32_t> perm(offsets.back() ? offsets.back() : 1), prec(nlist ? nlist : 1);
+        VIDC_FAISS_CHECK(vidc_roc_perm(ctx, roc, perm.data()));
+        VIDC_FAISS_CHECK(vidc_roc_list_info(roc, nullptr, prec.data(), nullptr, nullptr, nullptr));
+        id_symbol_precision.assign(prec.begin(), prec.begin() + nlist);
+        store_codes(il, perm.data()); /* codes follow the sampling order (:188-193) */
+        reference_codes_accounting();
     }
-    ~ROCNSGGraph() override {
-        vidc_dev_free(ctx, d_row);
-        vidc_roc_destroy(roc);
-        vidc_ctx_destroy(ctx);
+    ~ROCInvertedLists() override { vidc_roc_destroy(roc); }
+    int decode_lists_device(vidc_ctx* ctx, uint64_t m, const uint64_t* ln, uint64_t* d_out, uint64_t* off) const override {
+        return vidc_roc_decode_lists(ctx, roc, m, ln, d_out, off);
     }
-    size_t get_neighbors(int i, int32_t* neighbors) const override {
-        std::lock_guard<std::mutex> guard(ctx_mu);
+    /* get_single_id is not overridden in the reference: InvertedLists::get_single_id = get_ids()[offset] */
+};
+
+/* CompressedIDInvertedListsEliasFano (custom_invlists_impl.cpp:229-339) */
+struct EliasFanoInvertedLists : CompressedInvertedLists {
+    vidc_ef* ef = nullptr;
+    explicit EliasFanoInvertedLists(const faiss::InvertedLists& il) : CompressedInvertedLists(il) {
+        vidc_ctx* ctx = thread_ctx().ctx();
+        {
+            std::vector<uint64_t> ids = gather_ids(il, offsets);
+            DeviceArray d_ids(ctx, ids.data(), ids.size() * 8);
+            VIDC_FAISS_CHECK(vidc_ef_encode(ctx, nlist, offsets.data(), (const uint64_t*)d_ids.p, VIDC_EF_WANT_PERM, &ef));
+        }
+        compressed_ids_size_in_bytes = vidc_ef_compressed_bytes(ef); /* :272-282 */
+        std::vector<uint32_t> perm(offsets.back() ? offsets.back() : 1);
+        VIDC_FAISS_CHECK(vidc_ef_perm(ctx, ef, perm.data()));
+        store_codes(il, perm.data()); /* canonicalize_order_inplace (:324-339) */
+        reference_codes_accounting();
+    }
+    ~EliasFanoInvertedLists() override { vidc_ef_destroy(ef); }
+    int decode_lists_device(vidc_ctx* ctx, uint64_t m, const uint64_t* ln, uint64_t* d_out, uint64_t* off) const override {
+        return vidc_ef_decode_lists(ctx, ef, m, ln, d_out, off);
+    }
+    faiss::idx_t get_single_id(size_t l, size_t offset) const override { /* ef->select(offset), :314-318 */
+        uint64_t ln = l, of = offset;
+        int64_t id = -1;
+        VIDC_FAISS_CHECK(vidc_ef_get(thread_ctx().ctx(), ef, 1, &ln, &of, &id));
+        return id;
+    }
+};
+
+/* CompressedIDInvertedListsPackedBits (custom_invlists_impl.cpp:64-118) */
+struct PackedBitsInvertedLists : CompressedInvertedLists {
+    vidc_packed* pk = nullptr;
+    int bits = 0;
+    explicit PackedBitsInvertedLists(const faiss::InvertedLists& il) : CompressedInvertedLists(il) {
+        vidc_ctx* ctx = thread_ctx().ctx();
+        bits = vidc_packed_bits_for(offsets.back()); /* :68-70 */
+        std::vector<uint64_t> ids = gather_ids(il, offsets);
+        for (uint64_t v : ids) FAISS_THROW_IF_NOT(v < offsets.back()); /* ids_in[i] >= 0 && ids_in[i] < ntotal, :87 */
+        DeviceArray d_ids(ctx, ids.data(), ids.size() * 8);
+        VIDC_FAISS_CHECK(vidc_packed_encode(ctx, nlist, offsets.data(), (const uint64_t*)d_ids.p, bits, &pk));
+        compressed_ids_size_in_bytes = vidc_packed_compressed_bytes(pk); /* :80,85 */
+        store_codes(il, nullptr);
+    }
+    ~PackedBitsInvertedLists() override { vidc_packed_destroy(pk); }
+    int decode_lists_device(vidc_ctx* ctx, uint64_t m, const uint64_t* ln, uint64_t* d_out, uint64_t* off) const override {
+        return vidc_packed_decode_lists(ctx, pk, m, ln, d_out, off);
+    }
+    faiss::idx_t get_single_id(size_t l, size_t offset) const override { /* :108-113 */
+        uint64_t ln = l, of = offset;
+        int64_t id = -1;
+        VIDC_FAISS_CHECK(vidc_packed_get(thread_ctx().ctx(), pk, 1, &ln, &of, &id));
+        return id;
+    }
+};
+
+/* CompressedIDInvertedListsWaveletTree (custom_invlists_impl.cpp:346-397) */
+struct WaveletTreeInvertedLists : CompressedInvertedLists {
+    vidc_wt* wt = nullptr;
+    int wt_type = 0;
+    explicit WaveletTreeInvertedLists(const faiss::InvertedLists& il, int wt_type_ = 0)
+            : CompressedInvertedLists(il), wt_type(wt_type_) {
+        vidc_ctx* ctx = thread_ctx().ctx();
+        std::vector<uint64_t> ids = gather_ids(il, offsets);
+        DeviceArray d_ids(ctx, ids.data(), ids.size() * 8);
+        VIDC_FAISS_CHECK(vidc_wt_build(ctx, nlist, offsets.data(), (const uint64_t*)d_ids.p, wt_type, &wt));
+        compressed_ids_size_in_bytes = vidc_wt_size_in_bytes(wt); /* :369,372 */
+        store_codes(il, nullptr);
+    }
+    ~WaveletTreeInvertedLists() override { vidc_wt_destroy(wt); }
+    int decode_lists_device(vidc_ctx* ctx, uint64_t m, const uint64_t* ln, uint64_t* d_out, uint64_t* off) const override {
+        return vidc_wt_decode_lists(ctx, wt, m, ln, d_out, off);
+    }
+    faiss::idx_t get_single_id(size_t l, size_t offset) const override { /* wt.select(offset + 1, list_no), :377-379 */
+        uint64_t ln = l, of = offset;
+        int64_t id = -1;
+        VIDC_FAISS_CHECK(vidc_wt_select(thread_ctx().ctx(), wt, 1, &ln, &of, &id));
+        return id;
+    }
+};
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * search_IVF_defer_id_decoding (custom_invlists_impl.cpp:407-526, wrapper custom_invlists.swig:67-122).
+ * Identical up to the translation; the per-list OpenMP loop is one batched device decode when the index holds one of
+ * the containers above (any other InvertedLists takes the reference's loop).                                     */
+inline void search_IVF_defer_id_decoding(const faiss::IndexIVF& index, faiss::idx_t n, const float* x, int k,
+                                         float* distances, faiss::idx_t* labels, bool decode_1by1 = false,
+                                         uint8_t* codes = nullptr, bool include_listno = false) {
+    using faiss::idx_t;
+    std::unique_ptr<float[]> Dq(new float[n * index.nprobe]);
+    std::unique_ptr<idx_t[]> Iq(new idx_t[n * index.nprobe]);
+    FAISS_THROW_IF_NOT_MSG(index.parallel_mode == 3, "set the parallel mode to 3 otherwise search will be single-threaded");
+    index.quantizer->search(n, x, index.nprobe, Dq.get(), Iq.get());
+    index.search_preassigned(n, x, k, Iq.get(), Dq.get(), distances, labels, true);
+    const faiss::InvertedLists* invlists = index.invlists;
+    if (codes) { /* :434-462 */
+        size_t code_size = index.code_size, code_size_1 = code_size + (include_listno ? index.coarse_code_size() : 0);
+        for (idx_t ij = 0; ij < n * k; ij++) {
+            idx_t key = labels[ij];
+            uint8_t* code1 = codes + ij * code_size_1;
+            if (key < 0) {
+                std::memset(code1, -1, code_size_1);
+                continue;
+            }
+            const uint8_t* cc = invlists->get_single_code(faiss::lo_listno(key), faiss::lo_offset(key));
+            if (include_listno) {
+                index.encode_listno(faiss::lo_listno(key), code1);
+                code1 += code_size_1 - code_size;
+            }
+            std::memcpy(code1, cc, code_size);
+        }
+    }
+    if (decode_1by1) { /* :465-475 */
+        for (idx_t i = 0; i < n * k; i++)
+            if (labels[i] >= 0) labels[i] = invlists->get_single_id(faiss::lo_listno(labels[i]), faiss::lo_offset(labels[i]));
+        return;
+    }
+    /* touched lists (:477-502) */
+    std::unordered_map<idx_t, size_t> slot;
+    std::vector<uint64_t> lists;
+    for (idx_t i = 0; i < n * k; i++)
+        if (labels[i] >= 0 && slot.emplace(faiss::lo_listno(labels[i]), lists.size()).second)
+            lists.push_back((uint64_t)faiss::lo_listno(labels[i]));
+    if (auto* comp = dynamic_cast<const CompressedInvertedLists*>(invlists)) {
+        std::vector<idx_t> ids;
+        std::vector<uint64_t> out_off;
+        comp->decode_lists_host(lists.size(), lists.data(), ids, out_off); /* ONE decode call (:508-525) */
+        for (idx_t i = 0; i < n * k; i++)
+            if (labels[i] >= 0) labels[i] = ids[out_off[slot[faiss::lo_listno(labels[i])]] + faiss::lo_offset(labels[i])];
+        return;
+    }
+    for (idx_t i = 0; i < n * k; i++) { /* foreign container: one get_ids per touched list like the reference */
+        if (labels[i] < 0) continue;
+        faiss::InvertedLists::ScopedIds sids(invlists, faiss::lo_listno(labels[i]));
+        labels[i] = sids.get()[faiss::lo_offset(labels[i])];
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * graph containers (altid_impl.h:29-67).  The constructors read graph.data (N x K int32, -1 terminated rows) and set
+ * data = nullptr like the reference (altid_impl.cpp:38,89,150).                                                  */
+struct CompressedNSGGraph : faiss::nsg::Graph<int32_t> {
+    size_t compressed_ids_size_in_bytes = 0, overhead_in_bytes = 0;
+    explicit CompressedNSGGraph(const faiss::nsg::Graph<int32_t>& g) : faiss::nsg::Graph<int32_t>(g.data, g.N, g.K) {}
+    /* decode one row into neighbors[0..K) (-1 padded); returns the edge count */
+    template <class F>
+    size_t one_row(int i, int32_t* neighbors, F&& decode) const {
+        ThreadCtx& t = thread_ctx();
+        int32_t* d = (int32_t*)t.staging((size_t)K * 4);
         uint64_t node = (uint64_t)i;
         uint32_t count = 0;
-        VIDC_FAISS_CHECK(vidc_roc_decode_rows(ctx, roc, 1, &node, K, (int32_t*)d_row, &count));
-        VIDC_FAISS_CHECK(vidc_copy_d2h(ctx, neighbors, d_row, (size_t)K * 4));
-        return count; /* the reference returns K with only `count` slots written (altid_impl.cpp:163-164) */
+        VIDC_FAISS_CHECK(decode(t.ctx(), node, d, &count));
+        VIDC_FAISS_CHECK(vidc_copy_d2h(t.ctx(), neighbors, d, (size_t)K * 4));
+        return count;
+    }
+};
+
+/* CompactBitNSGGraph (altid_impl.cpp:20-51) */
+struct CompactBitNSGGraph : CompressedNSGGraph {
+    vidc_compact* c = nullptr;
+    int bits = 0;
+    size_t stride = 0;
+    explicit CompactBitNSGGraph(const faiss::nsg::Graph<int32_t>& g) : CompressedNSGGraph(g) {
+        vidc_ctx* ctx = thread_ctx().ctx();
+        DeviceArray d(ctx, g.data, (size_t)N * K * 4);
+        VIDC_FAISS_CHECK(vidc_compact_rows_encode(ctx, N, K, (const int32_t*)d.p, &c));
+        bits = (int)vidc_compact_bits(c);
+        stride = vidc_compact_stride(c);
+        compressed_ids_size_in_bytes = vidc_compact_size_in_bytes(c);
+        data = nullptr;
+    }
+    ~CompactBitNSGGraph() override { vidc_compact_destroy(c); }
+    size_t get_neighbors(int i, int32_t* neighbors) const override { /* returns the edge count (:41-50) */
+        return one_row(i, neighbors, [&](vidc_ctx* ctx, uint64_t node, int32_t* d, uint32_t* cnt) {
+            return vidc_compact_rows_decode(ctx, c, 1, &node, d, cnt);
+        });
+    }
+};
+
+/* EliasFanoNSGGraph (altid_impl.cpp:53-101) */
+struct EliasFanoNSGGraph : CompressedNSGGraph {
+    vidc_ef* ef = nullptr;
+    explicit EliasFanoNSGGraph(const faiss::nsg::Graph<int32_t>& g) : CompressedNSGGraph(g) {
+        vidc_ctx* ctx = thread_ctx().ctx();
+        DeviceArray d(ctx, g.data, (size_t)N * K * 4);
+        VIDC_FAISS_CHECK(vidc_ef_encode_rows(ctx, N, K, (const int32_t*)d.p, &ef));
+        compressed_ids_size_in_bytes = vidc_ef_compressed_bytes(ef); /* :86,88 */
+        overhead_in_bytes += N * std::ceil(std::log2(N)) / 8.0; /* :56-57, a size_t incremented twice by a double */
+        overhead_in_bytes += N * std::ceil(std::log2(N)) / 8.0;
+        data = nullptr;
+    }
+    ~EliasFanoNSGGraph() override { vidc_ef_destroy(ef); }
+    size_t get_neighbors(int i, int32_t* neighbors) const override { /* returns num_elements (:92-101) */
+        return one_row(i, neighbors, [&](vidc_ctx* ctx, uint64_t node, int32_t* d, uint32_t* cnt) {
+            return vidc_ef_decode_rows(ctx, ef, 1, &node, (uint32_t)K, d, cnt);
+        });
+    }
+};
+
+/* ROCNSGGraph (altid_impl.cpp:103-165) */
+struct ROCNSGGraph : CompressedNSGGraph {
+    vidc_roc* roc = nullptr;
+    std::vector<uint32_t> num_outgoing_edges; /* altid_impl.h:61 */
+    explicit ROCNSGGraph(const faiss::nsg::Graph<int32_t>& g) : CompressedNSGGraph(g), num_outgoing_edges(g.N) {
+        vidc_ctx* ctx = thread_ctx().ctx();
+        DeviceArray d(ctx, g.data, (size_t)N * K * 4);
+        VIDC_FAISS_CHECK(vidc_roc_encode_rows(ctx, N, K, (const int32_t*)d.p, VIDC_PREC_REFERENCE, 0, &roc));
+        VIDC_FAISS_CHECK(vidc_roc_list_info(roc, num_outgoing_edges.data(), nullptr, nullptr, nullptr, nullptr));
+        /* :148 adds ans_states[i].size() for EVERY node (8 bytes even for an empty state) */
+        compressed_ids_size_in_bytes = 8 * (size_t)N + 4 * vidc_roc_total_words(roc);
+        overhead_in_bytes += N * std::ceil(std::log2(N)) / 8.0; /* :105 */
+        data = nullptr;
+    }
+    ~ROCNSGGraph() override { vidc_roc_destroy(roc); }
+    size_t get_neighbors(int i, int32_t* neighbors) const override {
+        one_row(i, neighbors, [&](vidc_ctx* ctx, uint64_t node, int32_t* d, uint32_t* cnt) {
+            return vidc_roc_decode_rows(ctx, roc, 1, &node, (uint32_t)K, d, cnt);
+        });
+        return K; /* the reference returns K with only num_outgoing_edges[i] slots written (altid_impl.cpp:163-164);
+                     here the remaining slots hold -1, which the NSG search stops at */
     }
 };
 
 }  // namespace vidc_faiss
-#endif /* VIDC_HAVE_FAISS */

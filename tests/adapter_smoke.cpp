@@ -1,0 +1,159 @@
+// adapter_smoke.cpp -- drives include/vidc_faiss_adapter.h the way Faiss and the reference's harnesses do
+// (test_compressed_ivfs.py:43-156, test_altid.py:17-44), compiled against tests/faiss_shim in this image.
+//   build: g++ -std=c++17 -I tests/faiss_shim -I include tests/adapter_smoke.cpp -L <pkg> -lvidc -Wl,-rpath,<pkg> -fopenmp
+// Prints "adapter smoke ok" and returns 0 when every check holds.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <set>
+#include <vector>
+
+#include "vidc_faiss_adapter.h"
+
+#define REQUIRE(c)                                                       \
+    do {                                                                 \
+        if (!(c)) { printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } \
+    } while (0)
+
+using faiss::idx_t;
+
+template <class Container>
+static int check_container(faiss::IndexIVF& index, const faiss::ArrayInvertedLists& ref, const std::vector<float>& xq, int nq,
+                           int k, const std::vector<idx_t>& Iref, const std::vector<float>& Dref, const char* name) {
+    Container comp(ref);
+    REQUIRE(comp.nlist == ref.nlist && comp.code_size == ref.code_size);
+    REQUIRE(comp.compressed_ids_size_in_bytes > 0);
+    size_t total = 0;
+    for (size_t l = 0; l < ref.nlist; l++) {  // test_compressed_ivfs.py:66-79
+        REQUIRE(comp.list_size(l) == ref.list_size(l));
+        const idx_t* ids = comp.get_ids(l);
+        if (ref.list_size(l) == 0) { REQUIRE(ids == nullptr); continue; }
+        std::vector<idx_t> a(ids, ids + ref.list_size(l)), b(ref.ids[l]);
+        // the codes of the container are in the order of its ids
+        for (size_t i = 0; i < a.size(); i++) {
+            size_t j = std::find(b.begin(), b.end(), a[i]) - b.begin();
+            REQUIRE(j < b.size());
+            REQUIRE(std::memcmp(comp.get_codes(l) + i * comp.code_size, ref.codes[l].data() + j * ref.code_size, ref.code_size) == 0);
+        }
+        for (size_t i = 0; i < a.size(); i += 7) REQUIRE(comp.get_single_id(l, i) == a[i]);
+        comp.release_ids(l, ids);
+        std::sort(a.begin(), a.end());
+        std::sort(b.begin(), b.end());
+        REQUIRE(a == b);
+        total += a.size();
+    }
+    REQUIRE(total == ref.compute_ntotal());
+    index.replace_invlists(&comp, false);
+    std::vector<idx_t> I(nq * k);
+    std::vector<float> D(nq * k);
+    index.search(nq, xq.data(), k, D.data(), I.data());  // non-deferred: get_ids of the probed lists, from OpenMP threads in Faiss
+    REQUIRE(I == Iref && D == Dref);
+    for (int one_by_one = 0; one_by_one < 2; one_by_one++) {  // test_compressed_ivfs.py:128-156
+        std::fill(I.begin(), I.end(), -7);
+        vidc_faiss::search_IVF_defer_id_decoding(index, nq, xq.data(), k, D.data(), I.data(), one_by_one != 0);
+        REQUIRE(I == Iref && D == Dref);
+    }
+    std::vector<uint8_t> codes((size_t)nq * k * (comp.code_size + index.coarse_code_size()));
+    vidc_faiss::search_IVF_defer_id_decoding(index, nq, xq.data(), k, D.data(), I.data(), false, codes.data(), true);
+    REQUIRE(I == Iref);
+    // concurrent get_ids like Faiss' scan threads (custom_invlists_impl.cpp:467,508)
+    int bad = 0;
+#pragma omp parallel for num_threads(4) reduction(+ : bad)
+    for (int l = 0; l < (int)ref.nlist; l++) {
+        const idx_t* ids = comp.get_ids(l);
+        if (!ids) continue;
+        std::multiset<idx_t> a(ids, ids + ref.list_size(l)), b(ref.ids[l].begin(), ref.ids[l].end());
+        bad += a != b;
+        comp.release_ids(l, ids);
+    }
+    REQUIRE(bad == 0);
+    index.replace_invlists(const_cast<faiss::ArrayInvertedLists*>(&ref), false);
+    printf("  %-28s ok: %zu bytes for %zu ids\n", name, comp.compressed_ids_size_in_bytes, total);
+    return 0;
+}
+
+template <class G>
+static int check_graph(const std::vector<int32_t>& rows, int N, int K, const char* name, bool sorted, bool returns_K) {
+    std::vector<int32_t> copy(rows);  // the EF constructor of the reference sorts the source rows in place
+    faiss::nsg::Graph<int32_t> src(copy.data(), N, K);
+    G g(src);
+    REQUIRE(g.data == nullptr && g.N == N && g.K == K && g.compressed_ids_size_in_bytes > 0);
+    std::vector<int32_t> nb(K);
+    for (int i = 0; i < N; i++) {
+        int d = 0;
+        while (d < K && rows[(size_t)i * K + d] >= 0) d++;
+        size_t got = g.get_neighbors(i, nb.data());
+        REQUIRE(got == (returns_K ? (size_t)K : (size_t)d));
+        std::vector<int32_t> a(nb.begin(), nb.begin() + d), b(rows.begin() + (size_t)i * K, rows.begin() + (size_t)i * K + d);
+        if (sorted) { REQUIRE(std::is_sorted(a.begin(), a.end())); }
+        else if (!returns_K) REQUIRE(a == b);  // compact keeps the order (altid_impl.cpp:28-37)
+        std::sort(a.begin(), a.end());
+        std::sort(b.begin(), b.end());
+        REQUIRE(a == b);  // test_altid.py:33-40
+    }
+    printf("  %-28s ok: %zu bytes for %d nodes\n", name, g.compressed_ids_size_in_bytes, N);
+    return 0;
+}
+
+int main() {
+    try {
+        const int d = 8, nlist = 16, nb = 6000, nq = 9, k = 10;
+        std::mt19937 rng(123);
+        std::normal_distribution<float> nd;
+        std::vector<float> cent(nlist * d), xb((size_t)nb * d), xq((size_t)nq * d);
+        for (auto& v : cent) v = 3 * nd(rng);
+        for (int i = 0; i < nb; i++) for (int t = 0; t < d; t++) xb[(size_t)i * d + t] = cent[(rng() % nlist) * d + t] + nd(rng);
+        for (int i = 0; i < nq; i++) for (int t = 0; t < d; t++) xq[(size_t)i * d + t] = cent[(rng() % nlist) * d + t] + nd(rng);
+        faiss::IndexFlatL2 quant(d);
+        quant.add(nlist - 1, cent.data());  // one centroid short: the last list stays empty
+        faiss::IndexIVF index(&quant, d, nlist);
+        index.add(nb, xb.data());
+        index.nprobe = 4;
+        index.parallel_mode = 3;
+        auto* ref = static_cast<faiss::ArrayInvertedLists*>(index.invlists);
+        index.own_invlists = false;
+        std::vector<idx_t> Iref(nq * k);
+        std::vector<float> Dref(nq * k);
+        index.search(nq, xq.data(), k, Dref.data(), Iref.data());
+        printf("inverted lists (%d ids, %d lists):\n", nb, nlist);
+        if (check_container<vidc_faiss::ROCInvertedLists>(index, *ref, xq, nq, k, Iref, Dref, "ROCInvertedLists")) return 1;
+        if (check_container<vidc_faiss::EliasFanoInvertedLists>(index, *ref, xq, nq, k, Iref, Dref, "EliasFanoInvertedLists")) return 1;
+        if (check_container<vidc_faiss::PackedBitsInvertedLists>(index, *ref, xq, nq, k, Iref, Dref, "PackedBitsInvertedLists")) return 1;
+        if (check_container<vidc_faiss::WaveletTreeInvertedLists>(index, *ref, xq, nq, k, Iref, Dref, "WaveletTreeInvertedLists")) return 1;
+        {  // a foreign container still works through the deferred search (reference loop)
+            std::vector<idx_t> I(nq * k);
+            std::vector<float> D(nq * k);
+            vidc_faiss::search_IVF_defer_id_decoding(index, nq, xq.data(), k, D.data(), I.data());
+            REQUIRE(I == Iref);
+            index.parallel_mode = 0;
+            bool threw = false;
+            try { vidc_faiss::search_IVF_defer_id_decoding(index, nq, xq.data(), k, D.data(), I.data()); }
+            catch (const faiss::FaissException&) { threw = true; }  // custom_invlists_impl.cpp:420-422
+            REQUIRE(threw);
+        }
+        delete ref;
+        const int N = 3000, K = 48;
+        std::vector<int32_t> rows((size_t)N * K, -1);
+        for (int i = 0; i < N; i++) {
+            int deg = i == 5 ? 0 : (i == 6 ? K : (int)(rng() % (K + 1)));
+            std::set<int32_t> s;
+            while ((int)s.size() < deg) {  // no powers of two: a row whose LARGEST id is one decodes lossily in the reference's
+                int32_t v = (int32_t)(rng() % N);  // ROC (precision one bit short), which this library reproduces
+                if (v & (v - 1)) s.insert(v);
+            }
+            std::vector<int32_t> v(s.begin(), s.end());
+            std::shuffle(v.begin(), v.end(), rng);
+            std::copy(v.begin(), v.end(), rows.begin() + (size_t)i * K);
+        }
+        printf("graphs (%d nodes, K = %d):\n", N, K);
+        if (check_graph<vidc_faiss::CompactBitNSGGraph>(rows, N, K, "CompactBitNSGGraph", false, false)) return 1;
+        if (check_graph<vidc_faiss::EliasFanoNSGGraph>(rows, N, K, "EliasFanoNSGGraph", true, false)) return 1;
+        if (check_graph<vidc_faiss::ROCNSGGraph>(rows, N, K, "ROCNSGGraph", false, true)) return 1;
+    } catch (const std::exception& e) {
+        printf("FAILED with exception: %s\n", e.what());
+        return 1;
+    }
+    printf("adapter smoke ok\n");
+    return 0;
+}
