@@ -387,3 +387,43 @@ def test_ctx_trim_releases_cached_blocks():
     assert np.array_equal(np.sort(dec2.view(np.uint64)), np.sort(ids))
     del r
     ctx.close()
+
+
+@pytest.mark.parametrize("K", [65, 128, 200])
+def test_wide_graph_rows_take_the_list_kernels(K, oracle):
+    """NSG128 / NSG256-style graphs (max_degree is a CLI argument of graph_dynamic_bench_invlists.py): rows wider than
+    the lane-per-row kernels become CSR lists; every container answers get_neighbors like the reference."""
+    from vector_db_id_compression_amd import altid
+
+    rng = np.random.default_rng(K)
+    N = 3000
+    rows = np.full((N, K), -1, dtype=np.int32)
+    for i in range(N):
+        d = int(rng.integers(0, K + 1)) if i > 2 else (0, K, 1)[i]
+        v = rng.choice(N, size=d, replace=False)
+        rows[i, :d] = v
+    for name, cls in (("compact", altid.CompactBitNSGGraph), ("elias-fano", altid.EliasFanoNSGGraph), ("roc", altid.ROCNSGGraph)):
+        g = cls(rows.copy())
+        out, cnt = g.get_neighbors_batch(np.arange(N))
+        for i in range(0, N, 7):
+            d = int((rows[i] >= 0).sum())
+            assert cnt[i] == d, (name, i)
+            li = rows[i, :d].astype(np.uint64)
+            if name == "roc" and d:
+                P = oracle.list_precision(li)
+                e = oracle.roc_encode(li, P)
+                want = oracle.roc_decode(e["head"], e["words"], d, P, e["mt_draws"])[0]
+                assert out[i, :d].astype(np.uint64).tolist() == want.tolist(), (name, i)
+            elif name == "elias-fano":
+                assert out[i, :d].tolist() == sorted(rows[i, :d].tolist()), (name, i)
+            else:
+                assert out[i, :d].tolist() == rows[i, :d].tolist(), (name, i)
+            assert np.all(out[i, d:] == -1), (name, i)
+        if name == "compact":
+            assert g.stride == (K * g.bits + 7) // 8
+            d = int((rows[3] >= 0).sum())
+            vals = np.concatenate([rows[3, :d], [N] if d < K else []]).astype(np.uint64)
+            want = oracle.packed_encode(vals, g.bits)
+            got = g._c.export_row(3)
+            assert np.array_equal(got[: want.size], want) and not got[want.size:].any()
+        assert g.get_neighbors(1).size == K

@@ -55,7 +55,9 @@ class EliasFanoNSGGraph(_GraphBase):
         self._c = EfLists.encode_rows(self._rows)
         self.compressed_ids_size_in_bytes = self._c.compressed_bytes  # :86,88
         # :55-57: size of each friend list + its max id, ceil(log2 N) bits each
-        self.overhead_in_bytes = int(2 * (self.N * np.ceil(np.log2(self.N)) / 8.0)) if self.N > 1 else 0
+        # (a size_t incremented twice by a double: the value truncates after EACH addition)
+        x = self.N * np.ceil(np.log2(self.N)) / 8.0 if self.N > 1 else 0.0
+        self.overhead_in_bytes = int(int(x) + x)
         self._rows = None
 
 

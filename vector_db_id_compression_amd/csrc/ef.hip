@@ -16,6 +16,7 @@
 #include "chunks.h"
 #include "common.h"
 #include "scan.h"
+#include "rows_csr.h"
 #include "wave.h"
 
 using namespace vidc;
@@ -1326,8 +1327,19 @@ int vidc_ef_decode_rows(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint6
 int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_rows, vidc_ef **out) {
     if (!ctx || !out || (N && !d_rows)) return VIDC_ERR_INVALID;
     *out = nullptr;
-    if (K == 0 || K > 64) { set_error("EF rows: K=%u unsupported (1..64)", K); return VIDC_ERR_UNSUPPORTED; }
+    if (K == 0) { set_error("EF rows: K=0 unsupported"); return VIDC_ERR_UNSUPPORTED; }
     if (N >= 0xffffffffull) return VIDC_ERR_INVALID;
+    if (K > 64) {
+        // wide rows (NSG128, NSG256, ...): the rows become CSR lists and take the per-list kernels (which sort each list
+        // like altid_impl.cpp:76 and use its largest id as the universe, :75,77)
+        VIDC_HIP(hipSetDevice(ctx->device));
+        std::vector<uint64_t> offsets;
+        Scratch s_ids;
+        VIDC_TRY(rows_to_csr(ctx, N, K, d_rows, offsets, s_ids));
+        VIDC_TRY(vidc_ef_encode(ctx, N, offsets.data(), s_ids.as<uint64_t>(), 0, out));
+        (*out)->K = K;
+        return VIDC_OK;
+    }
     VIDC_HIP(hipSetDevice(ctx->device));
     std::unique_ptr<vidc_ef> e(new vidc_ef());
     e->device = ctx->device;

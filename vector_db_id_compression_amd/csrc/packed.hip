@@ -227,6 +227,67 @@ __global__ void __launch_bounds__(64) k_compact_rows_decode(const uint8_t *data,
     }
 }
 
+// the same for rows of any width (K > 64: NSG128 / NSG256 graphs): the wavefront walks the row 64 values at a time; the
+// row image lives in dynamic LDS (stride bytes + one spill word)
+__global__ void __launch_bounds__(64) k_compact_rows_encode_wide(const int32_t *rows, uint64_t N, uint32_t K, uint32_t bits,
+                                                                 uint32_t stride, uint8_t *out, uint32_t *err) {
+    extern __shared__ uint32_t wimg[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nw = stride / 4u + 2u;
+    for (uint64_t row = blockIdx.x; row < N; row += gridDim.x) {
+        for (uint32_t t = lane; t < nw; t += 64) wimg[t] = 0;
+        uint32_t n = K;  // edges before the first -1
+        for (uint32_t j0 = 0; j0 < K && n == K; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            const uint64_t endm = __ballot(j < K && rows[row * K + j] == -1);
+            if (endm) n = j0 + (uint32_t)__builtin_ctzll(endm);
+        }
+        __syncthreads();
+        bool bad = false;
+        for (uint32_t j = lane; j <= n && j < K; j += 64) {
+            const int32_t e = j < n ? rows[row * K + j] : 0;
+            bad |= j < n && (e < 0 || (uint64_t)e >= N);
+            const uint64_t v = j == n ? N : (uint64_t)(uint32_t)e;  // value n is the sentinel N (:31-36)
+            const uint32_t pos = j * bits;
+            const uint64_t sh = v << (pos & 31);
+            atomicOr(&wimg[pos >> 5], (uint32_t)sh);
+            if ((pos & 31) + bits > 32) atomicOr(&wimg[(pos >> 5) + 1], (uint32_t)(sh >> 32));
+        }
+        if (__ballot(bad) && lane == 0) atomicOr(err, 1u);
+        __syncthreads();
+        const uint8_t *b = (const uint8_t *)wimg;
+        for (uint32_t t = lane; t < stride; t += 64) out[row * stride + t] = b[t];
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(64) k_compact_rows_decode_wide(const uint8_t *data, uint64_t N, uint32_t K, uint32_t bits,
+                                                                 uint32_t stride, uint64_t m, const uint64_t *nodes,
+                                                                 int32_t *out, uint32_t *counts) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t mask = (1ull << bits) - 1ull;
+    for (uint64_t q = blockIdx.x; q < m; q += gridDim.x) {
+        const uint8_t *base = data + (nodes ? nodes[q] : q) * stride;
+        uint32_t n = K;
+        for (uint32_t j0 = 0; j0 < K; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            uint64_t v = ~0ull;
+            if (j < K) {
+                const uint32_t pos = j * bits;
+                const uintptr_t a = (uintptr_t)(base + (pos >> 3));
+                const uint32_t *w = (const uint32_t *)(a & ~(uintptr_t)3);
+                const uint32_t sh = (uint32_t)(a & 3u) * 8u + (pos & 7u);
+                v = ((((uint64_t)w[1] << 32) | w[0]) >> sh) & mask;
+            }
+            if (n == K) {  // the row ends at the sentinel N (:43-49)
+                const uint64_t endm = __ballot(j < K && v == N);
+                if (endm) n = j0 + (uint32_t)__builtin_ctzll(endm);
+            }
+            if (j < K) out[q * K + j] = j < n ? (int32_t)v : -1;
+        }
+        if (lane == 0) counts[q] = n;
+    }
+}
+
 }  // namespace
 
 struct vidc_compact {
@@ -241,7 +302,7 @@ extern "C" {
 int vidc_compact_rows_encode(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_rows, vidc_compact **out) {
     if (!ctx || !out || (N && !d_rows)) return VIDC_ERR_INVALID;
     *out = nullptr;
-    if (K == 0 || K > 64) { set_error("compact rows: K=%u unsupported (1..64)", K); return VIDC_ERR_UNSUPPORTED; }
+    if (K == 0 || K > 4096) { set_error("compact rows: K=%u unsupported (1..4096)", K); return VIDC_ERR_UNSUPPORTED; }
     VIDC_HIP(hipSetDevice(ctx->device));
     std::unique_ptr<vidc_compact> c(new vidc_compact());
     c->device = ctx->device;
@@ -257,8 +318,12 @@ int vidc_compact_rows_encode(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_
     if (N) {
         VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
         uint32_t grid = (uint32_t)std::min<uint64_t>(N, (uint64_t)ctx->num_cu * 64);
-        hipLaunchKernelGGL(k_compact_rows_encode, dim3(grid), dim3(64), 0, ctx->stream, d_rows, N, K, c->bits, c->stride,
-                           c->d_data.p, s_err.as<uint32_t>());
+        if (K <= 64)
+            hipLaunchKernelGGL(k_compact_rows_encode, dim3(grid), dim3(64), 0, ctx->stream, d_rows, N, K, c->bits, c->stride,
+                               c->d_data.p, s_err.as<uint32_t>());
+        else
+            hipLaunchKernelGGL(k_compact_rows_encode_wide, dim3(grid), dim3(64), (c->stride / 4u + 2u) * 4u, ctx->stream, d_rows,
+                               N, K, c->bits, c->stride, c->d_data.p, s_err.as<uint32_t>());
         VIDC_HIP(hipGetLastError());
         VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     }
@@ -299,8 +364,12 @@ int vidc_compact_rows_decode(vidc_ctx *ctx, const vidc_compact *c, uint64_t m, c
         d_nodes = s_n.as<uint64_t>();
     }
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_compact_rows_decode, dim3((uint32_t)std::min<uint64_t>((m + 3) / 4, (uint64_t)ctx->num_cu * 256)), dim3(64), 0, ctx->stream,
-                       c->d_data.p, c->N, c->K, c->bits, c->stride, m, d_nodes, d_out, s_c.as<uint32_t>());
+    if (c->K <= 64)
+        hipLaunchKernelGGL(k_compact_rows_decode, dim3((uint32_t)std::min<uint64_t>((m + 3) / 4, (uint64_t)ctx->num_cu * 256)), dim3(64), 0, ctx->stream,
+                           c->d_data.p, c->N, c->K, c->bits, c->stride, m, d_nodes, d_out, s_c.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_compact_rows_decode_wide, dim3((uint32_t)std::min<uint64_t>(m, (uint64_t)ctx->num_cu * 256)), dim3(64), 0,
+                           ctx->stream, c->d_data.p, c->N, c->K, c->bits, c->stride, m, d_nodes, d_out, s_c.as<uint32_t>());
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     if (counts) VIDC_HIP(hipMemcpyAsync(h_io.p, s_c.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -12,6 +12,7 @@
 #include "roc_kernels.h"
 #include "roc_u.h"
 #include "roc_u2.h"
+#include "rows_csr.h"
 #include "roc_lane.h"
 #include "scan.h"
 
@@ -1138,6 +1139,19 @@ int vidc_roc_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, cons
 int vidc_roc_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_rows, int precision_mode,
                          uint32_t flags, vidc_roc **out) {
     if (N && !d_rows) return VIDC_ERR_INVALID;
+    if (K > TINY_MAX && ctx && out) {
+        // wide rows (NSG128, NSG256, ...): the rows become CSR lists and take the per-list kernels; the object answers
+        // decode_rows like a graph object (sizes = edge counts, altid_impl.h:61)
+        if (N >= 0xffffffffull) { set_error("too many nodes"); return VIDC_ERR_INVALID; }
+        VIDC_HIP(hipSetDevice(ctx->device));
+        std::vector<uint64_t> offsets;
+        Scratch s_ids;
+        VIDC_TRY(rows_to_csr(ctx, N, K, d_rows, offsets, s_ids));
+        VIDC_TRY(encode_impl(ctx, N, offsets.data(), s_ids.as<uint64_t>(), false, 0, 0, nullptr, precision_mode,
+                             flags & ~VIDC_ROC_WANT_PERM, out));
+        (*out)->K = K;
+        return VIDC_OK;
+    }
     return encode_impl(ctx, 0, nullptr, nullptr, true, N, K, d_rows, precision_mode, flags, out);
 }
 
@@ -1187,14 +1201,33 @@ const uint32_t *vidc_roc_perm_dev(const vidc_roc *r) { return r ? r->d_perm.p : 
 int vidc_roc_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint32_t *precisions,
                     const uint64_t *heads, const uint32_t *nwords, const uint32_t *mt_draws,
                     const uint32_t *words_concat, vidc_roc **out) {
-    if (!ctx || !out || (nlist && (!offsets || !precisions || !heads || !nwords))) return VIDC_ERR_INVALID;
+    if (!ctx || !out) return VIDC_ERR_INVALID;
+    *out = nullptr;
+    if (nlist && (!offsets || !precisions || !heads || !nwords)) {
+        set_error("roc import: offsets, precisions, heads and nwords are required");
+        return VIDC_ERR_INVALID;
+    }
+    if (nlist >= 0xffffffffull) { set_error("too many lists"); return VIDC_ERR_INVALID; }
+    // the image is untrusted (.npz content): geometry and per-list state are checked before anything reaches a kernel
+    uint64_t tw = 0;
+    for (uint64_t l = 0; l < nlist; l++) {
+        if (offsets[l + 1] < offsets[l]) { set_error("roc import: offsets not monotone at list %llu", (unsigned long long)l); return VIDC_ERR_INVALID; }
+        const uint64_t n = offsets[l + 1] - offsets[l];
+        if (mt_draws && mt_draws[l] > VIDC_MT_TABLE) {
+            set_error("roc import: list %llu claims %u mt19937 draws (table holds %d)", (unsigned long long)l, mt_draws[l], VIDC_MT_TABLE);
+            return VIDC_ERR_INVALID;
+        }
+        if (n == 0 && nwords[l] != 0) { set_error("roc import: empty list %llu with %u stream words", (unsigned long long)l, nwords[l]); return VIDC_ERR_INVALID; }
+        tw += nwords[l];
+    }
+    if (tw && !words_concat) { set_error("roc import: %llu stream words announced but words == NULL", (unsigned long long)tw); return VIDC_ERR_INVALID; }
     VIDC_HIP(hipSetDevice(ctx->device));
     std::unique_ptr<vidc_roc> r(new vidc_roc());
     r->device = ctx->device;
     r->nlist = nlist;
-    r->offsets.assign(offsets, offsets + nlist + 1);
-    r->ntotal = nlist ? offsets[nlist] : 0;
-    if (!nlist) r->offsets.assign(1, 0);
+    if (nlist) r->offsets.assign(offsets, offsets + nlist + 1); else r->offsets.assign(1, 0);
+    r->ntotal = nlist ? offsets[nlist] - offsets[0] : 0;
+    if (nlist && offsets[0] != 0) { set_error("roc import: offsets[0] must be 0"); return VIDC_ERR_INVALID; }
     r->prec.assign(precisions, precisions + nlist);
     r->heads.assign(heads, heads + nlist);
     r->nwords.assign(nwords, nwords + nlist);
@@ -1286,8 +1319,28 @@ int vidc_roc_decode_lists(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const ui
 int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *nodes, uint32_t K,
                          int32_t *d_out, uint32_t *counts) {
     if (!ctx || !r || (m && !d_out)) return VIDC_ERR_INVALID;
-    if (K == 0 || K > TINY_MAX) { set_error("K=%u unsupported", K); return VIDC_ERR_UNSUPPORTED; }
+    if (K == 0) { set_error("K=0 unsupported"); return VIDC_ERR_UNSUPPORTED; }
     if (!nodes && m > r->nlist) { set_error("nodes == NULL selects nodes 0..m-1: m=%llu > %llu nodes", (unsigned long long)m, (unsigned long long)r->nlist); return VIDC_ERR_INVALID; }
+    if (K > TINY_MAX) {  // wide rows: lists of any length through the per-list decoders, -1 padded rows
+        VIDC_TRY(r->prec.size() == r->nlist ? ensure_offsets(r) : ensure_meta(r));
+        std::vector<uint32_t> lists(m);
+        for (uint64_t i = 0; i < m; i++) {
+            const uint64_t node = nodes ? nodes[i] : i;
+            if (node >= r->nlist) { set_error("node %llu out of range", (unsigned long long)node); return VIDC_ERR_INVALID; }
+            lists[i] = (uint32_t)node;
+            const uint64_t n = r->offsets[node + 1] - r->offsets[node];
+            if (n > K) { set_error("node %u has %llu edges > K=%u", lists[i], (unsigned long long)n, K); return VIDC_ERR_INVALID; }
+            if (counts) counts[i] = (uint32_t)n;
+        }
+        if (!m) return VIDC_OK;
+        VIDC_HIP(hipSetDevice(ctx->device));
+        VIDC_HIP(hipMemsetAsync(d_out, 0xff, m * (uint64_t)K * 4, ctx->stream));
+        DecPlan p;
+        plan_decode(r, lists, false, p, false);
+        std::vector<uint64_t> out_off(m);
+        for (size_t k = 0; k < m; k++) out_off[k] = (uint64_t)p.item[k] * K;
+        return decode_impl(ctx, r, p, out_off.data(), nullptr, d_out, K);
+    }
     const bool lean = r->rows && K >= r->K && !force_general() && lane_wanted(lane_policy(), m, LANE_MIN_TINY);
     if (lean && !nodes) {  // rows 0..m-1 of a graph object: nothing proportional to m is built on or leaves the host
         DecPlan p;
