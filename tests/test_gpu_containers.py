@@ -427,3 +427,48 @@ def test_wide_graph_rows_take_the_list_kernels(K, oracle):
             got = g._c.export_row(3)
             assert np.array_equal(got[: want.size], want) and not got[want.size:].any()
         assert g.get_neighbors(1).size == K
+
+
+def test_batched_graph_search_identical_with_compressed_graphs():
+    """graph_dynamic_bench_invlists.py:103-146 in miniature: the frontier search of a query batch returns the same ids and
+    distances with every compressed graph swapped in (one get_neighbors launch per round)."""
+    from vector_db_id_compression_amd import altid
+    from vector_db_id_compression_amd.graph_search import RawGraph, knn_graph, search, search_batched
+
+    rng = np.random.default_rng(12)
+    x = rng.normal(size=(4000, 16)).astype(np.float32)
+    xq = rng.normal(size=(12, 16)).astype(np.float32)
+    rows = knn_graph(x, 24, seed=3)
+    Dref, Iref = search_batched(RawGraph(rows), x, xq, 10, L=32)
+    assert (Iref >= 0).all()
+    D1, I1 = search(RawGraph(rows), x, xq[:3], 10, L=32)  # the one-query-at-a-time search visits the same pool
+    np.testing.assert_array_equal(I1, Iref[:3])
+    for name, cls in altid.AVAILABLE_COMPRESSED_GRAPHS.items():
+        if cls is None:
+            continue
+        D, I = search_batched(cls(rows.copy()), x, xq, 10, L=32)
+        np.testing.assert_array_equal(I, Iref, err_msg=name)
+        np.testing.assert_allclose(D, Dref, rtol=1e-6, err_msg=name)
+
+
+@pytest.mark.parametrize("name", ["packed-bits", "elias-fano", "roc", "wavelet-tree", "wavelet-tree-1"])
+def test_id_compression_switch(name):
+    """search_ivf_qinco.py:502-523: every `--id_compression` choice installs its container and leaves the search unchanged."""
+    from vector_db_id_compression_amd import custom_invlists as ci
+    from vector_db_id_compression_amd.ivf import IVFIndex
+
+    xt, xb, xq = _dataset(16, 4000, 4000, 6)
+    index = IVFIndex(16, 16, ("PQ", 4))
+    index.train(xt)
+    index.add(xb)
+    index.nprobe = 4
+    index.parallel_mode = 3
+    Dref, Iref = index.search(xq, 5)
+    assert ci.apply_id_compression(index, "none")[1] == {}
+    il, st = ci.apply_id_compression(index, name)
+    assert index.invlists is il and st["compressed_ids_size_in_bytes"] == il.compressed_ids_size_in_bytes > 0
+    assert st["id_compression_time"] >= 0 and getattr(il, "wt_type", 0) == (1 if name == "wavelet-tree-1" else 0)
+    D, I = index.search_defer_id_decoding(xq, 5)
+    np.testing.assert_array_equal(I, Iref)
+    with pytest.raises(ValueError):
+        ci.apply_id_compression(index, "zstd")

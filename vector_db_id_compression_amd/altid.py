@@ -34,6 +34,10 @@ class _GraphBase:
         out, cnt = self._c.decode_rows(np.asarray(nodes, dtype=np.uint64))
         return out.cpu().numpy(), cnt
 
+    def get_neighbors_device(self, nodes):
+        """The same with the rows left in HBM: int32 [m, K] CUDA tensor, -1 padded (no edge counts cross PCIe)."""
+        return self._c.decode_rows(np.asarray(nodes, dtype=np.uint64), self.K, want_counts=False)[0]
+
 
 class CompactBitNSGGraph(_GraphBase):
     """altid_impl.cpp:20-51: ceil(log2(N+1)) bits per edge, fixed stride, sentinel N."""

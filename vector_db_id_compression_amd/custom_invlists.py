@@ -198,3 +198,32 @@ AVAILABLE_COMPRESSED_IVFS = {  # bench_invlists.py:19-25
 def search_IVF_defer_id_decoding(index, x, k, decode_1by1=False, return_codes=0):
     """custom_invlists.swig:92-122 / custom_invlists_impl.cpp:407-526 on an `ivf.IVFIndex`."""
     return index.search_defer_id_decoding(x, k, decode_1by1=decode_1by1, return_codes=return_codes)
+
+
+ID_COMPRESSION_CHOICES = "none packed-bits elias-fano roc wavelet-tree wavelet-tree-1".split()  # search_ivf_qinco.py:384-388
+
+
+def apply_id_compression(index, id_compression):
+    """The `--id_compression` switch of the reference's large-scale driver (search_ivf_qinco.py:502-523): build the chosen
+    container from `index.invlists`, install it with `replace_invlists(il, False)` and return
+    (il, {"compressed_ids_size_in_bytes": ..., "id_compression_time": ...})."""
+    import time
+
+    if id_compression == "none":
+        return index.invlists, {}
+    t0 = time.time()
+    if id_compression == "packed-bits":
+        il = CompressedIDInvertedListsPackedBits(index.invlists)
+    elif id_compression == "elias-fano":
+        il = CompressedIDInvertedListsEliasFano(index.invlists)
+    elif id_compression == "roc":
+        il = CompressedIDInvertedListsFenwickTree(index.invlists)
+    elif id_compression == "wavelet-tree":
+        il = CompressedIDInvertedListsWaveletTree(index.invlists)
+    elif id_compression == "wavelet-tree-1":
+        il = CompressedIDInvertedListsWaveletTree(index.invlists, 1)
+    else:
+        raise ValueError(f"id_compression must be one of {ID_COMPRESSION_CHOICES}")
+    t1 = time.time()
+    index.replace_invlists(il, False)
+    return il, {"compressed_ids_size_in_bytes": il.compressed_ids_size_in_bytes, "id_compression_time": t1 - t0}

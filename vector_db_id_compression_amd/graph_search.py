@@ -15,6 +15,13 @@ class RawGraph:
         out = self.rows[np.asarray(nodes, dtype=np.int64)]
         return out, (out >= 0).sum(1).astype(np.uint32)
 
+    def get_neighbors_device(self, nodes):
+        import torch
+
+        if getattr(self, "_dev", None) is None:
+            self._dev = torch.from_numpy(self.rows).cuda()
+        return self._dev[torch.as_tensor(np.asarray(nodes, dtype=np.int64), device="cuda")]
+
 
 def knn_graph(x, K, seed=0):
     """Exact kNN graph (brute force on the GPU) with random out-degrees in [K/2, K], -1 padded: an NSG-shaped input."""
@@ -64,3 +71,54 @@ def search(graph, x, xq, k, L=32, entry=0):
         D[q, : len(top)] = [t[0] for t in top]
         I[q, : len(top)] = [t[1] for t in top]
     return D, I
+
+
+def search_batched(graph, x, xq, k, L=64, entry=0, max_rounds=None):
+    """The same best-first search for a whole batch of queries in lock step on the GPU: every round expands the best
+    unexpanded candidate of every query with ONE `get_neighbors_device` call (one decode launch for the whole
+    frontier) -- the shape in which a compressed graph pays off on a GPU.  Pools are ordered by (distance, node id), so
+    the result does not depend on the order in which a container returns the neighbours of a node.
+    -> (D float32 [nq, k], I int64 [nq, k])"""
+    import torch
+
+    xt = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x, dtype=np.float32)).cuda()
+    qt = torch.as_tensor(np.asarray(xq, dtype=np.float32)).cuda()
+    nq, N = qt.shape[0], xt.shape[0]
+    INF = torch.tensor(float("inf"), device="cuda")
+    visited = torch.zeros((nq, N + 1), dtype=torch.bool, device="cuda")  # column N absorbs the -1 padding
+    visited[:, entry] = True
+    pool_d = torch.full((nq, L), float("inf"), device="cuda")
+    pool_n = torch.full((nq, L), -1, dtype=torch.int64, device="cuda")
+    pool_e = torch.ones((nq, L), dtype=torch.bool, device="cuda")  # expanded (empty slots count as expanded)
+    pool_d[:, 0] = ((xt[entry][None, :] - qt) ** 2).sum(1)
+    pool_n[:, 0] = entry
+    pool_e[:, 0] = False
+    rows = torch.arange(nq, device="cuda")
+    rounds = 0
+    while True:
+        cand = torch.where(pool_e, INF, pool_d)
+        best = cand.argmin(1)
+        active = torch.isfinite(cand[rows, best])
+        if not bool(active.any()) or (max_rounds is not None and rounds >= max_rounds):
+            break
+        rounds += 1
+        nodes = torch.where(active, pool_n[rows, best], torch.zeros_like(best))
+        pool_e[rows, best] = True
+        nb = graph.get_neighbors_device(nodes.cpu().numpy()).long()  # [nq, K], -1 padded
+        ok = (nb >= 0) & active[:, None]
+        nbv = torch.where(nb >= 0, nb, torch.full_like(nb, N))
+        nbc = nb.clamp(min=0)
+        ok &= ~visited.gather(1, nbv)
+        # the neighbours of a node are distinct, so a scatter marks exactly the new ones
+        visited.scatter_(1, nbv, visited.gather(1, nbv) | ok)
+        d = ((xt[nbc] - qt[:, None, :]) ** 2).sum(2)
+        d = torch.where(ok, d, INF)
+        all_d = torch.cat([pool_d, d], 1)
+        all_n = torch.cat([pool_n, torch.where(ok, nbc, torch.full_like(nbc, -1))], 1)
+        all_e = torch.cat([pool_e, ~ok], 1)
+        # order by (distance, node): float32 bits of a non-negative distance sort like the value
+        key = (all_d.view(torch.int32).long() << 32) | all_n.clamp(min=0)
+        key = torch.where(torch.isfinite(all_d), key, torch.full_like(key, 0x7FFFFFFFFFFFFFFF))
+        idx = key.argsort(1)[:, :L]
+        pool_d, pool_n, pool_e = all_d.gather(1, idx), all_n.gather(1, idx), all_e.gather(1, idx)
+    return pool_d[:, :k].cpu().numpy(), pool_n[:, :k].cpu().numpy()
