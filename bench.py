@@ -258,8 +258,9 @@ def main():
                 "us_per_step": {"encode": 1e3 * e / 3 / (b - a), "decode": 1e3 * d / 3 / (b - a)}}
 
     def secondary(workload, codec, steps=3, floor=False):
-        """Short, untimed-by-the-driver measurement of another regime / codec (reported under `extra` only)."""
-        w2 = synth.workload(workload, seed=1042 + rank)
+        """Short, untimed-by-the-driver measurement of another regime / codec (reported under `extra` only).
+        `workload`: a name or an already generated workload dict (the 1 B-id set is generated once for the three codecs)."""
+        w2 = synth.workload(workload, seed=1042 + rank) if isinstance(workload, str) else workload
         ids2 = torch.from_numpy(w2["ids"].view(np.int64)).cuda() if isinstance(w2["ids"], np.ndarray) else w2["ids"]
         out2 = torch.empty(w2["ntotal"], dtype=torch.int64, device="cuda")
         cls = {"roc": RocLists, "ef": EfLists, "packed": PackedLists}[codec]
@@ -281,7 +282,7 @@ def main():
         c2 = obj.compressed_bytes / w2["ntotal"]
         kern = (ke + kd) / steps / 1e3
         gbs = (16.0 + 2.0 * c2) * w2["ntotal"] / kern / 1e9
-        ok = bool(torch.equal(torch.sort(out2).values, torch.sort(ids2).values))
+        ok = bool(torch.equal(torch.sort(out2).values, torch.sort(ids2).values)) if codec == "roc" else bool(torch.equal(out2, ids2))
         res2 = {"workload": w2["describe"], "codec": codec, "nlist": w2["nlist"], "max_list": w2["max_list"],
                 "median_list": w2["median_list"], "ids_per_s": w2["ntotal"] * steps / t_wall,
                 "ms_per_step": 1e3 * t_wall / steps, "kernel_ms": {"encode": ke / steps, "decode": kd / steps},
@@ -382,9 +383,13 @@ def main():
                     "graph_rows": secondary_graph(),
                     "c5": secondary("c5", "roc", floor=True),
                 }
-                if not args.no_s2:  # BASELINE north_star's roofline workload: 1 B ids on one GPU
+                if not args.no_s2:  # BASELINE north_star's roofline workload: 1 B ids on one GPU, through the three codecs
                     torch.cuda.empty_cache()
-                    res["extra"]["s2"] = secondary("s2", "roc", steps=2, floor=True)
+                    ws2 = synth.workload("s2", seed=1042 + rank)
+                    res["extra"]["s2"] = secondary(ws2, "roc", steps=2, floor=True)
+                    res["extra"]["s2_elias_fano"] = secondary(ws2, "ef", steps=2)
+                    res["extra"]["s2_packed_bits"] = secondary(ws2, "packed", steps=2)
+                    del ws2
             except Exception as e:
                 res["extra"] = {"error": str(e)}
         if world == 1 and args.codec == "roc":
