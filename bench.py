@@ -392,7 +392,7 @@ def main():
                     del ws2
             except Exception as e:
                 res["extra"] = {"error": str(e)}
-        if world == 1 and args.codec == "roc":
+        if world == 1 and args.codec == "roc" and not args.no_extra:
             try:
                 cf = chain_floor(wl, d_ids)
                 cf["chain_floor_ms"] = cf["encode_ms"] + cf["decode_ms"]

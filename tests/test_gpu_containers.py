@@ -472,3 +472,33 @@ def test_id_compression_switch(name):
     np.testing.assert_array_equal(I, Iref)
     with pytest.raises(ValueError):
         ci.apply_id_compression(index, "zstd")
+
+
+def test_sharded_bench_over_rccl_when_two_gpus_are_visible(tmp_path):
+    """`bench.py --sharded` over the nccl (= RCCL) backend: one index partitioned over 2 ranks, per-rank encode + decode,
+    search-shaped gather on rank 0 (verified inside the bench against the index).  Needs two GPUs; the driver's multi-GPU
+    tier and this test are the only places the RCCL path runs (the gloo test covers the logic on CPU)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--sharded", "--workload", "c5",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["gather_verified"] is True
+    assert sum(d["per_rank"]["ids"]) == 10_000_000 and abs(d["per_rank"]["ids"][0] - d["per_rank"]["ids"][1]) <= 65536

@@ -295,7 +295,7 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "v_readfirstlane_b32 s67, v31\n" \
     "v_mul_lo_u32 v48, v46, v9\n"
 
-#define U2_ENC_BOT(ORDER) \
+#define U2_ENC_BOT(ORDER, LSHR) \
     "v_mbcnt_lo_u32_b32 v49, s66, 0\n" \
     "v_mbcnt_hi_u32_b32 v49, s67, v49\n" \
     "v_cmp_eq_u32 vcc, v49, v12\n"                     /* bit of the word */ \
@@ -311,7 +311,7 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "s_set_gpr_idx_on s43, gpr_idx(DST)\n" \
     "v_mov_b32 v64, v13\n" \
     "s_set_gpr_idx_off\n" U2P(142) \
-    "s_lshr_b32 s68, s58, 31\n"                        /* next index pop must not renormalise (U2_SAFE_HI) */ \
+    LSHR                                               /* next index pop must not renormalise (U2_SAFE_HI): s68 = B_lo >> 31 */ \
     "s_add_u32 s68, s68, s59\n" \
     "s_add_u32 s68, s68, -1\n" \
     "s_cmp_ge_u32 s68, 0x7ff80000\n" \
@@ -324,7 +324,7 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "s_cbranch_scc1 1b\n"
 #define U2_ENC_ORDER \
     "s_mov_b32 m0, s69\n" \
-    "s_nop 0\n" \
+    "s_lshr_b32 s68, s58, 31\n"                        /* (first instruction of the exit test: m0 settles meanwhile) */ \
     "v_writelane_b32 v6, s40, m0\n"
 
 // store order-ring lanes [0, s72) at order[s87 ...]; s87 += s72
@@ -510,11 +510,11 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
               "s62", "s63", "s64", "s68", "s70", "s71", "s72", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s96",       \
               "s97", "s98", "s99")
         if (U::G == 4u) {
-            if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT(U2_ENC_ORDER) U2_ENC_OUTER(U2_ORDER_FLUSH));
-            else U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT("") U2_ENC_OUTER(""));
+            if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT(U2_ENC_ORDER, "") U2_ENC_OUTER(U2_ORDER_FLUSH));
+            else U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT("", "s_lshr_b32 s68, s58, 31\n") U2_ENC_OUTER(""));
         } else {
-            if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT(U2_ENC_ORDER) U2_ENC_OUTER(U2_ORDER_FLUSH));
-            else U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT("") U2_ENC_OUTER(""));
+            if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT(U2_ENC_ORDER, "") U2_ENC_OUTER(U2_ORDER_FLUSH));
+            else U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT("", "s_lshr_b32 s68, s58, 31\n") U2_ENC_OUTER(""));
         }
 #undef U2_ENC_ASM
         // clang-format on
@@ -648,9 +648,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
     "v_readlane_b32 s62, v10, s69\n"                   /* lq of this step */ \
     "v_subrev_u32 v58, s43, v2\n" \
     "v_subrev_u32 v59, s44, v2\n" \
-    "v_ashrrev_i32 v58, 31, v58\n" \
     "v_ashrrev_i32 v59, 31, v59\n" \
-    "v_sub_u32 v4, v4, v58\n"                          /* E1 += 1 in lanes below L1 */ \
     "v_sub_u32 v13, v13, v59\n"                        /* row += 1 in lanes below L2 */ \
     "s_and_b32 m0, s60, 63\n"                          /* index push, first half (codec.cpp:44-63): renormalise H */ \
     "s_cmp_ge_u32 s59, s62\n" \
@@ -662,12 +660,16 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
     "s_mul_hi_u32 s53, s50, s75\n" \
     "s_mul_i32 s68, s51, s75\n" \
     "s_add_u32 s53, s53, s68\n" \
-    "s_mov_b32 m0, s69\n" \
     "s_add_u32 s72, s49, s63\n" \
-    "v_writelane_b32 v6, s40, m0\n"                    /* output ring */ \
     "s_set_gpr_idx_on s43, gpr_idx(DST)\n" \
     "v_mov_b32 v64, v13\n" \
-    "s_set_gpr_idx_off\n"
+    "s_set_gpr_idx_off\n" \
+    "s_mov_b32 m0, s69\n"
+// (the three vector instructions that follow the last readlane of the rank keep the scalar tail off its SGPR write)
+#define U2_DEC_AFTER_RANK \
+    "v_writelane_b32 v6, s40, m0\n"                    /* output ring */ \
+    "v_ashrrev_i32 v58, 31, v58\n" \
+    "v_sub_u32 v4, v4, v58\n"                          /* E1 += 1 in lanes below L1 */
 #define U2_DEC_RANK_G4 \
     "s_waitcnt lgkmcnt(1)\n" \
     "v_bcnt_u32_b32 v32, v30, 0\n" \
@@ -681,7 +683,8 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
     "v_sub_u32 v33, v33, v32\n" \
     "v_add_u32 v37, v36, v33\n"                        /* lane g: bits of the entry below x */ \
     "s_nop 0\n" \
-    "v_readlane_b32 s64, v37, s47\n"
+    "v_readlane_b32 s64, v37, s47\n" \
+    U2_DEC_AFTER_RANK
 #define U2_DEC_RANK_G1 \
     "s_waitcnt lgkmcnt(1)\n" \
     "v_and_b32 v33, s66, v30\n" \
@@ -689,7 +692,8 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
     "v_bcnt_u32_b32 v33, v33, 0\n" \
     "v_bcnt_u32_b32 v37, v34, v33\n" \
     "s_nop 0\n" \
-    "v_readfirstlane_b32 s64, v37\n"
+    "v_readfirstlane_b32 s64, v37\n" \
+    U2_DEC_AFTER_RANK
 #define U2_DEC_BOT \
     "s_sub_u32 s68, s60, s61\n"                        /* ring: two pops and one push must fit the next step */ \
     "s_add_u32 s68, s68, -2\n" \
