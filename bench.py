@@ -187,12 +187,16 @@ def main():
     ntotal = wl["ntotal"]
     out = torch.empty(ntotal, dtype=torch.int64, device="cuda")
 
+    chain_ms = [0.0, 0.0]  # hipEvent time of the launch holding the longest chains (encode, decode), summed over steps
+
     def step():
         if args.codec == "roc":
             r = RocLists.encode(offsets, d_ids, ctx=ctx, want_perm=want_perm)
             t_enc = ctx.phase_ms(0) + ctx.phase_ms(1)
+            chain_ms[0] += ctx.phase_ms(3)
             r.decode_all(out)
             t_dec = ctx.phase_ms(2)
+            chain_ms[1] += ctx.phase_ms(4)
         elif args.codec == "ef":
             r = EfLists.encode(offsets, d_ids, ctx=ctx)
             t_enc = ctx.last_kernel_ms()
@@ -222,6 +226,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    chain_ms[0] = chain_ms[1] = 0.0
     t0 = time.perf_counter()
     k_enc = k_dec = 0.0
     for _ in range(args.steps):
@@ -236,6 +241,31 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    dominant = None
+    if args.codec == "roc" and chain_ms[0] > 0:
+        # The dominant kernel by the contract's definition: ONE launch (k_roc_encode_u2<UB, perm>) holding the lists longer than
+        # 4096 ids.  Algorithmic bytes of that launch = ids it read (8 B each) + streams and permutation it wrote.
+        try:
+            ci, cd = ctx.chain_info(0), ctx.chain_info(1)
+            info = r.info()
+            sizes = (offsets[1:] - offsets[:-1]).astype(np.int64)
+            in_launch = (sizes > 4096) & (info["precision"] <= ci["universe_bits"]) & (info["precision"] > (18 if ci["universe_bits"] == 20 else 0))
+            stream_bytes = float((8 + 4 * info["nwords"][in_launch].astype(np.int64)).sum())
+            n_ids = float(sizes[in_launch].sum())
+            enc_bytes = 8.0 * n_ids + stream_bytes + (4.0 * n_ids if want_perm else 0.0)
+            dec_bytes = stream_bytes + 8.0 * n_ids
+            e_ms, d_ms = chain_ms[0] / args.steps, chain_ms[1] / args.steps
+            dominant = {
+                "name": f"k_roc_encode_u2<{ci['universe_bits']}, {'true' if want_perm else 'false'}>", "launch_ms": e_ms,
+                "lists": ci["lists"], "ids": ci["ids"], "longest_list": ci["longest"], "ids_recount": n_ids,
+                "algorithmic_bytes_per_launch": enc_bytes, "achieved_GBs": enc_bytes / e_ms / 1e6, "frac": enc_bytes / e_ms / 1e6 / HBM_PEAK_GBS,
+                "second": {"name": f"k_roc_decode_u2<{cd['universe_bits']}>", "launch_ms": d_ms, "ids": cd["ids"],
+                           "algorithmic_bytes_per_launch": dec_bytes, "achieved_GBs": dec_bytes / d_ms / 1e6 if d_ms else None,
+                           "frac": dec_bytes / d_ms / 1e6 / HBM_PEAK_GBS if d_ms else None},
+                "note": "one wavefront per list: the launch lasts as long as its longest list's chain of dependent codec steps"}
+        except Exception as e:
+            dominant = {"error": str(e)}
 
     def chain_floor(w2, ids2):
         """The longest list of the workload encoded + decoded ALONE: its serial chain (one dependent codec step per id)
@@ -372,6 +402,8 @@ def main():
                          "kernels": "k_roc_encode_* + k_roc_compact + k_roc_decode_*" if args.codec == "roc" else args.codec,
                          "algorithmic_bytes_per_id": 16.0 + 2.0 * c},
         }
+        if dominant is not None:
+            res["roofline"]["dominant_kernel"] = dominant
         if world == 1 and not args.no_extra and args.codec == "roc" and args.workload == "s1":
             # other regimes of the same kernels, for context only (never part of `value`): many equal lists
             # (no long serial chain) and the two bandwidth-bound codecs of the same plugin surface

@@ -236,8 +236,13 @@ double vidc_ctx_last_kernel_ms(const vidc_ctx *ctx);
 #define VIDC_PHASE_ROC_ENCODE 0  /* k_roc_encode_tiny + k_roc_encode_gen launches */
 #define VIDC_PHASE_ROC_COMPACT 1 /* k_roc_compact */
 #define VIDC_PHASE_ROC_DECODE 2  /* k_roc_decode_gen + k_roc_decode_tiny launches */
+#define VIDC_PHASE_ROC_ENCODE_CHAIN 3 /* the ONE launch holding the call's longest chains (k_roc_encode_u2<20/18>): its duration */
+#define VIDC_PHASE_ROC_DECODE_CHAIN 4 /* k_roc_decode_u2<20/18>, same */
 #define VIDC_PHASE_COUNT 8
 double vidc_ctx_phase_ms(const vidc_ctx *ctx, int phase);
+/* What the chain launch of the last ROC encode (which = 0) / decode (1) on this context processed: ids, lists, longest list and
+ * the universe (18 or 20 bits; 0 when the call had no such class).  bench.py derives the dominant kernel's roofline from it. */
+int vidc_ctx_chain_info(const vidc_ctx *ctx, int which, uint64_t *ids, uint64_t *lists, uint64_t *longest, uint32_t *universe_bits);
 
 #ifdef __cplusplus
 }

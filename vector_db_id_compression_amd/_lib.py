@@ -51,6 +51,7 @@ def _declare(lib):
     f("vidc_copy_d2h", C.c_int, _vp, _vp, _vp, C.c_size_t)
     f("vidc_ctx_last_kernel_ms", C.c_double, _vp)
     f("vidc_ctx_phase_ms", C.c_double, _vp, C.c_int)
+    f("vidc_ctx_chain_info", C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp)
     # ROC
     f("vidc_roc_encode", C.c_int, _vp, _u64, _vp, _vp, C.c_int, _u32, _P(_vp))
     f("vidc_roc_encode_rows", C.c_int, _vp, _u64, _u32, _vp, C.c_int, _u32, _P(_vp))
@@ -119,7 +120,7 @@ def _declare(lib):
 EXPORTED_SYMBOLS = [
     "vidc_last_error", "vidc_version", "vidc_ctx_create", "vidc_ctx_destroy", "vidc_ctx_set_stream", "vidc_ctx_reset_stream",
     "vidc_ctx_synchronize", "vidc_ctx_trim", "vidc_dev_alloc", "vidc_dev_free", "vidc_copy_h2d", "vidc_copy_d2h",
-    "vidc_ctx_last_kernel_ms", "vidc_ctx_phase_ms",
+    "vidc_ctx_last_kernel_ms", "vidc_ctx_phase_ms", "vidc_ctx_chain_info",
     "vidc_roc_encode", "vidc_roc_encode_rows", "vidc_roc_destroy", "vidc_roc_nlist", "vidc_roc_ntotal",
     "vidc_roc_compressed_bytes", "vidc_roc_total_words", "vidc_roc_list_info", "vidc_roc_export_words", "vidc_roc_export_all_words",
     "vidc_roc_perm", "vidc_roc_perm_dev", "vidc_roc_import", "vidc_roc_decode_all", "vidc_roc_decode_lists",
@@ -203,6 +204,12 @@ class Context:
     def phase_ms(self, phase):
         """hipEvent time of one kernel phase of the latest call (VIDC_PHASE_* in include/vidc.h)."""
         return float(lib().vidc_ctx_phase_ms(self.h, phase))
+
+    def chain_info(self, which):
+        """What the chain launch (the kernel holding the longest lists) of the last ROC encode (0) / decode (1) processed."""
+        ids, lists, longest, ub = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32()
+        lib().vidc_ctx_chain_info(self.h, which, C.byref(ids), C.byref(lists), C.byref(longest), C.byref(ub))
+        return dict(ids=ids.value, lists=lists.value, longest=longest.value, universe_bits=ub.value)
 
 
 _default_ctx = {}

@@ -159,6 +159,7 @@ struct vidc_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_chain[2] = {nullptr, nullptr};  // around the launch of the longest-chain kernel class of a ROC call
     hipEvent_t tev[24] = {};   // event pairs of PhaseTimer (kernel phases timed without a host synchronisation each)
     // kernel classes of one call run concurrently: long chains on `stream`, shorter classes on these
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
@@ -169,6 +170,8 @@ struct vidc_ctx {
     int num_cu = 256;
     double last_kernel_ms = 0.0;
     double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see VIDC_PHASE_* in vidc.h
+    // what the chain launch of the last ROC encode [0] / decode [1] held: ids, lists, longest list, universe bits (0 = none)
+    uint64_t chain_info[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 };
 
 // Kernel time of a call made of several phases: every phase is bracketed by an event pair on the context's stream

@@ -149,6 +149,7 @@ int vidc_ctx_create(int device, vidc_ctx **out) {
         hipStreamCreateWithFlags(&c->aux[1], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->aux[2], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreate(&c->ev_chain[0]) != hipSuccess || hipEventCreate(&c->ev_chain[1]) != hipSuccess ||
         [&] { for (auto &ev : c->tev) if (hipEventCreate(&ev) != hipSuccess) return true; return false; }() ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join[0], hipEventDisableTiming) != hipSuccess ||
@@ -206,6 +207,7 @@ void vidc_ctx_destroy(vidc_ctx *c) {
     if (c->d_u2tab) (void)hipFree(c->d_u2tab);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto &ev : c->ev_chain) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->tev) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (int i = 0; i < 3; i++) {
@@ -289,6 +291,15 @@ int vidc_copy_d2h(vidc_ctx *c, void *h, const void *d, size_t bytes) {
 }
 
 double vidc_ctx_last_kernel_ms(const vidc_ctx *c) { return c ? c->last_kernel_ms : 0.0; }
+int vidc_ctx_chain_info(const vidc_ctx *c, int which, uint64_t *ids, uint64_t *lists, uint64_t *longest, uint32_t *universe_bits) {
+    if (!c || which < 0 || which > 1) return VIDC_ERR_INVALID;
+    if (ids) *ids = c->chain_info[which][0];
+    if (lists) *lists = c->chain_info[which][1];
+    if (longest) *longest = c->chain_info[which][2];
+    if (universe_bits) *universe_bits = (uint32_t)c->chain_info[which][3];
+    return VIDC_OK;
+}
+
 double vidc_ctx_phase_ms(const vidc_ctx *c, int phase) {
     return (c && phase >= 0 && phase < VIDC_PHASE_COUNT) ? c->phase_ms[phase] : 0.0;
 }

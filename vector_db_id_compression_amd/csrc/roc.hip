@@ -591,7 +591,17 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
         for (int i = 0; i < 3; i++) VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
         // main stream: bitmap-20 lists and the deepest general class (the critical paths)
+        ctx->chain_info[0][0] = ctx->chain_info[0][1] = ctx->chain_info[0][2] = ctx->chain_info[0][3] = 0;
+        ctx->phase_ms[VIDC_PHASE_ROC_ENCODE_CHAIN] = 0;
+        auto note_chain = [&](const std::vector<uint32_t> &w, uint32_t ub) {
+            uint64_t tot = 0;
+            for (uint32_t l : w) tot += r->offsets[l + 1] - r->offsets[l];
+            ctx->chain_info[0][0] = tot; ctx->chain_info[0][1] = w.size();
+            ctx->chain_info[0][2] = r->offsets[w[0] + 1] - r->offsets[w[0]]; ctx->chain_info[0][3] = ub;
+        };
         if (!wl_u20.empty()) {
+            note_chain(wl_u20, 20);
+            VIDC_HIP(hipEventRecord(ctx->ev_chain[0], ctx->stream));
             RocEncArgs b = a;
             b.worklist = d_wl + base[2]; b.nwork = (uint32_t)wl_u20.size();
             const U2Div *dt = (const U2Div *)ctx->d_u2tab;
@@ -607,6 +617,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 else hipLaunchKernelGGL((k_roc_encode_u2<20, false>), dim3(b.nwork), dim3(64), U2Geom<20>::LDS_BYTES, ctx->stream, b, dt);
             }
             VIDC_HIP(hipGetLastError());
+            VIDC_HIP(hipEventRecord(ctx->ev_chain[1], ctx->stream));
         }
         // the deepest class: prefix rows sized for its longest list (first of the work list).  With the fixed
         // 48 KiB layout a CU held 3 of these chains; lists up to 65 536 ids need 12 KiB (S2 encode 152 -> see DESIGN)
@@ -628,6 +639,8 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         // aux 0: mid-size general lists (calls without lane classes) and bitmap-18 lists
         if (!lanes_present) VIDC_TRY(launch_gen_on(ctx->aux[0], d_wl + base[4], (uint32_t)wl_c2.size(), 8));
         if (!wl_u18.empty()) {
+            const bool is_chain = wl_u20.empty();
+            if (is_chain) { note_chain(wl_u18, 18); VIDC_HIP(hipEventRecord(ctx->ev_chain[0], ctx->aux[0])); }
             RocEncArgs b = a;
             b.worklist = d_wl + base[1]; b.nwork = (uint32_t)wl_u18.size();
             const U2Div *dt = (const U2Div *)ctx->d_u2tab;
@@ -637,6 +650,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             } else if (want_perm) hipLaunchKernelGGL((k_roc_encode_u2<18, true>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, ctx->aux[0], b, dt);
             else hipLaunchKernelGGL((k_roc_encode_u2<18, false>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, ctx->aux[0], b, dt);
             VIDC_HIP(hipGetLastError());
+            if (is_chain) VIDC_HIP(hipEventRecord(ctx->ev_chain[1], ctx->aux[0]));
         }
         // aux 1: the lane-per-list kernels, then the general classes; aux 2: tiny lists
         if (!lanes_present) VIDC_TRY(launch_gen_on(ctx->aux[1], d_wl + base[3], (uint32_t)wl_c1.size(), 1));
@@ -694,6 +708,10 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         // object now (7 ms per million lists that decode_all would otherwise spend on its critical path)
         if (!rows && nlist >= PLAN_AHEAD_MIN_LISTS && r->prec.size() == nlist) r->plan_ahead = plan_ahead_build(r.get());
         kernel_ms += t.stop();
+        if (ctx->chain_info[0][3]) {  // (t.stop() synchronised the main stream, which joined the auxiliary ones)
+            float cms = 0;
+            if (hipEventElapsedTime(&cms, ctx->ev_chain[0], ctx->ev_chain[1]) == hipSuccess) ctx->phase_ms[VIDC_PHASE_ROC_ENCODE_CHAIN] = cms;
+        }
     }
 
     tr.mark("encode kernels (sync)");
@@ -1006,9 +1024,17 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
             load[best] += est[c] + 1.0;
         }
     }
+    ctx->chain_info[1][0] = ctx->chain_info[1][1] = ctx->chain_info[1][2] = ctx->chain_info[1][3] = 0;
+    ctx->phase_ms[VIDC_PHASE_ROC_DECODE_CHAIN] = 0;
+    const int chain_class = p.count[DC_U20] ? DC_U20 : (p.count[DC_U18] ? DC_U18 : -1);
     auto launch = [&](int c) -> int {
         if (!p.count[c]) return VIDC_OK;
         hipStream_t st_ = stream_of[c];
+        if (c == chain_class) {
+            ctx->chain_info[1][0] = p.sum_n[c]; ctx->chain_info[1][1] = p.count[c]; ctx->chain_info[1][2] = p.max_n[c];
+            ctx->chain_info[1][3] = c == DC_U20 ? 20 : 18;
+            VIDC_HIP(hipEventRecord(ctx->ev_chain[0], st_));
+        }
         RocDecArgs b = a;
         b.worklist = d_wl ? d_wl + base[c] : nullptr;
         b.nwork = (uint32_t)p.count[c];
@@ -1070,6 +1096,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                                        b, 1u << VIDC_DEC_MAX_FB, VIDC_DEC_CAP_BIG);
         }
         VIDC_HIP(hipGetLastError());
+        if (c == chain_class) VIDC_HIP(hipEventRecord(ctx->ev_chain[1], st_));
         return VIDC_OK;
     };
     for (int k = 0; k < DC_COUNT; k++) VIDC_TRY(launch(order[k]));  // longest first
@@ -1079,6 +1106,10 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     }
     ctx->last_kernel_ms = t.stop();
     ctx->phase_ms[VIDC_PHASE_ROC_DECODE] = ctx->last_kernel_ms;
+    if (chain_class >= 0) {
+        float cms = 0;
+        if (hipEventElapsedTime(&cms, ctx->ev_chain[0], ctx->ev_chain[1]) == hipSuccess) ctx->phase_ms[VIDC_PHASE_ROC_DECODE_CHAIN] = cms;
+    }
     tr.mark("decode kernels (sync)");
 
     // 16-byte summary instead of copying two nlist-sized arrays back
