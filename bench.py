@@ -356,7 +356,10 @@ def main():
 
     comp_bytes = r.compressed_bytes
     c = comp_bytes / ntotal  # compressed bytes per id
-    alg_bytes = (16.0 + 2.0 * c) * ntotal  # enc 8 B read + c written, dec c read + 8 B written
+    # enc 8 B read + c written, dec c read + 8 B written; the container path also writes the 4-byte
+    # position of every sampled id (custom_invlists_impl.cpp:188-193)
+    alg_per_id = 16.0 + 2.0 * c + (4.0 if (want_perm and args.codec == "roc") else 0.0)
+    alg_bytes = alg_per_id * ntotal
     kern_s = (k_enc + k_dec) / args.steps / 1e3
     achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
 
@@ -398,9 +401,10 @@ def main():
             "kernel_ms": {"encode": k_enc / args.steps, "decode": k_dec / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                          "algorithmic_bytes_per_step": alg_bytes,
                          "kernels": "k_roc_encode_* + k_roc_compact + k_roc_decode_*" if args.codec == "roc" else args.codec,
-                         "algorithmic_bytes_per_id": 16.0 + 2.0 * c},
+                         "algorithmic_bytes_per_id": alg_per_id},
         }
         if dominant is not None:
             res["roofline"]["dominant_kernel"] = dominant

@@ -128,6 +128,56 @@ def test_domain_errors(roc):
         roc.encode(np.array([0, 200], dtype=np.uint64), np.arange(200, dtype=np.uint64) + (1 << 40))
 
 
+def test_light_prepass_assumptions_are_checked_by_the_kernels(roc, oracle, monkeypatch):
+    """A call without lane-per-list classes classifies each list by its LAST id only; everything that id does not
+    prove is verified by the encode kernels (tools/fuzz_families.py seed 3 found the second case)."""
+    from vector_db_id_compression_amd import VidcError
+
+    monkeypatch.setenv("VIDC_NO_LANE", "1")
+    rng = np.random.default_rng(77)
+    # (a) unsorted long lists whose last id is small: the bitmap class chosen from it cannot hold the list
+    lists = []
+    for nbits, n in ((19, 4253), (20, 5000), (24, 4500), (17, 4100)):
+        li = rng.choice(1 << nbits, size=n, replace=False).astype(np.uint64)
+        li[-1] = li.min()  # classification sees a tiny maximum
+        lists.append(li)
+    lists.append(np.sort(rng.choice(1 << 19, size=6000, replace=False)).astype(np.uint64))
+    off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
+    ids = np.concatenate(lists)
+    for mode in (-1, 19, 24):
+        for want_perm in (False, True):
+            monkeypatch.delenv("VIDC_FULL_PREPASS", raising=False)
+            r = roc.encode(off, ids, precision_mode=mode, want_perm=want_perm)
+            monkeypatch.setenv("VIDC_FULL_PREPASS", "1")
+            r2 = roc.encode(off, ids, precision_mode=mode, want_perm=want_perm)
+            i1, i2 = r.info(), r2.info()
+            for k in ("heads", "nwords", "precision", "mt_draws"):
+                assert np.array_equal(i1[k], i2[k]), (mode, want_perm, k)
+            assert np.array_equal(r.all_words(), r2.all_words())
+            dec = r.decode_all().cpu().numpy().view(np.uint64)
+            assert np.array_equal(dec, r2.decode_all().cpu().numpy().view(np.uint64))
+            if want_perm:
+                assert np.array_equal(r.perm(), r2.perm())
+            if mode == -1:
+                _check_against_oracle(oracle, r, off, lists, r.perm() if want_perm else None, dec)
+    monkeypatch.delenv("VIDC_FULL_PREPASS", raising=False)
+    # (b) an id outside [0, 2^31) in the middle of a long ascending list (the last id is fine)
+    li = np.sort(rng.choice(1 << 20, size=5000, replace=False)).astype(np.uint64)
+    for badv in (1 << 31, (1 << 40) + 5):
+        bad = li.copy()
+        bad[1234] = badv
+        with pytest.raises(VidcError):
+            roc.encode(np.array([0, bad.size], dtype=np.uint64), bad)
+    # (c) duplicates in a bitmap-class list, with and without the permutation
+    dup = li.copy()
+    dup[2000] = dup[1999]
+    offd = np.array([0, dup.size], dtype=np.uint64)
+    for want_perm in (False, True):
+        r = roc.encode(offd, dup, want_perm=want_perm)
+        dec = r.decode_all().cpu().numpy().view(np.uint64)
+        _check_against_oracle(oracle, r, offd, [dup], r.perm() if want_perm else None, dec)
+
+
 def test_exact_precision_mode_is_lossless_for_pow2_max(roc):
     """VIDC_PREC_EXACT fixes the reference's pow-2 precision quirk (Q3); reference mode reproduces it."""
     ids = np.array([3, 1024, 7, 100], dtype=np.uint64)

@@ -93,6 +93,13 @@ inline bool lane_wanted(LanePolicy p, uint64_t nlists, uint64_t min_lists) {
 }
 
 // test hook: VIDC_OLD_U=1 keeps the round-1 bitmap kernels (roc_u.h) instead of the hand-scheduled ones (roc_u2.h)
+// Lists per wavefront of a lane-per-list launch (VIDC_LPW=8|16|32, measurements only; default 64).  Every list of a
+// launch is in flight at once either way, so fewer lists per wavefront only adds wavefronts: measured no better on
+// 65 536 x 256 ids (decode 0.99 / 1.01 / 1.04 / 1.16 ms for 64 / 32 / 16 / 8), worse for the 16 / 64-word strips.
+inline uint32_t lane_lists_per_wave(const vidc_ctx *, uint32_t, uint32_t) {
+    static const int forced = [] { const char *e = std::getenv("VIDC_LPW"); return e ? std::atoi(e) : 0; }();
+    return (forced == 8 || forced == 16 || forced == 32) ? (uint32_t)forced : 64u;
+}
 inline bool old_u_kernels() {
     const char *e = getenv("VIDC_OLD_U");
     return e && e[0] == '1';
@@ -372,6 +379,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     if (want_perm) VIDC_TRY(r->d_perm.alloc(ntotal_in ? ntotal_in : 1, ctx->dpool));
     tr.mark("persistent allocs");
     Scratch s_arena, s_status, s_sizes, s_sid, s_wl, s_maxid, s_flags, s_sum;
+    bool light_prepass = false;
     Pinned h_wl, h_pre;
     const uint32_t arena_stride = rows ? (uint32_t)arena_words_for(K) : 0u;
     uint64_t arena_words = 0, nonempty = 0, ntiny = 0;
@@ -412,38 +420,6 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             VIDC_HIP(hipStreamSynchronize(ctx->stream));
         }
         tr.mark("offsets");
-        // classification prepass (one workgroup per list): max id -> precision, sortedness, domain
-        const uint32_t *maxid = nullptr, *pflags = nullptr;
-        if (any_big) {
-            VIDC_TRY(s_maxid.get(ctx, nlist * 4));
-            VIDC_TRY(s_flags.get(ctx, nlist * 4));
-            VIDC_TRY(h_pre.get(ctx, nlist * 8));
-            EventTimer t(ctx);
-            hipLaunchKernelGGL(k_roc_prepass, dim3((uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 32)),
-                               dim3(256), 0, ctx->stream, d_ids, r->d_offsets.p, (uint32_t)nlist, precision_mode,
-                               s_maxid.as<uint32_t>(), s_flags.as<uint32_t>(), r->d_prec.p);
-            VIDC_HIP(hipGetLastError());
-            kernel_ms += t.stop();
-            VIDC_HIP(hipMemcpyAsync(h_pre.p, s_maxid.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
-            VIDC_HIP(hipMemcpyAsync(h_pre.as<uint32_t>() + nlist, s_flags.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
-            VIDC_HIP(hipStreamSynchronize(ctx->stream));
-            maxid = h_pre.as<uint32_t>();
-            pflags = maxid + nlist;
-            tr.mark("prepass kernel + d2h");
-            // what the decode planner needs later (kernel class, bucket geometry) is known right here
-            r->prec.resize(nlist);
-            par_ranges(nlist, par_parts(nlist), [&](uint64_t la, uint64_t lb, unsigned) {
-                for (uint64_t l = la; l < lb; l++) {
-                    const uint32_t m = maxid[l];
-                    r->prec[l] = offsets[l + 1] == offsets[l] ? 0u
-                                 : precision_mode >= 0    ? (uint32_t)precision_mode
-                                 : precision_mode == VIDC_PREC_EXACT ? (m ? 32u - (uint32_t)__builtin_clz(m) : 0u)
-                                                                     : (m > 1u ? 32u - (uint32_t)__builtin_clz(m - 1u) : 0u);
-                }
-            });
-        } else {
-            r->prec.assign(nlist, 0);  // tiny lists only: the planner does not look at their precision
-        }
         // The bitmap kernels own a whole CU's LDS (2^20-bit universe): latency-optimal for long lists, but only
         // num_cu lists in flight.  With many lists, short ones go to the high-occupancy kernels.
         const uint64_t u_min = U_MIN_LIST;
@@ -467,6 +443,49 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             use_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
             use_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
             use_lane_tiny = lane_wanted(lpol, n_tiny, LANE_MIN_TINY);
+        }
+        // classification prepass (one workgroup per list): max id -> precision, sortedness, domain
+        const uint32_t *maxid = nullptr, *pflags = nullptr;
+        if (any_big) {
+            VIDC_TRY(s_maxid.get(ctx, nlist * 4));
+            VIDC_TRY(s_flags.get(ctx, nlist * 4));
+            VIDC_TRY(h_pre.get(ctx, nlist * 8));
+            EventTimer t(ctx);
+            // Without lane-per-list classes in the call every kernel that takes a list streams it anyway and checks
+            // what the full prepass would (ids inside [0, 2^31), ascending order where it matters, ids that fit the
+            // precision): the prepass then only looks at the LAST id of each list -- the maximum of an ascending
+            // list -- instead of re-reading all of them (8 bytes per id).  A list that turns out not to be ascending
+            // comes back with VIDC_ST_PENDING_SORT and takes the sorting second pass like a multiset does.
+            light_prepass = !use_lane && !use_lane64 && !old_u_kernels() && !std::getenv("VIDC_FULL_PREPASS");
+            if (light_prepass)
+                hipLaunchKernelGGL(k_roc_prepass_last, dim3((uint32_t)((nlist + 255) / 256)), dim3(256), 0, ctx->stream, d_ids,
+                                   r->d_offsets.p, (uint32_t)nlist, precision_mode, s_maxid.as<uint32_t>(),
+                                   s_flags.as<uint32_t>(), r->d_prec.p);
+            else
+                hipLaunchKernelGGL(k_roc_prepass, dim3((uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 32)),
+                                   dim3(256), 0, ctx->stream, d_ids, r->d_offsets.p, (uint32_t)nlist, precision_mode,
+                                   s_maxid.as<uint32_t>(), s_flags.as<uint32_t>(), r->d_prec.p);
+            VIDC_HIP(hipGetLastError());
+            kernel_ms += t.stop();
+            VIDC_HIP(hipMemcpyAsync(h_pre.p, s_maxid.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+            VIDC_HIP(hipMemcpyAsync(h_pre.as<uint32_t>() + nlist, s_flags.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+            VIDC_HIP(hipStreamSynchronize(ctx->stream));
+            maxid = h_pre.as<uint32_t>();
+            pflags = maxid + nlist;
+            tr.mark("prepass kernel + d2h");
+            // what the decode planner needs later (kernel class, bucket geometry) is known right here
+            r->prec.resize(nlist);
+            par_ranges(nlist, par_parts(nlist), [&](uint64_t la, uint64_t lb, unsigned) {
+                for (uint64_t l = la; l < lb; l++) {
+                    const uint32_t m = maxid[l];
+                    r->prec[l] = offsets[l + 1] == offsets[l] ? 0u
+                                 : precision_mode >= 0    ? (uint32_t)precision_mode
+                                 : precision_mode == VIDC_PREC_EXACT ? (m ? 32u - (uint32_t)__builtin_clz(m) : 0u)
+                                                                     : (m > 1u ? 32u - (uint32_t)__builtin_clz(m - 1u) : 0u);
+                }
+            });
+        } else {
+            r->prec.assign(nlist, 0);  // tiny lists only: the planner does not look at their precision
         }
         {
             // per-thread work lists (contiguous list ranges), concatenated in range order: the same lists in the
@@ -533,7 +552,6 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             }
         }
         tr.mark("sort work lists");
-        if (!wl_c1.empty() || !wl_c2.empty() || !wl_c3.empty()) VIDC_TRY(s_sid.get(ctx, ntotal_in * 4));
     }
     VIDC_TRY(s_arena.get(ctx, arena_words * 4));
     VIDC_TRY(s_status.get(ctx, nlist * 4));
@@ -659,7 +677,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             if (w.empty()) continue;
             RocEncArgs b = a;
             b.worklist = d_wl + base[6 + cls]; b.nwork = (uint32_t)w.size();
-            const dim3 grid((b.nwork + 63u) / 64u);
+            // wavefronts a CU holds by LDS: 4-word strips 10.3 KiB, 16-word 14.5 KiB (the 32 / 64-word ones 5 / 3)
+            b.lpw = lane_lists_per_wave(ctx, b.nwork, cls == 0 ? 15 : cls == 1 ? 11 : 4);
+            const dim3 grid((b.nwork + b.lpw - 1u) / b.lpw);
             const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
             if (cls == 2) {
                 // lists are sorted longest first: the leading wavefronts need the 64-word strips (46.5 KiB of LDS,
@@ -667,11 +687,11 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 // ones (27.5 KiB, 5 per CU)
                 uint32_t n_big = 0;
                 while (n_big < b.nwork && r->offsets[w[n_big] + 1] - r->offsets[w[n_big]] > 2048) n_big++;
-                n_big = std::min<uint32_t>(b.nwork, (n_big + 63u) & ~63u);
+                n_big = std::min<uint32_t>(b.nwork, (n_big + b.lpw - 1u) / b.lpw * b.lpw);
                 RocEncArgs b2 = b;
                 b2.worklist = b.worklist + n_big; b2.nwork = b.nwork - n_big;
                 b.nwork = n_big;
-                const dim3 g1((b.nwork + 63u) / 64u), g2((b2.nwork + 63u) / 64u);
+                const dim3 g1((b.nwork + b.lpw - 1u) / b.lpw), g2((b2.nwork + b.lpw - 1u) / b.lpw);
                 if (b.nwork && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<64, true>), g1, dim3(64), 0, ctx->aux[1], b, dt);
                 else if (b.nwork) hipLaunchKernelGGL((k_roc_encode_lane<64, false>), g1, dim3(64), 0, ctx->aux[1], b, dt);
                 if (b2.nwork && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<32, true>), g2, dim3(64), 0, ctx->aux[1], b2, dt);
@@ -764,6 +784,14 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             VIDC_TRY(launch_gen(s_pend.as<uint32_t>(), (uint32_t)pend.size(), rl_max));
             kernel_ms += t2.stop();
             VIDC_HIP(hipStreamSynchronize(ctx->stream));  // scratch of this scope is released below
+            if (light_prepass) {
+                // the precision of these lists came from their last id, which was not their maximum if they were not
+                // ascending: the general kernel stored the real one
+                std::vector<uint32_t> dp;
+                VIDC_TRY(download(ctx, dp, r->d_prec.p, nlist));
+                for (uint32_t l : pend) r->prec[l] = dp[l];
+                r->plan_ahead.reset();
+            }
         }
     }
     // bitmap-kernel lists wrote sampled ids into the perm buffer: turn them into input positions
@@ -891,8 +919,9 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             uint32_t l = p.wl[k];
             uint64_t n = r->offsets[l + 1] - r->offsets[l];
             p.scratch_off[k] = so;
-            // re-spill scratch of the decoder stack (== roc_dec_stack_cap in the kernels)
-            so += roc_dec_stack_cap((uint32_t)n, r->meta_host ? r->nwords[l] : 0u);
+            // re-spill scratch of the decoder stack (== roc_dec_stack_cap in the kernels); the lane-per-list decoders
+            // keep what they push in LDS
+            if (c != DC_LANE && c != DC_LANE64) so += roc_dec_stack_cap((uint32_t)n, r->meta_host ? r->nwords[l] : 0u);
             p.slots_off[k] = sl;
             if (c == DC_LANE) {
                 sl = (sl + 3) & ~(uint64_t)3;  // rows are read as uint4
@@ -903,7 +932,8 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
                 p.slots_off[k] = sl;
                 sl += 256ull * roc_lane_cap_nb<256>((uint32_t)n);
             } else if (c == DC_U18 || c == DC_U20) sl += n;  // duplicate side list
-            else if (c >= DC_GSMALL) {
+            else if (c == DC_GSMALL) sl += n;  // overflow list only: the member rows are in LDS
+            else if (c > DC_GSMALL) {
                 uint32_t fb = roc_dec_fine_bits((uint32_t)n, r->prec[l] > 32 ? 32 : r->prec[l]);
                 sl += ((uint64_t)1 << fb) * roc_dec_cap((uint32_t)n) + n;
             }
@@ -1066,15 +1096,18 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                                        (const U2Div *)ctx->d_u2tab);
                 }
                 break;
-            case DC_GSMALL:
-                hipLaunchKernelGGL(k_roc_decode_gen<uint16_t>, dim3(b.nwork), dim3(64), 512 * 2, st_, b, 512u, VIDC_DEC_CAP);
+            case DC_GSMALL:  // member rows in LDS: 1 + 32 KiB
+                hipLaunchKernelGGL((k_roc_decode_gen<uint16_t, true>), dim3(b.nwork), dim3(64), 512 * 2 + 512 * VIDC_DEC_CAP * 4, st_,
+                                   b, 512u, VIDC_DEC_CAP);
                 break;
-            case DC_LANE:
-                hipLaunchKernelGGL(k_roc_decode_lane<64>, dim3((b.nwork + 63u) / 64u), dim3(64), 0, st_, b,
+            case DC_LANE:  // 6.5 KiB of LDS per wavefront
+                b.lpw = lane_lists_per_wave(ctx, b.nwork, 24);
+                hipLaunchKernelGGL(k_roc_decode_lane<64>, dim3((b.nwork + b.lpw - 1u) / b.lpw), dim3(64), 0, st_, b,
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
-            case DC_LANE64:
-                hipLaunchKernelGGL(k_roc_decode_lane<256>, dim3((b.nwork + 63u) / 64u), dim3(64), 0, st_, b,
+            case DC_LANE64:  // 20.5 KiB
+                b.lpw = lane_lists_per_wave(ctx, b.nwork, 7);
+                hipLaunchKernelGGL(k_roc_decode_lane<256>, dim3((b.nwork + b.lpw - 1u) / b.lpw), dim3(64), 0, st_, b,
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
             case DC_G8K:

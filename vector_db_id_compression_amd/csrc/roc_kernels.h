@@ -52,6 +52,7 @@ struct RocEncArgs {
     uint64_t *skey;            // sort scratch for unsorted lists (pow2-padded) or nullptr
     const uint64_t *skey_off;  // [nlist+1] or nullptr
     const uint32_t *mt;
+    uint32_t lpw;              // lane-per-list kernels: lists per wavefront (0 = 64); the remaining lanes idle
 };
 
 // Worst-case arena layout in closed form (no per-list offset array to build, upload or read): a list of n ids
@@ -93,6 +94,7 @@ struct RocDecArgs {
     uint32_t *end_state;        // [nlist] 0 = clean end state (head == 2^31 and stack == drawn words)
     uint32_t *status;           // [nlist]
     const uint32_t *mt;
+    uint32_t lpw;               // lane-per-list kernels: lists per wavefront (0 = 64)
 };
 
 #define VIDC_DEC_CAP 16u       // members per fine bucket before spilling to the overflow list (lists <= 32768)
@@ -319,7 +321,9 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
             }
             continue;
         }
-        // ---- phase 0: stream the list once: domain check, max id, sortedness, u32 copy
+        // ---- phase 0: stream the list once: domain check, max id, sortedness.  An ascending list (the usual case:
+        // Faiss lists are in add order) is sampled straight from the input; only a list that has to be sorted gets a
+        // u32 copy in `sid` (that copy used to be written and read back for every list: 4 + 4 bytes per id)
         uint32_t mx = 0;
         bool bad = false, unsorted = false;
         for (uint32_t j = lane; j < n; j += 64) {
@@ -328,7 +332,6 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
             if (j) unsorted |= a.ids[off + j - 1] >= id;
             uint32_t v = (uint32_t)id;
             mx = v > mx ? v : mx;
-            a.sid[off + j] = v;
         }
         if (ballot(bad)) {
             if (lane == 0) a.status[l] = VIDC_ST_DOMAIN;
@@ -387,7 +390,9 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
         uint64_t head = VIDC_RANS_L;
         Recip rc;
         uint32_t pbuf = 0;
-        const uint32_t *sid = a.sid + off;
+        // id of sorted position j: sid[j] after a sort, the low dword of ids[j] otherwise
+        const uint32_t *sid = need_sort ? a.sid + off : (const uint32_t *)(a.ids + off);
+        const uint32_t sidsh = need_sort ? 0u : 1u;
         const uint32_t *spos = a.spos + off;
         const bool want_perm = a.perm != nullptr;
         for (uint32_t i0 = 0; i0 < n; i0 += 64) {
@@ -415,7 +420,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
                 const uint64_t W = rfl64(words[w]);
                 const uint32_t b = ff1(ballot(mbcnt(W) == k) & W);
                 const uint32_t j = (w << 6) + b;
-                const uint32_t xv = sid[j];  // the only global load on the chain: issued first, consumed last
+                const uint32_t xv = sid[j << sidsh];  // the only global load on the chain: issued first, consumed last
                 __builtin_amdgcn_sched_barrier(0);
                 // remove (every lane stores the same word): runs in the shadow of the load
                 words[w] = W & ~(1ull << b);
@@ -450,7 +455,11 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
 // fewer than n ids are decoded, so it never exceeds 65 535 when it matters; the wrap at the last insert is never
 // read), uint32_t beyond.  Halves the LDS footprint: with 16 KiB per list the two deepest classes of S2 (7 + 10
 // lists per CU) did not fit a CU's LDS together and the second one ran at a third of its occupancy.
-template <typename CT>
+// LROWS: the member rows of the fine buckets live in LDS behind the prefix rows (lists up to 4096 ids: 512 buckets
+// x 16 members = 32 KiB) instead of global memory -- no scattered 4-byte stores (each one cost a 32-byte
+// write-back: 11.5 MB written per S1 step for 0.7 M ids) and no global load on the chain; only the overflow list of
+// a skewed bucket stays in memory.
+template <typename CT, bool LROWS = false>
 __global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t lds_entries, uint32_t cap) {
     extern __shared__ __align__(16) unsigned char smem[];
     CT *rowpref = (CT *)smem;
@@ -482,8 +491,8 @@ __global__ void __launch_bounds__(64) k_roc_decode_gen(RocDecArgs a, uint32_t ld
         const uint32_t NF = 1u << fb;
         for (uint32_t t = lane; t < NF && t < lds_entries; t += 64) rowpref[t] = 0;
         uint32_t C1 = 0;  // lane c: decoded elements in coarse buckets 0..c
-        uint32_t *slots = a.slots + rfl64(a.slots_off[wi]);
-        uint32_t *ovf = slots + (size_t)NF * cap;
+        uint32_t *slots = LROWS ? (uint32_t *)(smem + (size_t)lds_entries * sizeof(CT)) : a.slots + rfl64(a.slots_off[wi]);
+        uint32_t *ovf = LROWS ? a.slots + rfl64(a.slots_off[wi]) : slots + (size_t)NF * cap;
         uint32_t novf = 0, novf_vis = 0;
         uint32_t ring = 0;  // lane t: element decoded at step (block start + t)
         Recip rc;

@@ -128,6 +128,76 @@ __device__ __forceinline__ void le_flush(LEStack &s) {
     s.sp_mem = s.sp;
 }
 
+// Decoder stack of the mid-size lane kernels: no global access of it sits on the serial chain of a list.
+//   * the stored stream is consumed from its top: a 16-word window of it lives in an LDS ring per lane, refilled four
+//     words (one aligned 16-byte load) at a time from a uniform point of the loop, a step or more before the words
+//     are needed (a pop that outruns the window reads the stream directly);
+//   * the words the decoder pushes itself (IDX_push renormalisations, codec.cpp:44-63) are popped again within a
+//     step or two: they wait in an 8-deep LDS stack (ids of a list are distinct, so a step never pushes more bits
+//     than it popped: the depth stays at 1-2; deeper -> VIDC_ST_RETRY, the wave-per-list kernel redoes the list).
+// Before: every pop was a global load on the chain (stream word or a word pushed a step earlier), 3.9 us per step on
+// 65 536 lists of 256 ids; with the bucket row as the only global access of a step see DESIGN.
+#define VIDC_DWIN 16u
+#define VIDC_DPST 8u
+struct LWStack {
+    const uint32_t *wbase;  // stream of the list minus `al` words: 16-byte aligned
+    uint32_t *ring;         // LDS (lane offset included): shifted index s at ring[(s & 15) * 64]
+    uint32_t *pst;          // LDS (lane offset included): pushed word e at pst[e * 64]
+    uint32_t al;            // word_off & 3: shifted index = index in the list's stream + al
+    uint32_t otop;          // shifted index one past the next stored word to pop (== al: none left)
+    uint32_t wlo;           // lowest shifted index the window holds (multiple of 4)
+    uint32_t d;             // pushed words
+    uint32_t draws, err;
+    const uint32_t *mt;
+};
+__device__ __forceinline__ void ls_push(LWStack &s, uint32_t w) {
+    if (s.d < VIDC_DPST) { s.pst[s.d * 64u] = w; s.d++; } else s.err |= 4u;
+}
+__device__ __forceinline__ uint32_t ls_pop(LWStack &s) {  // codec.h:32-40
+    if (s.d) {
+        s.d--;
+        return s.pst[s.d * 64u];
+    }
+    if (__builtin_expect(s.otop == s.al, 0)) {
+        uint32_t w = 0;
+        if (s.draws < VIDC_MT_TABLE) w = s.mt[s.draws]; else s.err |= 2u;
+        s.draws++;
+        return w;
+    }
+    s.otop--;
+    return s.otop >= s.wlo ? s.ring[(s.otop & (VIDC_DWIN - 1u)) * 64u] : s.wbase[s.otop];
+}
+__device__ __forceinline__ void lw_init(LWStack &s, bool have, const uint32_t *words, uint64_t word_off, uint32_t W) {
+    s.al = (uint32_t)word_off & 3u;
+    s.wbase = words + (word_off - s.al);
+    s.otop = W + s.al;
+    s.wlo = s.otop > VIDC_DWIN ? ((s.otop - VIDC_DWIN + 3u) & ~3u) : 0u;
+    s.d = 0; s.err = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < VIDC_DWIN / 4u; k++) {
+        const uint32_t q = s.wlo + 4u * k;  // (the last chunk may read up to 3 words past the stream: padded allocation)
+        if (have && q < s.otop) {
+            const uint4 v = *(const uint4 *)(s.wbase + q);
+            uint32_t *r = s.ring + (q & (VIDC_DWIN - 1u)) * 64u;
+            r[0] = v.x; r[64] = v.y; r[128] = v.z; r[192] = v.w;
+        }
+    }
+}
+// uniform call sites: issue the load of the next four words below the window once four consumed slots are free ...
+__device__ __forceinline__ bool lw_issue(const LWStack &s, uint4 &pf) {
+    const bool go = s.wlo >= 4u && s.otop <= s.wlo + (VIDC_DWIN - 4u);
+    if (go) pf = *(const uint4 *)(s.wbase + (s.wlo - 4u));
+    return go;
+}
+// ... and move them into the ring later in the step (behind the step's own global access: no extra wait)
+__device__ __forceinline__ void lw_land(LWStack &s, bool go, const uint4 &pf) {
+    if (go) {
+        s.wlo -= 4u;
+        uint32_t *r = s.ring + (s.wlo & (VIDC_DWIN - 1u)) * 64u;
+        r[0] = pf.x; r[64] = pf.y; r[128] = pf.z; r[192] = pf.w;
+    }
+}
+
 // codec.cpp:65-76
 template <typename Stack>
 __device__ __forceinline__ void l_u_push(uint64_t &head, Stack &s, uint32_t start, uint32_t p) {
@@ -138,7 +208,8 @@ __device__ __forceinline__ void l_u_push(uint64_t &head, Stack &s, uint32_t star
     head = (head << p) + start;
 }
 // codec.cpp:78-90
-__device__ __forceinline__ uint32_t l_u_pop(uint64_t &head, LStack &s, uint32_t p) {
+template <typename Stack>
+__device__ __forceinline__ uint32_t l_u_pop(uint64_t &head, Stack &s, uint32_t p) {
     uint32_t sym = (uint32_t)head & ((1u << p) - 1u);
     head >>= p;
     if (l_lt_2p31(head)) head = (head << 32) | ls_pop(s);
@@ -179,8 +250,9 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
     uint64_t *gc = (uint64_t *)(smem + LaneEncGeom<NW>::BM_BYTES + LaneEncGeom<NW>::WC_BYTES);
     uint64_t *sc = (uint64_t *)(smem + LaneEncGeom<NW>::BM_BYTES + LaneEncGeom<NW>::WC_BYTES + LaneEncGeom<NW>::GC_BYTES);
     const uint32_t lane = lane_id();
-    const uint32_t wi = blockIdx.x * 64u + lane;
-    const bool have = wi < a.nwork;
+    const uint32_t lpw = a.lpw ? a.lpw : 64u;  // few lists in the launch: fewer per wavefront, more wavefronts (host)
+    const uint32_t wi = blockIdx.x * lpw + lane;
+    const bool have = lane < lpw && wi < a.nwork;
     const uint32_t l = have ? a.worklist[wi] : 0u;
     const uint64_t off = have ? a.offsets[l] : 0ull;
     const uint32_t n = have ? (uint32_t)(a.offsets[l + 1] - off) : 0u;
@@ -340,7 +412,9 @@ struct LaneDecGeom {
     static constexpr uint32_t GRP_BYTES = (NG / 4) * 64 * 8;  // u64 grp[NG/4][64]
     static constexpr uint32_t SUP_BYTES = NB > 64 ? 64 * 8 : 0;
     static constexpr uint32_t RING_BYTES = 8 * 64 * 4;        // u32 oring[8][64]
-    static constexpr uint32_t LDS_BYTES = CNT_BYTES + GRP_BYTES + SUP_BYTES + RING_BYTES;
+    static constexpr uint32_t WIN_BYTES = VIDC_DWIN * 64 * 4; // stream window
+    static constexpr uint32_t PST_BYTES = VIDC_DPST * 64 * 4; // pushed words
+    static constexpr uint32_t LDS_BYTES = CNT_BYTES + GRP_BYTES + SUP_BYTES + RING_BYTES + WIN_BYTES + PST_BYTES;
     static constexpr uint32_t BITS = NB == 64 ? 6u : 8u;
 };
 
@@ -356,8 +430,9 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
     // lines back to back, so a line is completed in L2 instead of being written back to HBM partially up to 8 times
     uint32_t *oring = (uint32_t *)(smem + G::CNT_BYTES + G::GRP_BYTES + G::SUP_BYTES);
     const uint32_t lane = lane_id();
-    const uint32_t wi = blockIdx.x * 64u + lane;
-    const bool have = wi < a.nwork;
+    const uint32_t lpw = a.lpw ? a.lpw : 64u;
+    const uint32_t wi = blockIdx.x * lpw + lane;
+    const bool have = lane < lpw && wi < a.nwork;
     const uint32_t l = have ? a.worklist[wi] : 0u;
     const uint32_t n = have ? (uint32_t)(a.offsets[l + 1] - a.offsets[l]) : 0u;
     const uint64_t ooff = have ? (a.out_off ? a.out_off[wi] : a.offsets[l]) : 0ull;
@@ -371,11 +446,11 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
     for (int q = 0; q < (int)G::NG / 4; q++) grp[q * 64 + lane] = 0;
     if (NB > 64) sup[lane] = 0;
 
-    LStack st;
-    const uint32_t W = have ? a.nwords[l] : 0u;
-    st.orig = a.words + (have ? a.word_off[l] : 0ull);
-    st.mem = a.scratch_words + (have ? a.scratch_off[wi] : 0ull);
-    st.cap = roc_dec_stack_cap(n, W); st.sp = W; st.dirty = 0xffffffffu; st.err = 0; st.mt = a.mt;
+    LWStack st;
+    st.ring = (uint32_t *)(smem + G::CNT_BYTES + G::GRP_BYTES + G::SUP_BYTES + G::RING_BYTES) + lane;
+    st.pst = (uint32_t *)(smem + G::CNT_BYTES + G::GRP_BYTES + G::SUP_BYTES + G::RING_BYTES + G::WIN_BYTES) + lane;
+    lw_init(st, have, a.words, have ? a.word_off[l] : 0ull, have ? a.nwords[l] : 0u);
+    st.mt = a.mt;
     st.draws = have ? a.draws[l] : 0u;
     const uint32_t draws0 = st.draws;
     uint64_t head = have ? a.heads[l] : VIDC_RANS_L;
@@ -386,6 +461,8 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
 
     for (uint32_t i = 0; i < nsteps; i++) {
         const uint32_t lq = dtab[i + 1u].w;  // uniform: floor(2^31 / (i + 1))
+        uint4 pf = make_uint4(0, 0, 0, 0);
+        const bool pf_go = (i & 1u) == 0u && i < n_eff && lw_issue(st, pf);  // a step pops at most two words
         if (i < n_eff) {
             // ---- x = ID_pop(P), codec.cpp:107-121 (slices 3, 2 have precision 0: refill test only)
             if (__builtin_expect(l_lt_2p31(head), 0)) {
@@ -442,6 +519,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
                 oring[(i & 7u) * 64u + lane] = x;
             }
         }
+        lw_land(st, pf_go, pf);
         if ((i & 7u) == 7u || i + 1u == nsteps) {  // uniform: flush the ring (steps s0 .. i)
             const uint32_t s0 = i & ~7u;
 #pragma unroll
@@ -453,9 +531,10 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
         }
     }
     if (have) {
-        const bool clean = (head == VIDC_RANS_L) && (st.sp == st.draws - draws0);
+        retry |= (st.err & 4u) != 0u;
+        const bool clean = (head == VIDC_RANS_L) && (st.otop - st.al + st.d == st.draws - draws0);
         a.end_state[l] = (clean || retry) ? 0u : 1u;
-        a.status[l] = retry ? VIDC_ST_RETRY : (st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK);
+        a.status[l] = retry ? VIDC_ST_RETRY : ((st.err & 2u) ? VIDC_ST_MT : VIDC_ST_OK);
     }
 }
 

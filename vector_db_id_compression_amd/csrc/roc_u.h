@@ -334,6 +334,19 @@ __global__ void __launch_bounds__(256) k_roc_prepass(const uint64_t *ids, const 
     }
 }
 
+// the same from the last id of each list alone (one thread per list): exact for ascending lists; the encode kernels
+// verify what this one assumes (roc.hip, light_prepass)
+__global__ void __launch_bounds__(256) k_roc_prepass_last(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist,
+                                                          int precision_mode, uint32_t *maxid, uint32_t *flags, uint32_t *prec) {
+    const uint32_t l = blockIdx.x * 256u + threadIdx.x;
+    if (l >= nlist) return;
+    const uint64_t off = offsets[l], n = offsets[l + 1] - off;
+    const uint64_t id = n ? ids[off + n - 1] : 0ull;
+    maxid[l] = (uint32_t)id;
+    flags[l] = id >= (1ull << 31) ? VIDC_PF_DOMAIN : 0u;
+    prec[l] = n ? precision_for((uint32_t)id, precision_mode) : 0u;
+}
+
 // order[] (sampled ids, written by the U encoder into the perm buffer) -> input positions, for lists whose
 // input is strictly ascending: position = index of the id in the list (binary search).
 __global__ void k_perm_from_order(const uint64_t *ids, const uint64_t *offsets, const uint32_t *lists, uint32_t nwork,

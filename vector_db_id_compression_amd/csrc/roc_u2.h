@@ -418,8 +418,13 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
         for (uint32_t w = lane; w < U::LDS_BYTES / 16u; w += 64) z[w] = make_uint4(0, 0, 0, 0);
     }
     wave_sync();
-    bool dup = false;
+    // The host classified this list by its LAST id (light prepass): the loop checks the rest -- every id inside
+    // [0, 2^31) and, because the sampled ids only turn into input positions for an ascending list, the order when the
+    // permutation is wanted.  An id beyond the bitmap is only counted in the maximum (the precision test below sends
+    // the list to the general kernels).
+    bool dup = false, bad = false;
     uint32_t mx = 0;
+    uint64_t prev_last = 0;  // id at j0 - 1
     for (uint32_t j0 = 0; j0 < n; j0 += 512u) {  // 8 loads per lane in flight (one per iteration made this loop 1.2 ms of S1)
         uint64_t v[8];
 #pragma unroll
@@ -429,20 +434,33 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
         }
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) {
+            if (WANT_ORDER) {
+                uint64_t below = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(v[u] >> 32), 1, 64) << 32) |
+                                 (uint32_t)__shfl_up((int)(uint32_t)v[u], 1, 64);
+                if (lane == 0) below = prev_last;
+                prev_last = rfl64(((uint64_t)rl((uint32_t)(v[u] >> 32), 63) << 32) | rl((uint32_t)v[u], 63));
+                if (v[u] != ~0ull && (j0 + u * 64u + lane) != 0u && below >= v[u]) dup = true;
+            }
             if (v[u] == ~0ull) continue;
-            const uint32_t x = (uint32_t)v[u];  // < 2^UB: guaranteed by the host's classification
+            bad |= (v[u] >> 31) != 0;
+            const uint32_t x = (uint32_t)v[u];
+            mx = x > mx ? x : mx;
+            if (x >> UB) continue;
             const uint32_t bit = 1u << (x & 31u);
             const uint32_t old = atomicOr(&bm32[u2_word_of<UB>(x) * 2u + ((x >> 5) & 1u)], bit);
             dup |= (old & bit) != 0;
-            mx = x > mx ? x : mx;
         }
     }
     wave_sync();
+    if (ballot(bad)) {
+        if (lane == 0) a.status[l] = VIDC_ST_DOMAIN;
+        return;
+    }
     const uint32_t P = rfl(a.prec[l]);  // written by the prepass
     const uint32_t maxid = wave_max_u32(mx);
     // multisets, precisions above 20 bits and ids that do not fit the precision (reference carry quirk) take the
     // general kernels
-    if (ballot(dup) || P > 20u || (maxid >> P) != 0u) {
+    if (ballot(dup) || P > 20u || (maxid >> P) != 0u || (maxid >> UB) != 0u) {
         if (lane == 0) a.status[l] = VIDC_ST_PENDING_SORT;
         return;
     }
