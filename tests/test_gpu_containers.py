@@ -136,7 +136,7 @@ def test_wavelet_tree_select_and_asserts(oracle):
     from vector_db_id_compression_amd.codecs import WaveletTreeLists
 
     rng = np.random.default_rng(3)
-    for nlist, ntotal in [(1, 10), (2, 100), (5, 1000), (37, 5000), (256, 20000), (1000, 3000)]:
+    for nlist, ntotal in [(1, 10), (2, 100), (5, 1000), (37, 5000), (256, 20000), (1000, 3000), (100, 150000)]:
         assign = rng.integers(0, nlist, ntotal)
         order = np.argsort(assign, kind="stable")
         counts = np.bincount(assign, minlength=nlist)
@@ -153,12 +153,45 @@ def test_wavelet_tree_select_and_asserts(oracle):
         for l, o, g in list(zip(ql, qo, got))[:40]:
             assert g == oracle.wt_select(list_nos, int(l), int(o))  # wt.select(offset + 1, list_no), :377-379
         assert np.array_equal(got, ids[off[ql].astype(np.int64) + qo].astype(np.int64))
+        # wt_type 1: the levels are RRR-63 coded (no plain bits kept): same answers from every entry point, and the
+        # size is the size of that coding -- recomputed here from the level bit vectors
         wt1 = WaveletTreeLists.build(off, ids, wt_type=1)
-        assert 0 < wt1.size_in_bytes and np.array_equal(wt1.select(ql, qo), got)
+        assert np.array_equal(wt1.select(ql, qo), got)
+        assert np.array_equal(wt1.decode_all().cpu().numpy().view(np.uint64), ids)
+        sel = np.unique(ql)[:17].astype(np.uint64)
+        d1, o1 = wt1.decode_lists(sel)
+        d0, o0 = wt.decode_lists(sel)
+        assert np.array_equal(o1, o0) and np.array_equal(d1.cpu().numpy(), d0.cpu().numpy())
+        assert wt1.size_in_bytes == _rrr_wt_size(list_nos, nlist)
     with pytest.raises(VidcError):  # assert(ids_data[i] > prev_id) / < ntotal, :359-360
         WaveletTreeLists.build(np.array([0, 3], dtype=np.uint64), np.array([2, 1, 0], dtype=np.uint64))
     with pytest.raises(VidcError):
         WaveletTreeLists.build(np.array([0, 3], dtype=np.uint64), np.array([0, 1, 7], dtype=np.uint64))
+
+
+def _rrr_wt_size(list_nos, nlist):
+    """Bytes of a levelwise wavelet tree whose levels are RRR coded with 63-bit blocks and one sample per 32 blocks:
+    6-bit class + ceil(log2 C(63, class)) offset bits per block, (32-bit stream pointer + 32-bit rank) per sample
+    (+ the final one), plus the table of symbol start positions (csrc/wt.hip)."""
+    import math
+
+    nt = list_nos.size
+    L = max(1, int(nlist - 1).bit_length())
+    ow = [0 if c in (0, 63) else math.ceil(math.log2(math.comb(63, c))) for c in range(64)]
+    nblk = (nt + 62) // 63
+    nsamp = (nblk + 31) // 32
+    order = np.arange(nt)
+    off_bits = 0
+    syms = list_nos.astype(np.int64)
+    for level in range(L):
+        bits = (syms[order] >> (L - 1 - level)) & 1
+        padded = np.zeros(nblk * 63, dtype=np.int64)
+        padded[:nt] = bits
+        cls = padded.reshape(nblk, 63).sum(1)
+        off_bits += int(sum(ow[int(c)] for c in cls))
+        # next level: stable sort by the top (level + 1) bits of the symbol
+        order = order[np.argsort(syms[order] >> (L - 1 - level), kind="stable")]
+    return (off_bits + 7) // 8 + L * ((6 * nblk + 7) // 8) + L * (nsamp + 1) * 8 + (nlist + 1) * 8
 
 
 def _random_graph(rng, N, K):

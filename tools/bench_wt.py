@@ -18,22 +18,23 @@ for name in sys.argv[1:] or ["s1", "uniform_16m"]:
     perm_ok = bool(torch.equal(torch.sort(ids).values, torch.arange(wl["ntotal"], device="cuda")))
     if not perm_ok:
         ids = torch.randperm(wl["ntotal"], device="cuda")
-    for rep in range(2):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        wt = WaveletTreeLists.build(wl["offsets"], ids, wt_type=0)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        out = wt.decode_all()
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        rng = np.random.default_rng(1)
-        q = 100000
-        ln = rng.integers(0, wl["nlist"], q).astype(np.uint64)
-        sizes = (wl["offsets"][1:] - wl["offsets"][:-1])[ln.astype(np.int64)]
-        keep = sizes > 0
-        ln = ln[keep]
-        of = (rng.random(ln.size) * sizes[keep]).astype(np.uint64)
-        t3 = time.perf_counter()
-        got = wt.select(ln, of)
-        t4 = time.perf_counter()
-    print(f"{name}: build {1e3*(t1-t0):.2f} ms, decode_all {1e3*(t2-t1):.2f} ms ({wl['ntotal']/(t2-t1)/1e6:.0f} M ids/s), "
-          f"{ln.size} selects {1e3*(t4-t3):.2f} ms ({ln.size/(t4-t3)/1e6:.1f} M/s), levels {wt.levels}, "
-          f"{8*wt.size_in_bytes/wl['ntotal']:.2f} bit/id", flush=True)
+    for wt_type in (0, 1):
+        for rep in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            wt = WaveletTreeLists.build(wl["offsets"], ids, wt_type=wt_type)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            out = wt.decode_all()
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            rng = np.random.default_rng(1)
+            q = 100000
+            ln = rng.integers(0, wl["nlist"], q).astype(np.uint64)
+            sizes = (wl["offsets"][1:] - wl["offsets"][:-1])[ln.astype(np.int64)]
+            keep = sizes > 0
+            ln = ln[keep]
+            of = (rng.random(ln.size) * sizes[keep]).astype(np.uint64)
+            t3 = time.perf_counter()
+            got = wt.select(ln, of)
+            t4 = time.perf_counter()
+        print(f"{name} wt_type={wt_type}: build {1e3*(t1-t0):.2f} ms, decode_all {1e3*(t2-t1):.2f} ms ({wl['ntotal']/(t2-t1)/1e6:.0f} M ids/s), "
+              f"{ln.size} selects {1e3*(t4-t3):.2f} ms ({ln.size/(t4-t3)/1e6:.1f} M/s), levels {wt.levels}, "
+              f"{8*wt.size_in_bytes/wl['ntotal']:.2f} bit/id", flush=True)

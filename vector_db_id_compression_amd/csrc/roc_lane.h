@@ -227,7 +227,8 @@ struct LaneEncGeom {
     static constexpr uint32_t GC_BYTES = NW > 4 ? (NW / 16) * 64 * 8 : 0;
     static constexpr uint32_t SC_BYTES = NW > 16 ? 64 * 8 : 0;
     static constexpr uint32_t RING_BYTES = VIDC_PRING * 64 * 4;
-    static constexpr uint32_t LDS_BYTES = BM_BYTES + WC_BYTES + GC_BYTES + SC_BYTES + RING_BYTES;
+    static constexpr uint32_t PERM_BYTES = 16 * 64 * 4;  // sampled positions of the last <= 16 steps
+    static constexpr uint32_t LDS_BYTES = BM_BYTES + WC_BYTES + GC_BYTES + SC_BYTES + RING_BYTES + PERM_BYTES;
 };
 
 // 4 u16 counters in v: the field f holding the k-th element (k < total), k reduced to its rank inside the field
@@ -308,6 +309,10 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
     uint64_t head = VIDC_RANS_L;
     const uint64_t *ids = a.ids + off;
     const uint32_t nsteps = wave_max_u32(n);
+    // the sampled positions leave 16 at a time (one 64-byte run per lane): a 4-byte store per step to a line that is
+    // written back before the next one arrives cost a 32-byte write each (15 GiB of S2's encode writes)
+    uint32_t *pring = (uint32_t *)(smem + LaneEncGeom<NW>::BM_BYTES + LaneEncGeom<NW>::WC_BYTES + LaneEncGeom<NW>::GC_BYTES +
+                                   LaneEncGeom<NW>::SC_BYTES + LaneEncGeom<NW>::RING_BYTES) + lane;
 
     for (uint32_t i = 0; i < nsteps; i++) {
         if (i < n) {
@@ -357,7 +362,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
             bm[w * 64 + lane] = word & ~(1ull << b);
             const uint32_t pos = (w << 6) + b;
             const uint32_t x = (uint32_t)ids[pos];
-            if (WANT_PERM) a.perm[off + i] = pos;
+            if (WANT_PERM) pring[(i & 15u) * 64u] = pos;
 
             // ---- ID_push(x, P), codec.cpp:92-105
             l_u_push(head, st, x & 0xffffu, p0);
@@ -368,6 +373,12 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
             }
         }
         le_drain16(st);  // at most 5 words per step: the ring (32) never overflows
+        if (WANT_PERM && ((i & 15u) == 15u || i + 1u == nsteps)) {  // uniform
+            const uint32_t s0 = i & ~15u;
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; k++)
+                if (s0 + k <= i && s0 + k < n) a.perm[off + s0 + k] = pring[k * 64u];
+        }
     }
     le_flush(st);
     if (have) {

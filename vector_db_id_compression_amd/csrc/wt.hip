@@ -9,12 +9,21 @@
 // select walks the levels bottom-up with one rank and one select per level.  Everything is built and
 // queried on the GPU: thread-per-word bit gathering, a workgroup scan for the rank directory, and a
 // rank-driven stable partition to derive the next level's order.
+//
+// wt_type = 1 (sdsl::wt_int<rrr_vector<63>>, custom_invlists_impl.h:104-113): every level is stored RRR-coded and the
+// plain bits are dropped after the build -- 63-bit blocks, each a 6-bit class (its popcount c) and a
+// ceil(log2 C(63, c))-bit offset (the block's index among the 63-bit words with c ones, combinatorial number
+// system), plus one (offset-stream pointer, ones-before) sample per 32 blocks.  rank / access decode ONE block
+// (sample -> add the classes of the blocks before it -> unrank the offset); select is a binary search over the
+// samples, a scan over <= 32 classes and one block decode.  The bit order inside sdsl's structure is not pinned
+// (sdsl is absent here); the structure, its parameters (block 63, sample rate 32) and what it answers are.
 #include <algorithm>
 #include <cmath>
 #include <memory>
 
 #include "bits.h"
 #include "common.h"
+#include "scan.h"
 
 using namespace vidc;
 using namespace vidc::dev;
@@ -27,9 +36,16 @@ struct vidc_wt {
     uint64_t words_per_level = 0, blocks_per_level = 0;
     uint64_t size_bytes = 0;
     std::vector<uint64_t> offsets;      // host copy of the symbol start positions C[s]
-    DevBuf<uint64_t> d_bits;            // L * words_per_level
+    DevBuf<uint64_t> d_bits;            // L * words_per_level                      (wt_type 0)
     DevBuf<uint32_t> d_rank;            // L * (blocks_per_level + 1): ones before each 512-bit block
     DevBuf<uint64_t> d_C;               // nlist + 1
+    // wt_type 1: RRR-63 levels
+    uint64_t rrr_nblk = 0, rrr_nsamp = 0, rrr_cls_wpl = 0;
+    std::vector<uint64_t> rrr_off_base;  // [L + 1] first word of every level's offset stream
+    DevBuf<uint32_t> d_cls;             // L * rrr_cls_wpl: packed 6-bit classes
+    DevBuf<uint64_t> d_offs;            // offset streams, level after level
+    DevBuf<uint32_t> d_ptr, d_rs;       // L * (rrr_nsamp + 1): bit position in the offset stream / ones before block 32 s
+    DevBuf<uint64_t> d_binom;           // C(n, k), n, k < 64 (row n at 64 n)
 };
 
 namespace {
@@ -127,6 +143,181 @@ __device__ __forceinline__ uint64_t select_bit(const uint64_t *bits, const uint3
     return ~0ull;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// bit-vector views: what the query kernels need from a level, over plain bits or over the RRR coding
+struct BvPlain {
+    const uint64_t *bits;
+    const uint32_t *rank;
+    uint64_t nblocks, nwords;
+    __device__ __forceinline__ uint64_t rank_1(uint64_t i) const { return rank1(bits, rank, i); }
+    __device__ __forceinline__ uint64_t rank_1_bit(uint64_t i, bool &bit) const {
+        bit = (bits[i >> 6] >> (i & 63)) & 1ull;
+        return rank1(bits, rank, i);
+    }
+    __device__ __forceinline__ uint64_t select(uint64_t j, bool one) const { return select_bit(bits, rank, nblocks, nwords, j, one); }
+};
+struct WtPlainView {
+    const uint64_t *bits;
+    const uint32_t *rank;
+    uint64_t wpl, bpl;
+    __device__ __forceinline__ BvPlain level(uint32_t l) const {
+        return BvPlain{bits + (uint64_t)l * wpl, rank + (uint64_t)l * (bpl + 1), bpl, wpl};
+    }
+};
+
+constexpr uint32_t RRR_B = 63, RRR_K = 32;
+struct RrrTab { uint8_t ow[64]; };  // offset width of class c: ceil(log2 C(63, c))
+
+// index of the 63-bit word v (c ones) among the words with c ones: sum over its ones (ascending, i = 1..c) of C(p_i, i)
+__device__ __forceinline__ uint64_t rrr_rank_word(uint64_t v, const uint64_t *binom) {
+    uint64_t o = 0;
+    uint32_t i = 1;
+    while (v) {
+        const uint32_t p = (uint32_t)__builtin_ctzll(v);
+        o += binom[p * 64u + i];
+        i++;
+        v &= v - 1;
+    }
+    return o;
+}
+__device__ __forceinline__ uint64_t rrr_unrank_word(uint32_t c, uint64_t o, const uint64_t *binom) {
+    if (c == 0) return 0;
+    if (c == RRR_B) return (1ull << RRR_B) - 1ull;
+    uint64_t v = 0;
+    for (int p = (int)RRR_B - 1; c; p--) {
+        const uint64_t b = binom[(uint32_t)p * 64u + c];  // words with c ones below position p
+        if (o >= b) { v |= 1ull << p; o -= b; c--; }
+    }
+    return v;
+}
+struct BvRrr {
+    const uint32_t *cls;
+    const uint64_t *offs;
+    const uint32_t *ptr, *rs;
+    const uint64_t *binom;
+    RrrTab tab;
+    uint64_t nblk, nsamp, nbits;
+    __device__ __forceinline__ uint32_t cls_at(uint64_t b) const {
+        const uint64_t bp = 6 * b;
+        uint32_t w = cls[bp >> 5] >> (bp & 31);
+        if ((bp & 31) > 26) w |= cls[(bp >> 5) + 1] << (32 - (bp & 31));
+        return w & 63u;
+    }
+    __device__ __forceinline__ uint64_t word_at(uint64_t bp, uint32_t c) const {  // the block whose offset starts at bit bp
+        const uint32_t wd = tab.ow[c];
+        uint64_t o = 0;
+        if (wd) {
+            o = offs[bp >> 6] >> (bp & 63);
+            if ((bp & 63) + wd > 64) o |= offs[(bp >> 6) + 1] << (64 - (bp & 63));
+            o &= (1ull << wd) - 1ull;
+        }
+        return rrr_unrank_word(c, o, binom);
+    }
+    __device__ __forceinline__ uint64_t rank_1_bit(uint64_t i, bool &bit) const {
+        const uint64_t blk = i / RRR_B, s = blk / RRR_K;
+        uint64_t r = rs[s], bp = ptr[s];
+        for (uint64_t b = s * RRR_K; b < blk; b++) {
+            const uint32_t c = cls_at(b);
+            r += c;
+            bp += tab.ow[c];
+        }
+        const uint32_t rem = (uint32_t)(i - blk * RRR_B);
+        bit = false;
+        if (blk < nblk) {
+            const uint64_t v = word_at(bp, cls_at(blk));
+            r += (uint64_t)__builtin_popcountll(v & ((1ull << rem) - 1ull));
+            bit = (v >> rem) & 1ull;
+        }
+        return r;
+    }
+    __device__ __forceinline__ uint64_t rank_1(uint64_t i) const {
+        bool b;
+        return rank_1_bit(i, b);
+    }
+    __device__ __forceinline__ uint64_t before(uint64_t s, bool one) const {  // ones / zeros in blocks [0, 32 s)
+        const uint64_t r = rs[s];
+        if (one) return r;
+        const uint64_t pos = s * RRR_K * RRR_B;
+        return (pos < nbits ? pos : nbits) - r;
+    }
+    __device__ __forceinline__ uint64_t select(uint64_t j, bool one) const {
+        uint64_t lo = 0, hi = nsamp;  // largest sample with before(s) <= j
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (before(mid, one) <= j) lo = mid; else hi = mid;
+        }
+        uint64_t seen = before(lo, one), bp = ptr[lo];
+        for (uint64_t b = lo * RRR_K; b < nblk; b++) {
+            const uint32_t c = cls_at(b);
+            const uint64_t len = nbits - b * RRR_B < RRR_B ? nbits - b * RRR_B : RRR_B;  // bits of this block that exist
+            const uint64_t cnt = one ? c : len - c;
+            if (seen + cnt > j) {
+                uint64_t v = word_at(bp, c);
+                if (!one) v = ~v & (len == 64 ? ~0ull : ((1ull << len) - 1ull));
+                for (uint64_t k = j - seen; k; k--) v &= v - 1;
+                return b * RRR_B + (uint64_t)__builtin_ctzll(v);
+            }
+            seen += cnt;
+            bp += tab.ow[c];
+        }
+        return ~0ull;
+    }
+};
+struct WtRrrView {
+    const uint32_t *cls;
+    const uint64_t *offs;
+    const uint32_t *ptr, *rs;
+    const uint64_t *binom;
+    uint64_t cls_wpl, nblk, nsamp, nbits;
+    uint64_t off_base[32];
+    RrrTab tab;
+    __device__ __forceinline__ BvRrr level(uint32_t l) const {
+        return BvRrr{cls + (uint64_t)l * cls_wpl, offs + off_base[l], ptr + (uint64_t)l * (nsamp + 1), rs + (uint64_t)l * (nsamp + 1),
+                     binom, tab, nblk, nsamp, nbits};
+    }
+};
+
+// ---- RRR build kernels (one thread per 63-bit block of a level's plain bits)
+__device__ __forceinline__ uint64_t rrr_get63(const uint64_t *bits, uint64_t b) {
+    const uint64_t pos = b * RRR_B;
+    uint64_t v = bits[pos >> 6] >> (pos & 63);
+    if ((pos & 63) + RRR_B > 64) v |= bits[(pos >> 6) + 1] << (64 - (pos & 63));
+    return v & ((1ull << RRR_B) - 1ull);
+}
+__global__ void k_rrr_classes(const uint64_t *bits, uint64_t nblk, RrrTab tab, uint32_t *cls, uint32_t *width) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += stride) {
+        const uint32_t c = (uint32_t)__builtin_popcountll(rrr_get63(bits, b));
+        width[b] = tab.ow[c];
+        const uint64_t bp = 6 * b;
+        atomicOr(&cls[bp >> 5], c << (bp & 31));
+        if ((bp & 31) > 26) atomicOr(&cls[(bp >> 5) + 1], c >> (32 - (bp & 31)));
+    }
+}
+__global__ void k_rrr_offsets(const uint64_t *bits, uint64_t nblk, RrrTab tab, const uint64_t *binom, const uint64_t *bitpos,
+                              unsigned long long *offs) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += stride) {
+        const uint64_t v = rrr_get63(bits, b);
+        const uint32_t wd = tab.ow[__builtin_popcountll(v)];
+        if (!wd) continue;
+        const uint64_t o = rrr_rank_word(v, binom), bp = bitpos[b];
+        atomicOr(&offs[bp >> 6], (unsigned long long)(o << (bp & 63)));
+        if ((bp & 63) + wd > 64) atomicOr(&offs[(bp >> 6) + 1], (unsigned long long)(o >> (64 - (bp & 63))));
+    }
+}
+__global__ void k_rrr_samples(const uint64_t *bits, const uint32_t *rank, uint64_t nbits, uint64_t nblk, uint64_t nsamp,
+                              const uint64_t *bitpos, uint32_t *ptr, uint32_t *rs) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= nsamp; s += stride) {
+        const uint64_t b = s * RRR_K < nblk ? s * RRR_K : nblk;
+        const uint64_t pos = b * RRR_B < nbits ? b * RRR_B : nbits;
+        ptr[s] = (uint32_t)bitpos[b];
+        rs[s] = (uint32_t)rank1(bits, rank, pos);
+    }
+}
+
 // stable partition of every node of the level by its bit -> order of the next level
 __global__ void k_wt_partition(const uint32_t *syms_in, uint32_t *syms_out, const uint64_t *bits, const uint32_t *rank,
                                const uint64_t *C, uint64_t ntotal, uint32_t nlist, uint32_t L, uint32_t level) {
@@ -147,8 +338,8 @@ __global__ void k_wt_partition(const uint32_t *syms_in, uint32_t *syms_out, cons
 }
 
 // one thread per query: id of the (k+1)-th element of list c
-__global__ void k_wt_select(const uint64_t *bits, const uint32_t *rank, const uint64_t *C, uint64_t words_per_level,
-                            uint64_t blocks_per_level, uint32_t nlist, uint32_t L, uint64_t m,
+template <class View>
+__global__ void k_wt_select(View vw, const uint64_t *C, uint32_t nlist, uint32_t L, uint64_t m,
                             const uint64_t *list_nos, const uint64_t *offs, int64_t *out) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride) {
@@ -160,11 +351,10 @@ __global__ void k_wt_select(const uint64_t *bits, const uint32_t *rank, const ui
             const uint64_t s_lo = sh >= 32 ? 0 : (p << sh);
             const uint64_t ns = C[s_lo];
             const bool bit = (c >> (L - 1u - (uint32_t)level)) & 1u;
-            const uint64_t *b = bits + (uint64_t)level * words_per_level;
-            const uint32_t *r = rank + (uint64_t)level * (blocks_per_level + 1);
-            const uint64_t r_ns = rank1(b, r, ns);
+            const auto bv = vw.level((uint32_t)level);
+            const uint64_t r_ns = bv.rank_1(ns);
             const uint64_t before = bit ? r_ns : ns - r_ns;
-            pos = select_bit(b, r, blocks_per_level, words_per_level, before + pos, bit) - ns;
+            pos = bv.select(before + pos, bit) - ns;
         }
         out[q] = (int64_t)pos;
     }
@@ -172,8 +362,8 @@ __global__ void k_wt_select(const uint64_t *bits, const uint32_t *rank, const ui
 
 // get_ids of the requested lists (custom_invlists_impl.cpp:381-392 loops get_single_id): one thread per output slot,
 // its request item found in the m + 1 output offsets
-__global__ void k_wt_decode_lists(const uint64_t *bits, const uint32_t *rank, const uint64_t *C, uint64_t words_per_level,
-                                  uint64_t blocks_per_level, uint32_t L, uint64_t m, const uint64_t *list_nos,
+template <class View>
+__global__ void k_wt_decode_lists(View vw, const uint64_t *C, uint32_t L, uint64_t m, const uint64_t *list_nos,
                                   const uint64_t *out_off, uint64_t total, uint64_t *out) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
@@ -189,18 +379,17 @@ __global__ void k_wt_decode_lists(const uint64_t *bits, const uint32_t *rank, co
             const uint64_t p = sh >= 32 ? 0 : (uint64_t)(c >> sh);
             const uint64_t ns = C[sh >= 32 ? 0 : (p << sh)];
             const bool bit = (c >> (L - 1u - (uint32_t)level)) & 1u;
-            const uint64_t *b = bits + (uint64_t)level * words_per_level;
-            const uint32_t *r = rank + (uint64_t)level * (blocks_per_level + 1);
-            const uint64_t r_ns = rank1(b, r, ns);
-            pos = select_bit(b, r, blocks_per_level, words_per_level, (bit ? r_ns : ns - r_ns) + pos, bit) - ns;
+            const auto bv = vw.level((uint32_t)level);
+            const uint64_t r_ns = bv.rank_1(ns);
+            pos = bv.select((bit ? r_ns : ns - r_ns) + pos, bit) - ns;
         }
         out[g] = pos;
     }
 }
 
 // get_ids for every list (custom_invlists_impl.cpp:381-392 loops get_single_id)
-__global__ void k_wt_decode_all(const uint64_t *bits, const uint32_t *rank, const uint64_t *C, uint64_t words_per_level,
-                                uint64_t blocks_per_level, uint32_t nlist, uint32_t L, uint64_t ntotal,
+template <class View>
+__global__ void k_wt_decode_all(View vw, const uint64_t *C, uint32_t nlist, uint32_t L, uint64_t ntotal,
                                 uint64_t *out) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ntotal; g += stride) {
@@ -211,10 +400,9 @@ __global__ void k_wt_decode_all(const uint64_t *bits, const uint32_t *rank, cons
             const uint64_t p = sh >= 32 ? 0 : (uint64_t)(c >> sh);
             const uint64_t ns = C[sh >= 32 ? 0 : (p << sh)];
             const bool bit = (c >> (L - 1u - (uint32_t)level)) & 1u;
-            const uint64_t *b = bits + (uint64_t)level * words_per_level;
-            const uint32_t *r = rank + (uint64_t)level * (blocks_per_level + 1);
-            const uint64_t r_ns = rank1(b, r, ns);
-            pos = select_bit(b, r, blocks_per_level, words_per_level, (bit ? r_ns : ns - r_ns) + pos, bit) - ns;
+            const auto bv = vw.level((uint32_t)level);
+            const uint64_t r_ns = bv.rank_1(ns);
+            pos = bv.select((bit ? r_ns : ns - r_ns) + pos, bit) - ns;
         }
         out[g] = pos;
     }
@@ -227,10 +415,9 @@ __global__ void k_wt_decode_all(const uint64_t *bits, const uint32_t *rank, cons
 struct WtItem {
     uint32_t id, pref;
 };
-template <bool LAST>
-__global__ void k_wt_decode_level(const WtItem *in, WtItem *out, uint64_t *out_ids, const uint64_t *bits,
-                                  const uint32_t *rank, const uint64_t *C, uint64_t ntotal, uint32_t nlist, uint32_t L,
-                                  uint32_t level) {
+template <bool LAST, class Bv>
+__global__ void k_wt_decode_level(const WtItem *in, WtItem *out, uint64_t *out_ids, Bv bv, const uint64_t *C, uint64_t ntotal,
+                                  uint32_t nlist, uint32_t L, uint32_t level) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t sh = L - level;  // symbols of one node share their top `level` bits
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ntotal; i += stride) {
@@ -240,8 +427,8 @@ __global__ void k_wt_decode_level(const WtItem *in, WtItem *out, uint64_t *out_i
         if (s_lo > nlist) s_lo = nlist;
         if (s_hi > nlist) s_hi = nlist;
         const uint64_t ns = C[s_lo], ne = C[s_hi];
-        const uint64_t r_ns = rank1(bits, rank, ns), r_i = rank1(bits, rank, i), r_ne = rank1(bits, rank, ne);
-        const bool bit = (bits[i >> 6] >> (i & 63)) & 1ull;
+        bool bit;
+        const uint64_t r_ns = bv.rank_1(ns), r_i = bv.rank_1_bit(i, bit), r_ne = bv.rank_1(ne);
         const uint64_t zeros_in_node = (ne - ns) - (r_ne - r_ns);
         const uint64_t dst = bit ? ns + zeros_in_node + (r_i - r_ns) : ns + ((i - ns) - (r_i - r_ns));
         if (LAST) out_ids[dst] = it.id;
@@ -249,20 +436,27 @@ __global__ void k_wt_decode_level(const WtItem *in, WtItem *out, uint64_t *out_i
     }
 }
 
-// size of an RRR-63 coded bitvector (sdsl::rrr_vector<63>): 6-bit class + ceil(log2 C(63, class)) offset bits
-// per 63-bit block, plus a 64-bit pointer and rank sample every 32 blocks (the layout sdsl documents)
-__global__ void k_wt_rrr_bits(const uint64_t *bits, uint64_t nbits, const uint8_t *offbits, unsigned long long *total) {
-    const uint64_t nblk = (nbits + 62) / 63;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned long long acc = 0;
-    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += stride) {
-        const uint64_t pos = b * 63;
-        uint64_t v = bits[pos >> 6] >> (pos & 63);
-        if ((pos & 63) + 63 > 64) v |= bits[(pos >> 6) + 1] << (64 - (pos & 63));
-        v &= (1ull << 63) - 1ull;
-        acc += 6u + offbits[__builtin_popcountll(v)];
+WtPlainView plain_view(const vidc_wt *w) { return WtPlainView{w->d_bits.p, w->d_rank.p, w->words_per_level, w->blocks_per_level}; }
+RrrTab rrr_tab() {
+    RrrTab t;
+    for (int c = 0; c <= 63; c++) {  // ceil(log2(binom(63, c)))
+        long double lg = 0;
+        for (int i = 1; i <= c; i++) lg += log2l((long double)(63 - c + i)) - log2l((long double)i);
+        t.ow[c] = (uint8_t)ceill(lg - 1e-12L);
     }
-    atomicAdd(total, acc);
+    return t;
+}
+BvRrr rrr_view_level(const vidc_wt *w, uint32_t l) {
+    return BvRrr{w->d_cls.p + (uint64_t)l * w->rrr_cls_wpl, w->d_offs.p + w->rrr_off_base[l], w->d_ptr.p + (uint64_t)l * (w->rrr_nsamp + 1),
+                 w->d_rs.p + (uint64_t)l * (w->rrr_nsamp + 1), w->d_binom.p, rrr_tab(), w->rrr_nblk, w->rrr_nsamp, w->ntotal};
+}
+WtRrrView rrr_view(const vidc_wt *w) {
+    WtRrrView v{};
+    v.cls = w->d_cls.p; v.offs = w->d_offs.p; v.ptr = w->d_ptr.p; v.rs = w->d_rs.p; v.binom = w->d_binom.p;
+    v.cls_wpl = w->rrr_cls_wpl; v.nblk = w->rrr_nblk; v.nsamp = w->rrr_nsamp; v.nbits = w->ntotal;
+    for (uint32_t l = 0; l < w->L && l < 32; l++) v.off_base[l] = w->rrr_off_base[l];
+    v.tab = rrr_tab();
+    return v;
 }
 
 }  // namespace
@@ -290,10 +484,40 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
     w->blocks_per_level = (w->words_per_level + BLK_WORDS - 1) / BLK_WORDS;
     VIDC_TRY(w->d_C.alloc(nlist + 1));
     VIDC_HIP(hipMemcpyAsync(w->d_C.p, w->offsets.data(), (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    VIDC_TRY(w->d_bits.alloc(L * w->words_per_level));
-    VIDC_TRY(w->d_rank.alloc(L * (w->blocks_per_level + 1)));
-    VIDC_HIP(hipMemsetAsync(w->d_bits.p, 0, L * w->words_per_level * 8, ctx->stream));
-    Scratch s_a, s_b, s_err, s_tot, s_tab;
+    // wt_type 1 keeps one level of plain bits at a time (scratch) and the RRR coding of every level
+    const bool rrr = wt_type == 1;
+    if (rrr && L > 32) { set_error("wavelet tree: more than 32 levels"); return VIDC_ERR_UNSUPPORTED; }
+    Scratch s_a, s_b, s_err, s_lvl_bits, s_lvl_rank, s_width, s_bitpos, s_scan, s_offs_tmp;
+    const uint64_t nblk = (nt + RRR_B - 1) / RRR_B, nsamp = (nblk + RRR_K - 1) / RRR_K;
+    const RrrTab tab = rrr_tab();
+    if (!rrr) {
+        VIDC_TRY(w->d_bits.alloc(L * w->words_per_level));
+        VIDC_TRY(w->d_rank.alloc(L * (w->blocks_per_level + 1)));
+        VIDC_HIP(hipMemsetAsync(w->d_bits.p, 0, L * w->words_per_level * 8, ctx->stream));
+    } else {
+        w->rrr_nblk = nblk; w->rrr_nsamp = nsamp;
+        w->rrr_cls_wpl = (6 * nblk + 31) / 32 + 1;
+        VIDC_TRY(w->d_cls.alloc(L * w->rrr_cls_wpl));
+        VIDC_TRY(w->d_ptr.alloc(L * (nsamp + 1)));
+        VIDC_TRY(w->d_rs.alloc(L * (nsamp + 1)));
+        VIDC_HIP(hipMemsetAsync(w->d_cls.p, 0, L * w->rrr_cls_wpl * 4, ctx->stream));
+        VIDC_TRY(s_lvl_bits.get(ctx, w->words_per_level * 8));
+        VIDC_TRY(s_lvl_rank.get(ctx, (w->blocks_per_level + 1) * 4));
+        VIDC_TRY(s_width.get(ctx, (nblk + 1) * 4));
+        VIDC_TRY(s_bitpos.get(ctx, (nblk + 1) * 8));
+        // worst case of a level's offset stream: 61 bits per block (transient; the object keeps the exact size)
+        VIDC_TRY(s_offs_tmp.get(ctx, (size_t)L * (w->words_per_level + 1) * 8));
+        VIDC_HIP(hipMemsetAsync(s_offs_tmp.p, 0, (size_t)L * (w->words_per_level + 1) * 8, ctx->stream));
+        std::vector<uint64_t> bn(64 * 64, 0);
+        for (int n = 0; n < 64; n++) {
+            bn[n * 64] = 1;
+            for (int k = 1; k <= n; k++) bn[n * 64 + k] = (n ? bn[(n - 1) * 64 + k - 1] : 0) + (k <= n - 1 ? bn[(n - 1) * 64 + k] : 0);
+        }
+        VIDC_TRY(w->d_binom.alloc(64 * 64));
+        VIDC_HIP(hipMemcpyAsync(w->d_binom.p, bn.data(), 64 * 64 * 8, hipMemcpyHostToDevice, ctx->stream));
+        VIDC_HIP(hipStreamSynchronize(ctx->stream));  // (bn leaves scope)
+        w->rrr_off_base.assign(L + 1, 0);
+    }
     VIDC_TRY(s_a.get(ctx, (nt ? nt : 1) * 4));
     VIDC_TRY(s_b.get(ctx, (nt ? nt : 1) * 4));
     VIDC_TRY(s_err.get(ctx, 4));
@@ -315,9 +539,11 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
         return VIDC_ERR_DOMAIN;
     }
     uint32_t *cur = s_a.as<uint32_t>(), *nxt = s_b.as<uint32_t>();
+    std::vector<uint64_t> lvl_bits(L, 0);  // wt_type 1: bits of every level's offset stream
     for (uint32_t level = 0; level < L && nt; level++) {
-        uint64_t *bits = w->d_bits.p + (uint64_t)level * w->words_per_level;
-        uint32_t *rank = w->d_rank.p + (uint64_t)level * (w->blocks_per_level + 1);
+        uint64_t *bits = rrr ? s_lvl_bits.as<uint64_t>() : w->d_bits.p + (uint64_t)level * w->words_per_level;
+        uint32_t *rank = rrr ? s_lvl_rank.as<uint32_t>() : w->d_rank.p + (uint64_t)level * (w->blocks_per_level + 1);
+        if (rrr) VIDC_HIP(hipMemsetAsync(bits, 0, w->words_per_level * 8, ctx->stream));
         hipLaunchKernelGGL(k_wt_bits, dim3(grid), dim3(256), 0, ctx->stream, cur, nt, L - 1 - level, bits,
                            (nt + 63) / 64);
         hipLaunchKernelGGL(k_wt_rankdir, dim3(1), dim3(1024), 0, ctx->stream, bits, w->words_per_level,
@@ -328,30 +554,37 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
             std::swap(cur, nxt);
         }
         VIDC_HIP(hipGetLastError());
-    }
-    // size accounting: plain = bits + rank directory; rrr = class/offset model of rrr_vector<63>
-    uint64_t plain = (uint64_t)L * (((nt + 63) / 64) * 8 + (w->blocks_per_level + 1) * 4) + (nlist + 1) * 8;
-    w->size_bytes = plain;
-    if (wt_type == 1 && nt) {
-        uint8_t tab[64];
-        for (int c = 0; c <= 63; c++) {  // ceil(log2(binom(63, c)))
-            long double lg = 0;
-            for (int i = 1; i <= c; i++) lg += log2l((long double)(63 - c + i)) - log2l((long double)i);
-            tab[c] = (uint8_t)ceill(lg - 1e-12L);
+        if (rrr) {  // code this level: classes -> offset widths -> bit positions (scan) -> offsets, samples
+            const uint32_t bgrid = (uint32_t)std::min<uint64_t>((nblk + 255) / 256 + 1, (uint64_t)ctx->num_cu * 32);
+            uint64_t *otmp = s_offs_tmp.as<uint64_t>() + (size_t)level * (w->words_per_level + 1);
+            hipLaunchKernelGGL(k_rrr_classes, dim3(bgrid), dim3(256), 0, ctx->stream, bits, nblk, tab,
+                               w->d_cls.p + (uint64_t)level * w->rrr_cls_wpl, s_width.as<uint32_t>());
+            VIDC_TRY(device_exscan(ctx, s_width.as<uint32_t>(), (uint32_t)nblk, s_bitpos.as<uint64_t>(), s_scan));
+            hipLaunchKernelGGL(k_rrr_offsets, dim3(bgrid), dim3(256), 0, ctx->stream, bits, nblk, tab, w->d_binom.p,
+                               s_bitpos.as<uint64_t>(), (unsigned long long *)otmp);
+            hipLaunchKernelGGL(k_rrr_samples, dim3((uint32_t)std::min<uint64_t>(nsamp / 256 + 1, 4096)), dim3(256), 0, ctx->stream,
+                               bits, rank, nt, nblk, nsamp, s_bitpos.as<uint64_t>(), w->d_ptr.p + (uint64_t)level * (nsamp + 1),
+                               w->d_rs.p + (uint64_t)level * (nsamp + 1));
+            VIDC_HIP(hipGetLastError());
+            VIDC_HIP(hipMemcpyAsync(&lvl_bits[level], s_bitpos.as<uint64_t>() + nblk, 8, hipMemcpyDeviceToHost, ctx->stream));
+            VIDC_HIP(hipStreamSynchronize(ctx->stream));  // (the scratch of the level is reused by the next one)
         }
-        VIDC_TRY(s_tab.get(ctx, 64));
-        VIDC_TRY(s_tot.get(ctx, 8));
-        VIDC_HIP(hipMemcpyAsync(s_tab.p, tab, 64, hipMemcpyHostToDevice, ctx->stream));
-        VIDC_HIP(hipMemsetAsync(s_tot.p, 0, 8, ctx->stream));
-        for (uint32_t level = 0; level < L; level++)
-            hipLaunchKernelGGL(k_wt_rrr_bits, dim3(grid), dim3(256), 0, ctx->stream,
-                               w->d_bits.p + (uint64_t)level * w->words_per_level, nt, s_tab.as<uint8_t>(),
-                               s_tot.as<unsigned long long>());
-        unsigned long long tot = 0;
-        VIDC_HIP(hipMemcpyAsync(&tot, s_tot.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-        VIDC_HIP(hipStreamSynchronize(ctx->stream));
-        const uint64_t nblk = (nt + 62) / 63;
-        w->size_bytes = (tot + 7) / 8 + (uint64_t)L * ((nblk + 31) / 32) * 16 + (nlist + 1) * 8;
+    }
+    if (rrr) {  // the exact-size offset streams, level after level (+ one pad word each: two-word reads)
+        for (uint32_t level = 0; level < L; level++) w->rrr_off_base[level + 1] = w->rrr_off_base[level] + (lvl_bits[level] + 63) / 64 + 1;
+        VIDC_TRY(w->d_offs.alloc(w->rrr_off_base[L] ? w->rrr_off_base[L] : 1));
+        for (uint32_t level = 0; level < L && nt; level++)
+            VIDC_HIP(hipMemcpyAsync(w->d_offs.p + w->rrr_off_base[level], s_offs_tmp.as<uint64_t>() + (size_t)level * (w->words_per_level + 1),
+                                    (w->rrr_off_base[level + 1] - w->rrr_off_base[level]) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    // size accounting = what the object holds: plain bits + rank directory, or the RRR arrays (packed classes,
+    // offset streams, samples); + the symbol start table
+    if (!rrr) {
+        w->size_bytes = (uint64_t)L * (((nt + 63) / 64) * 8 + (w->blocks_per_level + 1) * 4) + (nlist + 1) * 8;
+    } else {
+        uint64_t off_bits = 0;
+        for (uint32_t level = 0; level < L; level++) off_bits += lvl_bits[level];
+        w->size_bytes = (off_bits + 7) / 8 + (uint64_t)L * ((6 * nblk + 7) / 8) + (uint64_t)L * (nsamp + 1) * 8 + (nlist + 1) * 8;
     }
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
@@ -381,9 +614,13 @@ int vidc_wt_select(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint64_t *
     VIDC_TRY(s_l.get(ctx, m * 8)); VIDC_TRY(s_o.get(ctx, m * 8)); VIDC_TRY(s_r.get(ctx, m * 8));
     VIDC_HIP(hipMemcpyAsync(s_l.p, list_nos, m * 8, hipMemcpyHostToDevice, ctx->stream));
     VIDC_HIP(hipMemcpyAsync(s_o.p, offs, m * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_wt_select, dim3((uint32_t)std::min<uint64_t>((m + 127) / 128, 1u << 16)), dim3(128), 0,
-                       ctx->stream, w->d_bits.p, w->d_rank.p, w->d_C.p, w->words_per_level, w->blocks_per_level,
-                       (uint32_t)w->nlist, w->L, m, s_l.as<uint64_t>(), s_o.as<uint64_t>(), s_r.as<int64_t>());
+    const dim3 sgrid((uint32_t)std::min<uint64_t>((m + 127) / 128, 1u << 16));
+    if (w->wt_type == 1)
+        hipLaunchKernelGGL(k_wt_select<WtRrrView>, sgrid, dim3(128), 0, ctx->stream, rrr_view(w), w->d_C.p, (uint32_t)w->nlist,
+                           w->L, m, s_l.as<uint64_t>(), s_o.as<uint64_t>(), s_r.as<int64_t>());
+    else
+        hipLaunchKernelGGL(k_wt_select<WtPlainView>, sgrid, dim3(128), 0, ctx->stream, plain_view(w), w->d_C.p,
+                           (uint32_t)w->nlist, w->L, m, s_l.as<uint64_t>(), s_o.as<uint64_t>(), s_r.as<int64_t>());
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipMemcpyAsync(ids_out, s_r.p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
@@ -408,9 +645,13 @@ int vidc_wt_decode_lists(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint
     VIDC_HIP(hipMemcpyAsync(s_l.p, list_nos, m * 8, hipMemcpyHostToDevice, ctx->stream));
     VIDC_HIP(hipMemcpyAsync(s_o.p, out_offsets, (m + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_wt_decode_lists, dim3((uint32_t)std::min<uint64_t>((total + 127) / 128, 1u << 16)), dim3(128), 0,
-                       ctx->stream, w->d_bits.p, w->d_rank.p, w->d_C.p, w->words_per_level, w->blocks_per_level, w->L, m,
-                       s_l.as<uint64_t>(), s_o.as<uint64_t>(), total, d_out);
+    const dim3 dgrid((uint32_t)std::min<uint64_t>((total + 127) / 128, 1u << 16));
+    if (w->wt_type == 1)
+        hipLaunchKernelGGL(k_wt_decode_lists<WtRrrView>, dgrid, dim3(128), 0, ctx->stream, rrr_view(w), w->d_C.p, w->L, m,
+                           s_l.as<uint64_t>(), s_o.as<uint64_t>(), total, d_out);
+    else
+        hipLaunchKernelGGL(k_wt_decode_lists<WtPlainView>, dgrid, dim3(128), 0, ctx->stream, plain_view(w), w->d_C.p, w->L, m,
+                           s_l.as<uint64_t>(), s_o.as<uint64_t>(), total, d_out);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
@@ -427,8 +668,12 @@ int vidc_wt_decode_all(vidc_ctx *ctx, const vidc_wt *w, uint64_t *d_out) {
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     const uint32_t grid = (uint32_t)std::min<uint64_t>((w->ntotal + 255) / 256, (uint64_t)ctx->num_cu * 32);
     if (w->L == 0) {  // one list: ids 0..ntotal-1 in order (the per-id kernel handles it)
-        hipLaunchKernelGGL(k_wt_decode_all, dim3(grid), dim3(128), 0, ctx->stream, w->d_bits.p, w->d_rank.p, w->d_C.p,
-                           w->words_per_level, w->blocks_per_level, (uint32_t)w->nlist, w->L, w->ntotal, d_out);
+        if (w->wt_type == 1)
+            hipLaunchKernelGGL(k_wt_decode_all<WtRrrView>, dim3(grid), dim3(128), 0, ctx->stream, rrr_view(w), w->d_C.p,
+                               (uint32_t)w->nlist, w->L, w->ntotal, d_out);
+        else
+            hipLaunchKernelGGL(k_wt_decode_all<WtPlainView>, dim3(grid), dim3(128), 0, ctx->stream, plain_view(w), w->d_C.p,
+                               (uint32_t)w->nlist, w->L, w->ntotal, d_out);
     } else {
         Scratch s_a, s_b;  // ping-pong (id, symbol prefix) arrays
         if (w->L > 1) {
@@ -437,17 +682,24 @@ int vidc_wt_decode_all(vidc_ctx *ctx, const vidc_wt *w, uint64_t *d_out) {
         }
         const WtItem *in = nullptr;
         for (uint32_t level = 0; level < w->L; level++) {
-            const uint64_t *b = w->d_bits.p + (uint64_t)level * w->words_per_level;
-            const uint32_t *r = w->d_rank.p + (uint64_t)level * (w->blocks_per_level + 1);
-            if (level + 1 == w->L) {
-                hipLaunchKernelGGL(k_wt_decode_level<true>, dim3(grid), dim3(256), 0, ctx->stream, in, (WtItem *)nullptr,
-                                   d_out, b, r, w->d_C.p, w->ntotal, (uint32_t)w->nlist, w->L, level);
+            const bool last = level + 1 == w->L;
+            WtItem *out = last ? nullptr : ((level & 1u) ? s_b.as<WtItem>() : s_a.as<WtItem>());
+            uint64_t *oid = last ? d_out : nullptr;
+            if (w->wt_type == 1) {
+                const BvRrr bv = rrr_view_level(w, level);
+                if (last) hipLaunchKernelGGL((k_wt_decode_level<true, BvRrr>), dim3(grid), dim3(256), 0, ctx->stream, in, out, oid, bv,
+                                             w->d_C.p, w->ntotal, (uint32_t)w->nlist, w->L, level);
+                else hipLaunchKernelGGL((k_wt_decode_level<false, BvRrr>), dim3(grid), dim3(256), 0, ctx->stream, in, out, oid, bv,
+                                        w->d_C.p, w->ntotal, (uint32_t)w->nlist, w->L, level);
             } else {
-                WtItem *out = (level & 1u) ? s_b.as<WtItem>() : s_a.as<WtItem>();
-                hipLaunchKernelGGL(k_wt_decode_level<false>, dim3(grid), dim3(256), 0, ctx->stream, in, out,
-                                   (uint64_t *)nullptr, b, r, w->d_C.p, w->ntotal, (uint32_t)w->nlist, w->L, level);
-                in = out;
+                const BvPlain bv{w->d_bits.p + (uint64_t)level * w->words_per_level,
+                                 w->d_rank.p + (uint64_t)level * (w->blocks_per_level + 1), w->blocks_per_level, w->words_per_level};
+                if (last) hipLaunchKernelGGL((k_wt_decode_level<true, BvPlain>), dim3(grid), dim3(256), 0, ctx->stream, in, out, oid, bv,
+                                             w->d_C.p, w->ntotal, (uint32_t)w->nlist, w->L, level);
+                else hipLaunchKernelGGL((k_wt_decode_level<false, BvPlain>), dim3(grid), dim3(256), 0, ctx->stream, in, out, oid, bv,
+                                        w->d_C.p, w->ntotal, (uint32_t)w->nlist, w->L, level);
             }
+            in = out;
         }
         VIDC_HIP(hipGetLastError());
         VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
