@@ -1100,11 +1100,30 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 hipLaunchKernelGGL((k_roc_decode_gen<uint16_t, true>), dim3(b.nwork), dim3(64), 512 * 2 + 512 * VIDC_DEC_CAP * 4, st_,
                                    b, 512u, VIDC_DEC_CAP);
                 break;
-            case DC_LANE:  // 6.5 KiB of LDS per wavefront
+            case DC_LANE: {  // 12.5 KiB of LDS per wavefront
                 b.lpw = lane_lists_per_wave(ctx, b.nwork, 24);
-                hipLaunchKernelGGL(k_roc_decode_lane<64>, dim3((b.nwork + b.lpw - 1u) / b.lpw), dim3(64), 0, st_, b,
-                                   (const LaneDiv *)ctx->d_ltab);
+                // lists are sorted longest first: those of <= 256 ids (the tail of the work list, from a wavefront
+                // boundary on) take the decoder that keeps the decoded ids in registers
+                uint32_t n_big = b.nwork;
+                if (!std::getenv("VIDC_NO_LANE_REG") && !p.wl.empty()) {
+                    const uint32_t *wl0 = p.wl.data() + base[c];
+                    n_big = (uint32_t)(std::partition_point(wl0, wl0 + b.nwork, [&](uint32_t l) {
+                                           return r->offsets[l + 1] - r->offsets[l] > VIDC_LANE_REG_MAX;
+                                       }) - wl0);
+                    n_big = std::min<uint32_t>(b.nwork, (n_big + b.lpw - 1u) / b.lpw * b.lpw);
+                }
+                RocDecArgs b2 = b;
+                b2.worklist = b.worklist + n_big; b2.nwork = b.nwork - n_big;
+                if (b2.out_off) b2.out_off += n_big;
+                b.nwork = n_big;
+                if (b.nwork)
+                    hipLaunchKernelGGL(k_roc_decode_lane<64>, dim3((b.nwork + b.lpw - 1u) / b.lpw), dim3(64), 0, st_, b,
+                                       (const LaneDiv *)ctx->d_ltab);
+                if (b2.nwork)
+                    hipLaunchKernelGGL(k_roc_decode_lane_reg<VIDC_LANE_REG_EL>, dim3((b2.nwork + b2.lpw - 1u) / b2.lpw), dim3(64), 0, st_,
+                                       b2, (const LaneDiv *)ctx->d_ltab);
                 break;
+            }
             case DC_LANE64:  // 20.5 KiB
                 b.lpw = lane_lists_per_wave(ctx, b.nwork, 7);
                 hipLaunchKernelGGL(k_roc_decode_lane<256>, dim3((b.nwork + b.lpw - 1u) / b.lpw), dim3(64), 0, st_, b,

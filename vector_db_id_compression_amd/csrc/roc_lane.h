@@ -19,6 +19,7 @@
 // wave-per-list kernels, which handle every case.
 #pragma once
 #include "roc_kernels.h"
+#include "roc_lane_reg_asm.h"
 
 namespace vidc {
 namespace dev {
@@ -543,6 +544,146 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
     }
     if (have) {
         retry |= (st.err & 4u) != 0u;
+        const bool clean = (head == VIDC_RANS_L) && (st.otop - st.al + st.d == st.draws - draws0);
+        a.end_state[l] = (clean || retry) ? 0u : 1u;
+        a.status[l] = retry ? VIDC_ST_RETRY : ((st.err & 2u) ? VIDC_ST_MT : VIDC_ST_OK);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// decoder for lists of 65 .. 256 ids per lane with NOTHING in global memory but the stored stream and the output: the
+// ids decoded so far sit in the lane's own registers (slot i = the id of step i, 0xffffffff while empty) and the rank
+// of x is the number of slots below x -- two VALU instructions per slot (the sign of slot - x is shifted into a bit
+// string, one popcount per 16 slots), in blocks of 16 entered by a computed jump at the highest block that holds an id (roc_lane_reg_asm.h; the step
+// counter is wave-uniform, so slot i is one register for the whole wavefront, written with s_set_gpr_idx).  The 192
+// slots are pinned to v64..v255; slots from 192 on live in an LDS strip.  The bucket kernel above paid one random 64-byte row read and
+// a row write-back per step (881 MB fetched + 657 MB written for 134 MB of ids on 65 536 x 256; a step took 3.5 us with
+// every list in flight at once); here a step is issue-bound: ~2 i + 120 instructions.
+#define VIDC_LANE_REG_MAX 256u
+#ifndef VIDC_LANE_REG_EL
+#define VIDC_LANE_REG_EL 192  // slots in registers (the rest of the 256 in LDS)
+#endif
+template <int EL>
+struct LaneRegGeom {
+    static constexpr uint32_t TAIL = VIDC_LANE_REG_MAX - EL;          // slots kept in LDS
+    static constexpr uint32_t TAIL_BYTES = TAIL * 64 * 4;             // uint4 tail4[TAIL / 4][64]
+    static constexpr uint32_t RING_BYTES = 8 * 64 * 4;
+    static constexpr uint32_t WIN_BYTES = VIDC_DWIN * 64 * 4;
+    static constexpr uint32_t PST_BYTES = VIDC_DPST * 64 * 4;
+    static constexpr uint32_t LQ_BYTES = (VIDC_LANE_REG_MAX + 4) * 4;  // floor(2^31 / d), d = 0 .. 256 (a load per step otherwise)
+    static constexpr uint32_t LDS_BYTES = TAIL_BYTES + RING_BYTES + WIN_BYTES + PST_BYTES + LQ_BYTES;
+};
+template <int EL>
+__global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const LaneDiv *__restrict__ dtab) {
+    static_assert(EL == 192, "the rank asm is generated for 192 slots in v64..v255");
+    using G = LaneRegGeom<EL>;
+    __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
+    const uint32_t lane = lane_id();
+    uint4 *tail4 = (uint4 *)smem + lane;                       // chunk c of this lane at tail4[c * 64]
+    uint32_t *tail1 = (uint32_t *)smem + lane * 4u;            // slot s: tail1[(s >> 2) * 256 + (s & 3)]
+    uint32_t *oring = (uint32_t *)(smem + G::TAIL_BYTES);
+    const uint32_t lpw = a.lpw ? a.lpw : 64u;
+    const uint32_t wi = blockIdx.x * lpw + lane;
+    const bool have = lane < lpw && wi < a.nwork;
+    const uint32_t l = have ? a.worklist[wi] : 0u;
+    const uint32_t n = have ? (uint32_t)(a.offsets[l + 1] - a.offsets[l]) : 0u;
+    const uint64_t ooff = have ? (a.out_off ? a.out_off[wi] : a.offsets[l]) : 0ull;
+    const uint32_t P = have ? a.prec[l] : 0u;
+    const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
+#pragma unroll
+    for (uint32_t c = 0; c < G::TAIL / 4u; c++) tail4[c * 64u] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    uint32_t *lqs = (uint32_t *)(smem + G::TAIL_BYTES + G::RING_BYTES + G::WIN_BYTES + G::PST_BYTES);
+    for (uint32_t d = lane; d <= VIDC_LANE_REG_MAX; d += 64u) lqs[d] = dtab[d].w;
+    v32u e0, e1, e2, e3, e4, e5;  // slots 0..191, pinned to v64..v255 by the asm statements below
+#pragma unroll
+    for (int k = 0; k < 32; k++) e0[k] = e1[k] = e2[k] = e3[k] = e4[k] = e5[k] = 0x7fffffffu;  // empty: slot - x >= 0
+
+    LWStack st;
+    st.ring = (uint32_t *)(smem + G::TAIL_BYTES + G::RING_BYTES) + lane;
+    st.pst = (uint32_t *)(smem + G::TAIL_BYTES + G::RING_BYTES + G::WIN_BYTES) + lane;
+    lw_init(st, have, a.words, have ? a.word_off[l] : 0ull, have ? a.nwords[l] : 0u);
+    st.mt = a.mt;
+    st.draws = have ? a.draws[l] : 0u;
+    const uint32_t draws0 = st.draws;
+    uint64_t head = have ? a.heads[l] : VIDC_RANS_L;
+    const uint32_t nsteps = wave_max_u32(n);
+
+    wave_sync();
+    // the look-ahead load of the stream window is issued at the END of a step, ahead of the step's output stores, and
+    // lands at the end of the next one: a load issued behind the stores would wait for their write acknowledgements
+    uint4 pf = make_uint4(0, 0, 0, 0);
+    bool pf_go = false;
+    // rank of xx among the ids decoded in steps 0 .. i-1
+    auto rank_of = [&](uint32_t xx, uint32_t i) __attribute__((always_inline)) -> uint32_t {
+        uint32_t r = 0;
+        const uint32_t nb = i >= (uint32_t)EL ? (uint32_t)EL / 16u : (i + 15u) >> 4;  // register blocks holding an id
+        const uint32_t jmp = 12u + VIDC_LREG_BLOCK_BYTES * ((uint32_t)EL / 16u - nb) + (nb <= 8u ? VIDC_LREG_FLUSH_BYTES : 0u);
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, t0, t1, t2, t3;
+        asm volatile(VIDC_LREG_RANK_ASM
+                     : [r] "+v"(r), [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [t0] "=&v"(t0),
+                       [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), "+{v[64:95]}"(e0), "+{v[96:127]}"(e1),
+                       "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4), "+{v[224:255]}"(e5)
+                     : [x] "v"(xx), [jmp] "s"(jmp)
+                     : "s28", "s29", "scc");
+        if (i > (uint32_t)EL) {  // uniform: the LDS strip
+            const uint32_t nch = (i - (uint32_t)EL + 3u) >> 2;
+            for (uint32_t c = 0; c < nch; c++) {
+                const uint4 v = tail4[c * 64u];
+                r += (v.x < xx) + (v.y < xx) + (v.z < xx) + (v.w < xx);
+            }
+        }
+        return r;
+    };
+    for (uint32_t i = 0; i < nsteps; i++) {
+        const uint32_t lq = lqs[i + 1u];  // uniform: floor(2^31 / (i + 1))
+        const bool act = i < n;
+        uint32_t x = 0;
+        if (act) {
+            // ---- x = ID_pop(P), codec.cpp:107-121
+            if (__builtin_expect(l_lt_2p31(head), 0)) {
+                (void)l_u_pop(head, st, 0u);
+                (void)l_u_pop(head, st, 0u);
+            }
+            const uint32_t hi = l_u_pop(head, st, p1);
+            const uint32_t lo = l_u_pop(head, st, p0);
+            x = (hi << 16) | lo;
+        }
+        const uint32_t r = rank_of(x, i);
+        if (act) {
+            // ---- IDX_push(r, i + 1), codec.cpp:44-63
+            uint64_t h0 = head;
+            if ((uint32_t)(h0 >> 32) >= lq) {
+                ls_push(st, (uint32_t)h0);
+                h0 >>= 32;
+            }
+            uint64_t h = h0 * (uint64_t)(i + 1u) + r;
+            if (__builtin_expect(l_lt_2p31(h), 0)) h = (uint64_t)ls_pop(st) | (h << 32);
+            head = h;
+        }
+        if (act) oring[(i & 7u) * 64u + lane] = x;
+        // ---- slot i = x (lanes past their list only overwrite an empty slot they never read again)
+        if (i < (uint32_t)EL) {
+            asm volatile("s_set_gpr_idx_on %[i], gpr_idx(DST)\n\tv_mov_b32 v64, %[x]\n\ts_set_gpr_idx_off"
+                         : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                           "+{v[224:255]}"(e5)
+                         : [x] "v"(x), [i] "s"(i));
+        } else if (act) {
+            const uint32_t sidx = i - (uint32_t)EL;
+            tail1[(sidx >> 2) * 256u + (sidx & 3u)] = x;
+        }
+        lw_land(st, pf_go, pf);
+        pf_go = act && lw_issue(st, pf);
+        if ((i & 7u) == 7u || i + 1u == nsteps) {  // uniform: flush the ring (steps s0 .. i)
+            const uint32_t s0 = i & ~7u;
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) {
+                const uint32_t sstep = s0 + k;
+                if (sstep <= i && sstep < n) a.out[ooff + (n - 1u - sstep)] = (uint64_t)oring[k * 64u + lane];
+            }
+        }
+    }
+    if (have) {
+        const bool retry = (st.err & 4u) != 0u;
         const bool clean = (head == VIDC_RANS_L) && (st.otop - st.al + st.d == st.draws - draws0);
         a.end_state[l] = (clean || retry) ? 0u : 1u;
         a.status[l] = retry ? VIDC_ST_RETRY : ((st.err & 2u) ? VIDC_ST_MT : VIDC_ST_OK);
