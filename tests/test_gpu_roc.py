@@ -285,7 +285,7 @@ def force_lane(monkeypatch):
 def test_lane_kernels_boundaries_vs_oracle(roc, oracle, force_lane):
     """Sizes around every class boundary of the lane-per-list kernels, several universes, one call."""
     rng = np.random.default_rng(77)
-    sizes = [65, 66, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 767, 768, 769, 1000, 1023, 1024, 1025, 1100,
+    sizes = [65, 66, 80, 81, 96, 97, 127, 128, 129, 191, 192, 193, 194, 208, 209, 255, 256, 257, 300, 511, 512, 513, 767, 768, 769, 1000, 1023, 1024, 1025, 1100,
              1279, 1280, 1281, 2047, 2048, 2049, 3071, 3072, 3073, 3840, 4000, 4095, 4096, 4097, 4200]
     for nbits in (11, 16, 20, 24, 31):
         sz = [s for s in sizes if s <= (1 << nbits)]
@@ -293,6 +293,35 @@ def test_lane_kernels_boundaries_vs_oracle(roc, oracle, force_lane):
         r = roc.encode(off, ids, want_perm=True)
         dec = r.decode_all().cpu().numpy().view(np.uint64)
         _check_against_oracle(oracle, r, off, lists, r.perm(), dec)
+
+
+def test_lane_register_decoder_matches_bucket_decoder(roc, oracle, force_lane, monkeypatch):
+    """Lists of 65..256 ids decode with the ids in registers (k_roc_decode_lane_reg: 192 register slots + an LDS strip);
+    VIDC_NO_LANE_REG=1 sends them to the bucket-row decoder instead.  Ragged sizes inside one wavefront, several
+    universes (dense 9-bit lists pop the stream window fastest), the decoded order must be the same and the oracle's."""
+    rng = np.random.default_rng(81)
+    for nbits in (9, 13, 24, 31):
+        sizes = rng.integers(65, 257, 700)
+        sizes[:8] = [256, 256, 193, 192, 191, 65, 255, 129]
+        off, ids, lists = _random_lists(rng, sizes, nbits=nbits)
+        r = roc.encode(off, ids)
+        monkeypatch.delenv("VIDC_NO_LANE_REG", raising=False)
+        dec = r.decode_all().cpu().numpy().view(np.uint64)
+        assert r.last_decode_nonclean == 0
+        monkeypatch.setenv("VIDC_NO_LANE_REG", "1")
+        dec2 = r.decode_all().cpu().numpy().view(np.uint64)
+        monkeypatch.delenv("VIDC_NO_LANE_REG", raising=False)
+        assert np.array_equal(dec, dec2)
+        sub = list(range(12)) + [int(v) for v in rng.integers(0, len(lists), 20)]
+        for l in sub:
+            li = lists[l]
+            e = oracle.roc_encode(li, oracle.list_precision(li))
+            want = oracle.roc_decode(e["head"], e["words"], li.size, oracle.list_precision(li), e["mt_draws"])[0]
+            assert np.array_equal(dec[int(off[l]):int(off[l + 1])], want), (nbits, l)
+        got, goff = r.decode_lists(np.array(sub, dtype=np.uint64))
+        got = got.cpu().numpy().view(np.uint64)
+        for k, l in enumerate(sub):
+            assert np.array_equal(got[int(goff[k]):int(goff[k + 1])], dec[int(off[l]):int(off[l + 1])])
 
 
 def test_lane_kernels_dense_and_small_precision(roc, oracle, force_lane):
