@@ -17,10 +17,17 @@ from vector_db_id_compression_amd.codecs import RocLists  # noqa: E402
 MODES = {"u2": {"VIDC_OLD_U": "0", "VIDC_FORCE_GENERAL": "0"},
          "u1": {"VIDC_OLD_U": "1", "VIDC_FORCE_GENERAL": "0"},
          "general": {"VIDC_OLD_U": "0", "VIDC_FORCE_GENERAL": "1"}}
+# third argument "wide": universes 2^21 .. 2^31 -- the position-bitmap chain kernel (k_roc_encode_r2) against the general
+# kernels (VIDC_NO_R2=1: through the normal classes, VIDC_FORCE_GENERAL=1: everything) and the oracle
+WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"
+if WIDE:
+    MODES = {"u2": {"VIDC_NO_R2": "", "VIDC_FORCE_GENERAL": "0"},
+             "u1": {"VIDC_NO_R2": "1", "VIDC_FORCE_GENERAL": "0"},
+             "general": {"VIDC_NO_R2": "", "VIDC_FORCE_GENERAL": "1"}}
 
 
 def make_batch(rng):
-    nbits = int(rng.integers(13, 21))
+    nbits = int(rng.integers(21, 32)) if WIDE else int(rng.integers(13, 21))
     nlist = int(rng.integers(1, 6))
     lists = []
     for _ in range(nlist):

@@ -79,6 +79,7 @@ static_assert(VIDC_LANE_MAX64 == VIDC_LANE_TAB, "divisor table size");
 // (measured crossover ~8 000 lists of 65..1024 ids, ~2 000 tiny lists); smaller calls -- e.g. the few hundred lists
 // a search touches -- keep the latency-optimised wave-per-list kernels.  Test hooks: VIDC_NO_LANE=1 (never),
 // VIDC_FORCE_LANE=1 (always); both families produce the same bits.
+constexpr uint64_t R2_MIN_LIST = 4096;  // shorter lists: the general kernel (its chain is not on anybody's critical path)
 constexpr uint64_t LANE_MIN_LISTS = 8192, LANE_MIN_LISTS64 = 8192, LANE_MIN_TINY = 2048;  // 64: lists of 1025..4096 ids
 enum LanePolicy { LANE_NEVER = 0, LANE_AUTO = 1, LANE_ALWAYS = 2 };
 inline LanePolicy lane_policy() {
@@ -99,6 +100,10 @@ inline bool lane_wanted(LanePolicy p, uint64_t nlists, uint64_t min_lists) {
 inline uint32_t lane_lists_per_wave(const vidc_ctx *, uint32_t, uint32_t) {
     static const int forced = [] { const char *e = std::getenv("VIDC_LPW"); return e ? std::atoi(e) : 0; }();
     return (forced == 8 || forced == 16 || forced == 32) ? (uint32_t)forced : 64u;
+}
+inline bool env_on(const char *name) {  // set, not empty, not "0"
+    const char *e = std::getenv(name);
+    return e && *e && !(e[0] == '0' && !e[1]);
 }
 inline bool old_u_kernels() {
     const char *e = getenv("VIDC_OLD_U");
@@ -367,7 +372,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     HostTrace tr("roc encode");
     // work lists: tiny (n <= 64), universe-bitmap kernels (ids < 2^18 / 2^20), general kernels by bitmap depth,
     // lane-per-list kernels
-    std::vector<uint32_t> wl_tiny, wl_u18, wl_u20, wl_c1, wl_c2, wl_c3, wl_l4, wl_l16, wl_l64;
+    std::vector<uint32_t> wl_tiny, wl_u18, wl_u20, wl_c1, wl_c2, wl_c3, wl_l4, wl_l16, wl_l64, wl_r2;
     const bool want_perm = (flags & VIDC_ROC_WANT_PERM) && !rows;
     const uint64_t ntotal_in = rows ? N * K : (nlist ? offsets[nlist] : 0);
     const bool f_general = force_general();  // getenv once, not per list
@@ -551,6 +556,22 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 for (auto *w : ws) sort_desc(*w, r->offsets);
             }
         }
+        // The longest general lists (any precision) take the position-bitmap chain kernel (k_roc_encode_r2: 0.33 instead
+        // of 0.48 us per step) -- as many as are resident at once (32 KiB of LDS each), longest first; the rest stay on
+        // the general kernel, which packs six times as many chains per CU and wins on throughput.
+        if (!f_general && !old_u_kernels() && !env_on("VIDC_NO_R2")) {
+            const size_t cap = (size_t)ctx->num_cu * 4;
+            auto take = [&](std::vector<uint32_t> &w) {
+                size_t k = 0;
+                while (k < w.size() && wl_r2.size() < cap && r->offsets[w[k] + 1] - r->offsets[w[k]] > R2_MIN_LIST) {
+                    wl_r2.push_back(w[k]);
+                    k++;
+                }
+                w.erase(w.begin(), w.begin() + (ptrdiff_t)k);
+            };
+            take(wl_c3);
+            if (wl_c3.empty()) take(wl_c2);
+        }
         tr.mark("sort work lists");
     }
     VIDC_TRY(s_arena.get(ctx, arena_words * 4));
@@ -560,13 +581,13 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     const uint32_t *d_wl = nullptr;
     if (!rows) {
         size_t total = 0;
-        for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64}) {
+        for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64, &wl_r2}) {
             base.push_back(total);
             total += w->size();
         }
         VIDC_TRY(h_wl.get(ctx, total * 4));
         size_t k = 0;
-        for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64}) {
+        for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64, &wl_r2}) {
             if (!w->empty()) std::memcpy(h_wl.as<uint32_t>() + k, w->data(), w->size() * 4);
             k += w->size();
         }
@@ -574,7 +595,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         if (total) VIDC_HIP(hipMemcpyAsync(s_wl.p, h_wl.p, total * 4, hipMemcpyHostToDevice, ctx->stream));
         d_wl = s_wl.as<uint32_t>();
     } else {
-        base.assign(9, 0);
+        base.assign(10, 0);
     }
 
     RocEncArgs a{};
@@ -636,6 +657,14 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             }
             VIDC_HIP(hipGetLastError());
             VIDC_HIP(hipEventRecord(ctx->ev_chain[1], ctx->stream));
+        }
+        if (!wl_r2.empty()) {
+            RocEncArgs b = a;
+            b.worklist = d_wl + base[9]; b.nwork = (uint32_t)wl_r2.size();
+            const U2Div *dt = (const U2Div *)ctx->d_u2tab;
+            if (want_perm) hipLaunchKernelGGL((k_roc_encode_r2<true>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, ctx->stream, b, dt);
+            else hipLaunchKernelGGL((k_roc_encode_r2<false>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, ctx->stream, b, dt);
+            VIDC_HIP(hipGetLastError());
         }
         // the deepest class: prefix rows sized for its longest list (first of the work list).  With the fixed
         // 48 KiB layout a CU held 3 of these chains; lists up to 65 536 ids need 12 KiB (S2 encode 152 -> see DESIGN)

@@ -577,6 +577,253 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
 
 
 // ===============================================================================================================
+// The same encode loop for ids of ANY precision (P <= 31): k_roc_encode_r2.  The alive set is a bitmap over the
+// POSITIONS 0 .. n-1 of the (ascending) list instead of over the id universe -- n <= 262 144, so the 18-bit geometry
+// (32 KiB of LDS) always fits -- and the id of the selected position comes from the input array with one scalar load
+// per step (s_load_dword: the address is wave-uniform; the input is never written, so the scalar cache is coherent).
+// Everything else is the loop above: head' = B(q) + c(id), the division of B in the select's windows, reversed
+// counters, branch-free renormalisation.  Differences: the fix-up remainder is a full 32-bit multiply (q^ no longer
+// fits 24 bits: c(id) < 2^31), the order ring holds positions (= the sampling permutation itself, no
+// k_perm_from_order pass), and the load sits on the chain: the step's tail (order ring, row write-back, exit tests)
+// runs in its shadow.  The kernel verifies what it assumes (ascending, ids < 2^31) and computes the precision from
+// the list's own maximum like the general kernel; anything else goes back as VIDC_ST_PENDING_SORT.
+//   additional registers: s[36:37] input ids of the list (u64 each)   s39 id of the previously selected position
+#define U2_ENC_TOP_R \
+    "1:\n" \
+    "v_lshrrev_b32_e64 v14, 16, s39\n"                 /* id_hi */ \
+    "v_bfe_u32 v15, s39, 0, 16\n"                      /* id_lo */ \
+    "v_add_u32 v16, v48, v14\n"                        /* s = r_B + id_hi */ \
+    "v_mad_u32_u24 v16, v15, s41, v16\n"               /*   + id_lo * mul   (< 2^32) */ \
+    "v_mul_hi_u32 v17, v16, v10\n"                     /* q^ = mulhi(s, 2^32 / d) in {Q - 1, Q} */ \
+    "v_mul_lo_u32 v18, v17, v9\n" \
+    "v_sub_u32 v18, v16, v18\n"                        /* r = s - q^ d in [0, 2d) */ \
+    "v_sub_u32 v19, v18, v9\n" \
+    "v_min_u32 v52, v18, v19\n"                        /* k (of this lane's divisor) */ \
+    "v_ashrrev_i32 v27, 31, v19\n"                     /* -1 if r < d */ \
+    "v_add3_u32 v20, v17, v27, 1\n"                    /* qf = q^ + (r >= d) */ \
+    "v_readlane_b32 s42, v52, s69\n"                   /* k of the step */ \
+    "v_add_co_u32_e64 v50, s[78:79], v46, v20\n"       /* q = head div d (per lane) */ \
+    "v_addc_co_u32_e64 v51, s[78:79], 0, v47, s[78:79]\n" \
+    "v_mov_b32 v12, s42\n" \
+    "v_cmp_le_u32 vcc, v4, v12\n"                      /* level 1 */ \
+    "v_lshlrev_b64 v[22:23], s40, 1\n"                 /* removal of position x_{i-1} from the bitmap */ \
+    "v_bfi_b32 v24, v22, 0, s66\n" \
+    "v_readlane_b32 s50, v50, s69\n" \
+    "v_readlane_b32 s51, v51, s69\n" \
+    "v_bfi_b32 v25, v23, 0, s67\n" \
+    "v_mov_b32 v26, s65\n" \
+    "ds_write_b64 v26, v[24:25]\n" \
+    "s_ff1_i32_b64 s43, vcc\n" \
+    "s_set_gpr_idx_on s43, gpr_idx(SRC0)\n" \
+    "v_mov_b32 v13, v64\n"                             /* row L1 */ \
+    "s_set_gpr_idx_off\n" \
+    "s_and_b32 m0, s60, 63\n"                          /* slice 0 (codec.cpp:65-76), branch-free */ \
+    "s_cmp_ge_u32 s51, s73\n" \
+    "v_writelane_b32 v5, s50, m0\n" \
+    "s_cselect_b32 s52, s51, s50\n" \
+    "s_cselect_b32 s53, 0, s51\n" \
+    "s_addc_u32 s60, s60, 0\n" \
+    "s_lshl_b64 s[54:55], s[52:53], s76\n" \
+    "v_readlane_b32 s49, v4, s43\n" \
+    "v_subrev_u32 v27, s43, v2\n"                      /* lane - L1 */ \
+    "v_subrev_u32 v12, s49, v12\n" \
+    "v_cmp_le_u32 vcc, v13, v12\n"                     /* level 2 */ \
+    "v_ashrrev_i32 v27, 31, v27\n" \
+    "v_add_u32 v4, v4, v27\n"                          /* E1 -= 1 in lanes below L1 */ \
+    "s_ff1_i32_b64 s44, vcc\n" \
+    "s_lshl_b32 s45, s43, 6\n" \
+    "s_or_b32 s45, s45, s44\n"
+// the tail of the step: position x = s40, its id by a scalar load (s39) consumed by the slice word and the next step
+#define U2_ENC_BOT_R(ORDER, LSHR) \
+    "v_mbcnt_lo_u32_b32 v49, s66, 0\n" \
+    "v_mbcnt_hi_u32_b32 v49, s67, v49\n" \
+    "v_cmp_eq_u32 vcc, v49, v12\n"                     /* bit of the word */ \
+    "v_sub_u32 v48, s58, v48\n"                        /* r_B in [0, 2d) */ \
+    "s_and_b64 s[82:83], vcc, s[66:67]\n" \
+    "s_ff1_i32_b64 s48, s[82:83]\n" \
+    "s_or_b32 s40, s46, s48\n"                         /* position x */ \
+    "s_lshl_b32 s72, s40, 3\n" \
+    "s_load_dword s39, s[36:37], s72\n"                /* its id: low dword of ids[x] */ \
+    ORDER \
+    "s_set_gpr_idx_on s43, gpr_idx(DST)\n" \
+    "v_mov_b32 v64, v13\n" \
+    "s_set_gpr_idx_off\n" \
+    LSHR                                               /* next index pop must not renormalise (U2_SAFE_HI): s68 = B_lo >> 31 */ \
+    "s_add_u32 s68, s68, s59\n" \
+    "s_add_u32 s68, s68, -1\n" \
+    "s_cmp_ge_u32 s68, 0x7ff80000\n" \
+    "s_cselect_b32 s71, 0, s70\n" \
+    "s_sub_u32 s68, s60, s61\n"                        /* ring nearly full */ \
+    "s_cmp_ge_u32 s68, 62\n" \
+    "s_cselect_b32 s71, 0, s71\n" \
+    "s_add_u32 s69, s69, 1\n" \
+    "s_mov_b32 m0, s62\n" \
+    "s_waitcnt lgkmcnt(0)\n"                           /* the id (and the removal store of the step's top) */ \
+    "s_and_b32 s68, s39, 0xffff\n" \
+    "s_or_b32 s68, s68, s54\n" \
+    "v_writelane_b32 v5, s68, m0\n"                    /* word of the second slice (kept only if it renormalised) */ \
+    "s_cmp_lt_u32 s69, s71\n" \
+    "s_cbranch_scc1 1b\n"
+
+// one generic encode step in position space (rare path): codec.cpp:131-137; returns the position
+__device__ __forceinline__ uint32_t u2r_slow_step(uint64_t &head, WStack &st, uint32_t nmax, uint32_t &E1, v32u &ra, v32u &rb,
+                                                  uint64_t *bm, const uint64_t *ids, uint32_t p0, uint32_t p1, uint32_t &idv) {
+    using U = U2Geom<18>;
+    const uint32_t lane = lane_id();
+    ws_prepare(st);
+    const uint32_t lq = 0x80000000u / nmax;
+    uint32_t k = ans_idx_pop(head, st, nmax, lq * nmax, ~0ull / (uint64_t)nmax);
+    const uint32_t L1 = ff1(ballot(E1 <= k));
+    k -= rl(E1, L1);
+    uint32_t row = u2_row_get(ra, rb, L1);
+    const uint32_t L2 = ff1(ballot(row <= k));
+    k -= rl(row, L2);
+    const uint32_t e = L1 * 64u + L2;
+    const uint64_t W = rfl64(bm[e]);
+    const uint32_t b = ff1(ballot(mbcnt(W) == k) & W);
+    const uint32_t x = ((e ^ (U::NE - 1u)) << U::ESH) | b;
+    E1 -= lane < L1 ? 1u : 0u;
+    row -= lane < L2 ? 1u : 0u;
+    u2_row_set(ra, rb, L1, row);
+    bm[e] = W & ~(1ull << b);
+    wave_sync();
+    idv = rfl((uint32_t)ids[x]);
+    ans_id_push(head, st, idv, p0, p1);
+    return x;
+}
+
+template <bool WANT_ORDER>
+__global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div *__restrict__ dtab) {
+    using U = U2Geom<18>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *bm = (uint64_t *)smem;
+    const uint32_t lane = lane_id();
+    const uint32_t wi = blockIdx.x;
+    if (wi >= a.nwork) return;
+    const uint32_t l = rfl(a.worklist[wi]);
+    const uint64_t off = rfl64(a.offsets[l]);
+    const uint32_t n = rfl((uint32_t)(a.offsets[l + 1] - off));
+    const uint64_t *ids = a.ids + off;
+    // ---- the list: ascending, inside [0, 2^31); its maximum gives the precision (k_roc_encode_gen phase 0)
+    uint32_t mx = 0;
+    bool bad = false, unsorted = false;
+    for (uint32_t j0 = 0; j0 < n; j0 += 512u) {
+        uint64_t v[8], w[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            const uint32_t j = j0 + u * 64u + lane;
+            v[u] = j < n ? ids[j] : ~0ull;
+            w[u] = (j && j < n) ? ids[j - 1] : 0ull;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            const uint32_t j = j0 + u * 64u + lane;
+            if (j >= n) continue;
+            bad |= (v[u] >> 31) != 0;
+            if (j) unsorted |= w[u] >= v[u];
+            mx = (uint32_t)v[u] > mx ? (uint32_t)v[u] : mx;
+        }
+    }
+    if (ballot(bad)) {
+        if (lane == 0) a.status[l] = VIDC_ST_DOMAIN;
+        return;
+    }
+    const uint32_t maxid = wave_max_u32(mx);
+    const uint32_t P = precision_for(maxid, a.precision_mode);
+    // not ascending, or ids that do not fit the precision (explicit precision / the reference's power-of-two quirk): the
+    // general kernel's second pass
+    if (ballot(unsorted) || n > (1u << 18) || P > 31u || (P < 32u && (maxid >> P) != 0u)) {
+        if (lane == 0) a.status[l] = VIDC_ST_PENDING_SORT;
+        return;
+    }
+    // ---- alive bitmap over positions (reversed entry order, one 64-bit word per entry) + counters
+    for (uint32_t e = lane; e < U::NE; e += 64u) {
+        const uint32_t lo = e << 6;
+        const uint32_t c = lo >= n ? 0u : (n - lo >= 64u ? 64u : n - lo);
+        bm[e ^ (U::NE - 1u)] = c == 64u ? ~0ull : ((1ull << c) - 1ull);
+    }
+    if (lane == 0) { bm[U::NE] = 0; bm[U::NE + 1] = 0; }
+    wave_sync();
+    uint32_t E1;
+    v32u ra, rb;
+    u2_build_counts<18>(bm, E1, ra, rb);
+
+    const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? P - 16u : 0u;
+    WStack st;
+    {
+        const uint64_t ao = rfl64(arena_at(a, l));
+        ws_init_empty(st, a.arena + ao, rfl((uint32_t)(arena_at(a, l + 1) - ao)), a.mt, VIDC_MT_TABLE);
+    }
+    uint64_t head = VIDC_RANS_L;
+    uint32_t obuf = 0, obase = 0;
+    uint32_t *order = WANT_ORDER ? a.perm + off : nullptr;  // sampled POSITIONS: the permutation itself
+    const uint32_t T0 = 0x80000000u >> p0, T1 = 0x80000000u >> p1, MULN = 1u << p1;
+    const uint32_t l3off = 0u;
+
+    uint32_t nmax = n;  // divisor of the next step
+    while (nmax) {
+        if (st.sp - st.lo >= 62u) ws_spill32(st);
+        if (nmax < 3u || u2_needs_generic(head)) {
+            uint32_t idv;
+            const uint32_t x = u2r_slow_step(head, st, nmax, E1, ra, rb, bm, ids, p0, p1, idv);
+            if (WANT_ORDER) {
+                if (lane == 0) order[obase] = x;
+                obase++;
+            }
+            nmax--;
+            continue;
+        }
+        uint32_t s_x = 0, s_id = 0, s_mul = 0, s_t = 0, s_waddr = U::BITMAP_BYTES, s_D0 = rfl(nmax), s_left = rfl(nmax - 2u);
+        uint64_t s_w = 0, s_B = rfl64(head);
+        uint64_t z0 = 0, z1 = 0, z2 = 0;  // {value, 0} register pairs: the odd halves stay 0
+        uint64_t qh = 0;
+        uint32_t rr = 0;
+        st.sp = rfl(st.sp);
+        st.lo = rfl(st.lo);
+        st.err = rfl(st.err);
+        obase = rfl(obase);
+        const uint64_t idbase = rfl64((uint64_t)ids);
+        // clang-format off
+#define U2R_ENC_ASM(BODY)                                                                                                 \
+        asm volatile(BODY                                                                                                 \
+            : "+{v4}"(E1), "+{v5}"(st.win), "+{v6}"(obuf), "+{v[64:95]}"(ra), "+{v[96:127]}"(rb),                          \
+              "+{v[46:47]}"(qh), "+{v48}"(rr), "+{s40}"(s_x), "+{s39}"(s_id), "+{s41}"(s_mul), "+{s[58:59]}"(s_B),          \
+              "+{s60}"(st.sp), "+{s61}"(st.lo), "+{s65}"(s_waddr), "+{s[66:67]}"(s_w), "+{s69}"(s_t), "+{s85}"(s_D0),        \
+              "+{s86}"(s_left), "+{s87}"(obase), "+{s93}"(st.err), "+{v[20:21]}"(z0), "+{v[36:37]}"(z1), "+{v[40:41]}"(z2) \
+            : "{v2}"(lane), "{v3}"(l3off), "{s73}"(T0), "{s74}"(T1), "{s75}"(MULN), "{s76}"(p0), "{s77}"(p1),                \
+              "{s[88:89]}"(order), "{s[90:91]}"(st.mem), "{s92}"(st.cap), "{s[94:95]}"(dtab), "{s[36:37]}"(idbase)          \
+            : "memory", "vcc", "scc", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",  \
+              "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v38", "v39",\
+              "v42", "v43", "v44", "v45", "v49", "v50", "v51", "v52", "v54", "v55", "v56", "v57", "v58", "v59",                     \
+              "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57",\
+              "s62", "s63", "s64", "s68", "s70", "s71", "s72", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s96",       \
+              "s97", "s98", "s99")
+        if (WANT_ORDER) U2R_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP_R U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_R(U2_ENC_ORDER, "") U2_ENC_OUTER(U2_ORDER_FLUSH));
+        else U2R_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP_R U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_R("", "s_lshr_b32 s68, s58, 31\n") U2_ENC_OUTER(""));
+#undef U2R_ENC_ASM
+        // clang-format on
+        // ---- back to the plain state.  head = B + c(id); the position's bit leaves the bitmap
+        head = s_B + (uint64_t)((s_id & 0xffffu) * s_mul + (s_id >> 16));
+        bm[s_waddr >> 3] = s_w & ~(1ull << (s_x & 63u));
+        ws_window(st);
+        if (__builtin_expect((head >> 63) != 0ull, 0)) {
+            ws_prepare(st);
+            ans_u_push(head, st, 0u, 0u);
+            ans_u_push(head, st, 0u, 0u);
+        }
+        nmax = s_D0 - s_t;
+    }
+    ws_flush(st);
+    if (lane == 0) {
+        a.heads[l] = head;
+        a.prec[l] = P;
+        a.nwords[l] = st.sp;
+        a.draws[l] = st.draws;
+        a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
+    }
+}
+
+// ===============================================================================================================
 // Decode (codec.cpp:140-152): step i pops x (two 16-bit slices, high first), ranks it among the ids decoded so far,
 // pushes the rank as a uniform index over nmax = i + 1 and stores out[n - 1 - i] = x.
 //
