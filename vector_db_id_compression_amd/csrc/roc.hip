@@ -556,21 +556,36 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 for (auto *w : ws) sort_desc(*w, r->offsets);
             }
         }
-        // The longest general lists (any precision) take the position-bitmap chain kernel (k_roc_encode_r2: 0.33 instead
-        // of 0.48 us per step) -- as many as are resident at once (32 KiB of LDS each), longest first; the rest stay on
-        // the general kernel, which packs six times as many chains per CU and wins on throughput.
+        // The longest general lists (any precision) take the position-bitmap chain kernel (k_roc_encode_r2: 0.26 instead
+        // of 0.48 us per step alone) -- when ALL the chains that decide the call's duration fit on the machine at once with
+        // room to spare: at most two per CU (32 KiB of LDS and 233 VGPRs each), and only if no more than that many lists
+        // are at least half as long as the longest one.  On S2 (1754 lists of 32 769..65 536 ids) 1024 of these chains
+        // took the LDS the lane-per-list classes need and the call went from 78 to 117 ms: there the general kernel, which
+        // packs six times as many chains per CU, keeps all of them.
         if (!f_general && !old_u_kernels() && !env_on("VIDC_NO_R2")) {
-            const size_t cap = (size_t)ctx->num_cu * 4;
-            auto take = [&](std::vector<uint32_t> &w) {
-                size_t k = 0;
-                while (k < w.size() && wl_r2.size() < cap && r->offsets[w[k] + 1] - r->offsets[w[k]] > R2_MIN_LIST) {
-                    wl_r2.push_back(w[k]);
-                    k++;
+            const size_t cap = (size_t)ctx->num_cu * 2;
+            const std::vector<uint32_t> &top = !wl_c3.empty() ? wl_c3 : wl_c2;
+            if (!top.empty()) {
+                const uint64_t n_top = r->offsets[top[0] + 1] - r->offsets[top[0]];
+                size_t n_long = 0;
+                for (const std::vector<uint32_t> *w : {&wl_c3, &wl_c2})
+                    for (uint32_t l : *w) {
+                        if (2 * (r->offsets[l + 1] - r->offsets[l]) < n_top || n_long > cap) break;
+                        n_long++;
+                    }
+                if (n_long <= cap) {
+                    auto take = [&](std::vector<uint32_t> &w) {
+                        size_t k = 0;
+                        while (k < w.size() && wl_r2.size() < cap && r->offsets[w[k] + 1] - r->offsets[w[k]] > R2_MIN_LIST) {
+                            wl_r2.push_back(w[k]);
+                            k++;
+                        }
+                        w.erase(w.begin(), w.begin() + (ptrdiff_t)k);
+                    };
+                    take(wl_c3);
+                    if (wl_c3.empty()) take(wl_c2);
                 }
-                w.erase(w.begin(), w.begin() + (ptrdiff_t)k);
-            };
-            take(wl_c3);
-            if (wl_c3.empty()) take(wl_c2);
+            }
         }
         tr.mark("sort work lists");
     }
