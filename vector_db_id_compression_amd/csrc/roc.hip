@@ -869,13 +869,14 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
 // ---- decode planning: work items grouped by kernel class, each with private scratch
 // general decoder classes by LDS footprint of the fine prefix rows (2^fb u32, fb = lg(n) - 3): occupancy, not
 // arithmetic, bounds the general decoder when a batch has many mid-size lists
-enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_COUNT };
+enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_COUNT };
+constexpr size_t B2_CAP = 512;       // chains of k_roc_decode_b2 per call (two per CU of an MI355X: 1 MiB of member rows each)
 
 struct DecPlan {
     std::vector<uint32_t> wl;        // list numbers, grouped by class, longest first inside a class
     std::vector<uint32_t> item;      // index of each work item in the caller's request
-    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t sum_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t sum_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<uint64_t> scratch_off, slots_off;
     uint64_t scratch_words = 0, slots_words = 0;
     bool lean = false;               // graph rows, lane decoder: item k == request k, no scratch / offset arrays
@@ -900,7 +901,7 @@ inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general
 
 // lists[i] = list number of request item i (a list may appear more than once)
 void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool rows_flavour, DecPlan &p,
-                 bool allow_lane = true) {
+                 bool allow_lane = true, bool allow_b2 = true) {
     const bool f_general = force_general();
     const LanePolicy lpol = (allow_lane && !f_general) ? lane_policy() : LANE_NEVER;
     p.wl.clear(); p.item.clear(); p.scratch_off.clear(); p.slots_off.clear();
@@ -947,6 +948,37 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             for (uint32_t i : cls[c]) sorted[start[maxlen - len(i)]++] = i;
             cls[c].swap(sorted);
         }
+    }
+    // The longest general chains (precision above 20 bits) take k_roc_decode_b2 under the rule of the encoder's
+    // k_roc_encode_r2: only when every chain at least half as long as the longest one gets it (<= B2_CAP of them).
+    if (allow_b2 && !f_general && !rows_flavour && !old_u_kernels() && !env_on("VIDC_NO_R2")) {
+        const int order_[4] = {DC_GHUGE, DC_GMID, DC_G16K, DC_G8K};
+        uint64_t n_top = 0;
+        for (int c : order_)
+            if (!cls[c].empty()) { n_top = len(cls[c][0]); break; }
+        size_t n_long = 0;
+        bool stop = false;
+        for (int c : order_) {
+            for (uint32_t i : cls[c]) {
+                if (2 * len(i) < n_top || n_long > B2_CAP) { stop = true; break; }
+                n_long++;
+            }
+            if (stop) break;
+        }
+        if (n_top && n_long <= B2_CAP)
+            for (int c : order_) {
+                size_t k = 0;
+                // (beyond ~100 000 ids a 64-member row overflows too often: average bucket load n / 4096)
+                while (k < cls[c].size() && cls[DC_B2].size() < B2_CAP && len(cls[c][k]) <= 98304 && r->prec[lists[cls[c][k]]] >= 12 &&
+                       r->prec[lists[cls[c][k]]] <= 31) {
+                    cls[DC_B2].push_back(cls[c][k]);
+                    k++;
+                }
+                cls[c].erase(cls[c].begin(), cls[c].begin() + (ptrdiff_t)k);
+                if (!cls[c].empty()) break;  // (keeps the B2 list in descending order)
+            }
+    }
+    for (int c = 0; c < DC_COUNT; c++) {
         p.count[c] = cls[c].size();
         for (uint32_t i : cls[c]) {
             p.item.push_back(i); p.wl.push_back(lists[i]);
@@ -976,6 +1008,11 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
                 p.slots_off[k] = sl;
                 sl += 256ull * roc_lane_cap_nb<256>((uint32_t)n);
             } else if (c == DC_U18 || c == DC_U20) sl += n;  // duplicate side list
+            else if (c == DC_B2) {
+                sl = (sl + 63) & ~(uint64_t)63;  // 4096 rows of 64 members
+                p.slots_off[k] = sl;
+                sl += 4096ull * 64ull;
+            }
             else if (c == DC_GSMALL) sl += n;  // overflow list only: the member rows are in LDS
             else if (c > DC_GSMALL) {
                 uint32_t fb = roc_dec_fine_bits((uint32_t)n, r->prec[l] > 32 ? 32 : r->prec[l]);
@@ -1079,7 +1116,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         double est[DC_COUNT];
         for (int c = 0; c < DC_COUNT; c++) {
             order[c] = c;
-            const bool u = c == DC_U18 || c == DC_U20, lane = c == DC_LANE || c == DC_LANE64;
+            const bool u = c == DC_U18 || c == DC_U20 || c == DC_B2, lane = c == DC_LANE || c == DC_LANE64;
             // (constants fitted to the S2 timeline: general kernels ~2.5 G steps/s while they share the machine)
             const double step_us = u ? 0.4 : (lane ? 2.5 : (c == DC_TINY ? 0.5 : 1.2));       // one chain step
             const double rate = u ? 0.6e3 : (lane ? 16e3 : (c == DC_TINY ? 30e3 : 2.5e3));     // steps / us, all CUs
@@ -1173,6 +1210,9 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 hipLaunchKernelGGL(k_roc_decode_lane<256>, dim3((b.nwork + b.lpw - 1u) / b.lpw), dim3(64), 0, st_, b,
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
+            case DC_B2:
+                hipLaunchKernelGGL(k_roc_decode_b2, dim3(b.nwork), dim3(64), 0, st_, b, (const U2Div *)ctx->d_u2tab);
+                break;
             case DC_G8K:
                 hipLaunchKernelGGL(k_roc_decode_gen<uint16_t>, dim3(b.nwork), dim3(64), 1024 * 2, st_, b, 1024u, VIDC_DEC_CAP);
                 break;
@@ -1230,7 +1270,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
             // wave-per-list kernels, into the same output slots
             std::vector<uint32_t> lists2;
             std::vector<uint64_t> off2;
-            for (size_t k = base[DC_LANE]; k < base[DC_LANE] + p.count[DC_LANE] + p.count[DC_LANE64]; k++) {  // both lane classes
+            for (size_t k = base[DC_LANE]; k < base[DC_LANE] + p.count[DC_LANE] + p.count[DC_LANE64] + p.count[DC_B2]; k++) {  // lane classes + B2
                 if (status[p.wl[k]] != VIDC_ST_RETRY) continue;
                 lists2.push_back(p.wl[k]);
                 off2.push_back(out_off_host ? out_off_host[k] : r->offsets[p.wl[k]]);
@@ -1238,7 +1278,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
             for (uint32_t l : lists2) status[l] = VIDC_ST_OK;
             VIDC_TRY(check_status(status, "roc decode"));
             DecPlan p2;
-            plan_decode(r, lists2, false, p2, false);
+            plan_decode(r, lists2, false, p2, false, false);
             std::vector<uint64_t> out_off2(lists2.size());
             for (size_t k = 0; k < lists2.size(); k++) out_off2[k] = off2[p2.item[k]];
             VIDC_TRY(decode_impl(ctx, r, p2, out_off2.data(), d_out, nullptr, 0));

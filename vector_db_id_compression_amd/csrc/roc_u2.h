@@ -1145,5 +1145,192 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
     }
 }
 
+// ===============================================================================================================
+// The decode loop for ids of any precision 12 <= P <= 31: k_roc_decode_b2.  The bitmap over the id universe of
+// k_roc_decode_u2 becomes 4096 value buckets over the top 12 bits: the same reversed exclusive counters give the number
+// of decoded ids in smaller buckets, the members of x's bucket (<= 64, unsorted u32) sit in a row of global memory that
+// the wavefront reads with one load (lane j: member j) and compares with one v_cmp; the bucket sizes are u16 in LDS.
+// Members stored during the current 64-step block may not have reached memory yet: they are taken from the output
+// ring (lane t = the id of step t of the block) instead, and the row is only trusted up to the count it had when the
+// block began (the block change waits for the stores, as in k_roc_decode_gen).  A bucket that overflows its row
+// (skewed ids) flags the list: VIDC_ST_RETRY, the general kernel decodes it again.
+//   additional registers: s78 bucket shift (P - 12)  s79 overflow flag  s[80:81] scratch mask  s[82:83] member rows
+//   s48 bucket  s47 its size  s46 ring members below x  s64 ring members of the bucket, then all members below x
+//   v26 LDS address of the bucket size  v30 size  v31 row member of the lane  v33 buckets of the ring ids
+#define U2B_DEC_IDX \
+    "s_lshr_b32 s48, s40, s78\n"                       /* bucket */ \
+    "s_lshl_b32 s65, s48, 1\n" \
+    "v_mov_b32 v26, s65\n" \
+    "ds_read_u16 v30, v26\n"                           /* members of the bucket so far */ \
+    "s_lshl_b32 s47, s48, 8\n" \
+    "v_lshl_add_u32 v28, v2, 2, s47\n" \
+    "global_load_dword v31, v28, s[82:83]\n"           /* lane j: member j of the bucket's row */ \
+    "s_xor_b32 s45, s48, 0xfff\n"                      /* entry (reversed) */
+#define U2B_DEC_MID \
+    "s_lshr_b32 s43, s45, 6\n"                         /* L1 */ \
+    "s_and_b32 s44, s45, 63\n"                         /* L2 */ \
+    "s_set_gpr_idx_on s43, gpr_idx(SRC0)\n" \
+    "v_mov_b32 v13, v64\n" \
+    "s_set_gpr_idx_off\n" \
+    "v_lshrrev_b32 v33, s78, v6\n"                     /* buckets of the ids decoded in this block (output ring) */ \
+    "v_cmp_eq_u32 vcc, s48, v33\n" \
+    "v_cmp_gt_u32 s[66:67], s69, v2\n"                 /* ring lanes written in this block */ \
+    "v_cmp_gt_u32 s[80:81], s40, v6\n"                 /* ... holding an id below x */ \
+    "v_readlane_b32 s49, v4, s43\n"                    /* E1[L1] */ \
+    "v_readlane_b32 s63, v13, s44\n"                   /* row[L2] */ \
+    "v_readlane_b32 s62, v10, s69\n"                   /* lq of this step */ \
+    "v_subrev_u32 v58, s43, v2\n" \
+    "v_subrev_u32 v59, s44, v2\n" \
+    "v_ashrrev_i32 v59, 31, v59\n" \
+    "v_sub_u32 v13, v13, v59\n"                        /* row += 1 in lanes below L2 */ \
+    "s_and_b64 s[66:67], s[66:67], vcc\n"              /* members of the bucket that are still in flight */ \
+    "s_bcnt1_i32_b64 s64, s[66:67]\n" \
+    "s_and_b64 s[66:67], s[66:67], s[80:81]\n" \
+    "s_bcnt1_i32_b64 s46, s[66:67]\n"                  /* ... of them below x */ \
+    "s_and_b32 m0, s60, 63\n"                          /* index push, first half (codec.cpp:44-63): renormalise H */ \
+    "s_cmp_ge_u32 s59, s62\n" \
+    "v_writelane_b32 v5, s58, m0\n" \
+    "s_cselect_b32 s50, s59, s58\n" \
+    "s_cselect_b32 s51, 0, s59\n" \
+    "s_addc_u32 s60, s60, 0\n" \
+    "s_mul_i32 s52, s50, s75\n"                        /* H * nmax */ \
+    "s_mul_hi_u32 s53, s50, s75\n" \
+    "s_mul_i32 s68, s51, s75\n" \
+    "s_add_u32 s53, s53, s68\n" \
+    "s_add_u32 s72, s49, s63\n" \
+    "s_set_gpr_idx_on s43, gpr_idx(DST)\n" \
+    "v_mov_b32 v64, v13\n" \
+    "s_set_gpr_idx_off\n" \
+    "s_mov_b32 m0, s69\n"
+#define U2B_DEC_RANK \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
+    "v_readfirstlane_b32 s47, v30\n"                   /* members of the bucket */ \
+    "v_cmp_gt_u32 s[66:67], s40, v31\n"                /* row member below x */ \
+    "v_mov_b32 v27, s40\n" \
+    "s_sub_u32 s65, s47, s64\n"                        /* members visible in memory: not those of this block */ \
+    "v_cmp_gt_u32 vcc, s65, v2\n"                      /* the lane holds one of them */ \
+    "s_min_u32 s68, s47, 63\n"                         /* slot of x in the row */ \
+    "s_lshl_b32 s68, s68, 2\n" \
+    "s_lshl_b32 s65, s48, 8\n" \
+    "s_add_u32 s68, s68, s65\n" \
+    "v_mov_b32 v28, s68\n" \
+    "s_and_b64 vcc, vcc, s[66:67]\n" \
+    "s_bcnt1_i32_b64 s64, vcc\n" \
+    "s_add_u32 s64, s64, s46\n"                        /* members of the bucket below x */ \
+    "s_cmp_gt_u32 s47, 63\n" \
+    "s_cselect_b32 s68, 1, 0\n" \
+    "s_or_b32 s79, s79, s68\n"                         /* the row is full: the list is decoded again by the general kernel */ \
+    "s_add_u32 s47, s47, 1\n" \
+    "v_mov_b32 v32, s47\n" \
+    "s_mov_b64 exec, 1\n" \
+    "global_store_dword v28, v27, s[82:83]\n" \
+    "ds_write_b16 v26, v32\n" \
+    "s_mov_b64 exec, -1\n" \
+    U2_DEC_AFTER_RANK
+
+// one generic decode step on the bucket structure (rare path): codec.cpp:144-150
+__device__ __forceinline__ uint32_t u2b_slow_dec_step(uint64_t &head, WStack &st, uint32_t nmax, uint32_t &E1, v32u &ra, v32u &rb,
+                                                      uint16_t *cnt16, uint32_t *rows, uint32_t bsh, uint32_t p0, uint32_t p1,
+                                                      uint32_t &ovf) {
+    const uint32_t lane = lane_id();
+    ws_prepare(st);
+    const uint32_t x = ans_id_pop(head, st, p0, p1);
+    const uint32_t bkt = (x >> bsh) & 0xfffu;
+    const uint32_t e = bkt ^ 0xfffu, L1 = e >> 6, L2 = e & 63u;
+    uint32_t row = u2_row_get(ra, rb, L1);
+    uint32_t r = rl(E1, L1) + rl(row, L2);
+    const uint32_t c = rfl((uint32_t)cnt16[bkt]);
+    const uint32_t m = c < 64u ? c : 64u;
+    const uint32_t y = lane < m ? rows[bkt * 64u + lane] : 0xffffffffu;
+    r += popc64(ballot(lane < m && y < x));
+    ans_idx_push(head, st, r, nmax, 0x80000000u / nmax);
+    E1 += lane < L1 ? 1u : 0u;
+    row += lane < L2 ? 1u : 0u;
+    u2_row_set(ra, rb, L1, row);
+    if (c < 64u) {
+        if (lane == 0) rows[bkt * 64u + c] = x;
+    } else {
+        ovf |= 1u;
+    }
+    if (lane == 0) cnt16[bkt] = (uint16_t)(c + 1u);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the store is in memory before the loop reads rows again
+    wave_sync();
+    return x;
+}
+
+__global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div *__restrict__ dtab) {
+    __shared__ __align__(16) uint16_t cnt16[4096 + 8];
+    const uint32_t lane = lane_id();
+    const uint32_t wi = blockIdx.x;
+    if (wi >= a.nwork) return;
+    const uint32_t l = rfl(a.worklist[wi]);
+    const uint32_t n = rfl((uint32_t)(a.offsets[l + 1] - a.offsets[l]));
+    const uint64_t ooff = rfl64(a.out_off ? a.out_off[wi] : a.offsets[l]);
+    {
+        uint4 *z = (uint4 *)cnt16;
+        for (uint32_t w = lane; w < (4096u + 8u) * 2u / 16u; w += 64) z[w] = make_uint4(0, 0, 0, 0);
+    }
+    const uint32_t P = rfl(a.prec[l]);
+    const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
+    const uint32_t bsh = P > 12u ? P - 12u : 0u;
+    const uint32_t W0 = rfl(a.nwords[l]);
+    WStack st;
+    ws_init_loaded(st, a.words + rfl64(a.word_off[l]), W0, a.scratch_words + rfl64(a.scratch_off[wi]), roc_dec_stack_cap(n, W0),
+                   rfl(a.draws[l]), a.mt, VIDC_MT_TABLE);
+    const uint32_t draws0 = st.draws;
+    uint64_t head = rfl64(a.heads[l]);
+    uint32_t E1 = 0;
+    v32u ra, rb;
+#pragma unroll
+    for (int c = 0; c < 32; c++) { ra[c] = 0u; rb[c] = 0u; }
+    const uint32_t l3off = 0u;
+    const uint32_t M1 = (1u << p1) - 1u, M0 = (1u << p0) - 1u;
+    uint64_t *out = a.out + ooff;
+    uint32_t *rows = a.slots + rfl64(a.slots_off[wi]);
+    uint32_t ovf = 0;
+    wave_sync();
+
+    uint32_t i = 0;  // ids decoded so far
+    while (i < n) {
+        ws_prepare(st);
+        if (lt_2p31(head) || st.sp - st.lo < 2u || st.sp - st.lo > 61u) {  // generic step
+            const uint32_t x = u2b_slow_dec_step(head, st, i + 1u, E1, ra, rb, cnt16, rows, bsh, p0, p1, ovf);
+            if (lane == 0) out[n - 1u - i] = (uint64_t)x;
+            i++;
+            continue;
+        }
+        uint32_t s_t = 0, s_N0 = rfl(i + 1u), s_left = rfl(n - i), s_oidx = rfl(n - 1u - i), s_ovf = rfl(ovf);
+        uint64_t s_h = rfl64(head), oring = 0;
+        st.sp = rfl(st.sp);
+        st.lo = rfl(st.lo);
+        const uint64_t rowbase = rfl64((uint64_t)rows);
+        // clang-format off
+        asm volatile(U2_DEC_ENTRY U2_DEC_TOP U2B_DEC_IDX U2B_DEC_MID U2B_DEC_RANK U2_DEC_BOT U2_DEC_OUTER
+            : "+{v4}"(E1), "+{v5}"(st.win), "+{v[6:7]}"(oring), "+{v[64:95]}"(ra), "+{v[96:127]}"(rb),
+              "+{s[58:59]}"(s_h), "+{s60}"(st.sp), "+{s69}"(s_t), "+{s85}"(s_N0), "+{s86}"(s_left), "+{s87}"(s_oidx), "+{s79}"(s_ovf)
+            : "{v2}"(lane), "{v3}"(l3off), "{s61}"(st.lo), "{s73}"(M1), "{s74}"(M0), "{s76}"(p0), "{s77}"(p1),
+              "{s[88:89]}"(out), "{s[94:95]}"(dtab), "{s78}"(bsh), "{s[82:83]}"(rowbase)
+            : "memory", "vcc", "scc", "v10", "v13", "v26", "v27", "v28", "v30", "v31", "v32", "v33", "v34", "v35", "v36",
+              "v37", "v54", "v55", "v56", "v57", "v58", "v59", "s40", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",
+              "s51", "s52", "s53", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s70", "s71", "s72", "s75", "s80", "s81",
+              "s96", "s97", "s98", "s99");
+        // clang-format on
+        ovf = s_ovf;
+        head = s_h;
+        ws_window(st);
+        if (__builtin_expect(lt_2p31(head), 0)) {  // second half of the last index push (codec.cpp:59-61)
+            ws_prepare(st);
+            head = (uint64_t)ws_pop(st) | (head << 32);
+        }
+        i = s_N0 + s_t - 1u;
+    }
+    if (lane == 0) {
+        const bool retry = rfl(ovf) != 0u;
+        const bool clean = (head == VIDC_RANS_L) && (st.sp == st.draws - draws0);
+        a.end_state[l] = (clean || retry) ? 0u : 1u;
+        a.status[l] = retry ? 5u /* VIDC_ST_RETRY (roc_lane.h) */ : (st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK);
+    }
+}
+
 }  // namespace dev
 }  // namespace vidc
