@@ -178,6 +178,49 @@ def test_light_prepass_assumptions_are_checked_by_the_kernels(roc, oracle, monke
         _check_against_oracle(oracle, r, offd, [dup], r.perm() if want_perm else None, dec)
 
 
+def test_wide_precision_chain_kernels_match_general_kernels_and_oracle(roc, oracle, monkeypatch):
+    """Long lists whose ids need more than 20 bits take k_roc_encode_r2 (bitmap over list positions, id by scalar load)
+    and k_roc_decode_b2 (4096 value buckets, member rows in memory) when the call holds few of them; VIDC_NO_R2=1 keeps
+    them on the general kernels.  Streams, permutations and decoded order must not depend on it; a clustered list
+    overflows a 64-member bucket row and comes back through the retry pass."""
+    rng = np.random.default_rng(2024)
+    lists = [
+        np.sort(rng.choice(1 << 27, size=30000, replace=False)),
+        np.sort(rng.choice((1 << 31) - 1, size=9000, replace=False)),
+        np.sort(np.unique(np.concatenate([rng.choice(1 << 26, size=9000, replace=False),
+                                          (5 << 20) + rng.choice(1 << 10, size=600, replace=False)]))),  # 600 ids in one bucket
+        rng.choice(1 << 24, size=8000, replace=False),                                                  # unsorted
+        np.sort(rng.integers(0, 1 << 23, size=7000)),                                                   # duplicates
+        np.sort(rng.choice(1 << 21, size=4100, replace=False)),
+        np.sort(rng.choice(1 << 30, size=65536, replace=False)),
+    ]
+    lists = [li.astype(np.uint64) for li in lists]
+    off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
+    ids = np.concatenate(lists)
+    for want_perm in (True, False):
+        monkeypatch.delenv("VIDC_NO_R2", raising=False)
+        r = roc.encode(off, ids, want_perm=want_perm)
+        dec = r.decode_all().cpu().numpy().view(np.uint64)
+        monkeypatch.setenv("VIDC_NO_R2", "1")
+        r2 = roc.encode(off, ids, want_perm=want_perm)
+        dec_g = r.decode_all().cpu().numpy().view(np.uint64)   # the chain kernels' streams through the general decoder
+        dec2 = r2.decode_all().cpu().numpy().view(np.uint64)
+        monkeypatch.delenv("VIDC_NO_R2", raising=False)
+        i1, i2 = r.info(), r2.info()
+        for k in ("heads", "nwords", "precision", "mt_draws"):
+            assert np.array_equal(i1[k], i2[k]), (want_perm, k)
+        assert np.array_equal(r.all_words(), r2.all_words())
+        assert np.array_equal(dec, dec2) and np.array_equal(dec, dec_g)
+        if want_perm:
+            assert np.array_equal(r.perm(), r2.perm())
+        _check_against_oracle(oracle, r, off, lists, r.perm() if want_perm else None, dec)
+        sel = np.array([6, 2, 0], dtype=np.uint64)  # a search's decode_lists takes the same kernels
+        got, goff = r.decode_lists(sel)
+        got = got.cpu().numpy().view(np.uint64)
+        for k, l in enumerate(sel):
+            assert np.array_equal(got[int(goff[k]):int(goff[k + 1])], dec[int(off[int(l)]):int(off[int(l) + 1])])
+
+
 def test_exact_precision_mode_is_lossless_for_pow2_max(roc):
     """VIDC_PREC_EXACT fixes the reference's pow-2 precision quirk (Q3); reference mode reproduces it."""
     ids = np.array([3, 1024, 7, 100], dtype=np.uint64)

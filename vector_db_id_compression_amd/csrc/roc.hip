@@ -966,16 +966,15 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             if (stop) break;
         }
         if (n_top && n_long <= B2_CAP)
-            for (int c : order_) {
-                size_t k = 0;
-                // (beyond ~100 000 ids a 64-member row overflows too often: average bucket load n / 4096)
-                while (k < cls[c].size() && cls[DC_B2].size() < B2_CAP && len(cls[c][k]) <= 98304 && r->prec[lists[cls[c][k]]] >= 12 &&
-                       r->prec[lists[cls[c][k]]] <= 31) {
-                    cls[DC_B2].push_back(cls[c][k]);
-                    k++;
+            for (int c : order_) {  // longest first; a list that does not qualify stays where it is
+                std::vector<uint32_t> keep;
+                for (uint32_t i : cls[c]) {
+                    const uint32_t P = r->prec[lists[i]];
+                    // (beyond ~100 000 ids a 64-member row overflows too often: average bucket load n / 4096)
+                    if (cls[DC_B2].size() < B2_CAP && len(i) <= 98304 && P >= 12 && P <= 31) cls[DC_B2].push_back(i);
+                    else keep.push_back(i);
                 }
-                cls[c].erase(cls[c].begin(), cls[c].begin() + (ptrdiff_t)k);
-                if (!cls[c].empty()) break;  // (keeps the B2 list in descending order)
+                cls[c].swap(keep);
             }
     }
     for (int c = 0; c < DC_COUNT; c++) {
