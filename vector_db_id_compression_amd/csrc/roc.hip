@@ -965,13 +965,18 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             }
             if (stop) break;
         }
-        if (n_top && n_long <= B2_CAP)
+        size_t b2_cap = B2_CAP;
+        if (const char *e = std::getenv("VIDC_B2_CAP")) {  // measurements: take up to this many chains whatever the rule says
+            b2_cap = (size_t)std::atoll(e);
+            n_long = 0;
+        }
+        if (n_top && n_long <= b2_cap)
             for (int c : order_) {  // longest first; a list that does not qualify stays where it is
                 std::vector<uint32_t> keep;
                 for (uint32_t i : cls[c]) {
                     const uint32_t P = r->prec[lists[i]];
                     // (beyond ~100 000 ids a 64-member row overflows too often: average bucket load n / 4096)
-                    if (cls[DC_B2].size() < B2_CAP && len(i) <= 98304 && P >= 12 && P <= 31) cls[DC_B2].push_back(i);
+                    if (cls[DC_B2].size() < b2_cap && len(i) <= 98304 && P >= 12 && P <= 31) cls[DC_B2].push_back(i);
                     else keep.push_back(i);
                 }
                 cls[c].swap(keep);
