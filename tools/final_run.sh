@@ -10,6 +10,8 @@ VIDC_FORCE_LANE=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_
 VIDC_OLD_U=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_old_u.txt
 VIDC_FULL_PREPASS=1 VIDC_NO_LANE_REG=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_full_prepass_no_lane_reg.txt
 timeout 300 python tools/fuzz_chain.py 11 60 2>&1 | tail -1 > gpurun_out/$R/fuzz_chain.txt
+timeout 300 python tools/fuzz_chain.py 12 90 wide 2>&1 | tail -1 > gpurun_out/$R/fuzz_chain_wide.txt
+timeout 300 python tools/chain_probe.py 2>&1 | tail -6 > gpurun_out/$R/chain_probe.txt
 timeout 300 python tools/fuzz_families.py 31 90 2>&1 | tail -1 > gpurun_out/$R/fuzz_families.txt
 timeout 300 python tools/fuzz_ef_packed.py 31 40 2>&1 | tail -1 > gpurun_out/$R/fuzz_ef_packed.txt
 timeout 300 python tools/bench_wt.py 2>&1 | tail -4 > gpurun_out/$R/bench_wt.txt
@@ -28,7 +30,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/$R/prof_u16 -o u16 --
 python profiles/extract_rocprof.py gpurun_out/$R/prof_s1/s1_results.db gpurun_out/$R/bench_s1_kernel_stats.csv
 python profiles/extract_rocprof.py gpurun_out/$R/prof_u16/u16_results.db gpurun_out/$R/bench_uniform16m_kernel_stats.csv
 rm -rf gpurun_out/$R/prof_s1 gpurun_out/$R/prof_u16
-cat gpurun_out/$R/pytest_gpu.txt gpurun_out/$R/pytest_force_general.txt gpurun_out/$R/pytest_no_lane.txt gpurun_out/$R/pytest_force_lane.txt gpurun_out/$R/pytest_old_u.txt gpurun_out/$R/pytest_full_prepass_no_lane_reg.txt gpurun_out/$R/fuzz_chain.txt gpurun_out/$R/fuzz_families.txt gpurun_out/$R/fuzz_ef_packed.txt gpurun_out/$R/bench_wt.txt gpurun_out/$R/smoke.txt
+cat gpurun_out/$R/pytest_gpu.txt gpurun_out/$R/pytest_force_general.txt gpurun_out/$R/pytest_no_lane.txt gpurun_out/$R/pytest_force_lane.txt gpurun_out/$R/pytest_old_u.txt gpurun_out/$R/pytest_full_prepass_no_lane_reg.txt gpurun_out/$R/fuzz_chain.txt gpurun_out/$R/fuzz_chain_wide.txt gpurun_out/$R/chain_probe.txt gpurun_out/$R/fuzz_families.txt gpurun_out/$R/fuzz_ef_packed.txt gpurun_out/$R/bench_wt.txt gpurun_out/$R/smoke.txt
 python - <<PY
 import json
 for line in open("gpurun_out/$R/bench_other.jsonl"):
