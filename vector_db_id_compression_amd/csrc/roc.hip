@@ -1215,7 +1215,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
             case DC_B2:
-                hipLaunchKernelGGL(k_roc_decode_b2, dim3(b.nwork), dim3(64), 0, st_, b, (const U2Div *)ctx->d_u2tab);
+                hipLaunchKernelGGL(k_roc_decode_b2, dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
                 break;
             case DC_G8K:
                 hipLaunchKernelGGL(k_roc_decode_gen<uint16_t>, dim3(b.nwork), dim3(64), 1024 * 2, st_, b, 1024u, VIDC_DEC_CAP);

@@ -864,8 +864,15 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
         return sym;
     };
 
+    // the ids decoded so far also sit in 64 registers of the lane (slot i = step i, 0x7fffffff while empty): the rank
+    // is roc_lane_reg_asm.h's sign-bit count over the blocks of 16 slots in use instead of a scan of the LDS strip
+    // (one ds_read + three instructions per id)
+    v32u e0, e1;
+#pragma unroll
+    for (int k = 0; k < 32; k++) e0[k] = e1[k] = 0x7fffffffu;
     for (uint32_t i = 0; i < nsteps; i++) {
         const uint32_t lq = dtab[i + 1u].w;  // uniform: floor(2^31 / (i + 1))
+        uint32_t xs = 0;
         if (i < n_eff) {
             if (__builtin_expect(l_lt_2p31(head), 0)) {
                 (void)u_pop(0u);
@@ -874,16 +881,19 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
             const uint32_t hi = u_pop(p1);
             const uint32_t lo = u_pop(p0);
             const uint32_t x = (hi << 16) | lo;
+            xs = x;
             // rank among the i ids decoded so far (strictly smaller, fenwick_tree.h:42-94)
             uint32_t r = 0;
-            const uint32_t *top = buf + (VIDC_TINY_STRIP - 1u) * VIDC_TINY_LD + lane;
-            uint32_t e = 0;
-            for (; e + 4u <= i; e += 4u) {
-                const uint32_t v0 = top[-(int)(e * VIDC_TINY_LD)], v1 = top[-(int)((e + 1u) * VIDC_TINY_LD)],
-                               v2 = top[-(int)((e + 2u) * VIDC_TINY_LD)], v3 = top[-(int)((e + 3u) * VIDC_TINY_LD)];
-                r += (uint32_t)(v0 < x) + (uint32_t)(v1 < x) + (uint32_t)(v2 < x) + (uint32_t)(v3 < x);
+            {
+                const uint32_t nb = (i + 15u) >> 4;
+                const uint32_t jmp = 12u + VIDC_LREG_BLOCK_BYTES * (4u - nb);
+                uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, t0, t1, t2, t3;
+                asm volatile(VIDC_LREG64_RANK_ASM
+                             : [r] "+v"(r), [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [t0] "=&v"(t0),
+                               [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), "+{v[64:95]}"(e0), "+{v[96:127]}"(e1)
+                             : [x] "v"(x), [jmp] "s"(jmp)
+                             : "s28", "s29", "scc");
             }
-            for (; e < i; e++) r += (uint32_t)(top[-(int)(e * VIDC_TINY_LD)] < x);
             // IDX_push(r, i + 1), codec.cpp:44-63
             {
                 uint64_t h0 = head;
@@ -898,6 +908,10 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
             }
             if (sp + i < VIDC_TINY_STRIP) buf[(VIDC_TINY_STRIP - 1u - i) * VIDC_TINY_LD + lane] = x; else err |= 1u;
         }
+        // slot i = x (uniform register index; lanes past their list write an empty slot they never read)
+        asm volatile("s_set_gpr_idx_on %[i], gpr_idx(DST)\n\tv_mov_b32 v64, %[x]\n\ts_set_gpr_idx_off"
+                     : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1)
+                     : [x] "v"(xs), [i] "s"(i));
     }
     __syncthreads();
     // output, one list per iteration so that the stores are contiguous: decoded order == sampling order, the id

@@ -1258,8 +1258,12 @@ __device__ __forceinline__ uint32_t u2b_slow_dec_step(uint64_t &head, WStack &st
     return x;
 }
 
+#define VIDC_B2_LDS_BYTES ((4096u + 8u) * 2u)
 __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div *__restrict__ dtab) {
-    __shared__ __align__(16) uint16_t cnt16[4096 + 8];
+    // (dynamic LDS, the kernel's only allocation: the asm addresses the bucket sizes from LDS offset 0, like the bitmap of
+    // the u2 kernels)
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint16_t *cnt16 = (uint16_t *)smem;
     const uint32_t lane = lane_id();
     const uint32_t wi = blockIdx.x;
     if (wi >= a.nwork) return;
