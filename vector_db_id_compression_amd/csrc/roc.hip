@@ -846,11 +846,18 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         for (uint32_t l : wl_u18) if (!is_p[l]) ul.push_back(l);
         for (uint32_t l : wl_u20) if (!is_p[l]) ul.push_back(l);
         if (!ul.empty()) {
+            std::vector<uint32_t> items;  // (list, first id of the chunk) pairs
+            for (uint32_t l : ul)
+                for (uint64_t st0 = 0, n = r->offsets[l + 1] - r->offsets[l]; st0 < n; st0 += VIDC_PERM_CHUNK) {
+                    items.push_back(l);
+                    items.push_back((uint32_t)st0);
+                }
             Scratch s_ul;
-            VIDC_TRY(upload_scratch(ctx, s_ul, ul));
+            VIDC_TRY(upload_scratch(ctx, s_ul, items));
+            const uint32_t nitems = (uint32_t)(items.size() / 2);
             EventTimer t(ctx);
-            hipLaunchKernelGGL(k_perm_from_order, dim3((uint32_t)ul.size()), dim3(256), 0, ctx->stream, d_ids,
-                               r->d_offsets.p, s_ul.as<uint32_t>(), (uint32_t)ul.size(), r->d_perm.p);
+            hipLaunchKernelGGL(k_perm_from_order, dim3(std::min<uint32_t>(nitems, 1u << 20)), dim3(256), 0, ctx->stream, d_ids,
+                               r->d_offsets.p, s_ul.as<uint2>(), nitems, r->d_perm.p);
             VIDC_HIP(hipGetLastError());
             kernel_ms += t.stop();
         }

@@ -349,13 +349,17 @@ __global__ void __launch_bounds__(256) k_roc_prepass_last(const uint64_t *ids, c
 
 // order[] (sampled ids, written by the U encoder into the perm buffer) -> input positions, for lists whose
 // input is strictly ascending: position = index of the id in the list (binary search).
-__global__ void k_perm_from_order(const uint64_t *ids, const uint64_t *offsets, const uint32_t *lists, uint32_t nwork,
+// One workgroup per (list, chunk of VIDC_PERM_CHUNK ids): with a workgroup per LIST the 52 114-id list of S1 kept one
+// workgroup busy for 0.53 ms after the chain had finished (2 % of the step).
+#define VIDC_PERM_CHUNK 2048u
+__global__ void k_perm_from_order(const uint64_t *ids, const uint64_t *offsets, const uint2 *items, uint32_t nitems,
                                   uint32_t *perm) {
-    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const uint32_t l = lists[wi];
+    for (uint32_t wi = blockIdx.x; wi < nitems; wi += gridDim.x) {
+        const uint32_t l = items[wi].x, start = items[wi].y;
         const uint64_t off = offsets[l];
         const uint32_t n = (uint32_t)(offsets[l + 1] - off);
-        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+        const uint32_t end = start + VIDC_PERM_CHUNK < n ? start + VIDC_PERM_CHUNK : n;
+        for (uint32_t j = start + threadIdx.x; j < end; j += blockDim.x) {
             const uint64_t x = perm[off + j];
             uint32_t lo = 0, hi = n;
             while (hi - lo > 1) {
