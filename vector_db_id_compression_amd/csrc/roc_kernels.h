@@ -420,14 +420,19 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
                 const uint64_t W = rfl64(words[w]);
                 const uint32_t b = ff1(ballot(mbcnt(W) == k) & W);
                 const uint32_t j = (w << 6) + b;
-                const uint32_t xv = sid[j << sidsh];  // the only global load on the chain: issued first, consumed last
+                // the only global load on the chain: issued first, consumed last.  An ascending list is read from the
+                // input array (never written by this kernel): a scalar load (the address is wave-uniform), no v_readfirstlane
+                uint32_t xv = 0, xs = 0;
+                if (need_sort) xv = sid[j];
+                else asm volatile("s_load_dword %0, %1, %2" : "=s"(xs) : "s"(sid), "s"(j << 3) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 // remove (every lane stores the same word): runs in the shadow of the load
                 words[w] = W & ~(1ull << b);
                 if (RL > 1u && lane >= tsel && lane < RL) rowpref[(c << rlsh) + lane] = rowv - 1u;
                 P1 -= (lane >= c) ? 1u : 0u;
                 __builtin_amdgcn_sched_barrier(0);
-                const uint32_t x = rfl(xv);
+                if (!need_sort) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(xs) : : "memory");
+                const uint32_t x = need_sort ? rfl(xv) : xs;
                 ans_id_push(head, st, x, p0, p1);
                 if (want_perm) {
                     const uint32_t pos = need_sort ? rfl(spos[j]) : j;
