@@ -16,10 +16,10 @@ for c, name in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     db = glob.glob(f"gpurun_out/$R/pmc_{c}/*results.db")[0]
     pmc_summary(db, f"gpurun_out/$R/bench_s1_pmc_{name}.csv")
     cur = sqlite3.connect(db).cursor()
-    rows = list(cur.execute("select kernel_name, sum(value), count(*) from counters_collection where kernel_name like '%vidc::%' group by kernel_name"))
+    rows = list(cur.execute("select kernel_name, sum(value), count(*) from counters_collection where kernel_name like '%vidc::%' or kernel_name like '%(anonymous namespace)::k_%' group by kernel_name"))
     # 3 bench steps (1 warm-up + 2 timed) ran: per-step KiB = sum / 3
     out[name + "_KiB_per_step"] = sum(r[1] for r in rows) / 3.0
-    out[name + "_by_kernel_KiB_per_step"] = {r[0].split("(")[0][-40:]: r[1] / 3.0 for r in rows}
+    out[name + "_by_kernel_KiB_per_step"] = {(__import__("re").search(r"k_\w+(<[^>]*>)?", r[0]) or [r[0][:40]])[0]: r[1] / 3.0 for r in rows}
 print(json.dumps(out, indent=1))
 json.dump(out, open(f"gpurun_out/$R/pmc_traffic.json", "w"), indent=1)
 PY

@@ -12,9 +12,9 @@ out = {"workload": "$W", "codec": "$C", "steps_profiled": 2}
 for c, name in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     db = glob.glob(f"gpurun_out/$R/pmcw_{c}/*results.db")[0]
     cur = sqlite3.connect(db).cursor()
-    rows = list(cur.execute("select kernel_name, sum(value), count(*) from counters_collection where kernel_name like '%vidc::%' group by kernel_name"))
+    rows = list(cur.execute("select kernel_name, sum(value), count(*) from counters_collection where kernel_name like '%vidc::%' or kernel_name like '%(anonymous namespace)::k_%' group by kernel_name"))
     out[name + "_KiB_per_step"] = sum(r[1] for r in rows) / 2.0   # 1 warm-up + 1 timed step ran
-    out[name + "_by_kernel_KiB_per_step"] = {r[0].split("(")[0][-44:]: r[1] / 2.0 for r in sorted(rows, key=lambda r: -r[1])}
+    out[name + "_by_kernel_KiB_per_step"] = {(__import__("re").search(r"k_\w+(<[^>]*>)?", r[0]) or [r[0][:44]])[0]: r[1] / 2.0 for r in sorted(rows, key=lambda r: -r[1])}
 try:
     line = [l for l in open("gpurun_out/$R/pmcw_FETCH_SIZE.out") if l.startswith("{")][-1]
     d = json.loads(line)
