@@ -721,14 +721,14 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             if (w.empty()) continue;
             RocEncArgs b = a;
             b.worklist = d_wl + base[6 + cls]; b.nwork = (uint32_t)w.size();
-            // wavefronts a CU holds by LDS: 4-word strips 10.3 KiB, 16-word 14.5 KiB (the 32 / 64-word ones 5 / 3)
+            // (LDS per wavefront: 4-word strips 14.3 KiB, 16-word 21.5 KiB, 32-word 31.5 KiB, 64-word 50.5 KiB)
             b.lpw = lane_lists_per_wave(ctx, b.nwork, cls == 0 ? 15 : cls == 1 ? 11 : 4);
             const dim3 grid((b.nwork + b.lpw - 1u) / b.lpw);
             const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
             if (cls == 2) {
-                // lists are sorted longest first: the leading wavefronts need the 64-word strips (46.5 KiB of LDS,
+                // lists are sorted longest first: the leading wavefronts need the 64-word strips (50.5 KiB of LDS,
                 // 3 per CU), everything from the first wavefront whose longest list has <= 2048 ids the 32-word
-                // ones (27.5 KiB, 5 per CU)
+                // ones (31.5 KiB, 5 per CU)
                 uint32_t n_big = 0;
                 while (n_big < b.nwork && r->offsets[w[n_big] + 1] - r->offsets[w[n_big]] > 2048) n_big++;
                 n_big = std::min<uint32_t>(b.nwork, (n_big + b.lpw - 1u) / b.lpw * b.lpw);
@@ -1216,7 +1216,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                                        b2, (const LaneDiv *)ctx->d_ltab);
                 break;
             }
-            case DC_LANE64:  // 20.5 KiB
+            case DC_LANE64:  // 26.5 KiB of LDS per wavefront
                 b.lpw = lane_lists_per_wave(ctx, b.nwork, 7);
                 hipLaunchKernelGGL(k_roc_decode_lane<256>, dim3((b.nwork + b.lpw - 1u) / b.lpw), dim3(64), 0, st_, b,
                                    (const LaneDiv *)ctx->d_ltab);
