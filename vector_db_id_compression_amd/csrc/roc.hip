@@ -79,7 +79,7 @@ static_assert(VIDC_LANE_MAX64 == VIDC_LANE_TAB, "divisor table size");
 // (measured crossover ~8 000 lists of 65..1024 ids, ~2 000 tiny lists); smaller calls -- e.g. the few hundred lists
 // a search touches -- keep the latency-optimised wave-per-list kernels.  Test hooks: VIDC_NO_LANE=1 (never),
 // VIDC_FORCE_LANE=1 (always); both families produce the same bits.
-constexpr uint64_t R2_MIN_LIST = 4096;  // shorter lists: the general kernel (its chain is not on anybody's critical path)
+constexpr uint64_t R2_MIN_LIST = 256;   // shorter lists: the general kernel (the chain kernel's set-up -- 32 KiB bitmap, counters -- is ~10 us)
 constexpr uint64_t LANE_MIN_LISTS = 8192, LANE_MIN_LISTS64 = 8192, LANE_MIN_TINY = 2048;  // 64: lists of 1025..4096 ids
 enum LanePolicy { LANE_NEVER = 0, LANE_AUTO = 1, LANE_ALWAYS = 2 };
 inline LanePolicy lane_policy() {
@@ -556,19 +556,20 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 for (auto *w : ws) sort_desc(*w, r->offsets);
             }
         }
-        // The longest general lists (any precision) take the position-bitmap chain kernel (k_roc_encode_r2: 0.26 instead
-        // of 0.48 us per step alone) -- when ALL the chains that decide the call's duration fit on the machine at once with
-        // room to spare: at most two per CU (32 KiB of LDS and 233 VGPRs each), and only if no more than that many lists
-        // are at least half as long as the longest one.  On S2 (1754 lists of 32 769..65 536 ids) 1024 of these chains
-        // took the LDS the lane-per-list classes need and the call went from 78 to 117 ms: there the general kernel, which
-        // packs six times as many chains per CU, keeps all of them.
+        // The longest general lists (any precision, more than 256 ids) take the position-bitmap chain kernel
+        // (k_roc_encode_r2: 0.26 instead of 0.48 us per step alone) -- when ALL the chains that decide the call's duration
+        // fit on the machine at once: at most four per CU (32 KiB of LDS and 233 VGPRs each), and only if no more than that
+        // many lists are at least half as long as the longest one.  1024 lists of 977 ids: encode 0.51 -> 0.35 ms; 256 x
+        // 3900: 1.75 -> 1.07; 1024 x 6000: 3.9 -> 2.5.  On S2 (1754 lists of 32 769..65 536 ids) 1024 of these chains took
+        // the LDS the lane-per-list classes need and the call went from 78 to 117 ms: there the general kernel, which packs
+        // six times as many chains per CU, keeps all of them.
         if (!f_general && !old_u_kernels() && !env_on("VIDC_NO_R2")) {
-            const size_t cap = (size_t)ctx->num_cu * 2;
-            const std::vector<uint32_t> &top = !wl_c3.empty() ? wl_c3 : wl_c2;
+            const size_t cap = (size_t)ctx->num_cu * 4;
+            const std::vector<uint32_t> &top = !wl_c3.empty() ? wl_c3 : (!wl_c2.empty() ? wl_c2 : wl_c1);
             if (!top.empty()) {
                 const uint64_t n_top = r->offsets[top[0] + 1] - r->offsets[top[0]];
                 size_t n_long = 0;
-                for (const std::vector<uint32_t> *w : {&wl_c3, &wl_c2})
+                for (const std::vector<uint32_t> *w : {&wl_c3, &wl_c2, &wl_c1})
                     for (uint32_t l : *w) {
                         if (2 * (r->offsets[l + 1] - r->offsets[l]) < n_top || n_long > cap) break;
                         n_long++;
@@ -584,6 +585,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                     };
                     take(wl_c3);
                     if (wl_c3.empty()) take(wl_c2);
+                    if (wl_c3.empty() && wl_c2.empty()) take(wl_c1);
                 }
             }
         }
@@ -877,7 +879,8 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
 // general decoder classes by LDS footprint of the fine prefix rows (2^fb u32, fb = lg(n) - 3): occupancy, not
 // arithmetic, bounds the general decoder when a batch has many mid-size lists
 enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_COUNT };
-constexpr size_t B2_CAP = 512;       // chains of k_roc_decode_b2 per call (two per CU of an MI355X: 1 MiB of member rows each)
+constexpr uint64_t B2_MIN_LIST = 4096;
+constexpr size_t B2_CAP = 1024;      // chains of k_roc_decode_b2 per call (four per CU of an MI355X: 1 MiB of member rows each)
 
 struct DecPlan {
     std::vector<uint32_t> wl;        // list numbers, grouped by class, longest first inside a class
@@ -983,7 +986,10 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
                 for (uint32_t i : cls[c]) {
                     const uint32_t P = r->prec[lists[i]];
                     // (beyond ~100 000 ids a 64-member row overflows too often: average bucket load n / 4096)
-                    if (cls[DC_B2].size() < b2_cap && len(i) <= 98304 && P >= 12 && P <= 31) cls[DC_B2].push_back(i);
+                    // (shorter than B2_MIN_LIST: the general decoder keeps the member rows of such a list in LDS, while 1 MiB of
+                    // sparse rows per list -- 1 GiB for a thousand lists -- makes every step of this kernel an HBM miss:
+                    // 1024 x 977 ids decoded in 0.53 instead of 0.50 ms)
+                    if (cls[DC_B2].size() < b2_cap && len(i) <= 98304 && len(i) > B2_MIN_LIST && P >= 12 && P <= 31) cls[DC_B2].push_back(i);
                     else keep.push_back(i);
                 }
                 cls[c].swap(keep);
