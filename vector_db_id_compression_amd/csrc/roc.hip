@@ -679,8 +679,11 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             RocEncArgs b = a;
             b.worklist = d_wl + base[9]; b.nwork = (uint32_t)wl_r2.size();
             const U2Div *dt = (const U2Div *)ctx->d_u2tab;
-            if (want_perm) hipLaunchKernelGGL((k_roc_encode_r2<true>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, ctx->stream, b, dt);
-            else hipLaunchKernelGGL((k_roc_encode_r2<false>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, ctx->stream, b, dt);
+            // (behind a 20-bit bitmap launch on the main stream these chains would only start when that one has finished:
+            // S1 encode 12.5 -> 13.5 ms; they go to the first auxiliary stream then)
+            hipStream_t st_r2 = wl_u20.empty() ? ctx->stream : ctx->aux[0];
+            if (want_perm) hipLaunchKernelGGL((k_roc_encode_r2<true>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, st_r2, b, dt);
+            else hipLaunchKernelGGL((k_roc_encode_r2<false>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, st_r2, b, dt);
             VIDC_HIP(hipGetLastError());
         }
         // the deepest class: prefix rows sized for its longest list (first of the work list).  With the fixed
@@ -878,15 +881,15 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
 // ---- decode planning: work items grouped by kernel class, each with private scratch
 // general decoder classes by LDS footprint of the fine prefix rows (2^fb u32, fb = lg(n) - 3): occupancy, not
 // arithmetic, bounds the general decoder when a batch has many mid-size lists
-enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_COUNT };
+enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_B2L, DC_COUNT };
 constexpr uint64_t B2_MIN_LIST = 4096;
 constexpr size_t B2_CAP = 1024;      // chains of k_roc_decode_b2 per call (four per CU of an MI355X: 1 MiB of member rows each)
 
 struct DecPlan {
     std::vector<uint32_t> wl;        // list numbers, grouped by class, longest first inside a class
     std::vector<uint32_t> item;      // index of each work item in the caller's request
-    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t sum_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t sum_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<uint64_t> scratch_off, slots_off;
     uint64_t scratch_words = 0, slots_words = 0;
     bool lean = false;               // graph rows, lane decoder: item k == request k, no scratch / offset arrays
@@ -994,6 +997,23 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
                 }
                 cls[c].swap(keep);
             }
+        // short lists (257..2048 ids) of a call with few lists: the same loop with the member rows in LDS (33 KiB per chain)
+        // -- if the chains taken so far and all of these fit at four per CU
+        {
+            size_t n_short = 0;
+            for (uint32_t i : cls[DC_GSMALL]) n_short += len(i) > R2_MIN_LIST && len(i) <= VIDC_B2L_MAX_LIST;
+            bool longer_left = false;  // a longer general chain that stays on the general kernel decides the call anyway
+            for (int c : order_) longer_left |= !cls[c].empty();
+            for (uint32_t i : cls[DC_GSMALL]) longer_left |= len(i) > VIDC_B2L_MAX_LIST;
+            if (n_short && !longer_left && cls[DC_B2].size() + n_short <= b2_cap) {
+                std::vector<uint32_t> keep;
+                for (uint32_t i : cls[DC_GSMALL]) {
+                    if (len(i) > R2_MIN_LIST && len(i) <= VIDC_B2L_MAX_LIST && r->prec[lists[i]] <= 31) cls[DC_B2L].push_back(i);
+                    else keep.push_back(i);
+                }
+                cls[DC_GSMALL].swap(keep);
+            }
+        }
     }
     for (int c = 0; c < DC_COUNT; c++) {
         p.count[c] = cls[c].size();
@@ -1133,7 +1153,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         double est[DC_COUNT];
         for (int c = 0; c < DC_COUNT; c++) {
             order[c] = c;
-            const bool u = c == DC_U18 || c == DC_U20 || c == DC_B2, lane = c == DC_LANE || c == DC_LANE64;
+            const bool u = c == DC_U18 || c == DC_U20 || c == DC_B2 || c == DC_B2L, lane = c == DC_LANE || c == DC_LANE64;
             // (constants fitted to the S2 timeline: general kernels ~2.5 G steps/s while they share the machine)
             const double step_us = u ? 0.4 : (lane ? 2.5 : (c == DC_TINY ? 0.5 : 1.2));       // one chain step
             const double rate = u ? 0.6e3 : (lane ? 16e3 : (c == DC_TINY ? 30e3 : 2.5e3));     // steps / us, all CUs
@@ -1228,7 +1248,10 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
             case DC_B2:
-                hipLaunchKernelGGL(k_roc_decode_b2, dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
+                hipLaunchKernelGGL(k_roc_decode_b2<false>, dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
+                break;
+            case DC_B2L:
+                hipLaunchKernelGGL(k_roc_decode_b2<true>, dim3(b.nwork), dim3(64), VIDC_B2L_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
                 break;
             case DC_G8K:
                 hipLaunchKernelGGL(k_roc_decode_gen<uint16_t>, dim3(b.nwork), dim3(64), 1024 * 2, st_, b, 1024u, VIDC_DEC_CAP);
@@ -1287,7 +1310,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
             // wave-per-list kernels, into the same output slots
             std::vector<uint32_t> lists2;
             std::vector<uint64_t> off2;
-            for (size_t k = base[DC_LANE]; k < base[DC_LANE] + p.count[DC_LANE] + p.count[DC_LANE64] + p.count[DC_B2]; k++) {  // lane classes + B2
+            for (size_t k = base[DC_LANE]; k < base[DC_LANE] + p.count[DC_LANE] + p.count[DC_LANE64] + p.count[DC_B2] + p.count[DC_B2L]; k++) {  // lane classes + B2
                 if (status[p.wl[k]] != VIDC_ST_RETRY) continue;
                 lists2.push_back(p.wl[k]);
                 off2.push_back(out_off_host ? out_off_host[k] : r->offsets[p.wl[k]]);

@@ -1228,27 +1228,93 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
     "s_mov_b64 exec, -1\n" \
     U2_DEC_AFTER_RANK
 
+// The same with the member rows in LDS (lists of up to 2048 ids: 512 buckets x 16 members behind the bucket sizes, 33 KiB):
+// LDS operations of a wavefront are ordered, so a member is visible to the next step and the output-ring detour is not needed.
+//   s82 byte offset of the rows in LDS (= 2 x buckets); lanes >= 16 read past the row (inside the allocation, masked by the size)
+#define U2L_DEC_IDX \
+    "s_lshr_b32 s48, s40, s78\n"                       /* bucket */ \
+    "s_lshl_b32 s65, s48, 1\n" \
+    "v_mov_b32 v26, s65\n" \
+    "ds_read_u16 v30, v26\n"                           /* members of the bucket so far */ \
+    "s_lshl_b32 s47, s48, 6\n" \
+    "s_add_u32 s47, s47, s82\n" \
+    "v_lshl_add_u32 v28, v2, 2, s47\n" \
+    "ds_read_b32 v31, v28\n"                           /* lane j: member j of the bucket's row */ \
+    "s_xor_b32 s45, s48, 0xfff\n"                      /* entry (reversed) */
+#define U2L_DEC_MID \
+    "s_lshr_b32 s43, s45, 6\n"                         /* L1 */ \
+    "s_and_b32 s44, s45, 63\n"                         /* L2 */ \
+    "s_set_gpr_idx_on s43, gpr_idx(SRC0)\n" \
+    "v_mov_b32 v13, v64\n" \
+    "s_set_gpr_idx_off\n" \
+    "v_readlane_b32 s49, v4, s43\n"                    /* E1[L1] */ \
+    "v_readlane_b32 s63, v13, s44\n"                   /* row[L2] */ \
+    "v_readlane_b32 s62, v10, s69\n"                   /* lq of this step */ \
+    "v_subrev_u32 v58, s43, v2\n" \
+    "v_subrev_u32 v59, s44, v2\n" \
+    "v_ashrrev_i32 v59, 31, v59\n" \
+    "v_sub_u32 v13, v13, v59\n"                        /* row += 1 in lanes below L2 */ \
+    "s_and_b32 m0, s60, 63\n"                          /* index push, first half (codec.cpp:44-63): renormalise H */ \
+    "s_cmp_ge_u32 s59, s62\n" \
+    "v_writelane_b32 v5, s58, m0\n" \
+    "s_cselect_b32 s50, s59, s58\n" \
+    "s_cselect_b32 s51, 0, s59\n" \
+    "s_addc_u32 s60, s60, 0\n" \
+    "s_mul_i32 s52, s50, s75\n"                        /* H * nmax */ \
+    "s_mul_hi_u32 s53, s50, s75\n" \
+    "s_mul_i32 s68, s51, s75\n" \
+    "s_add_u32 s53, s53, s68\n" \
+    "s_add_u32 s72, s49, s63\n" \
+    "s_set_gpr_idx_on s43, gpr_idx(DST)\n" \
+    "v_mov_b32 v64, v13\n" \
+    "s_set_gpr_idx_off\n" \
+    "s_mov_b32 m0, s69\n"
+#define U2L_DEC_RANK \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "v_readfirstlane_b32 s47, v30\n"                   /* members of the bucket */ \
+    "v_cmp_gt_u32 s[66:67], s40, v31\n"                /* row member below x */ \
+    "v_mov_b32 v27, s40\n" \
+    "v_cmp_gt_u32 vcc, s47, v2\n"                      /* the lane holds a member */ \
+    "s_min_u32 s68, s47, 15\n"                         /* slot of x in the row */ \
+    "s_lshl_b32 s68, s68, 2\n" \
+    "s_lshl_b32 s65, s48, 6\n" \
+    "s_add_u32 s68, s68, s65\n" \
+    "s_add_u32 s68, s68, s82\n" \
+    "v_mov_b32 v28, s68\n" \
+    "s_and_b64 vcc, vcc, s[66:67]\n" \
+    "s_bcnt1_i32_b64 s64, vcc\n"                       /* members of the bucket below x */ \
+    "s_cmp_gt_u32 s47, 15\n" \
+    "s_cselect_b32 s68, 1, 0\n" \
+    "s_or_b32 s79, s79, s68\n"                         /* the row is full: the list is decoded again by the general kernel */ \
+    "s_add_u32 s47, s47, 1\n" \
+    "v_mov_b32 v32, s47\n" \
+    "s_mov_b64 exec, 1\n" \
+    "ds_write_b32 v28, v27\n" \
+    "ds_write_b16 v26, v32\n" \
+    "s_mov_b64 exec, -1\n" \
+    U2_DEC_AFTER_RANK
+
 // one generic decode step on the bucket structure (rare path): codec.cpp:144-150
 __device__ __forceinline__ uint32_t u2b_slow_dec_step(uint64_t &head, WStack &st, uint32_t nmax, uint32_t &E1, v32u &ra, v32u &rb,
                                                       uint16_t *cnt16, uint32_t *rows, uint32_t bsh, uint32_t p0, uint32_t p1,
-                                                      uint32_t &ovf) {
+                                                      uint32_t &ovf, uint32_t nbk = 4096u, uint32_t cap = 64u) {
     const uint32_t lane = lane_id();
     ws_prepare(st);
     const uint32_t x = ans_id_pop(head, st, p0, p1);
-    const uint32_t bkt = (x >> bsh) & 0xfffu;
+    const uint32_t bkt = rfl((x >> bsh) & (nbk - 1u));
     const uint32_t e = bkt ^ 0xfffu, L1 = e >> 6, L2 = e & 63u;
     uint32_t row = u2_row_get(ra, rb, L1);
     uint32_t r = rl(E1, L1) + rl(row, L2);
     const uint32_t c = rfl((uint32_t)cnt16[bkt]);
-    const uint32_t m = c < 64u ? c : 64u;
-    const uint32_t y = lane < m ? rows[bkt * 64u + lane] : 0xffffffffu;
+    const uint32_t m = c < cap ? c : cap;
+    const uint32_t y = lane < m ? rows[bkt * cap + lane] : 0xffffffffu;
     r += popc64(ballot(lane < m && y < x));
     ans_idx_push(head, st, r, nmax, 0x80000000u / nmax);
     E1 += lane < L1 ? 1u : 0u;
     row += lane < L2 ? 1u : 0u;
     u2_row_set(ra, rb, L1, row);
-    if (c < 64u) {
-        if (lane == 0) rows[bkt * 64u + c] = x;
+    if (c < cap) {
+        if (lane == 0) rows[bkt * cap + c] = x;
     } else {
         ovf |= 1u;
     }
@@ -1259,6 +1325,11 @@ __device__ __forceinline__ uint32_t u2b_slow_dec_step(uint64_t &head, WStack &st
 }
 
 #define VIDC_B2_LDS_BYTES ((4096u + 8u) * 2u)
+#define VIDC_B2L_BUCKETS 512u
+#define VIDC_B2L_CAP 16u
+#define VIDC_B2L_MAX_LIST 2048u  // average bucket load <= 4: a 16-member row overflows for about one bucket in 10^6
+#define VIDC_B2L_LDS_BYTES (VIDC_B2L_BUCKETS * 2u + VIDC_B2L_BUCKETS * VIDC_B2L_CAP * 4u + 256u)
+template <bool LROWS>
 __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div *__restrict__ dtab) {
     // (dynamic LDS, the kernel's only allocation: the asm addresses the bucket sizes from LDS offset 0, like the bitmap of
     // the u2 kernels)
@@ -1272,11 +1343,12 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
     const uint64_t ooff = rfl64(a.out_off ? a.out_off[wi] : a.offsets[l]);
     {
         uint4 *z = (uint4 *)cnt16;
-        for (uint32_t w = lane; w < (4096u + 8u) * 2u / 16u; w += 64) z[w] = make_uint4(0, 0, 0, 0);
+        for (uint32_t w = lane; w < (LROWS ? VIDC_B2L_BUCKETS : 4096u + 8u) * 2u / 16u; w += 64) z[w] = make_uint4(0, 0, 0, 0);
     }
     const uint32_t P = rfl(a.prec[l]);
     const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
-    const uint32_t bsh = P > 12u ? P - 12u : 0u;
+    const uint32_t bbits = LROWS ? 9u : 12u;
+    const uint32_t bsh = P > bbits ? P - bbits : 0u;
     const uint32_t W0 = rfl(a.nwords[l]);
     WStack st;
     ws_init_loaded(st, a.words + rfl64(a.word_off[l]), W0, a.scratch_words + rfl64(a.scratch_off[wi]), roc_dec_stack_cap(n, W0),
@@ -1290,7 +1362,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
     const uint32_t l3off = 0u;
     const uint32_t M1 = (1u << p1) - 1u, M0 = (1u << p0) - 1u;
     uint64_t *out = a.out + ooff;
-    uint32_t *rows = a.slots + rfl64(a.slots_off[wi]);
+    uint32_t *rows = LROWS ? (uint32_t *)(smem + VIDC_B2L_BUCKETS * 2u) : a.slots + rfl64(a.slots_off[wi]);
     uint32_t ovf = 0;
     wave_sync();
 
@@ -1298,7 +1370,8 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
     while (i < n) {
         ws_prepare(st);
         if (lt_2p31(head) || st.sp - st.lo < 2u || st.sp - st.lo > 61u) {  // generic step
-            const uint32_t x = u2b_slow_dec_step(head, st, i + 1u, E1, ra, rb, cnt16, rows, bsh, p0, p1, ovf);
+            const uint32_t x = u2b_slow_dec_step(head, st, i + 1u, E1, ra, rb, cnt16, rows, bsh, p0, p1, ovf,
+                                                 LROWS ? VIDC_B2L_BUCKETS : 4096u, LROWS ? VIDC_B2L_CAP : 64u);
             if (lane == 0) out[n - 1u - i] = (uint64_t)x;
             i++;
             continue;
@@ -1307,17 +1380,21 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
         uint64_t s_h = rfl64(head), oring = 0;
         st.sp = rfl(st.sp);
         st.lo = rfl(st.lo);
-        const uint64_t rowbase = rfl64((uint64_t)rows);
+        const uint64_t rowbase = LROWS ? (uint64_t)(VIDC_B2L_BUCKETS * 2u) : rfl64((uint64_t)rows);
         // clang-format off
-        asm volatile(U2_DEC_ENTRY U2_DEC_TOP U2B_DEC_IDX U2B_DEC_MID U2B_DEC_RANK U2_DEC_BOT U2_DEC_OUTER
-            : "+{v4}"(E1), "+{v5}"(st.win), "+{v[6:7]}"(oring), "+{v[64:95]}"(ra), "+{v[96:127]}"(rb),
-              "+{s[58:59]}"(s_h), "+{s60}"(st.sp), "+{s69}"(s_t), "+{s85}"(s_N0), "+{s86}"(s_left), "+{s87}"(s_oidx), "+{s79}"(s_ovf)
-            : "{v2}"(lane), "{v3}"(l3off), "{s61}"(st.lo), "{s73}"(M1), "{s74}"(M0), "{s76}"(p0), "{s77}"(p1),
-              "{s[88:89]}"(out), "{s[94:95]}"(dtab), "{s78}"(bsh), "{s[82:83]}"(rowbase)
-            : "memory", "vcc", "scc", "v10", "v13", "v26", "v27", "v28", "v30", "v31", "v32", "v33", "v34", "v35", "v36",
-              "v37", "v54", "v55", "v56", "v57", "v58", "v59", "s40", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",
-              "s51", "s52", "s53", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s70", "s71", "s72", "s75", "s80", "s81",
-              "s96", "s97", "s98", "s99");
+#define U2B_DEC_ASM(BODY)                                                                                                 \
+        asm volatile(BODY                                                                                                 \
+            : "+{v4}"(E1), "+{v5}"(st.win), "+{v[6:7]}"(oring), "+{v[64:95]}"(ra), "+{v[96:127]}"(rb),                    \
+              "+{s[58:59]}"(s_h), "+{s60}"(st.sp), "+{s69}"(s_t), "+{s85}"(s_N0), "+{s86}"(s_left), "+{s87}"(s_oidx), "+{s79}"(s_ovf)\
+            : "{v2}"(lane), "{v3}"(l3off), "{s61}"(st.lo), "{s73}"(M1), "{s74}"(M0), "{s76}"(p0), "{s77}"(p1),            \
+              "{s[88:89]}"(out), "{s[94:95]}"(dtab), "{s78}"(bsh), "{s[82:83]}"(rowbase)                                  \
+            : "memory", "vcc", "scc", "v10", "v13", "v26", "v27", "v28", "v30", "v31", "v32", "v33", "v34", "v35", "v36", \
+              "v37", "v54", "v55", "v56", "v57", "v58", "v59", "s40", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",\
+              "s51", "s52", "s53", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s70", "s71", "s72", "s75", "s80", "s81",\
+              "s96", "s97", "s98", "s99")
+        if (LROWS) U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_TOP U2L_DEC_IDX U2L_DEC_MID U2L_DEC_RANK U2_DEC_BOT U2_DEC_OUTER);
+        else U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_TOP U2B_DEC_IDX U2B_DEC_MID U2B_DEC_RANK U2_DEC_BOT U2_DEC_OUTER);
+#undef U2B_DEC_ASM
         // clang-format on
         ovf = s_ovf;
         head = s_h;
