@@ -30,6 +30,7 @@ struct vidc_roc {
     // the values the decode planner needs (lists above TINY_MAX) as soon as encode returns.
     mutable std::vector<uint64_t> offsets;   // nlist+1
     mutable std::vector<uint32_t> prec, nwords, draws;
+    std::vector<uint32_t> umax;  // largest id per list where the encoder knew it (empty / 0 = unknown: imported streams)
     mutable std::vector<uint64_t> heads;
     mutable std::vector<uint64_t> word_off;  // nlist+1
     mutable bool meta_host = false, offsets_host = false;
@@ -480,6 +481,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             tr.mark("prepass kernel + d2h");
             // what the decode planner needs later (kernel class, bucket geometry) is known right here
             r->prec.resize(nlist);
+            r->umax.assign(maxid, maxid + nlist);
             par_ranges(nlist, par_parts(nlist), [&](uint64_t la, uint64_t lb, unsigned) {
                 for (uint64_t l = la; l < lb; l++) {
                     const uint32_t m = maxid[l];
@@ -838,7 +840,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 // ascending: the general kernel stored the real one
                 std::vector<uint32_t> dp;
                 VIDC_TRY(download(ctx, dp, r->d_prec.p, nlist));
-                for (uint32_t l : pend) r->prec[l] = dp[l];
+                for (uint32_t l : pend) { r->prec[l] = dp[l]; r->umax[l] = 0; }
                 r->plan_ahead.reset();
             }
         }
@@ -881,15 +883,15 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
 // ---- decode planning: work items grouped by kernel class, each with private scratch
 // general decoder classes by LDS footprint of the fine prefix rows (2^fb u32, fb = lg(n) - 3): occupancy, not
 // arithmetic, bounds the general decoder when a batch has many mid-size lists
-enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_B2L, DC_COUNT };
+enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_B2L, DC_B2M, DC_COUNT };
 constexpr uint64_t B2_MIN_LIST = 4096;
 constexpr size_t B2_CAP = 1024;      // chains of k_roc_decode_b2 per call (four per CU of an MI355X: 1 MiB of member rows each)
 
 struct DecPlan {
     std::vector<uint32_t> wl;        // list numbers, grouped by class, longest first inside a class
     std::vector<uint32_t> item;      // index of each work item in the caller's request
-    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t sum_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t sum_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<uint64_t> scratch_off, slots_off;
     uint64_t scratch_words = 0, slots_words = 0;
     bool lean = false;               // graph rows, lane decoder: item k == request k, no scratch / offset arrays
@@ -997,18 +999,38 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
                 }
                 cls[c].swap(keep);
             }
-        // short lists (257..2048 ids) of a call with few lists: the same loop with the member rows in LDS (33 KiB per chain)
-        // -- if the chains taken so far and all of these fit at four per CU
+        // short lists (257..4096 ids) of a call with few lists: the same loop with 128 or 256 buckets and their 64-member rows
+        // in LDS (33 / 66 KiB per chain) -- if the chains taken so far and all of these fit at 132 KiB per CU.  The bucket count
+        // follows the expected load: ids are spread over (max id >> shift) + 1 buckets, half of them in the worst case when the
+        // maximum is unknown (imported streams); at <= 30 ids per bucket a 64-member row practically never overflows.
         {
-            size_t n_short = 0;
-            for (uint32_t i : cls[DC_GSMALL]) n_short += len(i) > R2_MIN_LIST && len(i) <= VIDC_B2L_MAX_LIST;
-            bool longer_left = false;  // a longer general chain that stays on the general kernel decides the call anyway
+            auto buckets_for = [&](uint32_t i) -> uint32_t {
+                const uint64_t n = len(i);
+                const uint32_t l = lists[i], P = r->prec[l];
+                if (n <= R2_MIN_LIST || n > VIDC_B2L_MAX_LIST || P > 31) return 0u;
+                for (uint32_t bk : {128u, 256u}) {
+                    const uint32_t bbits = bk == 128u ? 7u : 8u, bsh = P > bbits ? P - bbits : 0u;
+                    const uint32_t mx = (l < r->umax.size() && r->umax[l]) ? r->umax[l] : ((P ? (1u << (P - 1u)) : 1u));
+                    const uint64_t eff = std::min<uint64_t>(bk, (uint64_t)(mx >> bsh) + 1u);
+                    if (n <= VIDC_B2L_LOAD * eff) return bk;
+                }
+                return 0u;
+            };
+            size_t units = 0, n_el = 0;  // (units of 33 KiB of LDS)
+            bool longer_left = false;   // a longer chain that stays on the general kernel decides the call anyway
             for (int c : order_) longer_left |= !cls[c].empty();
-            for (uint32_t i : cls[DC_GSMALL]) longer_left |= len(i) > VIDC_B2L_MAX_LIST;
-            if (n_short && !longer_left && cls[DC_B2].size() + n_short <= b2_cap) {
+            for (uint32_t i : cls[DC_GSMALL]) {
+                const uint32_t bk = buckets_for(i);
+                units += bk == 256u ? 2 : (bk ? 1 : 0);
+                n_el += bk != 0;
+                longer_left |= !bk && len(i) > VIDC_B2L_MID_LIST;
+            }
+            if (n_el && !longer_left && cls[DC_B2].size() + units <= b2_cap) {
                 std::vector<uint32_t> keep;
                 for (uint32_t i : cls[DC_GSMALL]) {
-                    if (len(i) > R2_MIN_LIST && len(i) <= VIDC_B2L_MAX_LIST && r->prec[lists[i]] <= 31) cls[DC_B2L].push_back(i);
+                    const uint32_t bk = buckets_for(i);
+                    if (bk == 128u) cls[DC_B2L].push_back(i);
+                    else if (bk == 256u) cls[DC_B2M].push_back(i);
                     else keep.push_back(i);
                 }
                 cls[DC_GSMALL].swap(keep);
@@ -1153,7 +1175,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         double est[DC_COUNT];
         for (int c = 0; c < DC_COUNT; c++) {
             order[c] = c;
-            const bool u = c == DC_U18 || c == DC_U20 || c == DC_B2 || c == DC_B2L, lane = c == DC_LANE || c == DC_LANE64;
+            const bool u = c == DC_U18 || c == DC_U20 || c == DC_B2 || c == DC_B2L || c == DC_B2M, lane = c == DC_LANE || c == DC_LANE64;
             // (constants fitted to the S2 timeline: general kernels ~2.5 G steps/s while they share the machine)
             const double step_us = u ? 0.4 : (lane ? 2.5 : (c == DC_TINY ? 0.5 : 1.2));       // one chain step
             const double rate = u ? 0.6e3 : (lane ? 16e3 : (c == DC_TINY ? 30e3 : 2.5e3));     // steps / us, all CUs
@@ -1248,10 +1270,14 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
             case DC_B2:
-                hipLaunchKernelGGL(k_roc_decode_b2<false>, dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
+                hipLaunchKernelGGL(k_roc_decode_b2<0>, dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
                 break;
-            case DC_B2L:
-                hipLaunchKernelGGL(k_roc_decode_b2<true>, dim3(b.nwork), dim3(64), VIDC_B2L_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
+            case DC_B2L:  // 128 buckets, 33 KiB of LDS
+                hipLaunchKernelGGL(k_roc_decode_b2<128>, dim3(b.nwork), dim3(64), VIDC_B2L_LDS_BYTES(128u), st_, b, (const U2Div *)ctx->d_u2tab);
+                break;
+            case DC_B2M:  // 256 buckets, 66 KiB
+                VIDC_TRY(set_big_lds((const void *)k_roc_decode_b2<256>, VIDC_B2L_LDS_BYTES(256u)));
+                hipLaunchKernelGGL(k_roc_decode_b2<256>, dim3(b.nwork), dim3(64), VIDC_B2L_LDS_BYTES(256u), st_, b, (const U2Div *)ctx->d_u2tab);
                 break;
             case DC_G8K:
                 hipLaunchKernelGGL(k_roc_decode_gen<uint16_t>, dim3(b.nwork), dim3(64), 1024 * 2, st_, b, 1024u, VIDC_DEC_CAP);
@@ -1310,7 +1336,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
             // wave-per-list kernels, into the same output slots
             std::vector<uint32_t> lists2;
             std::vector<uint64_t> off2;
-            for (size_t k = base[DC_LANE]; k < base[DC_LANE] + p.count[DC_LANE] + p.count[DC_LANE64] + p.count[DC_B2] + p.count[DC_B2L]; k++) {  // lane classes + B2
+            for (size_t k = base[DC_LANE]; k < base[DC_LANE] + p.count[DC_LANE] + p.count[DC_LANE64] + p.count[DC_B2] + p.count[DC_B2L] + p.count[DC_B2M]; k++) {  // lane classes + B2
                 if (status[p.wl[k]] != VIDC_ST_RETRY) continue;
                 lists2.push_back(p.wl[k]);
                 off2.push_back(out_off_host ? out_off_host[k] : r->offsets[p.wl[k]]);

@@ -1228,15 +1228,17 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
     "s_mov_b64 exec, -1\n" \
     U2_DEC_AFTER_RANK
 
-// The same with the member rows in LDS (lists of up to 2048 ids: 512 buckets x 16 members behind the bucket sizes, 33 KiB):
-// LDS operations of a wavefront are ordered, so a member is visible to the next step and the output-ring detour is not needed.
-//   s82 byte offset of the rows in LDS (= 2 x buckets); lanes >= 16 read past the row (inside the allocation, masked by the size)
+// The same with the member rows in LDS (short lists: 128 or 256 buckets x 64 members behind the bucket sizes, 33 / 66 KiB --
+// few large rows rather than many small ones: a row must practically never overflow, because ONE list handed back costs the
+// call a whole serial chain on the general kernel afterwards): LDS operations of a wavefront are ordered, so a member is
+// visible to the next step and the output-ring detour is not needed.
+//   s82 byte offset of the rows in LDS (= 2 x buckets)
 #define U2L_DEC_IDX \
     "s_lshr_b32 s48, s40, s78\n"                       /* bucket */ \
     "s_lshl_b32 s65, s48, 1\n" \
     "v_mov_b32 v26, s65\n" \
     "ds_read_u16 v30, v26\n"                           /* members of the bucket so far */ \
-    "s_lshl_b32 s47, s48, 6\n" \
+    "s_lshl_b32 s47, s48, 8\n" \
     "s_add_u32 s47, s47, s82\n" \
     "v_lshl_add_u32 v28, v2, 2, s47\n" \
     "ds_read_b32 v31, v28\n"                           /* lane j: member j of the bucket's row */ \
@@ -1275,15 +1277,15 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
     "v_cmp_gt_u32 s[66:67], s40, v31\n"                /* row member below x */ \
     "v_mov_b32 v27, s40\n" \
     "v_cmp_gt_u32 vcc, s47, v2\n"                      /* the lane holds a member */ \
-    "s_min_u32 s68, s47, 15\n"                         /* slot of x in the row */ \
+    "s_min_u32 s68, s47, 63\n"                         /* slot of x in the row */ \
     "s_lshl_b32 s68, s68, 2\n" \
-    "s_lshl_b32 s65, s48, 6\n" \
+    "s_lshl_b32 s65, s48, 8\n" \
     "s_add_u32 s68, s68, s65\n" \
     "s_add_u32 s68, s68, s82\n" \
     "v_mov_b32 v28, s68\n" \
     "s_and_b64 vcc, vcc, s[66:67]\n" \
     "s_bcnt1_i32_b64 s64, vcc\n"                       /* members of the bucket below x */ \
-    "s_cmp_gt_u32 s47, 15\n" \
+    "s_cmp_gt_u32 s47, 63\n" \
     "s_cselect_b32 s68, 1, 0\n" \
     "s_or_b32 s79, s79, s68\n"                         /* the row is full: the list is decoded again by the general kernel */ \
     "s_add_u32 s47, s47, 1\n" \
@@ -1325,12 +1327,16 @@ __device__ __forceinline__ uint32_t u2b_slow_dec_step(uint64_t &head, WStack &st
 }
 
 #define VIDC_B2_LDS_BYTES ((4096u + 8u) * 2u)
-#define VIDC_B2L_BUCKETS 512u
-#define VIDC_B2L_CAP 16u
-#define VIDC_B2L_MAX_LIST 2048u  // average bucket load <= 4: a 16-member row overflows for about one bucket in 10^6
-#define VIDC_B2L_LDS_BYTES (VIDC_B2L_BUCKETS * 2u + VIDC_B2L_BUCKETS * VIDC_B2L_CAP * 4u + 256u)
-template <bool LROWS>
+#define VIDC_B2L_CAP 64u
+#define VIDC_B2L_MAX_LIST 4096u       // (the general decoder's small class)
+#define VIDC_B2L_MID_LIST 2048u
+#define VIDC_B2L_LOAD 30u             // ids per bucket (Poisson(30) exceeds 64 once in ~10^8 buckets)
+#define VIDC_B2L_LDS_BYTES(BK) ((BK) * 2u + (BK) * VIDC_B2L_CAP * 4u)
+// BK = 0: 4096 buckets, member rows in global memory; BK = 128 / 256: that many buckets, rows in LDS
+template <int BK>
 __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div *__restrict__ dtab) {
+    constexpr bool LROWS = BK != 0;
+    constexpr uint32_t VIDC_B2L_BUCKETS = LROWS ? (uint32_t)BK : 4096u;
     // (dynamic LDS, the kernel's only allocation: the asm addresses the bucket sizes from LDS offset 0, like the bitmap of
     // the u2 kernels)
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1347,7 +1353,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
     }
     const uint32_t P = rfl(a.prec[l]);
     const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
-    const uint32_t bbits = LROWS ? 9u : 12u;
+    const uint32_t bbits = BK == 128 ? 7u : (BK == 256 ? 8u : 12u);
     const uint32_t bsh = P > bbits ? P - bbits : 0u;
     const uint32_t W0 = rfl(a.nwords[l]);
     WStack st;
