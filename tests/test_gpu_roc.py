@@ -221,6 +221,41 @@ def test_wide_precision_chain_kernels_match_general_kernels_and_oracle(roc, orac
             assert np.array_equal(got[int(goff[k]):int(goff[k + 1])], dec[int(off[int(l)]):int(off[int(l) + 1])])
 
 
+def test_short_list_chain_kernels_of_small_calls(roc, oracle, monkeypatch):
+    """Calls with a few hundred lists of 257..4096 ids: encode through k_roc_encode_r2, decode through the bucket loop with
+    its rows in LDS (128 / 256 buckets by expected load).  One list packs 700 ids into a single bucket (row overflow ->
+    VIDC_ST_RETRY -> general kernel), one is a multiset, one is unsorted; imported streams (no maximum known) take the
+    worst-case bucket count.  Everything must equal the general kernels' output and the oracle."""
+    rng = np.random.default_rng(515)
+    lists = []
+    for nbits in (13, 20, 24, 31):
+        for n in (257, 300, 1000, 2048, 2049, 3900, 4096):
+            n = min(n, (1 << nbits) - 1)
+            lists.append(np.sort(rng.choice(1 << nbits, size=n, replace=False)))
+    lists.append(np.sort(np.unique(np.concatenate([rng.choice(1 << 24, size=1500, replace=False),
+                                                   (3 << 18) + rng.choice(1 << 12, size=700, replace=False)]))))
+    lists.append(np.sort(rng.integers(0, 1 << 22, size=3000)))
+    lists.append(rng.choice(1 << 20, size=2500, replace=False))
+    lists = [li.astype(np.uint64) for li in lists]
+    off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
+    ids = np.concatenate(lists)
+    r = roc.encode(off, ids, want_perm=True)
+    dec = r.decode_all().cpu().numpy().view(np.uint64)
+    monkeypatch.setenv("VIDC_NO_R2", "1")
+    r2 = roc.encode(off, ids, want_perm=True)
+    dec2 = r.decode_all().cpu().numpy().view(np.uint64)
+    monkeypatch.delenv("VIDC_NO_R2", raising=False)
+    assert np.array_equal(r.all_words(), r2.all_words()) and np.array_equal(r.perm(), r2.perm())
+    assert np.array_equal(dec, dec2)
+    _check_against_oracle(oracle, r, off, lists, r.perm(), dec)
+    # the same streams imported (the decoder then knows precisions only)
+    info = r.info()
+    from vector_db_id_compression_amd.codecs import RocLists
+
+    imp = RocLists.from_streams(off, info["precision"], info["heads"], info["nwords"], r.all_words(), mt_draws=info["mt_draws"])
+    assert np.array_equal(imp.decode_all().cpu().numpy().view(np.uint64), dec)
+
+
 def test_exact_precision_mode_is_lossless_for_pow2_max(roc):
     """VIDC_PREC_EXACT fixes the reference's pow-2 precision quirk (Q3); reference mode reproduces it."""
     ids = np.array([3, 1024, 7, 100], dtype=np.uint64)
