@@ -392,7 +392,6 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
         uint32_t pbuf = 0;
         // id of sorted position j: sid[j] after a sort, the low dword of ids[j] otherwise
         const uint32_t *sid = need_sort ? a.sid + off : (const uint32_t *)(a.ids + off);
-        const uint32_t sidsh = need_sort ? 0u : 1u;
         const uint32_t *spos = a.spos + off;
         const bool want_perm = a.perm != nullptr;
         for (uint32_t i0 = 0; i0 < n; i0 += 64) {
