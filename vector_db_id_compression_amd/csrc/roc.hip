@@ -883,19 +883,20 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
 // ---- decode planning: work items grouped by kernel class, each with private scratch
 // general decoder classes by LDS footprint of the fine prefix rows (2^fb u32, fb = lg(n) - 3): occupancy, not
 // arithmetic, bounds the general decoder when a batch has many mid-size lists
-enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_B2L, DC_B2M, DC_COUNT };
+enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_B2T, DC_B2S, DC_B2L, DC_B2M, DC_COUNT };
 constexpr uint64_t B2_MIN_LIST = 4096;
 constexpr size_t B2_CAP = 1024;      // chains of k_roc_decode_b2 per call (four per CU of an MI355X: 1 MiB of member rows each)
 
 struct DecPlan {
     std::vector<uint32_t> wl;        // list numbers, grouped by class, longest first inside a class
     std::vector<uint32_t> item;      // index of each work item in the caller's request
-    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t sum_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t sum_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<uint64_t> scratch_off, slots_off;
     uint64_t scratch_words = 0, slots_words = 0;
     bool lean = false;               // graph rows, lane decoder: item k == request k, no scratch / offset arrays
     bool tiny_lane = false;          // DC_TINY items run on the lane-per-list kernel
+    bool gsmall_lrows = false;       // DC_GSMALL items keep their member rows in LDS (33 KiB each: only for few lists)
     uint64_t implicit = 0;           // lean plan without a work list: items are rows 0..implicit-1
 };
 
@@ -999,8 +1000,9 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
                 }
                 cls[c].swap(keep);
             }
-        // short lists (257..4096 ids) of a call with few lists: the same loop with 128 or 256 buckets and their 64-member rows
-        // in LDS (33 / 66 KiB per chain) -- if the chains taken so far and all of these fit at 132 KiB per CU.  The bucket count
+        // short lists (257..4096 ids) of a call with few lists: the same loop with 32 .. 256 buckets and their 64-member rows in
+        // LDS (8.3 / 16.5 / 33 / 66 KiB per chain) -- if the chains taken so far and all of these fit at 150 KiB of LDS and 16
+        // wavefronts (128 VGPRs each) per CU: 1024 chains of 33 KiB, 4096 of 8.3 KiB on 256 CUs.  The bucket count
         // follows the expected load: ids are spread over (max id >> shift) + 1 buckets, half of them in the worst case when the
         // maximum is unknown (imported streams); at <= 30 ids per bucket a 64-member row practically never overflows.
         {
@@ -1008,28 +1010,30 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
                 const uint64_t n = len(i);
                 const uint32_t l = lists[i], P = r->prec[l];
                 if (n <= R2_MIN_LIST || n > VIDC_B2L_MAX_LIST || P > 31) return 0u;
-                for (uint32_t bk : {128u, 256u}) {
-                    const uint32_t bbits = bk == 128u ? 7u : 8u, bsh = P > bbits ? P - bbits : 0u;
+                for (uint32_t bk : {32u, 64u, 128u, 256u}) {
+                    const uint32_t bbits = bk == 32u ? 5u : (bk == 64u ? 6u : (bk == 128u ? 7u : 8u)), bsh = P > bbits ? P - bbits : 0u;
                     const uint32_t mx = (l < r->umax.size() && r->umax[l]) ? r->umax[l] : ((P ? (1u << (P - 1u)) : 1u));
                     const uint64_t eff = std::min<uint64_t>(bk, (uint64_t)(mx >> bsh) + 1u);
                     if (n <= VIDC_B2L_LOAD * eff) return bk;
                 }
                 return 0u;
             };
-            size_t units = 0, n_el = 0;  // (units of 33 KiB of LDS)
+            size_t units = 0, n_el = 0;  // (units of 8.25 KiB of LDS: 18 per CU; a chain with its rows in memory takes one)
             bool longer_left = false;   // a longer chain that stays on the general kernel decides the call anyway
             for (int c : order_) longer_left |= !cls[c].empty();
             for (uint32_t i : cls[DC_GSMALL]) {
                 const uint32_t bk = buckets_for(i);
-                units += bk == 256u ? 2 : (bk ? 1 : 0);
+                units += bk / 32u;
                 n_el += bk != 0;
                 longer_left |= !bk && len(i) > VIDC_B2L_MID_LIST;
             }
-            if (n_el && !longer_left && cls[DC_B2].size() + units <= b2_cap) {
+            if (n_el && !longer_left && cls[DC_B2].size() + units <= b2_cap * 9 / 2 && cls[DC_B2].size() + n_el <= b2_cap * 4) {
                 std::vector<uint32_t> keep;
                 for (uint32_t i : cls[DC_GSMALL]) {
                     const uint32_t bk = buckets_for(i);
-                    if (bk == 128u) cls[DC_B2L].push_back(i);
+                    if (bk == 32u) cls[DC_B2T].push_back(i);
+                    else if (bk == 64u) cls[DC_B2S].push_back(i);
+                    else if (bk == 128u) cls[DC_B2L].push_back(i);
                     else if (bk == 256u) cls[DC_B2M].push_back(i);
                     else keep.push_back(i);
                 }
@@ -1037,6 +1041,9 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             }
         }
     }
+    // LDS member rows for the short general lists only while all of them are resident at four per CU: beyond that the 33 KiB
+    // per wavefront cost more in occupancy than the global rows cost in traffic (6000 x 300 ids: 0.86 vs 0.3 ms)
+    p.gsmall_lrows = cls[DC_GSMALL].size() <= B2_CAP;
     for (int c = 0; c < DC_COUNT; c++) {
         p.count[c] = cls[c].size();
         for (uint32_t i : cls[c]) {
@@ -1072,8 +1079,8 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
                 p.slots_off[k] = sl;
                 sl += 4096ull * 64ull;
             }
-            else if (c == DC_GSMALL) sl += n;  // overflow list only: the member rows are in LDS
-            else if (c > DC_GSMALL) {
+            else if (c == DC_GSMALL && p.gsmall_lrows) sl += n;  // overflow list only: the member rows are in LDS
+            else if (c >= DC_GSMALL && c <= DC_GHUGE) {
                 uint32_t fb = roc_dec_fine_bits((uint32_t)n, r->prec[l] > 32 ? 32 : r->prec[l]);
                 sl += ((uint64_t)1 << fb) * roc_dec_cap((uint32_t)n) + n;
             }
@@ -1175,7 +1182,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         double est[DC_COUNT];
         for (int c = 0; c < DC_COUNT; c++) {
             order[c] = c;
-            const bool u = c == DC_U18 || c == DC_U20 || c == DC_B2 || c == DC_B2L || c == DC_B2M, lane = c == DC_LANE || c == DC_LANE64;
+            const bool u = c == DC_U18 || c == DC_U20 || c == DC_B2 || c == DC_B2T || c == DC_B2S || c == DC_B2L || c == DC_B2M, lane = c == DC_LANE || c == DC_LANE64;
             // (constants fitted to the S2 timeline: general kernels ~2.5 G steps/s while they share the machine)
             const double step_us = u ? 0.4 : (lane ? 2.5 : (c == DC_TINY ? 0.5 : 1.2));       // one chain step
             const double rate = u ? 0.6e3 : (lane ? 16e3 : (c == DC_TINY ? 30e3 : 2.5e3));     // steps / us, all CUs
@@ -1236,9 +1243,12 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                                        (const U2Div *)ctx->d_u2tab);
                 }
                 break;
-            case DC_GSMALL:  // member rows in LDS: 1 + 32 KiB
-                hipLaunchKernelGGL((k_roc_decode_gen<uint16_t, true>), dim3(b.nwork), dim3(64), 512 * 2 + 512 * VIDC_DEC_CAP * 4, st_,
-                                   b, 512u, VIDC_DEC_CAP);
+            case DC_GSMALL:
+                if (p.gsmall_lrows)  // member rows in LDS: 1 + 32 KiB
+                    hipLaunchKernelGGL((k_roc_decode_gen<uint16_t, true>), dim3(b.nwork), dim3(64), 512 * 2 + 512 * VIDC_DEC_CAP * 4, st_,
+                                       b, 512u, VIDC_DEC_CAP);
+                else
+                    hipLaunchKernelGGL(k_roc_decode_gen<uint16_t>, dim3(b.nwork), dim3(64), 512 * 2, st_, b, 512u, VIDC_DEC_CAP);
                 break;
             case DC_LANE: {  // 12.5 KiB of LDS per wavefront
                 b.lpw = lane_lists_per_wave(ctx, b.nwork, 24);
@@ -1271,6 +1281,12 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 break;
             case DC_B2:
                 hipLaunchKernelGGL(k_roc_decode_b2<0>, dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
+                break;
+            case DC_B2T:  // 32 buckets, 8.3 KiB of LDS
+                hipLaunchKernelGGL(k_roc_decode_b2<32>, dim3(b.nwork), dim3(64), VIDC_B2L_LDS_BYTES(32u), st_, b, (const U2Div *)ctx->d_u2tab);
+                break;
+            case DC_B2S:  // 64 buckets, 16.5 KiB of LDS
+                hipLaunchKernelGGL(k_roc_decode_b2<64>, dim3(b.nwork), dim3(64), VIDC_B2L_LDS_BYTES(64u), st_, b, (const U2Div *)ctx->d_u2tab);
                 break;
             case DC_B2L:  // 128 buckets, 33 KiB of LDS
                 hipLaunchKernelGGL(k_roc_decode_b2<128>, dim3(b.nwork), dim3(64), VIDC_B2L_LDS_BYTES(128u), st_, b, (const U2Div *)ctx->d_u2tab);
@@ -1336,7 +1352,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
             // wave-per-list kernels, into the same output slots
             std::vector<uint32_t> lists2;
             std::vector<uint64_t> off2;
-            for (size_t k = base[DC_LANE]; k < base[DC_LANE] + p.count[DC_LANE] + p.count[DC_LANE64] + p.count[DC_B2] + p.count[DC_B2L] + p.count[DC_B2M]; k++) {  // lane classes + B2
+            for (size_t k = base[DC_LANE]; k < base[DC_LANE] + p.count[DC_LANE] + p.count[DC_LANE64] + p.count[DC_B2] + p.count[DC_B2T] + p.count[DC_B2S] + p.count[DC_B2L] + p.count[DC_B2M]; k++) {  // lane classes + B2
                 if (status[p.wl[k]] != VIDC_ST_RETRY) continue;
                 lists2.push_back(p.wl[k]);
                 off2.push_back(out_off_host ? out_off_host[k] : r->offsets[p.wl[k]]);

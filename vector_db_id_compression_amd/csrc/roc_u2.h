@@ -1332,7 +1332,7 @@ __device__ __forceinline__ uint32_t u2b_slow_dec_step(uint64_t &head, WStack &st
 #define VIDC_B2L_MID_LIST 2048u
 #define VIDC_B2L_LOAD 30u             // ids per bucket (Poisson(30) exceeds 64 once in ~10^8 buckets)
 #define VIDC_B2L_LDS_BYTES(BK) ((BK) * 2u + (BK) * VIDC_B2L_CAP * 4u)
-// BK = 0: 4096 buckets, member rows in global memory; BK = 128 / 256: that many buckets, rows in LDS
+// BK = 0: 4096 buckets, member rows in global memory; BK = 32 / 64 / 128 / 256: that many buckets, rows in LDS
 template <int BK>
 __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div *__restrict__ dtab) {
     constexpr bool LROWS = BK != 0;
@@ -1353,7 +1353,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
     }
     const uint32_t P = rfl(a.prec[l]);
     const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
-    const uint32_t bbits = BK == 128 ? 7u : (BK == 256 ? 8u : 12u);
+    const uint32_t bbits = BK == 32 ? 5u : (BK == 64 ? 6u : (BK == 128 ? 7u : (BK == 256 ? 8u : 12u)));
     const uint32_t bsh = P > bbits ? P - bbits : 0u;
     const uint32_t W0 = rfl(a.nwords[l]);
     WStack st;
