@@ -853,18 +853,33 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         for (uint32_t l : wl_u18) if (!is_p[l]) ul.push_back(l);
         for (uint32_t l : wl_u20) if (!is_p[l]) ul.push_back(l);
         if (!ul.empty()) {
-            std::vector<uint32_t> items;  // (list, first id of the chunk) pairs
-            for (uint32_t l : ul)
-                for (uint64_t st0 = 0, n = r->offsets[l + 1] - r->offsets[l]; st0 < n; st0 += VIDC_PERM_CHUNK) {
-                    items.push_back(l);
-                    items.push_back((uint32_t)st0);
+            // lists -> 8 lanes (longest first to the lane with the fewest chunks), lane x's k-th chunk at item 8 k + x
+            std::vector<uint32_t> byl(ul);
+            std::stable_sort(byl.begin(), byl.end(), [&](uint32_t x, uint32_t y) {
+                return r->offsets[x + 1] - r->offsets[x] > r->offsets[y + 1] - r->offsets[y];
+            });
+            std::vector<std::vector<std::pair<uint32_t, uint32_t>>> lanes(8);
+            for (uint32_t l : byl) {
+                size_t best = 0;
+                for (size_t x = 1; x < 8; x++)
+                    if (lanes[x].size() < lanes[best].size()) best = x;
+                for (uint64_t st0 = 0, n = r->offsets[l + 1] - r->offsets[l]; st0 < n; st0 += VIDC_PERM_CHUNK)
+                    lanes[best].push_back({l, (uint32_t)st0});
+            }
+            size_t depth = 0;
+            for (auto &ln : lanes) depth = std::max(depth, ln.size());
+            std::vector<uint32_t> items(depth * 8 * 2, 0xffffffffu);
+            for (size_t x = 0; x < 8; x++)
+                for (size_t k = 0; k < lanes[x].size(); k++) {
+                    items[(k * 8 + x) * 2] = lanes[x][k].first;
+                    items[(k * 8 + x) * 2 + 1] = lanes[x][k].second;
                 }
             Scratch s_ul;
             VIDC_TRY(upload_scratch(ctx, s_ul, items));
-            const uint32_t nitems = (uint32_t)(items.size() / 2);
+            const uint32_t nitems = (uint32_t)(depth * 8);
             EventTimer t(ctx);
-            hipLaunchKernelGGL(k_perm_from_order, dim3(std::min<uint32_t>(nitems, 1u << 20)), dim3(256), 0, ctx->stream, d_ids,
-                               r->d_offsets.p, s_ul.as<uint2>(), nitems, r->d_perm.p);
+            hipLaunchKernelGGL(k_perm_from_order, dim3(nitems), dim3(256), 0, ctx->stream, d_ids, r->d_offsets.p, s_ul.as<uint2>(),
+                               nitems, r->d_perm.p);
             VIDC_HIP(hipGetLastError());
             kernel_ms += t.stop();
         }

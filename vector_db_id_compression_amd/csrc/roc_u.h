@@ -349,13 +349,16 @@ __global__ void __launch_bounds__(256) k_roc_prepass_last(const uint64_t *ids, c
 
 // order[] (sampled ids, written by the U encoder into the perm buffer) -> input positions, for lists whose
 // input is strictly ascending: position = index of the id in the list (binary search).
-// One workgroup per (list, chunk of VIDC_PERM_CHUNK ids): with a workgroup per LIST the 52 114-id list of S1 kept one
-// workgroup busy for 0.53 ms after the chain had finished (2 % of the step).
+// One workgroup per (list, chunk of VIDC_PERM_CHUNK ids), with all chunks of a list on ONE XCD: workgroups go to the 8 XCDs
+// round-robin by index, so item k of "lane" x sits at workgroup 8 k + x and the host fills each lane with whole lists
+// (roc.hip).  A workgroup per LIST kept one CU busy for 0.53 ms behind the S1 chain (2 % of the step); chunks spread over
+// all XCDs took 0.03 ms but every XCD's L2 fetched the whole list again (7.7 instead of 1.8 MiB per step).
 #define VIDC_PERM_CHUNK 2048u
 __global__ void k_perm_from_order(const uint64_t *ids, const uint64_t *offsets, const uint2 *items, uint32_t nitems,
                                   uint32_t *perm) {
     for (uint32_t wi = blockIdx.x; wi < nitems; wi += gridDim.x) {
         const uint32_t l = items[wi].x, start = items[wi].y;
+        if (l == 0xffffffffu) continue;  // padding of a shorter lane
         const uint64_t off = offsets[l];
         const uint32_t n = (uint32_t)(offsets[l + 1] - off);
         const uint32_t end = start + VIDC_PERM_CHUNK < n ? start + VIDC_PERM_CHUNK : n;
