@@ -12,7 +12,7 @@ from vector_db_id_compression_amd.codecs import RocLists  # noqa: E402
 MODES = {"lane": {"VIDC_FORCE_LANE": "1", "VIDC_NO_LANE": "0", "VIDC_FORCE_GENERAL": "0"},
          "wave": {"VIDC_FORCE_LANE": "0", "VIDC_NO_LANE": "1", "VIDC_FORCE_GENERAL": "0"},
          "general": {"VIDC_FORCE_LANE": "0", "VIDC_NO_LANE": "1", "VIDC_FORCE_GENERAL": "1"}}
-d = np.load(sys.argv[1] if len(sys.argv) > 1 else "tools/fuzz_fail.npz")
+d = np.load(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/fuzz_fail.npz")
 off, ids, mode = d["off"], d["ids"], int(d["mode"])
 for want_perm in (False, True):
     got = {}
