@@ -736,17 +736,29 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
         if (lane == 0) a.status[l] = VIDC_ST_PENDING_SORT;
         return;
     }
-    // ---- alive bitmap over positions (reversed entry order, one 64-bit word per entry) + counters
-    for (uint32_t e = lane; e < U::NE; e += 64u) {
+    // ---- alive bitmap over positions (reversed entry order, one 64-bit word per entry; entries past the list are never
+    // selected -- their counters are 0 -- and stay unwritten) + counters in closed form: every position below n is alive, so
+    // the exclusive counts of u2_build_counts are min(.., ..) of n and the block / entry boundaries
+    for (uint32_t e = lane; e < ((n + 63u) >> 6); e += 64u) {
         const uint32_t lo = e << 6;
-        const uint32_t c = lo >= n ? 0u : (n - lo >= 64u ? 64u : n - lo);
+        const uint32_t c = n - lo >= 64u ? 64u : n - lo;
         bm[e ^ (U::NE - 1u)] = c == 64u ? ~0ull : ((1ull << c) - 1ull);
     }
     if (lane == 0) { bm[U::NE] = 0; bm[U::NE + 1] = 0; }
     wave_sync();
-    uint32_t E1;
+    // lane L of E1 <-> block L: ids in blocks with a larger index (= smaller positions): 4096 positions per block
+    uint32_t E1 = 4096u * (63u - lane);
+    E1 = E1 < n ? E1 : n;
     v32u ra, rb;
-    u2_build_counts<18>(bm, E1, ra, rb);
+#pragma unroll
+    for (int L1 = 0; L1 < 64; L1++) {
+        // row L1, lane L2: alive positions of block L1 in entries with a larger lane index = the first 64 (63 - L2) positions
+        // of the block, which starts at position 4096 (63 - L1)
+        const uint32_t b0 = 4096u * (63u - (uint32_t)L1);
+        const uint32_t in_block = n > b0 ? n - b0 : 0u, want = 64u * (63u - lane);
+        const uint32_t v = in_block < want ? in_block : want;
+        if (L1 < 32) ra[L1] = v; else rb[L1 - 32] = v;
+    }
 
     const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? P - 16u : 0u;
     WStack st;
