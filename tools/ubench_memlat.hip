@@ -1,5 +1,5 @@
-// ubench_memlat.hip -- latency of a dependent global load on a lone wavefront: vector (global_load_dword) and scalar
-// (s_load_dword) pointer chases over buffers that fit L2 (1 MiB), the MALL (64 MiB) or neither (1 GiB) (dev tool).
+// ubench_memlat.hip -- latency of a dependent global load on a lone wavefront: vector (global_load_dword) pointer
+// chases over buffers that fit L2 (1 MiB), the MALL (64 MiB) or neither (1 GiB) (dev tool).
 // build: hipcc --offload-arch=gfx950 -O2 tools/ubench_memlat.hip -o tools/_bin/ubench_memlat
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -25,16 +25,6 @@ __global__ void __launch_bounds__(64) k_vec_plain(const uint32_t *buf, uint32_t 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1));
     if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = p; }
 }
-__global__ void __launch_bounds__(64) k_scalar(const uint32_t *buf, uint32_t steps, uint64_t *out) {
-    uint32_t p = 0;
-    uint64_t t0, t1;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0));
-    for (uint32_t i = 0; i < steps; i++)
-        asm volatile("s_lshl_b32 %0, %0, 2\n s_load_dword %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+s"(p) : "s"(buf));
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1));
-    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = p; }
-}
-
 int main() {
     uint64_t *d_out;
     hipMalloc(&d_out, 64);
@@ -51,12 +41,11 @@ int main() {
         hipMemcpy(d, buf.data(), words * 4, hipMemcpyHostToDevice);
         const uint32_t steps = 20000;
         uint64_t h[2];
-        const char *names[3] = {"vector, nontemporal", "vector", "scalar"};
-        for (int k = 0; k < 3; k++) {
+        const char *names[2] = {"vector, nontemporal", "vector"};
+        for (int k = 0; k < 2; k++) {
             for (int rep = 0; rep < 2; rep++) {
                 if (k == 0) hipLaunchKernelGGL(k_vec, dim3(1), dim3(64), 0, 0, d, steps, d_out);
-                else if (k == 1) hipLaunchKernelGGL(k_vec_plain, dim3(1), dim3(64), 0, 0, d, steps, d_out);
-                else hipLaunchKernelGGL(k_scalar, dim3(1), dim3(64), 0, 0, d, steps, d_out);
+                else hipLaunchKernelGGL(k_vec_plain, dim3(1), dim3(64), 0, 0, d, steps, d_out);
                 hipDeviceSynchronize();
             }
             hipMemcpy(h, d_out, 16, hipMemcpyDeviceToHost);
