@@ -221,6 +221,27 @@ def test_wide_precision_chain_kernels_match_general_kernels_and_oracle(roc, orac
             assert np.array_equal(got[int(goff[k]):int(goff[k + 1])], dec[int(off[int(l)]):int(off[int(l) + 1])])
 
 
+def test_chain_kernels_at_the_largest_list_sizes(roc, monkeypatch):
+    """k_roc_encode_r2 takes lists up to 262 144 ids (the position bitmap's 18 bits), k_roc_decode_b2 up to 98 304; the
+    reference's codec is lossy beyond 65 536 ids (SURVEY 8a-Q2), so the check is against the general kernels' streams and
+    their decode of them, not against the input."""
+    rng = np.random.default_rng(4242)
+    lists = [np.sort(rng.choice(1 << 28, size=n, replace=False)).astype(np.uint64) for n in (262144, 200000, 98304, 98305, 65537)]
+    off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
+    ids = np.concatenate(lists)
+    r = roc.encode(off, ids, want_perm=True)
+    dec = r.decode_all().cpu().numpy().view(np.uint64)
+    monkeypatch.setenv("VIDC_NO_R2", "1")
+    r2 = roc.encode(off, ids, want_perm=True)
+    dec2 = r2.decode_all().cpu().numpy().view(np.uint64)
+    monkeypatch.delenv("VIDC_NO_R2", raising=False)
+    i1, i2 = r.info(), r2.info()
+    for k in ("heads", "nwords", "precision", "mt_draws"):
+        assert np.array_equal(i1[k], i2[k]), k
+    assert np.array_equal(r.all_words(), r2.all_words()) and np.array_equal(r.perm(), r2.perm())
+    assert np.array_equal(dec, dec2)
+
+
 def test_short_list_chain_kernels_of_small_calls(roc, oracle, monkeypatch):
     """Calls with a few hundred lists of 257..4096 ids: encode through k_roc_encode_r2, decode through the bucket loop with
     its rows in LDS (128 / 256 buckets by expected load).  One list packs 700 ids into a single bucket (row overflow ->
