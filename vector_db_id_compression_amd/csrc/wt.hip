@@ -191,6 +191,22 @@ __device__ __forceinline__ uint64_t rrr_unrank_word(uint32_t c, uint64_t o, cons
     }
     return v;
 }
+// ones of the block (class c, offset o) below position rem, and the bit at rem: the unranking only has to walk the positions
+// from the top down to rem (what is left of c afterwards sits below)
+__device__ __forceinline__ uint32_t rrr_rank_below(uint32_t c, uint64_t o, uint32_t rem, bool &bit, const uint64_t *binom) {
+    bit = false;
+    if (c == 0) return 0;
+    if (c == RRR_B) { bit = rem < RRR_B; return rem; }
+    for (int p = (int)RRR_B - 1; p >= (int)rem && c; p--) {
+        const uint64_t b = binom[(uint32_t)p * 64u + c];
+        if (o >= b) {
+            o -= b;
+            c--;
+            if ((uint32_t)p == rem) { bit = true; }
+        }
+    }
+    return c;
+}
 struct BvRrr {
     const uint32_t *cls;
     const uint64_t *offs;
@@ -204,7 +220,7 @@ struct BvRrr {
         if ((bp & 31) > 26) w |= cls[(bp >> 5) + 1] << (32 - (bp & 31));
         return w & 63u;
     }
-    __device__ __forceinline__ uint64_t word_at(uint64_t bp, uint32_t c) const {  // the block whose offset starts at bit bp
+    __device__ __forceinline__ uint64_t offset_at(uint64_t bp, uint32_t c) const {  // offset field of the block starting at bit bp
         const uint32_t wd = tab.ow[c];
         uint64_t o = 0;
         if (wd) {
@@ -212,8 +228,9 @@ struct BvRrr {
             if ((bp & 63) + wd > 64) o |= offs[(bp >> 6) + 1] << (64 - (bp & 63));
             o &= (1ull << wd) - 1ull;
         }
-        return rrr_unrank_word(c, o, binom);
+        return o;
     }
+    __device__ __forceinline__ uint64_t word_at(uint64_t bp, uint32_t c) const { return rrr_unrank_word(c, offset_at(bp, c), binom); }
     __device__ __forceinline__ uint64_t rank_1_bit(uint64_t i, bool &bit) const {
         const uint64_t blk = i / RRR_B, s = blk / RRR_K;
         uint64_t r = rs[s], bp = ptr[s];
@@ -225,9 +242,8 @@ struct BvRrr {
         const uint32_t rem = (uint32_t)(i - blk * RRR_B);
         bit = false;
         if (blk < nblk) {
-            const uint64_t v = word_at(bp, cls_at(blk));
-            r += (uint64_t)__builtin_popcountll(v & ((1ull << rem) - 1ull));
-            bit = (v >> rem) & 1ull;
+            const uint32_t c = cls_at(blk);
+            r += rrr_rank_below(c, offset_at(bp, c), rem, bit, binom);
         }
         return r;
     }
