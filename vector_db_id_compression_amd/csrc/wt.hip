@@ -45,7 +45,7 @@ struct vidc_wt {
     DevBuf<uint32_t> d_cls;             // L * rrr_cls_wpl: packed 6-bit classes
     DevBuf<uint64_t> d_offs;            // offset streams, level after level
     DevBuf<uint32_t> d_ptr, d_rs;       // L * (rrr_nsamp + 1): bit position in the offset stream / ones before block 32 s
-    DevBuf<uint64_t> d_binom;           // C(n, k), n, k < 64 (row n at 64 n)
+    DevBuf<uint64_t> d_binom;           // C(n, k), n, k < 64 (row n at 64 n); behind it (d_binom + 4096) the 64 offset widths as bytes
 };
 
 namespace {
@@ -212,7 +212,7 @@ struct BvRrr {
     const uint64_t *offs;
     const uint32_t *ptr, *rs;
     const uint64_t *binom;
-    RrrTab tab;
+    const uint8_t *ow;  // offset width by class (memory, not a by-value table: a dynamically indexed kernel argument goes to scratch)
     uint64_t nblk, nsamp, nbits;
     __device__ __forceinline__ uint32_t cls_at(uint64_t b) const {
         const uint64_t bp = 6 * b;
@@ -221,7 +221,7 @@ struct BvRrr {
         return w & 63u;
     }
     __device__ __forceinline__ uint64_t offset_at(uint64_t bp, uint32_t c) const {  // offset field of the block starting at bit bp
-        const uint32_t wd = tab.ow[c];
+        const uint32_t wd = ow[c];
         uint64_t o = 0;
         if (wd) {
             o = offs[bp >> 6] >> (bp & 63);
@@ -237,7 +237,7 @@ struct BvRrr {
         for (uint64_t b = s * RRR_K; b < blk; b++) {
             const uint32_t c = cls_at(b);
             r += c;
-            bp += tab.ow[c];
+            bp += ow[c];
         }
         const uint32_t rem = (uint32_t)(i - blk * RRR_B);
         bit = false;
@@ -275,7 +275,7 @@ struct BvRrr {
                 return b * RRR_B + (uint64_t)__builtin_ctzll(v);
             }
             seen += cnt;
-            bp += tab.ow[c];
+            bp += ow[c];
         }
         return ~0ull;
     }
@@ -287,10 +287,9 @@ struct WtRrrView {
     const uint64_t *binom;
     uint64_t cls_wpl, nblk, nsamp, nbits;
     uint64_t off_base[32];
-    RrrTab tab;
     __device__ __forceinline__ BvRrr level(uint32_t l) const {
         return BvRrr{cls + (uint64_t)l * cls_wpl, offs + off_base[l], ptr + (uint64_t)l * (nsamp + 1), rs + (uint64_t)l * (nsamp + 1),
-                     binom, tab, nblk, nsamp, nbits};
+                     binom, (const uint8_t *)(binom + 64 * 64), nblk, nsamp, nbits};
     }
 };
 
@@ -464,14 +463,14 @@ RrrTab rrr_tab() {
 }
 BvRrr rrr_view_level(const vidc_wt *w, uint32_t l) {
     return BvRrr{w->d_cls.p + (uint64_t)l * w->rrr_cls_wpl, w->d_offs.p + w->rrr_off_base[l], w->d_ptr.p + (uint64_t)l * (w->rrr_nsamp + 1),
-                 w->d_rs.p + (uint64_t)l * (w->rrr_nsamp + 1), w->d_binom.p, rrr_tab(), w->rrr_nblk, w->rrr_nsamp, w->ntotal};
+                 w->d_rs.p + (uint64_t)l * (w->rrr_nsamp + 1), w->d_binom.p, (const uint8_t *)(w->d_binom.p + 64 * 64), w->rrr_nblk,
+                 w->rrr_nsamp, w->ntotal};
 }
 WtRrrView rrr_view(const vidc_wt *w) {
     WtRrrView v{};
     v.cls = w->d_cls.p; v.offs = w->d_offs.p; v.ptr = w->d_ptr.p; v.rs = w->d_rs.p; v.binom = w->d_binom.p;
     v.cls_wpl = w->rrr_cls_wpl; v.nblk = w->rrr_nblk; v.nsamp = w->rrr_nsamp; v.nbits = w->ntotal;
     for (uint32_t l = 0; l < w->L && l < 32; l++) v.off_base[l] = w->rrr_off_base[l];
-    v.tab = rrr_tab();
     return v;
 }
 
@@ -529,8 +528,9 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
             bn[n * 64] = 1;
             for (int k = 1; k <= n; k++) bn[n * 64 + k] = (n ? bn[(n - 1) * 64 + k - 1] : 0) + (k <= n - 1 ? bn[(n - 1) * 64 + k] : 0);
         }
-        VIDC_TRY(w->d_binom.alloc(64 * 64));
+        VIDC_TRY(w->d_binom.alloc(64 * 64 + 8));
         VIDC_HIP(hipMemcpyAsync(w->d_binom.p, bn.data(), 64 * 64 * 8, hipMemcpyHostToDevice, ctx->stream));
+        VIDC_HIP(hipMemcpyAsync(w->d_binom.p + 64 * 64, tab.ow, 64, hipMemcpyHostToDevice, ctx->stream));
         VIDC_HIP(hipStreamSynchronize(ctx->stream));  // (bn leaves scope)
         w->rrr_off_base.assign(L + 1, 0);
     }
