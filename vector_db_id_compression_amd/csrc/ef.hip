@@ -235,39 +235,271 @@ __global__ void __launch_bounds__(64) k_ef_high(const uint64_t *sorted_ids, cons
 }
 
 // ---- single-pass encoder for ascending lists (the normal case: Faiss lists are in add order, graph rows are sorted
-// by k_rows_sorted).  The universe of an ascending list is its last element, so the ids are streamed from HBM once:
-// k_ef_prep_last reads one id per list, k_ef_lowhigh writes both bit streams per chunk and checks the order on the
-// way; any violation raises `unsorted` and the caller redoes the object with the three-pass path below.
-__global__ void k_ef_prep_last(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist, PrepOut *outp) {
-    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x) {
-        const uint64_t n = offsets[l + 1] - offsets[l];
-        outp[l].max_id = n ? ids[offsets[l + 1] - 1] : 0ull;
-        outp[l].unsorted = 0;
+// by k_rows_sorted).  The universe of an ascending list is its last element, so the ids are streamed from HBM once.
+// Three launches whatever the number of lists:
+//   k_ef_meta      per-list geometry from (size, last id) and the totals of every tile of EF_META_TILE lists
+//   k_ef_offsets   word / batch / chunk offsets (tile prefix + scan inside the tile) and one 64-byte record per chunk
+//                  (fewer than EF_META_TILE lists: this kernel alone, it computes the geometry itself)
+//   k_ef_lowhigh*  one wavefront per chunk record: both bit streams, the order check, the list's padding word and the
+//                  select-directory entries whose batch starts inside the chunk
+// Any order violation raises `unsorted` and the caller redoes the object with the three-pass path further down.
+#define EF_META_E 4u                       // consecutive lists per thread
+#define EF_META_TILE (256u * EF_META_E)    // lists per workgroup
+struct EfRaw {     // the four per-list counts (k_ef_meta) whose prefix sums are the offsets of a list
+    uint64_t lw, hw, nb, cnt;  // low words (incl. the padding word), high words, batches of 64 high words, chunks
+};
+struct EfTile {    // totals of one tile
+    uint64_t lw, hw, nb, cnt, bits, wide;
+};
+struct EfSummary {  // what the host needs before it can allocate the streams
+    uint64_t low_words, high_words, nbatches, nchunks, total_bits;
+    uint32_t wide, unsorted;
+};
+// Everything a wavefront needs to encode one chunk, in one 64-byte record (one scalar load): with the CSR arrays a
+// wavefront walks chunk item -> six per-list arrays -> ids, three dependent round trips for 4 KiB of payload.
+struct EfChunkRec {
+    uint64_t src;        // index of the chunk's first id in the id array
+    uint64_t low_word;   // word offset of the list's low stream
+    uint64_t high_word;  // word offset of the list's high stream
+    uint64_t batch0;     // index of the list's first select-directory entry
+    uint64_t u;          // universe of the list (its last id)
+    uint32_t start;      // first id of the chunk inside its list
+    uint32_t n;          // ids in the list
+    uint32_t list;
+    uint32_t b;          // low bits per element
+    uint32_t nb;         // directory entries (batches) of the list
+    uint32_t pad;
+};
+struct EfListInfo {  // a list of the tile in LDS while its chunk records are written
+    uint64_t o0, u, lw, hw, nb;  // first id, universe, offsets of the list's low / high words and directory entries
+    uint64_t c0;                 // chunks of the tile before this list
+    uint32_t m, lb;
+};
+
+__device__ inline uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((unsigned long long)v, o, 64);
+    return v;
+}
+// sum over the 256 threads of the workgroup, returned to every thread (sh: 4 words, reusable after the call)
+__device__ inline uint64_t block_sum256(uint64_t v, uint64_t *sh) {
+    v = wave_sum64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+// exclusive prefix of v over the 256 threads
+__device__ inline uint64_t block_exscan256(uint64_t v, uint64_t *sh) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint64_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t t = __shfl_up((unsigned long long)incl, o, 64);
+        if (lane >= (uint32_t)o) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63u) sh[wave] = incl;
+    __syncthreads();
+    uint64_t before = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 3; w++) before += w < wave ? sh[w] : 0ull;
+    return before + incl - v;
+}
+// geometry of this thread's lists (elias_fano.hpp:28-29 per list) -> lbits, universe, raw and the registers o / u / lb / r;
+// returns the tile totals.  All loads of a step are issued together: the kernel is two memory round trips long.
+__device__ inline EfTile ef_meta_tile(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist, uint32_t tile,
+                                      uint32_t *lbits, uint64_t *universe, EfRaw *raw, uint64_t *sh,
+                                      uint64_t (&o)[EF_META_E + 1], uint64_t (&u)[EF_META_E], uint32_t (&lb)[EF_META_E],
+                                      EfRaw (&r)[EF_META_E]) {
+    const uint32_t base = tile * EF_META_TILE + threadIdx.x * EF_META_E;
+    EfTile t = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t j = 0; j <= EF_META_E; j++) o[j] = offsets[base + j <= nlist ? base + j : nlist];
+#pragma unroll
+    for (uint32_t j = 0; j < EF_META_E; j++) u[j] = o[j + 1] > o[j] ? ids[o[j + 1] - 1] : 0ull;
+#pragma unroll
+    for (uint32_t j = 0; j < EF_META_E; j++) {
+        const uint32_t l = base + j;
+        const uint64_t m = o[j + 1] - o[j];
+        r[j] = EfRaw{0, 0, 0, 0};
+        lb[j] = 0;
+        if (m) {  // empty lists have no bitstream object (ef_bitstreams[list_no] stays null, :239-241)
+            t.wide |= ((u[j] >> 32) != 0 || m >= (1ull << 30)) ? 1ull : 0ull;  // -> the 64-bit encoder kernel
+            const uint64_t q = (u[j] >> 32) == 0 && (m >> 32) == 0 ? (uint64_t)((uint32_t)u[j] / (uint32_t)m) : u[j] / m;
+            lb[j] = q ? (uint32_t)msb64(q) : 0u;
+            const uint64_t hb = (m + 1) + (u[j] >> lb[j]) + 1;
+            t.bits += m * lb[j] + hb;
+            r[j].lw = (m * lb[j] + 63) / 64 + 1;  // +1 padding word for read_bits
+            r[j].hw = (hb + 63) / 64;
+            r[j].nb = (r[j].hw + 63) / 64;
+            r[j].cnt = (m + CHUNK_IDS - 1) / CHUNK_IDS;
+        }
+        if (l < nlist) {
+            lbits[l] = lb[j];
+            universe[l] = u[j];
+            if (raw) raw[l] = r[j];
+        }
+        t.lw += r[j].lw; t.hw += r[j].hw; t.nb += r[j].nb; t.cnt += r[j].cnt;
+    }
+    t.lw = block_sum256(t.lw, sh); t.hw = block_sum256(t.hw, sh); t.nb = block_sum256(t.nb, sh);
+    t.cnt = block_sum256(t.cnt, sh); t.bits = block_sum256(t.bits, sh); t.wide = block_sum256(t.wide, sh);
+    return t;
+}
+__global__ void __launch_bounds__(256) k_ef_meta(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist,
+                                                 uint32_t *lbits, uint64_t *universe, EfRaw *raw, EfTile *tiles) {
+    __shared__ uint64_t sh[4];
+    uint64_t o[EF_META_E + 1], u[EF_META_E];
+    uint32_t lb[EF_META_E];
+    EfRaw r[EF_META_E];
+    const EfTile t = ef_meta_tile(ids, offsets, nlist, blockIdx.x, lbits, universe, raw, sh, o, u, lb, r);
+    if (threadIdx.x == 0) tiles[blockIdx.x] = t;
+}
+// SINGLE: the whole object is one tile (grid of 1); the geometry is computed here and `raw` / `tiles` are not used
+template <bool SINGLE>
+__global__ void __launch_bounds__(256) k_ef_offsets(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist,
+                                                    uint32_t *lbits, uint64_t *universe, const EfRaw *raw,
+                                                    const EfTile *tiles, uint32_t ntiles, uint64_t *low_off,
+                                                    uint64_t *high_off, uint64_t *batch_off, EfChunkRec *recs,
+                                                    EfSummary *sum) {
+    __shared__ uint64_t sh[4];
+    __shared__ EfListInfo info[EF_META_TILE];
+    const uint32_t tile = blockIdx.x, t = threadIdx.x;
+    const uint32_t base = tile * EF_META_TILE + t * EF_META_E;
+    EfRaw P = {0, 0, 0, 0};  // totals of the tiles before this one
+    uint64_t bits = 0, wide = 0, tile_cnt;
+    uint64_t o[EF_META_E + 1], u[EF_META_E];
+    uint32_t lb[EF_META_E];
+    EfRaw r[EF_META_E];
+    if (SINGLE) {
+        const EfTile mine = ef_meta_tile(ids, offsets, nlist, 0u, lbits, universe, nullptr, sh, o, u, lb, r);
+        bits = mine.bits; wide = mine.wide; tile_cnt = mine.cnt;
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j <= EF_META_E; j++) o[j] = offsets[base + j <= nlist ? base + j : nlist];
+#pragma unroll
+        for (uint32_t j = 0; j < EF_META_E; j++) {
+            const uint32_t l = base + j < nlist ? base + j : nlist - 1u;  // (nlist >= EF_META_TILE here)
+            r[j] = raw[l]; u[j] = universe[l]; lb[j] = lbits[l];
+            if (base + j >= nlist) r[j] = EfRaw{0, 0, 0, 0};
+        }
+        for (uint32_t i = t; i < tile; i += 256u) {
+            P.lw += tiles[i].lw; P.hw += tiles[i].hw; P.nb += tiles[i].nb; P.cnt += tiles[i].cnt;
+        }
+        P.lw = block_sum256(P.lw, sh); P.hw = block_sum256(P.hw, sh); P.nb = block_sum256(P.nb, sh);
+        P.cnt = block_sum256(P.cnt, sh);
+        tile_cnt = tiles[tile].cnt;
+        if (tile + 1u == ntiles) {
+            for (uint32_t i = t; i < ntiles; i += 256u) { bits += tiles[i].bits; wide += tiles[i].wide; }
+            bits = block_sum256(bits, sh); wide = block_sum256(wide, sh);
+        }
+    }
+    EfRaw s = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t j = 0; j < EF_META_E; j++) { s.lw += r[j].lw; s.hw += r[j].hw; s.nb += r[j].nb; s.cnt += r[j].cnt; }
+    EfRaw acc;
+    acc.lw = P.lw + block_exscan256(s.lw, sh); acc.hw = P.hw + block_exscan256(s.hw, sh);
+    acc.nb = P.nb + block_exscan256(s.nb, sh); acc.cnt = block_exscan256(s.cnt, sh);  // (chunks: inside the tile)
+#pragma unroll
+    for (uint32_t j = 0; j < EF_META_E; j++) {
+        const uint32_t l = base + j;
+        if (l <= nlist) { low_off[l] = acc.lw; high_off[l] = acc.hw; batch_off[l] = acc.nb; }
+        if (l == nlist) {  // (exactly one thread of the last tile)
+            EfSummary out;
+            out.low_words = acc.lw; out.high_words = acc.hw; out.nbatches = acc.nb; out.nchunks = P.cnt + acc.cnt;
+            out.total_bits = bits; out.wide = wide ? 1u : 0u; out.unsorted = 0u;
+            *sum = out;
+        }
+        EfListInfo li;
+        li.o0 = o[j]; li.u = u[j]; li.lw = acc.lw; li.hw = acc.hw; li.nb = acc.nb; li.c0 = acc.cnt;
+        li.m = (uint32_t)(o[j + 1] - o[j]); li.lb = lb[j];
+        info[t * EF_META_E + j] = li;  // (lists past the end: no chunks, c0 = the tile's count)
+        acc.lw += r[j].lw; acc.hw += r[j].hw; acc.nb += r[j].nb; acc.cnt += r[j].cnt;
+    }
+    __syncthreads();
+    // the tile's chunk records, one per thread and step: the list of record x is the last one with c0 <= x
+    for (uint64_t x = t; x < tile_cnt; x += 256u) {
+        uint32_t lo = 0, hi = EF_META_TILE;  // first list with c0 > x
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (info[mid].c0 > x) hi = mid; else lo = mid + 1;
+        }
+        const EfListInfo li = info[lo - 1u];
+        const uint64_t c = x - li.c0;
+        const uint64_t hw = ((uint64_t)li.m + 1 + (li.u >> li.lb) + 1 + 63) / 64;
+        EfChunkRec rc;
+        rc.src = li.o0 + c * CHUNK_IDS;
+        rc.low_word = li.lw; rc.high_word = li.hw; rc.batch0 = li.nb; rc.u = li.u;
+        rc.start = (uint32_t)(c * CHUNK_IDS);
+        rc.n = li.m;
+        rc.list = tile * EF_META_TILE + lo - 1u;
+        rc.b = li.lb;
+        rc.nb = (uint32_t)((hw + 63) / 64);
+        rc.pad = 0;
+        recs[P.cnt + x] = rc;
     }
 }
-__global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, const uint64_t *offsets,
-                                                   const uint64_t *low_off, const uint64_t *high_off,
-                                                   const uint32_t *lbits, const uint64_t *universe, const Chunk *chunks,
-                                                   uint64_t nchunks, uint64_t *low, uint64_t *high, uint32_t *unsorted) {
+
+// select-directory entries and padding word of a chunk (what k_fill_items + k_ef_hrank + k_ef_zero_low_pads do for the
+// three-pass encoder).  A chunk owns the batches whose first bit 4096 k lies in (position of the id before the chunk,
+// position of its last id]; the last chunk of a list also owns the batches behind its last id.  hrank[k] = number of
+// ids of the list with a position below 4096 k = start + (ids of this chunk below it).
+template <typename PT, int R>
+__device__ inline void ef_chunk_directory(const EfChunkRec &rc, const uint64_t *src, uint32_t nc, const PT (&pos)[R],
+                                          PT pos_before, PT pos_last, uint64_t *low, uint32_t *hrank, Chunk *batches) {
+    const uint32_t lane = lane_id();
+    const bool last_chunk = rc.start + nc == rc.n;
+    if (last_chunk && lane == 0) low[rc.low_word + (((uint64_t)rc.n * rc.b + 63) >> 6)] = 0ull;
+    const uint64_t kfirst = rc.start ? (uint64_t)(pos_before >> 12) + 1u : 0u;
+    const uint64_t kend = last_chunk ? (uint64_t)rc.nb : (uint64_t)(pos_last >> 12) + 1u;  // one past the last owned
+    if (kfirst >= kend) return;
+    if (kend - kfirst <= 4u) {
+        for (uint64_t k = kfirst; k < kend; k++) {
+            const PT T = (PT)(k << 12);
+            uint32_t below = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) below += popc64(ballot(pos[r] < T));  // (slots past the chunk hold the maximum)
+            if (lane == 0) {
+                hrank[rc.batch0 + k] = rc.start + below;
+                batches[rc.batch0 + k] = Chunk{rc.list, (uint32_t)k};
+            }
+        }
+    } else {  // a sparse chunk spanning many batches: a lane per batch, binary search over the chunk's ids
+        for (uint64_t k = kfirst + lane; k < kend; k += 64) {
+            const uint64_t T = k << 12;
+            uint32_t lo = 0, hi = nc;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((src[mid] >> rc.b) + rc.start + mid >= T) hi = mid; else lo = mid + 1;
+            }
+            hrank[rc.batch0 + k] = rc.start + lo;
+            batches[rc.batch0 + k] = Chunk{rc.list, (uint32_t)k};
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, const EfChunkRec *recs,
+                                                   uint64_t nchunks, uint64_t *low, uint64_t *high, uint32_t *hrank,
+                                                   Chunk *batches, uint32_t *unsorted) {
     __shared__ unsigned long long win[EF_WIN_WORDS];
     __shared__ unsigned long long img[CHUNK_IDS + 8];  // low words of the chunk (CHUNK_IDS * l / 64 <= CHUNK_IDS)
     const uint32_t lane = lane_id();
     for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const Chunk ch = chunks[c];
-        const uint32_t b = lbits[ch.list];
-        const uint64_t off = offsets[ch.list];
-        const uint64_t n = offsets[ch.list + 1] - off;
-        const uint64_t u = universe[ch.list];
-        const uint32_t nc = (uint32_t)(n - ch.start < CHUNK_IDS ? n - ch.start : CHUNK_IDS);
-        const uint64_t *src = sorted_ids + off;
-        unsigned long long *dst = (unsigned long long *)(high + high_off[ch.list]);
+        const EfChunkRec rc = recs[c];
+        const uint32_t start = rc.start;
+        const uint32_t b = rc.b;
+        const uint64_t n = rc.n;
+        const uint64_t u = rc.u;
+        const uint32_t nc = (uint32_t)(n - start < CHUNK_IDS ? n - start : CHUNK_IDS);
+        const uint64_t *src = sorted_ids + rc.src - start;  // the list's first id
+        unsigned long long *dst = (unsigned long long *)(high + rc.high_word);
         // the chunk's ids: eight independent coalesced loads per lane
         uint64_t v[CHUNK_IDS / 64];
-        const uint64_t before = ch.start ? src[ch.start - 1] : 0ull;  // the id before this chunk (order check)
+        const uint64_t before = start ? src[start - 1] : 0ull;  // the id before this chunk (order check)
 #pragma unroll
         for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
             const uint32_t i = lane + 64 * r;
-            v[r] = i < nc ? src[ch.start + i] : ~0ull;
+            v[r] = i < nc ? src[start + i] : ~0ull;
         }
         const uint32_t nlw = (uint32_t)(((uint64_t)nc * b + 63) >> 6);
         for (uint32_t w = lane; w < nlw + 1u; w += 64) img[w] = 0;
@@ -284,7 +516,7 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
             pos[r] = ~0ull;
             if (i < nc) {
                 bad |= v[r] > u || prev > v[r];
-                pos[r] = v[r] > u ? ~0ull : (v[r] >> b) + (ch.start + i);
+                pos[r] = v[r] > u ? ~0ull : (v[r] >> b) + (start + i);
             }
         }
         if (ballot(bad)) {
@@ -303,10 +535,10 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
         // Word ownership instead of global atomics on the two boundary words: a high word belongs to the chunk that
         // holds its first element.  This chunk skips word wf when the id before the chunk already lies in it, and
         // adds to word wl the bits of the (at most 63) ids after the chunk that still fall into it.
-        const bool own_first = !(ch.start && (((before >> b) + (ch.start - 1)) >> 6) == wf && before <= u);
+        const bool own_first = !(start && (((before >> b) + (start - 1)) >> 6) == wf && before <= u);
         uint64_t tail_bits = 0;
         {
-            const uint64_t j = (uint64_t)ch.start + nc + lane;
+            const uint64_t j = (uint64_t)start + nc + lane;
             if (j < n) {
                 const uint64_t vn = src[j];
                 const uint64_t pn = (vn >> b) + j;
@@ -353,11 +585,13 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
                 if (hv && w <= wl && (w != wf || own_first)) dst[w] = hv;  // (the stream was zeroed: empty words stay)
             }
             if (wbase == wf && b) {
-                uint64_t *ldst = low + low_off[ch.list] + (((uint64_t)ch.start * b) >> 6);
+                uint64_t *ldst = low + rc.low_word + (((uint64_t)start * b) >> 6);
                 for (uint32_t w = lane; w < nlw; w += 64) ldst[w] = img[w];
             }
             __syncthreads();
         }
+        ef_chunk_directory<uint64_t>(rc, src + start, nc, pos, start ? (before >> b) + (start - 1) : 0ull, last,
+                                     low, hrank, batches);
     }
 }
 
@@ -366,32 +600,30 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
 // low-bit image run on 32-bit values -- the 64-bit version spends about half of its instructions on two-register
 // compares, shifts and shuffles, and the kernel is as much issue- as bandwidth-bound (no stores, no LDS: 162 of
 // 227 us per 64 M ids).
-__global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *sorted_ids, const uint64_t *offsets,
-                                                     const uint64_t *low_off, const uint64_t *high_off,
-                                                     const uint32_t *lbits, const uint64_t *universe,
-                                                     const Chunk *chunks, uint64_t nchunks, uint64_t *low, uint64_t *high,
-                                                     uint32_t *unsorted) {
+__global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *sorted_ids, const EfChunkRec *recs,
+                                                     uint64_t nchunks, uint64_t *low, uint64_t *high, uint32_t *hrank,
+                                                     Chunk *batches, uint32_t *unsorted) {
     __shared__ uint32_t win32[EF_WIN_WORDS * 2];
     __shared__ uint32_t img32[(CHUNK_IDS + 8) * 2];  // low words of the chunk, as 32-bit halves
     const uint32_t lane = lane_id();
     constexpr uint32_t NONE = 0xffffffffu;
     for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const Chunk ch = chunks[c];
-        const uint32_t b = lbits[ch.list];
-        const uint64_t off = offsets[ch.list];
-        const uint32_t n = (uint32_t)(offsets[ch.list + 1] - off);
-        const uint32_t u = (uint32_t)universe[ch.list];
-        const uint32_t nc = n - ch.start < CHUNK_IDS ? n - ch.start : CHUNK_IDS;
-        const uint64_t *src = sorted_ids + off;
-        uint64_t *dst = high + high_off[ch.list];
+        const EfChunkRec rc = recs[c];
+        const uint32_t start = rc.start;
+        const uint32_t b = rc.b;
+        const uint32_t n = rc.n;
+        const uint32_t u = (uint32_t)rc.u;
+        const uint32_t nc = n - start < CHUNK_IDS ? n - start : CHUNK_IDS;
+        const uint64_t *src = sorted_ids + rc.src - start;  // the list's first id
+        uint64_t *dst = high + rc.high_word;
         uint64_t v[CHUNK_IDS / 64];
-        const uint64_t before64 = ch.start ? src[ch.start - 1] : 0ull;  // the id before this chunk (order check)
+        const uint64_t before64 = start ? src[start - 1] : 0ull;  // the id before this chunk (order check)
 #pragma unroll
         for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
             const uint32_t i = lane + 64 * r;
-            v[r] = i < nc ? src[ch.start + i] : 0ull;
+            v[r] = i < nc ? src[start + i] : 0ull;
         }
-        const uint32_t jn = ch.start + nc + lane;  // the (at most 64) ids after the chunk: last word's ownership
+        const uint32_t jn = start + nc + lane;  // the (at most 64) ids after the chunk: last word's ownership
         const uint64_t vnext = jn < n ? src[jn] : ~0ull;
         const uint32_t nlw32 = (nc * b + 31u) >> 5;
         for (uint32_t w = lane; w < nlw32 + 2u; w += 64) img32[w] = 0;
@@ -408,7 +640,7 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *sorted_ids,
             pos[r] = NONE;
             if (i < nc) {
                 bad |= (uint32_t)(v[r] >> 32) != 0u || x > u || prev > x;
-                pos[r] = (x >> b) + (ch.start + i);
+                pos[r] = (x >> b) + (start + i);
             }
         }
         if (ballot(bad)) {
@@ -425,7 +657,7 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *sorted_ids,
         const uint32_t wf = first >> 6, wl = last >> 6;
         // word ownership as in k_ef_lowhigh
         const uint32_t before = (uint32_t)before64;
-        const bool own_first = !(ch.start && (((before >> b) + (ch.start - 1u)) >> 6) == wf && before <= u);
+        const bool own_first = !(start && (((before >> b) + (start - 1u)) >> 6) == wf && before <= u);
         uint64_t tail_bits = 0;
         {
             if (jn < n && (vnext >> 32) == 0) {
@@ -474,12 +706,14 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *sorted_ids,
             }
             if (wbase == wf && b) {
                 const uint32_t nlw = (nc * b + 63u) >> 6;
-                uint64_t *ldst = low + low_off[ch.list] + (((uint64_t)ch.start * b) >> 6);
+                uint64_t *ldst = low + rc.low_word + (((uint64_t)start * b) >> 6);
                 const uint64_t *img = (const uint64_t *)img32;
                 for (uint32_t w = lane; w < nlw; w += 64) ldst[w] = img[w];
             }
             __syncthreads();
         }
+        ef_chunk_directory<uint32_t>(rc, src + start, nc, pos, start ? (before >> b) + (start - 1u) : 0u, last,
+                                     low, hrank, batches);
     }
 }
 
@@ -988,13 +1222,12 @@ int ef_ensure_meta(const vidc_ef *e) {
     return VIDC_OK;
 }
 
-// the part of the encoder shared by the list and the graph-row entry points: e->d_offsets, nlist, ntotal are set
-// assume_sorted: single-pass encoder; *retry is raised when some list turned out not to be ascending
-int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t flags, bool assume_sorted, bool *retry) {
+// the three-pass encoder for objects with lists that are not ascending (max + order check, sort, streams):
+// e->d_offsets, nlist, ntotal are set
+int ef_encode_general(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t flags) {
     const uint64_t nlist = e->nlist;
     const uint32_t nl32 = (uint32_t)nlist;
     double kernel_ms = 0;
-    bool check_unsorted = false;
     VidcPhaseTimer pt(ctx);  // phases are timed without a host synchronisation each
     auto timed = [&](auto &&fn) -> int {
         pt.begin();
@@ -1034,12 +1267,8 @@ int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t 
     VIDC_HIP(hipMemsetAsync(s_tot.p, 0, sizeof(EfTotals), ctx->stream));
     if (e->nchunks)
         VIDC_TRY(timed([&] {
-            if (assume_sorted)
-                hipLaunchKernelGGL(k_ef_prep_last, dim3(lgrid), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
-                                   s_prep.as<PrepOut>());
-            else
-                hipLaunchKernelGGL(k_ef_prep, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, e->d_offsets.p,
-                                   e->d_chunks.p, e->nchunks, s_prep.as<PrepOut>());
+            hipLaunchKernelGGL(k_ef_prep, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, e->d_offsets.p, e->d_chunks.p,
+                               e->nchunks, s_prep.as<PrepOut>());
         }));
     hipLaunchKernelGGL(k_ef_geom, dim3(lgrid), dim3(256), 0, ctx->stream, e->d_offsets.p, s_prep.as<PrepOut>(), nl32,
                        e->d_lbits.p, e->d_universe.p, s_lw.as<uint32_t>(), s_hw.as<uint32_t>(), s_nb.as<uint32_t>(),
@@ -1114,30 +1343,12 @@ int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t 
         // (a memset of the whole low stream -- 2 bytes per id -- cost more than the geometry kernels together)
         hipLaunchKernelGGL(k_ef_zero_low_pads, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 2048)), dim3(256), 0,
                            ctx->stream, e->d_low_off.p, (uint32_t)nlist, e->d_low.p);
-        if (assume_sorted) {
-            VIDC_HIP(hipMemsetAsync(s_tot.p, 0, sizeof(EfTotals), ctx->stream));
-            VIDC_TRY(timed([&] {
-                if (wide_ids)
-                    hipLaunchKernelGGL(k_ef_lowhigh, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p,
-                                       e->d_low_off.p, e->d_high_off.p, e->d_lbits.p, e->d_universe.p, e->d_chunks.p,
-                                       e->nchunks, e->d_low.p, e->d_high.p, &s_tot.as<EfTotals>()->n_unsorted);
-                else
-                    hipLaunchKernelGGL(k_ef_lowhigh32, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p,
-                                       e->d_low_off.p, e->d_high_off.p, e->d_lbits.p, e->d_universe.p, e->d_chunks.p,
-                                       e->nchunks, e->d_low.p, e->d_high.p, &s_tot.as<EfTotals>()->n_unsorted);
-            }));
-            // the "some list was not ascending" flag comes back with the final synchronisation (the directory
-            // kernels below are cheap and simply wasted in that rare case)
-            VIDC_HIP(hipMemcpyAsync(t, s_tot.p, sizeof(EfTotals), hipMemcpyDeviceToHost, ctx->stream));
-            check_unsorted = true;
-        } else {
-            VIDC_TRY(timed([&] {
-                hipLaunchKernelGGL(k_ef_low, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p,
-                                   e->d_low_off.p, e->d_lbits.p, e->d_chunks.p, e->nchunks, e->d_low.p);
-                hipLaunchKernelGGL(k_ef_high, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p,
-                                   e->d_high_off.p, e->d_lbits.p, e->d_chunks.p, e->nchunks, e->d_high.p);
-            }));
-        }
+        VIDC_TRY(timed([&] {
+            hipLaunchKernelGGL(k_ef_low, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p,
+                               e->d_low_off.p, e->d_lbits.p, e->d_chunks.p, e->nchunks, e->d_low.p);
+            hipLaunchKernelGGL(k_ef_high, dim3(cgrid), dim3(64), 0, ctx->stream, d_sorted, e->d_offsets.p,
+                               e->d_high_off.p, e->d_lbits.p, e->d_chunks.p, e->nchunks, e->d_high.p);
+        }));
     }
     // select directory
     VIDC_TRY(e->d_batches.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
@@ -1153,7 +1364,89 @@ int ef_encode_common(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t 
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
     kernel_ms += pt.collect();
     ctx->last_kernel_ms = kernel_ms;
-    if (check_unsorted && (uint32_t)(t[1] & 0xffffffffu)) *retry = true;
+    return VIDC_OK;
+}
+
+// the single-pass encoder (kernels above); *retry is raised when some list turned out not to be ascending.
+// nchunks: number of CHUNK_IDS-sized pieces of all lists (the caller walks the host offsets anyway)
+int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t flags, uint64_t nchunks, bool *retry) {
+    const uint64_t nlist = e->nlist;
+    const uint32_t nl32 = (uint32_t)nlist;
+    const uint32_t ntiles = nl32 / EF_META_TILE + 1u;  // (the entry behind the last list belongs to a tile as well)
+    VidcPhaseTimer pt(ctx);
+    Scratch s_raw, s_tiles, s_sum, s_recs;
+    Pinned tail;
+    VIDC_TRY(tail.get(ctx, 2 * sizeof(EfSummary)));
+    EfSummary *hs = tail.as<EfSummary>();
+    VIDC_TRY(s_raw.get(ctx, (nlist + 1) * sizeof(EfRaw)));
+    VIDC_TRY(s_tiles.get(ctx, (size_t)ntiles * sizeof(EfTile)));
+    VIDC_TRY(s_sum.get(ctx, sizeof(EfSummary)));
+    VIDC_TRY(s_recs.get(ctx, (nchunks ? nchunks : 1) * sizeof(EfChunkRec)));
+    VIDC_TRY(e->d_low_off.alloc(nlist + 1, ctx->dpool)); VIDC_TRY(e->d_high_off.alloc(nlist + 1, ctx->dpool));
+    VIDC_TRY(e->d_batch_off.alloc(nlist + 1, ctx->dpool));
+    VIDC_TRY(e->d_lbits.alloc(nlist ? nlist : 1, ctx->dpool)); VIDC_TRY(e->d_universe.alloc(nlist ? nlist : 1, ctx->dpool));
+    VIDC_TRY(e->d_chunks.alloc(1, ctx->dpool));  // (the chunk table of the three-pass encoder: not needed here)
+    pt.begin();
+    if (ntiles == 1u) {
+        hipLaunchKernelGGL(k_ef_offsets<true>, dim3(1), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
+                           e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), (const EfTile *)nullptr, 1u, e->d_low_off.p,
+                           e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(), s_sum.as<EfSummary>());
+    } else {
+        hipLaunchKernelGGL(k_ef_meta, dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32, e->d_lbits.p,
+                           e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>());
+        hipLaunchKernelGGL(k_ef_offsets<false>, dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
+                           e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>(), ntiles,
+                           e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
+                           s_sum.as<EfSummary>());
+    }
+    VIDC_HIP(hipGetLastError());
+    pt.end();
+    VIDC_HIP(hipMemcpyAsync(hs, s_sum.p, sizeof(EfSummary), hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    if (hs->nchunks != nchunks) {
+        set_error("elias-fano encoder: chunk count mismatch (%llu vs %llu)", (unsigned long long)hs->nchunks,
+                  (unsigned long long)nchunks);
+        return VIDC_ERR_OVERFLOW;
+    }
+    const uint64_t low_words = hs->low_words, high_words = hs->high_words;
+    e->nchunks = nchunks;
+    e->nbatches = hs->nbatches;
+    e->total_bits = hs->total_bits;
+    const bool wide_ids = hs->wide != 0;
+    e->narrow = !wide_ids;
+    VIDC_TRY(e->d_low.alloc(low_words ? low_words : 1, ctx->dpool));
+    VIDC_TRY(e->d_high.alloc(high_words ? high_words : 1, ctx->dpool));
+    VIDC_TRY(e->d_batches.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
+    VIDC_TRY(e->d_hrank.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
+    VIDC_HIP(hipMemsetAsync(e->d_high.p, 0, (high_words ? high_words : 1) * 8, ctx->stream));
+    if ((flags & VIDC_EF_WANT_PERM) != 0) {
+        VIDC_TRY(e->d_perm.alloc(e->ntotal ? e->ntotal : 1, ctx->dpool));
+        e->has_perm = true;
+        if (e->ntotal) {
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((e->ntotal + 255) / 256, (uint64_t)ctx->num_cu * 32);
+            pt.begin();
+            hipLaunchKernelGGL(k_iota_perm, dim3(grid), dim3(256), 0, ctx->stream, e->d_offsets.p, nl32, e->ntotal,
+                               e->d_perm.p);
+            pt.end();
+        }
+    }
+    if (nchunks) {
+        const uint32_t cgrid = (uint32_t)std::min<uint64_t>(nchunks, (uint64_t)ctx->num_cu * 256);
+        uint32_t *d_flag = &s_sum.as<EfSummary>()->unsorted;
+        pt.begin();
+        if (wide_ids)
+            hipLaunchKernelGGL(k_ef_lowhigh, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(), nchunks,
+                               e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+        else
+            hipLaunchKernelGGL(k_ef_lowhigh32, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
+                               nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+        VIDC_HIP(hipGetLastError());
+        pt.end();
+        VIDC_HIP(hipMemcpyAsync(hs + 1, s_sum.p, sizeof(EfSummary), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->last_kernel_ms = pt.collect();
+    if (nchunks && hs[1].unsorted) *retry = true;
     return VIDC_OK;
 }
 
@@ -1174,11 +1467,14 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     if (nlist) e->offsets.assign(offsets, offsets + nlist + 1);
     e->offsets_host = true;
     e->ntotal = e->offsets[nlist];
-    for (uint64_t l = 0; l < nlist; l++)
+    uint64_t nchunks = 0;
+    for (uint64_t l = 0; l < nlist; l++) {
         if (e->offsets[l + 1] < e->offsets[l] || e->offsets[l + 1] - e->offsets[l] > 0xfffffff0ull) {
             set_error("bad offsets at list %llu", (unsigned long long)l);
             return VIDC_ERR_INVALID;
         }
+        nchunks += (e->offsets[l + 1] - e->offsets[l] + CHUNK_IDS - 1) / CHUNK_IDS;
+    }
     if (e->ntotal && !d_ids) return VIDC_ERR_INVALID;
     VIDC_TRY(e->d_offsets.alloc(nlist + 1, ctx->dpool));
     Pinned h_off;
@@ -1186,11 +1482,11 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     std::memcpy(h_off.p, e->offsets.data(), (nlist + 1) * 8);
     VIDC_HIP(hipMemcpyAsync(e->d_offsets.p, h_off.p, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     bool retry = false;
-    VIDC_TRY(ef_encode_common(ctx, e.get(), d_ids, flags, true, &retry));
+    VIDC_TRY(ef_encode_fast(ctx, e.get(), d_ids, flags, nchunks, &retry));
     if (retry) {  // some list is not ascending: general three-pass encoder with the sort
         e->total_bits = 0;
         e->has_perm = false;
-        VIDC_TRY(ef_encode_common(ctx, e.get(), d_ids, flags, false, &retry));
+        VIDC_TRY(ef_encode_general(ctx, e.get(), d_ids, flags));
     }
     *out = e.release();
     return VIDC_OK;
