@@ -237,14 +237,16 @@ __global__ void __launch_bounds__(64) k_ef_high(const uint64_t *sorted_ids, cons
 // ---- single-pass encoder for ascending lists (the normal case: Faiss lists are in add order, graph rows are sorted
 // by k_rows_sorted).  The universe of an ascending list is its last element, so the ids are streamed from HBM once.
 // Three launches whatever the number of lists:
-//   k_ef_meta      per-list geometry from (size, last id) and the totals of every tile of EF_META_TILE lists
+//   k_ef_meta      per-list geometry from (size, last id) and the totals of every tile of lists
 //   k_ef_offsets   word / batch / chunk offsets (tile prefix + scan inside the tile) and one 64-byte record per chunk
-//                  (fewer than EF_META_TILE lists: this kernel alone, it computes the geometry itself)
+//                  (up to EF_SINGLE_LISTS lists: this kernel alone, it computes the geometry itself)
 //   k_ef_lowhigh*  one wavefront per chunk record: both bit streams, the order check, the list's padding word and the
 //                  select-directory entries whose batch starts inside the chunk
 // Any order violation raises `unsorted` and the caller redoes the object with the three-pass path further down.
-#define EF_META_E 4u                       // consecutive lists per thread
-#define EF_META_TILE (256u * EF_META_E)    // lists per workgroup
+// (a tile = the lists of one workgroup: 512 threads with two lists each when that is the whole object, else 256 threads
+// with one list each, or four each from 2^18 lists on -- every workgroup of k_ef_offsets sums the totals of the tiles before it)
+#define EF_SINGLE_LISTS 1024u
+#define EF_E1_MAX_LISTS 262144u
 struct EfRaw {     // the four per-list counts (k_ef_meta) whose prefix sums are the offsets of a list
     uint64_t lw, hw, nb, cnt;  // low words (incl. the padding word), high words, batches of 64 high words, chunks
 };
@@ -270,66 +272,98 @@ struct EfChunkRec {
     uint32_t nb;         // directory entries (batches) of the list
     uint32_t pad;
 };
-struct EfListInfo {  // a list of the tile in LDS while its chunk records are written
+struct EfListInfo {  // a list of the tile in LDS while the chunk records behind its first one are written
     uint64_t o0, u, lw, hw, nb;  // first id, universe, offsets of the list's low / high words and directory entries
-    uint64_t c0;                 // chunks of the tile before this list
+    uint32_t c0, x0;             // chunks / chunks other than first ones of the tile before this list
     uint32_t m, lb;
 };
 
-__device__ inline uint64_t wave_sum64(uint64_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((unsigned long long)v, o, 64);
-    return v;
+// inclusive prefix sum over the 64 lanes in six DPP adds (row_shr 1 2 4 8, row_bcast 15 31): the shuffle version is
+// six LDS-crossbar round trips per value, and these kernels are a few lone wavefronts whose time is their latency
+__device__ __forceinline__ uint32_t wave_scan32(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
 }
-// sum over the 256 threads of the workgroup, returned to every thread (sh: 4 words, reusable after the call)
-__device__ inline uint64_t block_sum256(uint64_t v, uint64_t *sh) {
-    v = wave_sum64(v);
-    __syncthreads();
-    if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
+// the same for values below 2^45 (word / chunk counts, stream bits of a few lists): two limbs of 20 + 25 bits
+__device__ __forceinline__ uint64_t wave_scan64(uint64_t v) {
+    const uint32_t lo = wave_scan32((uint32_t)v & 0xfffffu), hi = wave_scan32((uint32_t)(v >> 20));
+    return ((uint64_t)hi << 20) + lo;
 }
-// exclusive prefix of v over the 256 threads
-__device__ inline uint64_t block_exscan256(uint64_t v, uint64_t *sh) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint64_t incl = v;
+// sums of N values over the NW wavefronts of the workgroup, returned to every thread (sh: N * NW words)
+template <int N, int NW>
+__device__ inline void block_sum(uint64_t (&v)[N], uint64_t *sh) {
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint64_t t = __shfl_up((unsigned long long)incl, o, 64);
-        if (lane >= (uint32_t)o) incl += t;
+    for (int k = 0; k < N; k++) v[k] = wave_scan64(v[k]);  // (lane 63 holds the sum)
+    __syncthreads();  // (sh may still be read from an earlier call)
+    if ((threadIdx.x & 63u) == 63u)
+#pragma unroll
+        for (int k = 0; k < N; k++) sh[NW * k + (threadIdx.x >> 6)] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        v[k] = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) v[k] += sh[NW * k + w];
     }
-    __syncthreads();
-    if (lane == 63u) sh[wave] = incl;
-    __syncthreads();
-    uint64_t before = 0;
+}
+// exclusive prefixes of N values over the threads of the workgroup (v -> prefix), totals to tot
+template <int N, int NW>
+__device__ inline void block_exscan(uint64_t (&v)[N], uint64_t (&tot)[N], uint64_t *sh) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint64_t incl[N];
 #pragma unroll
-    for (uint32_t w = 0; w < 3; w++) before += w < wave ? sh[w] : 0ull;
-    return before + incl - v;
+    for (int k = 0; k < N; k++) incl[k] = wave_scan64(v[k]);
+    __syncthreads();
+    if (lane == 63u)
+#pragma unroll
+        for (int k = 0; k < N; k++) sh[NW * k + wave] = incl[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        uint64_t before = 0;
+        tot[k] = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < (uint32_t)NW; w++) {
+            const uint64_t x = sh[NW * k + w];
+            before += w < wave ? x : 0ull;
+            tot[k] += x;
+        }
+        v[k] = before + incl[k] - v[k];
+    }
 }
 // geometry of this thread's lists (elias_fano.hpp:28-29 per list) -> lbits, universe, raw and the registers o / u / lb / r;
 // returns the tile totals.  All loads of a step are issued together: the kernel is two memory round trips long.
+template <int E, int NT>
 __device__ inline EfTile ef_meta_tile(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist, uint32_t tile,
                                       uint32_t *lbits, uint64_t *universe, EfRaw *raw, uint64_t *sh,
-                                      uint64_t (&o)[EF_META_E + 1], uint64_t (&u)[EF_META_E], uint32_t (&lb)[EF_META_E],
-                                      EfRaw (&r)[EF_META_E]) {
-    const uint32_t base = tile * EF_META_TILE + threadIdx.x * EF_META_E;
-    EfTile t = {0, 0, 0, 0, 0, 0};
+                                      uint64_t (&o)[E + 1], uint64_t (&u)[E], uint32_t (&lb)[E], EfRaw (&r)[E]) {
+    const uint32_t base = (tile * NT + threadIdx.x) * E;
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};  // lw, hw, nb, cnt, bits, wide
 #pragma unroll
-    for (uint32_t j = 0; j <= EF_META_E; j++) o[j] = offsets[base + j <= nlist ? base + j : nlist];
+    for (uint32_t j = 0; j <= E; j++) o[j] = offsets[base + j <= nlist ? base + j : nlist];
 #pragma unroll
-    for (uint32_t j = 0; j < EF_META_E; j++) u[j] = o[j + 1] > o[j] ? ids[o[j + 1] - 1] : 0ull;
+    for (uint32_t j = 0; j < E; j++) u[j] = o[j + 1] > o[j] ? ids[o[j + 1] - 1] : 0ull;
 #pragma unroll
-    for (uint32_t j = 0; j < EF_META_E; j++) {
+    for (uint32_t j = 0; j < E; j++) {
         const uint32_t l = base + j;
         const uint64_t m = o[j + 1] - o[j];
         r[j] = EfRaw{0, 0, 0, 0};
         lb[j] = 0;
         if (m) {  // empty lists have no bitstream object (ef_bitstreams[list_no] stays null, :239-241)
-            t.wide |= ((u[j] >> 32) != 0 || m >= (1ull << 30)) ? 1ull : 0ull;  // -> the 64-bit encoder kernel
-            const uint64_t q = (u[j] >> 32) == 0 && (m >> 32) == 0 ? (uint64_t)((uint32_t)u[j] / (uint32_t)m) : u[j] / m;
-            lb[j] = q ? (uint32_t)msb64(q) : 0u;
+            t[5] |= ((u[j] >> 32) != 0 || m >= (1ull << 30)) ? 1ull : 0ull;  // -> the 64-bit encoder kernel
+            // msb(u / m) without the division: with k = msb(u) - msb(m), u / m lies in (2^(k-1), 2^(k+1)) and reaches
+            // 2^k exactly when (u >> k) >= m  (u < m: the quotient is 0 and l = 0, elias_fano.hpp:28)
+            if (u[j] >= m) {
+                const uint32_t k = (uint32_t)(msb64(u[j]) - msb64(m));
+                lb[j] = (u[j] >> k) >= m ? k : k - 1u;
+            }
             const uint64_t hb = (m + 1) + (u[j] >> lb[j]) + 1;
-            t.bits += m * lb[j] + hb;
+            t[4] += m * lb[j] + hb;
             r[j].lw = (m * lb[j] + 63) / 64 + 1;  // +1 padding word for read_bits
             r[j].hw = (hb + 63) / 64;
             r[j].nb = (r[j].hw + 63) / 64;
@@ -340,103 +374,114 @@ __device__ inline EfTile ef_meta_tile(const uint64_t *ids, const uint64_t *offse
             universe[l] = u[j];
             if (raw) raw[l] = r[j];
         }
-        t.lw += r[j].lw; t.hw += r[j].hw; t.nb += r[j].nb; t.cnt += r[j].cnt;
+        t[0] += r[j].lw; t[1] += r[j].hw; t[2] += r[j].nb; t[3] += r[j].cnt;
     }
-    t.lw = block_sum256(t.lw, sh); t.hw = block_sum256(t.hw, sh); t.nb = block_sum256(t.nb, sh);
-    t.cnt = block_sum256(t.cnt, sh); t.bits = block_sum256(t.bits, sh); t.wide = block_sum256(t.wide, sh);
-    return t;
+    block_sum<6, NT / 64>(t, sh);
+    return EfTile{t[0], t[1], t[2], t[3], t[4], t[5]};
 }
+template <int E>
 __global__ void __launch_bounds__(256) k_ef_meta(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist,
                                                  uint32_t *lbits, uint64_t *universe, EfRaw *raw, EfTile *tiles) {
-    __shared__ uint64_t sh[4];
-    uint64_t o[EF_META_E + 1], u[EF_META_E];
-    uint32_t lb[EF_META_E];
-    EfRaw r[EF_META_E];
-    const EfTile t = ef_meta_tile(ids, offsets, nlist, blockIdx.x, lbits, universe, raw, sh, o, u, lb, r);
+    __shared__ uint64_t sh[24];
+    uint64_t o[E + 1], u[E];
+    uint32_t lb[E];
+    EfRaw r[E];
+    const EfTile t = ef_meta_tile<E, 256>(ids, offsets, nlist, blockIdx.x, lbits, universe, raw, sh, o, u, lb, r);
     if (threadIdx.x == 0) tiles[blockIdx.x] = t;
 }
+__device__ inline EfChunkRec ef_make_rec(uint32_t l, uint64_t c, uint64_t o0, uint32_t m, uint64_t u, uint32_t lb,
+                                         uint64_t lw, uint64_t hw, uint64_t nb0) {
+    const uint64_t nhw = ((uint64_t)m + 1 + (u >> lb) + 1 + 63) / 64;
+    EfChunkRec rc;
+    rc.src = o0 + c * CHUNK_IDS;
+    rc.low_word = lw; rc.high_word = hw; rc.batch0 = nb0; rc.u = u;
+    rc.start = (uint32_t)(c * CHUNK_IDS);
+    rc.n = m;
+    rc.list = l;
+    rc.b = lb;
+    rc.nb = (uint32_t)((nhw + 63) / 64);
+    rc.pad = 0;
+    return rc;
+}
 // SINGLE: the whole object is one tile (grid of 1); the geometry is computed here and `raw` / `tiles` are not used
-template <bool SINGLE>
-__global__ void __launch_bounds__(256) k_ef_offsets(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist,
+template <bool SINGLE, int E, int NT>
+__global__ void __launch_bounds__(NT) k_ef_offsets(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist,
                                                     uint32_t *lbits, uint64_t *universe, const EfRaw *raw,
                                                     const EfTile *tiles, uint32_t ntiles, uint64_t *low_off,
                                                     uint64_t *high_off, uint64_t *batch_off, EfChunkRec *recs,
                                                     EfSummary *sum) {
-    __shared__ uint64_t sh[4];
-    __shared__ EfListInfo info[EF_META_TILE];
+    constexpr uint32_t TILE = NT * E;
+    __shared__ uint64_t sh[6 * (NT / 64)];
+    __shared__ EfListInfo info[TILE];
     const uint32_t tile = blockIdx.x, t = threadIdx.x;
-    const uint32_t base = tile * EF_META_TILE + t * EF_META_E;
-    EfRaw P = {0, 0, 0, 0};  // totals of the tiles before this one
-    uint64_t bits = 0, wide = 0, tile_cnt;
-    uint64_t o[EF_META_E + 1], u[EF_META_E];
-    uint32_t lb[EF_META_E];
-    EfRaw r[EF_META_E];
+    const uint32_t base = tile * TILE + t * E;
+    uint64_t P[6] = {0, 0, 0, 0, 0, 0};  // lw, hw, nb, cnt of the tiles before this one; bits, wide of all tiles
+    uint64_t o[E + 1], u[E];
+    uint32_t lb[E];
+    EfRaw r[E];
     if (SINGLE) {
-        const EfTile mine = ef_meta_tile(ids, offsets, nlist, 0u, lbits, universe, nullptr, sh, o, u, lb, r);
-        bits = mine.bits; wide = mine.wide; tile_cnt = mine.cnt;
+        const EfTile mine = ef_meta_tile<E, NT>(ids, offsets, nlist, 0u, lbits, universe, nullptr, sh, o, u, lb, r);
+        P[4] = mine.bits; P[5] = mine.wide;
     } else {
 #pragma unroll
-        for (uint32_t j = 0; j <= EF_META_E; j++) o[j] = offsets[base + j <= nlist ? base + j : nlist];
+        for (uint32_t j = 0; j <= E; j++) o[j] = offsets[base + j <= nlist ? base + j : nlist];
 #pragma unroll
-        for (uint32_t j = 0; j < EF_META_E; j++) {
-            const uint32_t l = base + j < nlist ? base + j : nlist - 1u;  // (nlist >= EF_META_TILE here)
+        for (uint32_t j = 0; j < E; j++) {
+            const uint32_t l = base + j < nlist ? base + j : nlist - 1u;
             r[j] = raw[l]; u[j] = universe[l]; lb[j] = lbits[l];
             if (base + j >= nlist) r[j] = EfRaw{0, 0, 0, 0};
         }
-        for (uint32_t i = t; i < tile; i += 256u) {
-            P.lw += tiles[i].lw; P.hw += tiles[i].hw; P.nb += tiles[i].nb; P.cnt += tiles[i].cnt;
+        const bool last_tile = tile + 1u == ntiles;
+        for (uint32_t i = t; i < (last_tile ? ntiles : tile); i += NT) {
+            const EfTile ti = tiles[i];
+            if (i < tile) { P[0] += ti.lw; P[1] += ti.hw; P[2] += ti.nb; P[3] += ti.cnt; }
+            P[4] += ti.bits; P[5] += ti.wide;  // (only the last tile uses them)
         }
-        P.lw = block_sum256(P.lw, sh); P.hw = block_sum256(P.hw, sh); P.nb = block_sum256(P.nb, sh);
-        P.cnt = block_sum256(P.cnt, sh);
-        tile_cnt = tiles[tile].cnt;
-        if (tile + 1u == ntiles) {
-            for (uint32_t i = t; i < ntiles; i += 256u) { bits += tiles[i].bits; wide += tiles[i].wide; }
-            bits = block_sum256(bits, sh); wide = block_sum256(wide, sh);
-        }
+        block_sum<6, NT / 64>(P, sh);
     }
-    EfRaw s = {0, 0, 0, 0};
+    uint64_t a[5] = {0, 0, 0, 0, 0}, tot[5];  // lw, hw, nb, cnt, chunks other than the first one of a list
 #pragma unroll
-    for (uint32_t j = 0; j < EF_META_E; j++) { s.lw += r[j].lw; s.hw += r[j].hw; s.nb += r[j].nb; s.cnt += r[j].cnt; }
-    EfRaw acc;
-    acc.lw = P.lw + block_exscan256(s.lw, sh); acc.hw = P.hw + block_exscan256(s.hw, sh);
-    acc.nb = P.nb + block_exscan256(s.nb, sh); acc.cnt = block_exscan256(s.cnt, sh);  // (chunks: inside the tile)
+    for (uint32_t j = 0; j < E; j++) {
+        a[0] += r[j].lw; a[1] += r[j].hw; a[2] += r[j].nb; a[3] += r[j].cnt; a[4] += r[j].cnt ? r[j].cnt - 1 : 0;
+    }
+    block_exscan<5, NT / 64>(a, tot, sh);
+    a[0] += P[0]; a[1] += P[1]; a[2] += P[2];
+    if (nlist == 0 && t == 0) {
+        low_off[0] = 0; high_off[0] = 0; batch_off[0] = 0;
+        *sum = EfSummary{0, 0, 0, 0, 0, 0u, 0u};
+    }
 #pragma unroll
-    for (uint32_t j = 0; j < EF_META_E; j++) {
+    for (uint32_t j = 0; j < E; j++) {
         const uint32_t l = base + j;
-        if (l <= nlist) { low_off[l] = acc.lw; high_off[l] = acc.hw; batch_off[l] = acc.nb; }
-        if (l == nlist) {  // (exactly one thread of the last tile)
+        const uint32_t m = (uint32_t)(o[j + 1] - o[j]);
+        if (l < nlist) { low_off[l] = a[0]; high_off[l] = a[1]; batch_off[l] = a[2]; }
+        if (r[j].cnt) recs[P[3] + a[3]] = ef_make_rec(l, 0, o[j], m, u[j], lb[j], a[0], a[1], a[2]);
+        EfListInfo li;
+        li.o0 = o[j]; li.u = u[j]; li.lw = a[0]; li.hw = a[1]; li.nb = a[2]; li.c0 = (uint32_t)a[3]; li.x0 = (uint32_t)a[4];
+        li.m = m; li.lb = lb[j];
+        info[t * E + j] = li;  // (lists past the end: no chunks, x0 = the tile's count)
+        a[0] += r[j].lw; a[1] += r[j].hw; a[2] += r[j].nb; a[3] += r[j].cnt; a[4] += r[j].cnt ? r[j].cnt - 1 : 0;
+        if (l + 1u == nlist) {  // (exactly one thread of the last tile): the entries behind the last list, the totals
+            low_off[nlist] = a[0]; high_off[nlist] = a[1]; batch_off[nlist] = a[2];
             EfSummary out;
-            out.low_words = acc.lw; out.high_words = acc.hw; out.nbatches = acc.nb; out.nchunks = P.cnt + acc.cnt;
-            out.total_bits = bits; out.wide = wide ? 1u : 0u; out.unsorted = 0u;
+            out.low_words = a[0]; out.high_words = a[1]; out.nbatches = a[2]; out.nchunks = P[3] + a[3];
+            out.total_bits = P[4]; out.wide = P[5] ? 1u : 0u; out.unsorted = 0u;
             *sum = out;
         }
-        EfListInfo li;
-        li.o0 = o[j]; li.u = u[j]; li.lw = acc.lw; li.hw = acc.hw; li.nb = acc.nb; li.c0 = acc.cnt;
-        li.m = (uint32_t)(o[j + 1] - o[j]); li.lb = lb[j];
-        info[t * EF_META_E + j] = li;  // (lists past the end: no chunks, c0 = the tile's count)
-        acc.lw += r[j].lw; acc.hw += r[j].hw; acc.nb += r[j].nb; acc.cnt += r[j].cnt;
     }
+    if (!tot[4]) return;
     __syncthreads();
-    // the tile's chunk records, one per thread and step: the list of record x is the last one with c0 <= x
-    for (uint64_t x = t; x < tile_cnt; x += 256u) {
-        uint32_t lo = 0, hi = EF_META_TILE;  // first list with c0 > x
+    // the records behind the first one of every list, one per thread and step: record x belongs to the last list
+    // with x0 <= x
+    for (uint64_t x = t; x < tot[4]; x += NT) {
+        uint32_t lo = 0, hi = TILE;  // first list with x0 > x
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (info[mid].c0 > x) hi = mid; else lo = mid + 1;
+            if (info[mid].x0 > x) hi = mid; else lo = mid + 1;
         }
         const EfListInfo li = info[lo - 1u];
-        const uint64_t c = x - li.c0;
-        const uint64_t hw = ((uint64_t)li.m + 1 + (li.u >> li.lb) + 1 + 63) / 64;
-        EfChunkRec rc;
-        rc.src = li.o0 + c * CHUNK_IDS;
-        rc.low_word = li.lw; rc.high_word = li.hw; rc.batch0 = li.nb; rc.u = li.u;
-        rc.start = (uint32_t)(c * CHUNK_IDS);
-        rc.n = li.m;
-        rc.list = tile * EF_META_TILE + lo - 1u;
-        rc.b = li.lb;
-        rc.nb = (uint32_t)((hw + 63) / 64);
-        rc.pad = 0;
-        recs[P.cnt + x] = rc;
+        const uint64_t c = 1u + (x - li.x0);
+        recs[P[3] + li.c0 + c] = ef_make_rec(tile * TILE + lo - 1u, c, li.o0, li.m, li.u, li.lb, li.lw, li.hw, li.nb);
     }
 }
 
@@ -630,17 +675,20 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *sorted_ids,
         uint32_t pos[CHUNK_IDS / 64];
         bool bad = (before64 >> 32) != 0;
         uint32_t carry = (uint32_t)before64;
+        const uint32_t nr = (nc + 63u) >> 6;  // registers in use (wave-uniform: short lists skip the rest)
 #pragma unroll
         for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
-            const uint32_t i = lane + 64 * r;
-            const uint32_t x = (uint32_t)v[r];
-            const uint32_t up = (uint32_t)__shfl_up((int)x, 1, 64);
-            const uint32_t prev = lane ? up : carry;
-            carry = rl(x, 63);
             pos[r] = NONE;
-            if (i < nc) {
-                bad |= (uint32_t)(v[r] >> 32) != 0u || x > u || prev > x;
-                pos[r] = (x >> b) + (start + i);
+            if (r < nr) {
+                const uint32_t i = lane + 64 * r;
+                const uint32_t x = (uint32_t)v[r];
+                const uint32_t up = lane_shr1(x);
+                const uint32_t prev = lane ? up : carry;
+                carry = rl(x, 63);
+                if (i < nc) {
+                    bad |= (uint32_t)(v[r] >> 32) != 0u || x > u || prev > x;
+                    pos[r] = (x >> b) + (start + i);
+                }
             }
         }
         if (ballot(bad)) {
@@ -658,19 +706,12 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *sorted_ids,
         // word ownership as in k_ef_lowhigh
         const uint32_t before = (uint32_t)before64;
         const bool own_first = !(start && (((before >> b) + (start - 1u)) >> 6) == wf && before <= u);
-        uint64_t tail_bits = 0;
-        {
-            if (jn < n && (vnext >> 32) == 0) {
-                const uint32_t xn = (uint32_t)vnext;
-                const uint32_t pn = (xn >> b) + jn;
-                if (xn <= u && (pn >> 6) == wl) tail_bits = 1ull << (pn & 63u);
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)tail_bits, o, 64);
-                const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(tail_bits >> 32), o, 64);
-                tail_bits |= ((uint64_t)hi << 32) | lo;
-            }
+        // the ids behind the chunk whose bit falls into the chunk's last word: set through the last window
+        uint32_t pnext = NONE;
+        if (jn < n && (vnext >> 32) == 0) {
+            const uint32_t xn = (uint32_t)vnext;
+            const uint32_t pn = (xn >> b) + jn;
+            if (xn <= u && (pn >> 6) == wl) pnext = pn;
         }
         const uint64_t *win = (const uint64_t *)win32;
         for (uint32_t wbase = wf; wbase <= wl; wbase += EF_WIN_WORDS) {
@@ -678,16 +719,22 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *sorted_ids,
             __syncthreads();
 #pragma unroll
             for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
-                const uint32_t rel = pos[r] - wbase * 64u;  // bit inside the window (wraps for earlier windows / NONE)
-                if (pos[r] != NONE && (pos[r] >> 6) >= wbase && rel < EF_WIN_WORDS * 64u)
-                    atomicOr(&win32[rel >> 5], 1u << (rel & 31u));
+                if (r < nr) {
+                    const uint32_t rel = pos[r] - wbase * 64u;  // bit inside the window (wraps for earlier windows / NONE)
+                    if (pos[r] != NONE && (pos[r] >> 6) >= wbase && rel < EF_WIN_WORDS * 64u)
+                        atomicOr(&win32[rel >> 5], 1u << (rel & 31u));
+                }
+            }
+            if (wl - wbase < EF_WIN_WORDS && pnext != NONE) {
+                const uint32_t rel = pnext - wbase * 64u;
+                atomicOr(&win32[rel >> 5], 1u << (rel & 31u));
             }
             if (wbase == wf && b) {  // low stream: the l low bits of every id into the LDS image, 32-bit halves
                 const uint32_t keep = b >= 32u ? 0xffffffffu : ((1u << b) - 1u);
 #pragma unroll
                 for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
                     const uint32_t i = lane + 64 * r;
-                    if (i < nc) {
+                    if (r < nr && i < nc) {
                         const uint32_t x = (uint32_t)v[r] & keep;
                         const uint32_t p = i * b, sh = p & 31u;
                         atomicOr(&img32[p >> 5], x << sh);
@@ -700,8 +747,7 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *sorted_ids,
             for (uint32_t t = 0; t < 2; t++) {
                 const uint32_t k = lane + 64 * t;
                 const uint32_t w = wbase + k;
-                uint64_t hv = win[k];
-                if (w == wl) hv |= tail_bits;
+                const uint64_t hv = win[k];
                 if (hv && w <= wl && (w != wf || own_first)) dst[w] = hv;  // (the stream was zeroed: empty words stay)
             }
             if (wbase == wf && b) {
@@ -1372,7 +1418,8 @@ int ef_encode_general(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t
 int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t flags, uint64_t nchunks, bool *retry) {
     const uint64_t nlist = e->nlist;
     const uint32_t nl32 = (uint32_t)nlist;
-    const uint32_t ntiles = nl32 / EF_META_TILE + 1u;  // (the entry behind the last list belongs to a tile as well)
+    const uint32_t tile_lists = nl32 <= EF_SINGLE_LISTS ? EF_SINGLE_LISTS : (nl32 <= EF_E1_MAX_LISTS ? 256u : 1024u);
+    const uint32_t ntiles = nl32 ? (nl32 + tile_lists - 1u) / tile_lists : 1u;
     VidcPhaseTimer pt(ctx);
     Scratch s_raw, s_tiles, s_sum, s_recs;
     Pinned tail;
@@ -1388,14 +1435,22 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
     VIDC_TRY(e->d_chunks.alloc(1, ctx->dpool));  // (the chunk table of the three-pass encoder: not needed here)
     pt.begin();
     if (ntiles == 1u) {
-        hipLaunchKernelGGL(k_ef_offsets<true>, dim3(1), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
-                           e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), (const EfTile *)nullptr, 1u, e->d_low_off.p,
-                           e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(), s_sum.as<EfSummary>());
+        hipLaunchKernelGGL((k_ef_offsets<true, 2, 512>), dim3(1), dim3(512), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
+                           e->d_lbits.p, e->d_universe.p, (const EfRaw *)nullptr, (const EfTile *)nullptr, 1u,
+                           e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
+                           s_sum.as<EfSummary>());
+    } else if (tile_lists == 256u) {
+        hipLaunchKernelGGL(k_ef_meta<1>, dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
+                           e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>());
+        hipLaunchKernelGGL((k_ef_offsets<false, 1, 256>), dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p,
+                           nl32, e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>(), ntiles,
+                           e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
+                           s_sum.as<EfSummary>());
     } else {
-        hipLaunchKernelGGL(k_ef_meta, dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32, e->d_lbits.p,
-                           e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>());
-        hipLaunchKernelGGL(k_ef_offsets<false>, dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
-                           e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>(), ntiles,
+        hipLaunchKernelGGL(k_ef_meta<4>, dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
+                           e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>());
+        hipLaunchKernelGGL((k_ef_offsets<false, 4, 256>), dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p,
+                           nl32, e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>(), ntiles,
                            e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
                            s_sum.as<EfSummary>());
     }
