@@ -87,6 +87,68 @@ def test_elias_fano_vs_oracle(oracle):
     assert got.tolist() == want
 
 
+def _check_ef_lists(oracle, ef, off, ids, sample):
+    info = ef.info()
+    for l in sample:
+        li = ids[int(off[l]):int(off[l + 1])]
+        if li.size == 0:
+            continue
+        e = oracle.ef_build(li)
+        low, high, lb, hb = ef.export(int(l))
+        assert int(info["low_bits"][l]) == e["l"] and lb == e["low_nbits"] and hb == e["high_nbits"]
+        assert np.array_equal(low, e["low"]) and np.array_equal(high, e["high"]), f"list {l}"
+    assert np.array_equal(ef.decode_all().cpu().numpy().view(np.uint64), ids)
+
+
+@pytest.mark.parametrize("nlist", [1, 1023, 1024, 1025, 4096, 262144, 262145, 300000])
+def test_elias_fano_single_pass_encoder_list_counts(oracle, nlist):
+    """The single-pass encoder computes offsets per tile of lists: one launch up to 1024 lists, tiles of 256 lists up
+    to 2^18 lists, tiles of 1024 beyond (csrc/ef.hip, k_ef_meta / k_ef_offsets): list counts on both sides of every
+    switch, lists of 0..3 chunks mixed, streams of sampled lists against the oracle and the decode of everything."""
+    from vector_db_id_compression_amd.codecs import EfLists
+
+    rng = np.random.default_rng(nlist)
+    sizes = rng.integers(0, 12, size=nlist)
+    big = rng.integers(0, nlist, size=min(nlist, 40))
+    sizes[big] = rng.integers(500, 1600, size=big.size)  # one to four chunks of 512 ids
+    sizes[-1] = 700 if nlist > 1 else 5  # (the last list: its end is the entry behind all lists)
+    off = np.zeros(nlist + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)
+    ids = rng.integers(0, 1 << 22, size=int(off[-1]), dtype=np.uint64)
+    ids = ids[np.lexsort((ids, np.repeat(np.arange(nlist), sizes)))]  # every list ascending: the single-pass path
+    ef = EfLists.encode(off, ids)
+    sample = np.unique(np.concatenate([big, [0, nlist - 1], np.arange(min(nlist, 50)), rng.integers(0, nlist, size=100)]))
+    _check_ef_lists(oracle, ef, off, ids, sample)
+
+
+def test_elias_fano_sparse_chunk_owns_many_directory_entries(oracle):
+    """A chunk whose ids are far apart in the high stream owns many batches of the select directory (the lane-per-batch
+    path of ef_chunk_directory), a dense one owns none: lists that are dense first and sparse at the end, and the
+    other way round; `get` walks the directory."""
+    from vector_db_id_compression_amd.codecs import EfLists
+
+    rng = np.random.default_rng(77)
+    dense = np.arange(100000, dtype=np.uint64)
+    sparse = np.uint64(100000) + np.sort(rng.integers(0, 1 << 31, size=600, dtype=np.uint64))
+    a = np.concatenate([dense, sparse])                       # sparse tail
+    b = np.concatenate([np.sort(rng.integers(0, 1 << 20, size=300, dtype=np.uint64)),
+                        np.uint64(1 << 30) + np.arange(50000, dtype=np.uint64)])  # sparse head, one huge gap
+    c = np.array([3, 1 << 31], dtype=np.uint64)               # two ids, l = 30
+    lists = [a, b, c, np.zeros(0, np.uint64), np.sort(rng.integers(0, 1 << 40, size=5000, dtype=np.uint64))]  # (wide ids)
+    off = np.zeros(len(lists) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([x.size for x in lists])
+    ids = np.concatenate(lists)
+    for sub in ([0, 1, 2, 3], [0, 1, 2, 3, 4]):  # 32-bit and 64-bit encoder kernels
+        o = np.zeros(len(sub) + 1, dtype=np.uint64)
+        o[1:] = np.cumsum([lists[i].size for i in sub])
+        x = np.concatenate([lists[i] for i in sub])
+        ef = EfLists.encode(o, x)
+        _check_ef_lists(oracle, ef, o, x, range(len(sub)))
+        ql = np.array([0, 0, 0, 1, 1, 1, 2], dtype=np.uint64)
+        qo = np.array([0, 99999, 100599, 0, 299, 50299, 1], dtype=np.uint64)
+        assert ef.get(ql, qo).tolist() == [int(lists[int(l)][int(q)]) for l, q in zip(ql, qo)]
+
+
 def test_elias_fano_unsorted_input_and_perm(oracle):
     """canonicalize_order_inplace (custom_invlists_impl.cpp:324-339): ids are sorted, codes follow via perm."""
     from vector_db_id_compression_amd.codecs import EfLists
