@@ -20,7 +20,7 @@ timeout 600 python bench.py > gpurun_out/$R/bench.json 2> gpurun_out/$R/bench.er
 for w in s1_uniform uniform_16m uniform_64m_1k c5 s2_64m; do
   timeout 900 python bench.py --workload $w --no-cpu-baseline --no-extra --steps 5 --warmup 2 2>/dev/null >> gpurun_out/$R/bench_other.jsonl
 done
-for c in packed ef; do for w in s1 uniform_64m_1k; do
+for c in packed ef; do for w in s1 uniform_16m uniform_64m_1k; do
   timeout 600 python bench.py --workload $w --codec $c --no-cpu-baseline --no-extra --steps 10 --warmup 3 2>/dev/null >> gpurun_out/$R/bench_other.jsonl
 done; done
 timeout 600 python tools/bench_graph.py 1000000 2>/dev/null | tail -1 > gpurun_out/$R/bench_graph.json
