@@ -22,13 +22,19 @@ def main():
     nb = nl = 0
     while time.time() - t0 < budget:
         nbits = int(rng.integers(3, 41))
-        nlist = int(rng.integers(1, 40))
-        sizes = np.minimum(rng.geometric(rng.choice([0.5, 0.02, 0.002]), nlist) - 1, 6000)
+        many = rng.random() < 0.04  # more than 1024 lists: the encoder's offsets are computed per tile of 256 lists
+        nlist = int(rng.integers(1025, 5000)) if many else int(rng.integers(1, 40))
+        sizes = np.minimum(rng.geometric(0.3 if many else rng.choice([0.5, 0.02, 0.002]), nlist) - 1, 6000)
+        if many:
+            sizes[rng.integers(0, nlist, size=6)] = rng.integers(400, 3000, size=6)
+        p_sorted = 1.0 if (many and rng.random() < 0.7) else 0.85
         lists = []
         for s in sizes:
             s = int(s)
             li = rng.integers(0, 1 << nbits, size=s, dtype=np.uint64)
-            if rng.random() < 0.85:
+            if s > 600 and rng.random() < 0.2:  # dense head, sparse tail: chunks that own many directory entries / none
+                li[: s - 300] = rng.integers(0, max(2, (1 << nbits) >> 12), size=s - 300, dtype=np.uint64)
+            if rng.random() < p_sorted:
                 li = np.sort(li)
             lists.append(li)
         off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
