@@ -245,6 +245,11 @@ __global__ void __launch_bounds__(64) k_ef_high(const uint64_t *sorted_ids, cons
 // Any order violation raises `unsorted` and the caller redoes the object with the three-pass path further down.
 // (a tile = the lists of one workgroup: 512 threads with two lists each when that is the whole object, else 256 threads
 // with one list each, or four each from 2^18 lists on -- every workgroup of k_ef_offsets sums the totals of the tiles before it)
+// ids per chunk record of the single-pass encoder (VIDC_EF_CHUNK: build-time experiment hook)
+#ifndef VIDC_EF_CHUNK
+#define VIDC_EF_CHUNK 512
+#endif
+constexpr uint32_t EF_CHUNK = VIDC_EF_CHUNK;
 #define EF_SINGLE_LISTS 1024u
 #define EF_E1_MAX_LISTS 262144u
 struct EfRaw {     // the four per-list counts (k_ef_meta) whose prefix sums are the offsets of a list
@@ -367,7 +372,7 @@ __device__ inline EfTile ef_meta_tile(const uint64_t *ids, const uint64_t *offse
             r[j].lw = (m * lb[j] + 63) / 64 + 1;  // +1 padding word for read_bits
             r[j].hw = (hb + 63) / 64;
             r[j].nb = (r[j].hw + 63) / 64;
-            r[j].cnt = (m + CHUNK_IDS - 1) / CHUNK_IDS;
+            r[j].cnt = (m + EF_CHUNK - 1) / EF_CHUNK;
         }
         if (l < nlist) {
             lbits[l] = lb[j];
@@ -393,9 +398,9 @@ __device__ inline EfChunkRec ef_make_rec(uint32_t l, uint64_t c, uint64_t o0, ui
                                          uint64_t lw, uint64_t hw, uint64_t nb0) {
     const uint64_t nhw = ((uint64_t)m + 1 + (u >> lb) + 1 + 63) / 64;
     EfChunkRec rc;
-    rc.src = o0 + c * CHUNK_IDS;
+    rc.src = o0 + c * EF_CHUNK;
     rc.low_word = lw; rc.high_word = hw; rc.batch0 = nb0; rc.u = u;
-    rc.start = (uint32_t)(c * CHUNK_IDS);
+    rc.start = (uint32_t)(c * EF_CHUNK);
     rc.n = m;
     rc.list = l;
     rc.b = lb;
@@ -527,7 +532,7 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
                                                    uint64_t nchunks, uint64_t *low, uint64_t *high, uint32_t *hrank,
                                                    Chunk *batches, uint32_t *unsorted) {
     __shared__ unsigned long long win[EF_WIN_WORDS];
-    __shared__ unsigned long long img[CHUNK_IDS + 8];  // low words of the chunk (CHUNK_IDS * l / 64 <= CHUNK_IDS)
+    __shared__ unsigned long long img[EF_CHUNK + 8];  // low words of the chunk (EF_CHUNK * l / 64 <= EF_CHUNK)
     const uint32_t lane = lane_id();
     for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const EfChunkRec rc = recs[c];
@@ -535,24 +540,24 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
         const uint32_t b = rc.b;
         const uint64_t n = rc.n;
         const uint64_t u = rc.u;
-        const uint32_t nc = (uint32_t)(n - start < CHUNK_IDS ? n - start : CHUNK_IDS);
+        const uint32_t nc = (uint32_t)(n - start < EF_CHUNK ? n - start : EF_CHUNK);
         const uint64_t *src = sorted_ids + rc.src - start;  // the list's first id
         unsigned long long *dst = (unsigned long long *)(high + rc.high_word);
         // the chunk's ids: eight independent coalesced loads per lane
-        uint64_t v[CHUNK_IDS / 64];
+        uint64_t v[EF_CHUNK / 64];
         const uint64_t before = start ? src[start - 1] : 0ull;  // the id before this chunk (order check)
 #pragma unroll
-        for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
+        for (uint32_t r = 0; r < EF_CHUNK / 64; r++) {
             const uint32_t i = lane + 64 * r;
             v[r] = i < nc ? src[start + i] : ~0ull;
         }
         const uint32_t nlw = (uint32_t)(((uint64_t)nc * b + 63) >> 6);
         for (uint32_t w = lane; w < nlw + 1u; w += 64) img[w] = 0;
-        uint64_t pos[CHUNK_IDS / 64];
+        uint64_t pos[EF_CHUNK / 64];
         bool bad = false;
         uint64_t carry = before;
 #pragma unroll
-        for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
+        for (uint32_t r = 0; r < EF_CHUNK / 64; r++) {
             const uint32_t i = lane + 64 * r;
             // predecessor = previous lane's id (lane 0: the last id of the previous 64-group)
             uint32_t plo = (uint32_t)__shfl_up((int)(uint32_t)v[r], 1, 64), phi = (uint32_t)__shfl_up((int)(uint32_t)(v[r] >> 32), 1, 64);
@@ -574,7 +579,7 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
         const uint32_t lr = (nc - 1u) >> 6, ll = (nc - 1u) & 63u;  // register / lane holding the last id
         uint64_t last = 0;
 #pragma unroll
-        for (uint32_t r = 0; r < CHUNK_IDS / 64; r++)
+        for (uint32_t r = 0; r < EF_CHUNK / 64; r++)
             if (r == lr) last = rl64((uint32_t)pos[r], (uint32_t)(pos[r] >> 32), ll);
         const uint64_t wf = first >> 6, wl = last >> 6;
         // Word ownership instead of global atomics on the two boundary words: a high word belongs to the chunk that
@@ -602,7 +607,7 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
             win[lane + 64] = 0;
             __syncthreads();
 #pragma unroll
-            for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
+            for (uint32_t r = 0; r < EF_CHUNK / 64; r++) {
                 const uint64_t w = pos[r] >> 6;
                 if (pos[r] != ~0ull && w >= wbase && w - wbase < EF_WIN_WORDS)
                     atomicOr(&win32[(uint32_t)(pos[r] - wbase * 64u) >> 5], 1u << (pos[r] & 31));
@@ -610,7 +615,7 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
             if (wbase == wf && b) {  // low stream: OR the l low bits of every id into the LDS image of the chunk's words
                 const uint64_t keep = (1ull << b) - 1ull;
 #pragma unroll
-                for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
+                for (uint32_t r = 0; r < EF_CHUNK / 64; r++) {
                     const uint32_t i = lane + 64 * r;
                     if (i < nc) {
                         const uint64_t x = v[r] & keep;
@@ -645,121 +650,140 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
 // low-bit image run on 32-bit values -- the 64-bit version spends about half of its instructions on two-register
 // compares, shifts and shuffles, and the kernel is as much issue- as bandwidth-bound (no stores, no LDS: 162 of
 // 227 us per 64 M ids).
+// one chunk record with R id registers per lane (64 R >= the ids of the chunk)
+template <int R>
+__device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const uint64_t *sorted_ids, uint64_t *low,
+                                                   uint64_t *high, uint32_t *hrank, Chunk *batches, uint32_t *unsorted,
+                                                   uint32_t *win32, uint32_t *img32) {
+    const uint32_t lane = lane_id();
+    constexpr uint32_t NONE = 0xffffffffu;
+    const uint32_t start = rc.start;
+    const uint32_t b = rc.b;
+    const uint32_t n = rc.n;
+    const uint32_t u = (uint32_t)rc.u;
+    const uint32_t nc = n - start < EF_CHUNK ? n - start : EF_CHUNK;
+    const uint64_t *src = sorted_ids + rc.src - start;  // the list's first id
+    uint64_t *dst = high + rc.high_word;
+    uint64_t v[R];
+    const uint64_t before64 = start ? src[start - 1] : 0ull;  // the id before this chunk (order check)
+#pragma unroll
+    for (uint32_t r = 0; r < R; r++) {
+        const uint32_t i = lane + 64 * r;
+        v[r] = i < nc ? src[start + i] : 0ull;
+    }
+    const uint32_t jn = start + nc + lane;  // the (at most 64) ids after the chunk: last word's ownership
+    const uint64_t vnext = jn < n ? src[jn] : ~0ull;
+    const uint32_t nlw32 = (nc * b + 31u) >> 5;
+    for (uint32_t w = lane; w < nlw32 + 2u; w += 64) img32[w] = 0;
+    uint32_t pos[R];
+    bool bad = (before64 >> 32) != 0;
+    uint32_t carry = (uint32_t)before64;
+    const uint32_t nr = (nc + 63u) >> 6;  // registers in use (wave-uniform: short lists skip the rest)
+#pragma unroll
+    for (uint32_t r = 0; r < R; r++) {
+        pos[r] = NONE;
+        if (r < nr) {
+            const uint32_t i = lane + 64 * r;
+            const uint32_t x = (uint32_t)v[r];
+            const uint32_t up = lane_shr1(x);
+            const uint32_t prev = lane ? up : carry;
+            carry = rl(x, 63);
+            if (i < nc) {
+                bad |= (uint32_t)(v[r] >> 32) != 0u || x > u || prev > x;
+                pos[r] = (x >> b) + (start + i);
+            }
+        }
+    }
+    if (ballot(bad)) {
+        if (lane == 0) atomicOr(unsorted, 1u);
+        __syncthreads();
+        return;  // the object is rebuilt by the general path
+    }
+    const uint32_t first = rl(pos[0], 0);
+    const uint32_t lr = (nc - 1u) >> 6, ll = (nc - 1u) & 63u;  // register / lane holding the last id
+    uint32_t last = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < R; r++)
+        if (r == lr) last = rl(pos[r], ll);
+    const uint32_t wf = first >> 6, wl = last >> 6;
+    // word ownership as in k_ef_lowhigh
+    const uint32_t before = (uint32_t)before64;
+    const bool own_first = !(start && (((before >> b) + (start - 1u)) >> 6) == wf && before <= u);
+    // the ids behind the chunk whose bit falls into the chunk's last word: set through the last window
+    uint32_t pnext = NONE;
+    if (jn < n && (vnext >> 32) == 0) {
+        const uint32_t xn = (uint32_t)vnext;
+        const uint32_t pn = (xn >> b) + jn;
+        if (xn <= u && (pn >> 6) == wl) pnext = pn;
+    }
+    const uint64_t *win = (const uint64_t *)win32;
+    for (uint32_t wbase = wf; wbase <= wl; wbase += EF_WIN_WORDS) {
+        win32[lane] = 0; win32[lane + 64] = 0; win32[lane + 128] = 0; win32[lane + 192] = 0;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < R; r++) {
+            if (r < nr) {
+                const uint32_t rel = pos[r] - wbase * 64u;  // bit inside the window (wraps for earlier windows / NONE)
+                if (pos[r] != NONE && (pos[r] >> 6) >= wbase && rel < EF_WIN_WORDS * 64u)
+                    atomicOr(&win32[rel >> 5], 1u << (rel & 31u));
+            }
+        }
+        if (wl - wbase < EF_WIN_WORDS && pnext != NONE) {
+            const uint32_t rel = pnext - wbase * 64u;
+            atomicOr(&win32[rel >> 5], 1u << (rel & 31u));
+        }
+        if (wbase == wf && b) {  // low stream: the l low bits of every id into the LDS image, 32-bit halves
+            const uint32_t keep = b >= 32u ? 0xffffffffu : ((1u << b) - 1u);
+#pragma unroll
+            for (uint32_t r = 0; r < R; r++) {
+                const uint32_t i = lane + 64 * r;
+                if (r < nr && i < nc) {
+                    const uint32_t x = (uint32_t)v[r] & keep;
+                    const uint32_t p = i * b, sh = p & 31u;
+                    atomicOr(&img32[p >> 5], x << sh);
+                    if (sh + b > 32u) atomicOr(&img32[(p >> 5) + 1u], x >> (32u - sh));
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t t = 0; t < 2; t++) {
+            const uint32_t k = lane + 64 * t;
+            const uint32_t w = wbase + k;
+            const uint64_t hv = win[k];
+            if (hv && w <= wl && (w != wf || own_first)) dst[w] = hv;  // (the stream was zeroed: empty words stay)
+        }
+        if (wbase == wf && b) {
+            const uint32_t nlw = (nc * b + 63u) >> 6;
+            uint64_t *ldst = low + rc.low_word + (((uint64_t)start * b) >> 6);
+            const uint64_t *img = (const uint64_t *)img32;
+            for (uint32_t w = lane; w < nlw; w += 64) ldst[w] = img[w];
+        }
+        __syncthreads();
+    }
+    ef_chunk_directory<uint32_t>(rc, src + start, nc, pos, start ? (before >> b) + (start - 1u) : 0u, last,
+                                 low, hrank, batches);
+}
+// RMAX = 8: any object.  RMAX = 4: no list of the object holds more than 256 ids (64 instead of 85 VGPRs, half the code).
+// SMALL: chunks of up to 64 / 256 ids take the code unrolled for one / four id registers -- a chunk costs its unrolled
+// instructions whether the slots are used or not, and the lists of a 65 536-list IVF index are mostly that short; the
+// extra code paths cost a wavefront per SIMD (97 VGPRs), so objects of mostly full chunks take the plain kernel.
+template <int RMAX, bool SMALL>
 __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *sorted_ids, const EfChunkRec *recs,
                                                      uint64_t nchunks, uint64_t *low, uint64_t *high, uint32_t *hrank,
                                                      Chunk *batches, uint32_t *unsorted) {
     __shared__ uint32_t win32[EF_WIN_WORDS * 2];
-    __shared__ uint32_t img32[(CHUNK_IDS + 8) * 2];  // low words of the chunk, as 32-bit halves
-    const uint32_t lane = lane_id();
-    constexpr uint32_t NONE = 0xffffffffu;
+    __shared__ uint32_t img32[(64 * RMAX + 8) * 2];  // low words of the chunk, as 32-bit halves
     for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const EfChunkRec rc = recs[c];
-        const uint32_t start = rc.start;
-        const uint32_t b = rc.b;
-        const uint32_t n = rc.n;
-        const uint32_t u = (uint32_t)rc.u;
-        const uint32_t nc = n - start < CHUNK_IDS ? n - start : CHUNK_IDS;
-        const uint64_t *src = sorted_ids + rc.src - start;  // the list's first id
-        uint64_t *dst = high + rc.high_word;
-        uint64_t v[CHUNK_IDS / 64];
-        const uint64_t before64 = start ? src[start - 1] : 0ull;  // the id before this chunk (order check)
-#pragma unroll
-        for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
-            const uint32_t i = lane + 64 * r;
-            v[r] = i < nc ? src[start + i] : 0ull;
-        }
-        const uint32_t jn = start + nc + lane;  // the (at most 64) ids after the chunk: last word's ownership
-        const uint64_t vnext = jn < n ? src[jn] : ~0ull;
-        const uint32_t nlw32 = (nc * b + 31u) >> 5;
-        for (uint32_t w = lane; w < nlw32 + 2u; w += 64) img32[w] = 0;
-        uint32_t pos[CHUNK_IDS / 64];
-        bool bad = (before64 >> 32) != 0;
-        uint32_t carry = (uint32_t)before64;
-        const uint32_t nr = (nc + 63u) >> 6;  // registers in use (wave-uniform: short lists skip the rest)
-#pragma unroll
-        for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
-            pos[r] = NONE;
-            if (r < nr) {
-                const uint32_t i = lane + 64 * r;
-                const uint32_t x = (uint32_t)v[r];
-                const uint32_t up = lane_shr1(x);
-                const uint32_t prev = lane ? up : carry;
-                carry = rl(x, 63);
-                if (i < nc) {
-                    bad |= (uint32_t)(v[r] >> 32) != 0u || x > u || prev > x;
-                    pos[r] = (x >> b) + (start + i);
-                }
-            }
-        }
-        if (ballot(bad)) {
-            if (lane == 0) atomicOr(unsorted, 1u);
-            __syncthreads();
-            continue;  // the object is rebuilt by the general path
-        }
-        const uint32_t first = rl(pos[0], 0);
-        const uint32_t lr = (nc - 1u) >> 6, ll = (nc - 1u) & 63u;  // register / lane holding the last id
-        uint32_t last = 0;
-#pragma unroll
-        for (uint32_t r = 0; r < CHUNK_IDS / 64; r++)
-            if (r == lr) last = rl(pos[r], ll);
-        const uint32_t wf = first >> 6, wl = last >> 6;
-        // word ownership as in k_ef_lowhigh
-        const uint32_t before = (uint32_t)before64;
-        const bool own_first = !(start && (((before >> b) + (start - 1u)) >> 6) == wf && before <= u);
-        // the ids behind the chunk whose bit falls into the chunk's last word: set through the last window
-        uint32_t pnext = NONE;
-        if (jn < n && (vnext >> 32) == 0) {
-            const uint32_t xn = (uint32_t)vnext;
-            const uint32_t pn = (xn >> b) + jn;
-            if (xn <= u && (pn >> 6) == wl) pnext = pn;
-        }
-        const uint64_t *win = (const uint64_t *)win32;
-        for (uint32_t wbase = wf; wbase <= wl; wbase += EF_WIN_WORDS) {
-            win32[lane] = 0; win32[lane + 64] = 0; win32[lane + 128] = 0; win32[lane + 192] = 0;
-            __syncthreads();
-#pragma unroll
-            for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
-                if (r < nr) {
-                    const uint32_t rel = pos[r] - wbase * 64u;  // bit inside the window (wraps for earlier windows / NONE)
-                    if (pos[r] != NONE && (pos[r] >> 6) >= wbase && rel < EF_WIN_WORDS * 64u)
-                        atomicOr(&win32[rel >> 5], 1u << (rel & 31u));
-                }
-            }
-            if (wl - wbase < EF_WIN_WORDS && pnext != NONE) {
-                const uint32_t rel = pnext - wbase * 64u;
-                atomicOr(&win32[rel >> 5], 1u << (rel & 31u));
-            }
-            if (wbase == wf && b) {  // low stream: the l low bits of every id into the LDS image, 32-bit halves
-                const uint32_t keep = b >= 32u ? 0xffffffffu : ((1u << b) - 1u);
-#pragma unroll
-                for (uint32_t r = 0; r < CHUNK_IDS / 64; r++) {
-                    const uint32_t i = lane + 64 * r;
-                    if (r < nr && i < nc) {
-                        const uint32_t x = (uint32_t)v[r] & keep;
-                        const uint32_t p = i * b, sh = p & 31u;
-                        atomicOr(&img32[p >> 5], x << sh);
-                        if (sh + b > 32u) atomicOr(&img32[(p >> 5) + 1u], x >> (32u - sh));
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (uint32_t t = 0; t < 2; t++) {
-                const uint32_t k = lane + 64 * t;
-                const uint32_t w = wbase + k;
-                const uint64_t hv = win[k];
-                if (hv && w <= wl && (w != wf || own_first)) dst[w] = hv;  // (the stream was zeroed: empty words stay)
-            }
-            if (wbase == wf && b) {
-                const uint32_t nlw = (nc * b + 63u) >> 6;
-                uint64_t *ldst = low + rc.low_word + (((uint64_t)start * b) >> 6);
-                const uint64_t *img = (const uint64_t *)img32;
-                for (uint32_t w = lane; w < nlw; w += 64) ldst[w] = img[w];
-            }
-            __syncthreads();
-        }
-        ef_chunk_directory<uint32_t>(rc, src + start, nc, pos, start ? (before >> b) + (start - 1u) : 0u, last,
-                                     low, hrank, batches);
+        const uint32_t nc = rc.n - rc.start < EF_CHUNK ? rc.n - rc.start : EF_CHUNK;
+        if (!SMALL || (RMAX > 4 && nc > 256u))
+            ef_lowhigh32_chunk<RMAX>(rc, sorted_ids, low, high, hrank, batches, unsorted, win32, img32);
+        else if (nc > 64u)
+            ef_lowhigh32_chunk<4>(rc, sorted_ids, low, high, hrank, batches, unsorted, win32, img32);
+        else
+            ef_lowhigh32_chunk<1>(rc, sorted_ids, low, high, hrank, batches, unsorted, win32, img32);
+        __syncthreads();
     }
 }
 
@@ -1414,8 +1438,9 @@ int ef_encode_general(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t
 }
 
 // the single-pass encoder (kernels above); *retry is raised when some list turned out not to be ascending.
-// nchunks: number of CHUNK_IDS-sized pieces of all lists (the caller walks the host offsets anyway)
-int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t flags, uint64_t nchunks, bool *retry) {
+// nchunks: number of EF_CHUNK-sized pieces of all lists (the caller walks the host offsets anyway)
+int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t flags, uint64_t nchunks, uint64_t max_list,
+                   bool *retry) {
     const uint64_t nlist = e->nlist;
     const uint32_t nl32 = (uint32_t)nlist;
     const uint32_t tile_lists = nl32 <= EF_SINGLE_LISTS ? EF_SINGLE_LISTS : (nl32 <= EF_E1_MAX_LISTS ? 256u : 1024u);
@@ -1492,9 +1517,15 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
         if (wide_ids)
             hipLaunchKernelGGL(k_ef_lowhigh, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(), nchunks,
                                e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
-        else
-            hipLaunchKernelGGL(k_ef_lowhigh32, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
+        else if (max_list <= 256)  // (16 M ids in lists of 256: 65 -> 57 us)
+            hipLaunchKernelGGL((k_ef_lowhigh32<4, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
                                nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+        else if (e->ntotal < 256 * nchunks)  // (chunks half full on average: 10 M ids in 65 536 Zipf lists 0.090 -> 0.082 ms)
+            hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
+                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+        else
+            hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
+                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
         VIDC_HIP(hipGetLastError());
         pt.end();
         VIDC_HIP(hipMemcpyAsync(hs + 1, s_sum.p, sizeof(EfSummary), hipMemcpyDeviceToHost, ctx->stream));
@@ -1522,13 +1553,14 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     if (nlist) e->offsets.assign(offsets, offsets + nlist + 1);
     e->offsets_host = true;
     e->ntotal = e->offsets[nlist];
-    uint64_t nchunks = 0;
+    uint64_t nchunks = 0, max_list = 0;
     for (uint64_t l = 0; l < nlist; l++) {
         if (e->offsets[l + 1] < e->offsets[l] || e->offsets[l + 1] - e->offsets[l] > 0xfffffff0ull) {
             set_error("bad offsets at list %llu", (unsigned long long)l);
             return VIDC_ERR_INVALID;
         }
-        nchunks += (e->offsets[l + 1] - e->offsets[l] + CHUNK_IDS - 1) / CHUNK_IDS;
+        nchunks += (e->offsets[l + 1] - e->offsets[l] + EF_CHUNK - 1) / EF_CHUNK;
+        max_list = std::max(max_list, e->offsets[l + 1] - e->offsets[l]);
     }
     if (e->ntotal && !d_ids) return VIDC_ERR_INVALID;
     VIDC_TRY(e->d_offsets.alloc(nlist + 1, ctx->dpool));
@@ -1537,7 +1569,7 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     std::memcpy(h_off.p, e->offsets.data(), (nlist + 1) * 8);
     VIDC_HIP(hipMemcpyAsync(e->d_offsets.p, h_off.p, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     bool retry = false;
-    VIDC_TRY(ef_encode_fast(ctx, e.get(), d_ids, flags, nchunks, &retry));
+    VIDC_TRY(ef_encode_fast(ctx, e.get(), d_ids, flags, nchunks, max_list, &retry));
     if (retry) {  // some list is not ascending: general three-pass encoder with the sort
         e->total_bits = 0;
         e->has_perm = false;
