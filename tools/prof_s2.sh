@@ -16,11 +16,11 @@ cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]; print(cols)
 gx = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else "0"); wx = "workgroup_x" if "workgroup_x" in cols else ("workgroup_size_x" if "workgroup_size_x" in cols else "1")
 rows = list(cur.execute(f"select name, start, end, {gx}, {wx} from kernels order by start")) if "kernels" in tabs else []
 if rows:
-    big = [i for i, r in enumerate(rows) if "k_roc_prepass" in r[0]]
+    big = [i for i, r in enumerate(rows) if "k_roc_prepass" in r[0]]  # (k_roc_prepass or k_roc_prepass_last)
     i0 = big[-1] if big else 0
     t0 = rows[i0][1]
     for r in rows[i0:]:
-        if r[2] - r[1] < 200000: continue
+        if r[2] - r[1] < int(__import__("os").environ.get("MIN_NS", "200000")): continue
         m = re.search(r"(k_\w+(<[^>]*>)?)", r[0]); print((m.group(1) if m else r[0][:40]).ljust(34), "start", round((r[1]-t0)/1e6,2), "end", round((r[2]-t0)/1e6,2), "wg", r[3]//max(r[4],1))
 PY
 rm -rf gpurun_out/s2p/prof
