@@ -950,7 +950,7 @@ __global__ void k_ef_build_recs(const uint64_t *offsets, const uint64_t *low_off
 // LW = uint64_t: any ids.  LW = uint32_t: objects whose ids fit 32 bits -- low bits come as 32-bit word pairs and the
 // value is assembled in one register (the 64-bit version reads 16 bytes of low words per element and does
 // two-register shifts: 0.19 vs 0.13 ms per 64 M ids).
-template <typename LW>
+template <typename LW, int R>  // R: elements per lane and pass (4: no batch of the object holds more than 256)
 __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const uint64_t *high, const EfRec *recs,
                                                       uint32_t nwork, uint64_t *out) {
     extern __shared__ uint16_t spos[];  // max elements per batch of this object (<= EF_BATCH_BITS) entries
@@ -968,9 +968,9 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
         const LW keep = b ? (LW)(((b >= WB ? (LW)0 : ((LW)1 << b))) - (LW)1) : (LW)0;
         const LW *lw = (const LW *)(low + low_base);
         uint64_t word = lane < nw ? high[hw_base + lane] : 0ull;
-        LW a[8], bw[8];
+        LW a[R], bw[R];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {  // both words, unconditionally (a padding word follows every stream)
+        for (uint32_t k = 0; k < R; k++) {  // both words, unconditionally (a padding word follows every stream)
             const uint32_t rr = lane + 64 * k;
             const uint64_t bp = ((uint64_t)done + (rr < tot ? rr : 0u)) * b;
             a[k] = b ? lw[bp >> WSH] : (LW)0;
@@ -999,10 +999,10 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
         }
         __syncthreads();
         const LW pbase = (LW)bt * EF_BATCH_BITS;
-        for (uint32_t r0 = 0; r0 < tot; r0 += 512) {
+        for (uint32_t r0 = 0; r0 < tot; r0 += 64 * R) {
             if (r0) {
 #pragma unroll
-                for (uint32_t k = 0; k < 8; k++) {
+                for (uint32_t k = 0; k < R; k++) {
                     const uint32_t rr = r0 + lane + 64 * k;
                     const uint64_t bp = ((uint64_t)done + (rr < tot ? rr : 0u)) * b;
                     a[k] = b ? lw[bp >> WSH] : (LW)0;
@@ -1010,7 +1010,7 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
                 }
             }
 #pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
+            for (uint32_t k = 0; k < R; k++) {
                 const uint32_t rr = r0 + lane + 64 * k;
                 if (rr < tot) {
                     const uint32_t rank = done + rr;
@@ -1620,13 +1620,23 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
         }
     }
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    if (e->nbatches && e->narrow)
-        hipLaunchKernelGGL(k_ef_decode_rec<uint32_t>, dim3((uint32_t)std::min<uint64_t>(e->nbatches, (uint64_t)ctx->num_cu * 256)),
-                           dim3(64), std::min<uint32_t>(EF_BATCH_BITS, (e->recs_max_cnt + 63u) & ~63u) * 2, ctx->stream,
-                           e->d_low.p, e->d_high.p, e->d_recs.p, (uint32_t)e->nbatches, d_out);
-    else if (e->nbatches)
-        hipLaunchKernelGGL(k_ef_decode_rec<uint64_t>, dim3((uint32_t)std::min<uint64_t>(e->nbatches, (uint64_t)ctx->num_cu * 256)),
-                           dim3(64), std::min<uint32_t>(EF_BATCH_BITS, (e->recs_max_cnt + 63u) & ~63u) * 2, ctx->stream, e->d_low.p, e->d_high.p, e->d_recs.p, (uint32_t)e->nbatches, d_out);
+    if (e->nbatches) {
+        const dim3 grid((uint32_t)std::min<uint64_t>(e->nbatches, (uint64_t)ctx->num_cu * 256));
+        const uint32_t lds = std::min<uint32_t>(EF_BATCH_BITS, (e->recs_max_cnt + 63u) & ~63u) * 2;
+        const bool small = e->recs_max_cnt <= 256;
+        if (e->narrow && small)
+            hipLaunchKernelGGL((k_ef_decode_rec<uint32_t, 4>), grid, dim3(64), lds, ctx->stream, e->d_low.p, e->d_high.p,
+                               e->d_recs.p, (uint32_t)e->nbatches, d_out);
+        else if (e->narrow)
+            hipLaunchKernelGGL((k_ef_decode_rec<uint32_t, 8>), grid, dim3(64), lds, ctx->stream, e->d_low.p, e->d_high.p,
+                               e->d_recs.p, (uint32_t)e->nbatches, d_out);
+        else if (small)
+            hipLaunchKernelGGL((k_ef_decode_rec<uint64_t, 4>), grid, dim3(64), lds, ctx->stream, e->d_low.p, e->d_high.p,
+                               e->d_recs.p, (uint32_t)e->nbatches, d_out);
+        else
+            hipLaunchKernelGGL((k_ef_decode_rec<uint64_t, 8>), grid, dim3(64), lds, ctx->stream, e->d_low.p, e->d_high.p,
+                               e->d_recs.p, (uint32_t)e->nbatches, d_out);
+    }
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
