@@ -1307,7 +1307,7 @@ int ef_encode_general(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t
         return VIDC_OK;
     };
     const uint32_t lgrid = (uint32_t)std::min<uint64_t>((nlist + 255) / 256 + 1, 2048);
-    Scratch s_cnt, s_coff, s_tmp, s_prep, s_lw, s_hw, s_nb, s_tot, s_tmp2, s_tmp3;
+    Scratch s_cnt, s_coff, s_tmp, s_prep, s_lw, s_hw, s_nb, s_tot, s_tmp2;
     Pinned tail;
     VIDC_TRY(tail.get(ctx, 64));
     unsigned long long *t = tail.as<unsigned long long>();
@@ -1343,9 +1343,12 @@ int ef_encode_general(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t
     hipLaunchKernelGGL(k_ef_geom, dim3(lgrid), dim3(256), 0, ctx->stream, e->d_offsets.p, s_prep.as<PrepOut>(), nl32,
                        e->d_lbits.p, e->d_universe.p, s_lw.as<uint32_t>(), s_hw.as<uint32_t>(), s_nb.as<uint32_t>(),
                        s_tot.as<EfTotals>());
-    VIDC_TRY(device_exscan(ctx, s_lw.as<uint32_t>(), nl32, e->d_low_off.p, s_tmp));
-    VIDC_TRY(device_exscan(ctx, s_hw.as<uint32_t>(), nl32, e->d_high_off.p, s_tmp2));
-    VIDC_TRY(device_exscan(ctx, s_nb.as<uint32_t>(), nl32, e->d_batch_off.p, s_tmp3));
+    {
+        Scan4 sc;
+        sc.in[0] = s_lw.as<uint32_t>(); sc.in[1] = s_hw.as<uint32_t>(); sc.in[2] = s_nb.as<uint32_t>(); sc.in[3] = nullptr;
+        sc.out[0] = e->d_low_off.p; sc.out[1] = e->d_high_off.p; sc.out[2] = e->d_batch_off.p; sc.out[3] = nullptr;
+        VIDC_TRY(device_exscan4(ctx, sc, 3, nl32, s_tmp2));
+    }
     VIDC_HIP(hipMemcpyAsync(t + 0, e->d_low_off.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipMemcpyAsync(t + 1, e->d_high_off.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipMemcpyAsync(t + 2, e->d_batch_off.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1740,7 +1743,7 @@ int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_
     e->rows = true;
     e->K = K;
     const uint32_t n32 = (uint32_t)N;
-    Scratch s_cnt, s_lw, s_hw, s_nb, s_tot, s_t0, s_t1, s_t2, s_t3;
+    Scratch s_cnt, s_lw, s_hw, s_nb, s_tot, s_t0;
     Pinned tail;
     VIDC_TRY(tail.get(ctx, 64));
     unsigned long long *t = tail.as<unsigned long long>();
@@ -1779,10 +1782,12 @@ int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_
                                    e->d_lbits.p, e->d_universe.p, s_lw.as<uint32_t>(), s_hw.as<uint32_t>(),
                                    s_nb.as<uint32_t>(), d_tot, d_err);
         }));
-    VIDC_TRY(device_exscan(ctx, s_cnt.as<uint32_t>(), n32, e->d_offsets.p, s_t0));
-    VIDC_TRY(device_exscan(ctx, s_lw.as<uint32_t>(), n32, e->d_low_off.p, s_t1));
-    VIDC_TRY(device_exscan(ctx, s_hw.as<uint32_t>(), n32, e->d_high_off.p, s_t2));
-    VIDC_TRY(device_exscan(ctx, s_nb.as<uint32_t>(), n32, e->d_batch_off.p, s_t3));
+    {
+        Scan4 sc;
+        sc.in[0] = s_cnt.as<uint32_t>(); sc.in[1] = s_lw.as<uint32_t>(); sc.in[2] = s_hw.as<uint32_t>(); sc.in[3] = s_nb.as<uint32_t>();
+        sc.out[0] = e->d_offsets.p; sc.out[1] = e->d_low_off.p; sc.out[2] = e->d_high_off.p; sc.out[3] = e->d_batch_off.p;
+        VIDC_TRY(device_exscan4(ctx, sc, 4, n32, s_t0));
+    }
     VIDC_HIP(hipMemcpyAsync(t + 0, e->d_offsets.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipMemcpyAsync(t + 1, e->d_low_off.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipMemcpyAsync(t + 2, e->d_high_off.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));

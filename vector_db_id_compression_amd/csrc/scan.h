@@ -155,5 +155,91 @@ inline int device_exscan(::vidc_ctx *ctx, const uint32_t *d_in, uint32_t n, uint
     return VIDC_OK;
 }
 
+
+// up to four scans of the same length in the launches of one (blockIdx.y = which): an Elias-Fano object built from graph
+// rows needs the prefix sums of four per-row counts, and at 10^6 rows a three-launch scan is mostly launch latency
+struct Scan4 {
+    const uint32_t *in[4];
+    uint64_t *out[4];
+};
+__global__ void __launch_bounds__(256) k_scan4_tile_sums(Scan4 a, uint32_t n, uint64_t *tile_sums, uint32_t ntiles) {
+    __shared__ uint64_t part[4];
+    const uint32_t *in = a.in[blockIdx.y];
+    const uint32_t base = blockIdx.x * VIDC_SCAN_TILE;
+    uint64_t s = 0;
+    for (uint32_t j = threadIdx.x; j < VIDC_SCAN_TILE; j += 256) s += base + j < n ? in[base + j] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor((unsigned long long)s, o, 64);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[(size_t)blockIdx.y * ntiles + blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ void __launch_bounds__(256) k_scan4_tiles(uint64_t *tile_sums, uint32_t ntiles) {  // one block per scan
+    __shared__ uint64_t sh[256];
+    __shared__ uint64_t carry;
+    uint64_t *ts = tile_sums + (size_t)blockIdx.x * ntiles;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < ntiles; b0 += 256) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint64_t v = i < ntiles ? ts[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t o = 1; o < 256; o <<= 1) {
+            const uint64_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < ntiles) ts[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += sh[255];
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_scan4_apply(Scan4 a, uint32_t n, const uint64_t *tile_off, uint32_t ntiles) {
+    __shared__ uint64_t sh[256];
+    const uint32_t *in = a.in[blockIdx.y];
+    uint64_t *out = a.out[blockIdx.y];
+    const uint32_t base = blockIdx.x * VIDC_SCAN_TILE + threadIdx.x * 16u;
+    uint32_t v[16];
+    uint64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        v[j] = base + j < n ? in[base + j] : 0u;
+        s += v[j];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256; o <<= 1) {
+        const uint64_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint64_t acc = tile_off[(size_t)blockIdx.y * ntiles + blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (base + j <= n) out[base + j] = acc;  // (index n receives the total)
+        acc += v[j];
+    }
+}
+// out[k][0..n] = exclusive prefix sums of in[k][0..n) for k < count (count <= 4) on the context's stream
+inline int device_exscan4(::vidc_ctx *ctx, const Scan4 &a, uint32_t count, uint32_t n, Scratch &tmp) {
+    if (n <= VIDC_SCAN_SMALL_MAX) {
+        for (uint32_t k = 0; k < count; k++)
+            hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, a.in[k], n, a.out[k]);
+        VIDC_HIP(hipGetLastError());
+        return VIDC_OK;
+    }
+    const uint32_t ntiles = n / VIDC_SCAN_TILE + 1u;
+    VIDC_TRY(tmp.get(ctx, (size_t)ntiles * count * 8));
+    hipLaunchKernelGGL(k_scan4_tile_sums, dim3(ntiles, count), dim3(256), 0, ctx->stream, a, n, tmp.as<uint64_t>(), ntiles);
+    hipLaunchKernelGGL(k_scan4_tiles, dim3(count), dim3(256), 0, ctx->stream, tmp.as<uint64_t>(), ntiles);
+    hipLaunchKernelGGL(k_scan4_apply, dim3(ntiles, count), dim3(256), 0, ctx->stream, a, n, tmp.as<const uint64_t>(), ntiles);
+    VIDC_HIP(hipGetLastError());
+    return VIDC_OK;
+}
+
 }  // namespace
 }  // namespace vidc
