@@ -188,8 +188,9 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "s_mov_b32 s69, 0\n" \
     "s_min_u32 s70, s86, 63\n"
 
-#define U2_ENC_TOP \
-    "1:\n" U2P(130) U2P(131) \
+#define U2_ENC_TOP "1:\n" U2_ENC_TOP_NL
+#define U2_ENC_TOP_NL \
+    U2P(130) U2P(131) \
     "v_lshrrev_b32_e64 v14, 16, s40\n"                 /* x_hi */ \
     "v_bfe_u32 v15, s40, 0, 16\n"                      /* x_lo */ \
     "v_add_u32 v16, v48, v14\n"                        /* s = r_B + x_hi */ \
@@ -295,7 +296,8 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "v_readfirstlane_b32 s67, v31\n" \
     "v_mul_lo_u32 v48, v46, v9\n"
 
-#define U2_ENC_BOT(ORDER, LSHR) \
+#define U2_ENC_BOT(ORDER, LSHR) U2_ENC_BOT_T(ORDER, LSHR, "s_cbranch_scc1 1b\n")
+#define U2_ENC_BOT_T(ORDER, LSHR, TAIL) \
     "v_mbcnt_lo_u32_b32 v49, s66, 0\n" \
     "v_mbcnt_hi_u32_b32 v49, s67, v49\n" \
     "v_cmp_eq_u32 vcc, v49, v12\n"                     /* bit of the word */ \
@@ -321,7 +323,7 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "s_cselect_b32 s71, 0, s71\n" \
     "s_add_u32 s69, s69, 1\n" U2P(143) \
     "s_cmp_lt_u32 s69, s71\n" \
-    "s_cbranch_scc1 1b\n"
+    TAIL
 #define U2_ENC_ORDER \
     "s_mov_b32 m0, s69\n" \
     "s_lshr_b32 s68, s58, 31\n"                        /* (first instruction of the exit test: m0 settles meanwhile) */ \
@@ -528,11 +530,16 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
               "s62", "s63", "s64", "s68", "s70", "s71", "s72", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s96",       \
               "s97", "s98", "s99")
         if (U::G == 4u) {
-            if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT(U2_ENC_ORDER, "") U2_ENC_OUTER(U2_ORDER_FLUSH));
-            else U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT("", "s_lshr_b32 s68, s58, 31\n") U2_ENC_OUTER(""));
+            // two steps per loop iteration: the taken branch at the end of a step costs an instruction-buffer refill
+            if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT_T(U2_ENC_ORDER, "", "s_cbranch_scc0 7f\n")
+                                       U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT(U2_ENC_ORDER, "") "7:\n" U2_ENC_OUTER(U2_ORDER_FLUSH));
+            else U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT_T("", "s_lshr_b32 s68, s58, 31\n", "s_cbranch_scc0 7f\n")
+                            U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT("", "s_lshr_b32 s68, s58, 31\n") "7:\n" U2_ENC_OUTER(""));
         } else {
-            if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT(U2_ENC_ORDER, "") U2_ENC_OUTER(U2_ORDER_FLUSH));
-            else U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT("", "s_lshr_b32 s68, s58, 31\n") U2_ENC_OUTER(""));
+            if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_T(U2_ENC_ORDER, "", "s_cbranch_scc0 7f\n")
+                                       U2_ENC_TOP_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT(U2_ENC_ORDER, "") "7:\n" U2_ENC_OUTER(U2_ORDER_FLUSH));
+            else U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_T("", "s_lshr_b32 s68, s58, 31\n", "s_cbranch_scc0 7f\n")
+                            U2_ENC_TOP_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT("", "s_lshr_b32 s68, s58, 31\n") "7:\n" U2_ENC_OUTER(""));
         }
 #undef U2_ENC_ASM
         // clang-format on
@@ -588,8 +595,8 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
 // runs in its shadow.  The kernel verifies what it assumes (ascending, ids < 2^31) and computes the precision from
 // the list's own maximum like the general kernel; anything else goes back as VIDC_ST_PENDING_SORT.
 //   additional registers: s[36:37] input ids of the list (u64 each)   s39 id of the previously selected position
-#define U2_ENC_TOP_R \
-    "1:\n" \
+#define U2_ENC_TOP_R "1:\n" U2_ENC_TOP_R_NL
+#define U2_ENC_TOP_R_NL \
     "v_lshrrev_b32_e64 v14, 16, s39\n"                 /* id_hi */ \
     "v_bfe_u32 v15, s39, 0, 16\n"                      /* id_lo */ \
     "v_add_u32 v16, v48, v14\n"                        /* s = r_B + id_hi */ \
@@ -634,7 +641,8 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
     "s_lshl_b32 s45, s43, 6\n" \
     "s_or_b32 s45, s45, s44\n"
 // the tail of the step: position x = s40, its id by a scalar load (s39) consumed by the slice word and the next step
-#define U2_ENC_BOT_R(ORDER, LSHR) \
+#define U2_ENC_BOT_R(ORDER, LSHR) U2_ENC_BOT_R_T(ORDER, LSHR, "s_cbranch_scc1 1b\n")
+#define U2_ENC_BOT_R_T(ORDER, LSHR, TAIL) \
     "v_mbcnt_lo_u32_b32 v49, s66, 0\n" \
     "v_mbcnt_hi_u32_b32 v49, s67, v49\n" \
     "v_cmp_eq_u32 vcc, v49, v12\n"                     /* bit of the word */ \
@@ -663,7 +671,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
     "s_or_b32 s68, s68, s54\n" \
     "v_writelane_b32 v5, s68, m0\n"                    /* word of the second slice (kept only if it renormalised) */ \
     "s_cmp_lt_u32 s69, s71\n" \
-    "s_cbranch_scc1 1b\n"
+    TAIL
 
 // one generic encode step in position space (rare path): codec.cpp:131-137; returns the position
 __device__ __forceinline__ uint32_t u2r_slow_step(uint64_t &head, WStack &st, uint32_t nmax, uint32_t &E1, v32u &ra, v32u &rb,
@@ -810,8 +818,11 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
               "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57",\
               "s62", "s63", "s64", "s68", "s70", "s71", "s72", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s96",       \
               "s97", "s98", "s99")
-        if (WANT_ORDER) U2R_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP_R U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_R(U2_ENC_ORDER, "") U2_ENC_OUTER(U2_ORDER_FLUSH));
-        else U2R_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP_R U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_R("", "s_lshr_b32 s68, s58, 31\n") U2_ENC_OUTER(""));
+        // (two steps per loop iteration, as in k_roc_encode_u2)
+        if (WANT_ORDER) U2R_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP_R U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_R_T(U2_ENC_ORDER, "", "s_cbranch_scc0 7f\n")
+                                    U2_ENC_TOP_R_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_R(U2_ENC_ORDER, "") "7:\n" U2_ENC_OUTER(U2_ORDER_FLUSH));
+        else U2R_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP_R U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_R_T("", "s_lshr_b32 s68, s58, 31\n", "s_cbranch_scc0 7f\n")
+                         U2_ENC_TOP_R_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_R("", "s_lshr_b32 s68, s58, 31\n") "7:\n" U2_ENC_OUTER(""));
 #undef U2R_ENC_ASM
         // clang-format on
         // ---- back to the plain state.  head = B + c(id); the position's bit leaves the bitmap
@@ -872,20 +883,20 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     "s_mov_b32 s75, s85\n" \
     "s_min_u32 s70, s86, 64\n"
 
-#define U2_DEC_TOP \
-    "1:\n" \
+#define U2_DEC_TOP "1:\n" U2_DEC_TOP_L("20", "21", "22", "23")
+#define U2_DEC_TOP_L(LA, LB, LC, LD)                   /* (labels of the two refill side paths and their returns) */ \
     "s_and_b32 s46, s58, s73\n"                        /* slice 1: x_hi (codec.cpp:78-90) */ \
     "s_lshr_b64 s[58:59], s[58:59], s77\n" \
     "s_lshr_b32 s68, s58, 31\n" \
     "s_or_b32 s68, s68, s59\n" \
-    "s_cbranch_scc0 20f\n"                             /* head < 2^31: refill */ \
-    "21:\n" \
+    "s_cbranch_scc0 " LA "f\n"                         /* head < 2^31: refill */ \
+    LB ":\n" \
     "s_and_b32 s40, s58, s74\n"                        /* slice 0: x_lo */ \
     "s_lshr_b64 s[58:59], s[58:59], s76\n" \
     "s_lshr_b32 s68, s58, 31\n" \
     "s_or_b32 s68, s68, s59\n" \
-    "s_cbranch_scc0 22f\n" \
-    "23:\n" \
+    "s_cbranch_scc0 " LC "f\n" \
+    LD ":\n" \
     "s_lshl_b32 s46, s46, 16\n" \
     "s_or_b32 s40, s40, s46\n"                         /* x */
 #define U2_DEC_IDX_G4 \
@@ -971,7 +982,8 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     "s_nop 0\n" \
     "v_readfirstlane_b32 s64, v37\n" \
     U2_DEC_AFTER_RANK
-#define U2_DEC_BOT \
+#define U2_DEC_BOT U2_DEC_BOT_CORE "s_cbranch_scc1 1b\n s_branch 2f\n" U2_DEC_SIDE("20", "21", "22", "23") "2:\n"
+#define U2_DEC_BOT_CORE \
     "s_sub_u32 s68, s60, s61\n"                        /* ring: two pops and one push must fit the next step */ \
     "s_add_u32 s68, s68, -2\n" \
     "s_add_u32 s69, s69, 1\n" \
@@ -984,22 +996,25 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     "s_lshr_b32 s68, s58, 31\n"                        /* head' < 2^31: the push refills (generic code) */ \
     "s_or_b32 s68, s68, s59\n" \
     "s_cselect_b32 s71, s71, 0\n" \
-    "s_cmp_lt_u32 s69, s71\n" \
-    "s_cbranch_scc1 1b\n" \
-    "s_branch 2f\n" \
-    "20:\n"                                            /* refills: head = (head << 32) | pop (codec.cpp:83-87) */ \
+    "s_cmp_lt_u32 s69, s71\n"
+#define U2_DEC_SIDE(LA, LB, LC, LD) \
+    LA ":\n"                                           /* refills: head = (head << 32) | pop (codec.cpp:83-87) */ \
     "s_sub_u32 s60, s60, 1\n" \
     "s_and_b32 s68, s60, 63\n" \
     "s_mov_b32 s59, s58\n" \
     "v_readlane_b32 s58, v5, s68\n" \
-    "s_branch 21b\n" \
-    "22:\n" \
+    "s_branch " LB "b\n" \
+    LC ":\n" \
     "s_sub_u32 s60, s60, 1\n" \
     "s_and_b32 s68, s60, 63\n" \
     "s_mov_b32 s59, s58\n" \
     "v_readlane_b32 s58, v5, s68\n" \
-    "s_branch 23b\n" \
-    "2:\n"
+    "s_branch " LD "b\n"
+// two steps per loop iteration (the taken branch behind a step costs an instruction-buffer refill)
+#define U2_DEC_LOOP2(IDX, MID, RANK) \
+    "1:\n" U2_DEC_TOP_L("20", "21", "22", "23") IDX MID RANK U2_DEC_BOT_CORE "s_cbranch_scc0 2f\n" \
+    U2_DEC_TOP_L("30", "31", "32", "33") IDX MID RANK U2_DEC_BOT_CORE "s_cbranch_scc1 1b\n s_branch 2f\n" \
+    U2_DEC_SIDE("20", "21", "22", "23") U2_DEC_SIDE("30", "31", "32", "33") "2:\n"
 // store output-ring lanes [0, s72) at out[s87 - lane]; s87 -= s72
 #define U2_DEC_FLUSH \
     "v_cmp_gt_u32 vcc, s72, v2\n" \
@@ -1125,8 +1140,8 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
               "v37", "v54", "v55", "v56", "v57", "v58", "v59", "s40", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",\
               "s51", "s52", "s53", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s70", "s71", "s72", "s75", "s96", "s97",\
               "s98", "s99")
-        if (U::G == 4u) U2_DEC_ASM(U2_DEC_ENTRY U2_DEC_TOP U2_DEC_IDX_G4 U2_DEC_MID U2_DEC_RANK_G4 U2_DEC_BOT U2_DEC_OUTER);
-        else U2_DEC_ASM(U2_DEC_ENTRY U2_DEC_TOP U2_DEC_IDX_G1 U2_DEC_MID U2_DEC_RANK_G1 U2_DEC_BOT U2_DEC_OUTER);
+        if (U::G == 4u) U2_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP2(U2_DEC_IDX_G4, U2_DEC_MID, U2_DEC_RANK_G4) U2_DEC_OUTER);
+        else U2_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP2(U2_DEC_IDX_G1, U2_DEC_MID, U2_DEC_RANK_G1) U2_DEC_OUTER);
 #undef U2_DEC_ASM
         // clang-format on
         head = s_h;
@@ -1410,8 +1425,8 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
               "v37", "v54", "v55", "v56", "v57", "v58", "v59", "s40", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",\
               "s51", "s52", "s53", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s70", "s71", "s72", "s75", "s80", "s81",\
               "s96", "s97", "s98", "s99")
-        if (LROWS) U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_TOP U2L_DEC_IDX U2L_DEC_MID U2L_DEC_RANK U2_DEC_BOT U2_DEC_OUTER);
-        else U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_TOP U2B_DEC_IDX U2B_DEC_MID U2B_DEC_RANK U2_DEC_BOT U2_DEC_OUTER);
+        if (LROWS) U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP2(U2L_DEC_IDX, U2L_DEC_MID, U2L_DEC_RANK) U2_DEC_OUTER);
+        else U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP2(U2B_DEC_IDX, U2B_DEC_MID, U2B_DEC_RANK) U2_DEC_OUTER);
 #undef U2B_DEC_ASM
         // clang-format on
         ovf = s_ovf;
