@@ -296,8 +296,15 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "v_readfirstlane_b32 s67, v31\n" \
     "v_mul_lo_u32 v48, v46, v9\n"
 
-#define U2_ENC_BOT(ORDER, LSHR) U2_ENC_BOT_T(ORDER, LSHR, "s_cbranch_scc1 1b\n")
-#define U2_ENC_BOT_T(ORDER, LSHR, TAIL) \
+// The output ring (64 words, a step pushes at most two) is checked by the LAST copy of the loop body only, for the up to eight
+// steps that follow: U2_RING_ROOM words at most on entry (the C++ glue and U2_ENC_OUTER spill from there on), 48 + 2 * 8 = 64.
+#define U2_RING_ROOM 48
+#define U2_RING_CHECK \
+    "s_sub_u32 s68, s60, s61\n"                        /* ring nearly full */ \
+    "s_cmp_ge_u32 s68, 48\n" \
+    "s_cselect_b32 s71, 0, s71\n"
+#define U2_ENC_BOT(ORDER, LSHR) U2_ENC_BOT_T(ORDER, LSHR, U2_RING_CHECK, "s_cbranch_scc1 1b\n")
+#define U2_ENC_BOT_T(ORDER, LSHR, RING, TAIL) \
     "v_mbcnt_lo_u32_b32 v49, s66, 0\n" \
     "v_mbcnt_hi_u32_b32 v49, s67, v49\n" \
     "v_cmp_eq_u32 vcc, v49, v12\n"                     /* bit of the word */ \
@@ -318,9 +325,7 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "s_add_u32 s68, s68, -1\n" \
     "s_cmp_ge_u32 s68, 0x7ff80000\n" \
     "s_cselect_b32 s71, 0, s70\n" \
-    "s_sub_u32 s68, s60, s61\n"                        /* ring nearly full */ \
-    "s_cmp_ge_u32 s68, 62\n" \
-    "s_cselect_b32 s71, 0, s71\n" \
+    RING \
     "s_add_u32 s69, s69, 1\n" U2P(143) \
     "s_cmp_lt_u32 s69, s71\n" \
     TAIL
@@ -347,7 +352,7 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "s_cmp_ge_u32 s68, 0x7ff80000\n" \
     "s_cselect_b32 s99, 1, 0\n" \
     "s_sub_u32 s68, s60, s61\n" \
-    "s_cmp_lt_u32 s68, 62\n" \
+    "s_cmp_lt_u32 s68, 48\n"                           /* (U2_RING_ROOM) */ \
     "s_cbranch_scc1 3f\n" \
     "v_subrev_u32 v27, s61, v2\n"                      /* spill the 32 oldest ring words (ws_spill32) */ \
     "v_and_b32 v27, 63, v27\n" \
@@ -491,7 +496,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
 #endif
     uint32_t nmax = n;  // divisor of the next step
     while (nmax) {
-        if (st.sp - st.lo >= 62u) ws_spill32(st);
+        if (st.sp - st.lo >= U2_RING_ROOM) ws_spill32(st);
         // generic step: the last two (the fix-up reciprocal needs nmax' >= 2) and index pops that renormalise
         if (nmax < 3u || u2_needs_generic(head)) {
             const uint32_t x = u2_slow_step<UB>(head, st, nmax, E1, ra, rb, bm, p0, p1);
@@ -531,16 +536,16 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
               "s97", "s98", "s99")
         if (U::G == 4u) {
             // four steps per loop iteration: the taken branch at the end of a step costs ~6 cycles of instruction-buffer refill
-#define U2_STEP_X(ORDER, LSHR) U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT_T(ORDER, LSHR, "s_cbranch_scc0 7f\n")
+#define U2_STEP_X(ORDER, LSHR) U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT_T(ORDER, LSHR, "", "s_cbranch_scc0 7f\n")
             if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY "1:\n" U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "")
                                        U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT(U2_ENC_ORDER, "") "7:\n" U2_ENC_OUTER(U2_ORDER_FLUSH));
             else U2_ENC_ASM(U2_ENC_ENTRY "1:\n" U2_STEP_X("", "s_lshr_b32 s68, s58, 31\n") U2_STEP_X("", "s_lshr_b32 s68, s58, 31\n") U2_STEP_X("", "s_lshr_b32 s68, s58, 31\n")
                             U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT("", "s_lshr_b32 s68, s58, 31\n") "7:\n" U2_ENC_OUTER(""));
 #undef U2_STEP_X
         } else {
-            if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_T(U2_ENC_ORDER, "", "s_cbranch_scc0 7f\n")
+            if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_T(U2_ENC_ORDER, "", "", "s_cbranch_scc0 7f\n")
                                        U2_ENC_TOP_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT(U2_ENC_ORDER, "") "7:\n" U2_ENC_OUTER(U2_ORDER_FLUSH));
-            else U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_T("", "s_lshr_b32 s68, s58, 31\n", "s_cbranch_scc0 7f\n")
+            else U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_T("", "s_lshr_b32 s68, s58, 31\n", "", "s_cbranch_scc0 7f\n")
                             U2_ENC_TOP_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT("", "s_lshr_b32 s68, s58, 31\n") "7:\n" U2_ENC_OUTER(""));
         }
 #undef U2_ENC_ASM
