@@ -990,20 +990,37 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     "v_readfirstlane_b32 s64, v37\n" \
     U2_DEC_AFTER_RANK
 #define U2_DEC_BOT U2_DEC_BOT_CORE "s_cbranch_scc1 1b\n s_branch 2f\n" U2_DEC_SIDE("20", "21", "22", "23") "2:\n"
-#define U2_DEC_BOT_CORE \
+#define U2_DEC_BOT_CORE U2_DEC_BOT_CORE_T("-2", "59")
+#define U2_DEC_BOT_CORE_T(RLO, RSPAN)                  /* the next step may run while RLO <= words in the ring <= RLO + RSPAN */ \
     "s_sub_u32 s68, s60, s61\n"                        /* ring: two pops and one push must fit the next step */ \
-    "s_add_u32 s68, s68, -2\n" \
+    "s_add_u32 s68, s68, " RLO "\n" \
     "s_add_u32 s69, s69, 1\n" \
     "s_add_u32 s75, s75, 1\n" \
     "s_add_u32 s72, s72, s64\n"                        /* rank */ \
     "s_add_u32 s58, s52, s72\n"                        /* head' = H * nmax + rank */ \
     "s_addc_u32 s59, s53, 0\n" \
-    "s_cmp_gt_u32 s68, 59\n" \
+    "s_cmp_gt_u32 s68, " RSPAN "\n" \
     "s_cselect_b32 s71, 0, s70\n" \
     "s_lshr_b32 s68, s58, 31\n"                        /* head' < 2^31: the push refills (generic code) */ \
     "s_or_b32 s68, s68, s59\n" \
     "s_cselect_b32 s71, s71, 0\n" \
     "s_cmp_lt_u32 s69, s71\n"
+// the same without the ring test: copies of the loop body whose ring state the last copy (or the entry) has vouched for
+#define U2_DEC_BOT_CORE_NR \
+    "s_add_u32 s69, s69, 1\n" \
+    "s_add_u32 s75, s75, 1\n" \
+    "s_add_u32 s72, s72, s64\n"                        /* rank */ \
+    "s_add_u32 s58, s52, s72\n"                        /* head' = H * nmax + rank */ \
+    "s_addc_u32 s59, s53, 0\n" \
+    "s_lshr_b32 s68, s58, 31\n"                        /* head' < 2^31: the push refills (generic code) */ \
+    "s_or_b32 s68, s68, s59\n" \
+    "s_cselect_b32 s71, s70, 0\n" \
+    "s_cmp_lt_u32 s69, s71\n"
+// Ring of the eight-copy loop: a step pops at most two words and pushes at most one, so eight steps are safe while the ring
+// holds U2_DEC_RING_LO .. U2_DEC_RING_HI words when the first copy starts (18 - 16 = 2 words left for the last pops, 53 + 8 = 61
+// before the last push); only the last copy, U2_DEC_OUTER and the C++ glue test it.
+#define U2_DEC_RING_LO 18u
+#define U2_DEC_RING_HI 53u
 #define U2_DEC_SIDE(LA, LB, LC, LD) \
     LA ":\n"                                           /* refills: head = (head << 32) | pop (codec.cpp:83-87) */ \
     "s_sub_u32 s60, s60, 1\n" \
@@ -1026,13 +1043,13 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     U2_DEC_TOP_L("50", "51", "52", "53") IDX MID RANK U2_DEC_BOT_CORE "s_cbranch_scc1 1b\n s_branch 2f\n" \
     U2_DEC_SIDE("20", "21", "22", "23") U2_DEC_SIDE("30", "31", "32", "33") U2_DEC_SIDE("40", "41", "42", "43") \
     U2_DEC_SIDE("50", "51", "52", "53") "2:\n"
-#define U2_DEC_STEP_X(IDX, MID, RANK, LA, LB, LC, LD) U2_DEC_TOP_L(LA, LB, LC, LD) IDX MID RANK U2_DEC_BOT_CORE "s_cbranch_scc0 2f\n"
+#define U2_DEC_STEP_X(IDX, MID, RANK, LA, LB, LC, LD) U2_DEC_TOP_L(LA, LB, LC, LD) IDX MID RANK U2_DEC_BOT_CORE_NR "s_cbranch_scc0 2f\n"
 #define U2_DEC_LOOP8(IDX, MID, RANK) \
     "1:\n" U2_DEC_STEP_X(IDX, MID, RANK, "20", "21", "22", "23") U2_DEC_STEP_X(IDX, MID, RANK, "30", "31", "32", "33") \
     U2_DEC_STEP_X(IDX, MID, RANK, "40", "41", "42", "43") U2_DEC_STEP_X(IDX, MID, RANK, "50", "51", "52", "53") \
     U2_DEC_STEP_X(IDX, MID, RANK, "60", "61", "62", "63") U2_DEC_STEP_X(IDX, MID, RANK, "70", "71", "72", "73") \
     U2_DEC_STEP_X(IDX, MID, RANK, "80", "81", "82", "83") \
-    U2_DEC_TOP_L("90", "91", "92", "93") IDX MID RANK U2_DEC_BOT_CORE "s_cbranch_scc1 1b\n s_branch 2f\n" \
+    U2_DEC_TOP_L("90", "91", "92", "93") IDX MID RANK U2_DEC_BOT_CORE_T("-18", "35") "s_cbranch_scc1 1b\n s_branch 2f\n" \
     U2_DEC_SIDE("20", "21", "22", "23") U2_DEC_SIDE("30", "31", "32", "33") U2_DEC_SIDE("40", "41", "42", "43") \
     U2_DEC_SIDE("50", "51", "52", "53") U2_DEC_SIDE("60", "61", "62", "63") U2_DEC_SIDE("70", "71", "72", "73") \
     U2_DEC_SIDE("80", "81", "82", "83") U2_DEC_SIDE("90", "91", "92", "93") "2:\n"
@@ -1049,13 +1066,14 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     "global_store_dwordx2 v58, v[6:7], s[88:89]\n" \
     "s_mov_b64 exec, s[96:97]\n" \
     "s_sub_u32 s87, s87, s72\n"
-#define U2_DEC_OUTER \
+#define U2_DEC_OUTER U2_DEC_OUTER_T("-2", "59")
+#define U2_DEC_OUTER_T(RLO, RSPAN) \
     "s_lshr_b32 s68, s58, 31\n" \
     "s_or_b32 s68, s68, s59\n" \
     "s_cselect_b32 s99, 0, 1\n"                        /* head < 2^31 */ \
     "s_sub_u32 s68, s60, s61\n" \
-    "s_add_u32 s68, s68, -2\n" \
-    "s_cmp_gt_u32 s68, 59\n" \
+    "s_add_u32 s68, s68, " RLO "\n" \
+    "s_cmp_gt_u32 s68, " RSPAN "\n" \
     "s_cselect_b32 s99, 1, s99\n"                      /* ring needs the host code */ \
     "s_cmp_lt_u32 s69, 64\n" \
     "s_cbranch_scc1 5f\n" \
@@ -1140,9 +1158,16 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
 #define U2_DBG(k)
 #endif
     uint32_t i = 0;  // ids decoded so far
+    constexpr uint32_t RING_LO = U::G == 4u ? U2_DEC_RING_LO : 2u, RING_HI = U::G == 4u ? U2_DEC_RING_HI : 61u;
     while (i < n) {
-        ws_prepare(st);
-        if (lt_2p31(head) || st.sp - st.lo < 2u || st.sp - st.lo > 61u) {  // generic step
+        if (U::G == 4u) {  // (the eight-copy loop wants 18..53 words: refill below 22 -- 21 + 32 = 53 -- instead of ws_prepare's 8)
+            const uint32_t res = st.sp - st.lo;
+            if (res > 56u) ws_spill32(st);
+            else if (res < 22u && st.lo != 0u) ws_refill32(st);
+        } else {
+            ws_prepare(st);
+        }
+        if (lt_2p31(head) || st.sp - st.lo < RING_LO || st.sp - st.lo > RING_HI) {  // generic step
             U2_DBG(0);
             const uint32_t x = u2_slow_dec_step<UB>(head, st, i + 1u, E1, ra, rb, bm, p0, p1);
             if (lane == 0) out[n - 1u - i] = (uint64_t)x;
@@ -1165,7 +1190,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
               "v37", "v54", "v55", "v56", "v57", "v58", "v59", "s40", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",\
               "s51", "s52", "s53", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s70", "s71", "s72", "s75", "s96", "s97",\
               "s98", "s99")
-        if (U::G == 4u) U2_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP8(U2_DEC_IDX_G4, U2_DEC_MID, U2_DEC_RANK_G4) U2_DEC_OUTER);
+        if (U::G == 4u) U2_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP8(U2_DEC_IDX_G4, U2_DEC_MID, U2_DEC_RANK_G4) U2_DEC_OUTER_T("-18", "35"));
         else U2_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP4(U2_DEC_IDX_G1, U2_DEC_MID, U2_DEC_RANK_G1) U2_DEC_OUTER);
 #undef U2_DEC_ASM
         // clang-format on
