@@ -55,6 +55,29 @@ def cpu_baseline(offsets, ids, budget_s=20.0):
                 bits_per_id=8.0 * r["bytes"] / ntotal, bad_lists=r["bad_lists"])
 
 
+def per_list_multisets_equal(offsets, got, want, chunk=1 << 27):
+    """Every list of `got` holds the same multiset of ids as the same list of `want` (both device int64, CSR `offsets`):
+    keyed sort (list number, id) of both sides, in chunks cut on list boundaries.  A list-boundary bug fails this; a
+    global sort of the whole array would not see it."""
+    import torch
+
+    ends = np.asarray(offsets[1:], dtype=np.int64)
+    n = int(ends[-1]) if ends.size else 0
+    bounds = torch.from_numpy(ends).to(got.device)
+    start = 0
+    while start < n:
+        j = int(np.searchsorted(ends, min(n, start + chunk), side="right"))
+        end = int(ends[j - 1]) if j > 0 and ends[j - 1] > start else int(ends[min(j, ends.size - 1)])
+        seg = torch.searchsorted(bounds, torch.arange(start, end, device=got.device), right=True) << 40  # ids < 2^40
+        a = torch.sort(seg + got[start:end]).values
+        b = torch.sort(seg + want[start:end]).values
+        if not torch.equal(a, b):
+            return False
+        del seg, a, b
+        start = end
+    return True
+
+
 def sharded_main(args, ctx, dist, rank, world):
     """Strong scaling of one index (BASELINE configs[4] shape): shard, encode + decode per rank, search-shaped gather."""
     import torch
@@ -143,6 +166,30 @@ def sharded_main(args, ctx, dist, rank, world):
         dist.destroy_process_group()
 
 
+def launch_ranks(n):
+    """Re-run this command as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same args>`
+    (one rank per GPU, rank r bound to GPU r through LOCAL_RANK, nccl = RCCL).  Fails loudly when the node has fewer GPUs."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node")
+    with socket.socket() as s:  # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    rc = subprocess.call(cmd, env=env)
+    if rc:
+        raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +204,11 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="strong scaling: one index sharded over the ranks + gather")
     ap.add_argument("--no-perm", action="store_true", help="encode the streams only (no sampling permutation)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, RCCL), exactly the
+        # command the driver would have used; rank 0 of the children prints the JSON line
+        return launch_ranks(args.gpus)
 
     import torch
 
@@ -214,14 +266,7 @@ def main():
     # correctness gate inside the bench: every list must come back as the same set of ids
     verified = None
     if not args.no_verify:
-        srt = torch.empty_like(out)
-        off_t = torch.from_numpy(offsets.astype(np.int64)).cuda()
-        seg = torch.searchsorted(off_t[1:], torch.arange(ntotal, device="cuda"), right=True)
-        key = seg * (1 << 40) + out
-        srt = torch.sort(key).values & ((1 << 40) - 1)
-        ref = torch.sort(seg * (1 << 40) + d_ids).values & ((1 << 40) - 1)
-        verified = bool(torch.equal(srt, ref))
-        del srt, ref, key, seg
+        verified = per_list_multisets_equal(offsets, out, d_ids)
 
     if dist is not None:
         dist.barrier()
@@ -313,12 +358,13 @@ def main():
         c2 = obj.compressed_bytes / w2["ntotal"]
         kern = (ke + kd) / steps / 1e3
         gbs = (16.0 + 2.0 * c2) * w2["ntotal"] / kern / 1e9
-        ok = bool(torch.equal(torch.sort(out2).values, torch.sort(ids2).values)) if codec == "roc" else bool(torch.equal(out2, ids2))
+        # ROC returns every list as the same SET of ids in sampling order: compared list by list, like the headline
+        ok = per_list_multisets_equal(w2["offsets"], out2, ids2) if codec == "roc" else bool(torch.equal(out2, ids2))
         res2 = {"workload": w2["describe"], "codec": codec, "nlist": w2["nlist"], "max_list": w2["max_list"],
                 "median_list": w2["median_list"], "ids_per_s": w2["ntotal"] * steps / t_wall,
                 "ms_per_step": 1e3 * t_wall / steps, "kernel_ms": {"encode": ke / steps, "decode": kd / steps},
                 "bits_per_id": 8.0 * c2, "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
-                "multiset_roundtrip_ok": ok}
+                "per_list_roundtrip_ok": ok}
         if floor:
             del out2
             cf = chain_floor(w2, ids2)

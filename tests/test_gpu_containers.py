@@ -535,3 +535,29 @@ def test_sharded_bench_over_rccl_when_two_gpus_are_visible(tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["gather_verified"] is True
     assert sum(d["per_rank"]["ids"]) == 10_000_000 and abs(d["per_rank"]["ids"][0] - d["per_rank"]["ids"][1]) <= 65536
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself(tmp_path):
+    """`python bench.py --gpus N` (no torchrun): the bench starts its N ranks, one per GPU over RCCL, and rank 0 prints
+    n_gpus == N.  With fewer GPUs than asked for it must fail loudly instead of printing a 1-GPU line as N GPUs."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    have = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    if have < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode != 0 and "only 1 GPU" in (r.stdout + r.stderr)
+        return
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extra",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["verified_roundtrip"] is True
+    assert d["config"]["ids_per_gpu"] == 1_000_000

@@ -586,3 +586,130 @@ def test_concurrent_decode_from_two_contexts(roc):
         assert np.array_equal(np.sort(a[int(off[l]):int(off[l + 1])]), lists[l])
     for c in ctxs:
         c.close()
+
+
+# ---- row-per-list kernels (roc_grp.h: 16 lanes per list, four lists per wavefront): the automatic policy only picks them for
+# calls with thousands of lists above 4096 ids; VIDC_FORCE_GRP=1 selects them for every list of 65 .. 131 072 ids.
+@pytest.fixture
+def force_grp(monkeypatch):
+    monkeypatch.setenv("VIDC_FORCE_GRP", "1")
+
+
+def test_row_kernels_boundaries_vs_oracle(roc, oracle, force_grp):
+    """Sizes around every geometry switch of the row-per-list kernels (512-position blocks, the two- / three-level select at
+    8192 ids, bucket bits at 2048 / 8192 / 16 384, row capacity at 32 768 / 65 536), several universes, ragged sizes inside
+    one wavefront."""
+    rng = np.random.default_rng(177)
+    sizes = [65, 66, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193, 8704, 16383, 16384,
+             16385, 20000, 32767, 32768, 32769, 40000, 100, 7000]
+    for nbits in (16, 20, 24, 31):
+        sz = [s for s in sizes if s <= (1 << nbits)]
+        off, ids, lists = _random_lists(rng, sz, nbits=nbits)
+        r = roc.encode(off, ids, want_perm=True)
+        dec = r.decode_all().cpu().numpy().view(np.uint64)
+        _check_against_oracle(oracle, r, off, lists, r.perm(), dec)
+        assert r.last_decode_nonclean == 0
+
+
+def test_row_kernels_longest_lists(roc, oracle, force_grp):
+    """65 536 / 65 537 / 131 072-id lists (the top level's last group, the 96-member rows) and a neighbour in the same wavefront."""
+    rng = np.random.default_rng(178)
+    off, ids, lists = _random_lists(rng, [65536, 131072, 65537, 300], nbits=27)
+    r = roc.encode(off, ids, want_perm=True)
+    dec = r.decode_all().cpu().numpy().view(np.uint64)
+    perm = r.perm()
+    info = r.info()
+    for l in (0, 3):  # (the oracle takes a second per 65 536-id list; lists beyond 65 536 ids are lossy in the reference, Q2)
+        li = lists[l]
+        e = oracle.roc_encode(li, oracle.list_precision(li))
+        a, b = int(off[l]), int(off[l + 1])
+        assert int(info["heads"][l]) == e["head"] and np.array_equal(r.words(l), e["words"])
+        assert np.array_equal(perm[a:b], e["perm"]) and np.array_equal(dec[a:b], e["order"])
+
+
+def test_row_kernels_dense_small_precision_and_fixed_precisions(roc, oracle, force_grp):
+    """Dense lists (n close to the universe: tiny precision, many renormalisation pops, stream windows that drain fast) and
+    explicit precisions above and below what the ids need (carry quirk of the uniform push)."""
+    rng = np.random.default_rng(179)
+    lists = [np.sort(rng.choice(m, size=n, replace=False)).astype(np.uint64)
+             for n, m in ((65, 66), (300, 301), (1024, 1025), (1000, 1 << 10), (4096, 4097), (4096, 5000), (9000, 9001),
+                          (9000, 1 << 14), (20000, 20001), (3000, 1 << 12))]
+    off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
+    ids = np.concatenate(lists)
+    r = roc.encode(off, ids, want_perm=True)
+    dec = r.decode_all().cpu().numpy().view(np.uint64)
+    _check_against_oracle(oracle, r, off, lists, r.perm(), dec)
+    for P in (12, 17, 32):
+        r = roc.encode(off, ids, precision_mode=P, want_perm=True)
+        info = r.info()
+        dec = r.decode_all().cpu().numpy().view(np.uint64)
+        for l, li in enumerate(lists):
+            e = oracle.roc_encode(li, P)
+            assert int(info["heads"][l]) == e["head"] and np.array_equal(r.words(l), e["words"]), (P, l)
+            want = oracle.roc_decode(e["head"], e["words"], li.size, P, e["mt_draws"])[0]
+            assert np.array_equal(dec[int(off[l]):int(off[l + 1])], want), (P, l)
+
+
+def test_row_kernels_hand_back_what_they_cannot_do(roc, oracle, force_grp):
+    """Unsorted and duplicate-holding lists (the encoder samples POSITIONS of an ascending list: it must notice and hand the
+    list to the sorting pass) and clustered ids (a full bucket row in the decoder -> VIDC_ST_RETRY): same bits as the oracle."""
+    rng = np.random.default_rng(180)
+    lists = []
+    for n in (700, 5000, 9000):
+        li = rng.choice(1 << 22, size=n, replace=False).astype(np.uint64)  # unsorted
+        lists.append(li)
+    dup = np.sort(rng.choice(1 << 22, size=6000, replace=False)).astype(np.uint64)
+    dup[3000] = dup[2999]  # one duplicate: not strictly ascending
+    lists.append(dup)
+    lists.append(np.sort(rng.choice(1 << 22, size=6000, replace=False)).astype(np.uint64))  # a clean neighbour
+    for n in (900, 5000, 12000):  # clustered: all but the maximum inside a sliver of the universe
+        body = np.sort(rng.choice(20000, size=n - 1, replace=False)).astype(np.uint64) + 5
+        lists.append(np.concatenate([body, [(1 << 22) - 1]]).astype(np.uint64))
+    off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
+    ids = np.concatenate(lists)
+    r = roc.encode(off, ids, want_perm=True)
+    dec = r.decode_all().cpu().numpy().view(np.uint64)
+    perm = r.perm()
+    info = r.info()
+    for l, li in enumerate(lists):
+        a, b = int(off[l]), int(off[l + 1])
+        srt = np.sort(li)
+        e = oracle.roc_encode(srt, oracle.list_precision(srt))
+        assert int(info["heads"][l]) == e["head"] and np.array_equal(r.words(l), e["words"]), l
+        assert np.array_equal(li[perm[a:b]], e["order"]), l   # positions in the caller's (unsorted) order
+        want = oracle.roc_decode(e["head"], e["words"], li.size, oracle.list_precision(srt), e["mt_draws"])[0]
+        assert np.array_equal(dec[a:b], want), l
+    req = [5, 0, 4, 7, 5]
+    sub, sub_off = r.decode_lists(np.array(req, dtype=np.uint64))
+    sub = sub.cpu().numpy().view(np.uint64)
+    for i, l in enumerate(req):
+        assert np.array_equal(sub[int(sub_off[i]):int(sub_off[i + 1])], dec[int(off[l]):int(off[l + 1])])
+
+
+def test_row_kernels_match_wave_kernels_and_the_automatic_policy(roc, monkeypatch):
+    """Same streams, permutations and decoded arrays from the row-per-list family and from the wave-per-list / lane families on
+    ragged lists; then a call large enough (10 000 lists above 4096 ids) to take the row kernels by itself, against VIDC_NO_GRP=1."""
+    rng = np.random.default_rng(181)
+    sizes = np.concatenate([rng.integers(0, 9000, 400), rng.integers(8000, 40000, 40)])
+    off, ids, _ = _random_lists(rng, sizes, nbits=26)
+    got = {}
+    for mode in ("grp", "nogrp"):
+        monkeypatch.setenv("VIDC_FORCE_GRP", "1" if mode == "grp" else "0")
+        monkeypatch.setenv("VIDC_NO_GRP", "0" if mode == "grp" else "1")
+        r = roc.encode(off, ids, want_perm=True)
+        info = r.info()
+        got[mode] = (info["heads"], info["nwords"], info["mt_draws"], r.all_words(), r.perm(), r.decode_all().cpu().numpy().copy())
+    for a, b in zip(got["grp"], got["nogrp"]):
+        assert np.array_equal(a, b)
+    monkeypatch.delenv("VIDC_FORCE_GRP")
+    sizes = rng.integers(4097, 6000, 10000)
+    off, ids, _ = _random_lists(rng, sizes, nbits=27)
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VIDC_NO_GRP", mode)
+        r = roc.encode(off, ids, want_perm=True)
+        info = r.info()
+        got[mode] = (info["heads"], info["nwords"], r.all_words(), r.perm(), r.decode_all().cpu().numpy().copy())
+        assert r.last_decode_nonclean == 0
+    for a, b in zip(got["0"], got["1"]):
+        assert np.array_equal(a, b)

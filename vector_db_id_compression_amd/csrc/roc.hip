@@ -14,6 +14,7 @@
 #include "roc_u2.h"
 #include "rows_csr.h"
 #include "roc_lane.h"
+#include "roc_grp.h"
 #include "scan.h"
 
 using namespace vidc;
@@ -94,6 +95,26 @@ inline bool lane_wanted(LanePolicy p, uint64_t nlists, uint64_t min_lists) {
     return p == LANE_ALWAYS || (p == LANE_AUTO && nlists >= min_lists);
 }
 
+inline bool env_on(const char *name) {  // set, not empty, not "0"
+    const char *e = std::getenv(name);
+    return e && *e && !(e[0] == '0' && !e[1]);
+}
+// Row-per-list kernels (roc_grp.h: 16 lanes per list, four lists per wavefront) for lists of 4097 .. 131 072 ids.  They are
+// throughput kernels -- a step costs about as many instructions as a wave-per-list step but advances four lists -- and
+// every list pays a longer step (LDS round trips instead of v_readlane), so they only pay once a call has more such
+// lists than the wave-per-list kernels keep resident.  Test hooks: VIDC_NO_GRP=1 (never), VIDC_FORCE_GRP=1 (every list
+// of 65 .. 131 072 ids), VIDC_GRP_MIN=<lists>, VIDC_GRP_MAXN=<ids> (measurements).
+constexpr uint64_t GRP_MIN_LISTS = 8192;
+struct GrpPolicy { uint64_t min_lists, min_n, max_n; };
+inline GrpPolicy grp_policy() {
+    GrpPolicy g{GRP_MIN_LISTS, VIDC_LANE_MAX64 + 1u, VIDC_GRP_MAX_LIST};
+    if (env_on("VIDC_NO_GRP") || env_on("VIDC_FORCE_GENERAL") || env_on("VIDC_OLD_U")) { g.min_lists = ~0ull; return g; }
+    if (env_on("VIDC_FORCE_GRP")) { g.min_lists = 0; g.min_n = VIDC_GRP_MIN_LIST; }
+    if (const char *e = std::getenv("VIDC_GRP_MIN")) g.min_lists = (uint64_t)std::atoll(e);
+    if (const char *e = std::getenv("VIDC_GRP_MAXN")) g.max_n = std::min<uint64_t>((uint64_t)std::atoll(e), VIDC_GRP_MAX_LIST);
+    return g;
+}
+
 // test hook: VIDC_OLD_U=1 keeps the round-1 bitmap kernels (roc_u.h) instead of the hand-scheduled ones (roc_u2.h)
 // Lists per wavefront of a lane-per-list launch (VIDC_LPW=8|16|32, measurements only; default 64).  Every list of a
 // launch is in flight at once either way, so fewer lists per wavefront only adds wavefronts: measured no better on
@@ -101,10 +122,6 @@ inline bool lane_wanted(LanePolicy p, uint64_t nlists, uint64_t min_lists) {
 inline uint32_t lane_lists_per_wave(const vidc_ctx *, uint32_t, uint32_t) {
     static const int forced = [] { const char *e = std::getenv("VIDC_LPW"); return e ? std::atoi(e) : 0; }();
     return (forced == 8 || forced == 16 || forced == 32) ? (uint32_t)forced : 64u;
-}
-inline bool env_on(const char *name) {  // set, not empty, not "0"
-    const char *e = std::getenv(name);
-    return e && *e && !(e[0] == '0' && !e[1]);
 }
 inline bool old_u_kernels() {
     const char *e = getenv("VIDC_OLD_U");
@@ -327,7 +344,7 @@ int finish_encode(vidc_ctx *ctx, vidc_roc *r, const uint32_t *d_arena, uint32_t 
     // ANSState::size() = 8 + 4 * words per non-empty list; "let's pretend no memory is used" for empty ones
     // (custom_invlists_impl.cpp:196-206).  Empty lists have no words.
     r->compressed_bytes = 8ull * nonempty_lists + 4ull * r->total_words;
-    VIDC_TRY(r->d_words.alloc(r->total_words + 4, ctx->dpool));  // + padding: the lane decoder's look-ahead reads orig[0..1]
+    VIDC_TRY(r->d_words.alloc(r->total_words + 16, ctx->dpool));  // + padding: the look-ahead of the lane / row decoders reads up to 15 words past the last stream
     if (nlist) {
         EventTimer tm(ctx);
         const uint64_t *d_off = r->rows ? (const uint64_t *)nullptr : (const uint64_t *)r->d_offsets.p;
@@ -373,12 +390,13 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     HostTrace tr("roc encode");
     // work lists: tiny (n <= 64), universe-bitmap kernels (ids < 2^18 / 2^20), general kernels by bitmap depth,
     // lane-per-list kernels
-    std::vector<uint32_t> wl_tiny, wl_u18, wl_u20, wl_c1, wl_c2, wl_c3, wl_l4, wl_l16, wl_l64, wl_r2;
+    std::vector<uint32_t> wl_tiny, wl_u18, wl_u20, wl_c1, wl_c2, wl_c3, wl_l4, wl_l16, wl_l64, wl_r2, wl_g2, wl_g3;
     const bool want_perm = (flags & VIDC_ROC_WANT_PERM) && !rows;
     const uint64_t ntotal_in = rows ? N * K : (nlist ? offsets[nlist] : 0);
     const bool f_general = force_general();  // getenv once, not per list
     const LanePolicy lpol = f_general ? LANE_NEVER : lane_policy();
-    bool use_lane = false, use_lane64 = false, use_lane_tiny = false;
+    bool use_lane = false, use_lane64 = false, use_lane_tiny = false, use_grp = false;
+    const GrpPolicy gpol = grp_policy();
     // persistent outputs
     VIDC_TRY(r->d_heads.alloc(nlist, ctx->dpool)); VIDC_TRY(r->d_prec.alloc(nlist, ctx->dpool));
     VIDC_TRY(r->d_nwords.alloc(nlist, ctx->dpool)); VIDC_TRY(r->d_draws.alloc(nlist, ctx->dpool));
@@ -430,25 +448,27 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         // num_cu lists in flight.  With many lists, short ones go to the high-occupancy kernels.
         const uint64_t u_min = U_MIN_LIST;
         {
-            uint64_t n_mid = 0, n_mid64 = 0, n_tiny = 0;
+            uint64_t n_mid = 0, n_mid64 = 0, n_tiny = 0, n_grp = 0;
             {
                 const unsigned parts = par_parts(nlist);
-                std::vector<uint64_t> cnt(3 * (size_t)parts, 0);
+                std::vector<uint64_t> cnt(4 * (size_t)parts, 0);
                 par_ranges(nlist, parts, [&](uint64_t la, uint64_t lb, unsigned t) {
-                    uint64_t a = 0, b = 0, c = 0;
+                    uint64_t a = 0, b = 0, c = 0, g = 0;
                     for (uint64_t l = la; l < lb; l++) {
                         const uint64_t n = offsets[l + 1] - offsets[l];
                         a += n <= TINY_MAX;
                         b += n > TINY_MAX && n <= VIDC_LANE_MAX;
                         c += n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64;
+                        g += n >= gpol.min_n && n <= gpol.max_n;
                     }
-                    cnt[3 * t] = a; cnt[3 * t + 1] = b; cnt[3 * t + 2] = c;
+                    cnt[4 * t] = a; cnt[4 * t + 1] = b; cnt[4 * t + 2] = c; cnt[4 * t + 3] = g;
                 });
-                for (unsigned t = 0; t < parts; t++) { n_tiny += cnt[3 * t]; n_mid += cnt[3 * t + 1]; n_mid64 += cnt[3 * t + 2]; }
+                for (unsigned t = 0; t < parts; t++) { n_tiny += cnt[4 * t]; n_mid += cnt[4 * t + 1]; n_mid64 += cnt[4 * t + 2]; n_grp += cnt[4 * t + 3]; }
             }
             use_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
             use_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
             use_lane_tiny = lane_wanted(lpol, n_tiny, LANE_MIN_TINY);
+            use_grp = n_grp && n_grp >= gpol.min_lists;
         }
         // classification prepass (one workgroup per list): max id -> precision, sortedness, domain
         const uint32_t *maxid = nullptr, *pflags = nullptr;
@@ -497,7 +517,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         {
             // per-thread work lists (contiguous list ranges), concatenated in range order: the same lists in the
             // same order as a single pass
-            enum { W_TINY = 0, W_U18, W_U20, W_C1, W_C2, W_C3, W_L4, W_L16, W_L64, W_COUNT };
+            enum { W_TINY = 0, W_U18, W_U20, W_C1, W_C2, W_C3, W_L4, W_L16, W_L64, W_G2, W_G3, W_COUNT };
             const unsigned parts = par_parts(nlist);
             std::vector<std::vector<uint32_t>> part_wl((size_t)parts * W_COUNT);
             std::vector<int64_t> bad_list(parts, -1);
@@ -517,8 +537,13 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                     const bool lane_ok = !(pflags[l] & VIDC_PF_UNSORTED) &&
                                          ((use_lane && n <= VIDC_LANE_MAX) ||
                                           (use_lane64 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64));
-                    const int cls = (u_ok && width <= 18) ? W_U18
+                    // (the row-per-list kernel samples positions: ascending input; it checks that itself under the light prepass)
+                    const bool grp_ok = use_grp && n >= gpol.min_n && n <= gpol.max_n && !(pflags[l] & VIDC_PF_UNSORTED);
+                    const bool grp_first = grp_ok && gpol.min_lists == 0;  // VIDC_FORCE_GRP: ahead of every other family
+                    const int cls = grp_first ? (n <= VIDC_GRP_LEV2_MAX ? W_G2 : W_G3)
+                                    : (u_ok && width <= 18) ? W_U18
                                     : (u_ok && width <= 20) ? W_U20
+                                    : grp_ok ? (n <= VIDC_GRP_LEV2_MAX ? W_G2 : W_G3)
                                     : (lane_ok && n <= 256) ? W_L4
                                     : (lane_ok && n <= VIDC_LANE_MAX) ? W_L16
                                     : lane_ok ? W_L64
@@ -533,7 +558,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                               "custom_invlists_impl.cpp:163)", (unsigned long long)bad_list[t]);
                     return VIDC_ERR_DOMAIN;
                 }
-            std::vector<uint32_t> *dst[W_COUNT] = {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64};
+            std::vector<uint32_t> *dst[W_COUNT] = {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64, &wl_g2, &wl_g3};
             for (int c = 0; c < W_COUNT; c++) {
                 size_t tot = 0;
                 for (unsigned t = 0; t < parts; t++) tot += part_wl[(size_t)t * W_COUNT + c].size();
@@ -547,10 +572,10 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         ntiny = wl_tiny.size();
         tr.mark("classify");
         {
-            std::vector<uint32_t> *ws[8] = {&wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64};
+            std::vector<uint32_t> *ws[10] = {&wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64, &wl_g2, &wl_g3};
             if (par_parts(nlist) > 1) {  // one thread per class (independent vectors, read-only offsets)
                 std::vector<std::thread> th;
-                for (int c = 1; c < 8; c++)
+                for (int c = 1; c < 10; c++)
                     if (ws[c]->size() > 1) th.emplace_back([&, c] { sort_desc(*ws[c], r->offsets); });
                 sort_desc(*ws[0], r->offsets);
                 for (auto &x : th) x.join();
@@ -600,13 +625,13 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     const uint32_t *d_wl = nullptr;
     if (!rows) {
         size_t total = 0;
-        for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64, &wl_r2}) {
+        for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64, &wl_r2, &wl_g2, &wl_g3}) {
             base.push_back(total);
             total += w->size();
         }
         VIDC_TRY(h_wl.get(ctx, total * 4));
         size_t k = 0;
-        for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64, &wl_r2}) {
+        for (auto *w : {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64, &wl_r2, &wl_g2, &wl_g3}) {
             if (!w->empty()) std::memcpy(h_wl.as<uint32_t>() + k, w->data(), w->size() * 4);
             k += w->size();
         }
@@ -614,7 +639,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         if (total) VIDC_HIP(hipMemcpyAsync(s_wl.p, h_wl.p, total * 4, hipMemcpyHostToDevice, ctx->stream));
         d_wl = s_wl.as<uint32_t>();
     } else {
-        base.assign(10, 0);
+        base.assign(12, 0);
     }
 
     RocEncArgs a{};
@@ -704,6 +729,48 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         // has the CUs to itself (the lane strips take 141 KiB of a CU's LDS, the general waves the issue slots).
         // With lane classes in the call they go first on aux 1 and the general classes queue behind them; the long
         // chains on the main stream overlap with all of it.
+        // row-per-list kernels: one launch per octave of list length (the LDS of a launch is sized by its longest list)
+        {
+            // Every launch is latency-bound (its duration is its longest list's chain) and light on issue slots, so the octaves
+            // must overlap: they alternate between the first and the third auxiliary stream (the lane classes own the second).
+            // VIDC_GRP_STREAMS="1313": stream digit per segment (0 = main, 1..3 = auxiliary), measurements.
+            const char *gmap = std::getenv("VIDC_GRP_STREAMS");
+            if (!gmap || !*gmap) gmap = "13";
+            const size_t gmap_n = std::strlen(gmap);
+            size_t seg_no = 0;
+            const U2Div *dt = (const U2Div *)ctx->d_u2tab;
+            auto launch_grp = [&](const std::vector<uint32_t> &w, size_t wbase, bool lev3) -> int {
+                size_t k0 = 0;
+                while (k0 < w.size()) {
+                    const uint64_t n0 = r->offsets[w[k0] + 1] - r->offsets[w[k0]];  // longest of the segment
+                    uint64_t lo = 1;                                                 // segment: lengths in (lo, 2 lo]
+                    while (lo * 2 < n0) lo *= 2;
+                    size_t k1 = k0;
+                    while (k1 < w.size() && r->offsets[w[k1] + 1] - r->offsets[w[k1]] > lo) k1++;
+                    const int sd = gmap[seg_no++ % gmap_n] - '0';
+                    hipStream_t st_g = (sd >= 1 && sd <= 3) ? ctx->aux[sd - 1] : ctx->stream;
+                    RocEncArgs b = a;
+                    b.worklist = d_wl + wbase + k0; b.nwork = (uint32_t)(k1 - k0);
+                    const uint32_t nblk = (uint32_t)((n0 + 511) >> 9);
+                    const size_t lds = (size_t)4 * 4 * (lev3 ? roc_grp_enc_lds_words<3>(nblk) : roc_grp_enc_lds_words<2>(nblk));
+                    const dim3 grid((b.nwork + 3u) / 4u);
+                    if (lev3) {
+                        if (lds > 65536) {
+                            VIDC_TRY(set_big_lds((const void *)k_roc_encode_grp<3, true>, lds));
+                            VIDC_TRY(set_big_lds((const void *)k_roc_encode_grp<3, false>, lds));
+                        }
+                        if (want_perm) hipLaunchKernelGGL((k_roc_encode_grp<3, true>), grid, dim3(64), lds, st_g, b, dt, nblk);
+                        else hipLaunchKernelGGL((k_roc_encode_grp<3, false>), grid, dim3(64), lds, st_g, b, dt, nblk);
+                    } else if (want_perm) hipLaunchKernelGGL((k_roc_encode_grp<2, true>), grid, dim3(64), lds, st_g, b, dt, nblk);
+                    else hipLaunchKernelGGL((k_roc_encode_grp<2, false>), grid, dim3(64), lds, st_g, b, dt, nblk);
+                    VIDC_HIP(hipGetLastError());
+                    k0 = k1;
+                }
+                return VIDC_OK;
+            };
+            VIDC_TRY(launch_grp(wl_g3, base[11], true));
+            VIDC_TRY(launch_grp(wl_g2, base[10], false));
+        }
         const bool lanes_present = !wl_l4.empty() || !wl_l16.empty() || !wl_l64.empty();
         // aux 0: mid-size general lists (calls without lane classes) and bitmap-18 lists
         if (!lanes_present) VIDC_TRY(launch_gen_on(ctx->aux[0], d_wl + base[4], (uint32_t)wl_c2.size(), 8));
@@ -898,15 +965,17 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
 // ---- decode planning: work items grouped by kernel class, each with private scratch
 // general decoder classes by LDS footprint of the fine prefix rows (2^fb u32, fb = lg(n) - 3): occupancy, not
 // arithmetic, bounds the general decoder when a batch has many mid-size lists
-enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_B2T, DC_B2S, DC_B2L, DC_B2M, DC_COUNT };
+// (DC_LANE .. the last class: kernels that may hand a list back with VIDC_ST_RETRY)
+enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_B2T, DC_B2S, DC_B2L, DC_B2M,
+                DC_GRP0, DC_GRP2, DC_GRP3, DC_GRP4, DC_COUNT };  // row-per-list decoder by bucket bits 8 + F (roc_grp.h)
 constexpr uint64_t B2_MIN_LIST = 4096;
 constexpr size_t B2_CAP = 1024;      // chains of k_roc_decode_b2 per call (four per CU of an MI355X: 1 MiB of member rows each)
 
 struct DecPlan {
     std::vector<uint32_t> wl;        // list numbers, grouped by class, longest first inside a class
     std::vector<uint32_t> item;      // index of each work item in the caller's request
-    size_t count[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t sum_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_n[DC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t count[DC_COUNT] = {};
+    uint64_t sum_n[DC_COUNT] = {}, max_n[DC_COUNT] = {};
     std::vector<uint64_t> scratch_off, slots_off;
     uint64_t scratch_words = 0, slots_words = 0;
     bool lean = false;               // graph rows, lane decoder: item k == request k, no scratch / offset arrays
@@ -915,12 +984,20 @@ struct DecPlan {
     uint64_t implicit = 0;           // lean plan without a work list: items are rows 0..implicit-1
 };
 
-inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane, bool allow_lane64) {  // (allow_lane*: mid-size policies)
+inline DecClass grp_dec_class(uint64_t n) {
+    const uint32_t f = roc_grp_dec_fbits((uint32_t)n);
+    return f == 0 ? DC_GRP0 : (f == 2 ? DC_GRP2 : (f == 3 ? DC_GRP3 : DC_GRP4));
+}
+inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane, bool allow_lane64,
+                          const GrpPolicy *grp = nullptr) {  // (allow_lane*: mid-size policies; grp: row-per-list kernels wanted)
     if (n <= TINY_MAX) return DC_TINY;
+    const bool grp_ok = grp && n >= grp->min_n && n <= grp->max_n && P <= 32;
+    if (grp_ok && grp->min_lists == 0) return grp_dec_class(n);  // VIDC_FORCE_GRP: ahead of every other family
     if (!f_general && n >= u_min) {
         if (P <= 18) return DC_U18;
         if (P <= 20) return DC_U20;
     }
+    if (grp_ok) return grp_dec_class(n);
     if (allow_lane && n <= VIDC_LANE_MAX) return DC_LANE;
     if (allow_lane64 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64) return DC_LANE64;
     if (n <= GEN_SMALL_MAX) return DC_GSMALL;
@@ -931,9 +1008,12 @@ inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general
 }
 
 // lists[i] = list number of request item i (a list may appear more than once)
+// only_general: the caller decodes into int32 rows (wide graph rows): only the kernels that honour out_rows -- the tiny
+// and the general wave-per-list decoders -- may be planned
 void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool rows_flavour, DecPlan &p,
-                 bool allow_lane = true, bool allow_b2 = true) {
-    const bool f_general = force_general();
+                 bool allow_lane = true, bool allow_b2 = true, bool only_general = false) {
+    const bool f_general = force_general() || only_general;
+    if (only_general) { allow_lane = false; allow_b2 = false; }
     const LanePolicy lpol = (allow_lane && !f_general) ? lane_policy() : LANE_NEVER;
     p.wl.clear(); p.item.clear(); p.scratch_off.clear(); p.slots_off.clear();
     p.scratch_words = 0; p.slots_words = 0;
@@ -951,14 +1031,18 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     std::vector<uint32_t> cls[DC_COUNT];
     const uint64_t u_min = U_MIN_LIST;
     bool allow_lane64 = false;
+    const GrpPolicy gpol = grp_policy();
+    bool use_grp = false;
     {
-        uint64_t n_mid = 0, n_mid64 = 0, n_tiny = 0;
+        uint64_t n_mid = 0, n_mid64 = 0, n_tiny = 0, n_grp = 0;
         for (uint32_t l : lists) {
             const uint64_t n = r->offsets[l + 1] - r->offsets[l];
             n_tiny += n <= TINY_MAX;
             n_mid += n > TINY_MAX && n <= VIDC_LANE_MAX;
             n_mid64 += n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64;
+            n_grp += n >= gpol.min_n && n <= gpol.max_n;
         }
+        use_grp = allow_b2 && !f_general && !rows_flavour && n_grp && n_grp >= gpol.min_lists;
         allow_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
         allow_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
         p.tiny_lane = lane_wanted(lpol, rows_flavour ? lists.size() : n_tiny, LANE_MIN_TINY);
@@ -966,7 +1050,7 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     for (uint32_t i = 0; i < lists.size(); i++) {
         uint32_t l = lists[i];
         uint64_t n = r->offsets[l + 1] - r->offsets[l];
-        cls[rows_flavour ? DC_TINY : dec_class(n, r->prec[l], u_min, f_general, allow_lane, allow_lane64)].push_back(i);
+        cls[rows_flavour ? DC_TINY : dec_class(n, r->prec[l], u_min, f_general, allow_lane, allow_lane64, use_grp ? &gpol : nullptr)].push_back(i);
     }
     auto len = [&](uint32_t i) { return r->offsets[lists[i] + 1] - r->offsets[lists[i]]; };
     for (int c = 0; c < DC_COUNT; c++) {
@@ -1078,7 +1162,7 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             p.scratch_off[k] = so;
             // re-spill scratch of the decoder stack (== roc_dec_stack_cap in the kernels); the lane-per-list decoders
             // keep what they push in LDS
-            if (c != DC_LANE && c != DC_LANE64) so += roc_dec_stack_cap((uint32_t)n, r->meta_host ? r->nwords[l] : 0u);
+            if (c != DC_LANE && c != DC_LANE64 && c < DC_GRP0) so += roc_dec_stack_cap((uint32_t)n, r->meta_host ? r->nwords[l] : 0u);
             p.slots_off[k] = sl;
             if (c == DC_LANE) {
                 sl = (sl + 3) & ~(uint64_t)3;  // rows are read as uint4
@@ -1088,6 +1172,10 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
                 sl = (sl + 3) & ~(uint64_t)3;
                 p.slots_off[k] = sl;
                 sl += 256ull * roc_lane_cap_nb<256>((uint32_t)n);
+            } else if (c >= DC_GRP0) {
+                sl = (sl + 15) & ~(uint64_t)15;  // member rows of 32 .. 96 u32: 64-byte aligned
+                p.slots_off[k] = sl;
+                sl += roc_grp_dec_slots((uint32_t)n);
             } else if (c == DC_U18 || c == DC_U20) sl += n;  // duplicate side list
             else if (c == DC_B2) {
                 sl = (sl + 63) & ~(uint64_t)63;  // 4096 rows of 64 members
@@ -1198,9 +1286,10 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         for (int c = 0; c < DC_COUNT; c++) {
             order[c] = c;
             const bool u = c == DC_U18 || c == DC_U20 || c == DC_B2 || c == DC_B2T || c == DC_B2S || c == DC_B2L || c == DC_B2M, lane = c == DC_LANE || c == DC_LANE64;
+            const bool grpc = c >= DC_GRP0;
             // (constants fitted to the S2 timeline: general kernels ~2.5 G steps/s while they share the machine)
-            const double step_us = u ? 0.4 : (lane ? 2.5 : (c == DC_TINY ? 0.5 : 1.2));       // one chain step
-            const double rate = u ? 0.6e3 : (lane ? 16e3 : (c == DC_TINY ? 30e3 : 2.5e3));     // steps / us, all CUs
+            const double step_us = u ? 0.4 : (lane ? 2.5 : (c == DC_TINY ? 0.5 : (grpc ? 1.5 : 1.2)));       // one chain step
+            const double rate = u ? 0.6e3 : (lane ? 16e3 : (c == DC_TINY ? 30e3 : (grpc ? 12e3 : 2.5e3)));     // steps / us, all CUs
             est[c] = std::max((double)p.max_n[c] * step_us, (double)p.sum_n[c] / rate);
         }
         std::sort(order, order + DC_COUNT, [&](int x, int y) { return est[x] > est[y]; });
@@ -1310,6 +1399,18 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 VIDC_TRY(set_big_lds((const void *)k_roc_decode_b2<256>, VIDC_B2L_LDS_BYTES(256u)));
                 hipLaunchKernelGGL(k_roc_decode_b2<256>, dim3(b.nwork), dim3(64), VIDC_B2L_LDS_BYTES(256u), st_, b, (const U2Div *)ctx->d_u2tab);
                 break;
+            case DC_GRP0:
+                hipLaunchKernelGGL(k_roc_decode_grp<0>, dim3((b.nwork + 3u) / 4u), dim3(64), 16u * roc_grp_dec_lds_words(0), st_, b, (const U2Div *)ctx->d_u2tab);
+                break;
+            case DC_GRP2:
+                hipLaunchKernelGGL(k_roc_decode_grp<2>, dim3((b.nwork + 3u) / 4u), dim3(64), 16u * roc_grp_dec_lds_words(2), st_, b, (const U2Div *)ctx->d_u2tab);
+                break;
+            case DC_GRP3:
+                hipLaunchKernelGGL(k_roc_decode_grp<3>, dim3((b.nwork + 3u) / 4u), dim3(64), 16u * roc_grp_dec_lds_words(3), st_, b, (const U2Div *)ctx->d_u2tab);
+                break;
+            case DC_GRP4:
+                hipLaunchKernelGGL(k_roc_decode_grp<4>, dim3((b.nwork + 3u) / 4u), dim3(64), 16u * roc_grp_dec_lds_words(4), st_, b, (const U2Div *)ctx->d_u2tab);
+                break;
             case DC_G8K:
                 hipLaunchKernelGGL(k_roc_decode_gen<uint16_t>, dim3(b.nwork), dim3(64), 1024 * 2, st_, b, 1024u, VIDC_DEC_CAP);
                 break;
@@ -1367,7 +1468,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
             // wave-per-list kernels, into the same output slots
             std::vector<uint32_t> lists2;
             std::vector<uint64_t> off2;
-            for (size_t k = base[DC_LANE]; k < base[DC_LANE] + p.count[DC_LANE] + p.count[DC_LANE64] + p.count[DC_B2] + p.count[DC_B2T] + p.count[DC_B2S] + p.count[DC_B2L] + p.count[DC_B2M]; k++) {  // lane classes + B2
+            for (size_t k = base[DC_LANE]; k < p.wl.size(); k++) {  // lane classes, B2, row-per-list classes
                 if (status[p.wl[k]] != VIDC_ST_RETRY) continue;
                 lists2.push_back(p.wl[k]);
                 off2.push_back(out_off_host ? out_off_host[k] : r->offsets[p.wl[k]]);
@@ -1511,7 +1612,7 @@ int vidc_roc_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, cons
     VIDC_TRY(upload(ctx, r->d_nwords, r->nwords));
     VIDC_TRY(upload(ctx, r->d_draws, r->draws));
     VIDC_TRY(upload(ctx, r->d_word_off, r->word_off));
-    VIDC_TRY(r->d_words.alloc(r->total_words + 4, ctx->dpool));  // + padding: the lane decoder's look-ahead reads orig[0..1]
+    VIDC_TRY(r->d_words.alloc(r->total_words + 16, ctx->dpool));  // + padding: the look-ahead of the lane / row decoders reads up to 15 words past the last stream
     if (r->total_words)
         VIDC_HIP(hipMemcpyAsync(r->d_words.p, words_concat, r->total_words * 4, hipMemcpyHostToDevice, ctx->stream));
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
@@ -1600,7 +1701,7 @@ int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uin
         VIDC_HIP(hipSetDevice(ctx->device));
         VIDC_HIP(hipMemsetAsync(d_out, 0xff, m * (uint64_t)K * 4, ctx->stream));
         DecPlan p;
-        plan_decode(r, lists, false, p, false);
+        plan_decode(r, lists, false, p, false, false, true);  // only the kernels that write int32 rows
         std::vector<uint64_t> out_off(m);
         for (size_t k = 0; k < m; k++) out_off[k] = (uint64_t)p.item[k] * K;
         return decode_impl(ctx, r, p, out_off.data(), nullptr, d_out, K);

@@ -71,8 +71,12 @@ class ShardedInvLists:
         self.local_offsets = np.concatenate([[0], np.cumsum(loc_sizes)]).astype(np.uint64)
         starts = offsets[:-1].astype(np.int64)[self.my_lists]
         if isinstance(ids, np.ndarray):
-            local_ids = np.ascontiguousarray(ids[_segment_index(starts, loc_sizes, np)]).view(np.uint64) \
-                if loc_sizes.size else np.zeros(0, dtype=np.uint64)
+            if ids.dtype.kind not in "iu":
+                raise TypeError(f"ids must be an integer array, got {ids.dtype}")
+            # 8-byte ids are reinterpreted, narrower ones (int32 / uint32 id arrays) converted: a view of those would
+            # halve the length and encode garbage
+            cut = np.ascontiguousarray(ids[_segment_index(starts, loc_sizes, np)]) if loc_sizes.size else np.zeros(0, dtype=np.uint64)
+            local_ids = cut.view(np.uint64) if cut.dtype.itemsize == 8 else cut.astype(np.uint64)
         else:  # CUDA tensor
             import torch
 
