@@ -25,6 +25,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# ROCm runtime setting, read when HIP initialises (i.e. before torch is imported): the number of hardware queues the
+# process's streams are multiplexed onto (default 4).  A large ROC call runs up to eight kernel classes side by side
+# (vidc_ctx: `wide` when this is >= 8, csrc/common.h); with 4 queues the library falls back to three streams.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 

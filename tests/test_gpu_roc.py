@@ -713,3 +713,27 @@ def test_row_kernels_match_wave_kernels_and_the_automatic_policy(roc, monkeypatc
         assert r.last_decode_nonclean == 0
     for a, b in zip(got["0"], got["1"]):
         assert np.array_equal(a, b)
+
+
+def test_wide_stream_context_takes_the_row_kernels_by_itself(roc, monkeypatch):
+    """A context created with GPU_MAX_HW_QUEUES >= 8 (here: the VIDC_WIDE_STREAMS test hook) runs every kernel class of a call
+    on its own stream and picks the row-per-list kernels for calls with thousands of lists above 4096 ids; same bits as a
+    plain context with the row kernels switched off."""
+    from vector_db_id_compression_amd import _lib
+
+    rng = np.random.default_rng(182)
+    sizes = np.concatenate([rng.integers(4097, 7000, 9000), rng.integers(0, 3000, 2000), [40000, 33000, 65536]])
+    off, ids, _ = _random_lists(rng, sizes, nbits=28)
+    monkeypatch.setenv("VIDC_WIDE_STREAMS", "1")
+    wide = _lib.Context(0)
+    monkeypatch.delenv("VIDC_WIDE_STREAMS")
+    got = {}
+    for mode in ("wide", "plain"):
+        monkeypatch.setenv("VIDC_NO_GRP", "0" if mode == "wide" else "1")
+        r = roc.encode(off, ids, want_perm=True, ctx=wide if mode == "wide" else None)
+        info = r.info()
+        got[mode] = (info["heads"], info["nwords"], r.all_words(), r.perm(), r.decode_all().cpu().numpy().copy())
+        assert r.last_decode_nonclean == 0
+    for a, b in zip(got["wide"], got["plain"]):
+        assert np.array_equal(a, b)
+    wide.close()

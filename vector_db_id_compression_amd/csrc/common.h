@@ -152,6 +152,7 @@ struct PoolBlock {
     bool in_use;
 };
 
+#define VIDC_NAUX 7
 struct vidc_ctx {
     std::shared_ptr<vidc::DevPool> dpool;  // device blocks (scratch + the objects created through this context)
     std::vector<PoolBlock> ppool;          // pinned host blocks
@@ -162,8 +163,13 @@ struct vidc_ctx {
     hipEvent_t ev_chain[2] = {nullptr, nullptr};  // around the launch of the longest-chain kernel class of a ROC call
     hipEvent_t tev[24] = {};   // event pairs of PhaseTimer (kernel phases timed without a host synchronisation each)
     // kernel classes of one call run concurrently: long chains on `stream`, shorter classes on these
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    // (aux[0..2] always; aux[3..] only when the process has the hardware queues for them: HIP multiplexes its streams onto
+    // GPU_MAX_HW_QUEUES (default 4) hardware queues, and two streams that share a queue run one after the other in
+    // submission order -- `wide` is set at context creation when that variable is at least 8)
+    hipStream_t aux[VIDC_NAUX] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[VIDC_NAUX] = {};
+    bool wide = false;
+    int naux() const { return wide ? VIDC_NAUX : 3; }
     uint32_t *d_mt = nullptr;  // VIDC_MT_TABLE words
     void *d_u2tab = nullptr;   // per-divisor constants of the hand-scheduled chain kernels (roc_u2.h), VIDC_ROC_MAX_LIST + 1 entries
     void *d_ltab = nullptr;    // divisor table of the lane-per-list kernels (roc_lane.h), VIDC_LANE_TAB + 1 entries

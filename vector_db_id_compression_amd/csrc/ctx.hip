@@ -1,6 +1,7 @@
 // ctx.hip -- context, error channel and raw device-memory helpers of libvidc.
 #include <random>
 
+#include <cstdlib>
 #include "common.h"
 
 namespace vidc {
@@ -144,17 +145,15 @@ int vidc_ctx_create(int device, vidc_ctx **out) {
     c->dpool->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    if (const char *e = std::getenv("GPU_MAX_HW_QUEUES")) c->wide = std::atoi(e) >= 8;
+    if (const char *e = std::getenv("VIDC_WIDE_STREAMS")) c->wide = e[0] == '1';  // test hook
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->aux[0], hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->aux[1], hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->aux[2], hipStreamNonBlocking) != hipSuccess ||
+        [&] { for (auto &st : c->aux) if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return true; return false; }() ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->ev_chain[0]) != hipSuccess || hipEventCreate(&c->ev_chain[1]) != hipSuccess ||
         [&] { for (auto &ev : c->tev) if (hipEventCreate(&ev) != hipSuccess) return true; return false; }() ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join[1], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join[2], hipEventDisableTiming) != hipSuccess ||
+        [&] { for (auto &ev : c->ev_join) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return true; return false; }() ||
         hipMalloc((void **)&c->d_mt, VIDC_MT_TABLE * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(&c->d_ltab, (VIDC_LANE_TAB + 1) * 16) != hipSuccess) {
         vidc::set_error("context resource creation failed");
@@ -210,7 +209,7 @@ void vidc_ctx_destroy(vidc_ctx *c) {
     for (auto &ev : c->ev_chain) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->tev) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < VIDC_NAUX; i++) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
     }

@@ -107,12 +107,20 @@ inline bool env_on(const char *name) {  // set, not empty, not "0"
 constexpr uint64_t GRP_MIN_LISTS = 8192;
 struct GrpPolicy { uint64_t min_lists, min_n, max_n; };
 inline GrpPolicy grp_policy() {
-    GrpPolicy g{GRP_MIN_LISTS, VIDC_LANE_MAX64 + 1u, VIDC_GRP_MAX_LIST};
+    // (lists beyond 32 768 ids are chains of >= 40 ms at this family's 1.2 us per step: they keep the lower-latency
+    // wave-per-list kernels unless VIDC_GRP_MAXN / VIDC_FORCE_GRP say otherwise)
+    GrpPolicy g{GRP_MIN_LISTS, VIDC_LANE_MAX64 + 1u, 32768u};
     if (env_on("VIDC_NO_GRP") || env_on("VIDC_FORCE_GENERAL") || env_on("VIDC_OLD_U")) { g.min_lists = ~0ull; return g; }
-    if (env_on("VIDC_FORCE_GRP")) { g.min_lists = 0; g.min_n = VIDC_GRP_MIN_LIST; }
+    if (env_on("VIDC_FORCE_GRP")) { g.min_lists = 0; g.min_n = VIDC_GRP_MIN_LIST; g.max_n = VIDC_GRP_MAX_LIST; }
     if (const char *e = std::getenv("VIDC_GRP_MIN")) g.min_lists = (uint64_t)std::atoll(e);
     if (const char *e = std::getenv("VIDC_GRP_MAXN")) g.max_n = std::min<uint64_t>((uint64_t)std::atoll(e), VIDC_GRP_MAX_LIST);
     return g;
+}
+
+// wavefronts of a bucket-row lane decoder launch (VIDC_LANE_GRID=<n>: at most n, the rest of the groups by grid stride)
+inline uint32_t lane_grid(uint32_t groups) {
+    static const uint32_t cap = [] { const char *e = std::getenv("VIDC_LANE_GRID"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    return cap && groups > cap ? cap : groups;
 }
 
 // test hook: VIDC_OLD_U=1 keeps the round-1 bitmap kernels (roc_u.h) instead of the hand-scheduled ones (roc_u2.h)
@@ -468,7 +476,8 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             use_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
             use_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
             use_lane_tiny = lane_wanted(lpol, n_tiny, LANE_MIN_TINY);
-            use_grp = n_grp && n_grp >= gpol.min_lists;
+            // (the octaves of a call must overlap: without spare hardware queues they would run one after the other)
+            use_grp = n_grp && n_grp >= gpol.min_lists && (ctx->wide || gpol.min_lists == 0 || std::getenv("VIDC_GRP_MIN"));
         }
         // classification prepass (one workgroup per list): max id -> precision, sortedness, domain
         const uint32_t *maxid = nullptr, *pflags = nullptr;
@@ -601,18 +610,24 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                         if (2 * (r->offsets[l + 1] - r->offsets[l]) < n_top || n_long > cap) break;
                         n_long++;
                     }
+                auto take = [&](std::vector<uint32_t> &w) {
+                    size_t k = 0;
+                    while (k < w.size() && wl_r2.size() < cap && r->offsets[w[k] + 1] - r->offsets[w[k]] > R2_MIN_LIST) {
+                        wl_r2.push_back(w[k]);
+                        k++;
+                    }
+                    w.erase(w.begin(), w.begin() + (ptrdiff_t)k);
+                };
                 if (n_long <= cap) {
-                    auto take = [&](std::vector<uint32_t> &w) {
-                        size_t k = 0;
-                        while (k < w.size() && wl_r2.size() < cap && r->offsets[w[k] + 1] - r->offsets[w[k]] > R2_MIN_LIST) {
-                            wl_r2.push_back(w[k]);
-                            k++;
-                        }
-                        w.erase(w.begin(), w.begin() + (ptrdiff_t)k);
-                    };
                     take(wl_c3);
                     if (wl_c3.empty()) take(wl_c2);
                     if (wl_c3.empty() && wl_c2.empty()) take(wl_c1);
+                } else if (n_top <= 65536 && !wl_c3.empty() && !env_on("VIDC_NO_R2_TOP")) {
+                    // More long chains than that (S2: 1754 lists of 32 769..65 536 ids): the `cap` longest ones -- one per SIMD --
+                    // still decide the call (65 536 steps at 0.9 us on the general kernel under load against ~0.7 here) and, with
+                    // the bitmap sized for 65 536 positions (8 KiB instead of 32), no longer take the LDS the other classes need;
+                    // the rest of the class (<= ~45 000 ids on S2) finishes earlier on the general kernel anyway.
+                    take(wl_c3);
                 }
             }
         }
@@ -672,7 +687,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     {
         EventTimer t(ctx);
         VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-        for (int i = 0; i < 3; i++) VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
+        for (int i = 0; i < ctx->naux(); i++) VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
         // main stream: bitmap-20 lists and the deepest general class (the critical paths)
         ctx->chain_info[0][0] = ctx->chain_info[0][1] = ctx->chain_info[0][2] = ctx->chain_info[0][3] = 0;
         ctx->phase_ms[VIDC_PHASE_ROC_ENCODE_CHAIN] = 0;
@@ -709,8 +724,12 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             // (behind a 20-bit bitmap launch on the main stream these chains would only start when that one has finished:
             // S1 encode 12.5 -> 13.5 ms; they go to the first auxiliary stream then)
             hipStream_t st_r2 = wl_u20.empty() ? ctx->stream : ctx->aux[0];
-            if (want_perm) hipLaunchKernelGGL((k_roc_encode_r2<true>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, st_r2, b, dt);
-            else hipLaunchKernelGGL((k_roc_encode_r2<false>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, st_r2, b, dt);
+            // (the bitmap of a launch whose longest list -- the first of the work list -- has at most 65 536 positions: 8 KiB)
+            const bool small = r->offsets[wl_r2[0] + 1] - r->offsets[wl_r2[0]] <= 65536 && !env_on("VIDC_R2_BIG");
+            if (small && want_perm) hipLaunchKernelGGL((k_roc_encode_r2<true, 10>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(10), st_r2, b, dt);
+            else if (small) hipLaunchKernelGGL((k_roc_encode_r2<false, 10>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(10), st_r2, b, dt);
+            else if (want_perm) hipLaunchKernelGGL((k_roc_encode_r2<true, 12>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(12), st_r2, b, dt);
+            else hipLaunchKernelGGL((k_roc_encode_r2<false, 12>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(12), st_r2, b, dt);
             VIDC_HIP(hipGetLastError());
         }
         // the deepest class: prefix rows sized for its longest list (first of the work list).  With the fixed
@@ -722,7 +741,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 rl3 = 16;
                 while ((uint64_t)64 * 64 * rl3 < nmax3) rl3 <<= 1;
             }
-            VIDC_TRY(launch_gen_on(ctx->stream, d_wl + base[5], (uint32_t)wl_c3.size(), rl3));
+            // (behind a chain launch on the main stream it would only start when that one has finished)
+            hipStream_t st_c3 = (!wl_r2.empty() && wl_u20.empty()) ? ctx->aux[0] : ctx->stream;
+            VIDC_TRY(launch_gen_on(st_c3, d_wl + base[5], (uint32_t)wl_c3.size(), rl3));
         }
         // The lane-per-list kernels and the throughput-bound general classes must not share the machine: on S2 the
         // 64-word lane class took 69 ms next to the 26 316-list general class (49 ms) -- 9 ms and ~35 ms when each
@@ -735,7 +756,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             // must overlap: they alternate between the first and the third auxiliary stream (the lane classes own the second).
             // VIDC_GRP_STREAMS="1313": stream digit per segment (0 = main, 1..3 = auxiliary), measurements.
             const char *gmap = std::getenv("VIDC_GRP_STREAMS");
-            if (!gmap || !*gmap) gmap = "13";
+            if (!gmap || !*gmap) gmap = ctx->wide ? "4567" : "13";
             const size_t gmap_n = std::strlen(gmap);
             size_t seg_no = 0;
             const U2Div *dt = (const U2Div *)ctx->d_u2tab;
@@ -748,7 +769,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                     size_t k1 = k0;
                     while (k1 < w.size() && r->offsets[w[k1] + 1] - r->offsets[w[k1]] > lo) k1++;
                     const int sd = gmap[seg_no++ % gmap_n] - '0';
-                    hipStream_t st_g = (sd >= 1 && sd <= 3) ? ctx->aux[sd - 1] : ctx->stream;
+                    hipStream_t st_g = (sd >= 1 && sd <= ctx->naux()) ? ctx->aux[sd - 1] : ctx->stream;
                     RocEncArgs b = a;
                     b.worklist = d_wl + wbase + k0; b.nwork = (uint32_t)(k1 - k0);
                     const uint32_t nblk = (uint32_t)((n0 + 511) >> 9);
@@ -838,7 +859,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             else hipLaunchKernelGGL(k_roc_encode_tiny<false>, dim3(b.nwork), dim3(64), 0, ctx->aux[2], b);
             VIDC_HIP(hipGetLastError());
         }
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < ctx->naux(); i++) {
             VIDC_HIP(hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
             VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
         }
@@ -998,6 +1019,8 @@ inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general
         if (P <= 20) return DC_U20;
     }
     if (grp_ok) return grp_dec_class(n);
+    static const bool nb256 = env_on("VIDC_LANE_NB256");  // measurements: 256 buckets for the 257..1024-id lists too
+    if (allow_lane && nb256 && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_MAX) return DC_LANE64;
     if (allow_lane && n <= VIDC_LANE_MAX) return DC_LANE;
     if (allow_lane64 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64) return DC_LANE64;
     if (n <= GEN_SMALL_MAX) return DC_GSMALL;
@@ -1085,8 +1108,11 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             b2_cap = (size_t)std::atoll(e);
             n_long = 0;
         }
-        if (n_top && n_long <= b2_cap)
+        // (more long chains than the cap: its `cap` longest ones -- the chains that decide the call -- take it alone, cf. the encoder)
+        const bool top_only = n_top && n_long > b2_cap && !env_on("VIDC_NO_R2_TOP");
+        if (n_top && (n_long <= b2_cap || top_only))
             for (int c : order_) {  // longest first; a list that does not qualify stays where it is
+                if (top_only && c != DC_GHUGE) break;
                 std::vector<uint32_t> keep;
                 for (uint32_t i : cls[c]) {
                     const uint32_t P = r->prec[lists[i]];
@@ -1274,7 +1300,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     EventTimer t(ctx);
     // classes run concurrently: the longest chains on the caller's stream, the rest on the auxiliary streams
     VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-    for (int i = 0; i < 3; i++) VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
+    for (int i = 0; i < ctx->naux(); i++) VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
     // Stream assignment: a class's kernel lasts about max(its longest chain, its share of the machine); classes are
     // taken longest first and each goes to the stream that frees up first (LPT over 3 streams).  A fixed
     // assignment left three general classes back to back on one stream on S2 (70 + 45 + 18 ms) while the
@@ -1295,11 +1321,16 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         std::sort(order, order + DC_COUNT, [&](int x, int y) { return est[x] > est[y]; });
         // three streams: a 4th one did not run concurrently (HIP maps streams onto 4 hardware queues and the
         // process has other streams; the kernels of aux[2] started when the main stream's had finished)
-        double load[3] = {0, 0, 0};
+        double load[VIDC_NAUX + 1] = {};
+        // (wide: four streams -- S2 decodes in 84 / 85 / 89 / 104 ms with 4 / 5 / 8 / 3 of them: the classes share one
+        // bound, the random-access rate of HBM, so more overlap buys nothing once the machine is full)
+        int nq = ctx->wide ? 4 : 3;
+        if (const char *e = std::getenv("VIDC_DEC_NQ")) nq = std::max(1, std::min(ctx->naux() + 1, std::atoi(e)));
         for (int k = 0; k < DC_COUNT; k++) {
             const int c = order[k];
+            if (!p.count[c]) continue;
             int best = 0;
-            for (int q = 1; q < 3; q++)
+            for (int q = 1; q < nq; q++)
                 if (load[q] < load[best]) best = q;
             stream_of[c] = best == 0 ? ctx->stream : ctx->aux[best - 1];
             load[best] += est[c] + 1.0;
@@ -1371,7 +1402,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 if (b2.out_off) b2.out_off += n_big;
                 b.nwork = n_big;
                 if (b.nwork)
-                    hipLaunchKernelGGL(k_roc_decode_lane<64>, dim3((b.nwork + b.lpw - 1u) / b.lpw), dim3(64), 0, st_, b,
+                    hipLaunchKernelGGL(k_roc_decode_lane<64>, dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
                                        (const LaneDiv *)ctx->d_ltab);
                 if (b2.nwork)
                     hipLaunchKernelGGL(k_roc_decode_lane_reg<VIDC_LANE_REG_EL>, dim3((b2.nwork + b2.lpw - 1u) / b2.lpw), dim3(64), 0, st_,
@@ -1380,7 +1411,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
             }
             case DC_LANE64:  // 26.5 KiB of LDS per wavefront
                 b.lpw = lane_lists_per_wave(ctx, b.nwork, 7);
-                hipLaunchKernelGGL(k_roc_decode_lane<256>, dim3((b.nwork + b.lpw - 1u) / b.lpw), dim3(64), 0, st_, b,
+                hipLaunchKernelGGL(k_roc_decode_lane<256>, dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
             case DC_B2:
@@ -1434,7 +1465,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         return VIDC_OK;
     };
     for (int k = 0; k < DC_COUNT; k++) VIDC_TRY(launch(order[k]));  // longest first
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < ctx->naux(); i++) {
         VIDC_HIP(hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
         VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
     }

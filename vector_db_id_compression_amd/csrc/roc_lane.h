@@ -443,7 +443,10 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
     uint32_t *oring = (uint32_t *)(smem + G::CNT_BYTES + G::GRP_BYTES + G::SUP_BYTES);
     const uint32_t lane = lane_id();
     const uint32_t lpw = a.lpw ? a.lpw : 64u;
-    const uint32_t wi = blockIdx.x * lpw + lane;
+    // (the host may launch fewer wavefronts than the work list has groups of lpw lists: a wavefront then takes every
+    // gridDim.x-th group -- fewer lists in flight keep their bucket rows in the caches)
+    for (uint32_t blk = blockIdx.x; blk * lpw < a.nwork; blk += gridDim.x) {
+    const uint32_t wi = blk * lpw + lane;
     const bool have = lane < lpw && wi < a.nwork;
     const uint32_t l = have ? a.worklist[wi] : 0u;
     const uint32_t n = have ? (uint32_t)(a.offsets[l + 1] - a.offsets[l]) : 0u;
@@ -548,6 +551,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
         a.end_state[l] = (clean || retry) ? 0u : 1u;
         a.status[l] = retry ? VIDC_ST_RETRY : ((st.err & 2u) ? VIDC_ST_MT : VIDC_ST_OK);
     }
+    }  // next group of lists
 }
 
 // ---------------------------------------------------------------------------------------------------------------

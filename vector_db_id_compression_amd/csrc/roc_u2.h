@@ -242,7 +242,8 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "v_lshlrev_b32_e64 v28, 3, s45\n" \
     "ds_read_b64 v[30:31], v28\n"
 
-#define U2_ENC_SLICE1(XSH) \
+#define U2_ENC_SLICE1(XSH) U2_ENC_SLICE1_X(XSH, "0xfff")
+#define U2_ENC_SLICE1_X(XSH, XORC)                     /* XORC: entries of the bitmap - 1 (reversed entry order) */ \
     "s_and_b32 s62, s60, 63\n"                         /* slice 1 */ \
     "s_cmp_ge_u32 s55, s74\n" \
     "s_cselect_b32 s41, 0, s75\n" \
@@ -250,7 +251,7 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "s_cselect_b32 s57, 0, s55\n" \
     "s_addc_u32 s60, s60, 0\n" \
     "s_lshl_b64 s[58:59], s[56:57], s77\n"             /* B */ \
-    "s_xor_b32 s46, s45, 0xfff\n" \
+    "s_xor_b32 s46, s45, " XORC "\n" \
     "s_lshl_b32 s46, s46, " XSH "\n"                   /* id bits of the entry */ \
     "v_readlane_b32 s63, v13, s44\n" \
     "v_subrev_u32 v59, s44, v2\n"                      /* lane - L2 */ \
@@ -681,9 +682,9 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
     TAIL
 
 // one generic encode step in position space (rare path): codec.cpp:131-137; returns the position
+template <uint32_t NE>
 __device__ __forceinline__ uint32_t u2r_slow_step(uint64_t &head, WStack &st, uint32_t nmax, uint32_t &E1, v32u &ra, v32u &rb,
                                                   uint64_t *bm, const uint64_t *ids, uint32_t p0, uint32_t p1, uint32_t &idv) {
-    using U = U2Geom<18>;
     const uint32_t lane = lane_id();
     ws_prepare(st);
     const uint32_t lq = 0x80000000u / nmax;
@@ -696,7 +697,7 @@ __device__ __forceinline__ uint32_t u2r_slow_step(uint64_t &head, WStack &st, ui
     const uint32_t e = L1 * 64u + L2;
     const uint64_t W = rfl64(bm[e]);
     const uint32_t b = ff1(ballot(mbcnt(W) == k) & W);
-    const uint32_t x = ((e ^ (U::NE - 1u)) << U::ESH) | b;
+    const uint32_t x = ((e ^ (NE - 1u)) << 6) | b;
     E1 -= lane < L1 ? 1u : 0u;
     row -= lane < L2 ? 1u : 0u;
     u2_row_set(ra, rb, L1, row);
@@ -707,9 +708,13 @@ __device__ __forceinline__ uint32_t u2r_slow_step(uint64_t &head, WStack &st, ui
     return x;
 }
 
-template <bool WANT_ORDER>
+// NEB: log2 of the bitmap's 64-position entries -- 12: 262 144 positions, 32 KiB of LDS; 10: 65 536 positions, 8 KiB (lists up
+// to 65 536 ids: sixteen blocks of 4096 positions in lanes 0..15 of the level-1 counters, rows 0..15)
+#define VIDC_R2_LDS_BYTES(NEB) ((8u << (NEB)) + 16u)
+template <bool WANT_ORDER, int NEB = 12>
 __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div *__restrict__ dtab) {
-    using U = U2Geom<18>;
+    static_assert(NEB == 12 || NEB == 10, "bitmap entries");
+    constexpr uint32_t NE = 1u << NEB, NBLK = NE / 64u;
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *bm = (uint64_t *)smem;
     const uint32_t lane = lane_id();
@@ -747,7 +752,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     const uint32_t P = precision_for(maxid, a.precision_mode);
     // not ascending, or ids that do not fit the precision (explicit precision / the reference's power-of-two quirk): the
     // general kernel's second pass
-    if (ballot(unsorted) || n > (1u << 18) || P > 31u || (P < 32u && (maxid >> P) != 0u)) {
+    if (ballot(unsorted) || n > NE * 64u || P > 31u || (P < 32u && (maxid >> P) != 0u)) {
         if (lane == 0) a.status[l] = VIDC_ST_PENDING_SORT;
         return;
     }
@@ -757,21 +762,25 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     for (uint32_t e = lane; e < ((n + 63u) >> 6); e += 64u) {
         const uint32_t lo = e << 6;
         const uint32_t c = n - lo >= 64u ? 64u : n - lo;
-        bm[e ^ (U::NE - 1u)] = c == 64u ? ~0ull : ((1ull << c) - 1ull);
+        bm[e ^ (NE - 1u)] = c == 64u ? ~0ull : ((1ull << c) - 1ull);
     }
-    if (lane == 0) { bm[U::NE] = 0; bm[U::NE + 1] = 0; }
+    if (lane == 0) { bm[NE] = 0; bm[NE + 1] = 0; }
     wave_sync();
     // lane L of E1 <-> block L: ids in blocks with a larger index (= smaller positions): 4096 positions per block
-    uint32_t E1 = 4096u * (63u - lane);
+    // (lanes from NBLK on own no block: their count 0 is never the FIRST one <= k)
+    uint32_t E1 = lane < NBLK ? 4096u * (NBLK - 1u - lane) : 0u;
     E1 = E1 < n ? E1 : n;
     v32u ra, rb;
 #pragma unroll
     for (int L1 = 0; L1 < 64; L1++) {
         // row L1, lane L2: alive positions of block L1 in entries with a larger lane index = the first 64 (63 - L2) positions
-        // of the block, which starts at position 4096 (63 - L1)
-        const uint32_t b0 = 4096u * (63u - (uint32_t)L1);
-        const uint32_t in_block = n > b0 ? n - b0 : 0u, want = 64u * (63u - lane);
-        const uint32_t v = in_block < want ? in_block : want;
+        // of the block, which starts at position 4096 (NBLK - 1 - L1)
+        uint32_t v = 0;
+        if ((uint32_t)L1 < NBLK) {
+            const uint32_t b0 = 4096u * (NBLK - 1u - (uint32_t)L1);
+            const uint32_t in_block = n > b0 ? n - b0 : 0u, want = 64u * (63u - lane);
+            v = in_block < want ? in_block : want;
+        }
         if (L1 < 32) ra[L1] = v; else rb[L1 - 32] = v;
     }
 
@@ -792,7 +801,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
         if (st.sp - st.lo >= 62u) ws_spill32(st);
         if (nmax < 3u || u2_needs_generic(head)) {
             uint32_t idv;
-            const uint32_t x = u2r_slow_step(head, st, nmax, E1, ra, rb, bm, ids, p0, p1, idv);
+            const uint32_t x = u2r_slow_step<NE>(head, st, nmax, E1, ra, rb, bm, ids, p0, p1, idv);
             if (WANT_ORDER) {
                 if (lane == 0) order[obase] = x;
                 obase++;
@@ -800,7 +809,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
             nmax--;
             continue;
         }
-        uint32_t s_x = 0, s_id = 0, s_mul = 0, s_t = 0, s_waddr = U::BITMAP_BYTES, s_D0 = rfl(nmax), s_left = rfl(nmax - 2u);
+        uint32_t s_x = 0, s_id = 0, s_mul = 0, s_t = 0, s_waddr = NE * 8u, s_D0 = rfl(nmax), s_left = rfl(nmax - 2u);
         uint64_t s_w = 0, s_B = rfl64(head);
         uint64_t z0 = 0, z1 = 0, z2 = 0;  // {value, 0} register pairs: the odd halves stay 0
         uint64_t qh = 0;
@@ -826,10 +835,13 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
               "s62", "s63", "s64", "s68", "s70", "s71", "s72", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s96",       \
               "s97", "s98", "s99")
         // (two steps per loop iteration, as in k_roc_encode_u2)
-        if (WANT_ORDER) U2R_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP_R U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_R_T(U2_ENC_ORDER, "", "s_cbranch_scc0 7f\n")
-                                    U2_ENC_TOP_R_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_R(U2_ENC_ORDER, "") "7:\n" U2_ENC_OUTER(U2_ORDER_FLUSH));
-        else U2R_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP_R U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_R_T("", "s_lshr_b32 s68, s58, 31\n", "s_cbranch_scc0 7f\n")
-                         U2_ENC_TOP_R_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_R("", "s_lshr_b32 s68, s58, 31\n") "7:\n" U2_ENC_OUTER(""));
+#define U2R_BODY(XORC)                                                                                                                      \
+        if (WANT_ORDER) U2R_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP_R U2_ENC_MID_G1 U2_ENC_SLICE1_X("6", XORC) U2_ENC_L3_G1 U2_ENC_BOT_R_T(U2_ENC_ORDER, "", "s_cbranch_scc0 7f\n") \
+                                    U2_ENC_TOP_R_NL U2_ENC_MID_G1 U2_ENC_SLICE1_X("6", XORC) U2_ENC_L3_G1 U2_ENC_BOT_R(U2_ENC_ORDER, "") "7:\n" U2_ENC_OUTER(U2_ORDER_FLUSH)); \
+        else U2R_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP_R U2_ENC_MID_G1 U2_ENC_SLICE1_X("6", XORC) U2_ENC_L3_G1 U2_ENC_BOT_R_T("", "s_lshr_b32 s68, s58, 31\n", "s_cbranch_scc0 7f\n") \
+                         U2_ENC_TOP_R_NL U2_ENC_MID_G1 U2_ENC_SLICE1_X("6", XORC) U2_ENC_L3_G1 U2_ENC_BOT_R("", "s_lshr_b32 s68, s58, 31\n") "7:\n" U2_ENC_OUTER(""))
+        if (NEB == 12) { U2R_BODY("0xfff"); } else { U2R_BODY("0x3ff"); }
+#undef U2R_BODY
 #undef U2R_ENC_ASM
         // clang-format on
         // ---- back to the plain state.  head = B + c(id); the position's bit leaves the bitmap
