@@ -14,7 +14,13 @@
  *   CompactBitNSGGraph / EliasFanoNSGGraph / ROCNSGGraph          vidc_faiss::CompactBitNSGGraph / EliasFanoNSGGraph / ROCNSGGraph
  *   (altid_impl.cpp:20-165)
  *   search_IVF_defer_id_decoding          (.cpp:407-526)          vidc_faiss::search_IVF_defer_id_decoding: the OpenMP loop
- *                                                                 over touched lists (:508-525) is ONE vidc_*_decode_lists call
+ *                                                                 over touched lists (:508-525) is ONE vidc_*_decode_lists call,
+ *                                                                 the OpenMP loop of decode_1by1 (:464-474) ONE vidc_*_get call
+ *
+ * With VIDC_FAISS_REFERENCE_NAMES defined before the include, the reference's own class names are exported at global scope
+ * (CompressedIDInvertedListsFenwickTree, ...EliasFano, ...PackedBits, ...WaveletTree, CompactBitNSGGraph, EliasFanoNSGGraph,
+ * ROCNSGGraph, search_IVF_defer_id_decoding): the SWIG modules then carry the names bench_invlists.py:19-25 and
+ * graph_dynamic_bench_invlists.py:21-26 look up, and the harnesses run unchanged.
  *
  * Needs the Faiss headers, include/vidc.h and -lvidc.  Faiss is not installed in this repository's build image: the
  * header is compiled and exercised there against the interface shim of tests/faiss_shim (tests/test_boundary.py,
@@ -26,12 +32,18 @@
  * no allocation, no lock on the per-call path.  Compressed objects are immutable and shared.
  */
 #pragma once
+#if defined(__has_include)
+#if !__has_include(<faiss/invlists/InvertedLists.h>)
+#error "vidc_faiss_adapter.h needs the Faiss headers (or tests/faiss_shim) on the include path"
+#endif
+#endif
 #include <faiss/IndexIVF.h>
 #include <faiss/impl/FaissAssert.h>
 #include <faiss/impl/NSG.h>
 #include <faiss/invlists/DirectMap.h>
 #include <faiss/invlists/InvertedLists.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -49,6 +61,7 @@ struct ThreadCtx {
     vidc_ctx* h = nullptr;
     void* d_buf = nullptr;
     size_t cap = 0;
+    size_t device_calls = 0; /* library calls that launch kernels, made through this thread's context (tests, tuning) */
     vidc_ctx* ctx() {
         if (!h) VIDC_FAISS_CHECK(vidc_ctx_create(-1, &h));
         return h;
@@ -136,11 +149,7 @@ struct CompressedInvertedLists : faiss::ReadOnlyInvertedLists {
     /* the reference adds the size of ALL code arrays once per non-empty list (custom_invlists_impl.cpp:203-205) */
     void reference_codes_accounting() {
         size_t total = 0, nonempty = 0;
-        for (auto& c : codes_all) {
-            total += c.size();
-            nonempty += !c.empty() || code_size == 0;
-        }
-        nonempty = 0;
+        for (auto& c : codes_all) total += c.size();
         for (size_t l = 0; l < nlist; l++) nonempty += offsets[l + 1] > offsets[l];
         codes_size_in_bytes = nonempty * total;
     }
@@ -161,6 +170,7 @@ struct CompressedInvertedLists : faiss::ReadOnlyInvertedLists {
         ThreadCtx& t = thread_ctx();
         uint64_t off[2], ln = l;
         uint64_t* d = (uint64_t*)t.staging(n * 8);
+        t.device_calls++;
         VIDC_FAISS_CHECK(decode_lists_device(t.ctx(), 1, &ln, d, off));
         VIDC_FAISS_CHECK(vidc_copy_d2h(t.ctx(), out.get(), d, n * 8));
         return out.release();
@@ -175,8 +185,23 @@ struct CompressedInvertedLists : faiss::ReadOnlyInvertedLists {
         if (!total) return;
         ThreadCtx& t = thread_ctx();
         uint64_t* d = (uint64_t*)t.staging(total * 8);
+        t.device_calls++;
         VIDC_FAISS_CHECK(decode_lists_device(t.ctx(), m, list_nos, d, out_off.data()));
         VIDC_FAISS_CHECK(vidc_copy_d2h(t.ctx(), ids.data(), d, total * 8));
+    }
+    /* m random accesses ids_out[i] = get_single_id(list_nos[i], offs[i]) in ONE library call (the OpenMP loop of
+     * decode_1by1, custom_invlists_impl.cpp:464-474).  Containers with a select (Elias-Fano, packed bits, wavelet tree)
+     * override it with their vidc_*_get; the default -- ROC, whose get_single_id IS get_ids()[offset] in the reference
+     * (faiss::InvertedLists::get_single_id) -- decodes the touched lists once and indexes them. */
+    virtual void get_single_ids(uint64_t m, const uint64_t* list_nos, const uint64_t* offs, faiss::idx_t* ids_out) const {
+        std::unordered_map<uint64_t, size_t> slot;
+        std::vector<uint64_t> lists;
+        for (uint64_t i = 0; i < m; i++)
+            if (slot.emplace(list_nos[i], lists.size()).second) lists.push_back(list_nos[i]);
+        std::vector<faiss::idx_t> ids;
+        std::vector<uint64_t> out_off;
+        decode_lists_host(lists.size(), lists.data(), ids, out_off);
+        for (uint64_t i = 0; i < m; i++) ids_out[i] = ids[out_off[slot[list_nos[i]]] + offs[i]];
     }
 };
 
@@ -231,8 +256,12 @@ struct EliasFanoInvertedLists : CompressedInvertedLists {
     faiss::idx_t get_single_id(size_t l, size_t offset) const override { /* ef->select(offset), :314-318 */
         uint64_t ln = l, of = offset;
         int64_t id = -1;
-        VIDC_FAISS_CHECK(vidc_ef_get(thread_ctx().ctx(), ef, 1, &ln, &of, &id));
+        get_single_ids(1, &ln, &of, &id);
         return id;
+    }
+    void get_single_ids(uint64_t m, const uint64_t* ln, const uint64_t* of, faiss::idx_t* out) const override {
+        thread_ctx().device_calls++;
+        VIDC_FAISS_CHECK(vidc_ef_get(thread_ctx().ctx(), ef, m, ln, of, (int64_t*)out));
     }
 };
 
@@ -257,8 +286,12 @@ struct PackedBitsInvertedLists : CompressedInvertedLists {
     faiss::idx_t get_single_id(size_t l, size_t offset) const override { /* :108-113 */
         uint64_t ln = l, of = offset;
         int64_t id = -1;
-        VIDC_FAISS_CHECK(vidc_packed_get(thread_ctx().ctx(), pk, 1, &ln, &of, &id));
+        get_single_ids(1, &ln, &of, &id);
         return id;
+    }
+    void get_single_ids(uint64_t m, const uint64_t* ln, const uint64_t* of, faiss::idx_t* out) const override {
+        thread_ctx().device_calls++;
+        VIDC_FAISS_CHECK(vidc_packed_get(thread_ctx().ctx(), pk, m, ln, of, (int64_t*)out));
     }
 };
 
@@ -282,8 +315,12 @@ struct WaveletTreeInvertedLists : CompressedInvertedLists {
     faiss::idx_t get_single_id(size_t l, size_t offset) const override { /* wt.select(offset + 1, list_no), :377-379 */
         uint64_t ln = l, of = offset;
         int64_t id = -1;
-        VIDC_FAISS_CHECK(vidc_wt_select(thread_ctx().ctx(), wt, 1, &ln, &of, &id));
+        get_single_ids(1, &ln, &of, &id);
         return id;
+    }
+    void get_single_ids(uint64_t m, const uint64_t* ln, const uint64_t* of, faiss::idx_t* out) const override {
+        thread_ctx().device_calls++;
+        VIDC_FAISS_CHECK(vidc_wt_select(thread_ctx().ctx(), wt, m, ln, of, (int64_t*)out));
     }
 };
 
@@ -318,7 +355,21 @@ inline void search_IVF_defer_id_decoding(const faiss::IndexIVF& index, faiss::id
             std::memcpy(code1, cc, code_size);
         }
     }
-    if (decode_1by1) { /* :465-475 */
+    if (decode_1by1) { /* :464-474: n * k cheap selects -- here ONE batched call instead of n * k launches */
+        if (auto* comp = dynamic_cast<const CompressedInvertedLists*>(invlists)) {
+            std::vector<uint64_t> ln, of;
+            std::vector<idx_t> where;
+            for (idx_t i = 0; i < n * k; i++)
+                if (labels[i] >= 0) {
+                    ln.push_back((uint64_t)faiss::lo_listno(labels[i]));
+                    of.push_back((uint64_t)faiss::lo_offset(labels[i]));
+                    where.push_back(i);
+                }
+            std::vector<idx_t> got(where.size());
+            if (!where.empty()) comp->get_single_ids(where.size(), ln.data(), of.data(), got.data());
+            for (size_t j = 0; j < where.size(); j++) labels[where[j]] = got[j];
+            return;
+        }
         for (idx_t i = 0; i < n * k; i++)
             if (labels[i] >= 0) labels[i] = invlists->get_single_id(faiss::lo_listno(labels[i]), faiss::lo_offset(labels[i]));
         return;
@@ -347,19 +398,97 @@ inline void search_IVF_defer_id_decoding(const faiss::IndexIVF& index, faiss::id
 /* ---------------------------------------------------------------------------------------------------------------
  * graph containers (altid_impl.h:29-67).  The constructors read graph.data (N x K int32, -1 terminated rows) and set
  * data = nullptr like the reference (altid_impl.cpp:38,89,150).                                                  */
+/* Faiss' NSG search asks for ONE row per expanded node through a virtual call (faiss/impl/NSG.cpp, search_on_graph) and the
+ * reference decodes <= 64 ids inline in ~0.2 us (altid_impl.cpp:153-165).  A kernel launch + synchronisation + copy per
+ * row costs ~30 us, so rows are served from a per-thread host cache (direct-mapped, VIDC_FAISS_ROW_CACHE_ROWS rows of K
+ * int32) that is filled a frontier at a time: a miss on node i decodes row i and, with a second call, the rows of i's
+ * neighbours that are not cached yet -- the nodes a greedy search expands next.  get_neighbors_batch is the same path
+ * for callers that know their frontier (graph_search.py's batched search). */
+#ifndef VIDC_FAISS_ROW_CACHE_ROWS
+#define VIDC_FAISS_ROW_CACHE_ROWS 16384
+#endif
+struct RowCache {
+    uint64_t owner = 0; /* id of the graph object the rows belong to */
+    int K = 0;
+    std::vector<int32_t> tag;     /* node held by a slot, -1 = empty */
+    std::vector<uint32_t> count;
+    std::vector<int32_t> rows;    /* slot * K */
+    size_t hits = 0, misses = 0;
+    void reset(uint64_t o, int k) {
+        owner = o; K = k;
+        tag.assign(VIDC_FAISS_ROW_CACHE_ROWS, -1);
+        count.assign(VIDC_FAISS_ROW_CACHE_ROWS, 0);
+        rows.assign((size_t)VIDC_FAISS_ROW_CACHE_ROWS * (size_t)k, -1);
+        hits = misses = 0;
+    }
+    static size_t slot_of(int node) { return ((uint32_t)node * 2654435761u >> 7) & (VIDC_FAISS_ROW_CACHE_ROWS - 1); }
+};
+inline RowCache& thread_row_cache() {
+    thread_local RowCache c;
+    return c;
+}
+static_assert((VIDC_FAISS_ROW_CACHE_ROWS & (VIDC_FAISS_ROW_CACHE_ROWS - 1)) == 0, "power of two");
+
 struct CompressedNSGGraph : faiss::nsg::Graph<int32_t> {
     size_t compressed_ids_size_in_bytes = 0, overhead_in_bytes = 0;
-    explicit CompressedNSGGraph(const faiss::nsg::Graph<int32_t>& g) : faiss::nsg::Graph<int32_t>(g.data, g.N, g.K) {}
-    /* decode one row into neighbors[0..K) (-1 padded); returns the edge count */
-    template <class F>
-    size_t one_row(int i, int32_t* neighbors, F&& decode) const {
+    uint64_t object_id; /* cache key: addresses are reused, ids are not */
+    explicit CompressedNSGGraph(const faiss::nsg::Graph<int32_t>& g) : faiss::nsg::Graph<int32_t>(g.data, g.N, g.K) {
+        static std::atomic<uint64_t> next{1};
+        object_id = next++;
+    }
+    /* decode m rows into device memory d_out (m x K int32, -1 padded), edge counts into counts[m] */
+    virtual int decode_rows_device(vidc_ctx* ctx, uint64_t m, const uint64_t* nodes, int32_t* d_out, uint32_t* counts) const = 0;
+
+    /* rows of m nodes in ONE library call: out[m * K] (-1 padded), counts[m] (may be NULL) */
+    void get_neighbors_batch(size_t m, const int* nodes, int32_t* out, uint32_t* counts = nullptr) const {
+        if (!m) return;
         ThreadCtx& t = thread_ctx();
-        int32_t* d = (int32_t*)t.staging((size_t)K * 4);
-        uint64_t node = (uint64_t)i;
-        uint32_t count = 0;
-        VIDC_FAISS_CHECK(decode(t.ctx(), node, d, &count));
-        VIDC_FAISS_CHECK(vidc_copy_d2h(t.ctx(), neighbors, d, (size_t)K * 4));
-        return count;
+        std::vector<uint64_t> nd(nodes, nodes + m);
+        std::vector<uint32_t> cnt(m);
+        int32_t* d = (int32_t*)t.staging(m * (size_t)K * 4);
+        t.device_calls++;
+        VIDC_FAISS_CHECK(decode_rows_device(t.ctx(), m, nd.data(), d, cnt.data()));
+        VIDC_FAISS_CHECK(vidc_copy_d2h(t.ctx(), out, d, m * (size_t)K * 4));
+        if (counts) std::copy(cnt.begin(), cnt.end(), counts);
+    }
+    /* one row through the cache; returns the edge count */
+    size_t cached_row(int i, int32_t* neighbors) const {
+        RowCache& c = thread_row_cache();
+        if (c.owner != object_id || c.K != K) c.reset(object_id, K);
+        size_t s = RowCache::slot_of(i);
+        if (c.tag[s] != i) {
+            c.misses++;
+            get_neighbors_batch(1, &i, &c.rows[s * (size_t)K], &c.count[s]);
+            c.tag[s] = i;
+            /* the frontier: neighbours of i that are not cached (a neighbour whose slot is i's own stays out) */
+            std::vector<int> want;
+            std::vector<size_t> slots;
+            for (uint32_t j = 0; j < c.count[s] && j < (uint32_t)K; j++) {
+                int v = c.rows[s * (size_t)K + j];
+                if (v < 0 || v >= N) continue;
+                size_t sv = RowCache::slot_of(v);
+                if (sv == s || c.tag[sv] == v) continue;
+                bool dup = false;
+                for (size_t q : slots) dup |= q == sv;
+                if (dup) continue;
+                want.push_back(v);
+                slots.push_back(sv);
+            }
+            if (!want.empty()) {
+                std::vector<int32_t> buf(want.size() * (size_t)K);
+                std::vector<uint32_t> cnt(want.size());
+                get_neighbors_batch(want.size(), want.data(), buf.data(), cnt.data());
+                for (size_t q = 0; q < want.size(); q++) {
+                    std::memcpy(&c.rows[slots[q] * (size_t)K], &buf[q * (size_t)K], (size_t)K * 4);
+                    c.count[slots[q]] = cnt[q];
+                    c.tag[slots[q]] = want[q];
+                }
+            }
+        } else {
+            c.hits++;
+        }
+        std::memcpy(neighbors, &c.rows[s * (size_t)K], (size_t)K * 4);
+        return c.count[s];
     }
 };
 
@@ -378,11 +507,10 @@ struct CompactBitNSGGraph : CompressedNSGGraph {
         data = nullptr;
     }
     ~CompactBitNSGGraph() override { vidc_compact_destroy(c); }
-    size_t get_neighbors(int i, int32_t* neighbors) const override { /* returns the edge count (:41-50) */
-        return one_row(i, neighbors, [&](vidc_ctx* ctx, uint64_t node, int32_t* d, uint32_t* cnt) {
-            return vidc_compact_rows_decode(ctx, c, 1, &node, d, cnt);
-        });
+    int decode_rows_device(vidc_ctx* ctx, uint64_t m, const uint64_t* nodes, int32_t* d, uint32_t* cnt) const override {
+        return vidc_compact_rows_decode(ctx, c, m, nodes, d, cnt);
     }
+    size_t get_neighbors(int i, int32_t* neighbors) const override { return cached_row(i, neighbors); } /* edge count (:41-50) */
 };
 
 /* EliasFanoNSGGraph (altid_impl.cpp:53-101) */
@@ -398,11 +526,10 @@ struct EliasFanoNSGGraph : CompressedNSGGraph {
         data = nullptr;
     }
     ~EliasFanoNSGGraph() override { vidc_ef_destroy(ef); }
-    size_t get_neighbors(int i, int32_t* neighbors) const override { /* returns num_elements (:92-101) */
-        return one_row(i, neighbors, [&](vidc_ctx* ctx, uint64_t node, int32_t* d, uint32_t* cnt) {
-            return vidc_ef_decode_rows(ctx, ef, 1, &node, (uint32_t)K, d, cnt);
-        });
+    int decode_rows_device(vidc_ctx* ctx, uint64_t m, const uint64_t* nodes, int32_t* d, uint32_t* cnt) const override {
+        return vidc_ef_decode_rows(ctx, ef, m, nodes, (uint32_t)K, d, cnt);
     }
+    size_t get_neighbors(int i, int32_t* neighbors) const override { return cached_row(i, neighbors); } /* num_elements (:92-101) */
 };
 
 /* ROCNSGGraph (altid_impl.cpp:103-165) */
@@ -420,13 +547,27 @@ struct ROCNSGGraph : CompressedNSGGraph {
         data = nullptr;
     }
     ~ROCNSGGraph() override { vidc_roc_destroy(roc); }
+    int decode_rows_device(vidc_ctx* ctx, uint64_t m, const uint64_t* nodes, int32_t* d, uint32_t* cnt) const override {
+        return vidc_roc_decode_rows(ctx, roc, m, nodes, (uint32_t)K, d, cnt);
+    }
     size_t get_neighbors(int i, int32_t* neighbors) const override {
-        one_row(i, neighbors, [&](vidc_ctx* ctx, uint64_t node, int32_t* d, uint32_t* cnt) {
-            return vidc_roc_decode_rows(ctx, roc, 1, &node, (uint32_t)K, d, cnt);
-        });
+        cached_row(i, neighbors);
         return K; /* the reference returns K with only num_outgoing_edges[i] slots written (altid_impl.cpp:163-164);
                      here the remaining slots hold -1, which the NSG search stops at */
     }
 };
 
 }  // namespace vidc_faiss
+
+#ifdef VIDC_FAISS_REFERENCE_NAMES
+/* the names the reference's harness dictionaries look up (bench_invlists.py:19-25, graph_dynamic_bench_invlists.py:21-26,
+ * search_ivf_qinco.py:502-523); define the macro in the SWIG module INSTEAD of including custom_invlists_impl.h / altid_impl.h */
+using CompressedIDInvertedListsFenwickTree = vidc_faiss::ROCInvertedLists;
+using CompressedIDInvertedListsEliasFano = vidc_faiss::EliasFanoInvertedLists;
+using CompressedIDInvertedListsPackedBits = vidc_faiss::PackedBitsInvertedLists;
+using CompressedIDInvertedListsWaveletTree = vidc_faiss::WaveletTreeInvertedLists;
+using vidc_faiss::CompactBitNSGGraph;
+using vidc_faiss::EliasFanoNSGGraph;
+using vidc_faiss::ROCNSGGraph;
+using vidc_faiss::search_IVF_defer_id_decoding;
+#endif

@@ -3,12 +3,14 @@
 //   build: g++ -std=c++17 -I tests/faiss_shim -I include tests/adapter_smoke.cpp -L <pkg> -lvidc -Wl,-rpath,<pkg> -fopenmp
 // Prints "adapter smoke ok" and returns 0 when every check holds.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
 #include <set>
 #include <vector>
 
+#define VIDC_FAISS_REFERENCE_NAMES  // the reference's class names at global scope (bench_invlists.py:19-25 runs unchanged)
 #include "vidc_faiss_adapter.h"
 
 #define REQUIRE(c)                                                       \
@@ -51,8 +53,12 @@ static int check_container(faiss::IndexIVF& index, const faiss::ArrayInvertedLis
     REQUIRE(I == Iref && D == Dref);
     for (int one_by_one = 0; one_by_one < 2; one_by_one++) {  // test_compressed_ivfs.py:128-156
         std::fill(I.begin(), I.end(), -7);
+        const size_t calls0 = vidc_faiss::thread_ctx().device_calls;
         vidc_faiss::search_IVF_defer_id_decoding(index, nq, xq.data(), k, D.data(), I.data(), one_by_one != 0);
         REQUIRE(I == Iref && D == Dref);
+        // the n * k selects of decode_1by1 (custom_invlists_impl.cpp:464-474) and the touched lists of the batched form are ONE
+        // library call each, not one launch per result
+        REQUIRE(vidc_faiss::thread_ctx().device_calls - calls0 <= 1);
     }
     std::vector<uint8_t> codes((size_t)nq * k * (comp.code_size + index.coarse_code_size()));
     vidc_faiss::search_IVF_defer_id_decoding(index, nq, xq.data(), k, D.data(), I.data(), false, codes.data(), true);
@@ -92,6 +98,43 @@ static int check_graph(const std::vector<int32_t>& rows, int N, int K, const cha
         std::sort(b.begin(), b.end());
         REQUIRE(a == b);  // test_altid.py:33-40
     }
+    // get_neighbors_batch: a frontier in one library call
+    {
+        std::vector<int> nodes;
+        for (int i = 0; i < N; i += 3) nodes.push_back(i);
+        std::vector<int32_t> out(nodes.size() * (size_t)K);
+        std::vector<uint32_t> cnt(nodes.size());
+        const size_t calls0 = vidc_faiss::thread_ctx().device_calls;
+        g.get_neighbors_batch(nodes.size(), nodes.data(), out.data(), cnt.data());
+        REQUIRE(vidc_faiss::thread_ctx().device_calls - calls0 == 1);
+        for (size_t q = 0; q < nodes.size(); q++) {
+            g.get_neighbors(nodes[q], nb.data());
+            REQUIRE(std::equal(nb.begin(), nb.end(), out.begin() + q * (size_t)K));
+        }
+    }
+    // a greedy walk the way the NSG search expands nodes (one virtual get_neighbors per node): rows come from the per-thread
+    // cache, filled a frontier at a time
+    {
+        auto& cache = vidc_faiss::thread_row_cache();
+        const size_t h0 = cache.hits, m0 = cache.misses, calls0 = vidc_faiss::thread_ctx().device_calls;
+        std::mt19937 rng(7);
+        size_t steps = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        for (int walk = 0; walk < 200; walk++) {
+            int cur = (int)(rng() % N);
+            for (int hop = 0; hop < 30; hop++, steps++) {
+                size_t d = 0;
+                g.get_neighbors(cur, nb.data());
+                while (d < (size_t)K && nb[d] >= 0) d++;
+                if (!d) break;
+                cur = nb[rng() % d];
+            }
+        }
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        printf("  %-28s walk: %zu get_neighbors calls, %.2f us each, %zu cache hits / %zu misses, %zu library calls\n", name, steps,
+               us / (double)steps, cache.hits - h0, cache.misses - m0, vidc_faiss::thread_ctx().device_calls - calls0);
+        REQUIRE(vidc_faiss::thread_ctx().device_calls - calls0 <= 2 * (cache.misses - m0));
+    }
     printf("  %-28s ok: %zu bytes for %d nodes\n", name, g.compressed_ids_size_in_bytes, N);
     return 0;
 }
@@ -117,10 +160,11 @@ int main() {
         std::vector<float> Dref(nq * k);
         index.search(nq, xq.data(), k, Dref.data(), Iref.data());
         printf("inverted lists (%d ids, %d lists):\n", nb, nlist);
-        if (check_container<vidc_faiss::ROCInvertedLists>(index, *ref, xq, nq, k, Iref, Dref, "ROCInvertedLists")) return 1;
-        if (check_container<vidc_faiss::EliasFanoInvertedLists>(index, *ref, xq, nq, k, Iref, Dref, "EliasFanoInvertedLists")) return 1;
-        if (check_container<vidc_faiss::PackedBitsInvertedLists>(index, *ref, xq, nq, k, Iref, Dref, "PackedBitsInvertedLists")) return 1;
-        if (check_container<vidc_faiss::WaveletTreeInvertedLists>(index, *ref, xq, nq, k, Iref, Dref, "WaveletTreeInvertedLists")) return 1;
+        // (through the reference's own class names, VIDC_FAISS_REFERENCE_NAMES)
+        if (check_container<CompressedIDInvertedListsFenwickTree>(index, *ref, xq, nq, k, Iref, Dref, "CompressedIDInvertedListsFenwickTree")) return 1;
+        if (check_container<CompressedIDInvertedListsEliasFano>(index, *ref, xq, nq, k, Iref, Dref, "CompressedIDInvertedListsEliasFano")) return 1;
+        if (check_container<CompressedIDInvertedListsPackedBits>(index, *ref, xq, nq, k, Iref, Dref, "CompressedIDInvertedListsPackedBits")) return 1;
+        if (check_container<CompressedIDInvertedListsWaveletTree>(index, *ref, xq, nq, k, Iref, Dref, "CompressedIDInvertedListsWaveletTree")) return 1;
         {  // a foreign container still works through the deferred search (reference loop)
             std::vector<idx_t> I(nq * k);
             std::vector<float> D(nq * k);
@@ -147,9 +191,9 @@ int main() {
             std::copy(v.begin(), v.end(), rows.begin() + (size_t)i * K);
         }
         printf("graphs (%d nodes, K = %d):\n", N, K);
-        if (check_graph<vidc_faiss::CompactBitNSGGraph>(rows, N, K, "CompactBitNSGGraph", false, false)) return 1;
-        if (check_graph<vidc_faiss::EliasFanoNSGGraph>(rows, N, K, "EliasFanoNSGGraph", true, false)) return 1;
-        if (check_graph<vidc_faiss::ROCNSGGraph>(rows, N, K, "ROCNSGGraph", false, true)) return 1;
+        if (check_graph<CompactBitNSGGraph>(rows, N, K, "CompactBitNSGGraph", false, false)) return 1;
+        if (check_graph<EliasFanoNSGGraph>(rows, N, K, "EliasFanoNSGGraph", true, false)) return 1;
+        if (check_graph<ROCNSGGraph>(rows, N, K, "ROCNSGGraph", false, true)) return 1;
     } catch (const std::exception& e) {
         printf("FAILED with exception: %s\n", e.what());
         return 1;

@@ -205,3 +205,57 @@ def test_c5_ivf65k_shape_roc_and_elias_fano(oracle):
     got, goff = ef.decode_lists(sample)
     for k, l in enumerate(sample):
         assert torch.equal(got[int(goff[k]):int(goff[k + 1])], d_ids[int(off[l]):int(off[l + 1])])
+
+
+def test_s2_shape_parity_roc_and_elias_fano(oracle):
+    """The S2 shape (BASELINE.json north_star's roofline workload: 2^20 Zipf(0.75) inverted lists capped at 65 536 ids) at a
+    tenth of its ids (10^8): every kernel family of a large call runs at once -- lane-per-list classes, row-per-list or general
+    mid-size classes, the chain kernels on the longest lists.  Checks at full size, on the device: every list decodes to its own
+    ids (keyed per-list sort, so a list-boundary bug fails) and the sampling permutation maps input positions to the decoded
+    order element by element; 300 sampled lists (the two longest included) against the CPU oracle word for word, ROC and
+    Elias-Fano.  (bench.py's `extra.s2` line runs the same per-list check at 10^9 ids.)"""
+    import torch
+
+    from vector_db_id_compression_amd import synth
+    from vector_db_id_compression_amd.codecs import EfLists, RocLists
+
+    off, d_ids = synth.make_lists_torch(100_000_000, 1 << 20, 0.75, seed=2042, cap=65536)
+    nlist, ntotal = off.size - 1, int(off[-1])
+    sizes = (off[1:] - off[:-1]).astype(np.int64)
+    assert sizes.max() == 65536 and (sizes == 65536).sum() >= 2
+    rng = np.random.default_rng(5)
+    order = np.argsort(-sizes, kind="stable")
+    # the two longest, a few around every kernel-class boundary of the planners, the rest uniformly
+    sample = [int(order[0]), int(order[1])]
+    for edge in (64, 256, 1024, 2048, 4096, 8192, 16384, 32768):
+        near = np.flatnonzero((sizes > edge - 40) & (sizes <= edge + 40))
+        sample += [int(v) for v in near[:4]]
+    sample += [int(v) for v in rng.integers(0, nlist, 300 - len(sample))]
+    starts = torch.from_numpy(off[:-1].astype(np.int64)).cuda()
+    seg_start = torch.repeat_interleave(starts, torch.from_numpy(sizes).cuda())
+
+    r = RocLists.encode(off, d_ids, want_perm=True)
+    dec = r.decode_all()
+    assert r.last_decode_nonclean == 0
+    assert torch.equal(_per_list_sorted(dec, off), d_ids)  # (input lists are ascending: sorted-per-list == input)
+    perm = torch.from_numpy(r.perm().astype(np.int64)).cuda()
+    assert torch.equal(d_ids[seg_start + perm], dec)       # perm[i] = input position of the id decoded into slot i
+    del perm, dec
+    ids_host = {l: d_ids[int(off[l]):int(off[l + 1])].cpu().numpy().view(np.uint64) for l in sample}
+
+    class _Lists:  # (the oracle helpers index one flat array: hand them the sampled lists only)
+        def __getitem__(self, sl):
+            return ids_by_start[sl.start]
+    ids_by_start = {int(off[l]): ids_host[l] for l in sample}
+    _check_roc_lists_vs_oracle(oracle, r, off, _Lists(), sample)
+    bits_roc = 8.0 * r.compressed_bytes / ntotal
+    del r
+
+    ef = EfLists.encode(off, d_ids)
+    assert torch.equal(ef.decode_all(), d_ids)
+    _check_ef_lists_vs_oracle(oracle, ef, off, _Lists(), sample)
+    got, goff = ef.decode_lists(np.asarray(sample[:40], dtype=np.uint64))
+    got = got.cpu().numpy().view(np.uint64)
+    for k, l in enumerate(sample[:40]):
+        assert np.array_equal(got[int(goff[k]):int(goff[k + 1])], ids_host[l])
+    assert 10.0 < bits_roc < 40.0 and 8.0 * ef.compressed_bytes / ntotal < 40.0
