@@ -277,6 +277,14 @@ struct EfChunkRec {
     uint32_t nb;         // directory entries (batches) of the list
     uint32_t pad;
 };
+// A list of more than EF_BIG_CHUNKS chunks leaves the records behind its first one to k_ef_big_recs: the tile holding the
+// longest lists of a Zipf-sized index (S2: 1024 lists of 65 536 ids = 130 000 records) kept its 256 threads busy for 0.4 ms
+// while the median tile wrote 1 500 records.
+#define EF_BIG_CHUNKS 8u
+struct EfBigList {
+    uint64_t o0, u, lw, hw, nb, rec0;  // first id, universe, offsets of the low / high words and directory entries, first record
+    uint32_t l, m, lb, pad;
+};
 struct EfListInfo {  // a list of the tile in LDS while the chunk records behind its first one are written
     uint64_t o0, u, lw, hw, nb;  // first id, universe, offsets of the list's low / high words and directory entries
     uint32_t c0, x0;             // chunks / chunks other than first ones of the tile before this list
@@ -414,7 +422,7 @@ __global__ void __launch_bounds__(NT) k_ef_offsets(const uint64_t *ids, const ui
                                                     uint32_t *lbits, uint64_t *universe, const EfRaw *raw,
                                                     const EfTile *tiles, uint32_t ntiles, uint64_t *low_off,
                                                     uint64_t *high_off, uint64_t *batch_off, EfChunkRec *recs,
-                                                    EfSummary *sum) {
+                                                    EfSummary *sum, EfBigList *big, uint32_t *nbig) {
     constexpr uint32_t TILE = NT * E;
     __shared__ uint64_t sh[6 * (NT / 64)];
     __shared__ EfListInfo info[TILE];
@@ -447,7 +455,8 @@ __global__ void __launch_bounds__(NT) k_ef_offsets(const uint64_t *ids, const ui
     uint64_t a[5] = {0, 0, 0, 0, 0}, tot[5];  // lw, hw, nb, cnt, chunks other than the first one of a list
 #pragma unroll
     for (uint32_t j = 0; j < E; j++) {
-        a[0] += r[j].lw; a[1] += r[j].hw; a[2] += r[j].nb; a[3] += r[j].cnt; a[4] += r[j].cnt ? r[j].cnt - 1 : 0;
+        a[0] += r[j].lw; a[1] += r[j].hw; a[2] += r[j].nb; a[3] += r[j].cnt;
+        a[4] += (r[j].cnt && r[j].cnt <= EF_BIG_CHUNKS) ? r[j].cnt - 1 : 0;
     }
     block_exscan<5, NT / 64>(a, tot, sh);
     a[0] += P[0]; a[1] += P[1]; a[2] += P[2];
@@ -461,11 +470,18 @@ __global__ void __launch_bounds__(NT) k_ef_offsets(const uint64_t *ids, const ui
         const uint32_t m = (uint32_t)(o[j + 1] - o[j]);
         if (l < nlist) { low_off[l] = a[0]; high_off[l] = a[1]; batch_off[l] = a[2]; }
         if (r[j].cnt) recs[P[3] + a[3]] = ef_make_rec(l, 0, o[j], m, u[j], lb[j], a[0], a[1], a[2]);
+        if (r[j].cnt > EF_BIG_CHUNKS) {
+            EfBigList bl;
+            bl.o0 = o[j]; bl.u = u[j]; bl.lw = a[0]; bl.hw = a[1]; bl.nb = a[2]; bl.rec0 = P[3] + a[3];
+            bl.l = l; bl.m = m; bl.lb = lb[j]; bl.pad = 0;
+            big[atomicAdd(nbig, 1u)] = bl;
+        }
         EfListInfo li;
         li.o0 = o[j]; li.u = u[j]; li.lw = a[0]; li.hw = a[1]; li.nb = a[2]; li.c0 = (uint32_t)a[3]; li.x0 = (uint32_t)a[4];
         li.m = m; li.lb = lb[j];
         info[t * E + j] = li;  // (lists past the end: no chunks, x0 = the tile's count)
-        a[0] += r[j].lw; a[1] += r[j].hw; a[2] += r[j].nb; a[3] += r[j].cnt; a[4] += r[j].cnt ? r[j].cnt - 1 : 0;
+        a[0] += r[j].lw; a[1] += r[j].hw; a[2] += r[j].nb; a[3] += r[j].cnt;
+        a[4] += (r[j].cnt && r[j].cnt <= EF_BIG_CHUNKS) ? r[j].cnt - 1 : 0;
         if (l + 1u == nlist) {  // (exactly one thread of the last tile): the entries behind the last list, the totals
             low_off[nlist] = a[0]; high_off[nlist] = a[1]; batch_off[nlist] = a[2];
             EfSummary out;
@@ -476,8 +492,8 @@ __global__ void __launch_bounds__(NT) k_ef_offsets(const uint64_t *ids, const ui
     }
     if (!tot[4]) return;
     __syncthreads();
-    // the records behind the first one of every list, one per thread and step: record x belongs to the last list
-    // with x0 <= x
+    // the records behind the first one of every list of at most EF_BIG_CHUNKS chunks, one per thread and step: record x
+    // belongs to the last list with x0 <= x (a long list has no such record: its x0 equals its successor's)
     for (uint64_t x = t; x < tot[4]; x += NT) {
         uint32_t lo = 0, hi = TILE;  // first list with x0 > x
         while (lo < hi) {
@@ -487,6 +503,17 @@ __global__ void __launch_bounds__(NT) k_ef_offsets(const uint64_t *ids, const ui
         const EfListInfo li = info[lo - 1u];
         const uint64_t c = 1u + (x - li.x0);
         recs[P[3] + li.c0 + c] = ef_make_rec(tile * TILE + lo - 1u, c, li.o0, li.m, li.u, li.lb, li.lw, li.hw, li.nb);
+    }
+}
+
+// the records behind the first one of the long lists: a wavefront per list, a record per lane and step
+__global__ void __launch_bounds__(64) k_ef_big_recs(const EfBigList *big, const uint32_t *nbig, EfChunkRec *recs) {
+    const uint32_t n = *nbig;
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        const EfBigList bl = big[k];
+        const uint32_t cnt = (bl.m + EF_CHUNK - 1u) / EF_CHUNK;
+        for (uint32_t c = 1u + threadIdx.x; c < cnt; c += 64u)
+            recs[bl.rec0 + c] = ef_make_rec(bl.l, c, bl.o0, bl.m, bl.u, bl.lb, bl.lw, bl.hw, bl.nb);
     }
 }
 
@@ -652,9 +679,10 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
 // 227 us per 64 M ids).
 // one chunk record with R id registers per lane (64 R >= the ids of the chunk)
 template <int R>
-__device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const uint64_t *sorted_ids, uint64_t *low,
-                                                   uint64_t *high, uint32_t *hrank, Chunk *batches, uint32_t *unsorted,
-                                                   uint32_t *win32, uint32_t *img32) {
+__device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const uint64_t *__restrict__ sorted_ids,
+                                                   uint64_t *__restrict__ low, uint64_t *__restrict__ high,
+                                                   uint32_t *__restrict__ hrank, Chunk *__restrict__ batches,
+                                                   uint32_t *__restrict__ unsorted, uint32_t *win32, uint32_t *img32) {
     const uint32_t lane = lane_id();
     constexpr uint32_t NONE = 0xffffffffu;
     const uint32_t start = rc.start;
@@ -768,10 +796,13 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
 // SMALL: chunks of up to 64 / 256 ids take the code unrolled for one / four id registers -- a chunk costs its unrolled
 // instructions whether the slots are used or not, and the lists of a 65 536-list IVF index are mostly that short; the
 // extra code paths cost a wavefront per SIMD (97 VGPRs), so objects of mostly full chunks take the plain kernel.
+// (recs / sorted_ids are read-only for the whole launch: __restrict__ lets the record and the wave-uniform neighbour ids come
+// through scalar loads instead of 64 identical vector loads + v_readfirstlane each)
 template <int RMAX, bool SMALL>
-__global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *sorted_ids, const EfChunkRec *recs,
-                                                     uint64_t nchunks, uint64_t *low, uint64_t *high, uint32_t *hrank,
-                                                     Chunk *batches, uint32_t *unsorted) {
+__global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *__restrict__ sorted_ids, const EfChunkRec *__restrict__ recs,
+                                                     uint64_t nchunks, uint64_t *__restrict__ low, uint64_t *__restrict__ high,
+                                                     uint32_t *__restrict__ hrank, Chunk *__restrict__ batches,
+                                                     uint32_t *__restrict__ unsorted) {
     __shared__ uint32_t win32[EF_WIN_WORDS * 2];
     __shared__ uint32_t img32[(64 * RMAX + 8) * 2];  // low words of the chunk, as 32-bit halves
     for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
@@ -1449,7 +1480,7 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
     const uint32_t tile_lists = nl32 <= EF_SINGLE_LISTS ? EF_SINGLE_LISTS : (nl32 <= EF_E1_MAX_LISTS ? 256u : 1024u);
     const uint32_t ntiles = nl32 ? (nl32 + tile_lists - 1u) / tile_lists : 1u;
     VidcPhaseTimer pt(ctx);
-    Scratch s_raw, s_tiles, s_sum, s_recs;
+    Scratch s_raw, s_tiles, s_sum, s_recs, s_big;
     Pinned tail;
     VIDC_TRY(tail.get(ctx, 2 * sizeof(EfSummary)));
     EfSummary *hs = tail.as<EfSummary>();
@@ -1457,6 +1488,12 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
     VIDC_TRY(s_tiles.get(ctx, (size_t)ntiles * sizeof(EfTile)));
     VIDC_TRY(s_sum.get(ctx, sizeof(EfSummary)));
     VIDC_TRY(s_recs.get(ctx, (nchunks ? nchunks : 1) * sizeof(EfChunkRec)));
+    // long lists (more than EF_BIG_CHUNKS chunks: at most nchunks / (EF_BIG_CHUNKS + 1) of them) + their count
+    const uint64_t big_cap = nchunks / (EF_BIG_CHUNKS + 1u) + 1u;
+    VIDC_TRY(s_big.get(ctx, big_cap * sizeof(EfBigList) + 16));
+    EfBigList *d_big = (EfBigList *)((char *)s_big.p + 16);
+    uint32_t *d_nbig = s_big.as<uint32_t>();
+    VIDC_HIP(hipMemsetAsync(d_nbig, 0, 16, ctx->stream));
     VIDC_TRY(e->d_low_off.alloc(nlist + 1, ctx->dpool)); VIDC_TRY(e->d_high_off.alloc(nlist + 1, ctx->dpool));
     VIDC_TRY(e->d_batch_off.alloc(nlist + 1, ctx->dpool));
     VIDC_TRY(e->d_lbits.alloc(nlist ? nlist : 1, ctx->dpool)); VIDC_TRY(e->d_universe.alloc(nlist ? nlist : 1, ctx->dpool));
@@ -1466,22 +1503,25 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
         hipLaunchKernelGGL((k_ef_offsets<true, 2, 512>), dim3(1), dim3(512), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
                            e->d_lbits.p, e->d_universe.p, (const EfRaw *)nullptr, (const EfTile *)nullptr, 1u,
                            e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
-                           s_sum.as<EfSummary>());
+                           s_sum.as<EfSummary>(), d_big, d_nbig);
     } else if (tile_lists == 256u) {
         hipLaunchKernelGGL(k_ef_meta<1>, dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
                            e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>());
         hipLaunchKernelGGL((k_ef_offsets<false, 1, 256>), dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p,
                            nl32, e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>(), ntiles,
                            e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
-                           s_sum.as<EfSummary>());
+                           s_sum.as<EfSummary>(), d_big, d_nbig);
     } else {
         hipLaunchKernelGGL(k_ef_meta<4>, dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
                            e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>());
         hipLaunchKernelGGL((k_ef_offsets<false, 4, 256>), dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p,
                            nl32, e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>(), ntiles,
                            e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
-                           s_sum.as<EfSummary>());
+                           s_sum.as<EfSummary>(), d_big, d_nbig);
     }
+    if (max_list > (uint64_t)EF_CHUNK * EF_BIG_CHUNKS)  // (some list is that long)
+        hipLaunchKernelGGL(k_ef_big_recs, dim3((uint32_t)std::min<uint64_t>(big_cap, (uint64_t)ctx->num_cu * 32)), dim3(64), 0, ctx->stream,
+                           d_big, d_nbig, s_recs.as<EfChunkRec>());
     VIDC_HIP(hipGetLastError());
     pt.end();
     VIDC_HIP(hipMemcpyAsync(hs, s_sum.p, sizeof(EfSummary), hipMemcpyDeviceToHost, ctx->stream));
