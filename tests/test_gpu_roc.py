@@ -737,3 +737,34 @@ def test_wide_stream_context_takes_the_row_kernels_by_itself(roc, monkeypatch):
     for a, b in zip(got["wide"], got["plain"]):
         assert np.array_equal(a, b)
     wide.close()
+
+
+def test_lane_pair_decoder_matches_bucket_decoder(roc, oracle, force_lane, monkeypatch):
+    """Lists of 257..512 ids decode on a PAIR of lanes with the ids in registers (k_roc_decode_lane_reg<192, true>: slot i >> 1 of
+    the lane with the parity of step i, rank = sum of the two lanes; opt-in through VIDC_LANE_PAIR=1), by default on the bucket-row decoder.
+    Ragged sizes inside one wavefront, every size boundary (257, 383 / 384 / 385: the register / LDS slot switch at slot 192,
+    511 / 512), dense lists that drain the stream window fastest: same decoded order, and the oracle's."""
+    rng = np.random.default_rng(91)
+    for nbits in (10, 13, 24, 31):
+        sizes = rng.integers(257, 513, 500)
+        sizes[:12] = [512, 512, 511, 385, 384, 383, 257, 258, 300, 448, 449, 512]
+        sizes = np.minimum(sizes, (1 << nbits) - 1)
+        off, ids, lists = _random_lists(rng, sizes, nbits=nbits)
+        r = roc.encode(off, ids)
+        monkeypatch.setenv("VIDC_LANE_PAIR", "1")   # (the pair decoder is opt-in, see roc.hip dec_class)
+        dec = r.decode_all().cpu().numpy().view(np.uint64)
+        assert r.last_decode_nonclean == 0
+        monkeypatch.delenv("VIDC_LANE_PAIR")
+        dec2 = r.decode_all().cpu().numpy().view(np.uint64)
+        monkeypatch.setenv("VIDC_LANE_PAIR", "1")
+        assert np.array_equal(dec, dec2)
+        sub = list(range(14)) + [int(v) for v in rng.integers(0, len(lists), 16)]
+        for l in sub:
+            li = lists[l]
+            e = oracle.roc_encode(li, oracle.list_precision(li))
+            want = oracle.roc_decode(e["head"], e["words"], li.size, oracle.list_precision(li), e["mt_draws"])[0]
+            assert np.array_equal(dec[int(off[l]):int(off[l + 1])], want), (nbits, l)
+        got, goff = r.decode_lists(np.array(sub, dtype=np.uint64))
+        got = got.cpu().numpy().view(np.uint64)
+        for k, l in enumerate(sub):
+            assert np.array_equal(got[int(goff[k]):int(goff[k + 1])], dec[int(off[l]):int(off[l + 1])])

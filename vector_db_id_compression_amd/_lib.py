@@ -141,8 +141,11 @@ def lib():
     """The loaded C-ABI library (built on first use)."""
     global _lib
     if _lib is None:
-        _build.build()  # returns at once unless a source is newer than the library (no stale kernels after an edit)
-        _lib = C.CDLL(LIB_PATH)
+        path = os.environ.get("VIDC_LIBRARY")  # a prebuilt libvidc.so somewhere else (A/B builds, packaging): loaded as is
+        if not path:
+            _build.build()  # returns at once unless the sources' content hash differs from the library's (build.py)
+            path = LIB_PATH
+        _lib = C.CDLL(path)
         _declare(_lib)
     return _lib
 

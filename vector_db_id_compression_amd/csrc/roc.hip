@@ -271,8 +271,15 @@ void par_ranges(uint64_t n, unsigned parts, F &&f) {
 // Counting sort by length (lengths are bounded by VIDC_ROC_MAX_LIST): O(n), stable.
 void sort_desc(std::vector<uint32_t> &wl, const std::vector<uint64_t> &offsets) {
     if (wl.size() < 2) return;
-    uint64_t maxlen = 0;
-    for (uint32_t l : wl) maxlen = std::max<uint64_t>(maxlen, offsets[l + 1] - offsets[l]);
+    uint64_t maxlen = 0, prev = ~0ull;
+    bool sorted = true;  // equal-sized lists, or an index whose lists come longest first: nothing to do
+    for (uint32_t l : wl) {
+        const uint64_t n = offsets[l + 1] - offsets[l];
+        maxlen = std::max<uint64_t>(maxlen, n);
+        sorted &= n <= prev;
+        prev = n;
+    }
+    if (sorted) return;
     if (maxlen > (1u << 22)) {  // not reachable for ROC lists; keep a comparison sort for safety
         std::stable_sort(wl.begin(), wl.end(), [&](uint32_t a, uint32_t b) {
             return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b];
@@ -988,7 +995,8 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
 // arithmetic, bounds the general decoder when a batch has many mid-size lists
 // (DC_LANE .. the last class: kernels that may hand a list back with VIDC_ST_RETRY)
 enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_B2T, DC_B2S, DC_B2L, DC_B2M,
-                DC_GRP0, DC_GRP2, DC_GRP3, DC_GRP4, DC_COUNT };  // row-per-list decoder by bucket bits 8 + F (roc_grp.h)
+                DC_GRP0, DC_GRP2, DC_GRP3, DC_GRP4,   // row-per-list decoder by bucket bits 8 + F (roc_grp.h)
+                DC_LANEP, DC_COUNT };                  // 257..512 ids on a pair of lanes, ids in registers (k_roc_decode_lane_reg<.., true>)
 constexpr uint64_t B2_MIN_LIST = 4096;
 constexpr size_t B2_CAP = 1024;      // chains of k_roc_decode_b2 per call (four per CU of an MI355X: 1 MiB of member rows each)
 
@@ -1020,6 +1028,12 @@ inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general
     }
     if (grp_ok) return grp_dec_class(n);
     static const bool nb256 = env_on("VIDC_LANE_NB256");  // measurements: 256 buckets for the 257..1024-id lists too
+    // Opt-in (VIDC_LANE_PAIR=1).  The kernel is bit-exact by itself (GPU test-suite) and decodes 240 M ids of 400-id lists in 7.2 ms
+    // against 11.7 for the bucket-row decoder -- but with it in the mix, S2-sized calls (10^6 lists, 10^9 ids) came back with one
+    // wrong list in ~10 % of the decodes, in OTHER classes (general decoder lists of 4000..7500 ids), also when this kernel stored
+    // nothing at all (VIDC_PAIR_DRY=1); 0 of 160 decodes without it.  Not understood; see DESIGN section 10.
+    const bool no_pair = !env_on("VIDC_LANE_PAIR") || env_on("VIDC_NO_LANE_PAIR") || env_on("VIDC_NO_LANE_REG");
+    if (allow_lane && !no_pair && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_PAIR_MAX) return DC_LANEP;
     if (allow_lane && nb256 && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_MAX) return DC_LANE64;
     if (allow_lane && n <= VIDC_LANE_MAX) return DC_LANE;
     if (allow_lane64 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64) return DC_LANE64;
@@ -1189,6 +1203,7 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             // re-spill scratch of the decoder stack (== roc_dec_stack_cap in the kernels); the lane-per-list decoders
             // keep what they push in LDS
             if (c != DC_LANE && c != DC_LANE64 && c < DC_GRP0) so += roc_dec_stack_cap((uint32_t)n, r->meta_host ? r->nwords[l] : 0u);
+            if (c == DC_LANEP) continue;  // no scratch of any kind
             p.slots_off[k] = sl;
             if (c == DC_LANE) {
                 sl = (sl + 3) & ~(uint64_t)3;  // rows are read as uint4
@@ -1311,8 +1326,8 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         double est[DC_COUNT];
         for (int c = 0; c < DC_COUNT; c++) {
             order[c] = c;
-            const bool u = c == DC_U18 || c == DC_U20 || c == DC_B2 || c == DC_B2T || c == DC_B2S || c == DC_B2L || c == DC_B2M, lane = c == DC_LANE || c == DC_LANE64;
-            const bool grpc = c >= DC_GRP0;
+            const bool u = c == DC_U18 || c == DC_U20 || c == DC_B2 || c == DC_B2T || c == DC_B2S || c == DC_B2L || c == DC_B2M, lane = c == DC_LANE || c == DC_LANE64 || c == DC_LANEP;
+            const bool grpc = c >= DC_GRP0 && c <= DC_GRP4;
             // (constants fitted to the S2 timeline: general kernels ~2.5 G steps/s while they share the machine)
             const double step_us = u ? 0.4 : (lane ? 2.5 : (c == DC_TINY ? 0.5 : (grpc ? 1.5 : 1.2)));       // one chain step
             const double rate = u ? 0.6e3 : (lane ? 16e3 : (c == DC_TINY ? 30e3 : (grpc ? 12e3 : 2.5e3)));     // steps / us, all CUs
@@ -1429,6 +1444,13 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
             case DC_B2M:  // 256 buckets, 66 KiB
                 VIDC_TRY(set_big_lds((const void *)k_roc_decode_b2<256>, VIDC_B2L_LDS_BYTES(256u)));
                 hipLaunchKernelGGL(k_roc_decode_b2<256>, dim3(b.nwork), dim3(64), VIDC_B2L_LDS_BYTES(256u), st_, b, (const U2Div *)ctx->d_u2tab);
+                break;
+            case DC_LANEP:
+                b.lpw = 32u;
+                if (env_on("VIDC_PAIR_DRY")) b.K = 0xdeadu;   // debug: no stores
+                if (env_on("VIDC_PAIR_NOP")) b.K = 0xdeaeu;   // debug: the kernel returns at once
+                hipLaunchKernelGGL((k_roc_decode_lane_reg<VIDC_LANE_REG_EL, true>), dim3((b.nwork + 31u) / 32u), dim3(64), 0, st_, b,
+                                   (const LaneDiv *)ctx->d_ltab);
                 break;
             case DC_GRP0:
                 hipLaunchKernelGGL(k_roc_decode_grp<0>, dim3((b.nwork + 3u) / 4u), dim3(64), 16u * roc_grp_dec_lds_words(0), st_, b, (const U2Div *)ctx->d_u2tab);

@@ -567,28 +567,38 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
 #ifndef VIDC_LANE_REG_EL
 #define VIDC_LANE_REG_EL 192  // slots in registers (the rest of the 256 in LDS)
 #endif
-template <int EL>
+// PAIR: a list of 257 .. 512 ids per PAIR of lanes (32 lists per wavefront).  Both lanes run the list's ANS chain (the state
+// is replicated, like the 16 lanes of a row in roc_grp.h); the id of step i goes to slot i >> 1 of the lane with the parity
+// of i, so each lane still holds at most 256 slots, and the rank is the sum of the two lanes' counts (one DPP swap).  The
+// bucket-row decoder these lists used before read and wrote a random 64-byte line per step (S2: 114 bytes of HBM traffic
+// per id on 217 M ids); here a step touches no memory but the stream window and the output ring.
+#define VIDC_LANE_PAIR_MAX (2u * VIDC_LANE_REG_MAX)
+template <int EL, bool PAIR = false>
 struct LaneRegGeom {
     static constexpr uint32_t TAIL = VIDC_LANE_REG_MAX - EL;          // slots kept in LDS
     static constexpr uint32_t TAIL_BYTES = TAIL * 64 * 4;             // uint4 tail4[TAIL / 4][64]
     static constexpr uint32_t RING_BYTES = 8 * 64 * 4;
     static constexpr uint32_t WIN_BYTES = VIDC_DWIN * 64 * 4;
     static constexpr uint32_t PST_BYTES = VIDC_DPST * 64 * 4;
-    static constexpr uint32_t LQ_BYTES = (VIDC_LANE_REG_MAX + 4) * 4;  // floor(2^31 / d), d = 0 .. 256 (a load per step otherwise)
+    static constexpr uint32_t NMAX = PAIR ? VIDC_LANE_PAIR_MAX : VIDC_LANE_REG_MAX;
+    static constexpr uint32_t LQ_BYTES = (NMAX + 4) * 4;  // floor(2^31 / d), d = 0 .. NMAX (a load per step otherwise)
     static constexpr uint32_t LDS_BYTES = TAIL_BYTES + RING_BYTES + WIN_BYTES + PST_BYTES + LQ_BYTES;
 };
-template <int EL>
+template <int EL, bool PAIR = false>
 __global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const LaneDiv *__restrict__ dtab) {
     static_assert(EL == 192, "the rank asm is generated for 192 slots in v64..v255");
-    using G = LaneRegGeom<EL>;
+    using G = LaneRegGeom<EL, PAIR>;
+    if (PAIR && a.K == 0xdeaeu) return;  // (debug: launch only)
     __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
     const uint32_t lane = lane_id();
     uint4 *tail4 = (uint4 *)smem + lane;                       // chunk c of this lane at tail4[c * 64]
     uint32_t *tail1 = (uint32_t *)smem + lane * 4u;            // slot s: tail1[(s >> 2) * 256 + (s & 3)]
     uint32_t *oring = (uint32_t *)(smem + G::TAIL_BYTES);
-    const uint32_t lpw = a.lpw ? a.lpw : 64u;
-    const uint32_t wi = blockIdx.x * lpw + lane;
-    const bool have = lane < lpw && wi < a.nwork;
+    const uint32_t lpw = a.lpw ? a.lpw : (PAIR ? 32u : 64u);
+    const uint32_t lslot = PAIR ? lane >> 1 : lane;  // list of the wavefront this lane works on
+    const uint32_t wi = blockIdx.x * lpw + lslot;
+    const bool have = lslot < lpw && wi < a.nwork;
+    const bool writer = (!PAIR || (lane & 1u) == 0u) && a.K != 0xdeadu;  // the lane of a pair that stores the list's results (0xdead: debug dry run)
     const uint32_t l = have ? a.worklist[wi] : 0u;
     const uint32_t n = have ? (uint32_t)(a.offsets[l + 1] - a.offsets[l]) : 0u;
     const uint64_t ooff = have ? (a.out_off ? a.out_off[wi] : a.offsets[l]) : 0ull;
@@ -597,7 +607,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const 
 #pragma unroll
     for (uint32_t c = 0; c < G::TAIL / 4u; c++) tail4[c * 64u] = make_uint4(~0u, ~0u, ~0u, ~0u);
     uint32_t *lqs = (uint32_t *)(smem + G::TAIL_BYTES + G::RING_BYTES + G::WIN_BYTES + G::PST_BYTES);
-    for (uint32_t d = lane; d <= VIDC_LANE_REG_MAX; d += 64u) lqs[d] = dtab[d].w;
+    for (uint32_t d = lane; d <= G::NMAX; d += 64u) lqs[d] = dtab[d].w;
     v32u e0, e1, e2, e3, e4, e5;  // slots 0..191, pinned to v64..v255 by the asm statements below
 #pragma unroll
     for (int k = 0; k < 32; k++) e0[k] = e1[k] = e2[k] = e3[k] = e4[k] = e5[k] = 0x7fffffffu;  // empty: slot - x >= 0
@@ -617,7 +627,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const 
     // lands at the end of the next one: a load issued behind the stores would wait for their write acknowledgements
     uint4 pf = make_uint4(0, 0, 0, 0);
     bool pf_go = false;
-    // rank of xx among the ids decoded in steps 0 .. i-1
+    // rank of xx among the ids in slots 0 .. i-1 of this lane
     auto rank_of = [&](uint32_t xx, uint32_t i) __attribute__((always_inline)) -> uint32_t {
         uint32_t r = 0;
         const uint32_t nb = i >= (uint32_t)EL ? (uint32_t)EL / 16u : (i + 15u) >> 4;  // register blocks holding an id
@@ -652,7 +662,9 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const 
             const uint32_t lo = l_u_pop(head, st, p0);
             x = (hi << 16) | lo;
         }
-        const uint32_t r = rank_of(x, i);
+        // (PAIR: the lane with the parity of a step holds its id: after i steps at most (i + 1) / 2 slots of a lane are in use)
+        uint32_t r = rank_of(x, PAIR ? (i + 1u) >> 1 : i);
+        if (PAIR) r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0xb1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]: the partner's count
         if (act) {
             // ---- IDX_push(r, i + 1), codec.cpp:44-63
             uint64_t h0 = head;
@@ -666,7 +678,20 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const 
         }
         if (act) oring[(i & 7u) * 64u + lane] = x;
         // ---- slot i = x (lanes past their list only overwrite an empty slot they never read again)
-        if (i < (uint32_t)EL) {
+        if (PAIR) {
+            const uint32_t sl = i >> 1;                       // slot, in the lane with the parity of the step
+            const bool mine = ((lane ^ i) & 1u) == 0u;
+            if (sl < (uint32_t)EL) {
+                const uint64_t m = __ballot(mine);
+                asm volatile("s_set_gpr_idx_on %[i], gpr_idx(SRC0,DST)\n\tv_cndmask_b32_e64 v64, v64, %[x], %[m]\n\ts_set_gpr_idx_off"
+                             : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5)
+                             : [x] "v"(x), [i] "s"(sl), [m] "s"(m));
+            } else if (act && mine) {
+                const uint32_t sidx = sl - (uint32_t)EL;
+                tail1[(sidx >> 2) * 256u + (sidx & 3u)] = x;
+            }
+        } else if (i < (uint32_t)EL) {
             asm volatile("s_set_gpr_idx_on %[i], gpr_idx(DST)\n\tv_mov_b32 v64, %[x]\n\ts_set_gpr_idx_off"
                          : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
                            "+{v[224:255]}"(e5)
@@ -682,11 +707,11 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const 
 #pragma unroll
             for (uint32_t k = 0; k < 8u; k++) {
                 const uint32_t sstep = s0 + k;
-                if (sstep <= i && sstep < n) a.out[ooff + (n - 1u - sstep)] = (uint64_t)oring[k * 64u + lane];
+                if (writer && sstep <= i && sstep < n) a.out[ooff + (n - 1u - sstep)] = (uint64_t)oring[k * 64u + lane];
             }
         }
     }
-    if (have) {
+    if (have && writer) {
         const bool retry = (st.err & 4u) != 0u;
         const bool clean = (head == VIDC_RANS_L) && (st.otop - st.al + st.d == st.draws - draws0);
         a.end_state[l] = (clean || retry) ? 0u : 1u;
