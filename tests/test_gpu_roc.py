@@ -741,7 +741,7 @@ def test_wide_stream_context_takes_the_row_kernels_by_itself(roc, monkeypatch):
 
 def test_lane_pair_decoder_matches_bucket_decoder(roc, oracle, force_lane, monkeypatch):
     """Lists of 257..512 ids decode on a PAIR of lanes with the ids in registers (k_roc_decode_lane_reg<192, true>: slot i >> 1 of
-    the lane with the parity of step i, rank = sum of the two lanes; opt-in through VIDC_LANE_PAIR=1), by default on the bucket-row decoder.
+    the lane with the parity of step i, rank = sum of the two lanes); VIDC_NO_LANE_PAIR=1 sends them to the bucket-row decoder.
     Ragged sizes inside one wavefront, every size boundary (257, 383 / 384 / 385: the register / LDS slot switch at slot 192,
     511 / 512), dense lists that drain the stream window fastest: same decoded order, and the oracle's."""
     rng = np.random.default_rng(91)
@@ -751,12 +751,12 @@ def test_lane_pair_decoder_matches_bucket_decoder(roc, oracle, force_lane, monke
         sizes = np.minimum(sizes, (1 << nbits) - 1)
         off, ids, lists = _random_lists(rng, sizes, nbits=nbits)
         r = roc.encode(off, ids)
-        monkeypatch.setenv("VIDC_LANE_PAIR", "1")   # (the pair decoder is opt-in, see roc.hip dec_class)
+        monkeypatch.delenv("VIDC_NO_LANE_PAIR", raising=False)
         dec = r.decode_all().cpu().numpy().view(np.uint64)
         assert r.last_decode_nonclean == 0
-        monkeypatch.delenv("VIDC_LANE_PAIR")
+        monkeypatch.setenv("VIDC_NO_LANE_PAIR", "1")
         dec2 = r.decode_all().cpu().numpy().view(np.uint64)
-        monkeypatch.setenv("VIDC_LANE_PAIR", "1")
+        monkeypatch.delenv("VIDC_NO_LANE_PAIR", raising=False)
         assert np.array_equal(dec, dec2)
         sub = list(range(14)) + [int(v) for v in rng.integers(0, len(lists), 16)]
         for l in sub:

@@ -31,7 +31,11 @@ struct vidc_roc {
     // the values the decode planner needs (lists above TINY_MAX) as soon as encode returns.
     mutable std::vector<uint64_t> offsets;   // nlist+1
     mutable std::vector<uint32_t> prec, nwords, draws;
-    std::vector<uint32_t> umax;  // largest id per list where the encoder knew it (empty / 0 = unknown: imported streams)
+    // HEURISTIC input of the decode planner (bucket geometry of the b2 kernels), never a correctness input: the prepass' view of
+    // a list's largest id -- its true maximum after the full prepass, its LAST id after the light one (== the maximum of an
+    // ascending list; a list that turned out not to be ascending is redone by the sorting pass and set to 0 here).  A value
+    // below the true maximum only makes the planner assume more ids per bucket.  Empty / 0 = unknown (imported streams).
+    std::vector<uint32_t> umax;
     mutable std::vector<uint64_t> heads;
     mutable std::vector<uint64_t> word_off;  // nlist+1
     mutable bool meta_host = false, offsets_host = false;
@@ -1017,8 +1021,14 @@ inline DecClass grp_dec_class(uint64_t n) {
     const uint32_t f = roc_grp_dec_fbits((uint32_t)n);
     return f == 0 ? DC_GRP0 : (f == 2 ? DC_GRP2 : (f == 3 ? DC_GRP3 : DC_GRP4));
 }
+// (the environment is read once per plan, not once per list: three getenv per list were 1 ms of a 65 536-list plan)
+struct DecEnv {
+    bool nb256, pair;
+    DecEnv() : nb256(env_on("VIDC_LANE_NB256")),  // measurements: 256 buckets for the 257..1024-id lists too
+               pair(!env_on("VIDC_NO_LANE_PAIR") && !env_on("VIDC_NO_LANE_REG")) {}
+};
 inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane, bool allow_lane64,
-                          const GrpPolicy *grp = nullptr) {  // (allow_lane*: mid-size policies; grp: row-per-list kernels wanted)
+                          const GrpPolicy *grp, const DecEnv &env) {  // (allow_lane*: mid-size policies; grp: row-per-list kernels wanted)
     if (n <= TINY_MAX) return DC_TINY;
     const bool grp_ok = grp && n >= grp->min_n && n <= grp->max_n && P <= 32;
     if (grp_ok && grp->min_lists == 0) return grp_dec_class(n);  // VIDC_FORCE_GRP: ahead of every other family
@@ -1027,14 +1037,9 @@ inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general
         if (P <= 20) return DC_U20;
     }
     if (grp_ok) return grp_dec_class(n);
-    static const bool nb256 = env_on("VIDC_LANE_NB256");  // measurements: 256 buckets for the 257..1024-id lists too
-    // Opt-in (VIDC_LANE_PAIR=1).  The kernel is bit-exact by itself (GPU test-suite) and decodes 240 M ids of 400-id lists in 7.2 ms
-    // against 11.7 for the bucket-row decoder -- but with it in the mix, S2-sized calls (10^6 lists, 10^9 ids) came back with one
-    // wrong list in ~10 % of the decodes, in OTHER classes (general decoder lists of 4000..7500 ids), also when this kernel stored
-    // nothing at all (VIDC_PAIR_DRY=1); 0 of 160 decodes without it.  Not understood; see DESIGN section 10.
-    const bool no_pair = !env_on("VIDC_LANE_PAIR") || env_on("VIDC_NO_LANE_PAIR") || env_on("VIDC_NO_LANE_REG");
-    if (allow_lane && !no_pair && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_PAIR_MAX) return DC_LANEP;
-    if (allow_lane && nb256 && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_MAX) return DC_LANE64;
+    // lists of 257..512 ids: the register decoder on lane pairs (VIDC_NO_LANE_PAIR=1: the bucket-row decoder)
+    if (allow_lane && env.pair && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_PAIR_MAX) return DC_LANEP;
+    if (allow_lane && env.nb256 && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_MAX) return DC_LANE64;
     if (allow_lane && n <= VIDC_LANE_MAX) return DC_LANE;
     if (allow_lane64 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64) return DC_LANE64;
     if (n <= GEN_SMALL_MAX) return DC_GSMALL;
@@ -1069,6 +1074,7 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     const uint64_t u_min = U_MIN_LIST;
     bool allow_lane64 = false;
     const GrpPolicy gpol = grp_policy();
+    const DecEnv denv;
     bool use_grp = false;
     {
         uint64_t n_mid = 0, n_mid64 = 0, n_tiny = 0, n_grp = 0;
@@ -1087,7 +1093,7 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     for (uint32_t i = 0; i < lists.size(); i++) {
         uint32_t l = lists[i];
         uint64_t n = r->offsets[l + 1] - r->offsets[l];
-        cls[rows_flavour ? DC_TINY : dec_class(n, r->prec[l], u_min, f_general, allow_lane, allow_lane64, use_grp ? &gpol : nullptr)].push_back(i);
+        cls[rows_flavour ? DC_TINY : dec_class(n, r->prec[l], u_min, f_general, allow_lane, allow_lane64, use_grp ? &gpol : nullptr, denv)].push_back(i);
     }
     auto len = [&](uint32_t i) { return r->offsets[lists[i] + 1] - r->offsets[lists[i]]; };
     for (int c = 0; c < DC_COUNT; c++) {
@@ -1337,9 +1343,10 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         // three streams: a 4th one did not run concurrently (HIP maps streams onto 4 hardware queues and the
         // process has other streams; the kernels of aux[2] started when the main stream's had finished)
         double load[VIDC_NAUX + 1] = {};
-        // (wide: four streams -- S2 decodes in 84 / 85 / 89 / 104 ms with 4 / 5 / 8 / 3 of them: the classes share one
-        // bound, the random-access rate of HBM, so more overlap buys nothing once the machine is full)
-        int nq = ctx->wide ? 4 : 3;
+        // (wide: six streams -- S2 decodes in 85-88 / 86 / 92 ms with 8 / 6 / 4 of them (84 / 85 / 89 / 104 ms with 4 / 5 / 8 / 3
+        // before the lane-pair register decoder, whose 256-VGPR wavefronts want to start early): the classes share one bound, the
+        // random-access rate of HBM, so more overlap buys nothing once the machine is full)
+        int nq = ctx->wide ? 6 : 3;
         if (const char *e = std::getenv("VIDC_DEC_NQ")) nq = std::max(1, std::min(ctx->naux() + 1, std::atoi(e)));
         for (int k = 0; k < DC_COUNT; k++) {
             const int c = order[k];

@@ -682,11 +682,17 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const 
             const uint32_t sl = i >> 1;                       // slot, in the lane with the parity of the step
             const bool mine = ((lane ^ i) & 1u) == 0u;
             if (sl < (uint32_t)EL) {
-                const uint64_t m = __ballot(mine);
-                asm volatile("s_set_gpr_idx_on %[i], gpr_idx(SRC0,DST)\n\tv_cndmask_b32_e64 v64, v64, %[x], %[m]\n\ts_set_gpr_idx_off"
-                             : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
-                               "+{v[224:255]}"(e5)
-                             : [x] "v"(x), [i] "s"(sl), [m] "s"(m));
+                // The lanes of the other parity are masked off by exec, as in the one-lane-per-list kernel.  The first version wrote
+                // the slot with "v_cndmask_b32_e64 v64, v64, x, mask" under s_set_gpr_idx_on ..., gpr_idx(SRC0,DST): bit-exact by
+                // itself, but with it running, S2-sized decodes came back with a wrong list of ANOTHER kernel class in ~10 % of the
+                // calls (also when this kernel stored nothing to memory; 0 of 100 with this form) -- the SRC0-relative VOP3 write
+                // appears to land outside the wavefront's own registers.  DESIGN section 10.
+                if (mine) {
+                    asm volatile("s_set_gpr_idx_on %[i], gpr_idx(DST)\n\tv_mov_b32 v64, %[x]\n\ts_set_gpr_idx_off"
+                                 : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                                   "+{v[224:255]}"(e5)
+                                 : [x] "v"(x), [i] "s"(sl));
+                }
             } else if (act && mine) {
                 const uint32_t sidx = sl - (uint32_t)EL;
                 tail1[(sidx >> 2) * 256u + (sidx & 3u)] = x;
