@@ -60,3 +60,31 @@ def test_product_does_not_touch_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in src.replace("the oracle", "").lower() or f == "never", (dirpath, f)
+
+
+def test_build_staleness_is_decided_by_content_not_mtime(tmp_path):
+    """build.needs_build(): a `touch` of a source (or a checkout / copy that changes mtimes) must not trigger a recompile, a
+    changed byte must; the library is never compiled into place (temporary file + rename under a lock)."""
+    import os
+    import time
+
+    from vector_db_id_compression_amd import build
+
+    build.build()
+    assert not build.needs_build()
+    src = build.sources()[0]
+    st = os.stat(src)
+    try:
+        os.utime(src, (time.time() + 100, time.time() + 100))  # newer than libvidc.so
+        assert not build.needs_build()
+    finally:
+        os.utime(src, (st.st_atime, st.st_mtime))
+    h0 = build.source_hash()
+    hdr = os.path.join(build.CSRC, "_hash_probe.h")  # an extra header changes the hash of the source set
+    try:
+        open(hdr, "w").write("// probe\n")
+        assert build.source_hash() != h0 and build.needs_build()
+    finally:
+        os.remove(hdr)
+    assert build.source_hash() == h0 and not build.needs_build()
+    assert "os.replace" in open(build.__file__).read()
