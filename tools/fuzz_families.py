@@ -35,7 +35,7 @@ def make_batch(rng):
     elif kind == 3:
         sizes = np.minimum(rng.geometric(0.01, nlist), 5000)
     elif rng.random() < 0.25:  # the row kernels' geometry switches (512-position blocks, 8192, 16 384, 32 768, 65 536)
-        nlist = min(nlist, 12)
+        nlist = max(3, min(nlist, 12))
         sizes = np.concatenate([rng.integers(4000, 9000, nlist - 2), rng.choice([8192, 8193, 16384, 16385, 32768, 32769, 65536, 20000, 40000], 2)])
     else:  # the 1025..4096 lane class and its boundaries
         nlist = min(nlist, 40)
