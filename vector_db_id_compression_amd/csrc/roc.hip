@@ -109,15 +109,18 @@ inline bool env_on(const char *name) {  // set, not empty, not "0"
 // lists than the wave-per-list kernels keep resident.  Test hooks: VIDC_NO_GRP=1 (never), VIDC_FORCE_GRP=1 (every list
 // of 65 .. 131 072 ids), VIDC_GRP_MIN=<lists>, VIDC_GRP_MAXN=<ids> (measurements).
 constexpr uint64_t GRP_MIN_LISTS = 8192;
-struct GrpPolicy { uint64_t min_lists, min_n, max_n; };
+struct GrpPolicy { uint64_t min_lists, min_n, max_n, dec_max_n; };
 inline GrpPolicy grp_policy() {
     // (lists beyond 32 768 ids are chains of >= 40 ms at this family's 1.2 us per step: they keep the lower-latency
     // wave-per-list kernels unless VIDC_GRP_MAXN / VIDC_FORCE_GRP say otherwise)
-    GrpPolicy g{GRP_MIN_LISTS, VIDC_LANE_MAX64 + 1u, 32768u};
+    // Decode: up to 16 384 ids -- the 16 385..32 768-id lists are the longest chains next to the b2 / general-kernel lists of a
+    // big call, and their step under load is 1.7-2.6 us here against ~1 us on the general decoder (S2: 53-85 ms against 32).
+    GrpPolicy g{GRP_MIN_LISTS, VIDC_LANE_MAX64 + 1u, 32768u, 16384u};
     if (env_on("VIDC_NO_GRP") || env_on("VIDC_FORCE_GENERAL") || env_on("VIDC_OLD_U")) { g.min_lists = ~0ull; return g; }
-    if (env_on("VIDC_FORCE_GRP")) { g.min_lists = 0; g.min_n = VIDC_GRP_MIN_LIST; g.max_n = VIDC_GRP_MAX_LIST; }
+    if (env_on("VIDC_FORCE_GRP")) { g.min_lists = 0; g.min_n = VIDC_GRP_MIN_LIST; g.max_n = g.dec_max_n = VIDC_GRP_MAX_LIST; }
     if (const char *e = std::getenv("VIDC_GRP_MIN")) g.min_lists = (uint64_t)std::atoll(e);
     if (const char *e = std::getenv("VIDC_GRP_MAXN")) g.max_n = std::min<uint64_t>((uint64_t)std::atoll(e), VIDC_GRP_MAX_LIST);
+    if (const char *e = std::getenv("VIDC_GRP_DEC_MAXN")) g.dec_max_n = std::min<uint64_t>((uint64_t)std::atoll(e), VIDC_GRP_MAX_LIST);
     return g;
 }
 
@@ -1030,7 +1033,7 @@ struct DecEnv {
 inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane, bool allow_lane64,
                           const GrpPolicy *grp, const DecEnv &env) {  // (allow_lane*: mid-size policies; grp: row-per-list kernels wanted)
     if (n <= TINY_MAX) return DC_TINY;
-    const bool grp_ok = grp && n >= grp->min_n && n <= grp->max_n && P <= 32;
+    const bool grp_ok = grp && n >= grp->min_n && n <= grp->dec_max_n && P <= 32;
     if (grp_ok && grp->min_lists == 0) return grp_dec_class(n);  // VIDC_FORCE_GRP: ahead of every other family
     if (!f_general && n >= u_min) {
         if (P <= 18) return DC_U18;
@@ -1083,7 +1086,7 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             n_tiny += n <= TINY_MAX;
             n_mid += n > TINY_MAX && n <= VIDC_LANE_MAX;
             n_mid64 += n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64;
-            n_grp += n >= gpol.min_n && n <= gpol.max_n;
+            n_grp += n >= gpol.min_n && n <= gpol.dec_max_n;
         }
         use_grp = allow_b2 && !f_general && !rows_flavour && n_grp && n_grp >= gpol.min_lists;
         allow_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
@@ -1319,9 +1322,13 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         for (int c = 0; c < DC_COUNT; c++) { base[c] = acc; acc += p.count[c]; }
     }
     EventTimer t(ctx);
-    // classes run concurrently: the longest chains on the caller's stream, the rest on the auxiliary streams
-    VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-    for (int i = 0; i < ctx->naux(); i++) VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
+    // classes run concurrently: the longest chains on the caller's stream, the rest on the auxiliary streams (fork below)
+    // The lane-pair register decoder goes FIRST and alone when the call has other work for the whole machine: its wavefronts
+    // need 256 VGPRs, and next to memory-bound classes that fill the SIMDs with small wavefronts they wait for register
+    // space -- 6 ms alone on S2's 217 M ids, 73 ms as the tail of the call when everything starts at once.
+    // (measured on S2: 92-95 ms of decode against 86-87 with everything started at once -- the other classes take their ~85 ms
+    // whether or not these lists are among them; opt-in for measurements)
+    const bool pair_first = p.count[DC_LANEP] && p.wl.size() > 4 * p.count[DC_LANEP] / 3 && env_on("VIDC_PAIR_FIRST");
     // Stream assignment: a class's kernel lasts about max(its longest chain, its share of the machine); classes are
     // taken longest first and each goes to the stream that frees up first (LPT over 3 streams).  A fixed
     // assignment left three general classes back to back on one stream on S2 (70 + 45 + 18 ms) while the
@@ -1343,14 +1350,15 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         // three streams: a 4th one did not run concurrently (HIP maps streams onto 4 hardware queues and the
         // process has other streams; the kernels of aux[2] started when the main stream's had finished)
         double load[VIDC_NAUX + 1] = {};
-        // (wide: six streams -- S2 decodes in 85-88 / 86 / 92 ms with 8 / 6 / 4 of them (84 / 85 / 89 / 104 ms with 4 / 5 / 8 / 3
-        // before the lane-pair register decoder, whose 256-VGPR wavefronts want to start early): the classes share one bound, the
-        // random-access rate of HBM, so more overlap buys nothing once the machine is full)
-        int nq = ctx->wide ? 6 : 3;
+        // (wide: a stream per class.  S2 decode by stream count, final kernel set (row decoder up to 16 384 ids, lane-pair register
+        // decoder): 78-79 ms with 8, 84-85 with 6 -- a class queued behind the lane-pair launch, whose 256-VGPR wavefronts are slow
+        // to find room, becomes the tail; without that decoder 81-82 / 83-84)
+        int nq = ctx->wide ? VIDC_NAUX + 1 : 3;
         if (const char *e = std::getenv("VIDC_DEC_NQ")) nq = std::max(1, std::min(ctx->naux() + 1, std::atoi(e)));
         for (int k = 0; k < DC_COUNT; k++) {
             const int c = order[k];
             if (!p.count[c]) continue;
+            if (pair_first && c == DC_LANEP) { stream_of[c] = ctx->stream; continue; }
             int best = 0;
             for (int q = 1; q < nq; q++)
                 if (load[q] < load[best]) best = q;
@@ -1493,7 +1501,11 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         if (c == chain_class) VIDC_HIP(hipEventRecord(ctx->ev_chain[1], st_));
         return VIDC_OK;
     };
-    for (int k = 0; k < DC_COUNT; k++) VIDC_TRY(launch(order[k]));  // longest first
+    if (pair_first) VIDC_TRY(launch(DC_LANEP));
+    VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+    for (int i = 0; i < ctx->naux(); i++) VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
+    for (int k = 0; k < DC_COUNT; k++)  // longest first
+        if (!(pair_first && order[k] == DC_LANEP)) VIDC_TRY(launch(order[k]));
     for (int i = 0; i < ctx->naux(); i++) {
         VIDC_HIP(hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
         VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
