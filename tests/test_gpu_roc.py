@@ -768,3 +768,33 @@ def test_lane_pair_decoder_matches_bucket_decoder(roc, oracle, force_lane, monke
         got = got.cpu().numpy().view(np.uint64)
         for k, l in enumerate(sub):
             assert np.array_equal(got[int(goff[k]):int(goff[k + 1])], dec[int(off[l]):int(off[l + 1])])
+
+
+def test_lane_quad_decoder_matches_bucket_decoder(roc, oracle, force_lane, monkeypatch):
+    """Lists of 513..1024 ids decode on a QUAD of lanes with the ids in registers (k_roc_decode_lane_reg<192, 4>: slot i >> 2 of lane
+    i & 3, rank = sum of the four lanes; opt-in through VIDC_LANE_QUAD=1), by default on the bucket-row decoder.  Ragged sizes inside one
+    wavefront, the size boundaries (513, 767 / 768 / 769: the register / LDS slot switch at slot 192, 1023 / 1024), dense lists."""
+    rng = np.random.default_rng(92)
+    for nbits in (11, 14, 24, 31):
+        sizes = rng.integers(513, 1025, 300)
+        sizes[:12] = [1024, 1024, 1023, 769, 768, 767, 513, 514, 600, 896, 897, 1024]
+        sizes = np.minimum(sizes, (1 << nbits) - 1)
+        off, ids, lists = _random_lists(rng, sizes, nbits=nbits)
+        r = roc.encode(off, ids)
+        monkeypatch.setenv("VIDC_LANE_QUAD", "1")  # (opt-in: measured slower than the bucket rows, see roc.hip DecEnv)
+        dec = r.decode_all().cpu().numpy().view(np.uint64)
+        assert r.last_decode_nonclean == 0
+        monkeypatch.delenv("VIDC_LANE_QUAD")
+        dec2 = r.decode_all().cpu().numpy().view(np.uint64)
+        assert np.array_equal(dec, dec2)
+        monkeypatch.setenv("VIDC_LANE_QUAD", "1")
+        sub = list(range(14)) + [int(v) for v in rng.integers(0, len(lists), 10)]
+        for l in sub:
+            li = lists[l]
+            e = oracle.roc_encode(li, oracle.list_precision(li))
+            want = oracle.roc_decode(e["head"], e["words"], li.size, oracle.list_precision(li), e["mt_draws"])[0]
+            assert np.array_equal(dec[int(off[l]):int(off[l + 1])], want), (nbits, l)
+        got, goff = r.decode_lists(np.array(sub, dtype=np.uint64))
+        got = got.cpu().numpy().view(np.uint64)
+        for k, l in enumerate(sub):
+            assert np.array_equal(got[int(goff[k]):int(goff[k + 1])], dec[int(off[l]):int(off[l + 1])])

@@ -109,15 +109,17 @@ inline bool env_on(const char *name) {  // set, not empty, not "0"
 // lists than the wave-per-list kernels keep resident.  Test hooks: VIDC_NO_GRP=1 (never), VIDC_FORCE_GRP=1 (every list
 // of 65 .. 131 072 ids), VIDC_GRP_MIN=<lists>, VIDC_GRP_MAXN=<ids> (measurements).
 constexpr uint64_t GRP_MIN_LISTS = 8192;
-struct GrpPolicy { uint64_t min_lists, min_n, max_n, dec_max_n; };
+struct GrpPolicy { uint64_t min_lists, min_n, max_n, dec_max_n, dec_min_n; };
 inline GrpPolicy grp_policy() {
     // (lists beyond 32 768 ids are chains of >= 40 ms at this family's 1.2 us per step: they keep the lower-latency
     // wave-per-list kernels unless VIDC_GRP_MAXN / VIDC_FORCE_GRP say otherwise)
     // Decode: up to 16 384 ids -- the 16 385..32 768-id lists are the longest chains next to the b2 / general-kernel lists of a
     // big call, and their step under load is 1.7-2.6 us here against ~1 us on the general decoder (S2: 53-85 ms against 32).
-    GrpPolicy g{GRP_MIN_LISTS, VIDC_LANE_MAX64 + 1u, 32768u, 16384u};
+    GrpPolicy g{GRP_MIN_LISTS, VIDC_LANE_MAX64 + 1u, 32768u, 16384u, VIDC_LANE_MAX64 + 1u};
     if (env_on("VIDC_NO_GRP") || env_on("VIDC_FORCE_GENERAL") || env_on("VIDC_OLD_U")) { g.min_lists = ~0ull; return g; }
-    if (env_on("VIDC_FORCE_GRP")) { g.min_lists = 0; g.min_n = VIDC_GRP_MIN_LIST; g.max_n = g.dec_max_n = VIDC_GRP_MAX_LIST; }
+    if (env_on("VIDC_FORCE_GRP")) { g.min_lists = 0; g.min_n = g.dec_min_n = VIDC_GRP_MIN_LIST; g.max_n = g.dec_max_n = VIDC_GRP_MAX_LIST; }
+    if (const char *e = std::getenv("VIDC_GRP_MINN")) g.min_n = std::max<uint64_t>((uint64_t)std::atoll(e), VIDC_GRP_MIN_LIST);
+    if (const char *e = std::getenv("VIDC_GRP_DEC_MINN")) g.dec_min_n = std::max<uint64_t>((uint64_t)std::atoll(e), VIDC_GRP_MIN_LIST);
     if (const char *e = std::getenv("VIDC_GRP_MIN")) g.min_lists = (uint64_t)std::atoll(e);
     if (const char *e = std::getenv("VIDC_GRP_MAXN")) g.max_n = std::min<uint64_t>((uint64_t)std::atoll(e), VIDC_GRP_MAX_LIST);
     if (const char *e = std::getenv("VIDC_GRP_DEC_MAXN")) g.dec_max_n = std::min<uint64_t>((uint64_t)std::atoll(e), VIDC_GRP_MAX_LIST);
@@ -1003,7 +1005,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
 // (DC_LANE .. the last class: kernels that may hand a list back with VIDC_ST_RETRY)
 enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_B2T, DC_B2S, DC_B2L, DC_B2M,
                 DC_GRP0, DC_GRP2, DC_GRP3, DC_GRP4,   // row-per-list decoder by bucket bits 8 + F (roc_grp.h)
-                DC_LANEP, DC_COUNT };                  // 257..512 ids on a pair of lanes, ids in registers (k_roc_decode_lane_reg<.., true>)
+                DC_LANEP, DC_LANEQ, DC_COUNT };        // 257..512 / 513..1024 ids on a pair / quad of lanes, ids in registers (k_roc_decode_lane_reg<.., 2 / 4>)
 constexpr uint64_t B2_MIN_LIST = 4096;
 constexpr size_t B2_CAP = 1024;      // chains of k_roc_decode_b2 per call (four per CU of an MI355X: 1 MiB of member rows each)
 
@@ -1026,14 +1028,17 @@ inline DecClass grp_dec_class(uint64_t n) {
 }
 // (the environment is read once per plan, not once per list: three getenv per list were 1 ms of a 65 536-list plan)
 struct DecEnv {
-    bool nb256, pair;
+    bool nb256, pair, quad;
     DecEnv() : nb256(env_on("VIDC_LANE_NB256")),  // measurements: 256 buckets for the 257..1024-id lists too
-               pair(!env_on("VIDC_NO_LANE_PAIR") && !env_on("VIDC_NO_LANE_REG")) {}
+               pair(!env_on("VIDC_NO_LANE_PAIR") && !env_on("VIDC_NO_LANE_REG")),
+               // (quads of lanes for 513..1024 ids: opt-in.  Measured slower than the bucket rows: 65 536 x 1024 ids decode in 5.6
+               // instead of 4.1 ms -- 16 lists per 256-VGPR wavefront means two rounds of wavefronts per SIMD --, S2 84 instead of 78 ms)
+               quad(env_on("VIDC_LANE_QUAD") && !env_on("VIDC_NO_LANE_PAIR") && !env_on("VIDC_NO_LANE_REG")) {}
 };
 inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane, bool allow_lane64,
                           const GrpPolicy *grp, const DecEnv &env) {  // (allow_lane*: mid-size policies; grp: row-per-list kernels wanted)
     if (n <= TINY_MAX) return DC_TINY;
-    const bool grp_ok = grp && n >= grp->min_n && n <= grp->dec_max_n && P <= 32;
+    const bool grp_ok = grp && n >= grp->dec_min_n && n <= grp->dec_max_n && P <= 32;
     if (grp_ok && grp->min_lists == 0) return grp_dec_class(n);  // VIDC_FORCE_GRP: ahead of every other family
     if (!f_general && n >= u_min) {
         if (P <= 18) return DC_U18;
@@ -1042,6 +1047,7 @@ inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general
     if (grp_ok) return grp_dec_class(n);
     // lists of 257..512 ids: the register decoder on lane pairs (VIDC_NO_LANE_PAIR=1: the bucket-row decoder)
     if (allow_lane && env.pair && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_PAIR_MAX) return DC_LANEP;
+    if (allow_lane && env.quad && n > VIDC_LANE_PAIR_MAX && n <= VIDC_LANE_QUAD_MAX) return DC_LANEQ;
     if (allow_lane && env.nb256 && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_MAX) return DC_LANE64;
     if (allow_lane && n <= VIDC_LANE_MAX) return DC_LANE;
     if (allow_lane64 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64) return DC_LANE64;
@@ -1086,7 +1092,7 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             n_tiny += n <= TINY_MAX;
             n_mid += n > TINY_MAX && n <= VIDC_LANE_MAX;
             n_mid64 += n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64;
-            n_grp += n >= gpol.min_n && n <= gpol.dec_max_n;
+            n_grp += n >= gpol.dec_min_n && n <= gpol.dec_max_n;
         }
         use_grp = allow_b2 && !f_general && !rows_flavour && n_grp && n_grp >= gpol.min_lists;
         allow_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
@@ -1212,7 +1218,7 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             // re-spill scratch of the decoder stack (== roc_dec_stack_cap in the kernels); the lane-per-list decoders
             // keep what they push in LDS
             if (c != DC_LANE && c != DC_LANE64 && c < DC_GRP0) so += roc_dec_stack_cap((uint32_t)n, r->meta_host ? r->nwords[l] : 0u);
-            if (c == DC_LANEP) continue;  // no scratch of any kind
+            if (c == DC_LANEP || c == DC_LANEQ) continue;  // no scratch of any kind
             p.slots_off[k] = sl;
             if (c == DC_LANE) {
                 sl = (sl + 3) & ~(uint64_t)3;  // rows are read as uint4
@@ -1339,7 +1345,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         double est[DC_COUNT];
         for (int c = 0; c < DC_COUNT; c++) {
             order[c] = c;
-            const bool u = c == DC_U18 || c == DC_U20 || c == DC_B2 || c == DC_B2T || c == DC_B2S || c == DC_B2L || c == DC_B2M, lane = c == DC_LANE || c == DC_LANE64 || c == DC_LANEP;
+            const bool u = c == DC_U18 || c == DC_U20 || c == DC_B2 || c == DC_B2T || c == DC_B2S || c == DC_B2L || c == DC_B2M, lane = c == DC_LANE || c == DC_LANE64 || c == DC_LANEP || c == DC_LANEQ;
             const bool grpc = c >= DC_GRP0 && c <= DC_GRP4;
             // (constants fitted to the S2 timeline: general kernels ~2.5 G steps/s while they share the machine)
             const double step_us = u ? 0.4 : (lane ? 2.5 : (c == DC_TINY ? 0.5 : (grpc ? 1.5 : 1.2)));       // one chain step
@@ -1460,11 +1466,17 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 VIDC_TRY(set_big_lds((const void *)k_roc_decode_b2<256>, VIDC_B2L_LDS_BYTES(256u)));
                 hipLaunchKernelGGL(k_roc_decode_b2<256>, dim3(b.nwork), dim3(64), VIDC_B2L_LDS_BYTES(256u), st_, b, (const U2Div *)ctx->d_u2tab);
                 break;
+            case DC_LANEQ:
+                b.lpw = 16u;
+                if (env_on("VIDC_PAIR_DRY")) b.K = 0xdeadu;
+                hipLaunchKernelGGL((k_roc_decode_lane_reg<VIDC_LANE_REG_EL, 4>), dim3((b.nwork + 15u) / 16u), dim3(64), 0, st_, b,
+                                   (const LaneDiv *)ctx->d_ltab);
+                break;
             case DC_LANEP:
                 b.lpw = 32u;
                 if (env_on("VIDC_PAIR_DRY")) b.K = 0xdeadu;   // debug: no stores
                 if (env_on("VIDC_PAIR_NOP")) b.K = 0xdeaeu;   // debug: the kernel returns at once
-                hipLaunchKernelGGL((k_roc_decode_lane_reg<VIDC_LANE_REG_EL, true>), dim3((b.nwork + 31u) / 32u), dim3(64), 0, st_, b,
+                hipLaunchKernelGGL((k_roc_decode_lane_reg<VIDC_LANE_REG_EL, 2>), dim3((b.nwork + 31u) / 32u), dim3(64), 0, st_, b,
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
             case DC_GRP0:

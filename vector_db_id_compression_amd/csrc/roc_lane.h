@@ -572,33 +572,39 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
 // of i, so each lane still holds at most 256 slots, and the rank is the sum of the two lanes' counts (one DPP swap).  The
 // bucket-row decoder these lists used before read and wrote a random 64-byte line per step (S2: 114 bytes of HBM traffic
 // per id on 217 M ids); here a step touches no memory but the stream window and the output ring.
+// LPL = 4: the same on QUADS of lanes (16 lists per wavefront) for lists of 513 .. 1024 ids: slot i >> 2 of lane i & 3, rank = sum of
+// the four lanes (two DPP swaps).  65 536 lists of 1024 ids decode in the time of 1024 steps at ~400 instructions each instead
+// of 1024 steps of 3.6 us with a bucket row read and written back per step.
 #define VIDC_LANE_PAIR_MAX (2u * VIDC_LANE_REG_MAX)
-template <int EL, bool PAIR = false>
+#define VIDC_LANE_QUAD_MAX (4u * VIDC_LANE_REG_MAX)
+template <int EL, int LPL = 1>
 struct LaneRegGeom {
     static constexpr uint32_t TAIL = VIDC_LANE_REG_MAX - EL;          // slots kept in LDS
     static constexpr uint32_t TAIL_BYTES = TAIL * 64 * 4;             // uint4 tail4[TAIL / 4][64]
     static constexpr uint32_t RING_BYTES = 8 * 64 * 4;
     static constexpr uint32_t WIN_BYTES = VIDC_DWIN * 64 * 4;
     static constexpr uint32_t PST_BYTES = VIDC_DPST * 64 * 4;
-    static constexpr uint32_t NMAX = PAIR ? VIDC_LANE_PAIR_MAX : VIDC_LANE_REG_MAX;
+    static constexpr uint32_t NMAX = (uint32_t)LPL * VIDC_LANE_REG_MAX;
     static constexpr uint32_t LQ_BYTES = (NMAX + 4) * 4;  // floor(2^31 / d), d = 0 .. NMAX (a load per step otherwise)
     static constexpr uint32_t LDS_BYTES = TAIL_BYTES + RING_BYTES + WIN_BYTES + PST_BYTES + LQ_BYTES;
 };
-template <int EL, bool PAIR = false>
+template <int EL, int LPL = 1>  // LPL lanes per list: 1, 2 (pairs) or 4 (quads)
 __global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const LaneDiv *__restrict__ dtab) {
     static_assert(EL == 192, "the rank asm is generated for 192 slots in v64..v255");
-    using G = LaneRegGeom<EL, PAIR>;
+    static_assert(LPL == 1 || LPL == 2 || LPL == 4, "lanes per list");
+    constexpr bool PAIR = LPL > 1;
+    using G = LaneRegGeom<EL, LPL>;
     if (PAIR && a.K == 0xdeaeu) return;  // (debug: launch only)
     __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
     const uint32_t lane = lane_id();
     uint4 *tail4 = (uint4 *)smem + lane;                       // chunk c of this lane at tail4[c * 64]
     uint32_t *tail1 = (uint32_t *)smem + lane * 4u;            // slot s: tail1[(s >> 2) * 256 + (s & 3)]
     uint32_t *oring = (uint32_t *)(smem + G::TAIL_BYTES);
-    const uint32_t lpw = a.lpw ? a.lpw : (PAIR ? 32u : 64u);
-    const uint32_t lslot = PAIR ? lane >> 1 : lane;  // list of the wavefront this lane works on
+    const uint32_t lpw = a.lpw ? a.lpw : 64u / (uint32_t)LPL;
+    const uint32_t lslot = lane / (uint32_t)LPL;  // list of the wavefront this lane works on
     const uint32_t wi = blockIdx.x * lpw + lslot;
     const bool have = lslot < lpw && wi < a.nwork;
-    const bool writer = (!PAIR || (lane & 1u) == 0u) && a.K != 0xdeadu;  // the lane of a pair that stores the list's results (0xdead: debug dry run)
+    const bool writer = (lane & ((uint32_t)LPL - 1u)) == 0u && a.K != 0xdeadu;  // the lane of a pair that stores the list's results (0xdead: debug dry run)
     const uint32_t l = have ? a.worklist[wi] : 0u;
     const uint32_t n = have ? (uint32_t)(a.offsets[l + 1] - a.offsets[l]) : 0u;
     const uint64_t ooff = have ? (a.out_off ? a.out_off[wi] : a.offsets[l]) : 0ull;
@@ -663,8 +669,9 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const 
             x = (hi << 16) | lo;
         }
         // (PAIR: the lane with the parity of a step holds its id: after i steps at most (i + 1) / 2 slots of a lane are in use)
-        uint32_t r = rank_of(x, PAIR ? (i + 1u) >> 1 : i);
-        if (PAIR) r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0xb1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]: the partner's count
+        uint32_t r = rank_of(x, (i + (uint32_t)LPL - 1u) / (uint32_t)LPL);
+        if (LPL >= 2) r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0xb1, 0xf, 0xf, false);  // quad_perm [1, 0, 3, 2]: the partner's count
+        if (LPL == 4) r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x4e, 0xf, 0xf, false);  // quad_perm [2, 3, 0, 1]: the other pair's
         if (act) {
             // ---- IDX_push(r, i + 1), codec.cpp:44-63
             uint64_t h0 = head;
@@ -679,8 +686,8 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const 
         if (act) oring[(i & 7u) * 64u + lane] = x;
         // ---- slot i = x (lanes past their list only overwrite an empty slot they never read again)
         if (PAIR) {
-            const uint32_t sl = i >> 1;                       // slot, in the lane with the parity of the step
-            const bool mine = ((lane ^ i) & 1u) == 0u;
+            const uint32_t sl = i / (uint32_t)LPL;            // slot, in the lane with the parity (LPL = 4: residue mod 4) of the step
+            const bool mine = ((lane ^ i) & ((uint32_t)LPL - 1u)) == 0u;
             if (sl < (uint32_t)EL) {
                 // The lanes of the other parity are masked off by exec, as in the one-lane-per-list kernel.  The first version wrote
                 // the slot with "v_cndmask_b32_e64 v64, v64, x, mask" under s_set_gpr_idx_on ..., gpr_idx(SRC0,DST): bit-exact by
