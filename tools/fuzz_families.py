@@ -14,12 +14,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle.pyoracle import Oracle  # noqa: E402  (dev tool: the checker)
 from vector_db_id_compression_amd.codecs import RocLists  # noqa: E402
 
-MODES = {"lane": {"VIDC_FORCE_LANE": "1", "VIDC_NO_LANE": "0", "VIDC_FORCE_GENERAL": "0", "VIDC_FORCE_GRP": "0", "VIDC_NO_LANE_PAIR": "1"},
-         "wave": {"VIDC_FORCE_LANE": "0", "VIDC_NO_LANE": "1", "VIDC_FORCE_GENERAL": "0", "VIDC_FORCE_GRP": "0", "VIDC_NO_LANE_PAIR": "1"},
-         "general": {"VIDC_FORCE_LANE": "0", "VIDC_NO_LANE": "1", "VIDC_FORCE_GENERAL": "1", "VIDC_FORCE_GRP": "0", "VIDC_NO_LANE_PAIR": "1"},
+MODES = {"lane": {"VIDC_FORCE_LANE": "1", "VIDC_NO_LANE": "0", "VIDC_FORCE_GENERAL": "0", "VIDC_FORCE_GRP": "0", "VIDC_NO_LANE_PAIR": "1", "VIDC_LANE_QUAD": "0"},
+         "wave": {"VIDC_FORCE_LANE": "0", "VIDC_NO_LANE": "1", "VIDC_FORCE_GENERAL": "0", "VIDC_FORCE_GRP": "0", "VIDC_NO_LANE_PAIR": "1", "VIDC_LANE_QUAD": "0"},
+         "general": {"VIDC_FORCE_LANE": "0", "VIDC_NO_LANE": "1", "VIDC_FORCE_GENERAL": "1", "VIDC_FORCE_GRP": "0", "VIDC_NO_LANE_PAIR": "1", "VIDC_LANE_QUAD": "0"},
          # round 3: the row-per-list kernels (roc_grp.h, every list of 65 .. 131 072 ids) and the lane-pair register decoder
-         "row": {"VIDC_FORCE_LANE": "0", "VIDC_NO_LANE": "1", "VIDC_FORCE_GENERAL": "0", "VIDC_FORCE_GRP": "1", "VIDC_NO_LANE_PAIR": "1"},
-         "lane_pair": {"VIDC_FORCE_LANE": "1", "VIDC_NO_LANE": "0", "VIDC_FORCE_GENERAL": "0", "VIDC_FORCE_GRP": "0", "VIDC_NO_LANE_PAIR": "0"}}
+         "row": {"VIDC_FORCE_LANE": "0", "VIDC_NO_LANE": "1", "VIDC_FORCE_GENERAL": "0", "VIDC_FORCE_GRP": "1", "VIDC_NO_LANE_PAIR": "1", "VIDC_LANE_QUAD": "0"},
+         "lane_quad": {"VIDC_FORCE_LANE": "1", "VIDC_NO_LANE": "0", "VIDC_FORCE_GENERAL": "0", "VIDC_FORCE_GRP": "0", "VIDC_NO_LANE_PAIR": "0", "VIDC_LANE_QUAD": "1"},
+         "lane_pair": {"VIDC_FORCE_LANE": "1", "VIDC_NO_LANE": "0", "VIDC_FORCE_GENERAL": "0", "VIDC_FORCE_GRP": "0", "VIDC_NO_LANE_PAIR": "0", "VIDC_LANE_QUAD": "0"}}
 
 
 def make_batch(rng):
@@ -89,7 +90,7 @@ def main():
             got[name] = (info["heads"], info["nwords"], info["precision"], info["mt_draws"], r.all_words(), dec,
                          r.perm() if want_perm else np.zeros(0))
             nonclean = r.last_decode_nonclean
-        for name in ("wave", "general", "row", "lane_pair"):
+        for name in ("wave", "general", "row", "lane_pair", "lane_quad"):
             for a, b in zip(got["lane"], got[name]):
                 if not np.array_equal(a, b):
                     print("MISMATCH lane vs", name, "seed", seed, "batch", nb, "mode", mode, flush=True)
@@ -110,7 +111,7 @@ def main():
             assert np.array_equal(dec[int(off[l]):int(off[l + 1])].view(np.uint64), ref), (seed, nb, l)
         nb += 1
         nl += len(lists)
-    print(f"fuzz ok: seed {seed}, {nb} batches, {nl} lists, five kernel-family modes identical, oracle samples identical", flush=True)
+    print(f"fuzz ok: seed {seed}, {nb} batches, {nl} lists, six kernel-family modes identical, oracle samples identical", flush=True)
 
 
 if __name__ == "__main__":
