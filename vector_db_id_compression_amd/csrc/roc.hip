@@ -703,7 +703,13 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     {
         EventTimer t(ctx);
         VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-        for (int i = 0; i < ctx->naux(); i++) VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
+        // an auxiliary stream joins the call at its first launch (and only those are joined at the end: a small call that uses
+        // one of them does not pay event traffic for seven)
+        uint32_t aux_used = 0;
+        auto AUX = [&](int i) -> hipStream_t {
+            if (!(aux_used >> i & 1u)) { (void)hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0); aux_used |= 1u << i; }
+            return ctx->aux[i];
+        };
         // main stream: bitmap-20 lists and the deepest general class (the critical paths)
         ctx->chain_info[0][0] = ctx->chain_info[0][1] = ctx->chain_info[0][2] = ctx->chain_info[0][3] = 0;
         ctx->phase_ms[VIDC_PHASE_ROC_ENCODE_CHAIN] = 0;
@@ -739,7 +745,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             const U2Div *dt = (const U2Div *)ctx->d_u2tab;
             // (behind a 20-bit bitmap launch on the main stream these chains would only start when that one has finished:
             // S1 encode 12.5 -> 13.5 ms; they go to the first auxiliary stream then)
-            hipStream_t st_r2 = wl_u20.empty() ? ctx->stream : ctx->aux[0];
+            hipStream_t st_r2 = wl_u20.empty() ? ctx->stream : AUX(0);
             // (the bitmap of a launch whose longest list -- the first of the work list -- has at most 65 536 positions: 8 KiB)
             const bool small = r->offsets[wl_r2[0] + 1] - r->offsets[wl_r2[0]] <= 65536 && !env_on("VIDC_R2_BIG");
             if (small && want_perm) hipLaunchKernelGGL((k_roc_encode_r2<true, 10>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(10), st_r2, b, dt);
@@ -758,8 +764,10 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 while ((uint64_t)64 * 64 * rl3 < nmax3) rl3 <<= 1;
             }
             // (behind a chain launch on the main stream it would only start when that one has finished)
-            hipStream_t st_c3 = (!wl_r2.empty() && wl_u20.empty()) ? ctx->aux[0] : ctx->stream;
-            VIDC_TRY(launch_gen_on(st_c3, d_wl + base[5], (uint32_t)wl_c3.size(), rl3));
+            if (!wl_c3.empty()) {
+                hipStream_t st_c3 = (!wl_r2.empty() && wl_u20.empty()) ? AUX(0) : ctx->stream;
+                VIDC_TRY(launch_gen_on(st_c3, d_wl + base[5], (uint32_t)wl_c3.size(), rl3));
+            }
         }
         // The lane-per-list kernels and the throughput-bound general classes must not share the machine: on S2 the
         // 64-word lane class took 69 ms next to the 26 316-list general class (49 ms) -- 9 ms and ~35 ms when each
@@ -785,7 +793,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                     size_t k1 = k0;
                     while (k1 < w.size() && r->offsets[w[k1] + 1] - r->offsets[w[k1]] > lo) k1++;
                     const int sd = gmap[seg_no++ % gmap_n] - '0';
-                    hipStream_t st_g = (sd >= 1 && sd <= ctx->naux()) ? ctx->aux[sd - 1] : ctx->stream;
+                    hipStream_t st_g = (sd >= 1 && sd <= ctx->naux()) ? AUX(sd - 1) : ctx->stream;
                     RocEncArgs b = a;
                     b.worklist = d_wl + wbase + k0; b.nwork = (uint32_t)(k1 - k0);
                     const uint32_t nblk = (uint32_t)((n0 + 511) >> 9);
@@ -810,23 +818,23 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         }
         const bool lanes_present = !wl_l4.empty() || !wl_l16.empty() || !wl_l64.empty();
         // aux 0: mid-size general lists (calls without lane classes) and bitmap-18 lists
-        if (!lanes_present) VIDC_TRY(launch_gen_on(ctx->aux[0], d_wl + base[4], (uint32_t)wl_c2.size(), 8));
+        if (!lanes_present && !wl_c2.empty()) VIDC_TRY(launch_gen_on(AUX(0), d_wl + base[4], (uint32_t)wl_c2.size(), 8));
         if (!wl_u18.empty()) {
             const bool is_chain = wl_u20.empty();
-            if (is_chain) { note_chain(wl_u18, 18); VIDC_HIP(hipEventRecord(ctx->ev_chain[0], ctx->aux[0])); }
+            if (is_chain) { note_chain(wl_u18, 18); VIDC_HIP(hipEventRecord(ctx->ev_chain[0], AUX(0))); }
             RocEncArgs b = a;
             b.worklist = d_wl + base[1]; b.nwork = (uint32_t)wl_u18.size();
             const U2Div *dt = (const U2Div *)ctx->d_u2tab;
             if (old_u_kernels()) {
-                if (want_perm) hipLaunchKernelGGL((k_roc_encode_u<18, true>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->aux[0], b);
-                else hipLaunchKernelGGL((k_roc_encode_u<18, false>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, ctx->aux[0], b);
-            } else if (want_perm) hipLaunchKernelGGL((k_roc_encode_u2<18, true>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, ctx->aux[0], b, dt);
-            else hipLaunchKernelGGL((k_roc_encode_u2<18, false>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, ctx->aux[0], b, dt);
+                if (want_perm) hipLaunchKernelGGL((k_roc_encode_u<18, true>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, AUX(0), b);
+                else hipLaunchKernelGGL((k_roc_encode_u<18, false>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, AUX(0), b);
+            } else if (want_perm) hipLaunchKernelGGL((k_roc_encode_u2<18, true>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, AUX(0), b, dt);
+            else hipLaunchKernelGGL((k_roc_encode_u2<18, false>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, AUX(0), b, dt);
             VIDC_HIP(hipGetLastError());
-            if (is_chain) VIDC_HIP(hipEventRecord(ctx->ev_chain[1], ctx->aux[0]));
+            if (is_chain) VIDC_HIP(hipEventRecord(ctx->ev_chain[1], AUX(0)));
         }
         // aux 1: the lane-per-list kernels, then the general classes; aux 2: tiny lists
-        if (!lanes_present) VIDC_TRY(launch_gen_on(ctx->aux[1], d_wl + base[3], (uint32_t)wl_c1.size(), 1));
+        if (!lanes_present && !wl_c1.empty()) VIDC_TRY(launch_gen_on(AUX(1), d_wl + base[3], (uint32_t)wl_c1.size(), 1));
         for (int cls = 2; cls >= 0; cls--) {  // longest chains first
             const std::vector<uint32_t> &w = cls == 2 ? wl_l64 : (cls ? wl_l16 : wl_l4);
             if (w.empty()) continue;
@@ -847,20 +855,20 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 b2.worklist = b.worklist + n_big; b2.nwork = b.nwork - n_big;
                 b.nwork = n_big;
                 const dim3 g1((b.nwork + b.lpw - 1u) / b.lpw), g2((b2.nwork + b.lpw - 1u) / b.lpw);
-                if (b.nwork && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<64, true>), g1, dim3(64), 0, ctx->aux[1], b, dt);
-                else if (b.nwork) hipLaunchKernelGGL((k_roc_encode_lane<64, false>), g1, dim3(64), 0, ctx->aux[1], b, dt);
-                if (b2.nwork && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<32, true>), g2, dim3(64), 0, ctx->aux[1], b2, dt);
-                else if (b2.nwork) hipLaunchKernelGGL((k_roc_encode_lane<32, false>), g2, dim3(64), 0, ctx->aux[1], b2, dt);
+                if (b.nwork && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<64, true>), g1, dim3(64), 0, AUX(1), b, dt);
+                else if (b.nwork) hipLaunchKernelGGL((k_roc_encode_lane<64, false>), g1, dim3(64), 0, AUX(1), b, dt);
+                if (b2.nwork && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<32, true>), g2, dim3(64), 0, AUX(1), b2, dt);
+                else if (b2.nwork) hipLaunchKernelGGL((k_roc_encode_lane<32, false>), g2, dim3(64), 0, AUX(1), b2, dt);
             }
-            else if (cls == 0 && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<4, true>), grid, dim3(64), 0, ctx->aux[1], b, dt);
-            else if (cls == 0) hipLaunchKernelGGL((k_roc_encode_lane<4, false>), grid, dim3(64), 0, ctx->aux[1], b, dt);
-            else if (want_perm) hipLaunchKernelGGL((k_roc_encode_lane<16, true>), grid, dim3(64), 0, ctx->aux[1], b, dt);
-            else hipLaunchKernelGGL((k_roc_encode_lane<16, false>), grid, dim3(64), 0, ctx->aux[1], b, dt);
+            else if (cls == 0 && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<4, true>), grid, dim3(64), 0, AUX(1), b, dt);
+            else if (cls == 0) hipLaunchKernelGGL((k_roc_encode_lane<4, false>), grid, dim3(64), 0, AUX(1), b, dt);
+            else if (want_perm) hipLaunchKernelGGL((k_roc_encode_lane<16, true>), grid, dim3(64), 0, AUX(1), b, dt);
+            else hipLaunchKernelGGL((k_roc_encode_lane<16, false>), grid, dim3(64), 0, AUX(1), b, dt);
             VIDC_HIP(hipGetLastError());
         }
         if (lanes_present) {
-            VIDC_TRY(launch_gen_on(ctx->aux[1], d_wl + base[4], (uint32_t)wl_c2.size(), 8));
-            VIDC_TRY(launch_gen_on(ctx->aux[1], d_wl + base[3], (uint32_t)wl_c1.size(), 1));
+            if (!wl_c2.empty()) VIDC_TRY(launch_gen_on(AUX(1), d_wl + base[4], (uint32_t)wl_c2.size(), 8));
+            if (!wl_c1.empty()) VIDC_TRY(launch_gen_on(AUX(1), d_wl + base[3], (uint32_t)wl_c1.size(), 1));
         }
         if (ntiny) {
             RocEncArgs b = a;
@@ -868,14 +876,15 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             if (use_lane_tiny) {  // one list per lane (roc_lane.h)
                 const dim3 grid((b.nwork + 63u) / 64u);
                 const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
-                if (rows && K <= 32) hipLaunchKernelGGL((k_roc_encode_tiny_lane<32, true>), grid, dim3(64), 0, ctx->aux[2], b, dt);
-                else if (rows) hipLaunchKernelGGL((k_roc_encode_tiny_lane<64, true>), grid, dim3(64), 0, ctx->aux[2], b, dt);
-                else hipLaunchKernelGGL((k_roc_encode_tiny_lane<64, false>), grid, dim3(64), 0, ctx->aux[2], b, dt);
-            } else if (rows) hipLaunchKernelGGL(k_roc_encode_tiny<true>, dim3(b.nwork), dim3(64), 0, ctx->aux[2], b);
-            else hipLaunchKernelGGL(k_roc_encode_tiny<false>, dim3(b.nwork), dim3(64), 0, ctx->aux[2], b);
+                if (rows && K <= 32) hipLaunchKernelGGL((k_roc_encode_tiny_lane<32, true>), grid, dim3(64), 0, AUX(2), b, dt);
+                else if (rows) hipLaunchKernelGGL((k_roc_encode_tiny_lane<64, true>), grid, dim3(64), 0, AUX(2), b, dt);
+                else hipLaunchKernelGGL((k_roc_encode_tiny_lane<64, false>), grid, dim3(64), 0, AUX(2), b, dt);
+            } else if (rows) hipLaunchKernelGGL(k_roc_encode_tiny<true>, dim3(b.nwork), dim3(64), 0, AUX(2), b);
+            else hipLaunchKernelGGL(k_roc_encode_tiny<false>, dim3(b.nwork), dim3(64), 0, AUX(2), b);
             VIDC_HIP(hipGetLastError());
         }
         for (int i = 0; i < ctx->naux(); i++) {
+            if (!(aux_used >> i & 1u)) continue;
             VIDC_HIP(hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
             VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
         }
@@ -1515,10 +1524,17 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     };
     if (pair_first) VIDC_TRY(launch(DC_LANEP));
     VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-    for (int i = 0; i < ctx->naux(); i++) VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
+    uint32_t aux_used = 0;  // only the auxiliary streams that carry a class of this call are forked and joined
+    for (int c = 0; c < DC_COUNT; c++)
+        for (int i = 0; i < ctx->naux(); i++)
+            if (p.count[c] && stream_of[c] == ctx->aux[i] && !(aux_used >> i & 1u)) {
+                VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
+                aux_used |= 1u << i;
+            }
     for (int k = 0; k < DC_COUNT; k++)  // longest first
         if (!(pair_first && order[k] == DC_LANEP)) VIDC_TRY(launch(order[k]));
     for (int i = 0; i < ctx->naux(); i++) {
+        if (!(aux_used >> i & 1u)) continue;
         VIDC_HIP(hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
         VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
     }
