@@ -228,6 +228,13 @@ struct EventTimer {
         (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
         return ms;
     }
+    // the same in two halves, for a caller that synchronises the stream anyway (one host wait instead of two)
+    void mark() { (void)hipEventRecord(c->ev1, c->stream); }
+    double elapsed() {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        return ms;
+    }
 };
 
 int check_status(const std::vector<uint32_t> &status, const char *what) {
@@ -428,7 +435,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     tr.mark("persistent allocs");
     Scratch s_arena, s_status, s_sizes, s_sid, s_wl, s_maxid, s_flags, s_sum;
     bool light_prepass = false;
-    Pinned h_wl, h_pre;
+    Pinned h_wl, h_pre, h_off;
     const uint32_t arena_stride = rows ? (uint32_t)arena_words_for(K) : 0u;
     uint64_t arena_words = 0, nonempty = 0, ntiny = 0;
     if (rows) {
@@ -460,13 +467,11 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         arena_words = roc_arena_at(r->offsets.data(), 0, nlist);
         r->ntotal = offsets[nlist];
         VIDC_TRY(r->d_offsets.alloc(nlist + 1, ctx->dpool));
-        {
-            Pinned h_off;  // (released after the synchronisation below or at the next one)
-            VIDC_TRY(h_off.get(ctx, (nlist + 1) * 8));
-            std::memcpy(h_off.p, offsets, (nlist + 1) * 8);
-            VIDC_HIP(hipMemcpyAsync(r->d_offsets.p, h_off.p, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-            VIDC_HIP(hipStreamSynchronize(ctx->stream));
-        }
+        // (no synchronisation of its own: the staging block lives until the call returns, and the call synchronises several
+        // times before that)
+        VIDC_TRY(h_off.get(ctx, (nlist + 1) * 8));
+        std::memcpy(h_off.p, offsets, (nlist + 1) * 8);
+        VIDC_HIP(hipMemcpyAsync(r->d_offsets.p, h_off.p, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
         tr.mark("offsets");
         // The bitmap kernels own a whole CU's LDS (2^20-bit universe): latency-optimal for long lists, but only
         // num_cu lists in flight.  With many lists, short ones go to the high-occupancy kernels.
@@ -517,10 +522,11 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                                    dim3(256), 0, ctx->stream, d_ids, r->d_offsets.p, (uint32_t)nlist, precision_mode,
                                    s_maxid.as<uint32_t>(), s_flags.as<uint32_t>(), r->d_prec.p);
             VIDC_HIP(hipGetLastError());
-            kernel_ms += t.stop();
+            t.mark();
             VIDC_HIP(hipMemcpyAsync(h_pre.p, s_maxid.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
             VIDC_HIP(hipMemcpyAsync(h_pre.as<uint32_t>() + nlist, s_flags.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
             VIDC_HIP(hipStreamSynchronize(ctx->stream));
+            kernel_ms += t.elapsed();
             maxid = h_pre.as<uint32_t>();
             pflags = maxid + nlist;
             tr.mark("prepass kernel + d2h");
