@@ -476,6 +476,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         // The bitmap kernels own a whole CU's LDS (2^20-bit universe): latency-optimal for long lists, but only
         // num_cu lists in flight.  With many lists, short ones go to the high-occupancy kernels.
         const uint64_t u_min = U_MIN_LIST;
+        uint64_t n_tiny_lists = 0, n_mid_lists = 0;
         {
             uint64_t n_mid = 0, n_mid64 = 0, n_tiny = 0, n_grp = 0;
             {
@@ -494,6 +495,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 });
                 for (unsigned t = 0; t < parts; t++) { n_tiny += cnt[4 * t]; n_mid += cnt[4 * t + 1]; n_mid64 += cnt[4 * t + 2]; n_grp += cnt[4 * t + 3]; }
             }
+            n_tiny_lists = n_tiny; n_mid_lists = n_mid;
             use_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
             use_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
             use_lane_tiny = lane_wanted(lpol, n_tiny, LANE_MIN_TINY);
@@ -531,17 +533,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             pflags = maxid + nlist;
             tr.mark("prepass kernel + d2h");
             // what the decode planner needs later (kernel class, bucket geometry) is known right here
+            // (the precisions are filled in by the classification loop below: one pass over the lists instead of two)
             r->prec.resize(nlist);
             r->umax.assign(maxid, maxid + nlist);
-            par_ranges(nlist, par_parts(nlist), [&](uint64_t la, uint64_t lb, unsigned) {
-                for (uint64_t l = la; l < lb; l++) {
-                    const uint32_t m = maxid[l];
-                    r->prec[l] = offsets[l + 1] == offsets[l] ? 0u
-                                 : precision_mode >= 0    ? (uint32_t)precision_mode
-                                 : precision_mode == VIDC_PREC_EXACT ? (m ? 32u - (uint32_t)__builtin_clz(m) : 0u)
-                                                                     : (m > 1u ? 32u - (uint32_t)__builtin_clz(m - 1u) : 0u);
-                }
-            });
         } else {
             r->prec.assign(nlist, 0);  // tiny lists only: the planner does not look at their precision
         }
@@ -554,8 +548,19 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             std::vector<int64_t> bad_list(parts, -1);
             par_ranges(nlist, parts, [&](uint64_t la, uint64_t lb, unsigned tpart) {
                 std::vector<uint32_t> *w = &part_wl[(size_t)tpart * W_COUNT];
+                if (parts == 1) {  // (upper bounds from the counting pass: no regrowth while 65 536 lists are appended)
+                    w[W_TINY].reserve(n_tiny_lists);
+                    w[W_L4].reserve(use_lane ? n_mid_lists : 0);
+                }
                 for (uint64_t l = la; l < lb; l++) {
                     const uint64_t n = offsets[l + 1] - offsets[l];
+                    if (maxid) {
+                        const uint32_t m = maxid[l];
+                        r->prec[l] = n == 0 ? 0u
+                                     : precision_mode >= 0    ? (uint32_t)precision_mode
+                                     : precision_mode == VIDC_PREC_EXACT ? (m ? 32u - (uint32_t)__builtin_clz(m) : 0u)
+                                                                         : (m > 1u ? 32u - (uint32_t)__builtin_clz(m - 1u) : 0u);
+                    }
                     if (n <= TINY_MAX) { w[W_TINY].push_back((uint32_t)l); continue; }
                     if (pflags[l] & VIDC_PF_DOMAIN) {
                         if (bad_list[tpart] < 0) bad_list[tpart] = (int64_t)l;
@@ -591,6 +596,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 }
             std::vector<uint32_t> *dst[W_COUNT] = {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64, &wl_g2, &wl_g3};
             for (int c = 0; c < W_COUNT; c++) {
+                if (parts == 1) { dst[c]->swap(part_wl[c]); continue; }
                 size_t tot = 0;
                 for (unsigned t = 0; t < parts; t++) tot += part_wl[(size_t)t * W_COUNT + c].size();
                 dst[c]->reserve(tot);
@@ -711,8 +717,15 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
         // an auxiliary stream joins the call at its first launch (and only those are joined at the end: a small call that uses
         // one of them does not pay event traffic for seven)
+        // A call without a class for the caller's stream (no bitmap-20, deepest-general or position-bitmap lists: e.g. an index
+        // of equal-sized short lists, graph rows) gives that stream to the first auxiliary class it launches: the class then
+        // starts without the fork event and the call ends without its join (65 536 lists of 256 ids: ~0.1 ms of idle GPU
+        // between the event records of the encode).
+        const bool main_idle = wl_u20.empty() && wl_c3.empty() && wl_r2.empty();
+        int promoted = -1;
         uint32_t aux_used = 0;
         auto AUX = [&](int i) -> hipStream_t {
+            if (main_idle && (promoted < 0 || promoted == i)) { promoted = i; return ctx->stream; }
             if (!(aux_used >> i & 1u)) { (void)hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0); aux_used |= 1u << i; }
             return ctx->aux[i];
         };
@@ -896,8 +909,11 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         }
         // the kernels are in flight and the host has nothing to do until they finish: plan the decode of the whole
         // object now (7 ms per million lists that decode_all would otherwise spend on its critical path)
+        // (the end event is recorded first: the planning is host time, not part of the kernels' duration)
+        t.mark();
         if (!rows && nlist >= PLAN_AHEAD_MIN_LISTS && r->prec.size() == nlist) r->plan_ahead = plan_ahead_build(r.get());
-        kernel_ms += t.stop();
+        (void)hipEventSynchronize(ctx->ev1);
+        kernel_ms += t.elapsed();
         if (ctx->chain_info[0][3]) {  // (t.stop() synchronised the main stream, which joined the auxiliary ones)
             float cms = 0;
             if (hipEventElapsedTime(&cms, ctx->ev_chain[0], ctx->ev_chain[1]) == hipSuccess) ctx->phase_ms[VIDC_PHASE_ROC_ENCODE_CHAIN] = cms;
@@ -1114,6 +1130,11 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
         allow_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
         p.tiny_lane = lane_wanted(lpol, rows_flavour ? lists.size() : n_tiny, LANE_MIN_TINY);
     }
+    {
+        // (the classes that can hold most lists of a big call grow once, not by doubling)
+        const uint64_t nl = lists.size();
+        if (nl >= 4096) for (int c : {(int)DC_TINY, (int)DC_LANE, (int)DC_GSMALL}) cls[c].reserve(nl);
+    }
     for (uint32_t i = 0; i < lists.size(); i++) {
         uint32_t l = lists[i];
         uint64_t n = r->offsets[l + 1] - r->offsets[l];
@@ -1122,8 +1143,15 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     auto len = [&](uint32_t i) { return r->offsets[lists[i] + 1] - r->offsets[lists[i]]; };
     for (int c = 0; c < DC_COUNT; c++) {
         if (c != DC_TINY && cls[c].size() > 1) {  // counting sort by length, longest first (stable)
-            uint64_t maxlen = 0;
-            for (uint32_t i : cls[c]) maxlen = std::max<uint64_t>(maxlen, len(i));
+            uint64_t maxlen = 0, prev = ~0ull;
+            bool sorted_already = true;  // equal-sized lists, or an index whose lists come longest first: nothing to do
+            for (uint32_t i : cls[c]) {
+                const uint64_t n = len(i);
+                maxlen = std::max<uint64_t>(maxlen, n);
+                sorted_already &= n <= prev;
+                prev = n;
+            }
+            if (sorted_already) continue;
             std::vector<uint32_t> start(maxlen + 2, 0), sorted(cls[c].size());
             for (uint32_t i : cls[c]) start[maxlen - len(i) + 1]++;
             for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
@@ -1213,6 +1241,8 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     // LDS member rows for the short general lists only while all of them are resident at four per CU: beyond that the 33 KiB
     // per wavefront cost more in occupancy than the global rows cost in traffic (6000 x 300 ids: 0.86 vs 0.3 ms)
     p.gsmall_lrows = cls[DC_GSMALL].size() <= B2_CAP;
+    p.item.reserve(lists.size());
+    p.wl.reserve(lists.size());
     for (int c = 0; c < DC_COUNT; c++) {
         p.count[c] = cls[c].size();
         for (uint32_t i : cls[c]) {
