@@ -491,6 +491,9 @@ def main():
                     "elias_fano": secondary("uniform_16m", "ef"),
                     "graph_rows": secondary_graph(),
                     "c5": secondary("c5", "roc", floor=True),
+                    # the size a search issues (S1: 1 M ids / 1024 lists): launch-bound, a few kernels of ~10 us each
+                    "s1_elias_fano": secondary(wl, "ef"),
+                    "s1_packed_bits": secondary(wl, "packed"),
                 }
                 if not args.no_s2:  # BASELINE north_star's roofline workload: 1 B ids on one GPU, through the three codecs
                     torch.cuda.empty_cache()

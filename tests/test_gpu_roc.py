@@ -111,6 +111,55 @@ def test_unsorted_lists_and_decode_lists(roc, oracle):
         assert np.array_equal(d[int(doff[i]):int(doff[i + 1])], dec[int(off[l]):int(off[l + 1])])
 
 
+def test_lane_encoders_check_what_the_light_prepass_assumes(roc, oracle, monkeypatch):
+    """With lane-per-list classes in the call the prepass also looks at the last id of each list only: the lane encoders
+    compare every sampled id with its left neighbour and hand anything not strictly ascending (or outside [0, 2^31)) back to
+    the wave-per-list kernel.  Streams, precisions and permutation must equal the full prepass's and the oracle's."""
+    from vector_db_id_compression_amd import VidcError
+
+    monkeypatch.setenv("VIDC_FORCE_LANE", "1")
+    rng = np.random.default_rng(78)
+    lists = []
+    for k, n in enumerate([66, 100, 256, 257, 700, 1024, 1025, 3000, 4096, 150, 512, 2048]):
+        li = np.sort(rng.choice(1 << 22, size=n, replace=False)).astype(np.uint64)
+        if k % 3 == 0:  # unsorted, with a small last id: the precision taken from it is too small for the list
+            li = rng.permutation(li)
+            li[[-1, int(np.argmin(li))]] = li[[int(np.argmin(li)), -1]]
+        elif k % 3 == 1:  # one duplicate somewhere in the middle
+            li[n // 2] = li[n // 2 - 1]
+        lists.append(li)
+    for n in (80, 300, 1500):  # and clean ones next to them
+        lists.append(np.sort(rng.choice(1 << 22, size=n, replace=False)).astype(np.uint64))
+    off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
+    ids = np.concatenate(lists)
+    for mode in (-1, 22):
+        for want_perm in (False, True):
+            monkeypatch.delenv("VIDC_FULL_PREPASS", raising=False)
+            r = roc.encode(off, ids, precision_mode=mode, want_perm=want_perm)
+            monkeypatch.setenv("VIDC_FULL_PREPASS", "1")
+            r2 = roc.encode(off, ids, precision_mode=mode, want_perm=want_perm)
+            i1, i2 = r.info(), r2.info()
+            for k in ("heads", "nwords", "precision", "mt_draws"):
+                assert np.array_equal(i1[k], i2[k]), (mode, want_perm, k)
+            assert np.array_equal(r.all_words(), r2.all_words())
+            dec = r.decode_all().cpu().numpy().view(np.uint64)
+            assert np.array_equal(dec, r2.decode_all().cpu().numpy().view(np.uint64))
+            if want_perm:
+                assert np.array_equal(r.perm(), r2.perm())
+            if mode == -1:
+                _check_against_oracle(oracle, r, off, lists, r.perm() if want_perm else None, dec)
+    monkeypatch.delenv("VIDC_FULL_PREPASS", raising=False)
+    # an id outside [0, 2^31) in the middle of an ascending lane-class list (the last id is fine)
+    for n in (200, 900, 3000):
+        li = np.sort(rng.choice(1 << 20, size=n, replace=False)).astype(np.uint64)
+        for badv in (1 << 31, (1 << 40) + 5):
+            bad = li.copy()
+            bad[n // 3] = badv
+            both = np.concatenate([lists[-1], bad])
+            with pytest.raises(VidcError):
+                roc.encode(np.array([0, lists[-1].size, both.size], dtype=np.uint64), both)
+
+
 def test_empty_inputs(roc):
     r = roc.encode(np.array([0], dtype=np.uint64), np.zeros(0, np.uint64))
     assert r.nlist == 0 and r.ntotal == 0 and r.compressed_bytes == 0

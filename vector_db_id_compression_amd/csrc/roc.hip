@@ -509,12 +509,12 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             VIDC_TRY(s_flags.get(ctx, nlist * 4));
             VIDC_TRY(h_pre.get(ctx, nlist * 8));
             EventTimer t(ctx);
-            // Without lane-per-list classes in the call every kernel that takes a list streams it anyway and checks
-            // what the full prepass would (ids inside [0, 2^31), ascending order where it matters, ids that fit the
-            // precision): the prepass then only looks at the LAST id of each list -- the maximum of an ascending
+            // Every kernel that takes a list streams it anyway and checks what the full prepass would (ids inside
+            // [0, 2^31), ascending order where it matters, ids that fit the precision; the lane-per-list encoders since
+            // round 3: each sampled id against its left neighbour): the prepass only looks at the LAST id of each list -- the maximum of an ascending
             // list -- instead of re-reading all of them (8 bytes per id).  A list that turns out not to be ascending
             // comes back with VIDC_ST_PENDING_SORT and takes the sorting second pass like a multiset does.
-            light_prepass = !use_lane && !use_lane64 && !old_u_kernels() && !std::getenv("VIDC_FULL_PREPASS");
+            light_prepass = !old_u_kernels() && !std::getenv("VIDC_FULL_PREPASS");
             if (light_prepass)
                 hipLaunchKernelGGL(k_roc_prepass_last, dim3((uint32_t)((nlist + 255) / 256)), dim3(256), 0, ctx->stream, d_ids,
                                    r->d_offsets.p, (uint32_t)nlist, precision_mode, s_maxid.as<uint32_t>(),

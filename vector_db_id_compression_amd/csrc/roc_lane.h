@@ -9,7 +9,7 @@
 //
 //   encode step (codec.cpp:131-137): k = IDX_pop(n - i) with a table of reciprocals indexed by the divisor,
 //        select+remove the k-th alive position in a 3-level counted bitmap (<= 4 groups x 4 words x 64 bits),
-//        x = ids[position] (the input list is strictly ascending: checked by k_roc_prepass), ID_push(x, P)
+//        x = ids[position] (the input list is strictly ascending: checked here, id by id, as positions are sampled), ID_push(x, P)
 //   decode step (codec.cpp:140-152): x = ID_pop(P); rank of x among the decoded ids through bucket counters
 //        (64 buckets over the top bits, two-level byte counters in LDS) + the members of x's bucket (global
 //        memory, one 64/128-byte row); IDX_push(rank, i + 1)
@@ -318,6 +318,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
     // the divisor entry of step i + 1 is requested during step i: a per-lane load at the head of the step cost every step a
     // round trip to the table before its first instruction (65 536 lists of 256 ids: 326 -> 297 us)
     LaneDiv dv_next = dtab[n ? n : 1u];
+    bool disorder = false;
     for (uint32_t i = 0; i < nsteps; i++) {
         if (i < n) {
             // ---- k = IDX_pop(n - i), codec.cpp:21-42
@@ -366,7 +367,13 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
             const uint32_t b = lane_select64(word, k);
             bm[w * 64 + lane] = word & ~(1ull << b);
             const uint32_t pos = (w << 6) + b;
-            const uint32_t x = (uint32_t)ids[pos];
+            // the sampled id and its left neighbour (the same 64-byte line seven times out of eight): every position is
+            // sampled exactly once, so the list is checked to be strictly ascending -- what select over POSITIONS relies on
+            // -- and to lie below 2^31; the classification prepass then only needs the last id of each list (roc.hip)
+            const uint64_t xid = ids[pos];
+            const uint64_t xprev = pos ? ids[pos - 1u] : 0ull;
+            disorder |= (pos && xprev >= xid) || (xid >> 31) != 0ull;
+            const uint32_t x = (uint32_t)xid;
             if (WANT_PERM) pring[(i & 15u) * 64u] = pos;
 
             // ---- ID_push(x, P), codec.cpp:92-105
@@ -390,7 +397,8 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
         a.heads[l] = head;
         a.nwords[l] = st.sp;
         a.draws[l] = st.draws;
-        a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
+        // (not ascending / outside the domain: the wave-per-list kernel redoes the list and reports what is wrong with it)
+        a.status[l] = disorder ? VIDC_ST_PENDING_SORT : (st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK);
     }
 }
 
