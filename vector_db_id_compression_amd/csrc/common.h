@@ -161,6 +161,7 @@ struct vidc_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_chain[2] = {nullptr, nullptr};  // around the launch of the longest-chain kernel class of a ROC call
+    hipEvent_t ev_pre[3] = {};  // ROC encode, classification prepass read back late: before the kernel, behind it, behind its copies
     hipEvent_t tev[24] = {};   // event pairs of PhaseTimer (kernel phases timed without a host synchronisation each)
     // kernel classes of one call run concurrently: long chains on `stream`, shorter classes on these
     // (aux[0..2] always; aux[3..] only when the process has the hardware queues for them: HIP multiplexes its streams onto

@@ -152,6 +152,7 @@ int vidc_ctx_create(int device, vidc_ctx **out) {
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->ev_chain[0]) != hipSuccess || hipEventCreate(&c->ev_chain[1]) != hipSuccess ||
         [&] { for (auto &ev : c->tev) if (hipEventCreate(&ev) != hipSuccess) return true; return false; }() ||
+        [&] { for (auto &ev : c->ev_pre) if (hipEventCreate(&ev) != hipSuccess) return true; return false; }() ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         [&] { for (auto &ev : c->ev_join) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return true; return false; }() ||
         hipMalloc((void **)&c->d_mt, VIDC_MT_TABLE * sizeof(uint32_t)) != hipSuccess ||
@@ -208,6 +209,7 @@ void vidc_ctx_destroy(vidc_ctx *c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto &ev : c->ev_chain) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->tev) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->ev_pre) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (int i = 0; i < VIDC_NAUX; i++) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);

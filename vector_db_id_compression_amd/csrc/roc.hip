@@ -434,7 +434,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     if (want_perm) VIDC_TRY(r->d_perm.alloc(ntotal_in ? ntotal_in : 1, ctx->dpool));
     tr.mark("persistent allocs");
     Scratch s_arena, s_status, s_sizes, s_sid, s_wl, s_maxid, s_flags, s_sum;
-    bool light_prepass = false;
+    bool light_prepass = false, pre_deferred = false;
     Pinned h_wl, h_pre, h_off;
     const uint32_t arena_stride = rows ? (uint32_t)arena_words_for(K) : 0u;
     uint64_t arena_words = 0, nonempty = 0, ntiny = 0;
@@ -452,6 +452,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         r->offsets.assign(offsets, offsets + nlist + 1);
         r->offsets_host = true;
         bool any_big = false;
+        uint64_t max_n = 0;
         for (uint64_t l = 0; l < nlist; l++) {
             if (offsets[l + 1] < offsets[l]) { set_error("offsets not monotone at list %llu", (unsigned long long)l); return VIDC_ERR_INVALID; }
             uint64_t n = offsets[l + 1] - offsets[l];
@@ -462,6 +463,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 return VIDC_ERR_DOMAIN;
             }
             any_big |= n > TINY_MAX;
+            max_n = std::max(max_n, n);
             nonempty += n != 0;
         }
         arena_words = roc_arena_at(r->offsets.data(), 0, nlist);
@@ -515,6 +517,23 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             // list -- instead of re-reading all of them (8 bytes per id).  A list that turns out not to be ascending
             // comes back with VIDC_ST_PENDING_SORT and takes the sorting second pass like a multiset does.
             light_prepass = !old_u_kernels() && !std::getenv("VIDC_FULL_PREPASS");
+            // No list long enough for the bitmap kernels (the only classes chosen by the width of a list's ids): the host
+            // classifies by length alone and reads the maxima back when it needs them -- for the decode plan, while the
+            // encode kernels run -- instead of waiting for the prepass here (0.1 ms per call at 65 536 lists).  A last id
+            // outside the domain is then reported by the kernel that takes the list, like one in the middle of a list.
+            pre_deferred = light_prepass && max_n < u_min && !env_on("VIDC_NO_DEFER_PREPASS");
+            if (pre_deferred) {
+                VIDC_HIP(hipEventRecord(ctx->ev_pre[0], ctx->stream));
+                hipLaunchKernelGGL(k_roc_prepass_last, dim3((uint32_t)((nlist + 255) / 256)), dim3(256), 0, ctx->stream, d_ids,
+                                   r->d_offsets.p, (uint32_t)nlist, precision_mode, s_maxid.as<uint32_t>(),
+                                   s_flags.as<uint32_t>(), r->d_prec.p);
+                VIDC_HIP(hipGetLastError());
+                VIDC_HIP(hipEventRecord(ctx->ev_pre[1], ctx->stream));
+                VIDC_HIP(hipMemcpyAsync(h_pre.p, s_maxid.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+                VIDC_HIP(hipEventRecord(ctx->ev_pre[2], ctx->stream));
+                r->prec.resize(nlist);
+                tr.mark("prepass kernel (read back later)");
+            } else {
             if (light_prepass)
                 hipLaunchKernelGGL(k_roc_prepass_last, dim3((uint32_t)((nlist + 255) / 256)), dim3(256), 0, ctx->stream, d_ids,
                                    r->d_offsets.p, (uint32_t)nlist, precision_mode, s_maxid.as<uint32_t>(),
@@ -536,6 +555,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             // (the precisions are filled in by the classification loop below: one pass over the lists instead of two)
             r->prec.resize(nlist);
             r->umax.assign(maxid, maxid + nlist);
+            }
         } else {
             r->prec.assign(nlist, 0);  // tiny lists only: the planner does not look at their precision
         }
@@ -562,19 +582,20 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                                                                          : (m > 1u ? 32u - (uint32_t)__builtin_clz(m - 1u) : 0u);
                     }
                     if (n <= TINY_MAX) { w[W_TINY].push_back((uint32_t)l); continue; }
-                    if (pflags[l] & VIDC_PF_DOMAIN) {
+                    const uint32_t pf = pflags ? pflags[l] : 0u;  // (deferred prepass: no list of the call depends on them)
+                    if (pf & VIDC_PF_DOMAIN) {
                         if (bad_list[tpart] < 0) bad_list[tpart] = (int64_t)l;
                         continue;
                     }
-                    const uint32_t width = maxid[l] ? 32u - (uint32_t)__builtin_clz(maxid[l]) : 0u;  // ids < 2^width
+                    const uint32_t width = (maxid && maxid[l]) ? 32u - (uint32_t)__builtin_clz(maxid[l]) : 0u;  // ids < 2^width
                     // the bitmap kernels need no sort; they cannot report input positions of an unsorted list
-                    const bool u_ok = !f_general && !((pflags[l] & VIDC_PF_UNSORTED) && want_perm) &&
-                                      (n >= u_min || (pflags[l] & VIDC_PF_UNSORTED));
-                    const bool lane_ok = !(pflags[l] & VIDC_PF_UNSORTED) &&
+                    const bool u_ok = maxid && !f_general && !((pf & VIDC_PF_UNSORTED) && want_perm) &&
+                                      (n >= u_min || (pf & VIDC_PF_UNSORTED));
+                    const bool lane_ok = !(pf & VIDC_PF_UNSORTED) &&
                                          ((use_lane && n <= VIDC_LANE_MAX) ||
                                           (use_lane64 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64));
                     // (the row-per-list kernel samples positions: ascending input; it checks that itself under the light prepass)
-                    const bool grp_ok = use_grp && n >= gpol.min_n && n <= gpol.max_n && !(pflags[l] & VIDC_PF_UNSORTED);
+                    const bool grp_ok = use_grp && n >= gpol.min_n && n <= gpol.max_n && !(pf & VIDC_PF_UNSORTED);
                     const bool grp_first = grp_ok && gpol.min_lists == 0;  // VIDC_FORCE_GRP: ahead of every other family
                     const int cls = grp_first ? (n <= VIDC_GRP_LEV2_MAX ? W_G2 : W_G3)
                                     : (u_ok && width <= 18) ? W_U18
@@ -911,6 +932,20 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         // object now (7 ms per million lists that decode_all would otherwise spend on its critical path)
         // (the end event is recorded first: the planning is host time, not part of the kernels' duration)
         t.mark();
+        if (pre_deferred) {  // the maxima of the lists: precisions and bucket geometry for the decode planner
+            VIDC_HIP(hipEventSynchronize(ctx->ev_pre[2]));
+            const uint32_t *mx = h_pre.as<uint32_t>();
+            r->umax.assign(mx, mx + nlist);
+            for (uint64_t l = 0; l < nlist; l++) {
+                const uint32_t m = mx[l];
+                r->prec[l] = offsets[l + 1] == offsets[l] ? 0u
+                             : precision_mode >= 0    ? (uint32_t)precision_mode
+                             : precision_mode == VIDC_PREC_EXACT ? (m ? 32u - (uint32_t)__builtin_clz(m) : 0u)
+                                                                 : (m > 1u ? 32u - (uint32_t)__builtin_clz(m - 1u) : 0u);
+            }
+            float pms = 0;
+            if (hipEventElapsedTime(&pms, ctx->ev_pre[0], ctx->ev_pre[1]) == hipSuccess) kernel_ms += pms;
+        }
         if (!rows && nlist >= PLAN_AHEAD_MIN_LISTS && r->prec.size() == nlist) r->plan_ahead = plan_ahead_build(r.get());
         (void)hipEventSynchronize(ctx->ev1);
         kernel_ms += t.elapsed();
