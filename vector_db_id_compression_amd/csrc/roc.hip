@@ -1276,54 +1276,65 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     // LDS member rows for the short general lists only while all of them are resident at four per CU: beyond that the 33 KiB
     // per wavefront cost more in occupancy than the global rows cost in traffic (6000 x 300 ids: 0.86 vs 0.3 ms)
     p.gsmall_lrows = cls[DC_GSMALL].size() <= B2_CAP;
-    p.item.reserve(lists.size());
-    p.wl.reserve(lists.size());
-    for (int c = 0; c < DC_COUNT; c++) {
-        p.count[c] = cls[c].size();
-        for (uint32_t i : cls[c]) {
-            p.item.push_back(i); p.wl.push_back(lists[i]);
-            p.sum_n[c] += len(i);
-            p.max_n[c] = std::max<uint64_t>(p.max_n[c], len(i));
-        }
-    }
-    p.scratch_off.resize(p.wl.size());
-    p.slots_off.resize(p.wl.size());
+    // one pass per class over its work items: work list, per-class totals, scratch / slot offsets (65 536 lists: the two
+    // passes with push_back this replaces were half of the planner's time)
+    size_t total_items = 0;
+    for (int c = 0; c < DC_COUNT; c++) total_items += cls[c].size();
+    p.item.resize(total_items);
+    p.wl.resize(total_items);
+    p.scratch_off.resize(total_items);
+    p.slots_off.resize(total_items);
     uint64_t so = 0, sl = 0;
     size_t k = 0;
+    const uint64_t *offs = r->offsets.data();
+    const bool have_nwords = r->meta_host;
     for (int c = 0; c < DC_COUNT; c++) {
-        for (size_t j = 0; j < p.count[c]; j++, k++) {
-            uint32_t l = p.wl[k];
-            uint64_t n = r->offsets[l + 1] - r->offsets[l];
+        p.count[c] = cls[c].size();
+        uint64_t sum_n = 0, max_n = 0;
+        // re-spill scratch of the decoder stack (== roc_dec_stack_cap in the kernels); the lane-per-list decoders
+        // keep what they push in LDS
+        const bool stack_scratch = c != DC_LANE && c != DC_LANE64 && c < DC_GRP0;
+        for (const uint32_t i : cls[c]) {
+            const uint32_t l = lists[i];
+            const uint64_t n = offs[l + 1] - offs[l];
+            p.item[k] = i;
+            p.wl[k] = l;
+            sum_n += n;
+            max_n = std::max(max_n, n);
             p.scratch_off[k] = so;
-            // re-spill scratch of the decoder stack (== roc_dec_stack_cap in the kernels); the lane-per-list decoders
-            // keep what they push in LDS
-            if (c != DC_LANE && c != DC_LANE64 && c < DC_GRP0) so += roc_dec_stack_cap((uint32_t)n, r->meta_host ? r->nwords[l] : 0u);
-            if (c == DC_LANEP || c == DC_LANEQ) continue;  // no scratch of any kind
-            p.slots_off[k] = sl;
-            if (c == DC_LANE) {
+            if (stack_scratch) so += roc_dec_stack_cap((uint32_t)n, have_nwords ? r->nwords[l] : 0u);
+            uint64_t slot = sl;
+            if (c == DC_LANEP || c == DC_LANEQ) {
+                slot = 0;  // no scratch of any kind
+            } else if (c == DC_LANE) {
                 sl = (sl + 3) & ~(uint64_t)3;  // rows are read as uint4
-                p.slots_off[k] = sl;
+                slot = sl;
                 sl += 64ull * roc_lane_cap((uint32_t)n);
             } else if (c == DC_LANE64) {
                 sl = (sl + 3) & ~(uint64_t)3;
-                p.slots_off[k] = sl;
+                slot = sl;
                 sl += 256ull * roc_lane_cap_nb<256>((uint32_t)n);
             } else if (c >= DC_GRP0) {
                 sl = (sl + 15) & ~(uint64_t)15;  // member rows of 32 .. 96 u32: 64-byte aligned
-                p.slots_off[k] = sl;
+                slot = sl;
                 sl += roc_grp_dec_slots((uint32_t)n);
-            } else if (c == DC_U18 || c == DC_U20) sl += n;  // duplicate side list
-            else if (c == DC_B2) {
+            } else if (c == DC_U18 || c == DC_U20) {
+                sl += n;  // duplicate side list
+            } else if (c == DC_B2) {
                 sl = (sl + 63) & ~(uint64_t)63;  // 4096 rows of 64 members
-                p.slots_off[k] = sl;
+                slot = sl;
                 sl += 4096ull * 64ull;
-            }
-            else if (c == DC_GSMALL && p.gsmall_lrows) sl += n;  // overflow list only: the member rows are in LDS
-            else if (c >= DC_GSMALL && c <= DC_GHUGE) {
-                uint32_t fb = roc_dec_fine_bits((uint32_t)n, r->prec[l] > 32 ? 32 : r->prec[l]);
+            } else if (c == DC_GSMALL && p.gsmall_lrows) {
+                sl += n;  // overflow list only: the member rows are in LDS
+            } else if (c >= DC_GSMALL && c <= DC_GHUGE) {
+                const uint32_t fb = roc_dec_fine_bits((uint32_t)n, r->prec[l] > 32 ? 32 : r->prec[l]);
                 sl += ((uint64_t)1 << fb) * roc_dec_cap((uint32_t)n) + n;
             }
+            p.slots_off[k] = slot;
+            k++;
         }
+        p.sum_n[c] += sum_n;
+        p.max_n[c] = std::max<uint64_t>(p.max_n[c], max_n);
     }
     p.scratch_words = so;
     p.slots_words = sl;
