@@ -534,27 +534,27 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 r->prec.resize(nlist);
                 tr.mark("prepass kernel (read back later)");
             } else {
-            if (light_prepass)
-                hipLaunchKernelGGL(k_roc_prepass_last, dim3((uint32_t)((nlist + 255) / 256)), dim3(256), 0, ctx->stream, d_ids,
-                                   r->d_offsets.p, (uint32_t)nlist, precision_mode, s_maxid.as<uint32_t>(),
-                                   s_flags.as<uint32_t>(), r->d_prec.p);
-            else
-                hipLaunchKernelGGL(k_roc_prepass, dim3((uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 32)),
-                                   dim3(256), 0, ctx->stream, d_ids, r->d_offsets.p, (uint32_t)nlist, precision_mode,
-                                   s_maxid.as<uint32_t>(), s_flags.as<uint32_t>(), r->d_prec.p);
-            VIDC_HIP(hipGetLastError());
-            t.mark();
-            VIDC_HIP(hipMemcpyAsync(h_pre.p, s_maxid.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
-            VIDC_HIP(hipMemcpyAsync(h_pre.as<uint32_t>() + nlist, s_flags.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
-            VIDC_HIP(hipStreamSynchronize(ctx->stream));
-            kernel_ms += t.elapsed();
-            maxid = h_pre.as<uint32_t>();
-            pflags = maxid + nlist;
-            tr.mark("prepass kernel + d2h");
-            // what the decode planner needs later (kernel class, bucket geometry) is known right here
-            // (the precisions are filled in by the classification loop below: one pass over the lists instead of two)
-            r->prec.resize(nlist);
-            r->umax.assign(maxid, maxid + nlist);
+                if (light_prepass)
+                    hipLaunchKernelGGL(k_roc_prepass_last, dim3((uint32_t)((nlist + 255) / 256)), dim3(256), 0, ctx->stream, d_ids,
+                                       r->d_offsets.p, (uint32_t)nlist, precision_mode, s_maxid.as<uint32_t>(),
+                                       s_flags.as<uint32_t>(), r->d_prec.p);
+                else
+                    hipLaunchKernelGGL(k_roc_prepass, dim3((uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 32)),
+                                       dim3(256), 0, ctx->stream, d_ids, r->d_offsets.p, (uint32_t)nlist, precision_mode,
+                                       s_maxid.as<uint32_t>(), s_flags.as<uint32_t>(), r->d_prec.p);
+                VIDC_HIP(hipGetLastError());
+                t.mark();
+                VIDC_HIP(hipMemcpyAsync(h_pre.p, s_maxid.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+                VIDC_HIP(hipMemcpyAsync(h_pre.as<uint32_t>() + nlist, s_flags.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
+                VIDC_HIP(hipStreamSynchronize(ctx->stream));
+                kernel_ms += t.elapsed();
+                maxid = h_pre.as<uint32_t>();
+                pflags = maxid + nlist;
+                tr.mark("prepass kernel + d2h");
+                // what the decode planner needs later (kernel class, bucket geometry) is known right here
+                // (the precisions are filled in by the classification loop below: one pass over the lists instead of two)
+                r->prec.resize(nlist);
+                r->umax.assign(maxid, maxid + nlist);
             }
         } else {
             r->prec.assign(nlist, 0);  // tiny lists only: the planner does not look at their precision
