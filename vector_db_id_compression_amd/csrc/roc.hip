@@ -435,6 +435,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     tr.mark("persistent allocs");
     Scratch s_arena, s_status, s_sizes, s_sid, s_wl, s_maxid, s_flags, s_sum;
     bool light_prepass = false, pre_deferred = false;
+    bool wl_sorted[10] = {};  // work-list classes found longest-first while they were filled
     Pinned h_wl, h_pre, h_off;
     const uint32_t arena_stride = rows ? (uint32_t)arena_words_for(K) : 0u;
     uint64_t arena_words = 0, nonempty = 0, ntiny = 0;
@@ -566,6 +567,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             const unsigned parts = par_parts(nlist);
             std::vector<std::vector<uint32_t>> part_wl((size_t)parts * W_COUNT);
             std::vector<int64_t> bad_list(parts, -1);
+            bool cls_desc[W_COUNT];
+            uint64_t cls_last[W_COUNT];
+            for (int c = 0; c < W_COUNT; c++) { cls_desc[c] = parts == 1; cls_last[c] = ~0ull; }
             par_ranges(nlist, parts, [&](uint64_t la, uint64_t lb, unsigned tpart) {
                 std::vector<uint32_t> *w = &part_wl[(size_t)tpart * W_COUNT];
                 if (parts == 1) {  // (upper bounds from the counting pass: no regrowth while 65 536 lists are appended)
@@ -607,6 +611,10 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                                     : n <= 4096 ? W_C1
                                     : n <= 32768 ? W_C2 : W_C3;
                     w[cls].push_back((uint32_t)l);
+                    if (parts == 1) {  // (is the class already longest-first?  equal-sized lists: saves sort_desc's own pass)
+                        cls_desc[cls] &= n <= cls_last[cls];
+                        cls_last[cls] = n;
+                    }
                 }
             });
             for (unsigned t = 0; t < parts; t++)
@@ -616,6 +624,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                     return VIDC_ERR_DOMAIN;
                 }
             std::vector<uint32_t> *dst[W_COUNT] = {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64, &wl_g2, &wl_g3};
+            for (int c = 1; c < W_COUNT; c++) wl_sorted[c - 1] = cls_desc[c];  // (ws[] below: the classes without the tiny one)
             for (int c = 0; c < W_COUNT; c++) {
                 if (parts == 1) { dst[c]->swap(part_wl[c]); continue; }
                 size_t tot = 0;
@@ -638,7 +647,8 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 sort_desc(*ws[0], r->offsets);
                 for (auto &x : th) x.join();
             } else {
-                for (auto *w : ws) sort_desc(*w, r->offsets);
+                for (int c = 0; c < 10; c++)
+                    if (!wl_sorted[c]) sort_desc(*ws[c], r->offsets);
             }
         }
         // The longest general lists (any precision, more than 256 ids) take the position-bitmap chain kernel
