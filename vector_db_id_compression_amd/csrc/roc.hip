@@ -437,6 +437,12 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     bool light_prepass = false, pre_deferred = false;
     bool wl_sorted[10] = {};  // work-list classes found longest-first while they were filled
     Pinned h_wl, h_pre, h_off;
+    struct SyncOnExit {  // an early return while the deferred prepass copy is in flight must not release its staging blocks
+                        // (declared behind them: destroyed first)
+        vidc_ctx *c;
+        bool armed = false;
+        ~SyncOnExit() { if (armed) (void)hipStreamSynchronize(c->stream); }
+    } pre_guard{ctx};
     const uint32_t arena_stride = rows ? (uint32_t)arena_words_for(K) : 0u;
     uint64_t arena_words = 0, nonempty = 0, ntiny = 0;
     if (rows) {
@@ -532,6 +538,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 VIDC_HIP(hipEventRecord(ctx->ev_pre[1], ctx->stream));
                 VIDC_HIP(hipMemcpyAsync(h_pre.p, s_maxid.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
                 VIDC_HIP(hipEventRecord(ctx->ev_pre[2], ctx->stream));
+                pre_guard.armed = true;
                 r->prec.resize(nlist);
                 tr.mark("prepass kernel (read back later)");
             } else {
@@ -944,6 +951,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         t.mark();
         if (pre_deferred) {  // the maxima of the lists: precisions and bucket geometry for the decode planner
             VIDC_HIP(hipEventSynchronize(ctx->ev_pre[2]));
+            pre_guard.armed = false;
             const uint32_t *mx = h_pre.as<uint32_t>();
             r->umax.assign(mx, mx + nlist);
             for (uint64_t l = 0; l < nlist; l++) {
