@@ -370,8 +370,11 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
             // the sampled id and its left neighbour (the same 64-byte line seven times out of eight): every position is
             // sampled exactly once, so the list is checked to be strictly ascending -- what select over POSITIONS relies on
             // -- and to lie below 2^31; the classification prepass then only needs the last id of each list (roc.hip)
-            const uint64_t xid = ids[pos];
-            const uint64_t xprev = pos ? ids[pos - 1u] : 0ull;
+            // (one 16-byte load for both: a lane-class list has more than 64 ids, so ids[1] exists when pos is 0)
+            struct __attribute__((aligned(8))) IdPair { uint64_t a, b; };
+            const IdPair pr = *(const IdPair *)(ids + (pos ? pos - 1u : 0u));
+            const uint64_t xid = pos ? pr.b : pr.a;
+            const uint64_t xprev = pos ? pr.a : 0ull;
             disorder |= (pos && xprev >= xid) || (xid >> 31) != 0ull;
             const uint32_t x = (uint32_t)xid;
             if (WANT_PERM) pring[(i & 15u) * 64u] = pos;
