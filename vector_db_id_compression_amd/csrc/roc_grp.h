@@ -230,8 +230,11 @@ __global__ void __launch_bounds__(64) k_roc_encode_grp(RocEncArgs a, const U2Div
             // the sampled id and its left neighbour (same 64-byte line seven times out of eight): every position is sampled
             // exactly once, so the list is checked to be strictly ascending -- what select over POSITIONS relies on -- and,
             // with its last id below 2^31, to lie inside the domain
-            const uint64_t xid = ids[pos];
-            const uint64_t xprev = pos ? ids[pos - 1u] : 0ull;
+            // (one 16-byte load for both: a list of these kernels has at least VIDC_GRP_MIN_LIST ids, so ids[1] exists when pos is 0)
+            struct __attribute__((aligned(8))) IdPair { uint64_t a, b; };
+            const IdPair pr = *(const IdPair *)(ids + (pos ? pos - 1u : 0u));
+            const uint64_t xid = pos ? pr.b : pr.a;
+            const uint64_t xprev = pos ? pr.a : 0ull;
             disorder |= (pos && xprev >= xid) || (xid >> 31) != 0ull;
             const uint32_t x = (uint32_t)xid;
             if (WANT_PERM && st.w0) pring[i & 15u] = pos;
