@@ -1,0 +1,72 @@
+"""bench.py's own rank launcher (`python bench.py --gpus N` without torchrun), checked without a GPU: the command it
+re-executes must be the one the driver uses for N > 1 (one rank per GPU over RCCL, rendezvous on 127.0.0.1) with the
+caller's arguments passed through, and it must refuse a node with fewer GPUs than asked for."""
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    try:
+        return importlib.import_module("bench")
+    finally:
+        sys.path.pop(0)
+
+
+def test_gpus_flag_re_executes_under_torch_distributed_run(monkeypatch):
+    bench = _bench()
+    import subprocess
+
+    import torch
+
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    monkeypatch.delenv("RANK", raising=False)
+    bench.main()  # returns after the (faked) child launch: the parent measures nothing itself
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 0 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"  # dmabuf IPC: RCCL across processes on this driver
+
+
+def test_gpus_flag_refuses_a_node_with_fewer_gpus(monkeypatch):
+    bench = _bench()
+    import torch
+
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "only 1 GPU" in str(e.value)
+
+
+def test_child_failure_is_the_parents_exit_code(monkeypatch):
+    bench = _bench()
+    import subprocess
+
+    import torch
+
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: 3)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 3
