@@ -676,9 +676,10 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                         if (2 * (r->offsets[l + 1] - r->offsets[l]) < n_top || n_long > cap) break;
                         n_long++;
                     }
+                size_t take_cap = cap;
                 auto take = [&](std::vector<uint32_t> &w) {
                     size_t k = 0;
-                    while (k < w.size() && wl_r2.size() < cap && r->offsets[w[k] + 1] - r->offsets[w[k]] > R2_MIN_LIST) {
+                    while (k < w.size() && wl_r2.size() < take_cap && r->offsets[w[k] + 1] - r->offsets[w[k]] > R2_MIN_LIST) {
                         wl_r2.push_back(w[k]);
                         k++;
                     }
@@ -693,6 +694,11 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                     // still decide the call (65 536 steps at 0.9 us on the general kernel under load against ~0.7 here) and, with
                     // the bitmap sized for 65 536 positions (8 KiB instead of 32), no longer take the LDS the other classes need;
                     // the rest of the class (<= ~45 000 ids on S2) finishes earlier on the general kernel anyway.
+                    // Half as many again queue behind the resident ones in the same launch: each starts when one of the longest
+                    // chains has finished, still ends before the launch's longest chain would have on the general kernel, and
+                    // leaves that kernel ~500 fewer chains (S2 encode 59-62 -> 55-57 ms; all 1754: 59).  VIDC_R2_TAKE=<n>: measurements.
+                    take_cap = cap + cap / 2;
+                    if (const char *e = std::getenv("VIDC_R2_TAKE")) take_cap = (size_t)std::atoll(e);
                     take(wl_c3);
                 }
             }
