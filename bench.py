@@ -60,6 +60,22 @@ def cpu_baseline(offsets, ids, budget_s=20.0):
                 bits_per_id=8.0 * r["bytes"] / ntotal, bad_lists=r["bad_lists"])
 
 
+def committed_traffic(tag, alg_bytes):
+    """HBM-side bytes of one step of a workload from the PMC counters: collected offline (rocprofv3 cannot wrap its own caller;
+    tools/pmc_workload.sh / tools/pmc_s1.sh: separate FETCH_SIZE / WRITE_SIZE passes of this very command) and committed as
+    profiles/pmc_traffic_<tag>.json; tools/final_run.sh regenerates them.  None when the file is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"pmc_traffic_{tag}.json")) as f:
+            pt = json.load(f)
+        traffic = 1024.0 * (pt["fetch_KiB_per_step"] + pt["write_KiB_per_step"])
+        return {"traffic": traffic, "traffic_over_algorithmic": traffic / alg_bytes if alg_bytes else None,
+                "fetch_GiB": pt["fetch_KiB_per_step"] / 2 ** 20, "write_GiB": pt["write_KiB_per_step"] / 2 ** 20,
+                "source": f"profiles/pmc_traffic_{tag}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the "
+                          "kernels of a step; offline: the counters cannot be read from inside the timed process)"}
+    except Exception:
+        return None
+
+
 def per_list_multisets_equal(offsets, got, want, chunk=1 << 27):
     """Every list of `got` holds the same multiset of ids as the same list of `want` (both device int64, CSR `offsets`):
     keyed sort (list number, id) of both sides, in chunks cut on list boundaries.  A list-boundary bug fails this; a
@@ -284,9 +300,11 @@ def main():
         k_enc += te
         k_dec += td
     torch.cuda.synchronize()
+    t_own = time.perf_counter()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_own = t_own - t0  # this rank's K steps, before the closing barrier
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -339,7 +357,7 @@ def main():
         return {"list": l, "ids": b - a, "encode_ms": e / 3, "decode_ms": d / 3,
                 "us_per_step": {"encode": 1e3 * e / 3 / (b - a), "decode": 1e3 * d / 3 / (b - a)}}
 
-    def secondary(workload, codec, steps=3, floor=False):
+    def secondary(workload, codec, steps=3, floor=False, traffic_tag=None):
         """Short, untimed-by-the-driver measurement of another regime / codec (reported under `extra` only).
         `workload`: a name or an already generated workload dict (the 1 B-id set is generated once for the three codecs)."""
         w2 = synth.workload(workload, seed=1042 + rank) if isinstance(workload, str) else workload
@@ -385,8 +403,18 @@ def main():
         res2 = {"workload": w2["describe"], "codec": codec, "nlist": w2["nlist"], "max_list": w2["max_list"],
                 "median_list": w2["median_list"], "ids_per_s": w2["ntotal"] * steps / t_wall,
                 "ms_per_step": 1e3 * t_wall / steps, "kernel_ms": {"encode": ke / steps, "decode": kd / steps},
+                # wall clock of a step minus the hipEvent time of its kernels: host planning, launches, synchronisations
+                "host_ms_per_step": 1e3 * t_wall / steps - (ke + kd) / steps,
                 "bits_per_id": 8.0 * c2, "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
                 "per_list_roundtrip_ok": ok, "passes_checked": 4}
+        if traffic_tag:
+            alg2 = (16.0 + 2.0 * c2 + (4.0 if (codec == "roc" and want_perm) else 0.0)) * w2["ntotal"]
+            tr2 = committed_traffic(traffic_tag, alg2)
+            res2["algorithmic_bytes_per_step"] = alg2
+            res2["traffic"] = tr2["traffic"] if tr2 else None
+            res2["traffic_over_algorithmic"] = tr2["traffic_over_algorithmic"] if tr2 else None
+            if tr2:
+                res2["traffic_source"] = tr2["source"]
         if floor:
             del out2
             cf = chain_floor(w2, ids2)
@@ -419,7 +447,9 @@ def main():
                     ke += e_ms
                     kd += d_ms
             ok = bool(((dec >= 0).sum() == edges).item())
-            res[name] = {"edges_per_s": edges * steps / t_wall, "kernel_ms": {"encode": ke / steps, "decode": kd / steps},
+            res[name] = {"edges_per_s": edges * steps / t_wall, "ms_per_step": 1e3 * t_wall / steps,
+                         "kernel_ms": {"encode": ke / steps, "decode": kd / steps},
+                         "host_ms_per_step": 1e3 * t_wall / steps - (ke + kd) / steps,
                          "bits_per_edge": 8.0 * g.compressed_bytes / edges, "edge_count_ok": ok}
         return res
 
@@ -437,14 +467,19 @@ def main():
     traffic = None
     traffic_note = None
     if args.codec == "roc" and args.workload == "s1":
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic_s1.json")) as f:
-                pt = json.load(f)
-            traffic = 1024.0 * (pt["fetch_KiB_per_step"] + pt["write_KiB_per_step"])
+        pt = committed_traffic("s1", alg_bytes)
+        if pt:
+            traffic = pt["traffic"]
             traffic_note = ("bytes per step, FETCH_SIZE + WRITE_SIZE summed over the ROC kernels of a step (rocprofv3 --pmc, "
                             "separate passes, raw counters: gfx950 counts wide coalesced reads at half their bytes)")
-        except Exception:
-            pass
+
+    # per-rank step time (weak scaling): what the ">= 6x at 8 GPUs" target is read from the day a multi-GPU run exists
+    per_rank_ms = [1e3 * elapsed_own / args.steps]
+    if dist is not None and world > 1:
+        mine = torch.tensor([per_rank_ms[0]], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [float(x.item()) for x in allr]
 
     if rank == 0:
         res = {
@@ -468,6 +503,10 @@ def main():
             "bits_per_id": 8.0 * c,
             "verified_roundtrip": verified,
             "kernel_ms": {"encode": k_enc / args.steps, "decode": k_dec / args.steps},
+            "host_ms_per_step": 1e3 * elapsed / args.steps - (k_enc + k_dec) / args.steps,
+            # every rank's own K steps (max over ranks + the closing barrier = ms_per_step): load balance of the weak form
+            "per_rank": {"ms_per_step": per_rank_ms, "spread_ms": max(per_rank_ms) - min(per_rank_ms),
+                         "class_streams": ctx.class_streams()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
@@ -486,7 +525,7 @@ def main():
             # (no long serial chain) and the two bandwidth-bound codecs of the same plugin surface
             try:
                 res["extra"] = {
-                    "roc_many_equal_lists": secondary("uniform_16m", "roc"),
+                    "roc_many_equal_lists": secondary("uniform_16m", "roc", traffic_tag="uniform_16m_roc"),
                     "packed_bits": secondary("uniform_16m", "packed"),
                     "elias_fano": secondary("uniform_16m", "ef"),
                     "graph_rows": secondary_graph(),
@@ -498,9 +537,9 @@ def main():
                 if not args.no_s2:  # BASELINE north_star's roofline workload: 1 B ids on one GPU, through the three codecs
                     torch.cuda.empty_cache()
                     ws2 = synth.workload("s2", seed=1042 + rank)
-                    res["extra"]["s2"] = secondary(ws2, "roc", steps=2, floor=True)
-                    res["extra"]["s2_elias_fano"] = secondary(ws2, "ef", steps=2)
-                    res["extra"]["s2_packed_bits"] = secondary(ws2, "packed", steps=2)
+                    res["extra"]["s2"] = secondary(ws2, "roc", steps=2, floor=True, traffic_tag="s2_roc")
+                    res["extra"]["s2_elias_fano"] = secondary(ws2, "ef", steps=2, traffic_tag="s2_ef")
+                    res["extra"]["s2_packed_bits"] = secondary(ws2, "packed", steps=2, traffic_tag="s2_packed")
                     del ws2
             except Exception as e:
                 res["extra"] = {"error": str(e)}

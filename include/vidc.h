@@ -67,6 +67,12 @@ int vidc_ctx_synchronize(vidc_ctx *ctx);
  * context's stream and releases every cached block that is not in use; *freed_bytes (optional) = device + pinned
  * bytes returned to the driver.  Blocks held by live objects are untouched. */
 int vidc_ctx_trim(vidc_ctx *ctx, uint64_t *freed_bytes);
+/* Streams the kernel classes of one large ROC call are spread over: 8 when the PROCESS was started with the ROCm runtime
+ * variable GPU_MAX_HW_QUEUES >= 8 (HIP multiplexes a process's streams onto that many hardware queues, default 4, and reads
+ * the variable when it initialises: export it before the process starts -- for a Faiss-hosted process in the environment of
+ * the Python / C++ program that loads Faiss, not after `import faiss`), otherwise 4.  The published S2 numbers are the 8-stream
+ * mode; the 4-stream mode is ~10 % slower on calls of ~10^6 lists and identical on small calls.  Returns 0 for NULL. */
+int vidc_ctx_class_streams(const vidc_ctx *ctx);
 /* Device memory helpers for hosts without their own allocator (Python uses torch tensors instead). */
 int vidc_dev_alloc(vidc_ctx *ctx, size_t bytes, void **dev_ptr);
 int vidc_dev_free(vidc_ctx *ctx, void *dev_ptr);

@@ -11,16 +11,19 @@
  *   CompressedIDInvertedListsEliasFano    (.cpp:229-339)          vidc_faiss::EliasFanoInvertedLists
  *   CompressedIDInvertedListsPackedBits   (.cpp:64-118)           vidc_faiss::PackedBitsInvertedLists
  *   CompressedIDInvertedListsWaveletTree  (.cpp:346-397)          vidc_faiss::WaveletTreeInvertedLists
- *   CompactBitNSGGraph / EliasFanoNSGGraph / ROCNSGGraph          vidc_faiss::CompactBitNSGGraph / EliasFanoNSGGraph / ROCNSGGraph
+ *   CompactBitNSGGraph / EliasFanoNSGGraph / ROCNSGGraph          vidc_faiss::CompactBitGraph / EliasFanoGraph / ROCGraph
  *   (altid_impl.cpp:20-165)
  *   search_IVF_defer_id_decoding          (.cpp:407-526)          vidc_faiss::search_IVF_defer_id_decoding: the OpenMP loop
  *                                                                 over touched lists (:508-525) is ONE vidc_*_decode_lists call,
  *                                                                 the OpenMP loop of decode_1by1 (:464-474) ONE vidc_*_get call
  *
- * With VIDC_FAISS_REFERENCE_NAMES defined before the include, the reference's own class names are exported at global scope
+ * With VIDC_FAISS_REFERENCE_NAMES defined before the include, the reference's own class names exist at global scope
  * (CompressedIDInvertedListsFenwickTree, ...EliasFano, ...PackedBits, ...WaveletTree, CompactBitNSGGraph, EliasFanoNSGGraph,
- * ROCNSGGraph, search_IVF_defer_id_decoding): the SWIG modules then carry the names bench_invlists.py:19-25 and
- * graph_dynamic_bench_invlists.py:21-26 look up, and the harnesses run unchanged.
+ * ROCNSGGraph, search_IVF_defer_id_decoding) as DERIVED structs with the reference's constructor signatures -- not as alias
+ * declarations: SWIG treats `using A = B;` as a typedef and would generate the Python proxy under B's name only, while a derived
+ * struct is wrapped under its own name.  The SWIG modules then carry the names bench_invlists.py:19-25 and
+ * graph_dynamic_bench_invlists.py:21-26 look up, and the harnesses run unchanged (INTEGRATION.md section 2 has the .swig diff).
+ * Everything SWIG need not see (thread contexts, staging, the row cache) is fenced with `#ifndef SWIG`.
  *
  * Needs the Faiss headers, include/vidc.h and -lvidc.  Faiss is not installed in this repository's build image: the
  * header is compiled and exercised there against the interface shim of tests/faiss_shim (tests/test_boundary.py,
@@ -56,6 +59,7 @@ namespace vidc_faiss {
 
 #define VIDC_FAISS_CHECK(expr) FAISS_THROW_IF_NOT_MSG((expr) == VIDC_OK, vidc_last_error())
 
+#ifndef SWIG /* implementation detail: not part of the wrapped surface */
 /* per-thread context + pooled device staging */
 struct ThreadCtx {
     vidc_ctx* h = nullptr;
@@ -109,6 +113,7 @@ struct DeviceArray {
     DeviceArray(const DeviceArray&) = delete;
     DeviceArray& operator=(const DeviceArray&) = delete;
 };
+#endif /* SWIG */
 
 /* ---------------------------------------------------------------------------------------------------------------
  * InvertedListsArrayCodes (custom_invlists_impl.h:22-33): CSR of the list sizes + the vector codes, optionally
@@ -194,12 +199,16 @@ struct CompressedInvertedLists : faiss::ReadOnlyInvertedLists {
      * override it with their vidc_*_get; the default -- ROC, whose get_single_id IS get_ids()[offset] in the reference
      * (faiss::InvertedLists::get_single_id) -- decodes the touched lists once and indexes them. */
     virtual void get_single_ids(uint64_t m, const uint64_t* list_nos, const uint64_t* offs, faiss::idx_t* ids_out) const {
-        std::unordered_map<uint64_t, size_t> slot;
-        std::vector<uint64_t> lists;
-        for (uint64_t i = 0; i < m; i++)
+        /* (scratch of the calling thread, reused from call to call) */
+        thread_local std::unordered_map<uint64_t, size_t> slot;
+        thread_local std::vector<uint64_t> lists, out_off;
+        thread_local std::vector<faiss::idx_t> ids;
+        slot.clear();
+        lists.clear();
+        for (uint64_t i = 0; i < m; i++) {
+            FAISS_THROW_IF_NOT_MSG(list_nos[i] < nlist && offs[i] < list_size(list_nos[i]), "get_single_ids: (list, offset) out of range");
             if (slot.emplace(list_nos[i], lists.size()).second) lists.push_back(list_nos[i]);
-        std::vector<faiss::idx_t> ids;
-        std::vector<uint64_t> out_off;
+        }
         decode_lists_host(lists.size(), lists.data(), ids, out_off);
         for (uint64_t i = 0; i < m; i++) ids_out[i] = ids[out_off[slot[list_nos[i]]] + offs[i]];
     }
@@ -407,13 +416,24 @@ inline void search_IVF_defer_id_decoding(const faiss::IndexIVF& index, faiss::id
 #ifndef VIDC_FAISS_ROW_CACHE_ROWS
 #define VIDC_FAISS_ROW_CACHE_ROWS 16384
 #endif
+#ifndef VIDC_FAISS_ROW_CACHES
+#define VIDC_FAISS_ROW_CACHES 4 /* graphs a thread can alternate between without losing their cached rows */
+#endif
+#ifndef SWIG
 struct RowCache {
-    uint64_t owner = 0; /* id of the graph object the rows belong to */
+    uint64_t owner = 0; /* id of the graph object the rows belong to (0 = unused) */
+    uint64_t stamp = 0; /* last use (least recently used cache of the thread is recycled) */
     int K = 0;
     std::vector<int32_t> tag;     /* node held by a slot, -1 = empty */
     std::vector<uint32_t> count;
     std::vector<int32_t> rows;    /* slot * K */
     size_t hits = 0, misses = 0;
+    /* scratch of the miss path (kept: a miss allocates nothing once the vectors have grown) */
+    std::vector<int> want;
+    std::vector<size_t> slots;
+    std::vector<int32_t> buf;
+    std::vector<uint32_t> cnt;
+    std::vector<uint64_t> nd;
     void reset(uint64_t o, int k) {
         owner = o; K = k;
         tag.assign(VIDC_FAISS_ROW_CACHE_ROWS, -1);
@@ -423,11 +443,30 @@ struct RowCache {
     }
     static size_t slot_of(int node) { return ((uint32_t)node * 2654435761u >> 7) & (VIDC_FAISS_ROW_CACHE_ROWS - 1); }
 };
-inline RowCache& thread_row_cache() {
-    thread_local RowCache c;
-    return c;
+/* the calling thread's cache for graph object `owner`: a thread that alternates between graphs (e.g. comparing containers
+ * query by query) keeps one cache per graph, up to VIDC_FAISS_ROW_CACHES of them */
+struct RowCacheSet {
+    RowCache c[VIDC_FAISS_ROW_CACHES];
+    uint64_t clock = 0;
+    size_t resets = 0;
+    RowCache& get(uint64_t owner, int K) {
+        RowCache* lru = &c[0];
+        for (RowCache& x : c) {
+            if (x.owner == owner && x.K == K) { x.stamp = ++clock; return x; }
+            if (x.stamp < lru->stamp) lru = &x;
+        }
+        lru->reset(owner, K);
+        lru->stamp = ++clock;
+        resets++;
+        return *lru;
+    }
+};
+inline RowCacheSet& thread_row_caches() {
+    thread_local RowCacheSet s;
+    return s;
 }
 static_assert((VIDC_FAISS_ROW_CACHE_ROWS & (VIDC_FAISS_ROW_CACHE_ROWS - 1)) == 0, "power of two");
+#endif /* SWIG */
 
 struct CompressedNSGGraph : faiss::nsg::Graph<int32_t> {
     size_t compressed_ids_size_in_bytes = 0, overhead_in_bytes = 0;
@@ -443,45 +482,47 @@ struct CompressedNSGGraph : faiss::nsg::Graph<int32_t> {
     void get_neighbors_batch(size_t m, const int* nodes, int32_t* out, uint32_t* counts = nullptr) const {
         if (!m) return;
         ThreadCtx& t = thread_ctx();
-        std::vector<uint64_t> nd(nodes, nodes + m);
-        std::vector<uint32_t> cnt(m);
+        RowCache& c = thread_row_caches().get(object_id, K); /* (its scratch vectors: no allocation per call) */
+        c.nd.assign(nodes, nodes + m);
+        c.cnt.resize(m);
         int32_t* d = (int32_t*)t.staging(m * (size_t)K * 4);
         t.device_calls++;
-        VIDC_FAISS_CHECK(decode_rows_device(t.ctx(), m, nd.data(), d, cnt.data()));
+        VIDC_FAISS_CHECK(decode_rows_device(t.ctx(), m, c.nd.data(), d, c.cnt.data()));
         VIDC_FAISS_CHECK(vidc_copy_d2h(t.ctx(), out, d, m * (size_t)K * 4));
-        if (counts) std::copy(cnt.begin(), cnt.end(), counts);
+        if (counts) std::copy(c.cnt.begin(), c.cnt.begin() + m, counts);
     }
     /* one row through the cache; returns the edge count */
     size_t cached_row(int i, int32_t* neighbors) const {
-        RowCache& c = thread_row_cache();
-        if (c.owner != object_id || c.K != K) c.reset(object_id, K);
+        RowCache& c = thread_row_caches().get(object_id, K);
         size_t s = RowCache::slot_of(i);
         if (c.tag[s] != i) {
             c.misses++;
-            get_neighbors_batch(1, &i, &c.rows[s * (size_t)K], &c.count[s]);
+            uint32_t cnt_i = 0;
+            get_neighbors_batch(1, &i, &c.rows[s * (size_t)K], &cnt_i);
+            c.count[s] = cnt_i;
             c.tag[s] = i;
             /* the frontier: neighbours of i that are not cached (a neighbour whose slot is i's own stays out) */
-            std::vector<int> want;
-            std::vector<size_t> slots;
+            c.want.clear();
+            c.slots.clear();
             for (uint32_t j = 0; j < c.count[s] && j < (uint32_t)K; j++) {
                 int v = c.rows[s * (size_t)K + j];
                 if (v < 0 || v >= N) continue;
                 size_t sv = RowCache::slot_of(v);
                 if (sv == s || c.tag[sv] == v) continue;
                 bool dup = false;
-                for (size_t q : slots) dup |= q == sv;
+                for (size_t q : c.slots) dup |= q == sv;
                 if (dup) continue;
-                want.push_back(v);
-                slots.push_back(sv);
+                c.want.push_back(v);
+                c.slots.push_back(sv);
             }
-            if (!want.empty()) {
-                std::vector<int32_t> buf(want.size() * (size_t)K);
-                std::vector<uint32_t> cnt(want.size());
-                get_neighbors_batch(want.size(), want.data(), buf.data(), cnt.data());
-                for (size_t q = 0; q < want.size(); q++) {
-                    std::memcpy(&c.rows[slots[q] * (size_t)K], &buf[q * (size_t)K], (size_t)K * 4);
-                    c.count[slots[q]] = cnt[q];
-                    c.tag[slots[q]] = want[q];
+            if (!c.want.empty()) {
+                const size_t nw = c.want.size();
+                c.buf.resize(nw * (size_t)K);
+                get_neighbors_batch(nw, c.want.data(), c.buf.data(), nullptr); /* (edge counts stay in c.cnt) */
+                for (size_t q = 0; q < nw; q++) {
+                    std::memcpy(&c.rows[c.slots[q] * (size_t)K], &c.buf[q * (size_t)K], (size_t)K * 4);
+                    c.count[c.slots[q]] = c.cnt[q];
+                    c.tag[c.slots[q]] = c.want[q];
                 }
             }
         } else {
@@ -493,11 +534,11 @@ struct CompressedNSGGraph : faiss::nsg::Graph<int32_t> {
 };
 
 /* CompactBitNSGGraph (altid_impl.cpp:20-51) */
-struct CompactBitNSGGraph : CompressedNSGGraph {
+struct CompactBitGraph : CompressedNSGGraph {
     vidc_compact* c = nullptr;
     int bits = 0;
     size_t stride = 0;
-    explicit CompactBitNSGGraph(const faiss::nsg::Graph<int32_t>& g) : CompressedNSGGraph(g) {
+    explicit CompactBitGraph(const faiss::nsg::Graph<int32_t>& g) : CompressedNSGGraph(g) {
         vidc_ctx* ctx = thread_ctx().ctx();
         DeviceArray d(ctx, g.data, (size_t)N * K * 4);
         VIDC_FAISS_CHECK(vidc_compact_rows_encode(ctx, N, K, (const int32_t*)d.p, &c));
@@ -506,7 +547,7 @@ struct CompactBitNSGGraph : CompressedNSGGraph {
         compressed_ids_size_in_bytes = vidc_compact_size_in_bytes(c);
         data = nullptr;
     }
-    ~CompactBitNSGGraph() override { vidc_compact_destroy(c); }
+    ~CompactBitGraph() override { vidc_compact_destroy(c); }
     int decode_rows_device(vidc_ctx* ctx, uint64_t m, const uint64_t* nodes, int32_t* d, uint32_t* cnt) const override {
         return vidc_compact_rows_decode(ctx, c, m, nodes, d, cnt);
     }
@@ -514,9 +555,9 @@ struct CompactBitNSGGraph : CompressedNSGGraph {
 };
 
 /* EliasFanoNSGGraph (altid_impl.cpp:53-101) */
-struct EliasFanoNSGGraph : CompressedNSGGraph {
+struct EliasFanoGraph : CompressedNSGGraph {
     vidc_ef* ef = nullptr;
-    explicit EliasFanoNSGGraph(const faiss::nsg::Graph<int32_t>& g) : CompressedNSGGraph(g) {
+    explicit EliasFanoGraph(const faiss::nsg::Graph<int32_t>& g) : CompressedNSGGraph(g) {
         vidc_ctx* ctx = thread_ctx().ctx();
         DeviceArray d(ctx, g.data, (size_t)N * K * 4);
         VIDC_FAISS_CHECK(vidc_ef_encode_rows(ctx, N, K, (const int32_t*)d.p, &ef));
@@ -525,7 +566,7 @@ struct EliasFanoNSGGraph : CompressedNSGGraph {
         overhead_in_bytes += N * std::ceil(std::log2(N)) / 8.0;
         data = nullptr;
     }
-    ~EliasFanoNSGGraph() override { vidc_ef_destroy(ef); }
+    ~EliasFanoGraph() override { vidc_ef_destroy(ef); }
     int decode_rows_device(vidc_ctx* ctx, uint64_t m, const uint64_t* nodes, int32_t* d, uint32_t* cnt) const override {
         return vidc_ef_decode_rows(ctx, ef, m, nodes, (uint32_t)K, d, cnt);
     }
@@ -533,10 +574,10 @@ struct EliasFanoNSGGraph : CompressedNSGGraph {
 };
 
 /* ROCNSGGraph (altid_impl.cpp:103-165) */
-struct ROCNSGGraph : CompressedNSGGraph {
+struct ROCGraph : CompressedNSGGraph {
     vidc_roc* roc = nullptr;
     std::vector<uint32_t> num_outgoing_edges; /* altid_impl.h:61 */
-    explicit ROCNSGGraph(const faiss::nsg::Graph<int32_t>& g) : CompressedNSGGraph(g), num_outgoing_edges(g.N) {
+    explicit ROCGraph(const faiss::nsg::Graph<int32_t>& g) : CompressedNSGGraph(g), num_outgoing_edges(g.N) {
         vidc_ctx* ctx = thread_ctx().ctx();
         DeviceArray d(ctx, g.data, (size_t)N * K * 4);
         VIDC_FAISS_CHECK(vidc_roc_encode_rows(ctx, N, K, (const int32_t*)d.p, VIDC_PREC_REFERENCE, 0, &roc));
@@ -546,7 +587,7 @@ struct ROCNSGGraph : CompressedNSGGraph {
         overhead_in_bytes += N * std::ceil(std::log2(N)) / 8.0; /* :105 */
         data = nullptr;
     }
-    ~ROCNSGGraph() override { vidc_roc_destroy(roc); }
+    ~ROCGraph() override { vidc_roc_destroy(roc); }
     int decode_rows_device(vidc_ctx* ctx, uint64_t m, const uint64_t* nodes, int32_t* d, uint32_t* cnt) const override {
         return vidc_roc_decode_rows(ctx, roc, m, nodes, (uint32_t)K, d, cnt);
     }
@@ -560,14 +601,52 @@ struct ROCNSGGraph : CompressedNSGGraph {
 }  // namespace vidc_faiss
 
 #ifdef VIDC_FAISS_REFERENCE_NAMES
-/* the names the reference's harness dictionaries look up (bench_invlists.py:19-25, graph_dynamic_bench_invlists.py:21-26,
- * search_ivf_qinco.py:502-523); define the macro in the SWIG module INSTEAD of including custom_invlists_impl.h / altid_impl.h */
-using CompressedIDInvertedListsFenwickTree = vidc_faiss::ROCInvertedLists;
-using CompressedIDInvertedListsEliasFano = vidc_faiss::EliasFanoInvertedLists;
-using CompressedIDInvertedListsPackedBits = vidc_faiss::PackedBitsInvertedLists;
-using CompressedIDInvertedListsWaveletTree = vidc_faiss::WaveletTreeInvertedLists;
-using vidc_faiss::CompactBitNSGGraph;
-using vidc_faiss::EliasFanoNSGGraph;
-using vidc_faiss::ROCNSGGraph;
-using vidc_faiss::search_IVF_defer_id_decoding;
+/* The names the reference's harness dictionaries look up (bench_invlists.py:19-25, graph_dynamic_bench_invlists.py:21-26,
+ * search_ivf_qinco.py:502-523); define the macro in the SWIG module INSTEAD of including custom_invlists_impl.h / altid_impl.h.
+ * Derived structs with the reference's constructor signatures (custom_invlists_impl.h:48,67,85,117; altid_impl.h:33,46,58), spelled
+ * out rather than inherited (`using Base::Base;` is only wrapped by SWIG >= 4.2): SWIG generates one Python proxy class per struct,
+ * under exactly these names.  An alias declaration would not do that (SWIG treats it as a typedef); the static_asserts below keep
+ * one from coming back. */
+struct CompressedIDInvertedListsFenwickTree : vidc_faiss::ROCInvertedLists {
+    explicit CompressedIDInvertedListsFenwickTree(const faiss::InvertedLists& il) : vidc_faiss::ROCInvertedLists(il) {}
+};
+struct CompressedIDInvertedListsEliasFano : vidc_faiss::EliasFanoInvertedLists {
+    explicit CompressedIDInvertedListsEliasFano(const faiss::InvertedLists& il) : vidc_faiss::EliasFanoInvertedLists(il) {}
+};
+struct CompressedIDInvertedListsPackedBits : vidc_faiss::PackedBitsInvertedLists {
+    explicit CompressedIDInvertedListsPackedBits(const faiss::InvertedLists& il) : vidc_faiss::PackedBitsInvertedLists(il) {}
+};
+struct CompressedIDInvertedListsWaveletTree : vidc_faiss::WaveletTreeInvertedLists {
+    explicit CompressedIDInvertedListsWaveletTree(const faiss::InvertedLists& il, int wt_type = 0)
+            : vidc_faiss::WaveletTreeInvertedLists(il, wt_type) {}
+};
+struct CompactBitNSGGraph : vidc_faiss::CompactBitGraph {
+    explicit CompactBitNSGGraph(const faiss::nsg::Graph<int32_t>& graph) : vidc_faiss::CompactBitGraph(graph) {}
+};
+struct EliasFanoNSGGraph : vidc_faiss::EliasFanoGraph {
+    explicit EliasFanoNSGGraph(const faiss::nsg::Graph<int32_t>& graph) : vidc_faiss::EliasFanoGraph(graph) {}
+};
+struct ROCNSGGraph : vidc_faiss::ROCGraph {
+    explicit ROCNSGGraph(const faiss::nsg::Graph<int32_t>& graph) : vidc_faiss::ROCGraph(graph) {}
+};
+/* (a function needs no proxy class: the %inline wrapper of custom_invlists.swig:67-84 calls it by this name) */
+inline void search_IVF_defer_id_decoding(const faiss::IndexIVF& index, faiss::idx_t n, const float* x, int k, float* distances,
+                                         faiss::idx_t* labels, bool decode_1by1 = false, uint8_t* codes = nullptr,
+                                         bool include_listno = false) {
+    vidc_faiss::search_IVF_defer_id_decoding(index, n, x, k, distances, labels, decode_1by1, codes, include_listno);
+}
+#ifndef SWIG
+#include <type_traits>
+static_assert(!std::is_same<CompressedIDInvertedListsFenwickTree, vidc_faiss::ROCInvertedLists>::value &&
+                      !std::is_same<CompressedIDInvertedListsEliasFano, vidc_faiss::EliasFanoInvertedLists>::value &&
+                      !std::is_same<CompressedIDInvertedListsPackedBits, vidc_faiss::PackedBitsInvertedLists>::value &&
+                      !std::is_same<CompressedIDInvertedListsWaveletTree, vidc_faiss::WaveletTreeInvertedLists>::value &&
+                      !std::is_same<CompactBitNSGGraph, vidc_faiss::CompactBitGraph>::value &&
+                      !std::is_same<EliasFanoNSGGraph, vidc_faiss::EliasFanoGraph>::value &&
+                      !std::is_same<ROCNSGGraph, vidc_faiss::ROCGraph>::value,
+              "the reference names must be classes of their own (SWIG wraps an alias under the aliased name only)");
+static_assert(std::is_base_of<faiss::InvertedLists, CompressedIDInvertedListsFenwickTree>::value &&
+                      std::is_base_of<faiss::nsg::Graph<int32_t>, ROCNSGGraph>::value,
+              "the reference names plug into Faiss through the reference's base classes");
+#endif
 #endif

@@ -115,7 +115,7 @@ static int check_graph(const std::vector<int32_t>& rows, int N, int K, const cha
     // a greedy walk the way the NSG search expands nodes (one virtual get_neighbors per node): rows come from the per-thread
     // cache, filled a frontier at a time
     {
-        auto& cache = vidc_faiss::thread_row_cache();
+        auto& cache = vidc_faiss::thread_row_caches().get(g.object_id, K);
         const size_t h0 = cache.hits, m0 = cache.misses, calls0 = vidc_faiss::thread_ctx().device_calls;
         std::mt19937 rng(7);
         size_t steps = 0;
@@ -134,6 +134,26 @@ static int check_graph(const std::vector<int32_t>& rows, int N, int K, const cha
         printf("  %-28s walk: %zu get_neighbors calls, %.2f us each, %zu cache hits / %zu misses, %zu library calls\n", name, steps,
                us / (double)steps, cache.hits - h0, cache.misses - m0, vidc_faiss::thread_ctx().device_calls - calls0);
         REQUIRE(vidc_faiss::thread_ctx().device_calls - calls0 <= 2 * (cache.misses - m0));
+    }
+    // a thread that alternates between two graph objects keeps one row cache per object: no cache is rebuilt, and the second
+    // round over the same nodes is served from the caches without a library call
+    {
+        std::vector<int32_t> copy2(rows);
+        faiss::nsg::Graph<int32_t> src2(copy2.data(), N, K);
+        G g2(src2);
+        std::vector<int32_t> nb2(K);
+        for (int round = 0; round < 2; round++) {
+            const size_t resets0 = vidc_faiss::thread_row_caches().resets, calls0 = vidc_faiss::thread_ctx().device_calls;
+            for (int i = 0; i < 64; i++) {
+                size_t a = g.get_neighbors(i, nb.data()), b = g2.get_neighbors(i, nb2.data());
+                REQUIRE(a == b && nb == nb2);
+            }
+            if (round == 0) REQUIRE(vidc_faiss::thread_row_caches().resets - resets0 <= 1);  // g2's cache; g's exists already
+            else {
+                REQUIRE(vidc_faiss::thread_row_caches().resets == resets0);
+                REQUIRE(vidc_faiss::thread_ctx().device_calls == calls0);
+            }
+        }
     }
     printf("  %-28s ok: %zu bytes for %d nodes\n", name, g.compressed_ids_size_in_bytes, N);
     return 0;
@@ -165,6 +185,25 @@ int main() {
         if (check_container<CompressedIDInvertedListsEliasFano>(index, *ref, xq, nq, k, Iref, Dref, "CompressedIDInvertedListsEliasFano")) return 1;
         if (check_container<CompressedIDInvertedListsPackedBits>(index, *ref, xq, nq, k, Iref, Dref, "CompressedIDInvertedListsPackedBits")) return 1;
         if (check_container<CompressedIDInvertedListsWaveletTree>(index, *ref, xq, nq, k, Iref, Dref, "CompressedIDInvertedListsWaveletTree")) return 1;
+        {  // the batched random access of the ROC container checks (list, offset) against the list sizes
+            CompressedIDInvertedListsFenwickTree comp(*ref);
+            size_t l0 = 0;
+            while (ref->list_size(l0) == 0) l0++;
+            uint64_t ln = l0, of = ref->list_size(l0);
+            idx_t got = -1;
+            bool threw = false;
+            try { comp.get_single_ids(1, &ln, &of, &got); }
+            catch (const faiss::FaissException&) { threw = true; }
+            REQUIRE(threw);
+            of--;
+            comp.get_single_ids(1, &ln, &of, &got);
+            const idx_t* ids = comp.get_ids(l0);
+            REQUIRE(got == ids[of]);
+            comp.release_ids(l0, ids);
+            // the reference names are classes of their own, usable wherever the reference's are (SWIG wraps them by these names)
+            faiss::InvertedLists* as_base = &comp;
+            REQUIRE(dynamic_cast<vidc_faiss::ROCInvertedLists*>(as_base) != nullptr);
+        }
         {  // a foreign container still works through the deferred search (reference loop)
             std::vector<idx_t> I(nq * k);
             std::vector<float> D(nq * k);

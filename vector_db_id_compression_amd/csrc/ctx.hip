@@ -119,6 +119,7 @@ extern "C" {
 
 const char *vidc_last_error(void) { return vidc::g_last_error.c_str(); }
 int vidc_version(void) { return VIDC_VERSION; }
+int vidc_ctx_class_streams(const vidc_ctx *ctx) { return ctx ? ctx->naux() + 1 : 0; }
 
 int vidc_ctx_create(int device, vidc_ctx **out) {
     if (!out) return VIDC_ERR_INVALID;

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -768,7 +769,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         const bool main_idle = wl_u20.empty() && wl_c3.empty() && wl_r2.empty();
         int promoted = -1;
         uint32_t aux_used = 0;
+        const bool serial = env_on("VIDC_SERIAL");  // measurements: every class on the caller's stream, one after the other
         auto AUX = [&](int i) -> hipStream_t {
+            if (serial) return ctx->stream;
             if (main_idle && (promoted < 0 || promoted == i)) { promoted = i; return ctx->stream; }
             if (!(aux_used >> i & 1u)) { (void)hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0); aux_used |= 1u << i; }
             return ctx->aux[i];
@@ -782,55 +785,64 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             ctx->chain_info[0][0] = tot; ctx->chain_info[0][1] = w.size();
             ctx->chain_info[0][2] = r->offsets[w[0] + 1] - r->offsets[w[0]]; ctx->chain_info[0][3] = ub;
         };
-        if (!wl_u20.empty()) {
-            note_chain(wl_u20, 20);
-            VIDC_HIP(hipEventRecord(ctx->ev_chain[0], ctx->stream));
-            RocEncArgs b = a;
-            b.worklist = d_wl + base[2]; b.nwork = (uint32_t)wl_u20.size();
-            const U2Div *dt = (const U2Div *)ctx->d_u2tab;
-            if (old_u_kernels()) {
-                VIDC_TRY(set_big_lds((const void *)k_roc_encode_u<20, false>, UGeom<20>::LDS_BYTES));
-                VIDC_TRY(set_big_lds((const void *)k_roc_encode_u<20, true>, UGeom<20>::LDS_BYTES));
-                if (want_perm) hipLaunchKernelGGL((k_roc_encode_u<20, true>), dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, ctx->stream, b);
-                else hipLaunchKernelGGL((k_roc_encode_u<20, false>), dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, ctx->stream, b);
-            } else {
-                VIDC_TRY(set_big_lds((const void *)k_roc_encode_u2<20, false>, U2Geom<20>::LDS_BYTES));
-                VIDC_TRY(set_big_lds((const void *)k_roc_encode_u2<20, true>, U2Geom<20>::LDS_BYTES));
-                if (want_perm) hipLaunchKernelGGL((k_roc_encode_u2<20, true>), dim3(b.nwork), dim3(64), U2Geom<20>::LDS_BYTES, ctx->stream, b, dt);
-                else hipLaunchKernelGGL((k_roc_encode_u2<20, false>), dim3(b.nwork), dim3(64), U2Geom<20>::LDS_BYTES, ctx->stream, b, dt);
-            }
-            VIDC_HIP(hipGetLastError());
-            VIDC_HIP(hipEventRecord(ctx->ev_chain[1], ctx->stream));
+        // Every kernel class of the call is one entry here: its name, its default stream (0 = the caller's, i = auxiliary i - 1)
+        // and its launch.  Default streams / order = the schedule measured best (comments at the entries); VIDC_ENC_SCHED
+        // (measurements) replaces it: streams separated by ';' (first = the caller's stream), the launches of a stream by ','
+        // in FIFO order, "NAME^DEP" also waits for launch DEP; host launch order: first entries of every stream, then the
+        // second ones, ...; names: U20 R2 C3 G3.<k> G2.<k> (octaves of the row-per-list classes, longest first) C2 U18 C1 L64 L32 L16
+        // L4 TINY.  Launches the string does not name keep their default stream and go out last.
+        struct EncLaunch { std::string name; int def_stream; std::function<int(hipStream_t)> fn; };
+        std::vector<EncLaunch> L;
+        if (!wl_u20.empty()) {  // main stream: bitmap-20 lists (the critical path of the 1 M-vector configurations)
+            L.push_back({"U20", 0, [&](hipStream_t st_) -> int {
+                note_chain(wl_u20, 20);
+                VIDC_HIP(hipEventRecord(ctx->ev_chain[0], st_));
+                RocEncArgs b = a;
+                b.worklist = d_wl + base[2]; b.nwork = (uint32_t)wl_u20.size();
+                const U2Div *dt = (const U2Div *)ctx->d_u2tab;
+                if (old_u_kernels()) {
+                    VIDC_TRY(set_big_lds((const void *)k_roc_encode_u<20, false>, UGeom<20>::LDS_BYTES));
+                    VIDC_TRY(set_big_lds((const void *)k_roc_encode_u<20, true>, UGeom<20>::LDS_BYTES));
+                    if (want_perm) hipLaunchKernelGGL((k_roc_encode_u<20, true>), dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, st_, b);
+                    else hipLaunchKernelGGL((k_roc_encode_u<20, false>), dim3(b.nwork), dim3(64), UGeom<20>::LDS_BYTES, st_, b);
+                } else {
+                    VIDC_TRY(set_big_lds((const void *)k_roc_encode_u2<20, false>, U2Geom<20>::LDS_BYTES));
+                    VIDC_TRY(set_big_lds((const void *)k_roc_encode_u2<20, true>, U2Geom<20>::LDS_BYTES));
+                    if (want_perm) hipLaunchKernelGGL((k_roc_encode_u2<20, true>), dim3(b.nwork), dim3(64), U2Geom<20>::LDS_BYTES, st_, b, dt);
+                    else hipLaunchKernelGGL((k_roc_encode_u2<20, false>), dim3(b.nwork), dim3(64), U2Geom<20>::LDS_BYTES, st_, b, dt);
+                }
+                VIDC_HIP(hipGetLastError());
+                VIDC_HIP(hipEventRecord(ctx->ev_chain[1], st_));
+                return VIDC_OK;
+            }});
         }
         if (!wl_r2.empty()) {
-            RocEncArgs b = a;
-            b.worklist = d_wl + base[9]; b.nwork = (uint32_t)wl_r2.size();
-            const U2Div *dt = (const U2Div *)ctx->d_u2tab;
             // (behind a 20-bit bitmap launch on the main stream these chains would only start when that one has finished:
             // S1 encode 12.5 -> 13.5 ms; they go to the first auxiliary stream then)
-            hipStream_t st_r2 = wl_u20.empty() ? ctx->stream : AUX(0);
-            // (the bitmap of a launch whose longest list -- the first of the work list -- has at most 65 536 positions: 8 KiB)
-            const bool small = r->offsets[wl_r2[0] + 1] - r->offsets[wl_r2[0]] <= 65536 && !env_on("VIDC_R2_BIG");
-            if (small && want_perm) hipLaunchKernelGGL((k_roc_encode_r2<true, 10>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(10), st_r2, b, dt);
-            else if (small) hipLaunchKernelGGL((k_roc_encode_r2<false, 10>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(10), st_r2, b, dt);
-            else if (want_perm) hipLaunchKernelGGL((k_roc_encode_r2<true, 12>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(12), st_r2, b, dt);
-            else hipLaunchKernelGGL((k_roc_encode_r2<false, 12>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(12), st_r2, b, dt);
-            VIDC_HIP(hipGetLastError());
+            L.push_back({"R2", wl_u20.empty() ? 0 : 1, [&](hipStream_t st_r2) -> int {
+                RocEncArgs b = a;
+                b.worklist = d_wl + base[9]; b.nwork = (uint32_t)wl_r2.size();
+                const U2Div *dt = (const U2Div *)ctx->d_u2tab;
+                // (the bitmap of a launch whose longest list -- the first of the work list -- has at most 65 536 positions: 8 KiB)
+                const bool small = r->offsets[wl_r2[0] + 1] - r->offsets[wl_r2[0]] <= 65536 && !env_on("VIDC_R2_BIG");
+                if (small && want_perm) hipLaunchKernelGGL((k_roc_encode_r2<true, 10>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(10), st_r2, b, dt);
+                else if (small) hipLaunchKernelGGL((k_roc_encode_r2<false, 10>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(10), st_r2, b, dt);
+                else if (want_perm) hipLaunchKernelGGL((k_roc_encode_r2<true, 12>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(12), st_r2, b, dt);
+                else hipLaunchKernelGGL((k_roc_encode_r2<false, 12>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(12), st_r2, b, dt);
+                VIDC_HIP(hipGetLastError());
+                return VIDC_OK;
+            }});
         }
         // the deepest class: prefix rows sized for its longest list (first of the work list).  With the fixed
         // 48 KiB layout a CU held 3 of these chains; lists up to 65 536 ids need 12 KiB (S2 encode 152 -> see DESIGN)
-        {
-            uint32_t rl3 = 64;
-            if (!wl_c3.empty()) {
-                const uint64_t nmax3 = r->offsets[wl_c3[0] + 1] - r->offsets[wl_c3[0]];
-                rl3 = 16;
-                while ((uint64_t)64 * 64 * rl3 < nmax3) rl3 <<= 1;
-            }
+        if (!wl_c3.empty()) {
             // (behind a chain launch on the main stream it would only start when that one has finished)
-            if (!wl_c3.empty()) {
-                hipStream_t st_c3 = (!wl_r2.empty() && wl_u20.empty()) ? AUX(0) : ctx->stream;
-                VIDC_TRY(launch_gen_on(st_c3, d_wl + base[5], (uint32_t)wl_c3.size(), rl3));
-            }
+            L.push_back({"C3", (!wl_r2.empty() && wl_u20.empty()) ? 1 : 0, [&](hipStream_t st_c3) -> int {
+                const uint64_t nmax3 = r->offsets[wl_c3[0] + 1] - r->offsets[wl_c3[0]];
+                uint32_t rl3 = 16;
+                while ((uint64_t)64 * 64 * rl3 < nmax3) rl3 <<= 1;
+                return launch_gen_on(st_c3, d_wl + base[5], (uint32_t)wl_c3.size(), rl3);
+            }});
         }
         // The lane-per-list kernels and the throughput-bound general classes must not share the machine: on S2 the
         // 64-word lane class took 69 ms next to the 26 316-list general class (49 ms) -- 9 ms and ~35 ms when each
@@ -846,9 +858,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             if (!gmap || !*gmap) gmap = ctx->wide ? "4567" : "13";
             const size_t gmap_n = std::strlen(gmap);
             size_t seg_no = 0;
-            const U2Div *dt = (const U2Div *)ctx->d_u2tab;
-            auto launch_grp = [&](const std::vector<uint32_t> &w, size_t wbase, bool lev3) -> int {
+            auto add_grp = [&](const std::vector<uint32_t> &w, size_t wbase, bool lev3) {
                 size_t k0 = 0;
+                int seg_of_class = 0;
                 while (k0 < w.size()) {
                     const uint64_t n0 = r->offsets[w[k0] + 1] - r->offsets[w[k0]];  // longest of the segment
                     uint64_t lo = 1;                                                 // segment: lengths in (lo, 2 lo]
@@ -856,48 +868,62 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                     size_t k1 = k0;
                     while (k1 < w.size() && r->offsets[w[k1] + 1] - r->offsets[w[k1]] > lo) k1++;
                     const int sd = gmap[seg_no++ % gmap_n] - '0';
-                    hipStream_t st_g = (sd >= 1 && sd <= ctx->naux()) ? AUX(sd - 1) : ctx->stream;
-                    RocEncArgs b = a;
-                    b.worklist = d_wl + wbase + k0; b.nwork = (uint32_t)(k1 - k0);
-                    const uint32_t nblk = (uint32_t)((n0 + 511) >> 9);
-                    const size_t lds = (size_t)4 * 4 * (lev3 ? roc_grp_enc_lds_words<3>(nblk) : roc_grp_enc_lds_words<2>(nblk));
-                    const dim3 grid((b.nwork + 3u) / 4u);
-                    if (lev3) {
-                        if (lds > 65536) {
-                            VIDC_TRY(set_big_lds((const void *)k_roc_encode_grp<3, true>, lds));
-                            VIDC_TRY(set_big_lds((const void *)k_roc_encode_grp<3, false>, lds));
-                        }
-                        if (want_perm) hipLaunchKernelGGL((k_roc_encode_grp<3, true>), grid, dim3(64), lds, st_g, b, dt, nblk);
-                        else hipLaunchKernelGGL((k_roc_encode_grp<3, false>), grid, dim3(64), lds, st_g, b, dt, nblk);
-                    } else if (want_perm) hipLaunchKernelGGL((k_roc_encode_grp<2, true>), grid, dim3(64), lds, st_g, b, dt, nblk);
-                    else hipLaunchKernelGGL((k_roc_encode_grp<2, false>), grid, dim3(64), lds, st_g, b, dt, nblk);
-                    VIDC_HIP(hipGetLastError());
+                    const uint32_t nwork = (uint32_t)(k1 - k0);
+                    const size_t woff = wbase + k0;
+                    L.push_back({std::string(lev3 ? "G3." : "G2.") + std::to_string(seg_of_class++), (sd >= 1 && sd <= ctx->naux()) ? sd : 0,
+                                 [&, n0, nwork, woff, lev3](hipStream_t st_g) -> int {
+                        const U2Div *dt = (const U2Div *)ctx->d_u2tab;
+                        RocEncArgs b = a;
+                        b.worklist = d_wl + woff; b.nwork = nwork;
+                        const uint32_t nblk = (uint32_t)((n0 + 511) >> 9);
+                        const size_t lds = (size_t)4 * 4 * (lev3 ? roc_grp_enc_lds_words<3>(nblk) : roc_grp_enc_lds_words<2>(nblk));
+                        const dim3 grid((b.nwork + 3u) / 4u);
+                        if (lev3) {
+                            if (lds > 65536) {
+                                VIDC_TRY(set_big_lds((const void *)k_roc_encode_grp<3, true>, lds));
+                                VIDC_TRY(set_big_lds((const void *)k_roc_encode_grp<3, false>, lds));
+                            }
+                            if (want_perm) hipLaunchKernelGGL((k_roc_encode_grp<3, true>), grid, dim3(64), lds, st_g, b, dt, nblk);
+                            else hipLaunchKernelGGL((k_roc_encode_grp<3, false>), grid, dim3(64), lds, st_g, b, dt, nblk);
+                        } else if (want_perm) hipLaunchKernelGGL((k_roc_encode_grp<2, true>), grid, dim3(64), lds, st_g, b, dt, nblk);
+                        else hipLaunchKernelGGL((k_roc_encode_grp<2, false>), grid, dim3(64), lds, st_g, b, dt, nblk);
+                        VIDC_HIP(hipGetLastError());
+                        return VIDC_OK;
+                    }});
                     k0 = k1;
                 }
-                return VIDC_OK;
             };
-            VIDC_TRY(launch_grp(wl_g3, base[11], true));
-            VIDC_TRY(launch_grp(wl_g2, base[10], false));
+            add_grp(wl_g3, base[11], true);
+            add_grp(wl_g2, base[10], false);
         }
         const bool lanes_present = !wl_l4.empty() || !wl_l16.empty() || !wl_l64.empty();
         // aux 0: mid-size general lists (calls without lane classes) and bitmap-18 lists
-        if (!lanes_present && !wl_c2.empty()) VIDC_TRY(launch_gen_on(AUX(0), d_wl + base[4], (uint32_t)wl_c2.size(), 8));
+        auto add_c2 = [&](int sdef) {
+            L.push_back({"C2", sdef, [&](hipStream_t st_) -> int { return launch_gen_on(st_, d_wl + base[4], (uint32_t)wl_c2.size(), 8); }});
+        };
+        auto add_c1 = [&](int sdef) {
+            L.push_back({"C1", sdef, [&](hipStream_t st_) -> int { return launch_gen_on(st_, d_wl + base[3], (uint32_t)wl_c1.size(), 1); }});
+        };
+        if (!lanes_present && !wl_c2.empty()) add_c2(1);
         if (!wl_u18.empty()) {
-            const bool is_chain = wl_u20.empty();
-            if (is_chain) { note_chain(wl_u18, 18); VIDC_HIP(hipEventRecord(ctx->ev_chain[0], AUX(0))); }
-            RocEncArgs b = a;
-            b.worklist = d_wl + base[1]; b.nwork = (uint32_t)wl_u18.size();
-            const U2Div *dt = (const U2Div *)ctx->d_u2tab;
-            if (old_u_kernels()) {
-                if (want_perm) hipLaunchKernelGGL((k_roc_encode_u<18, true>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, AUX(0), b);
-                else hipLaunchKernelGGL((k_roc_encode_u<18, false>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, AUX(0), b);
-            } else if (want_perm) hipLaunchKernelGGL((k_roc_encode_u2<18, true>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, AUX(0), b, dt);
-            else hipLaunchKernelGGL((k_roc_encode_u2<18, false>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, AUX(0), b, dt);
-            VIDC_HIP(hipGetLastError());
-            if (is_chain) VIDC_HIP(hipEventRecord(ctx->ev_chain[1], AUX(0)));
+            L.push_back({"U18", 1, [&](hipStream_t st_) -> int {
+                const bool is_chain = wl_u20.empty();
+                if (is_chain) { note_chain(wl_u18, 18); VIDC_HIP(hipEventRecord(ctx->ev_chain[0], st_)); }
+                RocEncArgs b = a;
+                b.worklist = d_wl + base[1]; b.nwork = (uint32_t)wl_u18.size();
+                const U2Div *dt = (const U2Div *)ctx->d_u2tab;
+                if (old_u_kernels()) {
+                    if (want_perm) hipLaunchKernelGGL((k_roc_encode_u<18, true>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, st_, b);
+                    else hipLaunchKernelGGL((k_roc_encode_u<18, false>), dim3(b.nwork), dim3(64), UGeom<18>::LDS_BYTES, st_, b);
+                } else if (want_perm) hipLaunchKernelGGL((k_roc_encode_u2<18, true>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, st_, b, dt);
+                else hipLaunchKernelGGL((k_roc_encode_u2<18, false>), dim3(b.nwork), dim3(64), U2Geom<18>::LDS_BYTES, st_, b, dt);
+                VIDC_HIP(hipGetLastError());
+                if (is_chain) VIDC_HIP(hipEventRecord(ctx->ev_chain[1], st_));
+                return VIDC_OK;
+            }});
         }
         // aux 1: the lane-per-list kernels, then the general classes; aux 2: tiny lists
-        if (!lanes_present && !wl_c1.empty()) VIDC_TRY(launch_gen_on(AUX(1), d_wl + base[3], (uint32_t)wl_c1.size(), 1));
+        if (!lanes_present && !wl_c1.empty()) add_c1(2);
         for (int cls = 2; cls >= 0; cls--) {  // longest chains first
             const std::vector<uint32_t> &w = cls == 2 ? wl_l64 : (cls ? wl_l16 : wl_l4);
             if (w.empty()) continue;
@@ -905,8 +931,6 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             b.worklist = d_wl + base[6 + cls]; b.nwork = (uint32_t)w.size();
             // (LDS per wavefront: 4-word strips 14.3 KiB, 16-word 21.5 KiB, 32-word 31.5 KiB, 64-word 50.5 KiB)
             b.lpw = lane_lists_per_wave(ctx, b.nwork, cls == 0 ? 15 : cls == 1 ? 11 : 4);
-            const dim3 grid((b.nwork + b.lpw - 1u) / b.lpw);
-            const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
             if (cls == 2) {
                 // lists are sorted longest first: the leading wavefronts need the 64-word strips (50.5 KiB of LDS,
                 // 3 per CU), everything from the first wavefront whose longest list has <= 2048 ids the 32-word
@@ -917,34 +941,114 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 RocEncArgs b2 = b;
                 b2.worklist = b.worklist + n_big; b2.nwork = b.nwork - n_big;
                 b.nwork = n_big;
-                const dim3 g1((b.nwork + b.lpw - 1u) / b.lpw), g2((b2.nwork + b.lpw - 1u) / b.lpw);
-                if (b.nwork && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<64, true>), g1, dim3(64), 0, AUX(1), b, dt);
-                else if (b.nwork) hipLaunchKernelGGL((k_roc_encode_lane<64, false>), g1, dim3(64), 0, AUX(1), b, dt);
-                if (b2.nwork && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<32, true>), g2, dim3(64), 0, AUX(1), b2, dt);
-                else if (b2.nwork) hipLaunchKernelGGL((k_roc_encode_lane<32, false>), g2, dim3(64), 0, AUX(1), b2, dt);
+                if (b.nwork)
+                    L.push_back({"L64", 2, [&, b](hipStream_t st_) -> int {
+                        const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
+                        const dim3 g1((b.nwork + b.lpw - 1u) / b.lpw);
+                        if (want_perm) hipLaunchKernelGGL((k_roc_encode_lane<64, true>), g1, dim3(64), 0, st_, b, dt);
+                        else hipLaunchKernelGGL((k_roc_encode_lane<64, false>), g1, dim3(64), 0, st_, b, dt);
+                        VIDC_HIP(hipGetLastError());
+                        return VIDC_OK;
+                    }});
+                if (b2.nwork)
+                    L.push_back({"L32", 2, [&, b2](hipStream_t st_) -> int {
+                        const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
+                        const dim3 g2((b2.nwork + b2.lpw - 1u) / b2.lpw);
+                        if (want_perm) hipLaunchKernelGGL((k_roc_encode_lane<32, true>), g2, dim3(64), 0, st_, b2, dt);
+                        else hipLaunchKernelGGL((k_roc_encode_lane<32, false>), g2, dim3(64), 0, st_, b2, dt);
+                        VIDC_HIP(hipGetLastError());
+                        return VIDC_OK;
+                    }});
+            } else {
+                L.push_back({cls == 0 ? "L4" : "L16", 2, [&, b, cls](hipStream_t st_) -> int {
+                    const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
+                    const dim3 grid((b.nwork + b.lpw - 1u) / b.lpw);
+                    if (cls == 0 && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<4, true>), grid, dim3(64), 0, st_, b, dt);
+                    else if (cls == 0) hipLaunchKernelGGL((k_roc_encode_lane<4, false>), grid, dim3(64), 0, st_, b, dt);
+                    else if (want_perm) hipLaunchKernelGGL((k_roc_encode_lane<16, true>), grid, dim3(64), 0, st_, b, dt);
+                    else hipLaunchKernelGGL((k_roc_encode_lane<16, false>), grid, dim3(64), 0, st_, b, dt);
+                    VIDC_HIP(hipGetLastError());
+                    return VIDC_OK;
+                }});
             }
-            else if (cls == 0 && want_perm) hipLaunchKernelGGL((k_roc_encode_lane<4, true>), grid, dim3(64), 0, AUX(1), b, dt);
-            else if (cls == 0) hipLaunchKernelGGL((k_roc_encode_lane<4, false>), grid, dim3(64), 0, AUX(1), b, dt);
-            else if (want_perm) hipLaunchKernelGGL((k_roc_encode_lane<16, true>), grid, dim3(64), 0, AUX(1), b, dt);
-            else hipLaunchKernelGGL((k_roc_encode_lane<16, false>), grid, dim3(64), 0, AUX(1), b, dt);
-            VIDC_HIP(hipGetLastError());
         }
         if (lanes_present) {
-            if (!wl_c2.empty()) VIDC_TRY(launch_gen_on(AUX(1), d_wl + base[4], (uint32_t)wl_c2.size(), 8));
-            if (!wl_c1.empty()) VIDC_TRY(launch_gen_on(AUX(1), d_wl + base[3], (uint32_t)wl_c1.size(), 1));
+            if (!wl_c2.empty()) add_c2(2);
+            if (!wl_c1.empty()) add_c1(2);
         }
         if (ntiny) {
-            RocEncArgs b = a;
-            b.worklist = rows ? nullptr : d_wl; b.nwork = (uint32_t)ntiny;
-            if (use_lane_tiny) {  // one list per lane (roc_lane.h)
-                const dim3 grid((b.nwork + 63u) / 64u);
-                const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
-                if (rows && K <= 32) hipLaunchKernelGGL((k_roc_encode_tiny_lane<32, true>), grid, dim3(64), 0, AUX(2), b, dt);
-                else if (rows) hipLaunchKernelGGL((k_roc_encode_tiny_lane<64, true>), grid, dim3(64), 0, AUX(2), b, dt);
-                else hipLaunchKernelGGL((k_roc_encode_tiny_lane<64, false>), grid, dim3(64), 0, AUX(2), b, dt);
-            } else if (rows) hipLaunchKernelGGL(k_roc_encode_tiny<true>, dim3(b.nwork), dim3(64), 0, AUX(2), b);
-            else hipLaunchKernelGGL(k_roc_encode_tiny<false>, dim3(b.nwork), dim3(64), 0, AUX(2), b);
-            VIDC_HIP(hipGetLastError());
+            L.push_back({"TINY", 3, [&](hipStream_t st_) -> int {
+                RocEncArgs b = a;
+                b.worklist = rows ? nullptr : d_wl; b.nwork = (uint32_t)ntiny;
+                if (use_lane_tiny) {  // one list per lane (roc_lane.h)
+                    const dim3 grid((b.nwork + 63u) / 64u);
+                    const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
+                    if (rows && K <= 32) hipLaunchKernelGGL((k_roc_encode_tiny_lane<32, true>), grid, dim3(64), 0, st_, b, dt);
+                    else if (rows) hipLaunchKernelGGL((k_roc_encode_tiny_lane<64, true>), grid, dim3(64), 0, st_, b, dt);
+                    else hipLaunchKernelGGL((k_roc_encode_tiny_lane<64, false>), grid, dim3(64), 0, st_, b, dt);
+                } else if (rows) hipLaunchKernelGGL(k_roc_encode_tiny<true>, dim3(b.nwork), dim3(64), 0, st_, b);
+                else hipLaunchKernelGGL(k_roc_encode_tiny<false>, dim3(b.nwork), dim3(64), 0, st_, b);
+                VIDC_HIP(hipGetLastError());
+                return VIDC_OK;
+            }});
+        }
+        {
+            auto stream_no = [&](int sno) -> hipStream_t { return sno == 0 ? ctx->stream : AUX(sno - 1); };
+            std::vector<int> sch_stream(L.size(), -1), sch_pos(L.size(), 0);
+            std::vector<std::vector<int>> deps(L.size());
+            auto find = [&](const std::string &t) { for (size_t i = 0; i < L.size(); i++) if (L[i].name == t) return (int)i; return -1; };
+            std::vector<int> order_l;
+            if (const char *e = std::getenv("VIDC_ENC_SCHED")) {
+                std::string str(e);
+                int grp = 0, pos = 0;
+                size_t i0 = 0;
+                for (size_t i = 0; i <= str.size(); i++) {
+                    if (i < str.size() && str[i] != ',' && str[i] != ';') continue;
+                    std::string tok = str.substr(i0, i - i0);
+                    i0 = i + 1;
+                    if (!tok.empty()) {
+                        int me = -1;
+                        size_t j0 = 0;
+                        bool first = true;
+                        for (size_t j = 0; j <= tok.size(); j++) {
+                            if (j < tok.size() && tok[j] != '^') continue;
+                            const int c = find(tok.substr(j0, j - j0));
+                            j0 = j + 1;
+                            if (first) me = c; else if (c >= 0 && me >= 0) deps[me].push_back(c);
+                            first = false;
+                        }
+                        if (me >= 0 && sch_stream[me] < 0 && grp <= ctx->naux()) { sch_stream[me] = grp; sch_pos[me] = pos++; order_l.push_back(me); }
+                    }
+                    if (i < str.size() && str[i] == ';') { grp++; pos = 0; }
+                }
+                std::stable_sort(order_l.begin(), order_l.end(), [&](int x, int y) { return sch_pos[x] < sch_pos[y]; });
+            }
+            for (size_t i = 0; i < L.size(); i++)
+                if (sch_stream[i] < 0) order_l.push_back((int)i);
+            std::vector<char> done(L.size(), 0);
+            size_t left = L.size();
+            while (left) {
+                const size_t before = left;
+                for (int i : order_l) {
+                    if (done[i]) continue;
+                    bool ready = true;
+                    for (int d : deps[i]) ready &= done[d] != 0;
+                    if (!ready) continue;
+                    hipStream_t st_ = serial ? ctx->stream : (sch_stream[i] >= 0 ? (sch_stream[i] == 0 ? ctx->stream : [&] {
+                        const int x = sch_stream[i] - 1;
+                        if (!(aux_used >> x & 1u)) { (void)hipStreamWaitEvent(ctx->aux[x], ctx->ev_fork, 0); aux_used |= 1u << x; }
+                        return ctx->aux[x];
+                    }()) : stream_no(L[i].def_stream));
+                    for (int d : deps[i]) VIDC_HIP(hipStreamWaitEvent(st_, ctx->tev[d % 24], 0));
+                    VIDC_TRY(L[i].fn(st_));
+                    if ((size_t)i < 24) VIDC_HIP(hipEventRecord(ctx->tev[i], st_));
+                    done[i] = 1;
+                    left--;
+                }
+                if (left == before) {  // circular / unknown dependencies: drop them
+                    for (auto &d : deps) d.clear();
+                }
+            }
         }
         for (int i = 0; i < ctx->naux(); i++) {
             if (!(aux_used >> i & 1u)) continue;
@@ -1476,6 +1580,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         // to find room, becomes the tail; without that decoder 81-82 / 83-84)
         int nq = ctx->wide ? VIDC_NAUX + 1 : 3;
         if (const char *e = std::getenv("VIDC_DEC_NQ")) nq = std::max(1, std::min(ctx->naux() + 1, std::atoi(e)));
+        if (env_on("VIDC_SERIAL")) nq = 1;  // measurements: one class after the other
         for (int k = 0; k < DC_COUNT; k++) {
             const int c = order[k];
             if (!p.count[c]) continue;
@@ -1552,7 +1657,10 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 b2.worklist = b.worklist + n_big; b2.nwork = b.nwork - n_big;
                 if (b2.out_off) b2.out_off += n_big;
                 b.nwork = n_big;
-                if (b.nwork)
+                if (b.nwork && env_on("VIDC_LANE_BATCH"))
+                    hipLaunchKernelGGL((k_roc_decode_lane<64, true>), dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
+                                       (const LaneDiv *)ctx->d_ltab);
+                else if (b.nwork)
                     hipLaunchKernelGGL(k_roc_decode_lane<64>, dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
                                        (const LaneDiv *)ctx->d_ltab);
                 if (b2.nwork)
@@ -1562,6 +1670,10 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
             }
             case DC_LANE64:  // 26.5 KiB of LDS per wavefront
                 b.lpw = lane_lists_per_wave(ctx, b.nwork, 7);
+                if (env_on("VIDC_LANE_BATCH"))
+                    hipLaunchKernelGGL((k_roc_decode_lane<256, true>), dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
+                                       (const LaneDiv *)ctx->d_ltab);
+                else
                 hipLaunchKernelGGL(k_roc_decode_lane<256>, dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
@@ -1628,6 +1740,40 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         if (c == chain_class) VIDC_HIP(hipEventRecord(ctx->ev_chain[1], st_));
         return VIDC_OK;
     };
+    // VIDC_DEC_SCHED (measurements): explicit schedule.  Streams separated by ';' (first = the caller's stream, then the
+    // auxiliary ones), the classes of a stream separated by ',' run in that order; "CLS^DEP" additionally waits for class DEP
+    // (on another stream) to finish.  Launch order on the host: first entries of every stream, then the second ones, ...
+    // Classes of the call the string does not name keep the automatic assignment.  E.g. "B2;GHUGE;LANEP,LANE,LANE64;GMID^LANEP".
+    struct SchedItem { int cls, grp, pos; std::vector<int> deps; };
+    std::vector<SchedItem> sched;
+    if (const char *e = std::getenv("VIDC_DEC_SCHED")) {
+        static const char *names[DC_COUNT] = {"TINY", "U18", "U20", "GSMALL", "G8K", "G16K", "GMID", "GHUGE", "LANE", "LANE64", "B2", "B2T", "B2S",
+                                              "B2L", "B2M", "GRP0", "GRP2", "GRP3", "GRP4", "LANEP", "LANEQ"};
+        auto cls_of = [&](const std::string &t) { for (int c = 0; c < DC_COUNT; c++) if (t == names[c]) return c; return -1; };
+        std::string str(e);
+        int grp = 0, pos = 0;
+        size_t i0 = 0;
+        for (size_t i = 0; i <= str.size(); i++) {
+            if (i < str.size() && str[i] != ',' && str[i] != ';') continue;
+            std::string tok = str.substr(i0, i - i0);
+            i0 = i + 1;
+            if (!tok.empty()) {
+                SchedItem it{-1, grp, pos, {}};
+                size_t j0 = 0;
+                bool first = true;
+                for (size_t j = 0; j <= tok.size(); j++) {
+                    if (j < tok.size() && tok[j] != '^') continue;
+                    const int c = cls_of(tok.substr(j0, j - j0));
+                    j0 = j + 1;
+                    if (first) it.cls = c; else if (c >= 0) it.deps.push_back(c);
+                    first = false;
+                }
+                if (it.cls >= 0 && p.count[it.cls] && grp <= ctx->naux()) { sched.push_back(it); pos++; }
+            }
+            if (i < str.size() && str[i] == ';') { grp++; pos = 0; }
+        }
+        for (const SchedItem &it : sched) stream_of[it.cls] = it.grp == 0 ? ctx->stream : ctx->aux[it.grp - 1];
+    }
     if (pair_first) VIDC_TRY(launch(DC_LANEP));
     VIDC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     uint32_t aux_used = 0;  // only the auxiliary streams that carry a class of this call are forked and joined
@@ -1637,6 +1783,29 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 VIDC_HIP(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
                 aux_used |= 1u << i;
             }
+    if (!sched.empty()) {
+        bool done[DC_COUNT] = {};
+        std::stable_sort(sched.begin(), sched.end(), [](const SchedItem &x, const SchedItem &y) { return x.pos < y.pos; });
+        size_t left = sched.size();
+        while (left) {  // (an entry whose dependency is launched later in the list waits for the next round)
+            size_t before = left;
+            for (SchedItem &it : sched) {
+                if (it.cls < 0 || done[it.cls]) continue;
+                bool ready = true;
+                for (int d : it.deps) ready &= !p.count[d] || done[d];
+                if (!ready) continue;
+                for (int d : it.deps)
+                    if (p.count[d]) VIDC_HIP(hipStreamWaitEvent(stream_of[it.cls], ctx->tev[d], 0));
+                VIDC_TRY(launch(it.cls));
+                VIDC_HIP(hipEventRecord(ctx->tev[it.cls], stream_of[it.cls]));
+                done[it.cls] = true;
+                left--;
+            }
+            if (left == before) break;  // circular dependencies: the rest goes out below, unordered
+        }
+        for (int k = 0; k < DC_COUNT; k++)
+            if (!done[order[k]] && !(pair_first && order[k] == DC_LANEP)) VIDC_TRY(launch(order[k]));
+    } else
     for (int k = 0; k < DC_COUNT; k++)  // longest first
         if (!(pair_first && order[k] == DC_LANEP)) VIDC_TRY(launch(order[k]));
     for (int i = 0; i < ctx->naux(); i++) {

@@ -445,7 +445,10 @@ struct LaneDecGeom {
     static constexpr uint32_t BITS = NB == 64 ? 6u : 8u;
 };
 
-template <int NB>
+// BATCH: the first four 16-byte chunks of the bucket's row are requested together (a lane only asks for the chunks its
+// bucket holds) and counted behind ONE wait; the loop form waits for every chunk in turn, and the wavefront makes as many
+// round trips as its fullest bucket has chunks (3-5 at ~16 members for the longest lists of a class).
+template <int NB, bool BATCH = false>
 __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const LaneDiv *__restrict__ dtab) {
     using G = LaneDecGeom<NB>;
     __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
@@ -520,6 +523,25 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
             r += j > 8u ? lane_sum_bytes_below(c_hi, j - 8u) : 0u;
             const uint32_t cb = cnt1[(g * 64 + lane) * 16 + j];
             const uint4 *row4 = (const uint4 *)(slots + (size_t)b * cap);
+            if (BATCH) {
+                // (unconditional loads at clamped chunk numbers, counts masked afterwards: a load under a lane predicate is
+                // followed by its own wait -- the compiler sinks the compares into the predicated block)
+                const uint32_t nch = (cb + 3u) >> 2;
+                const uint32_t last = nch ? nch - 1u : 0u;
+                const uint4 v0 = row4[0];
+                const uint4 v1 = row4[last < 1u ? last : 1u];
+                const uint4 v2 = row4[last < 2u ? last : 2u];
+                const uint4 v3 = row4[last < 3u ? last : 3u];
+                const uint32_t c0 = (v0.x < x) + (v0.y < x) + (v0.z < x) + (v0.w < x);
+                const uint32_t c1 = (v1.x < x) + (v1.y < x) + (v1.z < x) + (v1.w < x);
+                const uint32_t c2 = (v2.x < x) + (v2.y < x) + (v2.z < x) + (v2.w < x);
+                const uint32_t c3 = (v3.x < x) + (v3.y < x) + (v3.z < x) + (v3.w < x);
+                r += (nch > 0u ? c0 : 0u) + (nch > 1u ? c1 : 0u) + (nch > 2u ? c2 : 0u) + (nch > 3u ? c3 : 0u);
+                for (uint32_t c = 4u; c < nch; c++) {
+                    const uint4 v = row4[c];
+                    r += (v.x < x) + (v.y < x) + (v.z < x) + (v.w < x);
+                }
+            } else
             for (uint32_t c = 0; c * 4u < cb; c++) {
                 const uint4 v = row4[c];
                 r += (v.x < x) + (v.y < x) + (v.z < x) + (v.w < x);
