@@ -20,7 +20,11 @@ MODES = {"lane": {"VIDC_FORCE_LANE": "1", "VIDC_NO_LANE": "0", "VIDC_FORCE_GENER
          # round 3: the row-per-list kernels (roc_grp.h, every list of 65 .. 131 072 ids) and the lane-pair register decoder
          "row": {"VIDC_FORCE_LANE": "0", "VIDC_NO_LANE": "1", "VIDC_FORCE_GENERAL": "0", "VIDC_FORCE_GRP": "1", "VIDC_NO_LANE_PAIR": "1", "VIDC_LANE_QUAD": "0"},
          "lane_quad": {"VIDC_FORCE_LANE": "1", "VIDC_NO_LANE": "0", "VIDC_FORCE_GENERAL": "0", "VIDC_FORCE_GRP": "0", "VIDC_NO_LANE_PAIR": "0", "VIDC_LANE_QUAD": "1"},
-         "lane_pair": {"VIDC_FORCE_LANE": "1", "VIDC_NO_LANE": "0", "VIDC_FORCE_GENERAL": "0", "VIDC_FORCE_GRP": "0", "VIDC_NO_LANE_PAIR": "0", "VIDC_LANE_QUAD": "0"}}
+         "lane_pair": {"VIDC_FORCE_LANE": "1", "VIDC_NO_LANE": "0", "VIDC_FORCE_GENERAL": "0", "VIDC_FORCE_GRP": "0", "VIDC_NO_LANE_PAIR": "0", "VIDC_LANE_QUAD": "0"},
+         # round 4: the bucket-row lane decoder with its stores behind the loads against the round-1 loop form (VIDC_LANE_LOOP=1)
+         "lane_old": {"VIDC_FORCE_LANE": "1", "VIDC_NO_LANE": "0", "VIDC_FORCE_GENERAL": "0", "VIDC_FORCE_GRP": "0", "VIDC_NO_LANE_PAIR": "1", "VIDC_LANE_QUAD": "0", "VIDC_LANE_LOOP": "1"}}
+for _m in MODES.values():
+    _m.setdefault("VIDC_LANE_LOOP", "0")
 
 
 def make_batch(rng):
@@ -100,7 +104,7 @@ def main():
             print("ERROR: families disagree about rejecting seed", seed, "batch", nb, "mode", mode, ":", errors, "accepted by", sorted(got), flush=True)
             np.savez("gpurun_out/fuzz_fail.npz", off=off, ids=ids, mode=mode)
             sys.exit(1)
-        for name in ("wave", "general", "row", "lane_pair", "lane_quad"):
+        for name in ("wave", "general", "row", "lane_pair", "lane_quad", "lane_old"):
             for a, b in zip(got["lane"], got[name]):
                 if not np.array_equal(a, b):
                     print("MISMATCH lane vs", name, "seed", seed, "batch", nb, "mode", mode, flush=True)

@@ -1657,11 +1657,11 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 b2.worklist = b.worklist + n_big; b2.nwork = b.nwork - n_big;
                 if (b2.out_off) b2.out_off += n_big;
                 b.nwork = n_big;
-                if (b.nwork && env_on("VIDC_LANE_BATCH"))
-                    hipLaunchKernelGGL((k_roc_decode_lane<64, true>), dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
+                if (b.nwork && env_on("VIDC_LANE_LOOP"))
+                    hipLaunchKernelGGL((k_roc_decode_lane<64, false>), dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
                                        (const LaneDiv *)ctx->d_ltab);
                 else if (b.nwork)
-                    hipLaunchKernelGGL(k_roc_decode_lane<64>, dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
+                    hipLaunchKernelGGL((k_roc_decode_lane<64, true>), dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
                                        (const LaneDiv *)ctx->d_ltab);
                 if (b2.nwork)
                     hipLaunchKernelGGL(k_roc_decode_lane_reg<VIDC_LANE_REG_EL>, dim3((b2.nwork + b2.lpw - 1u) / b2.lpw), dim3(64), 0, st_,
@@ -1670,12 +1670,12 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
             }
             case DC_LANE64:  // 26.5 KiB of LDS per wavefront
                 b.lpw = lane_lists_per_wave(ctx, b.nwork, 7);
-                if (env_on("VIDC_LANE_BATCH"))
-                    hipLaunchKernelGGL((k_roc_decode_lane<256, true>), dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
+                if (env_on("VIDC_LANE_LOOP"))
+                    hipLaunchKernelGGL((k_roc_decode_lane<256, false>), dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
                                        (const LaneDiv *)ctx->d_ltab);
                 else
-                hipLaunchKernelGGL(k_roc_decode_lane<256>, dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
-                                   (const LaneDiv *)ctx->d_ltab);
+                    hipLaunchKernelGGL((k_roc_decode_lane<256, true>), dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
+                                       (const LaneDiv *)ctx->d_ltab);
                 break;
             case DC_B2:
                 hipLaunchKernelGGL(k_roc_decode_b2<0>, dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);

@@ -445,10 +445,14 @@ struct LaneDecGeom {
     static constexpr uint32_t BITS = NB == 64 ? 6u : 8u;
 };
 
-// BATCH: the first four 16-byte chunks of the bucket's row are requested together (a lane only asks for the chunks its
-// bucket holds) and counted behind ONE wait; the loop form waits for every chunk in turn, and the wavefront makes as many
-// round trips as its fullest bucket has chunks (3-5 at ~16 members for the longest lists of a class).
-template <int NB, bool BATCH = false>
+// BATCH (default since round 4; VIDC_LANE_LOOP=1: the loop form): the first four 16-byte chunks of the bucket's row are
+// requested together and counted behind ONE wait; the loop form waits for every chunk in turn, and the wavefront makes as many
+// round trips as its fullest bucket has chunks (3-5 at ~16 members for the longest lists of a class).  65 536 lists of 1024
+// ids: 3.9 -> 3.1-3.5 ms, S2 decode 78 -> 76 ms.  Measured on top and dropped: the row store of a step
+// issued BEHIND the next step's loads with the id forwarded from a register (one asm statement, wait = vmcnt(stores behind
+// the loads)) -- bit-exact, and no faster than this form whether it waited for vmcnt(2) or vmcnt(0): the kernel is bound by
+// the number of scattered L2 transactions per step (~5 per lane), not by the store acknowledgements a load waits behind.
+template <int NB, bool BATCH = true>
 __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const LaneDiv *__restrict__ dtab) {
     using G = LaneDecGeom<NB>;
     __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
