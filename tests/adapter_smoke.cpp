@@ -135,15 +135,17 @@ static int check_graph(const std::vector<int32_t>& rows, int N, int K, const cha
                us / (double)steps, cache.hits - h0, cache.misses - m0, vidc_faiss::thread_ctx().device_calls - calls0);
         REQUIRE(vidc_faiss::thread_ctx().device_calls - calls0 <= 2 * (cache.misses - m0));
     }
-    // a thread that alternates between two graph objects keeps one row cache per object: no cache is rebuilt, and the second
-    // round over the same nodes is served from the caches without a library call
+    // a thread that alternates between two graph objects keeps one row cache per object: no cache is rebuilt when the thread
+    // switches, and the second round over the same nodes is served mostly from the caches (a frontier fill of the first round may
+    // have replaced a few of the direct-mapped slots)
     {
         std::vector<int32_t> copy2(rows);
         faiss::nsg::Graph<int32_t> src2(copy2.data(), N, K);
         G g2(src2);
         std::vector<int32_t> nb2(K);
         for (int round = 0; round < 2; round++) {
-            const size_t resets0 = vidc_faiss::thread_row_caches().resets, calls0 = vidc_faiss::thread_ctx().device_calls;
+            const size_t resets0 = vidc_faiss::thread_row_caches().resets;
+            const size_t miss0 = vidc_faiss::thread_row_caches().get(g.object_id, K).misses + vidc_faiss::thread_row_caches().get(g2.object_id, K).misses;
             for (int i = 0; i < 64; i++) {
                 size_t a = g.get_neighbors(i, nb.data()), b = g2.get_neighbors(i, nb2.data());
                 REQUIRE(a == b && nb == nb2);
@@ -151,7 +153,8 @@ static int check_graph(const std::vector<int32_t>& rows, int N, int K, const cha
             if (round == 0) REQUIRE(vidc_faiss::thread_row_caches().resets - resets0 <= 1);  // g2's cache; g's exists already
             else {
                 REQUIRE(vidc_faiss::thread_row_caches().resets == resets0);
-                REQUIRE(vidc_faiss::thread_ctx().device_calls == calls0);
+                const size_t miss1 = vidc_faiss::thread_row_caches().get(g.object_id, K).misses + vidc_faiss::thread_row_caches().get(g2.object_id, K).misses;
+                REQUIRE(miss1 - miss0 <= 32);  // (128 lookups; with one shared cache every one of them would miss)
             }
         }
     }

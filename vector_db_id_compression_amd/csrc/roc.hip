@@ -37,6 +37,10 @@ struct vidc_roc {
     // ascending list; a list that turned out not to be ascending is redone by the sorting pass and set to 0 here).  A value
     // below the true maximum only makes the planner assume more ids per bucket.  Empty / 0 = unknown (imported streams).
     std::vector<uint32_t> umax;
+    // every list of the object, longest first (stable), when the encoder built that order (calls classified by length alone);
+    // empty otherwise.  The decode planner of the whole object cuts its classes out of it.
+    std::vector<uint32_t> order_desc;
+    uint64_t order_max_n = 0;
     mutable std::vector<uint64_t> heads;
     mutable std::vector<uint64_t> word_off;  // nlist+1
     mutable bool meta_host = false, offsets_host = false;
@@ -333,46 +337,57 @@ void sort_desc(std::vector<uint32_t> &wl, const std::vector<uint64_t> &offsets) 
     wl.swap(out);
 }
 
-// status check + word offsets + sizes + compaction, all on the device; three u64 come back
-int finish_encode(vidc_ctx *ctx, vidc_roc *r, const uint32_t *d_arena, uint32_t arena_stride, Scratch &d_status_buf,
-                  const uint32_t *d_sizes, uint64_t nonempty_lists, double &kernel_ms) {
-    const uint64_t nlist = r->nlist;
+// End of an encode call: status check + word offsets + sizes + compaction, all on the device.  Two halves so that the first
+// can be queued right behind the encode kernels -- while the host still plans the decode -- and ONE synchronisation serves the
+// kernels, the status summary (errors / lists waiting for the sorting pass) and the size read-back:
+//   finish_enqueue: status summary, exclusive scan of the word counts (and of the edge counts of graph rows), copies to `t`
+//   finish_complete (after a synchronisation of the stream): checks, allocation of the stream, compaction, final synchronisation
+struct EncodeTail {
     Scratch s_sum, s_tmp, s_tmp2;
     Pinned tail;
-    VIDC_TRY(tail.get(ctx, 64));
-    unsigned long long *t = tail.as<unsigned long long>();  // [0..2] status summary, [3] total words, [4] ntotal, [5] non-empty
-    t[0] = ~0ull; t[1] = 0; t[2] = 0; t[3] = 0; t[4] = 0; t[5] = 0;
-    VIDC_TRY(s_sum.get(ctx, 64));
-    VIDC_HIP(hipMemcpyAsync(s_sum.p, t, 48, hipMemcpyHostToDevice, ctx->stream));
+    unsigned long long *t = nullptr;  // [0..3] status summary (first bad list, -, retries, pending sorts), [4] total words, [5] ntotal, [6] non-empty rows
+};
+int finish_enqueue(vidc_ctx *ctx, vidc_roc *r, EncodeTail &e, Scratch &d_status_buf, const uint32_t *d_sizes) {
+    const uint64_t nlist = r->nlist;
+    VIDC_TRY(e.tail.get(ctx, 128));
+    unsigned long long *t = e.t = e.tail.as<unsigned long long>();
+    t[0] = ~0ull; t[1] = 0; t[2] = 0; t[3] = 0; t[4] = 0; t[5] = 0; t[6] = 0; t[7] = 0;
+    VIDC_TRY(e.s_sum.get(ctx, 64));
+    VIDC_HIP(hipMemcpyAsync(e.s_sum.p, t, 64, hipMemcpyHostToDevice, ctx->stream));
     VIDC_TRY(r->d_word_off.alloc(nlist + 1, ctx->dpool));
     if (nlist) {
         hipLaunchKernelGGL(k_roc_status_summary, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 1024)), dim3(256),
                            0, ctx->stream, d_status_buf.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t)nlist,
-                           s_sum.as<unsigned long long>());
-        VIDC_TRY(device_exscan(ctx, r->d_nwords.p, (uint32_t)nlist, r->d_word_off.p, s_tmp));
+                           e.s_sum.as<unsigned long long>());
+        VIDC_TRY(device_exscan(ctx, r->d_nwords.p, (uint32_t)nlist, r->d_word_off.p, e.s_tmp));
         if (r->rows) {
             VIDC_TRY(r->d_offsets.alloc(nlist + 1, ctx->dpool));
-            VIDC_TRY(device_exscan(ctx, d_sizes, (uint32_t)nlist, r->d_offsets.p, s_tmp2));
+            VIDC_TRY(device_exscan(ctx, d_sizes, (uint32_t)nlist, r->d_offsets.p, e.s_tmp2));
             hipLaunchKernelGGL(k_count_nonzero, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 64)), dim3(256), 0,
-                               ctx->stream, d_sizes, (uint32_t)nlist, s_sum.as<unsigned long long>() + 5);
-            VIDC_HIP(hipMemcpyAsync(t + 4, r->d_offsets.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
+                               ctx->stream, d_sizes, (uint32_t)nlist, e.s_sum.as<unsigned long long>() + 6);
+            VIDC_HIP(hipMemcpyAsync(t + 5, r->d_offsets.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
         }
         VIDC_HIP(hipGetLastError());
-        VIDC_HIP(hipMemcpyAsync(t + 3, r->d_word_off.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
+        VIDC_HIP(hipMemcpyAsync(t + 4, r->d_word_off.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
     } else {
         VIDC_HIP(hipMemsetAsync(r->d_word_off.p, 0, 8, ctx->stream));
         if (r->rows) { VIDC_TRY(r->d_offsets.alloc(1, ctx->dpool)); VIDC_HIP(hipMemsetAsync(r->d_offsets.p, 0, 8, ctx->stream)); }
     }
-    VIDC_HIP(hipMemcpyAsync(t, s_sum.p, 24, hipMemcpyDeviceToHost, ctx->stream));
-    if (r->rows) VIDC_HIP(hipMemcpyAsync(t + 5, s_sum.as<unsigned long long>() + 5, 8, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(t, e.s_sum.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (r->rows) VIDC_HIP(hipMemcpyAsync(t + 6, e.s_sum.as<unsigned long long>() + 6, 8, hipMemcpyDeviceToHost, ctx->stream));
+    return VIDC_OK;
+}
+int finish_complete(vidc_ctx *ctx, vidc_roc *r, EncodeTail &e, const uint32_t *d_arena, uint32_t arena_stride, Scratch &d_status_buf,
+                    uint64_t nonempty_lists, double &kernel_ms) {
+    const uint64_t nlist = r->nlist;
+    const unsigned long long *t = e.t;
     if (t[0] != ~0ull) {
         std::vector<uint32_t> status;
         VIDC_TRY(download(ctx, status, d_status_buf.as<uint32_t>(), nlist));
         VIDC_TRY(check_status(status, "roc encode"));
     }
-    r->total_words = t[3];
-    if (r->rows) { r->ntotal = t[4]; nonempty_lists = t[5]; }
+    r->total_words = t[4];
+    if (r->rows) { r->ntotal = t[5]; nonempty_lists = t[6]; }
     // ANSState::size() = 8 + 4 * words per non-empty list; "let's pretend no memory is used" for empty ones
     // (custom_invlists_impl.cpp:196-206).  Empty lists have no words.
     r->compressed_bytes = 8ull * nonempty_lists + 4ull * r->total_words;
@@ -390,12 +405,48 @@ int finish_encode(vidc_ctx *ctx, vidc_roc *r, const uint32_t *d_arena, uint32_t 
                                r->d_word_off.p, r->d_words.p, (uint32_t)nlist);
         }
         VIDC_HIP(hipGetLastError());
-        double ms = tm.stop();
+        double ms = tm.stop();  // (synchronises: the call's last wait)
         ctx->phase_ms[VIDC_PHASE_ROC_COMPACT] = ms;
         kernel_ms += ms;
+    } else {
+        VIDC_HIP(hipStreamSynchronize(ctx->stream));
     }
     return VIDC_OK;
 }
+
+// ---- decode planning: work items grouped by kernel class, each with private scratch
+// general decoder classes by LDS footprint of the fine prefix rows (2^fb u32, fb = lg(n) - 3): occupancy, not
+// arithmetic, bounds the general decoder when a batch has many mid-size lists
+// (DC_LANE .. the last class: kernels that may hand a list back with VIDC_ST_RETRY)
+enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_B2T, DC_B2S, DC_B2L, DC_B2M,
+                DC_GRP0, DC_GRP2, DC_GRP3, DC_GRP4,   // row-per-list decoder by bucket bits 8 + F (roc_grp.h)
+                DC_LANEP, DC_LANEQ, DC_COUNT };        // 257..512 / 513..1024 ids on a pair / quad of lanes, ids in registers (k_roc_decode_lane_reg<.., 2 / 4>)
+constexpr uint64_t B2_MIN_LIST = 4096;
+constexpr size_t B2_CAP = 1024;      // chains of k_roc_decode_b2 per call (four per CU of an MI355X: 1 MiB of member rows each)
+
+struct DecPlan {
+    std::vector<uint32_t> wl;        // list numbers, grouped by class, longest first inside a class
+    std::vector<uint32_t> item;      // index of each work item in the caller's request
+    size_t count[DC_COUNT] = {};
+    uint64_t sum_n[DC_COUNT] = {}, max_n[DC_COUNT] = {};
+    std::vector<uint64_t> scratch_off, slots_off;
+    uint64_t scratch_words = 0, slots_words = 0;
+    bool lean = false;               // graph rows, lane decoder: item k == request k, no scratch / offset arrays
+    bool tiny_lane = false;          // DC_TINY items run on the lane-per-list kernel
+    bool gsmall_lrows = false;       // DC_GSMALL items keep their member rows in LDS (33 KiB each: only for few lists)
+    uint64_t implicit = 0;           // lean plan without a work list: items are rows 0..implicit-1
+};
+
+}  // namespace
+
+// device copy of a plan, kept with the compressed object for repeated decode_all calls
+struct DecPlanCache {
+    DecPlan plan;
+    DevBuf<uint32_t> d_wl;
+    DevBuf<uint64_t> d_scratch_off, d_slots_off;
+};
+
+namespace {
 
 // decode_all plan of a freshly encoded object (defined with the planner below)
 std::shared_ptr<DecPlanCache> plan_ahead_build(const vidc_roc *r);
@@ -435,10 +486,12 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     if (want_perm) VIDC_TRY(r->d_perm.alloc(ntotal_in ? ntotal_in : 1, ctx->dpool));
     tr.mark("persistent allocs");
     Scratch s_arena, s_status, s_sizes, s_sid, s_wl, s_maxid, s_flags, s_sum;
+    EncodeTail tail;  // status summary + sizes of the call, queued behind the encode kernels
     bool light_prepass = false, pre_deferred = false;
     bool wl_sorted[10] = {};  // work-list classes found longest-first while they were filled
-    Pinned h_wl, h_pre, h_off;
-    struct SyncOnExit {  // an early return while the deferred prepass copy is in flight must not release its staging blocks
+    Pinned h_wl, h_pre, h_off, h_plan;
+    bool plan_on_device = false;
+    struct SyncOnExit {  // an early return while the offsets upload / the deferred prepass copy is in flight must not release their staging blocks
                         // (declared behind them: destroyed first)
         vidc_ctx *c;
         bool armed = false;
@@ -459,59 +512,70 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         if (!offsets) return VIDC_ERR_INVALID;
         r->offsets.assign(offsets, offsets + nlist + 1);
         r->offsets_host = true;
-        bool any_big = false;
+        // one pass over the offsets: validation, longest list, non-empty lists and the class sizes the kernel-family policies
+        // look at (two passes cost a 65 536-list call 30 us more)
+        bool any_big = false, all_desc = false;
         uint64_t max_n = 0;
-        for (uint64_t l = 0; l < nlist; l++) {
-            if (offsets[l + 1] < offsets[l]) { set_error("offsets not monotone at list %llu", (unsigned long long)l); return VIDC_ERR_INVALID; }
-            uint64_t n = offsets[l + 1] - offsets[l];
-            if (n > VIDC_ROC_MAX_LIST) {
-                set_error("list %llu has %llu ids; ROC lists are limited to %u (the reference codec is only "
-                          "lossless up to 65536, SURVEY 8a-Q2)", (unsigned long long)l, (unsigned long long)n,
-                          VIDC_ROC_MAX_LIST);
-                return VIDC_ERR_DOMAIN;
+        uint64_t n_tiny_lists = 0, n_mid_lists = 0, n_mid64_lists = 0, n_grp_lists = 0;
+        {
+            const unsigned parts = par_parts(nlist);
+            struct Acc { uint64_t tiny = 0, mid = 0, mid64 = 0, grp = 0, nonempty = 0, max_n = 0, prev = ~0ull; bool desc = true; int64_t bad_mono = -1, bad_len = -1; };
+            std::vector<Acc> acc(parts);
+            par_ranges(nlist, parts, [&](uint64_t la, uint64_t lb, unsigned t) {
+                Acc x;
+                for (uint64_t l = la; l < lb; l++) {
+                    const uint64_t n = offsets[l + 1] - offsets[l];
+                    if (__builtin_expect(offsets[l + 1] < offsets[l], 0)) { if (x.bad_mono < 0) x.bad_mono = (int64_t)l; continue; }
+                    if (__builtin_expect(n > VIDC_ROC_MAX_LIST, 0)) { if (x.bad_len < 0) x.bad_len = (int64_t)l; continue; }
+                    x.tiny += n <= TINY_MAX;
+                    x.mid += n > TINY_MAX && n <= VIDC_LANE_MAX;
+                    x.mid64 += n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64;
+                    x.grp += n >= gpol.min_n && n <= gpol.max_n;
+                    x.nonempty += n != 0;
+                    x.max_n = std::max(x.max_n, n);
+                    x.desc &= n <= x.prev;  // (equal-sized lists, or an index stored longest list first)
+                    x.prev = n;
+                }
+                acc[t] = x;
+            });
+            for (unsigned t = 0; t < parts; t++) {  // (the first offending list, as a single pass would report it)
+                const Acc &x = acc[t];
+                const int64_t first_bad = x.bad_mono >= 0 && (x.bad_len < 0 || x.bad_mono < x.bad_len) ? x.bad_mono : x.bad_len;
+                if (first_bad >= 0 && first_bad == x.bad_mono) {
+                    set_error("offsets not monotone at list %llu", (unsigned long long)first_bad);
+                    return VIDC_ERR_INVALID;
+                }
+                if (first_bad >= 0) {
+                    set_error("list %llu has %llu ids; ROC lists are limited to %u (the reference codec is only "
+                              "lossless up to 65536, SURVEY 8a-Q2)", (unsigned long long)first_bad,
+                              (unsigned long long)(offsets[first_bad + 1] - offsets[first_bad]), VIDC_ROC_MAX_LIST);
+                    return VIDC_ERR_DOMAIN;
+                }
+                n_tiny_lists += x.tiny; n_mid_lists += x.mid; n_mid64_lists += x.mid64; n_grp_lists += x.grp;
+                nonempty += x.nonempty;
+                max_n = std::max(max_n, x.max_n);
             }
-            any_big |= n > TINY_MAX;
-            max_n = std::max(max_n, n);
-            nonempty += n != 0;
+            any_big = max_n > TINY_MAX;
+            all_desc = parts == 1 && acc[0].desc;
         }
         arena_words = roc_arena_at(r->offsets.data(), 0, nlist);
         r->ntotal = offsets[nlist];
         VIDC_TRY(r->d_offsets.alloc(nlist + 1, ctx->dpool));
-        // (no synchronisation of its own: the staging block lives until the call returns, and the call synchronises several
-        // times before that)
+        // (no synchronisation of its own: the staging block lives until the call returns; an early error return before the
+        // call's first wait synchronises through the guard)
         VIDC_TRY(h_off.get(ctx, (nlist + 1) * 8));
         std::memcpy(h_off.p, offsets, (nlist + 1) * 8);
         VIDC_HIP(hipMemcpyAsync(r->d_offsets.p, h_off.p, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        pre_guard.armed = true;
         tr.mark("offsets");
         // The bitmap kernels own a whole CU's LDS (2^20-bit universe): latency-optimal for long lists, but only
         // num_cu lists in flight.  With many lists, short ones go to the high-occupancy kernels.
         const uint64_t u_min = U_MIN_LIST;
-        uint64_t n_tiny_lists = 0, n_mid_lists = 0;
-        {
-            uint64_t n_mid = 0, n_mid64 = 0, n_tiny = 0, n_grp = 0;
-            {
-                const unsigned parts = par_parts(nlist);
-                std::vector<uint64_t> cnt(4 * (size_t)parts, 0);
-                par_ranges(nlist, parts, [&](uint64_t la, uint64_t lb, unsigned t) {
-                    uint64_t a = 0, b = 0, c = 0, g = 0;
-                    for (uint64_t l = la; l < lb; l++) {
-                        const uint64_t n = offsets[l + 1] - offsets[l];
-                        a += n <= TINY_MAX;
-                        b += n > TINY_MAX && n <= VIDC_LANE_MAX;
-                        c += n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64;
-                        g += n >= gpol.min_n && n <= gpol.max_n;
-                    }
-                    cnt[4 * t] = a; cnt[4 * t + 1] = b; cnt[4 * t + 2] = c; cnt[4 * t + 3] = g;
-                });
-                for (unsigned t = 0; t < parts; t++) { n_tiny += cnt[4 * t]; n_mid += cnt[4 * t + 1]; n_mid64 += cnt[4 * t + 2]; n_grp += cnt[4 * t + 3]; }
-            }
-            n_tiny_lists = n_tiny; n_mid_lists = n_mid;
-            use_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
-            use_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
-            use_lane_tiny = lane_wanted(lpol, n_tiny, LANE_MIN_TINY);
-            // (the octaves of a call must overlap: without spare hardware queues they would run one after the other)
-            use_grp = n_grp && n_grp >= gpol.min_lists && (ctx->wide || gpol.min_lists == 0 || std::getenv("VIDC_GRP_MIN"));
-        }
+        use_lane = lane_wanted(lpol, n_mid_lists, LANE_MIN_LISTS);
+        use_lane64 = lane_wanted(lpol, n_mid64_lists, LANE_MIN_LISTS64);
+        use_lane_tiny = lane_wanted(lpol, n_tiny_lists, LANE_MIN_TINY);
+        // (the octaves of a call must overlap: without spare hardware queues they would run one after the other)
+        use_grp = n_grp_lists && n_grp_lists >= gpol.min_lists && (ctx->wide || gpol.min_lists == 0 || std::getenv("VIDC_GRP_MIN"));
         // classification prepass (one workgroup per list): max id -> precision, sortedness, domain
         const uint32_t *maxid = nullptr, *pflags = nullptr;
         if (any_big) {
@@ -556,6 +620,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 VIDC_HIP(hipMemcpyAsync(h_pre.p, s_maxid.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
                 VIDC_HIP(hipMemcpyAsync(h_pre.as<uint32_t>() + nlist, s_flags.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
                 VIDC_HIP(hipStreamSynchronize(ctx->stream));
+                pre_guard.armed = false;
                 kernel_ms += t.elapsed();
                 maxid = h_pre.as<uint32_t>();
                 pflags = maxid + nlist;
@@ -573,6 +638,59 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             // same order as a single pass
             enum { W_TINY = 0, W_U18, W_U20, W_C1, W_C2, W_C3, W_L4, W_L16, W_L64, W_G2, W_G3, W_COUNT };
             const unsigned parts = par_parts(nlist);
+            std::vector<uint32_t> *dst[W_COUNT] = {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64, &wl_g2, &wl_g3};
+            // Without per-list maxima (the prepass is read back later: no list is long enough for the bitmap kernels, the only
+            // classes chosen by the width of the ids) the class of a list is a function of its LENGTH: the lists are ordered by
+            // length once -- longest first, a stable counting sort, or nothing at all for an index of equal-sized lists -- and
+            // every class is a run of that order, copied out between two binary searches.  The per-list loop below with its
+            // dozen push_back targets and the per-class sorts behind it were 0.13 + 0.02 ms of a 65 536-list call.
+            const bool by_length = !maxid && !pflags && parts == 1 && !f_general && !env_on("VIDC_NO_LENGTH_CLASSES");
+            if (by_length) {
+                std::vector<uint32_t> order(nlist);
+                if (all_desc) {
+                    std::iota(order.begin(), order.end(), 0u);
+                } else {
+                    std::vector<uint32_t> start(max_n + 2, 0);
+                    for (uint64_t l = 0; l < nlist; l++) start[max_n - (offsets[l + 1] - offsets[l]) + 1]++;  // bucket 0 = longest
+                    for (size_t i = 1; i < start.size(); i++) start[i] += start[i - 1];
+                    for (uint64_t l = 0; l < nlist; l++) order[start[max_n - (offsets[l + 1] - offsets[l])]++] = (uint32_t)l;
+                }
+                auto len_at = [&](size_t i) { return offsets[order[i] + 1] - offsets[order[i]]; };
+                auto first_le = [&](uint64_t bound) {  // first position of the order whose list has at most `bound` ids
+                    size_t lo = 0, hi = nlist;
+                    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (len_at(mid) > bound) lo = mid + 1; else hi = mid; }
+                    return lo;
+                };
+                auto class_of = [&](uint64_t n) -> int {  // the decisions of the per-list loop below for a sorted list of n ids
+                    if (n <= TINY_MAX) return W_TINY;
+                    const bool lane_ok = (use_lane && n <= VIDC_LANE_MAX) || (use_lane64 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64);
+                    const bool grp_ok = use_grp && n >= gpol.min_n && n <= gpol.max_n;
+                    return grp_ok ? (n <= VIDC_GRP_LEV2_MAX ? W_G2 : W_G3)
+                           : (lane_ok && n <= 256) ? W_L4
+                           : (lane_ok && n <= VIDC_LANE_MAX) ? W_L16
+                           : lane_ok ? W_L64
+                           : n <= 4096 ? W_C1
+                           : n <= 32768 ? W_C2 : W_C3;
+                };
+                // upper ends of the length intervals on which class_of is constant, longest first
+                uint64_t cuts[] = {VIDC_ROC_MAX_LIST, gpol.max_n, 32768, VIDC_GRP_LEV2_MAX, 4096, VIDC_LANE_MAX64, gpol.min_n - 1, VIDC_LANE_MAX, 256, TINY_MAX};
+                std::sort(std::begin(cuts), std::end(cuts), std::greater<uint64_t>());
+                size_t pos = 0;
+                for (size_t c = 0; c < sizeof(cuts) / sizeof(cuts[0]) && pos < nlist; c++) {
+                    const uint64_t hi = cuts[c], lo = c + 1 < sizeof(cuts) / sizeof(cuts[0]) ? cuts[c + 1] : 0;  // interval (lo, hi]
+                    if (hi == lo) continue;
+                    const size_t end = lo ? first_le(lo) : nlist;  // (the last interval also takes the empty lists)
+                    if (end > pos) {
+                        std::vector<uint32_t> &w = *dst[class_of(hi)];
+                        w.insert(w.end(), order.begin() + (ptrdiff_t)pos, order.begin() + (ptrdiff_t)end);
+                        pos = end;
+                    }
+                }
+                // (the precisions are filled in when the prepass has been read back; tiny-only calls set them above)
+                for (int c = 1; c < W_COUNT; c++) wl_sorted[c - 1] = true;
+                r->order_desc.swap(order);  // the decode planner cuts its classes out of the same order
+                r->order_max_n = max_n;
+            } else {
             std::vector<std::vector<uint32_t>> part_wl((size_t)parts * W_COUNT);
             std::vector<int64_t> bad_list(parts, -1);
             bool cls_desc[W_COUNT];
@@ -631,7 +749,6 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                               "custom_invlists_impl.cpp:163)", (unsigned long long)bad_list[t]);
                     return VIDC_ERR_DOMAIN;
                 }
-            std::vector<uint32_t> *dst[W_COUNT] = {&wl_tiny, &wl_u18, &wl_u20, &wl_c1, &wl_c2, &wl_c3, &wl_l4, &wl_l16, &wl_l64, &wl_g2, &wl_g3};
             for (int c = 1; c < W_COUNT; c++) wl_sorted[c - 1] = cls_desc[c];  // (ws[] below: the classes without the tiny one)
             for (int c = 0; c < W_COUNT; c++) {
                 if (parts == 1) { dst[c]->swap(part_wl[c]); continue; }
@@ -643,6 +760,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                     dst[c]->insert(dst[c]->end(), v.begin(), v.end());
                 }
             }
+            }  // per-list classification
         }
         ntiny = wl_tiny.size();
         tr.mark("classify");
@@ -1059,9 +1177,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         // object now (7 ms per million lists that decode_all would otherwise spend on its critical path)
         // (the end event is recorded first: the planning is host time, not part of the kernels' duration)
         t.mark();
+        VIDC_TRY(finish_enqueue(ctx, r.get(), tail, s_status, s_sizes.as<uint32_t>()));
         if (pre_deferred) {  // the maxima of the lists: precisions and bucket geometry for the decode planner
             VIDC_HIP(hipEventSynchronize(ctx->ev_pre[2]));
-            pre_guard.armed = false;
             const uint32_t *mx = h_pre.as<uint32_t>();
             r->umax.assign(mx, mx + nlist);
             for (uint64_t l = 0; l < nlist; l++) {
@@ -1074,10 +1192,38 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             float pms = 0;
             if (hipEventElapsedTime(&pms, ctx->ev_pre[0], ctx->ev_pre[1]) == hipSuccess) kernel_ms += pms;
         }
-        if (!rows && nlist >= PLAN_AHEAD_MIN_LISTS && r->prec.size() == nlist) r->plan_ahead = plan_ahead_build(r.get());
-        (void)hipEventSynchronize(ctx->ev1);
+        if (!rows && nlist >= PLAN_AHEAD_MIN_LISTS && r->prec.size() == nlist) {
+            r->plan_ahead = plan_ahead_build(r.get());
+            // ... and send its work list and scratch offsets to the device behind the kernels (decode_all then finds the
+            // plan complete: 0.04 ms of its critical path at 65 536 lists)
+            DecPlanCache &pc = *r->plan_ahead;
+            const size_t ni = pc.plan.wl.size();
+            if (ni && !pc.plan.lean) {
+                VIDC_TRY(h_plan.get(ctx, ni * 20));
+                uint64_t *h64 = h_plan.as<uint64_t>();
+                uint32_t *h32 = (uint32_t *)(h64 + 2 * ni);
+                std::memcpy(h64, pc.plan.scratch_off.data(), ni * 8);
+                std::memcpy(h64 + ni, pc.plan.slots_off.data(), ni * 8);
+                std::memcpy(h32, pc.plan.wl.data(), ni * 4);
+                VIDC_TRY(pc.d_scratch_off.alloc(ni, ctx->dpool));
+                VIDC_TRY(pc.d_slots_off.alloc(ni, ctx->dpool));
+                VIDC_TRY(pc.d_wl.alloc(ni, ctx->dpool));
+                // (on a stream of their own -- the last auxiliary one, which no kernel class of this call uses --: behind the
+                // kernels on the caller's stream the 1.3 MB of a 65 536-list plan were 0.06 ms more before the call's wait)
+                hipStream_t cs = ctx->aux[VIDC_NAUX - 1];
+                VIDC_HIP(hipMemcpyAsync(pc.d_scratch_off.p, h64, ni * 8, hipMemcpyHostToDevice, cs));
+                VIDC_HIP(hipMemcpyAsync(pc.d_slots_off.p, h64 + ni, ni * 8, hipMemcpyHostToDevice, cs));
+                VIDC_HIP(hipMemcpyAsync(pc.d_wl.p, h32, ni * 4, hipMemcpyHostToDevice, cs));
+                VIDC_HIP(hipEventRecord(ctx->ev_join[VIDC_NAUX - 1], cs));
+                VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[VIDC_NAUX - 1], 0));
+                plan_on_device = true;
+            }
+        }
+        // ONE wait for the kernels, the status summary and the sizes (queued behind the kernels above)
+        VIDC_HIP(hipStreamSynchronize(ctx->stream));
+        pre_guard.armed = false;
         kernel_ms += t.elapsed();
-        if (ctx->chain_info[0][3]) {  // (t.stop() synchronised the main stream, which joined the auxiliary ones)
+        if (ctx->chain_info[0][3]) {  // (the main stream joined the auxiliary ones)
             float cms = 0;
             if (hipEventElapsedTime(&cms, ctx->ev_chain[0], ctx->ev_chain[1]) == hipSuccess) ctx->phase_ms[VIDC_PHASE_ROC_ENCODE_CHAIN] = cms;
         }
@@ -1088,19 +1234,8 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     // lists are in add order, i.e. normally sorted) and multiset input of the bitmap kernels
     std::vector<uint32_t> pend;
     if (!rows && nlist) {
-        // how many lists are pending: 32 bytes come back, the status array only if there are any
-        Pinned h_sum;
-        VIDC_TRY(h_sum.get(ctx, 64));
-        unsigned long long *t = h_sum.as<unsigned long long>();
-        t[0] = ~0ull; t[1] = 0; t[2] = 0; t[3] = 0;
-        VIDC_TRY(s_sum.get(ctx, 64));
-        VIDC_HIP(hipMemcpyAsync(s_sum.p, t, 32, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_roc_status_summary, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 1024)), dim3(256),
-                           0, ctx->stream, s_status.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t)nlist,
-                           s_sum.as<unsigned long long>());
-        VIDC_HIP(hipGetLastError());
-        VIDC_HIP(hipMemcpyAsync(t, s_sum.p, 32, hipMemcpyDeviceToHost, ctx->stream));
-        VIDC_HIP(hipStreamSynchronize(ctx->stream));
+        // how many lists are pending: the summary came back with the sizes, the status array only if there are any
+        const unsigned long long *t = tail.t;
         if (t[3]) {
             std::vector<uint32_t> status;
             VIDC_TRY(download(ctx, status, s_status.as<uint32_t>(), nlist));
@@ -1141,6 +1276,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 for (uint32_t l : pend) { r->prec[l] = dp[l]; r->umax[l] = 0; }
                 r->plan_ahead.reset();
             }
+            // statuses and word counts of the redone lists: summary and offsets again
+            VIDC_TRY(finish_enqueue(ctx, r.get(), tail, s_status, s_sizes.as<uint32_t>()));
+            VIDC_HIP(hipStreamSynchronize(ctx->stream));
         }
     }
     // bitmap-kernel lists wrote sampled ids into the perm buffer: turn them into input positions
@@ -1184,37 +1322,13 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     }
     tr.mark("second pass / perm");
     ctx->phase_ms[VIDC_PHASE_ROC_ENCODE] = kernel_ms;
-    VIDC_TRY(finish_encode(ctx, r.get(), s_arena.as<uint32_t>(), arena_stride, s_status, s_sizes.as<uint32_t>(), nonempty,
-                           kernel_ms));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_TRY(finish_complete(ctx, r.get(), tail, s_arena.as<uint32_t>(), arena_stride, s_status, nonempty, kernel_ms));
     tr.mark("metadata + compaction");
     ctx->last_kernel_ms = kernel_ms;
+    if (plan_on_device && r->plan_ahead) r->plan_all = std::move(r->plan_ahead);  // (a sorting second pass drops the plan)
     *out = r.release();
     return VIDC_OK;
 }
-
-// ---- decode planning: work items grouped by kernel class, each with private scratch
-// general decoder classes by LDS footprint of the fine prefix rows (2^fb u32, fb = lg(n) - 3): occupancy, not
-// arithmetic, bounds the general decoder when a batch has many mid-size lists
-// (DC_LANE .. the last class: kernels that may hand a list back with VIDC_ST_RETRY)
-enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_B2T, DC_B2S, DC_B2L, DC_B2M,
-                DC_GRP0, DC_GRP2, DC_GRP3, DC_GRP4,   // row-per-list decoder by bucket bits 8 + F (roc_grp.h)
-                DC_LANEP, DC_LANEQ, DC_COUNT };        // 257..512 / 513..1024 ids on a pair / quad of lanes, ids in registers (k_roc_decode_lane_reg<.., 2 / 4>)
-constexpr uint64_t B2_MIN_LIST = 4096;
-constexpr size_t B2_CAP = 1024;      // chains of k_roc_decode_b2 per call (four per CU of an MI355X: 1 MiB of member rows each)
-
-struct DecPlan {
-    std::vector<uint32_t> wl;        // list numbers, grouped by class, longest first inside a class
-    std::vector<uint32_t> item;      // index of each work item in the caller's request
-    size_t count[DC_COUNT] = {};
-    uint64_t sum_n[DC_COUNT] = {}, max_n[DC_COUNT] = {};
-    std::vector<uint64_t> scratch_off, slots_off;
-    uint64_t scratch_words = 0, slots_words = 0;
-    bool lean = false;               // graph rows, lane decoder: item k == request k, no scratch / offset arrays
-    bool tiny_lane = false;          // DC_TINY items run on the lane-per-list kernel
-    bool gsmall_lrows = false;       // DC_GSMALL items keep their member rows in LDS (33 KiB each: only for few lists)
-    uint64_t implicit = 0;           // lean plan without a work list: items are rows 0..implicit-1
-};
 
 inline DecClass grp_dec_class(uint64_t n) {
     const uint32_t f = roc_grp_dec_fbits((uint32_t)n);
@@ -1255,8 +1369,9 @@ inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general
 // lists[i] = list number of request item i (a list may appear more than once)
 // only_general: the caller decodes into int32 rows (wide graph rows): only the kernels that honour out_rows -- the tiny
 // and the general wave-per-list decoders -- may be planned
+// whole_sorted: `lists` is 0 .. nlist-1 and r->order_desc holds the same lists longest first
 void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool rows_flavour, DecPlan &p,
-                 bool allow_lane = true, bool allow_b2 = true, bool only_general = false) {
+                 bool allow_lane = true, bool allow_b2 = true, bool only_general = false, bool whole_sorted = false) {
     const bool f_general = force_general() || only_general;
     if (only_general) { allow_lane = false; allow_b2 = false; }
     const LanePolicy lpol = (allow_lane && !f_general) ? lane_policy() : LANE_NEVER;
@@ -1279,6 +1394,48 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     const GrpPolicy gpol = grp_policy();
     const DecEnv denv;
     bool use_grp = false;
+    auto len = [&](uint32_t i) { return r->offsets[lists[i] + 1] - r->offsets[lists[i]]; };
+    bool by_length = false;
+    if (whole_sorted && !rows_flavour && !f_general && r->order_desc.size() == lists.size() && r->order_max_n <= VIDC_LANE_MAX64 &&
+        !env_on("VIDC_NO_LENGTH_CLASSES")) {
+        // The whole object, no list beyond the lane classes, and the encoder left its lists ordered by length: the class of a list
+        // is a function of its length (dec_class below looks at the precision only for lists of more than 4096 ids), so every class
+        // is one or two runs of that order.  Replaces three passes over the lists (counts, classification with a push_back per
+        // list, sortedness) of a 65 536-list plan.
+        const std::vector<uint32_t> &order = r->order_desc;
+        const uint64_t *offs = r->offsets.data();
+        const size_t nl = order.size();
+        auto first_le = [&](uint64_t bound) {
+            size_t lo = 0, hi = nl;
+            while (lo < hi) { const size_t mid = (lo + hi) / 2; if (offs[order[mid] + 1] - offs[order[mid]] > bound) lo = mid + 1; else hi = mid; }
+            return lo;
+        };
+        const size_t e4096 = 0, e1024 = first_le(VIDC_LANE_MAX), e512 = first_le(VIDC_LANE_PAIR_MAX), e256 = first_le(VIDC_LANE_REG_MAX),
+                     e64 = first_le(TINY_MAX);
+        const uint64_t n_mid64 = e1024 - e4096, n_mid = e64 - e1024, n_tiny = nl - e64;
+        allow_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
+        allow_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
+        p.tiny_lane = lane_wanted(lpol, n_tiny, LANE_MIN_TINY);
+        const bool grp_in_reach = allow_b2 && gpol.dec_min_n <= r->order_max_n && gpol.min_lists != ~0ull;  // (VIDC_FORCE_GRP / VIDC_GRP_DEC_MINN)
+        if ((allow_lane || !n_mid) && (allow_lane64 || !n_mid64) && !grp_in_reach) {
+            by_length = true;
+            auto take = [&](int c, size_t a, size_t b) { if (b > a) cls[c].insert(cls[c].end(), order.begin() + (ptrdiff_t)a, order.begin() + (ptrdiff_t)b); };
+            take(DC_LANE64, e4096, e1024);
+            // 513..1024 | 257..512 | 65..256 (dec_class: pair, quad, 256 buckets, 64 buckets -- in that order)
+            take(denv.quad ? DC_LANEQ : (denv.nb256 ? DC_LANE64 : DC_LANE), e1024, e512);
+            take(denv.pair ? DC_LANEP : (denv.nb256 ? DC_LANE64 : DC_LANE), e512, e256);
+            take(DC_LANE, e256, e64);
+            // (tiny lists in request order, like the per-list loop)
+            if (n_tiny) {
+                if (n_tiny == nl) { cls[DC_TINY].resize(nl); std::iota(cls[DC_TINY].begin(), cls[DC_TINY].end(), 0u); }
+                else {
+                    cls[DC_TINY].assign(order.begin() + (ptrdiff_t)e64, order.end());
+                    std::sort(cls[DC_TINY].begin(), cls[DC_TINY].end());
+                }
+            }
+        }
+    }
+    if (!by_length) {
     {
         uint64_t n_mid = 0, n_mid64 = 0, n_tiny = 0, n_grp = 0;
         for (uint32_t l : lists) {
@@ -1303,7 +1460,6 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
         uint64_t n = r->offsets[l + 1] - r->offsets[l];
         cls[rows_flavour ? DC_TINY : dec_class(n, r->prec[l], u_min, f_general, allow_lane, allow_lane64, use_grp ? &gpol : nullptr, denv)].push_back(i);
     }
-    auto len = [&](uint32_t i) { return r->offsets[lists[i] + 1] - r->offsets[lists[i]]; };
     for (int c = 0; c < DC_COUNT; c++) {
         if (c != DC_TINY && cls[c].size() > 1) {  // counting sort by length, longest first (stable)
             uint64_t maxlen = 0, prev = ~0ull;
@@ -1322,6 +1478,7 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             cls[c].swap(sorted);
         }
     }
+    }  // per-list classification
     // The longest general chains (precision above 20 bits) take k_roc_decode_b2 under the rule of the encoder's
     // k_roc_encode_r2: only when every chain at least half as long as the longest one gets it (<= B2_CAP of them).
     if (allow_b2 && !f_general && !rows_flavour && !old_u_kernels() && !env_on("VIDC_NO_R2")) {
@@ -1468,16 +1625,7 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     p.slots_words = sl;
 }
 
-}  // namespace
 
-// device copy of a plan, kept with the compressed object for repeated decode_all calls
-struct DecPlanCache {
-    DecPlan plan;
-    DevBuf<uint32_t> d_wl;
-    DevBuf<uint64_t> d_scratch_off, d_slots_off;
-};
-
-namespace {
 
 int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64_t *out_off_host, uint64_t *d_out,
                 int32_t *d_out_rows, uint32_t K, const struct DecPlanCache *cache = nullptr) {
@@ -1485,7 +1633,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     const size_t nwork = p.implicit ? (size_t)p.implicit : p.wl.size();
     if (nwork == 0) { ctx->last_kernel_ms = 0; return VIDC_OK; }
     HostTrace tr("roc decode");
-    Scratch s_wl, s_scr_off, s_slots_off, s_scr, s_slots, s_out_off, s_end, s_status, s_sum;
+    Scratch s_wl, s_scr_off, s_slots_off, s_scr, s_slots, s_out_off, s_end, s_sum;
     Pinned h_up;
     const uint32_t *d_wl;
     const uint64_t *d_scr_off = nullptr, *d_slots_off = nullptr;
@@ -1526,10 +1674,9 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     }
     VIDC_TRY(s_scr.get(ctx, p.scratch_words * 4));
     VIDC_TRY(s_slots.get(ctx, p.slots_words * 4));
-    VIDC_TRY(s_end.get(ctx, r->nlist * 4));
-    VIDC_TRY(s_status.get(ctx, r->nlist * 4));
-    VIDC_HIP(hipMemsetAsync(s_end.p, 0, r->nlist * 4, ctx->stream));
-    VIDC_HIP(hipMemsetAsync(s_status.p, 0, r->nlist * 4, ctx->stream));
+    VIDC_TRY(s_end.get(ctx, r->nlist * 8));  // end states | statuses: one block, one memset
+    VIDC_HIP(hipMemsetAsync(s_end.p, 0, r->nlist * 8, ctx->stream));
+    uint32_t *const d_status = s_end.as<uint32_t>() + r->nlist;
     tr.mark("scratch + uploads");
     RocDecArgs a{};
     a.offsets = r->d_offsets.p;
@@ -1538,7 +1685,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     a.out = d_out; a.out_rows = d_out_rows; a.K = K;
     a.scratch_words = s_scr.as<uint32_t>();
     a.slots = s_slots.as<uint32_t>();
-    a.end_state = s_end.as<uint32_t>(); a.status = s_status.as<uint32_t>();
+    a.end_state = s_end.as<uint32_t>(); a.status = d_status;
     a.mt = ctx->d_mt;
 
     size_t base[DC_COUNT];
@@ -1813,31 +1960,34 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         VIDC_HIP(hipEventRecord(ctx->ev_join[i], ctx->aux[i]));
         VIDC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
     }
-    ctx->last_kernel_ms = t.stop();
+    // the end event of the kernels, then the 32-byte status summary (instead of copying two nlist-sized arrays back) behind them:
+    // ONE wait for both
+    t.mark();
+    Pinned h_sum;
+    VIDC_TRY(h_sum.get(ctx, 64));
+    unsigned long long *sum = h_sum.as<unsigned long long>();
+    sum[0] = ~0ull; sum[1] = 0; sum[2] = 0; sum[3] = 0;
+    VIDC_TRY(s_sum.get(ctx, 32));
+    VIDC_HIP(hipMemcpyAsync(s_sum.p, sum, 32, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_roc_status_summary, dim3((uint32_t)std::min<uint64_t>((r->nlist + 255) / 256, 1024)), dim3(256),
+                       0, ctx->stream, d_status, s_end.as<uint32_t>(), (uint32_t)r->nlist,
+                       s_sum.as<unsigned long long>());
+    VIDC_HIP(hipGetLastError());
+    VIDC_HIP(hipMemcpyAsync(sum + 4, s_sum.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    sum += 4;
+    ctx->last_kernel_ms = t.elapsed();
     ctx->phase_ms[VIDC_PHASE_ROC_DECODE] = ctx->last_kernel_ms;
     if (chain_class >= 0) {
         float cms = 0;
         if (hipEventElapsedTime(&cms, ctx->ev_chain[0], ctx->ev_chain[1]) == hipSuccess) ctx->phase_ms[VIDC_PHASE_ROC_DECODE_CHAIN] = cms;
     }
-    tr.mark("decode kernels (sync)");
-
-    // 16-byte summary instead of copying two nlist-sized arrays back
-    VIDC_TRY(s_sum.get(ctx, 32));
-    const unsigned long long init[4] = {~0ull, 0ull, 0ull, 0ull};
-    VIDC_HIP(hipMemcpyAsync(s_sum.p, init, 32, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_roc_status_summary, dim3((uint32_t)std::min<uint64_t>((r->nlist + 255) / 256, 1024)), dim3(256),
-                       0, ctx->stream, s_status.as<uint32_t>(), s_end.as<uint32_t>(), (uint32_t)r->nlist,
-                       s_sum.as<unsigned long long>());
-    VIDC_HIP(hipGetLastError());
-    unsigned long long sum[3] = {0, 0, 0};
-    VIDC_HIP(hipMemcpyAsync(sum, s_sum.p, 24, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
-    tr.mark("status summary");
+    tr.mark("decode kernels + status summary (sync)");
     const double first_ms = ctx->last_kernel_ms;
     uint64_t nonclean = sum[1];
     if (sum[0] != ~0ull || sum[2]) {
         std::vector<uint32_t> status(r->nlist);
-        VIDC_HIP(hipMemcpy(status.data(), s_status.p, r->nlist * 4, hipMemcpyDeviceToHost));
+        VIDC_HIP(hipMemcpy(status.data(), d_status, r->nlist * 4, hipMemcpyDeviceToHost));
         if (sum[2]) {
             // lists the lane-per-list decoder handed back (a full bucket row on skewed ids): redo them with the
             // wave-per-list kernels, into the same output slots
@@ -2002,7 +2152,7 @@ std::shared_ptr<DecPlanCache> plan_ahead_build(const vidc_roc *r) {
     std::vector<uint32_t> all(r->nlist);
     std::iota(all.begin(), all.end(), 0u);
     auto c = std::make_shared<DecPlanCache>();
-    plan_decode(r, all, false, c->plan);
+    plan_decode(r, all, false, c->plan, true, true, false, /*whole_sorted=*/true);
     return c;
 }
 }  // namespace
