@@ -45,6 +45,10 @@ struct vidc_wt {
     DevBuf<uint32_t> d_cls;             // L * rrr_cls_wpl: packed 6-bit classes
     DevBuf<uint64_t> d_offs;            // offset streams, level after level
     DevBuf<uint32_t> d_ptr, d_rs;       // L * (rrr_nsamp + 1): bit position in the offset stream / ones before block 32 s
+    // Query acceleration (both types; like the batch records of an Elias-Fano object it is not part of the reported size):
+    // ones before the start of every node of every level -- level l has 2^l nodes, entry (l, p) at wt_nrank_base(l) + p,
+    // entry (l, 2^l) = the level's total --, what every step of a select / decode walk asked the level's rank structure for.
+    DevBuf<uint32_t> d_nrank;
     DevBuf<uint64_t> d_binom;           // C(n, k), n, k < 64 (row n at 64 n); behind it (d_binom + 4096) the 64 offset widths as bytes
 };
 
@@ -156,8 +160,31 @@ struct BvPlain {
         return rank1(bits, rank, i);
     }
     __device__ __forceinline__ uint64_t select(uint64_t j, bool one) const { return select_bit(bits, rank, nblocks, nwords, j, one); }
+    // the same when the answer is known to lie in [p0, p1) (a node of the level): the directory search starts from the node's blocks
+    __device__ __forceinline__ uint64_t select_in(uint64_t j, bool one, uint64_t p0, uint64_t p1) const {
+        uint64_t lo = p0 / (64 * BLK_WORDS), hi = p1 / (64 * BLK_WORDS) + 1;
+        if (hi > nblocks) hi = nblocks;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            const uint64_t before = one ? rank[mid] : mid * 64 * BLK_WORDS - rank[mid];
+            if (before <= j) lo = mid; else hi = mid;
+        }
+        uint64_t seen = one ? rank[lo] : lo * 64 * BLK_WORDS - rank[lo];
+        for (uint64_t w = lo * BLK_WORDS; w < nwords; w++) {
+            uint64_t word = one ? bits[w] : ~bits[w];
+            const uint32_t c = (uint32_t)__builtin_popcountll(word);
+            if (seen + c > j) {
+                for (uint64_t k = j - seen; k; k--) word &= word - 1;
+                return w * 64 + (uint64_t)__builtin_ctzll(word);
+            }
+            seen += c;
+        }
+        return ~0ull;
+    }
+    static constexpr bool kRrr = false;
 };
 struct WtPlainView {
+    static constexpr bool kRrrView = false;
     const uint64_t *bits;
     const uint32_t *rank;
     uint64_t wpl, bpl;
@@ -231,6 +258,23 @@ struct BvRrr {
         return o;
     }
     __device__ __forceinline__ uint64_t word_at(uint64_t bp, uint32_t c) const { return rrr_unrank_word(c, offset_at(bp, c), binom); }
+    // position inside the block (class c, offset o, `len` existing bits) of its (k+1)-th bit equal to `one`: the unranking walks
+    // the positions from the top and stops at the wanted bit (the k-th from below is the (count - 1 - k)-th from above) instead
+    // of rebuilding the whole word and clearing k bits
+    __device__ __forceinline__ uint32_t select_in_block(uint32_t c, uint64_t o, uint32_t k, bool one, uint32_t len) const {
+        uint32_t t = (one ? c : len - c) - 1u - k;  // wanted bit, counted from the top among the existing bits of its kind
+        for (int p = (int)RRR_B - 1; p >= 0; p--) {
+            if (c == 0) return one ? 0u : (uint32_t)p - t - ((uint32_t)p >= len ? (uint32_t)p + 1u - len : 0u);  // only zeros below
+            const uint64_t b = binom[(uint32_t)p * 64u + c];
+            const bool bit = o >= b;
+            if (bit) { o -= b; c--; }
+            if ((uint32_t)p < len && bit == one) {
+                if (t == 0) return (uint32_t)p;
+                t--;
+            }
+        }
+        return 0u;
+    }
     __device__ __forceinline__ uint64_t rank_1_bit(uint64_t i, bool &bit) const {
         const uint64_t blk = i / RRR_B, s = blk / RRR_K;
         uint64_t r = rs[s], bp = ptr[s];
@@ -257,30 +301,55 @@ struct BvRrr {
         const uint64_t pos = s * RRR_K * RRR_B;
         return (pos < nbits ? pos : nbits) - r;
     }
-    __device__ __forceinline__ uint64_t select(uint64_t j, bool one) const {
-        uint64_t lo = 0, hi = nsamp;  // largest sample with before(s) <= j
+    __device__ __forceinline__ uint64_t select(uint64_t j, bool one) const { return select_in(j, one, 0, nbits); }
+    // (j+1)-th bit equal to `one`, known to lie in [p0, p1) (a node of the level).  The sample search starts from the node's
+    // samples (a node of a deep level spans one or two), the 32 classes behind the sample -- 192 bits, word-aligned: sample s
+    // starts at bit 6 * 32 s -- come with three independent 8-byte loads and are walked in registers, and the unranking stops at
+    // the wanted bit.  The first version made up to 13 + 2 * 31 + 63 DEPENDENT loads per level (directory, one class and one
+    // width per block, one binomial per position): 5 ms for a select on a 16-level tree, whatever the number of queries.
+    __device__ __forceinline__ uint64_t select_in(uint64_t j, bool one, uint64_t p0, uint64_t p1) const {
+        uint64_t lo = p0 / (RRR_K * RRR_B), hi = p1 / (RRR_K * RRR_B) + 1;
+        if (hi > nsamp) hi = nsamp;
         while (hi - lo > 1) {
             const uint64_t mid = (lo + hi) >> 1;
             if (before(mid, one) <= j) lo = mid; else hi = mid;
         }
         uint64_t seen = before(lo, one), bp = ptr[lo];
-        for (uint64_t b = lo * RRR_K; b < nblk; b++) {
-            const uint32_t c = cls_at(b);
-            const uint64_t len = nbits - b * RRR_B < RRR_B ? nbits - b * RRR_B : RRR_B;  // bits of this block that exist
-            const uint64_t cnt = one ? c : len - c;
-            if (seen + cnt > j) {
-                uint64_t v = word_at(bp, c);
-                if (!one) v = ~v & (len == 64 ? ~0ull : ((1ull << len) - 1ull));
-                for (uint64_t k = j - seen; k; k--) v &= v - 1;
-                return b * RRR_B + (uint64_t)__builtin_ctzll(v);
+        const uint2 *cw = (const uint2 *)(cls + 6 * lo);  // (cls_wpl has a pad word; the level's last sample may read into it)
+        const uint2 q0 = cw[0], q1 = cw[1], q2 = cw[2];
+        const uint32_t w[7] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, 0u};
+        bool found = false;
+        uint64_t fb = 0, fbp = 0, fseen = 0;
+        uint32_t fc = 0, flen = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < RRR_K; k++) {
+            const uint64_t b = lo * RRR_K + k;
+            const uint32_t bit0 = 6u * k, wi = bit0 >> 5, sh = bit0 & 31u;
+            uint32_t c = w[wi] >> sh;
+            if (sh > 26u) c |= w[wi + 1] << (32u - sh);
+            c &= 63u;
+            if (!found && b < nblk) {
+                const uint64_t len = nbits - b * RRR_B < RRR_B ? nbits - b * RRR_B : RRR_B;  // bits of this block that exist
+                const uint64_t cnt = one ? c : len - c;
+                if (seen + cnt > j) { found = true; fb = b; fbp = bp; fseen = seen; fc = c; flen = (uint32_t)len; }
+                else { seen += cnt; bp += ow[c]; }
             }
+        }
+        if (found) return fb * RRR_B + select_in_block(fc, offset_at(fbp, fc), (uint32_t)(j - fseen), one, flen);
+        for (uint64_t b = (lo + 1) * RRR_K; b < nblk; b++) {  // (not reached while the samples are consistent)
+            const uint32_t c = cls_at(b);
+            const uint64_t len = nbits - b * RRR_B < RRR_B ? nbits - b * RRR_B : RRR_B;
+            const uint64_t cnt = one ? c : len - c;
+            if (seen + cnt > j) return b * RRR_B + select_in_block(c, offset_at(bp, c), (uint32_t)(j - seen), one, (uint32_t)len);
             seen += cnt;
             bp += ow[c];
         }
         return ~0ull;
     }
+    static constexpr bool kRrr = true;
 };
 struct WtRrrView {
+    static constexpr bool kRrrView = true;
     const uint32_t *cls;
     const uint64_t *offs;
     const uint32_t *ptr, *rs;
@@ -333,6 +402,44 @@ __global__ void k_rrr_samples(const uint64_t *bits, const uint32_t *rank, uint64
     }
 }
 
+__host__ __device__ inline uint64_t wt_nrank_base(uint32_t level) { return ((uint64_t)1 << level) - 1u + level; }  // sum of (2^j + 1), j < level
+// ones before the start of every node of a level (and the level's total), from the level's plain bits
+__global__ void k_wt_node_ranks(const uint64_t *bits, const uint32_t *rank, const uint64_t *C, uint32_t nlist, uint32_t L, uint32_t level,
+                                uint32_t *nrank) {
+    const uint32_t sh = L - level;
+    const uint64_t nodes = (uint64_t)1 << level;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p <= nodes; p += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t s_lo = sh >= 32 ? (p ? nlist : 0) : (p << sh);
+        if (s_lo > nlist) s_lo = nlist;
+        nrank[p] = (uint32_t)rank1(bits, rank, C[s_lo]);
+    }
+}
+
+// Bulk decode of a compressed tree: a level is turned back into plain bits ONCE -- a thread per 63-bit block: the sample before
+// it, the classes up to it, one unranking -- with the 512-bit rank directory the plain kernels use (a thread per entry, from
+// the samples and classes), and the level's partition then runs on the plain view.  The per-element form unranked a block for
+// each of the three ranks every element asks its level for: 16 M ids decoded in 23 ms, 11 x the plain tree.
+__global__ void k_rrr_expand(BvRrr bv, unsigned long long *bits) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < bv.nblk; b += stride) {
+        const uint64_t s = b / RRR_K;
+        uint64_t bp = bv.ptr[s];
+        for (uint64_t k = s * RRR_K; k < b; k++) bp += bv.ow[bv.cls_at(k)];
+        const uint32_t c = bv.cls_at(b);
+        if (!c) continue;  // (the scratch is zeroed)
+        const uint64_t v = bv.word_at(bp, c), pos = b * RRR_B;
+        atomicOr(&bits[pos >> 6], (unsigned long long)(v << (pos & 63)));
+        if ((pos & 63) + RRR_B > 64) atomicOr(&bits[(pos >> 6) + 1], (unsigned long long)(v >> (64 - (pos & 63))));
+    }
+}
+__global__ void k_rrr_rankdir(BvRrr bv, uint64_t nblocks, uint32_t *rank) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j <= nblocks; j += stride) {
+        const uint64_t pos = j * 64 * BLK_WORDS;
+        rank[j] = (uint32_t)bv.rank_1(pos < bv.nbits ? pos : bv.nbits);
+    }
+}
+
 // stable partition of every node of the level by its bit -> order of the next level
 __global__ void k_wt_partition(const uint32_t *syms_in, uint32_t *syms_out, const uint64_t *bits, const uint32_t *rank,
                                const uint64_t *C, uint64_t ntotal, uint32_t nlist, uint32_t L, uint32_t level) {
@@ -352,10 +459,29 @@ __global__ void k_wt_partition(const uint32_t *syms_in, uint32_t *syms_out, cons
     }
 }
 
+// the tables an RRR view looks up once per position / per block, in LDS for the kernels that walk levels per query (the binomials
+// are a dependent load per unranked position: ~30 of them per level and query)
+template <class View>
+__device__ __forceinline__ void wt_stage_tables(const View &vw, uint64_t *s_binom, uint8_t *s_ow) {
+    if constexpr (View::kRrrView) {
+        for (uint32_t i = threadIdx.x; i < 64u * 64u; i += blockDim.x) s_binom[i] = vw.binom[i];
+        const uint8_t *ow = (const uint8_t *)(vw.binom + 64 * 64);
+        for (uint32_t i = threadIdx.x; i < 64u; i += blockDim.x) s_ow[i] = ow[i];
+        __syncthreads();
+    }
+}
+template <class Bv>
+__device__ __forceinline__ void wt_use_tables(Bv &bv, const uint64_t *s_binom, const uint8_t *s_ow) {
+    if constexpr (Bv::kRrr) { bv.binom = s_binom; bv.ow = s_ow; }
+}
+
 // one thread per query: id of the (k+1)-th element of list c
 template <class View>
-__global__ void k_wt_select(View vw, const uint64_t *C, uint32_t nlist, uint32_t L, uint64_t m,
+__global__ void k_wt_select(View vw, const uint64_t *C, const uint32_t *__restrict__ nrank, uint32_t nlist, uint32_t L, uint64_t m,
                             const uint64_t *list_nos, const uint64_t *offs, int64_t *out) {
+    __shared__ uint64_t s_binom[View::kRrrView ? 64 * 64 : 1];
+    __shared__ uint8_t s_ow[64];
+    wt_stage_tables(vw, s_binom, s_ow);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride) {
         const uint32_t c = (uint32_t)list_nos[q];
@@ -364,12 +490,15 @@ __global__ void k_wt_select(View vw, const uint64_t *C, uint32_t nlist, uint32_t
             const uint32_t sh = L - (uint32_t)level;
             const uint64_t p = sh >= 32 ? 0 : (uint64_t)(c >> sh);
             const uint64_t s_lo = sh >= 32 ? 0 : (p << sh);
-            const uint64_t ns = C[s_lo];
+            uint64_t s_hi = sh >= 32 ? nlist : ((p + 1) << sh);
+            if (s_hi > nlist) s_hi = nlist;
+            const uint64_t ns = C[s_lo], ne = C[s_hi];
             const bool bit = (c >> (L - 1u - (uint32_t)level)) & 1u;
-            const auto bv = vw.level((uint32_t)level);
-            const uint64_t r_ns = bv.rank_1(ns);
+            auto bv = vw.level((uint32_t)level);
+            wt_use_tables(bv, s_binom, s_ow);
+            const uint64_t r_ns = nrank[wt_nrank_base((uint32_t)level) + p];  // (== bv.rank_1(ns), from the build)
             const uint64_t before = bit ? r_ns : ns - r_ns;
-            pos = bv.select(before + pos, bit) - ns;
+            pos = bv.select_in(before + pos, bit, ns, ne) - ns;
         }
         out[q] = (int64_t)pos;
     }
@@ -378,8 +507,11 @@ __global__ void k_wt_select(View vw, const uint64_t *C, uint32_t nlist, uint32_t
 // get_ids of the requested lists (custom_invlists_impl.cpp:381-392 loops get_single_id): one thread per output slot,
 // its request item found in the m + 1 output offsets
 template <class View>
-__global__ void k_wt_decode_lists(View vw, const uint64_t *C, uint32_t L, uint64_t m, const uint64_t *list_nos,
-                                  const uint64_t *out_off, uint64_t total, uint64_t *out) {
+__global__ void k_wt_decode_lists(View vw, const uint64_t *C, const uint32_t *__restrict__ nrank, uint32_t nlist_, uint32_t L, uint64_t m,
+                                  const uint64_t *list_nos, const uint64_t *out_off, uint64_t total, uint64_t *out) {
+    __shared__ uint64_t s_binom[View::kRrrView ? 64 * 64 : 1];
+    __shared__ uint8_t s_ow[64];
+    wt_stage_tables(vw, s_binom, s_ow);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
         uint64_t lo = 0, hi = m;  // largest i with out_off[i] <= g
@@ -393,10 +525,14 @@ __global__ void k_wt_decode_lists(View vw, const uint64_t *C, uint32_t L, uint64
             const uint32_t sh = L - (uint32_t)level;
             const uint64_t p = sh >= 32 ? 0 : (uint64_t)(c >> sh);
             const uint64_t ns = C[sh >= 32 ? 0 : (p << sh)];
+            uint64_t s_hi = sh >= 32 ? nlist_ : ((p + 1) << sh);
+            if (s_hi > nlist_) s_hi = nlist_;
+            const uint64_t ne = C[s_hi];
             const bool bit = (c >> (L - 1u - (uint32_t)level)) & 1u;
-            const auto bv = vw.level((uint32_t)level);
-            const uint64_t r_ns = bv.rank_1(ns);
-            pos = bv.select((bit ? r_ns : ns - r_ns) + pos, bit) - ns;
+            auto bv = vw.level((uint32_t)level);
+            wt_use_tables(bv, s_binom, s_ow);
+            const uint64_t r_ns = nrank[wt_nrank_base((uint32_t)level) + p];
+            pos = bv.select_in((bit ? r_ns : ns - r_ns) + pos, bit, ns, ne) - ns;
         }
         out[g] = pos;
     }
@@ -404,8 +540,12 @@ __global__ void k_wt_decode_lists(View vw, const uint64_t *C, uint32_t L, uint64
 
 // get_ids for every list (custom_invlists_impl.cpp:381-392 loops get_single_id)
 template <class View>
-__global__ void k_wt_decode_all(View vw, const uint64_t *C, uint32_t nlist, uint32_t L, uint64_t ntotal,
+__global__ void k_wt_decode_all(View vw, const uint64_t *C, const uint32_t *__restrict__ nrank, uint32_t nlist, uint32_t L, uint64_t ntotal,
                                 uint64_t *out) {
+    __shared__ uint64_t s_binom[View::kRrrView ? 64 * 64 : 1];
+    __shared__ uint8_t s_ow[64];
+    wt_stage_tables(vw, s_binom, s_ow);
+    const uint32_t nlist_ = nlist;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ntotal; g += stride) {
         const uint32_t c = find_list(C, nlist, g);
@@ -414,10 +554,14 @@ __global__ void k_wt_decode_all(View vw, const uint64_t *C, uint32_t nlist, uint
             const uint32_t sh = L - (uint32_t)level;
             const uint64_t p = sh >= 32 ? 0 : (uint64_t)(c >> sh);
             const uint64_t ns = C[sh >= 32 ? 0 : (p << sh)];
+            uint64_t s_hi = sh >= 32 ? nlist_ : ((p + 1) << sh);
+            if (s_hi > nlist_) s_hi = nlist_;
+            const uint64_t ne = C[s_hi];
             const bool bit = (c >> (L - 1u - (uint32_t)level)) & 1u;
-            const auto bv = vw.level((uint32_t)level);
-            const uint64_t r_ns = bv.rank_1(ns);
-            pos = bv.select((bit ? r_ns : ns - r_ns) + pos, bit) - ns;
+            auto bv = vw.level((uint32_t)level);
+            wt_use_tables(bv, s_binom, s_ow);
+            const uint64_t r_ns = nrank[wt_nrank_base((uint32_t)level) + p];
+            pos = bv.select_in((bit ? r_ns : ns - r_ns) + pos, bit, ns, ne) - ns;
         }
         out[g] = pos;
     }
@@ -431,8 +575,8 @@ struct WtItem {
     uint32_t id, pref;
 };
 template <bool LAST, class Bv>
-__global__ void k_wt_decode_level(const WtItem *in, WtItem *out, uint64_t *out_ids, Bv bv, const uint64_t *C, uint64_t ntotal,
-                                  uint32_t nlist, uint32_t L, uint32_t level) {
+__global__ void k_wt_decode_level(const WtItem *in, WtItem *out, uint64_t *out_ids, Bv bv, const uint64_t *C,
+                                  const uint32_t *__restrict__ nrank_level, uint64_t ntotal, uint32_t nlist, uint32_t L, uint32_t level) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t sh = L - level;  // symbols of one node share their top `level` bits
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ntotal; i += stride) {
@@ -443,7 +587,8 @@ __global__ void k_wt_decode_level(const WtItem *in, WtItem *out, uint64_t *out_i
         if (s_hi > nlist) s_hi = nlist;
         const uint64_t ns = C[s_lo], ne = C[s_hi];
         bool bit;
-        const uint64_t r_ns = bv.rank_1(ns), r_i = bv.rank_1_bit(i, bit), r_ne = bv.rank_1(ne);
+        // (ones before the node and before the next one: from the build's table -- one rank per element instead of three)
+        const uint64_t r_ns = nrank_level[p], r_ne = nrank_level[p + 1], r_i = bv.rank_1_bit(i, bit);
         const uint64_t zeros_in_node = (ne - ns) - (r_ne - r_ns);
         const uint64_t dst = bit ? ns + zeros_in_node + (r_i - r_ns) : ns + ((i - ns) - (r_i - r_ns));
         if (LAST) out_ids[dst] = it.id;
@@ -511,7 +656,7 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
         VIDC_HIP(hipMemsetAsync(w->d_bits.p, 0, L * w->words_per_level * 8, ctx->stream));
     } else {
         w->rrr_nblk = nblk; w->rrr_nsamp = nsamp;
-        w->rrr_cls_wpl = (6 * nblk + 31) / 32 + 1;
+        w->rrr_cls_wpl = 6 * nsamp + 2;  // 192 bits per sample of 32 blocks (whole samples: select_in reads a sample's six words), even: 8-byte loads
         VIDC_TRY(w->d_cls.alloc(L * w->rrr_cls_wpl));
         VIDC_TRY(w->d_ptr.alloc(L * (nsamp + 1)));
         VIDC_TRY(w->d_rs.alloc(L * (nsamp + 1)));
@@ -534,6 +679,8 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
         VIDC_HIP(hipStreamSynchronize(ctx->stream));  // (bn leaves scope)
         w->rrr_off_base.assign(L + 1, 0);
     }
+    VIDC_TRY(w->d_nrank.alloc(wt_nrank_base(L) + 1));
+    VIDC_HIP(hipMemsetAsync(w->d_nrank.p, 0, (wt_nrank_base(L) + 1) * 4, ctx->stream));
     VIDC_TRY(s_a.get(ctx, (nt ? nt : 1) * 4));
     VIDC_TRY(s_b.get(ctx, (nt ? nt : 1) * 4));
     VIDC_TRY(s_err.get(ctx, 4));
@@ -564,6 +711,8 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
                            (nt + 63) / 64);
         hipLaunchKernelGGL(k_wt_rankdir, dim3(1), dim3(1024), 0, ctx->stream, bits, w->words_per_level,
                            w->blocks_per_level, rank);
+        hipLaunchKernelGGL(k_wt_node_ranks, dim3((uint32_t)std::min<uint64_t>((((uint64_t)1 << level) + 256) / 256, 1024)), dim3(256), 0,
+                           ctx->stream, bits, rank, w->d_C.p, (uint32_t)nlist, L, level, w->d_nrank.p + wt_nrank_base(level));
         if (level + 1 < L) {
             hipLaunchKernelGGL(k_wt_partition, dim3(grid), dim3(256), 0, ctx->stream, cur, nxt, bits, rank, w->d_C.p, nt,
                                (uint32_t)nlist, L, level);
@@ -632,10 +781,10 @@ int vidc_wt_select(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint64_t *
     VIDC_HIP(hipMemcpyAsync(s_o.p, offs, m * 8, hipMemcpyHostToDevice, ctx->stream));
     const dim3 sgrid((uint32_t)std::min<uint64_t>((m + 127) / 128, 1u << 16));
     if (w->wt_type == 1)
-        hipLaunchKernelGGL(k_wt_select<WtRrrView>, sgrid, dim3(128), 0, ctx->stream, rrr_view(w), w->d_C.p, (uint32_t)w->nlist,
+        hipLaunchKernelGGL(k_wt_select<WtRrrView>, sgrid, dim3(128), 0, ctx->stream, rrr_view(w), w->d_C.p, w->d_nrank.p, (uint32_t)w->nlist,
                            w->L, m, s_l.as<uint64_t>(), s_o.as<uint64_t>(), s_r.as<int64_t>());
     else
-        hipLaunchKernelGGL(k_wt_select<WtPlainView>, sgrid, dim3(128), 0, ctx->stream, plain_view(w), w->d_C.p,
+        hipLaunchKernelGGL(k_wt_select<WtPlainView>, sgrid, dim3(128), 0, ctx->stream, plain_view(w), w->d_C.p, w->d_nrank.p,
                            (uint32_t)w->nlist, w->L, m, s_l.as<uint64_t>(), s_o.as<uint64_t>(), s_r.as<int64_t>());
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipMemcpyAsync(ids_out, s_r.p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -663,10 +812,10 @@ int vidc_wt_decode_lists(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     const dim3 dgrid((uint32_t)std::min<uint64_t>((total + 127) / 128, 1u << 16));
     if (w->wt_type == 1)
-        hipLaunchKernelGGL(k_wt_decode_lists<WtRrrView>, dgrid, dim3(128), 0, ctx->stream, rrr_view(w), w->d_C.p, w->L, m,
+        hipLaunchKernelGGL(k_wt_decode_lists<WtRrrView>, dgrid, dim3(128), 0, ctx->stream, rrr_view(w), w->d_C.p, w->d_nrank.p, (uint32_t)w->nlist, w->L, m,
                            s_l.as<uint64_t>(), s_o.as<uint64_t>(), total, d_out);
     else
-        hipLaunchKernelGGL(k_wt_decode_lists<WtPlainView>, dgrid, dim3(128), 0, ctx->stream, plain_view(w), w->d_C.p, w->L, m,
+        hipLaunchKernelGGL(k_wt_decode_lists<WtPlainView>, dgrid, dim3(128), 0, ctx->stream, plain_view(w), w->d_C.p, w->d_nrank.p, (uint32_t)w->nlist, w->L, m,
                            s_l.as<uint64_t>(), s_o.as<uint64_t>(), total, d_out);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
@@ -685,13 +834,18 @@ int vidc_wt_decode_all(vidc_ctx *ctx, const vidc_wt *w, uint64_t *d_out) {
     const uint32_t grid = (uint32_t)std::min<uint64_t>((w->ntotal + 255) / 256, (uint64_t)ctx->num_cu * 32);
     if (w->L == 0) {  // one list: ids 0..ntotal-1 in order (the per-id kernel handles it)
         if (w->wt_type == 1)
-            hipLaunchKernelGGL(k_wt_decode_all<WtRrrView>, dim3(grid), dim3(128), 0, ctx->stream, rrr_view(w), w->d_C.p,
+            hipLaunchKernelGGL(k_wt_decode_all<WtRrrView>, dim3(grid), dim3(128), 0, ctx->stream, rrr_view(w), w->d_C.p, w->d_nrank.p,
                                (uint32_t)w->nlist, w->L, w->ntotal, d_out);
         else
-            hipLaunchKernelGGL(k_wt_decode_all<WtPlainView>, dim3(grid), dim3(128), 0, ctx->stream, plain_view(w), w->d_C.p,
+            hipLaunchKernelGGL(k_wt_decode_all<WtPlainView>, dim3(grid), dim3(128), 0, ctx->stream, plain_view(w), w->d_C.p, w->d_nrank.p,
                                (uint32_t)w->nlist, w->L, w->ntotal, d_out);
     } else {
         Scratch s_a, s_b;  // ping-pong (id, symbol prefix) arrays
+        Scratch s_bits, s_rank;  // wt_type 1: one level as plain bits + rank directory
+        if (w->wt_type == 1) {
+            VIDC_TRY(s_bits.get(ctx, w->words_per_level * 8));
+            VIDC_TRY(s_rank.get(ctx, (w->blocks_per_level + 1) * 4));
+        }
         if (w->L > 1) {
             VIDC_TRY(s_a.get(ctx, w->ntotal * sizeof(WtItem)));
             if (w->L > 2) VIDC_TRY(s_b.get(ctx, w->ntotal * sizeof(WtItem)));
@@ -701,20 +855,22 @@ int vidc_wt_decode_all(vidc_ctx *ctx, const vidc_wt *w, uint64_t *d_out) {
             const bool last = level + 1 == w->L;
             WtItem *out = last ? nullptr : ((level & 1u) ? s_b.as<WtItem>() : s_a.as<WtItem>());
             uint64_t *oid = last ? d_out : nullptr;
-            if (w->wt_type == 1) {
-                const BvRrr bv = rrr_view_level(w, level);
-                if (last) hipLaunchKernelGGL((k_wt_decode_level<true, BvRrr>), dim3(grid), dim3(256), 0, ctx->stream, in, out, oid, bv,
-                                             w->d_C.p, w->ntotal, (uint32_t)w->nlist, w->L, level);
-                else hipLaunchKernelGGL((k_wt_decode_level<false, BvRrr>), dim3(grid), dim3(256), 0, ctx->stream, in, out, oid, bv,
-                                        w->d_C.p, w->ntotal, (uint32_t)w->nlist, w->L, level);
-            } else {
-                const BvPlain bv{w->d_bits.p + (uint64_t)level * w->words_per_level,
-                                 w->d_rank.p + (uint64_t)level * (w->blocks_per_level + 1), w->blocks_per_level, w->words_per_level};
-                if (last) hipLaunchKernelGGL((k_wt_decode_level<true, BvPlain>), dim3(grid), dim3(256), 0, ctx->stream, in, out, oid, bv,
-                                             w->d_C.p, w->ntotal, (uint32_t)w->nlist, w->L, level);
-                else hipLaunchKernelGGL((k_wt_decode_level<false, BvPlain>), dim3(grid), dim3(256), 0, ctx->stream, in, out, oid, bv,
-                                        w->d_C.p, w->ntotal, (uint32_t)w->nlist, w->L, level);
+            const uint32_t *nr = w->d_nrank.p + wt_nrank_base(level);
+            BvPlain bv{w->d_bits.p + (uint64_t)level * w->words_per_level,
+                       w->d_rank.p + (uint64_t)level * (w->blocks_per_level + 1), w->blocks_per_level, w->words_per_level};
+            if (w->wt_type == 1) {  // the level back as plain bits + rank directory (scratch), each block unranked once
+                const BvRrr rv = rrr_view_level(w, level);
+                VIDC_HIP(hipMemsetAsync(s_bits.p, 0, w->words_per_level * 8, ctx->stream));
+                hipLaunchKernelGGL(k_rrr_expand, dim3((uint32_t)std::min<uint64_t>((w->rrr_nblk + 255) / 256, (uint64_t)ctx->num_cu * 32)),
+                                   dim3(256), 0, ctx->stream, rv, (unsigned long long *)s_bits.p);
+                hipLaunchKernelGGL(k_rrr_rankdir, dim3((uint32_t)std::min<uint64_t>((w->blocks_per_level + 256) / 256, 1024)), dim3(256),
+                                   0, ctx->stream, rv, w->blocks_per_level, s_rank.as<uint32_t>());
+                bv = BvPlain{s_bits.as<uint64_t>(), s_rank.as<uint32_t>(), w->blocks_per_level, w->words_per_level};
             }
+            if (last) hipLaunchKernelGGL((k_wt_decode_level<true, BvPlain>), dim3(grid), dim3(256), 0, ctx->stream, in, out, oid, bv,
+                                         w->d_C.p, nr, w->ntotal, (uint32_t)w->nlist, w->L, level);
+            else hipLaunchKernelGGL((k_wt_decode_level<false, BvPlain>), dim3(grid), dim3(256), 0, ctx->stream, in, out, oid, bv,
+                                    w->d_C.p, nr, w->ntotal, (uint32_t)w->nlist, w->L, level);
             in = out;
         }
         VIDC_HIP(hipGetLastError());
