@@ -544,10 +544,13 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
                             U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT("", "s_lshr_b32 s68, s58, 31\n") "7:\n" U2_ENC_OUTER(""));
 #undef U2_STEP_X
         } else {
-            if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_T(U2_ENC_ORDER, "", "", "s_cbranch_scc0 7f\n")
+            // (round 4: the 18-bit bodies in eight / four copies with the ring test in the last one, like the 20-bit ones)
+#define U2_STEP_X1(ORDER, LSHR) U2_ENC_TOP_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_T(ORDER, LSHR, "", "s_cbranch_scc0 7f\n")
+            if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY "1:\n" U2_STEP_X1(U2_ENC_ORDER, "") U2_STEP_X1(U2_ENC_ORDER, "") U2_STEP_X1(U2_ENC_ORDER, "") U2_STEP_X1(U2_ENC_ORDER, "") U2_STEP_X1(U2_ENC_ORDER, "") U2_STEP_X1(U2_ENC_ORDER, "") U2_STEP_X1(U2_ENC_ORDER, "")
                                        U2_ENC_TOP_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT(U2_ENC_ORDER, "") "7:\n" U2_ENC_OUTER(U2_ORDER_FLUSH));
-            else U2_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_T("", "s_lshr_b32 s68, s58, 31\n", "", "s_cbranch_scc0 7f\n")
+            else U2_ENC_ASM(U2_ENC_ENTRY "1:\n" U2_STEP_X1("", "s_lshr_b32 s68, s58, 31\n") U2_STEP_X1("", "s_lshr_b32 s68, s58, 31\n") U2_STEP_X1("", "s_lshr_b32 s68, s58, 31\n")
                             U2_ENC_TOP_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT("", "s_lshr_b32 s68, s58, 31\n") "7:\n" U2_ENC_OUTER(""));
+#undef U2_STEP_X1
         }
 #undef U2_ENC_ASM
         // clang-format on
@@ -1170,14 +1173,12 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
 #define U2_DBG(k)
 #endif
     uint32_t i = 0;  // ids decoded so far
-    constexpr uint32_t RING_LO = U::G == 4u ? U2_DEC_RING_LO : 2u, RING_HI = U::G == 4u ? U2_DEC_RING_HI : 61u;
+    constexpr uint32_t RING_LO = U2_DEC_RING_LO, RING_HI = U2_DEC_RING_HI;  // (both geometries run the eight-copy loop since round 4)
     while (i < n) {
-        if (U::G == 4u) {  // (the eight-copy loop wants 18..53 words: refill below 22 -- 21 + 32 = 53 -- instead of ws_prepare's 8)
+        {  // (the eight-copy loop wants 18..53 words: refill below 22 -- 21 + 32 = 53 -- instead of ws_prepare's 8)
             const uint32_t res = st.sp - st.lo;
             if (res > 56u) ws_spill32(st);
             else if (res < 22u && st.lo != 0u) ws_refill32(st);
-        } else {
-            ws_prepare(st);
         }
         if (lt_2p31(head) || st.sp - st.lo < RING_LO || st.sp - st.lo > RING_HI) {  // generic step
             U2_DBG(0);
@@ -1203,7 +1204,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
               "s51", "s52", "s53", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s70", "s71", "s72", "s75", "s96", "s97",\
               "s98", "s99")
         if (U::G == 4u) U2_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP8(U2_DEC_IDX_G4, U2_DEC_MID, U2_DEC_RANK_G4) U2_DEC_OUTER_T("-18", "35"));
-        else U2_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP4(U2_DEC_IDX_G1, U2_DEC_MID, U2_DEC_RANK_G1) U2_DEC_OUTER);
+        else U2_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP8(U2_DEC_IDX_G1, U2_DEC_MID, U2_DEC_RANK_G1) U2_DEC_OUTER_T("-18", "35"));
 #undef U2_DEC_ASM
         // clang-format on
         head = s_h;
