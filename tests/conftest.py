@@ -8,6 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# Hardware queues of the test process (ROCm runtime variable, read when HIP initialises -- i.e. before the first torch / libvidc
+# call): 8, so that a test can create a context whose kernel classes really run on 8 streams (VIDC_WIDE_STREAMS=1 when the
+# context is created; the S2 repeated-decode stress runs in both modes).  Contexts stay in the default 4-stream mode unless a
+# test asks otherwise: the automatic policies of the library are tested as a process without the variable would see them.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("VIDC_WIDE_STREAMS", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -11,11 +11,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench():
+    """bench.py sets GPU_MAX_HW_QUEUES for its own process at import time: importing it into the test process must not leak
+    that into os.environ (contexts created by later GPU tests of the same pytest run would all come up in the 8-stream
+    mode and the default 4-stream path would go unexercised)."""
+    saved = os.environ.get("GPU_MAX_HW_QUEUES")
     sys.path.insert(0, ROOT)
     try:
         return importlib.import_module("bench")
     finally:
         sys.path.pop(0)
+        if saved is None:
+            os.environ.pop("GPU_MAX_HW_QUEUES", None)
+        else:
+            os.environ["GPU_MAX_HW_QUEUES"] = saved
+
+
+def test_importing_bench_does_not_change_the_environment_of_the_test_process():
+    before = os.environ.get("GPU_MAX_HW_QUEUES")
+    _bench()
+    assert os.environ.get("GPU_MAX_HW_QUEUES") == before
 
 
 def test_gpus_flag_re_executes_under_torch_distributed_run(monkeypatch):

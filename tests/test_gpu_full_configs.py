@@ -259,3 +259,53 @@ def test_s2_shape_parity_roc_and_elias_fano(oracle):
     for k, l in enumerate(sample[:40]):
         assert np.array_equal(got[int(goff[k]):int(goff[k + 1])], ids_host[l])
     assert 10.0 < bits_roc < 40.0 and 8.0 * ef.compressed_bytes / ntotal < 40.0
+
+
+@pytest.mark.gpu
+def test_s2_repeated_decodes_are_identical_with_4_and_8_class_streams(monkeypatch):
+    """The full S2 object (10^9 ids in 2^20 Zipf lists, every kernel family of a large call at once) decoded again and again must
+    give the same array every time, on a context with 8 class streams and on one with 4.  Round 3 found a register-indexing form
+    in the lane-pair decoder that passed every unit test and corrupted a list of ANOTHER kernel class in one S2-sized decode out
+    of ten; the form is gone, its root cause is not known, so this stress gates every change."""
+    import torch
+
+    from vector_db_id_compression_amd import _lib, synth
+    from vector_db_id_compression_amd.codecs import RocLists
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2 ** 30:
+        pytest.skip("needs ~50 GiB of device memory")
+    w = synth.workload("s2", seed=1043)
+    off, ids = w["offsets"], w["ids"]
+    n = int(off[-1])
+    ref = None
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    for wide in ("1", "0"):
+        monkeypatch.setenv("VIDC_WIDE_STREAMS", wide)
+        ctx = _lib.Context(0)
+        assert ctx.class_streams() == (8 if wide == "1" else 4)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        r = RocLists.encode(off, ids, ctx=ctx, want_perm=True)
+        for it in range(24):
+            out.fill_(-1)
+            r.decode_all(out)
+            assert r.last_decode_nonclean == 0
+            if ref is None:
+                ref = out.clone()
+                # the first decode against the input: every list holds its own ids
+                ends = off[1:].astype(np.int64)
+                bounds = torch.from_numpy(ends).cuda()
+                a = 0
+                while a < n:  # chunks cut on list boundaries
+                    j = int(np.searchsorted(ends, min(n, a + (1 << 27)), side="right"))
+                    b = int(ends[j - 1]) if j > 0 and ends[j - 1] > a else int(ends[min(j, ends.size - 1)])
+                    seg = torch.searchsorted(bounds, torch.arange(a, b, device="cuda"), right=True) << 32
+                    assert torch.equal(torch.sort(seg + ref[a:b]).values, torch.sort(seg + ids[a:b]).values)
+                    del seg
+                    a = b
+            else:
+                assert torch.equal(out, ref), f"decode {it} on the {'8' if wide == '1' else '4'}-stream context differs from the first one"
+        del r
+        ctx.close()
+    del ref, out
+    _lib.default_context(0).trim()

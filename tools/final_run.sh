@@ -10,7 +10,7 @@ VIDC_FORCE_LANE=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_
 VIDC_OLD_U=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_old_u.txt
 VIDC_FULL_PREPASS=1 VIDC_NO_LANE_REG=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_full_prepass_no_lane_reg.txt
 VIDC_FORCE_GRP=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_force_grp.txt
-GPU_MAX_HW_QUEUES=8 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_wide.txt
+GPU_MAX_HW_QUEUES=8 VIDC_WIDE_STREAMS=1 timeout 1200 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_wide.txt
 VIDC_NO_LANE_PAIR=1 VIDC_FORCE_LANE=1 timeout 900 python -m pytest tests/test_gpu_roc.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_no_lane_pair.txt
 # S2 decoded 100 times per mode and compared with the first decode (the list-level flake hunt of round 3)
 (GPU_MAX_HW_QUEUES=8 NQS=4,8,5,6 ITERS=100 timeout 200 python tools/repro_s2b.py "X=1" 2>&1 | grep "differs\|it 99" | cut -c1-160; GPU_MAX_HW_QUEUES=4 NQS=3 ITERS=100 timeout 200 python tools/repro_s2b.py "X=1" 2>&1 | grep "differs\|it 99" | cut -c1-160) > gpurun_out/$R/s2_repeated_decodes.txt

@@ -449,7 +449,7 @@ struct DecPlanCache {
 namespace {
 
 // decode_all plan of a freshly encoded object (defined with the planner below)
-std::shared_ptr<DecPlanCache> plan_ahead_build(const vidc_roc *r);
+std::shared_ptr<DecPlanCache> plan_ahead_build(const vidc_roc *r, bool wide);
 constexpr uint64_t PLAN_AHEAD_MIN_LISTS = 4096;
 
 int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint64_t *d_ids, bool rows, uint64_t N,
@@ -1193,7 +1193,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             if (hipEventElapsedTime(&pms, ctx->ev_pre[0], ctx->ev_pre[1]) == hipSuccess) kernel_ms += pms;
         }
         if (!rows && nlist >= PLAN_AHEAD_MIN_LISTS && r->prec.size() == nlist) {
-            r->plan_ahead = plan_ahead_build(r.get());
+            r->plan_ahead = plan_ahead_build(r.get(), ctx->wide);
             // ... and send its work list and scratch offsets to the device behind the kernels (decode_all then finds the
             // plan complete: 0.04 ms of its critical path at 65 536 lists)
             DecPlanCache &pc = *r->plan_ahead;
@@ -1370,7 +1370,9 @@ inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general
 // only_general: the caller decodes into int32 rows (wide graph rows): only the kernels that honour out_rows -- the tiny
 // and the general wave-per-list decoders -- may be planned
 // whole_sorted: `lists` is 0 .. nlist-1 and r->order_desc holds the same lists longest first
-void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool rows_flavour, DecPlan &p,
+// wide: the context that will run the plan has a stream per kernel class (8 hardware queues): the row-per-list kernels are
+// only planned then, like the encoder only takes them then (their octaves must overlap)
+void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool rows_flavour, DecPlan &p, bool wide,
                  bool allow_lane = true, bool allow_b2 = true, bool only_general = false, bool whole_sorted = false) {
     const bool f_general = force_general() || only_general;
     if (only_general) { allow_lane = false; allow_b2 = false; }
@@ -1445,7 +1447,8 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             n_mid64 += n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64;
             n_grp += n >= gpol.dec_min_n && n <= gpol.dec_max_n;
         }
-        use_grp = allow_b2 && !f_general && !rows_flavour && n_grp && n_grp >= gpol.min_lists;
+        use_grp = allow_b2 && !f_general && !rows_flavour && n_grp && n_grp >= gpol.min_lists &&
+                  (wide || gpol.min_lists == 0 || std::getenv("VIDC_GRP_MIN"));
         allow_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
         allow_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
         p.tiny_lane = lane_wanted(lpol, rows_flavour ? lists.size() : n_tiny, LANE_MIN_TINY);
@@ -1842,14 +1845,11 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 break;
             case DC_LANEQ:
                 b.lpw = 16u;
-                if (env_on("VIDC_PAIR_DRY")) b.K = 0xdeadu;
                 hipLaunchKernelGGL((k_roc_decode_lane_reg<VIDC_LANE_REG_EL, 4>), dim3((b.nwork + 15u) / 16u), dim3(64), 0, st_, b,
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
             case DC_LANEP:
                 b.lpw = 32u;
-                if (env_on("VIDC_PAIR_DRY")) b.K = 0xdeadu;   // debug: no stores
-                if (env_on("VIDC_PAIR_NOP")) b.K = 0xdeaeu;   // debug: the kernel returns at once
                 hipLaunchKernelGGL((k_roc_decode_lane_reg<VIDC_LANE_REG_EL, 2>), dim3((b.nwork + 31u) / 32u), dim3(64), 0, st_, b,
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
@@ -2001,7 +2001,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
             for (uint32_t l : lists2) status[l] = VIDC_ST_OK;
             VIDC_TRY(check_status(status, "roc decode"));
             DecPlan p2;
-            plan_decode(r, lists2, false, p2, false, false);
+            plan_decode(r, lists2, false, p2, ctx->wide, false, false);
             std::vector<uint64_t> out_off2(lists2.size());
             for (size_t k = 0; k < lists2.size(); k++) out_off2[k] = off2[p2.item[k]];
             VIDC_TRY(decode_impl(ctx, r, p2, out_off2.data(), d_out, nullptr, 0));
@@ -2148,11 +2148,11 @@ int vidc_roc_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, cons
 }
 
 namespace {
-std::shared_ptr<DecPlanCache> plan_ahead_build(const vidc_roc *r) {
+std::shared_ptr<DecPlanCache> plan_ahead_build(const vidc_roc *r, bool wide) {
     std::vector<uint32_t> all(r->nlist);
     std::iota(all.begin(), all.end(), 0u);
     auto c = std::make_shared<DecPlanCache>();
-    plan_decode(r, all, false, c->plan, true, true, false, /*whole_sorted=*/true);
+    plan_decode(r, all, false, c->plan, wide, true, true, false, /*whole_sorted=*/true);
     return c;
 }
 }  // namespace
@@ -2172,7 +2172,7 @@ int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out) {
             std::lock_guard<std::mutex> g(r->mu);
             c = std::move(r->plan_ahead);
         }
-        if (!c) c = plan_ahead_build(r);
+        if (!c) c = plan_ahead_build(r, ctx->wide);
         tr.mark("plan");
         VIDC_HIP(hipSetDevice(ctx->device));
         VIDC_TRY(upload(ctx, c->d_wl, c->plan.wl));
@@ -2200,7 +2200,7 @@ int vidc_roc_decode_lists(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const ui
     }
     std::memcpy(out_offsets, req_off.data(), (m + 1) * 8);
     DecPlan p;
-    plan_decode(r, lists, false, p);
+    plan_decode(r, lists, false, p, ctx->wide);
     std::vector<uint64_t> out_off(m);
     for (size_t k = 0; k < m; k++) out_off[k] = req_off[p.item[k]];  // work item k -> its slot in the request
     return decode_impl(ctx, r, p, out_off.data(), d_out, nullptr, 0);
@@ -2226,7 +2226,7 @@ int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uin
         VIDC_HIP(hipSetDevice(ctx->device));
         VIDC_HIP(hipMemsetAsync(d_out, 0xff, m * (uint64_t)K * 4, ctx->stream));
         DecPlan p;
-        plan_decode(r, lists, false, p, false, false, true);  // only the kernels that write int32 rows
+        plan_decode(r, lists, false, p, ctx->wide, false, false, true);  // only the kernels that write int32 rows
         std::vector<uint64_t> out_off(m);
         for (size_t k = 0; k < m; k++) out_off[k] = (uint64_t)p.item[k] * K;
         return decode_impl(ctx, r, p, out_off.data(), nullptr, d_out, K);
@@ -2253,7 +2253,7 @@ int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uin
         }
     }
     DecPlan p;
-    plan_decode(r, lists, true, p, lean);
+    plan_decode(r, lists, true, p, ctx->wide, lean);
     if (p.lean) {
         VIDC_TRY(decode_impl(ctx, r, p, nullptr, nullptr, d_out, K));
         if (counts && m) {  // edge counts of the requested nodes, gathered on the device

@@ -635,7 +635,6 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const 
     static_assert(LPL == 1 || LPL == 2 || LPL == 4, "lanes per list");
     constexpr bool PAIR = LPL > 1;
     using G = LaneRegGeom<EL, LPL>;
-    if (PAIR && a.K == 0xdeaeu) return;  // (debug: launch only)
     __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
     const uint32_t lane = lane_id();
     uint4 *tail4 = (uint4 *)smem + lane;                       // chunk c of this lane at tail4[c * 64]
@@ -645,7 +644,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const 
     const uint32_t lslot = lane / (uint32_t)LPL;  // list of the wavefront this lane works on
     const uint32_t wi = blockIdx.x * lpw + lslot;
     const bool have = lslot < lpw && wi < a.nwork;
-    const bool writer = (lane & ((uint32_t)LPL - 1u)) == 0u && a.K != 0xdeadu;  // the lane of a pair that stores the list's results (0xdead: debug dry run)
+    const bool writer = (lane & ((uint32_t)LPL - 1u)) == 0u;  // the lane of a pair that stores the list's results
     const uint32_t l = have ? a.worklist[wi] : 0u;
     const uint32_t n = have ? (uint32_t)(a.offsets[l + 1] - a.offsets[l]) : 0u;
     const uint64_t ooff = have ? (a.out_off ? a.out_off[wi] : a.offsets[l]) : 0ull;
