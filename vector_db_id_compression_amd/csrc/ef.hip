@@ -50,6 +50,7 @@ struct vidc_ef {
     mutable DevBuf<struct EfRec> d_recs;
     mutable bool recs_ready = false;
     mutable uint32_t recs_max_cnt = 0;  // largest element count of a batch: sizes the decode kernel's LDS table
+    uint64_t max_list = 0;              // longest list (0: unknown): an upper bound of that count, known without a read-back
     bool narrow = false;  // every id < 2^32 and every list < 2^30 ids (known from the encoder): 32-bit decode kernel
 };
 
@@ -946,39 +947,62 @@ __global__ void __launch_bounds__(64) k_ef_decode(const uint64_t *low, const uin
     }
 }
 
-// one thread per batch: the record of EfRec from the CSR arrays (coalesced over batches, off every decode's path)
-__global__ void k_ef_build_recs(const uint64_t *offsets, const uint64_t *low_off, const uint64_t *high_off,
-                                const uint32_t *lbits, const uint64_t *batch_off, const uint32_t *hrank,
-                                const Chunk *items, uint64_t nbatches, EfRec *recs, unsigned int *max_cnt) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+// one thread per batch: the record of EfRec from the CSR arrays (coalesced over batches, off every decode's path).  The records
+// of a workgroup leave through LDS as contiguous 16-byte pieces (a 48-byte struct store per thread is three stores of 16 bytes
+// at a stride of 48: every 64-byte line of the record array was written in three partial passes).
+__global__ void __launch_bounds__(256) k_ef_build_recs(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ low_off,
+                                const uint64_t *__restrict__ high_off, const uint32_t *__restrict__ lbits,
+                                const uint64_t *__restrict__ batch_off, const uint32_t *__restrict__ hrank,
+                                const Chunk *__restrict__ items, uint64_t nbatches, EfRec *recs, unsigned int *max_cnt) {
+    static_assert(sizeof(EfRec) == 48, "three 16-byte pieces per record");
+    __shared__ uint4 stage[256 * 3];
     unsigned int mx = 0;
-    for (uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < nbatches; it += stride) {
-        const uint64_t l = items[it].list, bt = items[it].start;
-        const uint64_t m = offsets[l + 1] - offsets[l];
-        const uint64_t nhw = high_off[l + 1] - high_off[l];
-        const uint64_t nb = batch_off[l + 1] - batch_off[l];
-        const uint64_t done = hrank[batch_off[l] + bt];
-        const uint64_t next = bt + 1 < nb ? (uint64_t)hrank[batch_off[l] + bt + 1] : m;
-        EfRec r;
-        r.out_pos = offsets[l] + done;
-        r.low_base = low_off[l];
-        r.hw_base = high_off[l] + bt * 64;
-        r.done = (uint32_t)done;
-        r.cnt = done >= m ? 0u : (uint32_t)((next < m ? next : m) - done);
-        r.nw = (uint32_t)(bt * 64 >= nhw ? 0 : (nhw - bt * 64 < 64 ? nhw - bt * 64 : 64));
-        r.b = lbits[l];
-        r.bt = (uint32_t)bt;
-        r.pad = 0;
-        recs[it] = r;
-        mx = r.cnt > mx ? r.cnt : mx;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256u; base < nbatches; base += (uint64_t)gridDim.x * 256u) {
+        const uint64_t it = base + threadIdx.x;
+        if (it < nbatches) {
+            const uint64_t l = items[it].list, bt = items[it].start;
+            const uint64_t o0 = offsets[l], m = offsets[l + 1] - o0;
+            const uint64_t h0 = high_off[l], nhw = high_off[l + 1] - h0;
+            const uint64_t b0 = batch_off[l], nb = batch_off[l + 1] - b0;
+            const uint64_t done = hrank[b0 + bt];
+            const uint64_t next = bt + 1 < nb ? (uint64_t)hrank[b0 + bt + 1] : m;
+            EfRec r;
+            r.out_pos = o0 + done;
+            r.low_base = low_off[l];
+            r.hw_base = h0 + bt * 64;
+            r.done = (uint32_t)done;
+            r.cnt = done >= m ? 0u : (uint32_t)((next < m ? next : m) - done);
+            r.nw = (uint32_t)(bt * 64 >= nhw ? 0 : (nhw - bt * 64 < 64 ? nhw - bt * 64 : 64));
+            r.b = lbits[l];
+            r.bt = (uint32_t)bt;
+            r.pad = 0;
+            uint4 *dst = stage + threadIdx.x * 3u;
+            dst[0] = make_uint4((uint32_t)r.out_pos, (uint32_t)(r.out_pos >> 32), (uint32_t)r.low_base, (uint32_t)(r.low_base >> 32));
+            dst[1] = make_uint4((uint32_t)r.hw_base, (uint32_t)(r.hw_base >> 32), r.done, r.cnt);
+            dst[2] = make_uint4(r.nw, r.b, r.bt, 0u);
+            mx = r.cnt > mx ? r.cnt : mx;
+        }
+        __syncthreads();
+        const uint64_t left = nbatches - base < 256u ? nbatches - base : 256u;  // records of this pass
+        uint4 *out = (uint4 *)(recs + base);
+        for (uint32_t k = threadIdx.x; k < left * 3u; k += 256u) out[k] = stage[k];
+        __syncthreads();
     }
-    // one atomic per wavefront: a thread each -- 488 000 of them on ONE address for S2's batches -- were 0.17 of the kernel's 0.2 ms
+    // the largest batch: one atomic per WORKGROUP, and only while it still raises the maximum (the compiler already folds the
+    // atomics of a wavefront into one; 20 000 of them on one address were 0.17 of this kernel's 0.19 ms on S2)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned int other = (unsigned int)__shfl_xor((int)mx, o, 64);
         mx = other > mx ? other : mx;
     }
-    if (mx && (threadIdx.x & 63u) == 0u) atomicMax(max_cnt, mx);
+    __shared__ unsigned int wmx[4];
+    if ((threadIdx.x & 63u) == 0u) wmx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int b = wmx[0];
+        for (int k = 1; k < 4; k++) b = wmx[k] > b ? wmx[k] : b;
+        if (max_cnt && b > *(volatile unsigned int *)max_cnt) atomicMax(max_cnt, b);
+    }
 }
 
 // decode_all with batch records: record -> {high word, low words of the first 512 elements} -> stores.  The low
@@ -1618,6 +1642,7 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     std::memcpy(h_off.p, e->offsets.data(), (nlist + 1) * 8);
     VIDC_HIP(hipMemcpyAsync(e->d_offsets.p, h_off.p, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     bool retry = false;
+    e->max_list = max_list;
     VIDC_TRY(ef_encode_fast(ctx, e.get(), d_ids, flags, nchunks, max_list, &retry));
     if (retry) {  // some list is not ascending: general three-pass encoder with the sort
         e->total_bits = 0;
@@ -1649,29 +1674,45 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
     if (!e->ntotal) return VIDC_OK;
     VIDC_HIP(hipSetDevice(ctx->device));
     double recs_ms = 0;
+    bool recs_timed = false, publish_after_sync = false;
+    std::unique_lock<std::mutex> g(e->mu, std::defer_lock);
     if (e->nbatches) {  // batch records: built once per object, on its first bulk decode (its time is part of that decode's)
-        std::lock_guard<std::mutex> g(e->mu);
+        g.lock();
         if (!e->recs_ready) {
-            VIDC_HIP(hipEventRecord(ctx->ev_chain[0], ctx->stream));
             VIDC_TRY(e->d_recs.alloc(e->nbatches, ctx->dpool));
+            // The decode kernel's LDS table is sized by the largest batch.  A small object whose longest list bounds it well
+            // (no batch holds more elements than its list) takes that bound: the records are built and used back to back,
+            // without the read-back of the exact maximum and its synchronisation (S1-sized calls: two launches of ~5 + ~12 us
+            // instead of fill + build + copy + wait + decode).  Large objects keep the exact value (occupancy of a 2 ms kernel).
+            const bool bounded = e->max_list && e->nbatches < (1u << 18);
+            VIDC_HIP(hipEventRecord(ctx->ev_chain[0], ctx->stream));
             Scratch s_mx;
             Pinned h_mx;
-            VIDC_TRY(s_mx.get(ctx, 16));
-            VIDC_TRY(h_mx.get(ctx, 16));
-            VIDC_HIP(hipMemsetAsync(s_mx.p, 0, 4, ctx->stream));
+            if (!bounded) {
+                VIDC_TRY(s_mx.get(ctx, 16));
+                VIDC_TRY(h_mx.get(ctx, 16));
+                VIDC_HIP(hipMemsetAsync(s_mx.p, 0, 4, ctx->stream));
+            }
             hipLaunchKernelGGL(k_ef_build_recs, dim3((uint32_t)std::min<uint64_t>((e->nbatches + 255) / 256, 4096)),
                                dim3(256), 0, ctx->stream, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p, e->d_lbits.p,
                                e->d_batch_off.p, e->d_hrank.p, e->d_batches.p, e->nbatches, e->d_recs.p,
-                               s_mx.as<unsigned int>());
+                               bounded ? (unsigned int *)nullptr : s_mx.as<unsigned int>());
             VIDC_HIP(hipGetLastError());
             VIDC_HIP(hipEventRecord(ctx->ev_chain[1], ctx->stream));
-            VIDC_HIP(hipMemcpyAsync(h_mx.p, s_mx.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-            VIDC_HIP(hipStreamSynchronize(ctx->stream));  // another context may use the records next
-            e->recs_max_cnt = *h_mx.as<unsigned int>();
-            e->recs_ready = true;
-            float rms = 0;
-            if (hipEventElapsedTime(&rms, ctx->ev_chain[0], ctx->ev_chain[1]) == hipSuccess) recs_ms = rms;
+            if (bounded) {
+                // (the records are published -- other contexts may use them -- when this call has synchronised; until then the
+                // object's lock stays with this call)
+                e->recs_max_cnt = (uint32_t)std::min<uint64_t>(e->max_list, EF_BATCH_BITS);
+                publish_after_sync = true;
+            } else {
+                VIDC_HIP(hipMemcpyAsync(h_mx.p, s_mx.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+                VIDC_HIP(hipStreamSynchronize(ctx->stream));  // another context may use the records next
+                e->recs_max_cnt = *h_mx.as<unsigned int>();
+                e->recs_ready = true;
+            }
+            recs_timed = true;
         }
+        if (!publish_after_sync) g.unlock();
     }
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     if (e->nbatches) {
@@ -1696,6 +1737,11 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
     VIDC_HIP(hipStreamSynchronize(ctx->stream));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    if (publish_after_sync) { e->recs_ready = true; g.unlock(); }
+    if (recs_timed) {
+        float rms = 0;
+        if (hipEventElapsedTime(&rms, ctx->ev_chain[0], ctx->ev_chain[1]) == hipSuccess) recs_ms = rms;
+    }
     ctx->last_kernel_ms = ms + recs_ms;
     return VIDC_OK;
 }

@@ -418,7 +418,7 @@ int finish_complete(vidc_ctx *ctx, vidc_roc *r, EncodeTail &e, const uint32_t *d
 // general decoder classes by LDS footprint of the fine prefix rows (2^fb u32, fb = lg(n) - 3): occupancy, not
 // arithmetic, bounds the general decoder when a batch has many mid-size lists
 // (DC_LANE .. the last class: kernels that may hand a list back with VIDC_ST_RETRY)
-enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_B2, DC_B2T, DC_B2S, DC_B2L, DC_B2M,
+enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID, DC_GHUGE, DC_LANE, DC_LANE64, DC_LANE128, DC_B2, DC_B2T, DC_B2S, DC_B2L, DC_B2M,
                 DC_GRP0, DC_GRP2, DC_GRP3, DC_GRP4,   // row-per-list decoder by bucket bits 8 + F (roc_grp.h)
                 DC_LANEP, DC_LANEQ, DC_COUNT };        // 257..512 / 513..1024 ids on a pair / quad of lanes, ids in registers (k_roc_decode_lane_reg<.., 2 / 4>)
 constexpr uint64_t B2_MIN_LIST = 4096;
@@ -1337,11 +1337,14 @@ inline DecClass grp_dec_class(uint64_t n) {
 // (the environment is read once per plan, not once per list: three getenv per list were 1 ms of a 65 536-list plan)
 struct DecEnv {
     bool nb256, pair, quad;
+    bool nb128;
     DecEnv() : nb256(env_on("VIDC_LANE_NB256")),  // measurements: 256 buckets for the 257..1024-id lists too
                pair(!env_on("VIDC_NO_LANE_PAIR") && !env_on("VIDC_NO_LANE_REG")),
                // (quads of lanes for 513..1024 ids: opt-in.  Measured slower than the bucket rows: 65 536 x 1024 ids decode in 5.6
                // instead of 4.1 ms -- 16 lists per 256-VGPR wavefront means two rounds of wavefronts per SIMD --, S2 84 instead of 78 ms)
-               quad(env_on("VIDC_LANE_QUAD") && !env_on("VIDC_NO_LANE_PAIR") && !env_on("VIDC_NO_LANE_REG")) {}
+               quad(env_on("VIDC_LANE_QUAD") && !env_on("VIDC_NO_LANE_PAIR") && !env_on("VIDC_NO_LANE_REG")) {
+        nb128 = !env_on("VIDC_NO_LANE128");  // lists of 1025..2048 ids on 128 buckets (VIDC_NO_LANE128=1: 256, as before round 4)
+    }
 };
 inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane, bool allow_lane64,
                           const GrpPolicy *grp, const DecEnv &env) {  // (allow_lane*: mid-size policies; grp: row-per-list kernels wanted)
@@ -1358,6 +1361,7 @@ inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general
     if (allow_lane && env.quad && n > VIDC_LANE_PAIR_MAX && n <= VIDC_LANE_QUAD_MAX) return DC_LANEQ;
     if (allow_lane && env.nb256 && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_MAX) return DC_LANE64;
     if (allow_lane && n <= VIDC_LANE_MAX) return DC_LANE;
+    if (allow_lane64 && env.nb128 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX128) return DC_LANE128;
     if (allow_lane64 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64) return DC_LANE64;
     if (n <= GEN_SMALL_MAX) return DC_GSMALL;
     if (n <= 8192) return DC_G8K;
@@ -1412,8 +1416,8 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             while (lo < hi) { const size_t mid = (lo + hi) / 2; if (offs[order[mid] + 1] - offs[order[mid]] > bound) lo = mid + 1; else hi = mid; }
             return lo;
         };
-        const size_t e4096 = 0, e1024 = first_le(VIDC_LANE_MAX), e512 = first_le(VIDC_LANE_PAIR_MAX), e256 = first_le(VIDC_LANE_REG_MAX),
-                     e64 = first_le(TINY_MAX);
+        const size_t e4096 = 0, e2048 = first_le(VIDC_LANE_MAX128), e1024 = first_le(VIDC_LANE_MAX), e512 = first_le(VIDC_LANE_PAIR_MAX),
+                     e256 = first_le(VIDC_LANE_REG_MAX), e64 = first_le(TINY_MAX);
         const uint64_t n_mid64 = e1024 - e4096, n_mid = e64 - e1024, n_tiny = nl - e64;
         allow_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
         allow_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
@@ -1422,7 +1426,8 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
         if ((allow_lane || !n_mid) && (allow_lane64 || !n_mid64) && !grp_in_reach) {
             by_length = true;
             auto take = [&](int c, size_t a, size_t b) { if (b > a) cls[c].insert(cls[c].end(), order.begin() + (ptrdiff_t)a, order.begin() + (ptrdiff_t)b); };
-            take(DC_LANE64, e4096, e1024);
+            take(DC_LANE64, e4096, e2048);
+            take(denv.nb128 ? DC_LANE128 : DC_LANE64, e2048, e1024);
             // 513..1024 | 257..512 | 65..256 (dec_class: pair, quad, 256 buckets, 64 buckets -- in that order)
             take(denv.quad ? DC_LANEQ : (denv.nb256 ? DC_LANE64 : DC_LANE), e1024, e512);
             take(denv.pair ? DC_LANEP : (denv.nb256 ? DC_LANE64 : DC_LANE), e512, e256);
@@ -1581,7 +1586,7 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
         uint64_t sum_n = 0, max_n = 0;
         // re-spill scratch of the decoder stack (== roc_dec_stack_cap in the kernels); the lane-per-list decoders
         // keep what they push in LDS
-        const bool stack_scratch = c != DC_LANE && c != DC_LANE64 && c < DC_GRP0;
+        const bool stack_scratch = c != DC_LANE && c != DC_LANE64 && c != DC_LANE128 && c < DC_GRP0;
         for (const uint32_t i : cls[c]) {
             const uint32_t l = lists[i];
             const uint64_t n = offs[l + 1] - offs[l];
@@ -1602,6 +1607,10 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
                 sl = (sl + 3) & ~(uint64_t)3;
                 slot = sl;
                 sl += 256ull * roc_lane_cap_nb<256>((uint32_t)n);
+            } else if (c == DC_LANE128) {
+                sl = (sl + 3) & ~(uint64_t)3;
+                slot = sl;
+                sl += 128ull * roc_lane_cap_nb<128>((uint32_t)n);
             } else if (c >= DC_GRP0) {
                 sl = (sl + 15) & ~(uint64_t)15;  // member rows of 32 .. 96 u32: 64-byte aligned
                 slot = sl;
@@ -1714,7 +1723,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         double est[DC_COUNT];
         for (int c = 0; c < DC_COUNT; c++) {
             order[c] = c;
-            const bool u = c == DC_U18 || c == DC_U20 || c == DC_B2 || c == DC_B2T || c == DC_B2S || c == DC_B2L || c == DC_B2M, lane = c == DC_LANE || c == DC_LANE64 || c == DC_LANEP || c == DC_LANEQ;
+            const bool u = c == DC_U18 || c == DC_U20 || c == DC_B2 || c == DC_B2T || c == DC_B2S || c == DC_B2L || c == DC_B2M, lane = c == DC_LANE || c == DC_LANE64 || c == DC_LANE128 || c == DC_LANEP || c == DC_LANEQ;
             const bool grpc = c >= DC_GRP0 && c <= DC_GRP4;
             // (constants fitted to the S2 timeline: general kernels ~2.5 G steps/s while they share the machine)
             const double step_us = u ? 0.4 : (lane ? 2.5 : (c == DC_TINY ? 0.5 : (grpc ? 1.5 : 1.2)));       // one chain step
@@ -1827,6 +1836,11 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                     hipLaunchKernelGGL((k_roc_decode_lane<256, true>), dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
                                        (const LaneDiv *)ctx->d_ltab);
                 break;
+            case DC_LANE128:  // 18.5 KiB of LDS per wavefront
+                b.lpw = lane_lists_per_wave(ctx, b.nwork, 7);
+                hipLaunchKernelGGL((k_roc_decode_lane<128, true>), dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
+                                   (const LaneDiv *)ctx->d_ltab);
+                break;
             case DC_B2:
                 hipLaunchKernelGGL(k_roc_decode_b2<0>, dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
                 break;
@@ -1894,7 +1908,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     struct SchedItem { int cls, grp, pos; std::vector<int> deps; };
     std::vector<SchedItem> sched;
     if (const char *e = std::getenv("VIDC_DEC_SCHED")) {
-        static const char *names[DC_COUNT] = {"TINY", "U18", "U20", "GSMALL", "G8K", "G16K", "GMID", "GHUGE", "LANE", "LANE64", "B2", "B2T", "B2S",
+        static const char *names[DC_COUNT] = {"TINY", "U18", "U20", "GSMALL", "G8K", "G16K", "GMID", "GHUGE", "LANE", "LANE64", "LANE128", "B2", "B2T", "B2S",
                                               "B2L", "B2M", "GRP0", "GRP2", "GRP3", "GRP4", "LANEP", "LANEQ"};
         auto cls_of = [&](const std::string &t) { for (int c = 0; c < DC_COUNT; c++) if (t == names[c]) return c; return -1; };
         std::string str(e);

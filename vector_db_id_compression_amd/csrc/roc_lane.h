@@ -26,6 +26,7 @@ namespace dev {
 
 #define VIDC_LANE_MAX 1024u    // NW = 16 encoder / 64-bucket decoder
 #define VIDC_LANE_MAX64 4096u  // NW = 64 encoder / 256-bucket decoder (the divisor table ends here)
+#define VIDC_LANE_MAX128 2048u // 128-bucket decoder (round 4): lists of 1025 .. 2048 ids, 18.5 instead of 26.5 KiB of LDS per wavefront
 #define VIDC_ST_RETRY 5u  // lane decoder: redo this list with the wave-per-list kernel
 
 // entry d of the divisor table (d = 1 .. VIDC_LANE_MAX64): x = m_lo, y = m_hi of floor((2^64-1)/d),
@@ -78,7 +79,12 @@ __device__ __forceinline__ bool l_lt_2p31(uint64_t v) { return (v >> 31) == 0; }
 // Encoder stack of the mid-size lane kernels: pushed words wait in a 32-deep LDS ring per lane and are stored 16 at
 // a time, back to back.  Single 4-byte stores, one every step or two, left every 64-byte arena
 // line partially written for so long that it went to HBM several times (WRITE_SIZE 7x the stream size).
+// (round 4: a 16-deep ring with 32-byte runs -- 15.5 instead of 21.5 KiB of LDS per wavefront of the 1024-id class -- measured
+// slower: 64 M ids in lists of 1024 encode in 1.95 instead of 1.69 ms, S2 55-56 instead of 54-55 ms; -DVIDC_PRING=16)
+#ifndef VIDC_PRING
 #define VIDC_PRING 32u
+#endif
+#define VIDC_PDRAIN (VIDC_PRING / 2u)  // words stored per drain: a 64-byte run
 struct LEStack {
     uint32_t *mem;   // the list's arena
     uint32_t *ring;  // LDS: entry e of this lane at ring[e * 64]
@@ -104,16 +110,16 @@ __device__ __forceinline__ uint32_t ls_pop(LEStack &s) {  // codec.h:32-40 (rare
     s.sp_mem = s.sp;
     return s.mem[s.sp];
 }
-// per lane: once 16 words are pending, store them as one run (a full 64-byte line, or the tails of two)
+// per lane: once half a ring of words is pending, store them as one run (a full 64-byte line, or the tails of two)
 __device__ __forceinline__ void le_drain16(LEStack &s) {
-    if (s.sp - s.sp_mem >= 16u) {
-        if (s.sp_mem + 16u <= s.cap) {
+    if (s.sp - s.sp_mem >= VIDC_PDRAIN) {
+        if (s.sp_mem + VIDC_PDRAIN <= s.cap) {
 #pragma unroll
-            for (uint32_t j = 0; j < 16u; j++) s.mem[s.sp_mem + j] = s.ring[((s.sp_mem + j) & (VIDC_PRING - 1u)) * 64u];
+            for (uint32_t j = 0; j < VIDC_PDRAIN; j++) s.mem[s.sp_mem + j] = s.ring[((s.sp_mem + j) & (VIDC_PRING - 1u)) * 64u];
         } else {
             s.err |= 1u;
         }
-        s.sp_mem += 16u;
+        s.sp_mem += VIDC_PDRAIN;
     }
 }
 // wave-uniform call: every lane stores its pending words
@@ -228,7 +234,7 @@ struct LaneEncGeom {
     static constexpr uint32_t GC_BYTES = NW > 4 ? (NW / 16) * 64 * 8 : 0;
     static constexpr uint32_t SC_BYTES = NW > 16 ? 64 * 8 : 0;
     static constexpr uint32_t RING_BYTES = VIDC_PRING * 64 * 4;
-    static constexpr uint32_t PERM_BYTES = 16 * 64 * 4;  // sampled positions of the last <= 16 steps
+    static constexpr uint32_t PERM_BYTES = VIDC_PDRAIN * 64 * 4;  // sampled positions of the last <= VIDC_PDRAIN steps
     static constexpr uint32_t LDS_BYTES = BM_BYTES + WC_BYTES + GC_BYTES + SC_BYTES + RING_BYTES + PERM_BYTES;
 };
 
@@ -377,7 +383,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
             const uint64_t xprev = pos ? pr.a : 0ull;
             disorder |= (pos && xprev >= xid) || (xid >> 31) != 0ull;
             const uint32_t x = (uint32_t)xid;
-            if (WANT_PERM) pring[(i & 15u) * 64u] = pos;
+            if (WANT_PERM) pring[(i & (VIDC_PDRAIN - 1u)) * 64u] = pos;
 
             // ---- ID_push(x, P), codec.cpp:92-105
             l_u_push(head, st, x & 0xffffu, p0);
@@ -387,11 +393,11 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
                 l_u_push(head, st, 0u, 0u);
             }
         }
-        le_drain16(st);  // at most 5 words per step: the ring (32) never overflows
-        if (WANT_PERM && ((i & 15u) == 15u || i + 1u == nsteps)) {  // uniform
-            const uint32_t s0 = i & ~15u;
+        le_drain16(st);  // at most 5 words per step: fewer than half a ring are pending afterwards, the ring never overflows
+        if (WANT_PERM && ((i & (VIDC_PDRAIN - 1u)) == VIDC_PDRAIN - 1u || i + 1u == nsteps)) {  // uniform
+            const uint32_t s0 = i & ~(VIDC_PDRAIN - 1u);
 #pragma unroll
-            for (uint32_t k = 0; k < 16u; k++)
+            for (uint32_t k = 0; k < VIDC_PDRAIN; k++)
                 if (s0 + k <= i && s0 + k < n) a.perm[off + s0 + k] = pring[k * 64u];
         }
     }
@@ -433,7 +439,7 @@ __device__ __forceinline__ uint32_t lane_sum_u16_below(uint64_t v, uint32_t t) {
 
 template <int NB>
 struct LaneDecGeom {
-    static_assert(NB == 64 || NB == 256, "2 or 3 counter levels");
+    static_assert(NB == 64 || NB == 128 || NB == 256, "2 or 3 counter levels");
     static constexpr uint32_t NG = NB / 16;                   // groups of 16 byte counters
     static constexpr uint32_t CNT_BYTES = NG * 64 * 16;       // uint4 cnt[NG][64]
     static constexpr uint32_t GRP_BYTES = (NG / 4) * 64 * 8;  // u64 grp[NG/4][64]
@@ -442,7 +448,7 @@ struct LaneDecGeom {
     static constexpr uint32_t WIN_BYTES = VIDC_DWIN * 64 * 4; // stream window
     static constexpr uint32_t PST_BYTES = VIDC_DPST * 64 * 4; // pushed words
     static constexpr uint32_t LDS_BYTES = CNT_BYTES + GRP_BYTES + SUP_BYTES + RING_BYTES + WIN_BYTES + PST_BYTES;
-    static constexpr uint32_t BITS = NB == 64 ? 6u : 8u;
+    static constexpr uint32_t BITS = NB == 64 ? 6u : (NB == 128 ? 7u : 8u);
 };
 
 // BATCH (default since round 4; VIDC_LANE_LOOP=1: the loop form): the first four 16-byte chunks of the bucket's row are
