@@ -343,10 +343,20 @@ void sort_desc(std::vector<uint32_t> &wl, const std::vector<uint64_t> &offsets) 
 //   finish_enqueue: status summary, exclusive scan of the word counts (and of the edge counts of graph rows), copies to `t`
 //   finish_complete (after a synchronisation of the stream): checks, allocation of the stream, compaction, final synchronisation
 struct EncodeTail {
-    Scratch s_sum, s_tmp, s_tmp2;
+    Scratch s_sum, s_tmp, s_tmp2, s_state;
+    bool state_zeroed = false;  // the tile states of k_roc_tail were cleared ahead of the encode kernels
     Pinned tail;
     unsigned long long *t = nullptr;  // [0..3] status summary (first bad list, -, retries, pending sorts), [4] total words, [5] ntotal, [6] non-empty rows
 };
+// (ahead of the encode kernels: the tile states of the tail kernel, so that clearing them is not part of the tail)
+int finish_prepare(vidc_ctx *ctx, const vidc_roc *r, EncodeTail &e) {
+    if (r->rows || !r->nlist) return VIDC_OK;
+    const uint32_t ntiles = (uint32_t)(r->nlist / VIDC_TAIL_TILE + 1u);
+    VIDC_TRY(e.s_state.get(ctx, ((size_t)ntiles + 1) * 8));  // (+ the tile counter)
+    VIDC_HIP(hipMemsetAsync(e.s_state.p, 0, ((size_t)ntiles + 1) * 8, ctx->stream));
+    e.state_zeroed = true;
+    return VIDC_OK;
+}
 int finish_enqueue(vidc_ctx *ctx, vidc_roc *r, EncodeTail &e, Scratch &d_status_buf, const uint32_t *d_sizes) {
     const uint64_t nlist = r->nlist;
     VIDC_TRY(e.tail.get(ctx, 128));
@@ -355,6 +365,19 @@ int finish_enqueue(vidc_ctx *ctx, vidc_roc *r, EncodeTail &e, Scratch &d_status_
     VIDC_TRY(e.s_sum.get(ctx, 64));
     VIDC_HIP(hipMemcpyAsync(e.s_sum.p, t, 64, hipMemcpyHostToDevice, ctx->stream));
     VIDC_TRY(r->d_word_off.alloc(nlist + 1, ctx->dpool));
+    if (nlist && !r->rows) {  // summary + word offsets + total in one launch and one copy (k_roc_tail)
+        const uint32_t ntiles = (uint32_t)(nlist / VIDC_TAIL_TILE + 1u);
+        if (!e.state_zeroed) {
+            VIDC_TRY(e.s_state.get(ctx, ((size_t)ntiles + 1) * 8));
+            VIDC_HIP(hipMemsetAsync(e.s_state.p, 0, ((size_t)ntiles + 1) * 8, ctx->stream));
+        }
+        e.state_zeroed = false;  // (used up)
+        hipLaunchKernelGGL(k_roc_tail, dim3(ntiles), dim3(256), 0, ctx->stream, r->d_nwords.p, (uint32_t)nlist, r->d_word_off.p,
+                           d_status_buf.as<uint32_t>(), e.s_state.as<unsigned long long>(), e.s_sum.as<unsigned long long>());
+        VIDC_HIP(hipGetLastError());
+        VIDC_HIP(hipMemcpyAsync(t, e.s_sum.p, 40, hipMemcpyDeviceToHost, ctx->stream));
+        return VIDC_OK;
+    }
     if (nlist) {
         hipLaunchKernelGGL(k_roc_status_summary, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 1024)), dim3(256),
                            0, ctx->stream, d_status_buf.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t)nlist,
@@ -512,48 +535,81 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         if (!offsets) return VIDC_ERR_INVALID;
         r->offsets.assign(offsets, offsets + nlist + 1);
         r->offsets_host = true;
-        // one pass over the offsets: validation, longest list, non-empty lists and the class sizes the kernel-family policies
-        // look at (two passes cost a 65 536-list call 30 us more)
+        // the offsets: validation, longest list, non-empty lists and the class sizes the kernel-family policies look at
         bool any_big = false, all_desc = false;
         uint64_t max_n = 0;
         uint64_t n_tiny_lists = 0, n_mid_lists = 0, n_mid64_lists = 0, n_grp_lists = 0;
         {
             const unsigned parts = par_parts(nlist);
-            struct Acc { uint64_t tiny = 0, mid = 0, mid64 = 0, grp = 0, nonempty = 0, max_n = 0, prev = ~0ull; bool desc = true; int64_t bad_mono = -1, bad_len = -1; };
+            // (first the cheap facts -- extremes, order, validity as ONE flag --; the class sizes only need their own pass when the
+            // lengths straddle a class boundary: an index of equal-sized lists, or a graph, is classified by its extremes)
+            struct Acc { uint64_t nonempty = 0, max_n = 0, min_n = ~0ull, prev = ~0ull; bool desc = true, bad = false; };
             std::vector<Acc> acc(parts);
             par_ranges(nlist, parts, [&](uint64_t la, uint64_t lb, unsigned t) {
                 Acc x;
                 for (uint64_t l = la; l < lb; l++) {
-                    const uint64_t n = offsets[l + 1] - offsets[l];
-                    if (__builtin_expect(offsets[l + 1] < offsets[l], 0)) { if (x.bad_mono < 0) x.bad_mono = (int64_t)l; continue; }
-                    if (__builtin_expect(n > VIDC_ROC_MAX_LIST, 0)) { if (x.bad_len < 0) x.bad_len = (int64_t)l; continue; }
-                    x.tiny += n <= TINY_MAX;
-                    x.mid += n > TINY_MAX && n <= VIDC_LANE_MAX;
-                    x.mid64 += n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64;
-                    x.grp += n >= gpol.min_n && n <= gpol.max_n;
+                    const uint64_t n = offsets[l + 1] - offsets[l];  // (wraps when the offsets decrease: caught as "too long")
+                    x.bad |= n > VIDC_ROC_MAX_LIST;
                     x.nonempty += n != 0;
                     x.max_n = std::max(x.max_n, n);
+                    x.min_n = std::min(x.min_n, n);
                     x.desc &= n <= x.prev;  // (equal-sized lists, or an index stored longest list first)
                     x.prev = n;
                 }
                 acc[t] = x;
             });
-            for (unsigned t = 0; t < parts; t++) {  // (the first offending list, as a single pass would report it)
-                const Acc &x = acc[t];
-                const int64_t first_bad = x.bad_mono >= 0 && (x.bad_len < 0 || x.bad_mono < x.bad_len) ? x.bad_mono : x.bad_len;
-                if (first_bad >= 0 && first_bad == x.bad_mono) {
-                    set_error("offsets not monotone at list %llu", (unsigned long long)first_bad);
-                    return VIDC_ERR_INVALID;
+            uint64_t min_n = ~0ull;
+            bool bad = false;
+            for (unsigned t = 0; t < parts; t++) {
+                bad |= acc[t].bad;
+                nonempty += acc[t].nonempty;
+                max_n = std::max(max_n, acc[t].max_n);
+                min_n = std::min(min_n, acc[t].min_n);
+            }
+            if (bad)  // the first offending list, as a single pass would report it
+                for (uint64_t l = 0; l < nlist; l++) {
+                    if (offsets[l + 1] < offsets[l]) {
+                        set_error("offsets not monotone at list %llu", (unsigned long long)l);
+                        return VIDC_ERR_INVALID;
+                    }
+                    if (offsets[l + 1] - offsets[l] > VIDC_ROC_MAX_LIST) {
+                        set_error("list %llu has %llu ids; ROC lists are limited to %u (the reference codec is only "
+                                  "lossless up to 65536, SURVEY 8a-Q2)", (unsigned long long)l,
+                                  (unsigned long long)(offsets[l + 1] - offsets[l]), VIDC_ROC_MAX_LIST);
+                        return VIDC_ERR_DOMAIN;
+                    }
                 }
-                if (first_bad >= 0) {
-                    set_error("list %llu has %llu ids; ROC lists are limited to %u (the reference codec is only "
-                              "lossless up to 65536, SURVEY 8a-Q2)", (unsigned long long)first_bad,
-                              (unsigned long long)(offsets[first_bad + 1] - offsets[first_bad]), VIDC_ROC_MAX_LIST);
-                    return VIDC_ERR_DOMAIN;
-                }
-                n_tiny_lists += x.tiny; n_mid_lists += x.mid; n_mid64_lists += x.mid64; n_grp_lists += x.grp;
-                nonempty += x.nonempty;
-                max_n = std::max(max_n, x.max_n);
+            auto in_one = [&](uint64_t lo, uint64_t hi) { return nlist && min_n >= lo && max_n <= hi; };
+            if (in_one(0, TINY_MAX) || in_one(TINY_MAX + 1, VIDC_LANE_MAX) || in_one(VIDC_LANE_MAX + 1, VIDC_LANE_MAX64) ||
+                (nlist && min_n > VIDC_LANE_MAX64)) {
+                n_tiny_lists = max_n <= TINY_MAX ? nlist : 0;
+                n_mid_lists = in_one(TINY_MAX + 1, VIDC_LANE_MAX) ? nlist : 0;
+                n_mid64_lists = in_one(VIDC_LANE_MAX + 1, VIDC_LANE_MAX64) ? nlist : 0;
+            } else {
+                std::vector<uint64_t> cnt(3 * (size_t)parts, 0);
+                par_ranges(nlist, parts, [&](uint64_t la, uint64_t lb, unsigned t) {
+                    uint64_t c0 = 0, c1 = 0, c2 = 0;
+                    for (uint64_t l = la; l < lb; l++) {
+                        const uint64_t n = offsets[l + 1] - offsets[l];
+                        c0 += n <= TINY_MAX;
+                        c1 += n > TINY_MAX && n <= VIDC_LANE_MAX;
+                        c2 += n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64;
+                    }
+                    cnt[3 * t] = c0; cnt[3 * t + 1] = c1; cnt[3 * t + 2] = c2;
+                });
+                for (unsigned t = 0; t < parts; t++) { n_tiny_lists += cnt[3 * t]; n_mid_lists += cnt[3 * t + 1]; n_mid64_lists += cnt[3 * t + 2]; }
+            }
+            if (max_n >= gpol.min_n && min_n <= gpol.max_n) {  // (lists in reach of the row-per-list kernels: large calls only)
+                std::vector<uint64_t> cnt(parts, 0);
+                par_ranges(nlist, parts, [&](uint64_t la, uint64_t lb, unsigned t) {
+                    uint64_t c = 0;
+                    for (uint64_t l = la; l < lb; l++) {
+                        const uint64_t n = offsets[l + 1] - offsets[l];
+                        c += n >= gpol.min_n && n <= gpol.max_n;
+                    }
+                    cnt[t] = c;
+                });
+                for (unsigned t = 0; t < parts; t++) n_grp_lists += cnt[t];
             }
             any_big = max_n > TINY_MAX;
             all_desc = parts == 1 && acc[0].desc;
@@ -827,6 +883,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     VIDC_TRY(s_arena.get(ctx, arena_words * 4));
     VIDC_TRY(s_status.get(ctx, nlist * 4));
     if (nlist) VIDC_HIP(hipMemsetAsync(s_status.p, 0xff, nlist * 4, ctx->stream));
+    VIDC_TRY(finish_prepare(ctx, r.get(), tail));
     std::vector<size_t> base;
     const uint32_t *d_wl = nullptr;
     if (!rows) {

@@ -594,6 +594,82 @@ __global__ void k_roc_status_summary(const uint32_t *status, const uint32_t *end
 }
 
 // ---------------------------------------------------------------------------------------------
+// The tail of an encode call in ONE launch (lists of an IVF object): status summary (as k_roc_status_summary) + exclusive scan
+// of the word counts into word_off[0..n] + the total to sum[4].  A single-pass chained scan: tile t (4096 lists) publishes its
+// sum in state[t] (bit 63 = valid; the array is zeroed before the launch) and adds up the sums of the tiles before it.  Tile
+// numbers are handed out by a counter (state[gridDim.x]) in the order the workgroups START, not taken from blockIdx: a
+// workgroup only waits for tiles whose workgroups are already running -- so the wait always ends, whatever the dispatch order.  The four launches this replaces (summary, tile sums, scan of the
+// tiles, apply) were ~25 us between the end of a 65 536-list call's encode kernel and the host's wake-up.
+#define VIDC_TAIL_TILE 4096u
+__global__ void __launch_bounds__(256) k_roc_tail(const uint32_t *__restrict__ nwords, uint32_t n, uint64_t *__restrict__ word_off,
+                                                  const uint32_t *__restrict__ status, unsigned long long *state,
+                                                  unsigned long long *sum) {
+    __shared__ uint64_t sh[256];
+    __shared__ uint64_t tile_off_s;
+    __shared__ uint32_t tile_s;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) tile_s = (uint32_t)atomicAdd(&state[gridDim.x], 1ull);
+    __syncthreads();
+    const uint32_t tile = tile_s;
+    const uint32_t base = tile * VIDC_TAIL_TILE + t * 16u;
+    uint32_t v[16];
+    uint64_t s = 0;
+    unsigned long long bad = ~0ull, retry = 0, pending = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t l = base + j;
+        v[j] = l < n ? nwords[l] : 0u;
+        s += v[j];
+        if (l < n) {
+            const uint32_t st = status[l];
+            if (st == 5u) retry++;  // VIDC_ST_RETRY (roc_lane.h)
+            else if (st != VIDC_ST_OK && (unsigned long long)l < bad) bad = l;
+            if (st == VIDC_ST_PENDING_SORT) pending++;
+        }
+    }
+    sh[t] = s;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256; o <<= 1) {
+        const uint64_t x = t >= o ? sh[t - o] : 0;
+        __syncthreads();
+        sh[t] += x;
+        __syncthreads();
+    }
+    const uint64_t incl = sh[t], tile_sum = sh[255];
+    if (t == 0) {
+        __threadfence();
+        atomicExch(&state[tile], (1ull << 63) | tile_sum);
+    }
+    // sums of the tiles before this one (they were dispatched earlier: every wait ends)
+    uint64_t before = 0;
+    for (uint32_t k = t; k < tile; k += 256u) {
+        unsigned long long x;
+        do { x = atomicAdd(&state[k], 0ull); } while (!(x >> 63));
+        before += x & ~(1ull << 63);
+    }
+    __syncthreads();  // (sh is read above by every thread before it is reused)
+    sh[t] = before;
+    __syncthreads();
+    for (uint32_t o = 128; o > 0; o >>= 1) {
+        if (t < o) sh[t] += sh[t + o];
+        __syncthreads();
+    }
+    if (t == 0) tile_off_s = sh[0];
+    __syncthreads();
+    uint64_t acc = tile_off_s + incl - s;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (base + j <= n) word_off[base + j] = acc;  // (index n receives the total)
+        if (base + j == n) sum[4] = acc;
+        acc += v[j];
+    }
+    // status summary: few lists ever report anything
+    if (bad != ~0ull) atomicMin(&sum[0], bad);
+    if (retry) atomicAdd(&sum[2], retry);
+    if (pending) atomicAdd(&sum[3], pending);
+}
+
+// ---------------------------------------------------------------------------------------------
 // compaction of the worst-case arena into the CSR stream
 __global__ void k_roc_compact(const uint32_t *arena, const uint64_t *offsets, uint32_t stride, const uint64_t *word_off,
                               uint32_t *words, uint32_t nlist) {
