@@ -43,6 +43,7 @@ for cfg in sys.argv[1:]:
                 if v == "": os.environ.pop(k, None)
                 else: os.environ[k] = v
         print("env", val, flush=True)
+        enc()  # (plan-time switches: the decode plan of an object is built while it is encoded)
         continue
     var = "VIDC_ENC_SCHED" if kind == "E" else "VIDC_DEC_SCHED"
     if val: os.environ[var] = val
@@ -55,7 +56,8 @@ for cfg in sys.argv[1:]:
             r._plan = None
             res.append(dec())
     ks = sorted(x[1] for x in res)
-    print("%s %-72s kernels min %.2f med %.2f ms (wall med %.2f)%s" % (kind, val or "(default)", ks[0], ks[len(ks) // 2], sorted(x[0] for x in res)[len(res) // 2],
-          "" if kind == "E" or all(x[2] for x in res) else "  DECODE DIFFERS"), flush=True)
+    print("%s %-72s kernels min %.2f med %.2f ms (wall med %.2f)%s%s" % (kind, val or "(default)", ks[0], ks[len(ks) // 2], sorted(x[0] for x in res)[len(res) // 2],
+          "" if kind == "E" or all(x[2] for x in res) else "  DECODE DIFFERS",
+          ("  all: " + " ".join("%.1f" % x[1] for x in res)) if os.environ.get("SHOW_ALL") else ""), flush=True)
     os.environ.pop(var, None)
     if kind == "E": dec()

@@ -446,6 +446,7 @@ enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID
                 DC_LANEP, DC_LANEQ, DC_COUNT };        // 257..512 / 513..1024 ids on a pair / quad of lanes, ids in registers (k_roc_decode_lane_reg<.., 2 / 4>)
 constexpr uint64_t B2_MIN_LIST = 4096;
 constexpr size_t B2_CAP = 1024;      // chains of k_roc_decode_b2 per call (four per CU of an MI355X: 1 MiB of member rows each)
+constexpr size_t B2_TOP_CAP = 5120;  // ... of a call with more long chains than that: every list beyond 16 384 ids (comment at the planner)
 
 struct DecPlan {
     std::vector<uint32_t> wl;        // list numbers, grouped by class, longest first inside a class
@@ -1394,13 +1395,14 @@ inline DecClass grp_dec_class(uint64_t n) {
 // (the environment is read once per plan, not once per list: three getenv per list were 1 ms of a 65 536-list plan)
 struct DecEnv {
     bool nb256, pair, quad;
-    bool nb128;
+    bool nb128, mid128;
     DecEnv() : nb256(env_on("VIDC_LANE_NB256")),  // measurements: 256 buckets for the 257..1024-id lists too
                pair(!env_on("VIDC_NO_LANE_PAIR") && !env_on("VIDC_NO_LANE_REG")),
                // (quads of lanes for 513..1024 ids: opt-in.  Measured slower than the bucket rows: 65 536 x 1024 ids decode in 5.6
                // instead of 4.1 ms -- 16 lists per 256-VGPR wavefront means two rounds of wavefronts per SIMD --, S2 84 instead of 78 ms)
                quad(env_on("VIDC_LANE_QUAD") && !env_on("VIDC_NO_LANE_PAIR") && !env_on("VIDC_NO_LANE_REG")) {
         nb128 = !env_on("VIDC_NO_LANE128");  // lists of 1025..2048 ids on 128 buckets (VIDC_NO_LANE128=1: 256, as before round 4)
+        mid128 = env_on("VIDC_LANE_MID128");  // measurements: the bucket-row lists of up to 1024 ids on 128 buckets
     }
 };
 inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane, bool allow_lane64,
@@ -1417,6 +1419,7 @@ inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general
     if (allow_lane && env.pair && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_PAIR_MAX) return DC_LANEP;
     if (allow_lane && env.quad && n > VIDC_LANE_PAIR_MAX && n <= VIDC_LANE_QUAD_MAX) return DC_LANEQ;
     if (allow_lane && env.nb256 && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_MAX) return DC_LANE64;
+    if (allow_lane && env.mid128 && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_MAX) return DC_LANE128;
     if (allow_lane && n <= VIDC_LANE_MAX) return DC_LANE;
     if (allow_lane64 && env.nb128 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX128) return DC_LANE128;
     if (allow_lane64 && n > VIDC_LANE_MAX && n <= VIDC_LANE_MAX64) return DC_LANE64;
@@ -1486,8 +1489,9 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             take(DC_LANE64, e4096, e2048);
             take(denv.nb128 ? DC_LANE128 : DC_LANE64, e2048, e1024);
             // 513..1024 | 257..512 | 65..256 (dec_class: pair, quad, 256 buckets, 64 buckets -- in that order)
-            take(denv.quad ? DC_LANEQ : (denv.nb256 ? DC_LANE64 : DC_LANE), e1024, e512);
-            take(denv.pair ? DC_LANEP : (denv.nb256 ? DC_LANE64 : DC_LANE), e512, e256);
+            const int mid = denv.nb256 ? DC_LANE64 : (denv.mid128 ? DC_LANE128 : DC_LANE);
+            take(denv.quad ? DC_LANEQ : mid, e1024, e512);
+            take(denv.pair ? DC_LANEP : mid, e512, e256);
             take(DC_LANE, e256, e64);
             // (tiny lists in request order, like the per-list loop)
             if (n_tiny) {
@@ -1565,11 +1569,16 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             b2_cap = (size_t)std::atoll(e);
             n_long = 0;
         }
-        // (more long chains than the cap: its `cap` longest ones -- the chains that decide the call -- take it alone, cf. the encoder)
+        // More long chains than the cap (S2: 1754 lists of 32 769..65 536 ids and 2666 of 16 385..32 768): round 3 gave the `cap`
+        // longest ones to this kernel and left the rest on the general decoder, whose step under load is ~1.1 us against ~0.65
+        // here.  Measured in round 4 (S2 decode, kernels): 1024 chains 77-79 ms, all 1754 lists beyond 32 768 ids 74, these and
+        // the 2666 lists of 16 385..32 768 ids 71-73; the lists of 8193..16 384 ids too (instead of the row-per-list kernel): 80-90.
+        // So every list beyond 16 384 ids takes it, up to B2_TOP_CAP chains (20 per CU of an MI355X: 8 KiB of LDS each).
         const bool top_only = n_top && n_long > b2_cap && !env_on("VIDC_NO_R2_TOP");
+        if (top_only && !std::getenv("VIDC_B2_CAP")) b2_cap = env_on("VIDC_B2_TOP_OLD") ? B2_CAP : B2_TOP_CAP;
         if (n_top && (n_long <= b2_cap || top_only))
             for (int c : order_) {  // longest first; a list that does not qualify stays where it is
-                if (top_only && c != DC_GHUGE) break;
+                if (top_only && c != DC_GHUGE && (c != DC_GMID || env_on("VIDC_B2_TOP_OLD"))) break;
                 std::vector<uint32_t> keep;
                 for (uint32_t i : cls[c]) {
                     const uint32_t P = r->prec[lists[i]];
