@@ -12,6 +12,9 @@ VIDC_FULL_PREPASS=1 VIDC_NO_LANE_REG=1 timeout 900 python -m pytest tests/test_g
 VIDC_FORCE_GRP=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_force_grp.txt
 GPU_MAX_HW_QUEUES=8 VIDC_WIDE_STREAMS=1 timeout 1200 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_wide.txt
 VIDC_NO_LANE_PAIR=1 VIDC_FORCE_LANE=1 timeout 900 python -m pytest tests/test_gpu_roc.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_no_lane_pair.txt
+# round 4: the loop form of the bucket-row lane decoders + 256 buckets for 1025..2048 ids; per-list classification instead of the length order
+VIDC_LANE_LOOP=1 VIDC_NO_LANE128=1 VIDC_FORCE_LANE=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_lane_loop.txt
+VIDC_NO_LENGTH_CLASSES=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_no_length_classes.txt
 # S2 decoded 100 times per mode and compared with the first decode (the list-level flake hunt of round 3)
 (GPU_MAX_HW_QUEUES=8 NQS=4,8,5,6 ITERS=100 timeout 200 python tools/repro_s2b.py "X=1" 2>&1 | grep "differs\|it 99" | cut -c1-160; GPU_MAX_HW_QUEUES=4 NQS=3 ITERS=100 timeout 200 python tools/repro_s2b.py "X=1" 2>&1 | grep "differs\|it 99" | cut -c1-160) > gpurun_out/$R/s2_repeated_decodes.txt
 timeout 300 python tools/fuzz_chain.py 11 60 2>&1 | tail -1 > gpurun_out/$R/fuzz_chain.txt
@@ -37,9 +40,15 @@ python profiles/extract_rocprof.py gpurun_out/$R/prof_u16/u16_results.db gpurun_
 rm -rf gpurun_out/$R/prof_s1 gpurun_out/$R/prof_u16
 timeout 600 python tools/probe_grp.py 2>&1 | tail -10 > gpurun_out/$R/probe_grp.txt
 MIN_NS=500000 GPU_MAX_HW_QUEUES=8 bash tools/prof_s2.sh s2 2>&1 | grep "start" | grep -v "^\[" > gpurun_out/$R/s2_timeline.txt
-GPU_MAX_HW_QUEUES=8 bash tools/pmc_workload.sh $R s2 roc > /dev/null 2>&1
+VIDC_SERIAL=1 MIN_NS=500000 GPU_MAX_HW_QUEUES=8 bash tools/prof_s2.sh s2 2>&1 | grep "start" | grep -v "^\[" > gpurun_out/$R/s2_timeline_serial.txt
+# S2 step (encode + decode of a fresh object) over 10 rounds, defaults against the round-3 policies (interleaved)
+ROUNDS=10 timeout 900 python tools/s2_ab.py - VIDC_B2_TOP_OLD=1,VIDC_LANE_LOOP=1,VIDC_NO_LANE128=1 2>&1 | grep -v amdgpu > gpurun_out/$R/s2_ab.txt
+# HBM-side traffic (PMC) of S2 through the three codecs and of the 16 M-id call; kernel stats of the Elias-Fano / packed-bits benches
+for c in roc ef packed; do GPU_MAX_HW_QUEUES=8 bash tools/pmc_workload.sh $R s2 $c > /dev/null 2>&1; done
+GPU_MAX_HW_QUEUES=8 bash tools/pmc_workload.sh $R uniform_16m roc > /dev/null 2>&1
 bash tools/pmc_s1.sh $R > /dev/null 2>&1
-cat gpurun_out/$R/pytest_force_grp.txt gpurun_out/$R/pytest_wide.txt gpurun_out/$R/pytest_no_lane_pair.txt gpurun_out/$R/s2_repeated_decodes.txt gpurun_out/$R/s2_timeline.txt gpurun_out/$R/probe_grp.txt
+bash tools/prof_ef_s2.sh $R > gpurun_out/$R/prof_ef_s2.txt 2>&1
+cat gpurun_out/$R/s2_ab.txt gpurun_out/$R/pytest_lane_loop.txt gpurun_out/$R/pytest_no_length_classes.txt gpurun_out/$R/pytest_force_grp.txt gpurun_out/$R/pytest_wide.txt gpurun_out/$R/pytest_no_lane_pair.txt gpurun_out/$R/s2_repeated_decodes.txt gpurun_out/$R/s2_timeline.txt gpurun_out/$R/probe_grp.txt
 cat gpurun_out/$R/pytest_gpu.txt gpurun_out/$R/pytest_force_general.txt gpurun_out/$R/pytest_no_lane.txt gpurun_out/$R/pytest_force_lane.txt gpurun_out/$R/pytest_old_u.txt gpurun_out/$R/pytest_full_prepass_no_lane_reg.txt gpurun_out/$R/fuzz_chain.txt gpurun_out/$R/fuzz_chain_wide.txt gpurun_out/$R/chain_probe.txt gpurun_out/$R/fuzz_families.txt gpurun_out/$R/fuzz_ef_packed.txt gpurun_out/$R/bench_wt.txt gpurun_out/$R/smoke.txt
 python - <<PY
 import json
