@@ -679,7 +679,10 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
 // compares, shifts and shuffles, and the kernel is as much issue- as bandwidth-bound (no stores, no LDS: 162 of
 // 227 us per 64 M ids).
 // one chunk record with R id registers per lane (64 R >= the ids of the chunk)
-template <int R>
+// FULL: the chunk holds exactly 64 R ids (every chunk but the last of a list; every chunk of an object of equal lists that are a
+// multiple of 64 R long): no lane predicate on the id slots -- the exec-mask arithmetic of `i < nc` for R slots in five loops was a
+// quarter of the kernel's 538 scalar instructions, and the kernel sits at the scalar AND the vector issue limit.
+template <int R, bool FULL = false>
 __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const uint64_t *__restrict__ sorted_ids,
                                                    uint64_t *__restrict__ low, uint64_t *__restrict__ high,
                                                    uint32_t *__restrict__ hrank, Chunk *__restrict__ batches,
@@ -690,7 +693,7 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
     const uint32_t b = rc.b;
     const uint32_t n = rc.n;
     const uint32_t u = (uint32_t)rc.u;
-    const uint32_t nc = n - start < EF_CHUNK ? n - start : EF_CHUNK;
+    const uint32_t nc = FULL ? 64u * R : (n - start < EF_CHUNK ? n - start : EF_CHUNK);
     const uint64_t *src = sorted_ids + rc.src - start;  // the list's first id
     uint64_t *dst = high + rc.high_word;
     uint64_t v[R];
@@ -698,7 +701,7 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
 #pragma unroll
     for (uint32_t r = 0; r < R; r++) {
         const uint32_t i = lane + 64 * r;
-        v[r] = i < nc ? src[start + i] : 0ull;
+        v[r] = (FULL || i < nc) ? src[start + i] : 0ull;
     }
     const uint32_t jn = start + nc + lane;  // the (at most 64) ids after the chunk: last word's ownership
     const uint64_t vnext = jn < n ? src[jn] : ~0ull;
@@ -707,17 +710,17 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
     uint32_t pos[R];
     bool bad = (before64 >> 32) != 0;
     uint32_t carry = (uint32_t)before64;
-    const uint32_t nr = (nc + 63u) >> 6;  // registers in use (wave-uniform: short lists skip the rest)
+    const uint32_t nr = FULL ? (uint32_t)R : (nc + 63u) >> 6;  // registers in use (wave-uniform: short lists skip the rest)
 #pragma unroll
     for (uint32_t r = 0; r < R; r++) {
         pos[r] = NONE;
-        if (r < nr) {
+        if (FULL || r < nr) {
             const uint32_t i = lane + 64 * r;
             const uint32_t x = (uint32_t)v[r];
             const uint32_t up = lane_shr1(x);
             const uint32_t prev = lane ? up : carry;
             carry = rl(x, 63);
-            if (i < nc) {
+            if (FULL || i < nc) {
                 bad |= (uint32_t)(v[r] >> 32) != 0u || x > u || prev > x;
                 pos[r] = (x >> b) + (start + i);
             }
@@ -751,9 +754,9 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
         __syncthreads();
 #pragma unroll
         for (uint32_t r = 0; r < R; r++) {
-            if (r < nr) {
+            if (FULL || r < nr) {
                 const uint32_t rel = pos[r] - wbase * 64u;  // bit inside the window (wraps for earlier windows / NONE)
-                if (pos[r] != NONE && (pos[r] >> 6) >= wbase && rel < EF_WIN_WORDS * 64u)
+                if ((FULL || pos[r] != NONE) && (pos[r] >> 6) >= wbase && rel < EF_WIN_WORDS * 64u)
                     atomicOr(&win32[rel >> 5], 1u << (rel & 31u));
             }
         }
@@ -766,7 +769,7 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
 #pragma unroll
             for (uint32_t r = 0; r < R; r++) {
                 const uint32_t i = lane + 64 * r;
-                if (r < nr && i < nc) {
+                if (FULL || (r < nr && i < nc)) {
                     const uint32_t x = (uint32_t)v[r] & keep;
                     const uint32_t p = i * b, sh = p & 31u;
                     atomicOr(&img32[p >> 5], x << sh);
@@ -799,7 +802,8 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
 // extra code paths cost a wavefront per SIMD (97 VGPRs), so objects of mostly full chunks take the plain kernel.
 // (recs / sorted_ids are read-only for the whole launch: __restrict__ lets the record and the wave-uniform neighbour ids come
 // through scalar loads instead of 64 identical vector loads + v_readfirstlane each)
-template <int RMAX, bool SMALL>
+// WITHFULL: full chunks take the predicate-free body (VIDC_EF_NO_FULL=1: the single-body kernels of round 3, for comparisons)
+template <int RMAX, bool SMALL, bool WITHFULL = true>
 __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *__restrict__ sorted_ids, const EfChunkRec *__restrict__ recs,
                                                      uint64_t nchunks, uint64_t *__restrict__ low, uint64_t *__restrict__ high,
                                                      uint32_t *__restrict__ hrank, Chunk *__restrict__ batches,
@@ -809,8 +813,12 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *__restrict_
     for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const EfChunkRec rc = recs[c];
         const uint32_t nc = rc.n - rc.start < EF_CHUNK ? rc.n - rc.start : EF_CHUNK;
+        // (the predicate-free body pays for four id registers per lane -- 16 M ids in lists of 256: 66 -> 62 us, 10 M ids in 65 536
+        // Zipf lists -3 % -- and not for eight: 64 M ids in lists of 1024 165 against 158 us, S2 3.19 against 3.23 ms, interleaved)
         if (!SMALL || (RMAX > 4 && nc > 256u))
             ef_lowhigh32_chunk<RMAX>(rc, sorted_ids, low, high, hrank, batches, unsorted, win32, img32);
+        else if (WITHFULL && nc == 256u)
+            ef_lowhigh32_chunk<4, true>(rc, sorted_ids, low, high, hrank, batches, unsorted, win32, img32);
         else if (nc > 64u)
             ef_lowhigh32_chunk<4>(rc, sorted_ids, low, high, hrank, batches, unsorted, win32, img32);
         else
@@ -1590,15 +1598,22 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
         if (wide_ids)
             hipLaunchKernelGGL(k_ef_lowhigh, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(), nchunks,
                                e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
-        else if (max_list <= 256)  // (16 M ids in lists of 256: 65 -> 57 us)
-            hipLaunchKernelGGL((k_ef_lowhigh32<4, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
+        else if (const bool nofull = std::getenv("VIDC_EF_NO_FULL") != nullptr; max_list <= 256) {  // (16 M ids in lists of 256: 65 -> 57 us)
+            if (nofull) hipLaunchKernelGGL((k_ef_lowhigh32<4, true, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
                                nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
-        else if (e->ntotal < 256 * nchunks)  // (chunks half full on average: 10 M ids in 65 536 Zipf lists 0.090 -> 0.082 ms)
-            hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
+            else hipLaunchKernelGGL((k_ef_lowhigh32<4, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
+                               nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+        } else if (e->ntotal < 256 * nchunks) {  // (chunks half full on average: 10 M ids in 65 536 Zipf lists 0.090 -> 0.082 ms)
+            if (nofull) hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, true, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
                                s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
-        else
-            hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
+            else hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
                                s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+        } else {
+            if (nofull) hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
+                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+            else hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
+                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+        }
         VIDC_HIP(hipGetLastError());
         pt.end();
         VIDC_HIP(hipMemcpyAsync(hs + 1, s_sum.p, sizeof(EfSummary), hipMemcpyDeviceToHost, ctx->stream));
