@@ -234,14 +234,14 @@ int vidc_ctx_reset_stream(vidc_ctx *c) {
 
 int vidc_ctx_synchronize(vidc_ctx *c) {
     if (!c) return VIDC_ERR_INVALID;
-    VIDC_HIP(hipStreamSynchronize(c->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(c->stream));
     return VIDC_OK;
 }
 
 int vidc_ctx_trim(vidc_ctx *c, uint64_t *freed_bytes) {
     if (!c) return VIDC_ERR_INVALID;
     VIDC_HIP(hipSetDevice(c->device));
-    VIDC_HIP(hipStreamSynchronize(c->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(c->stream));
     uint64_t freed = 0;
     if (c->dpool) {
         std::lock_guard<std::mutex> g(c->dpool->m);
@@ -279,7 +279,7 @@ int vidc_copy_h2d(vidc_ctx *c, void *d, const void *h, size_t bytes) {
     if (!c) return VIDC_ERR_INVALID;
     if (bytes) {
         VIDC_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
-        VIDC_HIP(hipStreamSynchronize(c->stream));
+        VIDC_HIP(vidc::vidc_stream_wait(c->stream));
     }
     return VIDC_OK;
 }
@@ -287,7 +287,7 @@ int vidc_copy_d2h(vidc_ctx *c, void *h, const void *d, size_t bytes) {
     if (!c) return VIDC_ERR_INVALID;
     if (bytes) {
         VIDC_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
-        VIDC_HIP(hipStreamSynchronize(c->stream));
+        VIDC_HIP(vidc::vidc_stream_wait(c->stream));
     }
     return VIDC_OK;
 }

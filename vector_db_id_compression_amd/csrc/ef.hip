@@ -62,12 +62,15 @@ struct EfRec {
     uint64_t low_base;  // word offset of the list's low stream
     uint64_t hw_base;   // word offset of the batch's first high word
     uint32_t done;      // elements of the list before this batch (select directory entry)
-    uint32_t cnt;       // elements of this batch
+    uint32_t m;         // elements of the list (the batch holds those up to the NEXT record's `done`, or up to m in the list's last batch)
     uint32_t nw;        // high words of this batch (<= 64)
     uint32_t b;         // low bits per element
     uint32_t bt;        // batch number inside the list
-    uint32_t pad;
+    uint32_t nb;        // batches of the list
 };
+// (the record array ends with one unused record: a wavefront loads its record and the next one together)
+#define EF_CLEAR_HIGH_BYTES (64ull << 20)  // high streams beyond this are cleared ahead of the chunk kernels (comment at the memset)
+#define EF_ENC_RECS_MAX (1u << 18)  // objects of fewer batches: records written by the encoder, LDS table sized by the longest list
 
 namespace {
 
@@ -522,9 +525,20 @@ __global__ void __launch_bounds__(64) k_ef_big_recs(const EfBigList *big, const 
 // three-pass encoder).  A chunk owns the batches whose first bit 4096 k lies in (position of the id before the chunk,
 // position of its last id]; the last chunk of a list also owns the batches behind its last id.  hrank[k] = number of
 // ids of the list with a position below 4096 k = start + (ids of this chunk below it).
+// the decode record of batch k of the chunk's list (what k_ef_build_recs derives from the CSR arrays for objects of the other encoders)
+__device__ inline void ef_store_rec(EfRec *dst, const EfChunkRec &rc, uint64_t k, uint32_t done) {
+    const uint64_t nhw = ((uint64_t)rc.n + 1 + (rc.u >> rc.b) + 1 + 63) / 64;  // (= ef_make_rec's)
+    const uint64_t out_pos = rc.src - rc.start + done, hw_base = rc.high_word + 64 * k;
+    const uint32_t nw = (uint32_t)(64 * k >= nhw ? 0 : (nhw - 64 * k < 64 ? nhw - 64 * k : 64));
+    uint4 *d = (uint4 *)dst;
+    d[0] = make_uint4((uint32_t)out_pos, (uint32_t)(out_pos >> 32), (uint32_t)rc.low_word, (uint32_t)(rc.low_word >> 32));
+    d[1] = make_uint4((uint32_t)hw_base, (uint32_t)(hw_base >> 32), done, rc.n);
+    d[2] = make_uint4(nw, rc.b, (uint32_t)k, rc.nb);
+}
 template <typename PT, int R>
 __device__ inline void ef_chunk_directory(const EfChunkRec &rc, const uint64_t *src, uint32_t nc, const PT (&pos)[R],
-                                          PT pos_before, PT pos_last, uint64_t *low, uint32_t *hrank, Chunk *batches) {
+                                          PT pos_before, PT pos_last, uint64_t *low, uint32_t *hrank, Chunk *batches,
+                                          EfRec *drecs) {
     const uint32_t lane = lane_id();
     const bool last_chunk = rc.start + nc == rc.n;
     if (last_chunk && lane == 0) low[rc.low_word + (((uint64_t)rc.n * rc.b + 63) >> 6)] = 0ull;
@@ -540,6 +554,7 @@ __device__ inline void ef_chunk_directory(const EfChunkRec &rc, const uint64_t *
             if (lane == 0) {
                 hrank[rc.batch0 + k] = rc.start + below;
                 batches[rc.batch0 + k] = Chunk{rc.list, (uint32_t)k};
+                if (drecs) ef_store_rec(drecs + rc.batch0 + k, rc, k, rc.start + below);
             }
         }
     } else {  // a sparse chunk spanning many batches: a lane per batch, binary search over the chunk's ids
@@ -552,13 +567,14 @@ __device__ inline void ef_chunk_directory(const EfChunkRec &rc, const uint64_t *
             }
             hrank[rc.batch0 + k] = rc.start + lo;
             batches[rc.batch0 + k] = Chunk{rc.list, (uint32_t)k};
+            if (drecs) ef_store_rec(drecs + rc.batch0 + k, rc, k, rc.start + lo);
         }
     }
 }
 
 __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, const EfChunkRec *recs,
                                                    uint64_t nchunks, uint64_t *low, uint64_t *high, uint32_t *hrank,
-                                                   Chunk *batches, uint32_t *unsorted) {
+                                                   Chunk *batches, uint32_t *unsorted, EfRec *drecs) {
     __shared__ unsigned long long win[EF_WIN_WORDS];
     __shared__ unsigned long long img[EF_CHUNK + 8];  // low words of the chunk (EF_CHUNK * l / 64 <= EF_CHUNK)
     const uint32_t lane = lane_id();
@@ -598,22 +614,23 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
             }
         }
         if (ballot(bad)) {
-            if (lane == 0) atomicOr(unsorted, 1u);
+            if (lane == 0) *(volatile uint32_t *)unsorted = 1u;  // (pinned host memory: every writer stores the same value)
             __syncthreads();
             continue;  // the object is rebuilt by the general path
         }
         // high stream: positions increase strictly, the chunk covers a contiguous bit range (see k_ef_high)
-        const uint64_t first = rl64((uint32_t)pos[0], (uint32_t)(pos[0] >> 32), 0);
         const uint32_t lr = (nc - 1u) >> 6, ll = (nc - 1u) & 63u;  // register / lane holding the last id
         uint64_t last = 0;
 #pragma unroll
         for (uint32_t r = 0; r < EF_CHUNK / 64; r++)
             if (r == lr) last = rl64((uint32_t)pos[r], (uint32_t)(pos[r] >> 32), ll);
-        const uint64_t wf = first >> 6, wl = last >> 6;
-        // Word ownership instead of global atomics on the two boundary words: a high word belongs to the chunk that
-        // holds its first element.  This chunk skips word wf when the id before the chunk already lies in it, and
-        // adds to word wl the bits of the (at most 63) ids after the chunk that still fall into it.
-        const bool own_first = !(start && (((before >> b) + (start - 1)) >> 6) == wf && before <= u);
+        const uint64_t wl = last >> 6;
+        // Word ownership instead of global atomics on boundary words and instead of a zeroed stream: every high word of a list is
+        // written by exactly one chunk.  A chunk owns the words behind the one that holds the id before it (a list's first chunk:
+        // from word 0) up to the word of its own last id (the last chunk: up to the list's last word); it leaves its bits of the
+        // previous chunk's last word to that chunk and adds to word wl the bits of the (at most 63) ids after the chunk that fall into it.
+        const uint64_t wlo = start ? (((before >> b) + (start - 1)) >> 6) + 1u : 0ull;
+        const uint64_t whi = start + nc == n ? ((n + 1 + (u >> b) + 1 + 63) >> 6) - 1u : wl;
         uint64_t tail_bits = 0;
         {
             const uint64_t j = (uint64_t)start + nc + lane;
@@ -629,8 +646,25 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
                 tail_bits |= ((uint64_t)hi << 32) | lo;
             }
         }
+        if (b) {  // low stream: OR the l low bits of every id into the LDS image of the chunk's words
+            __syncthreads();
+            const uint64_t keep = (1ull << b) - 1ull;
+#pragma unroll
+            for (uint32_t r = 0; r < EF_CHUNK / 64; r++) {
+                const uint32_t i = lane + 64 * r;
+                if (i < nc) {
+                    const uint64_t x = v[r] & keep;
+                    const uint32_t p = i * b, sh = p & 63u;
+                    atomicOr(&img[p >> 6], x << sh);
+                    if (sh + b > 64u) atomicOr(&img[(p >> 6) + 1u], x >> (64u - sh));
+                }
+            }
+            __syncthreads();
+            uint64_t *ldst = low + rc.low_word + (((uint64_t)start * b) >> 6);
+            for (uint32_t w = lane; w < nlw; w += 64) ldst[w] = img[w];
+        }
         uint32_t *win32 = (uint32_t *)win;  // 32-bit LDS atomics (the 64-bit ones run at half rate)
-        for (uint64_t wbase = wf; wbase <= wl; wbase += EF_WIN_WORDS) {
+        for (uint64_t wbase = wlo; wbase <= whi; wbase += EF_WIN_WORDS) {
             win[lane] = 0;
             win[lane + 64] = 0;
             __syncthreads();
@@ -640,19 +674,6 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
                 if (pos[r] != ~0ull && w >= wbase && w - wbase < EF_WIN_WORDS)
                     atomicOr(&win32[(uint32_t)(pos[r] - wbase * 64u) >> 5], 1u << (pos[r] & 31));
             }
-            if (wbase == wf && b) {  // low stream: OR the l low bits of every id into the LDS image of the chunk's words
-                const uint64_t keep = (1ull << b) - 1ull;
-#pragma unroll
-                for (uint32_t r = 0; r < EF_CHUNK / 64; r++) {
-                    const uint32_t i = lane + 64 * r;
-                    if (i < nc) {
-                        const uint64_t x = v[r] & keep;
-                        const uint32_t p = i * b, sh = p & 63u;
-                        atomicOr(&img[p >> 6], x << sh);
-                        if (sh + b > 64u) atomicOr(&img[(p >> 6) + 1u], x >> (64u - sh));
-                    }
-                }
-            }
             __syncthreads();
 #pragma unroll
             for (uint32_t t = 0; t < 2; t++) {
@@ -660,16 +681,12 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
                 const uint64_t w = wbase + k;
                 unsigned long long hv = win[k];
                 if (w == wl) hv |= tail_bits;
-                if (hv && w <= wl && (w != wf || own_first)) dst[w] = hv;  // (the stream was zeroed: empty words stay)
-            }
-            if (wbase == wf && b) {
-                uint64_t *ldst = low + rc.low_word + (((uint64_t)start * b) >> 6);
-                for (uint32_t w = lane; w < nlw; w += 64) ldst[w] = img[w];
+                if (w <= whi) dst[w] = hv;  // (empty words too: nothing zeroes the stream beforehand)
             }
             __syncthreads();
         }
         ef_chunk_directory<uint64_t>(rc, src + start, nc, pos, start ? (before >> b) + (start - 1) : 0ull, last,
-                                     low, hrank, batches);
+                                     low, hrank, batches, drecs);
     }
 }
 
@@ -686,7 +703,8 @@ template <int R, bool FULL = false>
 __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const uint64_t *__restrict__ sorted_ids,
                                                    uint64_t *__restrict__ low, uint64_t *__restrict__ high,
                                                    uint32_t *__restrict__ hrank, Chunk *__restrict__ batches,
-                                                   uint32_t *__restrict__ unsorted, uint32_t *win32, uint32_t *img32) {
+                                                   uint32_t *__restrict__ unsorted, EfRec *__restrict__ drecs, uint32_t *win32,
+                                                   uint32_t *img32) {
     const uint32_t lane = lane_id();
     constexpr uint32_t NONE = 0xffffffffu;
     const uint32_t start = rc.start;
@@ -727,20 +745,20 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
         }
     }
     if (ballot(bad)) {
-        if (lane == 0) atomicOr(unsorted, 1u);
+        if (lane == 0) *(volatile uint32_t *)unsorted = 1u;  // (pinned host memory: every writer stores the same value)
         __syncthreads();
         return;  // the object is rebuilt by the general path
     }
-    const uint32_t first = rl(pos[0], 0);
     const uint32_t lr = (nc - 1u) >> 6, ll = (nc - 1u) & 63u;  // register / lane holding the last id
     uint32_t last = 0;
 #pragma unroll
     for (uint32_t r = 0; r < R; r++)
         if (r == lr) last = rl(pos[r], ll);
-    const uint32_t wf = first >> 6, wl = last >> 6;
-    // word ownership as in k_ef_lowhigh
+    const uint32_t wl = last >> 6;
+    // word ownership as in k_ef_lowhigh: words [wlo, whi] are this chunk's
     const uint32_t before = (uint32_t)before64;
-    const bool own_first = !(start && (((before >> b) + (start - 1u)) >> 6) == wf && before <= u);
+    const uint32_t wlo = start ? (((before >> b) + (start - 1u)) >> 6) + 1u : 0u;
+    const uint32_t whi = start + nc == n ? (uint32_t)(((uint64_t)n + 1 + (u >> b) + 1 + 63) >> 6) - 1u : wl;
     // the ids behind the chunk whose bit falls into the chunk's last word: set through the last window
     uint32_t pnext = NONE;
     if (jn < n && (vnext >> 32) == 0) {
@@ -748,8 +766,27 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
         const uint32_t pn = (xn >> b) + jn;
         if (xn <= u && (pn >> 6) == wl) pnext = pn;
     }
+    if (b) {  // low stream: the l low bits of every id into the LDS image, 32-bit halves
+        __syncthreads();
+        const uint32_t keep = b >= 32u ? 0xffffffffu : ((1u << b) - 1u);
+#pragma unroll
+        for (uint32_t r = 0; r < R; r++) {
+            const uint32_t i = lane + 64 * r;
+            if (FULL || (r < nr && i < nc)) {
+                const uint32_t x = (uint32_t)v[r] & keep;
+                const uint32_t p = i * b, sh = p & 31u;
+                atomicOr(&img32[p >> 5], x << sh);
+                if (sh + b > 32u) atomicOr(&img32[(p >> 5) + 1u], x >> (32u - sh));
+            }
+        }
+        __syncthreads();
+        const uint32_t nlw = (nc * b + 63u) >> 6;
+        uint64_t *ldst = low + rc.low_word + (((uint64_t)start * b) >> 6);
+        const uint64_t *img = (const uint64_t *)img32;
+        for (uint32_t w = lane; w < nlw; w += 64) ldst[w] = img[w];
+    }
     const uint64_t *win = (const uint64_t *)win32;
-    for (uint32_t wbase = wf; wbase <= wl; wbase += EF_WIN_WORDS) {
+    for (uint32_t wbase = wlo; wbase <= whi; wbase += EF_WIN_WORDS) {
         win32[lane] = 0; win32[lane + 64] = 0; win32[lane + 128] = 0; win32[lane + 192] = 0;
         __syncthreads();
 #pragma unroll
@@ -760,41 +797,21 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
                     atomicOr(&win32[rel >> 5], 1u << (rel & 31u));
             }
         }
-        if (wl - wbase < EF_WIN_WORDS && pnext != NONE) {
+        if (wl >= wbase && wl - wbase < EF_WIN_WORDS && pnext != NONE) {
             const uint32_t rel = pnext - wbase * 64u;
             atomicOr(&win32[rel >> 5], 1u << (rel & 31u));
-        }
-        if (wbase == wf && b) {  // low stream: the l low bits of every id into the LDS image, 32-bit halves
-            const uint32_t keep = b >= 32u ? 0xffffffffu : ((1u << b) - 1u);
-#pragma unroll
-            for (uint32_t r = 0; r < R; r++) {
-                const uint32_t i = lane + 64 * r;
-                if (FULL || (r < nr && i < nc)) {
-                    const uint32_t x = (uint32_t)v[r] & keep;
-                    const uint32_t p = i * b, sh = p & 31u;
-                    atomicOr(&img32[p >> 5], x << sh);
-                    if (sh + b > 32u) atomicOr(&img32[(p >> 5) + 1u], x >> (32u - sh));
-                }
-            }
         }
         __syncthreads();
 #pragma unroll
         for (uint32_t t = 0; t < 2; t++) {
             const uint32_t k = lane + 64 * t;
             const uint32_t w = wbase + k;
-            const uint64_t hv = win[k];
-            if (hv && w <= wl && (w != wf || own_first)) dst[w] = hv;  // (the stream was zeroed: empty words stay)
-        }
-        if (wbase == wf && b) {
-            const uint32_t nlw = (nc * b + 63u) >> 6;
-            uint64_t *ldst = low + rc.low_word + (((uint64_t)start * b) >> 6);
-            const uint64_t *img = (const uint64_t *)img32;
-            for (uint32_t w = lane; w < nlw; w += 64) ldst[w] = img[w];
+            if (w <= whi) dst[w] = win[k];  // (empty words too: nothing zeroes the stream beforehand)
         }
         __syncthreads();
     }
     ef_chunk_directory<uint32_t>(rc, src + start, nc, pos, start ? (before >> b) + (start - 1u) : 0u, last,
-                                 low, hrank, batches);
+                                 low, hrank, batches, drecs);
 }
 // RMAX = 8: any object.  RMAX = 4: no list of the object holds more than 256 ids (64 instead of 85 VGPRs, half the code).
 // SMALL: chunks of up to 64 / 256 ids take the code unrolled for one / four id registers -- a chunk costs its unrolled
@@ -807,7 +824,7 @@ template <int RMAX, bool SMALL, bool WITHFULL = true>
 __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *__restrict__ sorted_ids, const EfChunkRec *__restrict__ recs,
                                                      uint64_t nchunks, uint64_t *__restrict__ low, uint64_t *__restrict__ high,
                                                      uint32_t *__restrict__ hrank, Chunk *__restrict__ batches,
-                                                     uint32_t *__restrict__ unsorted) {
+                                                     uint32_t *__restrict__ unsorted, EfRec *__restrict__ drecs) {
     __shared__ uint32_t win32[EF_WIN_WORDS * 2];
     __shared__ uint32_t img32[(64 * RMAX + 8) * 2];  // low words of the chunk, as 32-bit halves
     for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
@@ -816,13 +833,13 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *__restrict_
         // (the predicate-free body pays for four id registers per lane -- 16 M ids in lists of 256: 66 -> 62 us, 10 M ids in 65 536
         // Zipf lists -3 % -- and not for eight: 64 M ids in lists of 1024 165 against 158 us, S2 3.19 against 3.23 ms, interleaved)
         if (!SMALL || (RMAX > 4 && nc > 256u))
-            ef_lowhigh32_chunk<RMAX>(rc, sorted_ids, low, high, hrank, batches, unsorted, win32, img32);
+            ef_lowhigh32_chunk<RMAX>(rc, sorted_ids, low, high, hrank, batches, unsorted, drecs, win32, img32);
         else if (WITHFULL && nc == 256u)
-            ef_lowhigh32_chunk<4, true>(rc, sorted_ids, low, high, hrank, batches, unsorted, win32, img32);
+            ef_lowhigh32_chunk<4, true>(rc, sorted_ids, low, high, hrank, batches, unsorted, drecs, win32, img32);
         else if (nc > 64u)
-            ef_lowhigh32_chunk<4>(rc, sorted_ids, low, high, hrank, batches, unsorted, win32, img32);
+            ef_lowhigh32_chunk<4>(rc, sorted_ids, low, high, hrank, batches, unsorted, drecs, win32, img32);
         else
-            ef_lowhigh32_chunk<1>(rc, sorted_ids, low, high, hrank, batches, unsorted, win32, img32);
+            ef_lowhigh32_chunk<1>(rc, sorted_ids, low, high, hrank, batches, unsorted, drecs, win32, img32);
         __syncthreads();
     }
 }
@@ -979,16 +996,17 @@ __global__ void __launch_bounds__(256) k_ef_build_recs(const uint64_t *__restric
             r.low_base = low_off[l];
             r.hw_base = h0 + bt * 64;
             r.done = (uint32_t)done;
-            r.cnt = done >= m ? 0u : (uint32_t)((next < m ? next : m) - done);
+            const uint32_t cnt = done >= m ? 0u : (uint32_t)((next < m ? next : m) - done);
+            r.m = (uint32_t)m;
             r.nw = (uint32_t)(bt * 64 >= nhw ? 0 : (nhw - bt * 64 < 64 ? nhw - bt * 64 : 64));
             r.b = lbits[l];
             r.bt = (uint32_t)bt;
-            r.pad = 0;
+            r.nb = (uint32_t)nb;
             uint4 *dst = stage + threadIdx.x * 3u;
             dst[0] = make_uint4((uint32_t)r.out_pos, (uint32_t)(r.out_pos >> 32), (uint32_t)r.low_base, (uint32_t)(r.low_base >> 32));
-            dst[1] = make_uint4((uint32_t)r.hw_base, (uint32_t)(r.hw_base >> 32), r.done, r.cnt);
-            dst[2] = make_uint4(r.nw, r.b, r.bt, 0u);
-            mx = r.cnt > mx ? r.cnt : mx;
+            dst[1] = make_uint4((uint32_t)r.hw_base, (uint32_t)(r.hw_base >> 32), r.done, r.m);
+            dst[2] = make_uint4(r.nw, r.b, r.bt, r.nb);
+            mx = cnt > mx ? cnt : mx;
         }
         __syncthreads();
         const uint64_t left = nbatches - base < 256u ? nbatches - base : 256u;  // records of this pass
@@ -1026,13 +1044,15 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
     constexpr uint32_t WB = sizeof(LW) * 8u, WSH = sizeof(LW) == 8 ? 6u : 5u;
     const uint32_t lane = lane_id();
     for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        // the record as 12 dwords through one vector load, broadcast to SGPRs
+        // the record and the next one (its `done` ends this batch) as 24 dwords through one vector load, broadcast to SGPRs
         const uint32_t *rp = (const uint32_t *)(recs + wi);
-        const uint32_t rv = lane < 12u ? rp[lane] : 0u;
+        const uint32_t rv = lane < 24u ? rp[lane] : 0u;
         const uint64_t out_pos = ((uint64_t)rl(rv, 1) << 32) | rl(rv, 0);
         const uint64_t low_base = ((uint64_t)rl(rv, 3) << 32) | rl(rv, 2);
         const uint64_t hw_base = ((uint64_t)rl(rv, 5) << 32) | rl(rv, 4);
-        const uint32_t done = rl(rv, 6), tot = rl(rv, 7), nw = rl(rv, 8), b = rl(rv, 9), bt = rl(rv, 10);
+        const uint32_t done = rl(rv, 6), m = rl(rv, 7), nw = rl(rv, 8), b = rl(rv, 9), bt = rl(rv, 10), nb = rl(rv, 11);
+        const uint32_t next = rl(rv, 18);
+        const uint32_t tot = done >= m ? 0u : ((bt + 1u < nb && next < m) ? next : m) - done;
         if (!tot) continue;
         const LW keep = b ? (LW)(((b >= WB ? (LW)0 : ((LW)1 << b))) - (LW)1) : (LW)0;
         const LW *lw = (const LW *)(low + low_base);
@@ -1387,7 +1407,7 @@ int ef_encode_general(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t
     hipLaunchKernelGGL(k_count_chunks, dim3(lgrid), dim3(256), 0, ctx->stream, e->d_offsets.p, nl32, s_cnt.as<uint32_t>());
     VIDC_TRY(device_exscan(ctx, s_cnt.as<uint32_t>(), nl32, s_coff.as<uint64_t>(), s_tmp));
     VIDC_HIP(hipMemcpyAsync(t, s_coff.as<uint64_t>() + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     e->nchunks = t[0];
     VIDC_TRY(e->d_chunks.alloc(e->nchunks ? e->nchunks : 1, ctx->dpool));
     if (e->nchunks)
@@ -1422,7 +1442,7 @@ int ef_encode_general(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t
     VIDC_HIP(hipMemcpyAsync(t + 1, e->d_high_off.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipMemcpyAsync(t + 2, e->d_batch_off.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipMemcpyAsync(t + 3, s_tot.p, sizeof(EfTotals), hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     const uint64_t low_words = t[0], high_words = t[1];
     e->nbatches = t[2];
     e->total_bits = t[3];
@@ -1503,7 +1523,7 @@ int ef_encode_general(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t
                                e->d_hrank.p);
         }));
     }
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     kernel_ms += pt.collect();
     ctx->last_kernel_ms = kernel_ms;
     return VIDC_OK;
@@ -1518,13 +1538,12 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
     const uint32_t tile_lists = nl32 <= EF_SINGLE_LISTS ? EF_SINGLE_LISTS : (nl32 <= EF_E1_MAX_LISTS ? 256u : 1024u);
     const uint32_t ntiles = nl32 ? (nl32 + tile_lists - 1u) / tile_lists : 1u;
     VidcPhaseTimer pt(ctx);
-    Scratch s_raw, s_tiles, s_sum, s_recs, s_big;
+    Scratch s_raw, s_tiles, s_recs, s_big;
     Pinned tail;
     VIDC_TRY(tail.get(ctx, 2 * sizeof(EfSummary)));
     EfSummary *hs = tail.as<EfSummary>();
     VIDC_TRY(s_raw.get(ctx, (nlist + 1) * sizeof(EfRaw)));
     VIDC_TRY(s_tiles.get(ctx, (size_t)ntiles * sizeof(EfTile)));
-    VIDC_TRY(s_sum.get(ctx, sizeof(EfSummary)));
     VIDC_TRY(s_recs.get(ctx, (nchunks ? nchunks : 1) * sizeof(EfChunkRec)));
     // long lists (more than EF_BIG_CHUNKS chunks: at most nchunks / (EF_BIG_CHUNKS + 1) of them) + their count
     const uint64_t big_cap = nchunks / (EF_BIG_CHUNKS + 1u) + 1u;
@@ -1541,29 +1560,30 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
         hipLaunchKernelGGL((k_ef_offsets<true, 2, 512>), dim3(1), dim3(512), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
                            e->d_lbits.p, e->d_universe.p, (const EfRaw *)nullptr, (const EfTile *)nullptr, 1u,
                            e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
-                           s_sum.as<EfSummary>(), d_big, d_nbig);
+                           hs, d_big, d_nbig);
     } else if (tile_lists == 256u) {
         hipLaunchKernelGGL(k_ef_meta<1>, dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
                            e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>());
         hipLaunchKernelGGL((k_ef_offsets<false, 1, 256>), dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p,
                            nl32, e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>(), ntiles,
                            e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
-                           s_sum.as<EfSummary>(), d_big, d_nbig);
+                           hs, d_big, d_nbig);
     } else {
         hipLaunchKernelGGL(k_ef_meta<4>, dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
                            e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>());
         hipLaunchKernelGGL((k_ef_offsets<false, 4, 256>), dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p,
                            nl32, e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>(), ntiles,
                            e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
-                           s_sum.as<EfSummary>(), d_big, d_nbig);
+                           hs, d_big, d_nbig);
     }
     if (max_list > (uint64_t)EF_CHUNK * EF_BIG_CHUNKS)  // (some list is that long)
         hipLaunchKernelGGL(k_ef_big_recs, dim3((uint32_t)std::min<uint64_t>(big_cap, (uint64_t)ctx->num_cu * 32)), dim3(64), 0, ctx->stream,
                            d_big, d_nbig, s_recs.as<EfChunkRec>());
     VIDC_HIP(hipGetLastError());
     pt.end();
-    VIDC_HIP(hipMemcpyAsync(hs, s_sum.p, sizeof(EfSummary), hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    // (the geometry kernel stores its summary into the pinned block itself, and the chunk kernels their "not ascending" flag: a copy
+    // engine between a kernel and the host's wake-up costs more than these kernels)
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     if (hs->nchunks != nchunks) {
         set_error("elias-fano encoder: chunk count mismatch (%llu vs %llu)", (unsigned long long)hs->nchunks,
                   (unsigned long long)nchunks);
@@ -1579,7 +1599,25 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
     VIDC_TRY(e->d_high.alloc(high_words ? high_words : 1, ctx->dpool));
     VIDC_TRY(e->d_batches.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
     VIDC_TRY(e->d_hrank.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
-    VIDC_HIP(hipMemsetAsync(e->d_high.p, 0, (high_words ? high_words : 1) * 8, ctx->stream));
+    // The chunk kernels write every word of the high stream (k_ef_lowhigh), so nothing has to zero it.  A stream that does not
+    // fit the caches is cleared all the same, inside the timed region: the kernels store a chunk's 100-200 bytes at a time, lines shared
+    // between wavefronts reach HBM as partial writes, and the same kernel runs 8 % faster on lines a fill has just left in the
+    // memory-side cache (S2, 250 MB of high words: 2.95 + 0.08 ms instead of 3.19; 16 M ids, 4 MB: 68.7 instead of 65.8 + 4.5 us).
+    // VIDC_EF_MEMSET=1 / 0 (measurements): always / never.
+    const char *ms_env = std::getenv("VIDC_EF_MEMSET");
+    const bool clear_high = ms_env ? ms_env[0] == '1' : high_words * 8 > EF_CLEAR_HIGH_BYTES;
+    // Objects of up to 2^18 batches get their bulk-decode records (EfRec) from the encoder: the wavefront that writes a batch's
+    // directory entry holds everything the record needs, and the first decode_all of a fresh object is one launch instead of
+    // k_ef_build_recs + decode (16 M ids in lists of 256: 53 -> ~47 us; S1-sized: 20 -> ~15 us).  Larger objects keep the lazy
+    // build: it also finds the exact size of the largest batch, which sets the occupancy of their millisecond-long decode.
+    EfRec *d_drecs = nullptr;
+    const bool enc_recs = nchunks && max_list && e->nbatches && e->nbatches < EF_ENC_RECS_MAX && !std::getenv("VIDC_EF_LAZY_RECS");
+    if (enc_recs) {
+        std::lock_guard<std::mutex> g(e->mu);
+        e->recs_ready = false;
+        VIDC_TRY(e->d_recs.alloc(e->nbatches + 1, ctx->dpool));
+        d_drecs = e->d_recs.p;
+    }
     if ((flags & VIDC_EF_WANT_PERM) != 0) {
         VIDC_TRY(e->d_perm.alloc(e->ntotal ? e->ntotal : 1, ctx->dpool));
         e->has_perm = true;
@@ -1593,34 +1631,40 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
     }
     if (nchunks) {
         const uint32_t cgrid = (uint32_t)std::min<uint64_t>(nchunks, (uint64_t)ctx->num_cu * 256);
-        uint32_t *d_flag = &s_sum.as<EfSummary>()->unsorted;
+        hs[1].unsorted = 0u;
+        uint32_t *d_flag = &hs[1].unsorted;
         pt.begin();
+        if (clear_high) VIDC_HIP(hipMemsetAsync(e->d_high.p, 0, high_words * 8, ctx->stream));
         if (wide_ids)
             hipLaunchKernelGGL(k_ef_lowhigh, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(), nchunks,
-                               e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+                               e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
         else if (const bool nofull = std::getenv("VIDC_EF_NO_FULL") != nullptr; max_list <= 256) {  // (16 M ids in lists of 256: 65 -> 57 us)
             if (nofull) hipLaunchKernelGGL((k_ef_lowhigh32<4, true, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
-                               nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+                               nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
             else hipLaunchKernelGGL((k_ef_lowhigh32<4, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
-                               nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+                               nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
         } else if (e->ntotal < 256 * nchunks) {  // (chunks half full on average: 10 M ids in 65 536 Zipf lists 0.090 -> 0.082 ms)
             if (nofull) hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, true, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
-                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
             else hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
-                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
         } else {
             if (nofull) hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
-                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
             else hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
-                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag);
+                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
         }
         VIDC_HIP(hipGetLastError());
         pt.end();
-        VIDC_HIP(hipMemcpyAsync(hs + 1, s_sum.p, sizeof(EfSummary), hipMemcpyDeviceToHost, ctx->stream));
     }
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     ctx->last_kernel_ms = pt.collect();
     if (nchunks && hs[1].unsorted) *retry = true;
+    if (enc_recs && !*retry) {
+        std::lock_guard<std::mutex> g(e->mu);
+        e->recs_max_cnt = (uint32_t)std::min<uint64_t>(max_list, EF_BATCH_BITS);
+        e->recs_ready = true;
+    }
     return VIDC_OK;
 }
 
@@ -1662,6 +1706,8 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     if (retry) {  // some list is not ascending: general three-pass encoder with the sort
         e->total_bits = 0;
         e->has_perm = false;
+        e->recs_ready = false;  // (the general encoder's objects build their records on the first bulk decode)
+        e->d_recs.release();
         VIDC_TRY(ef_encode_general(ctx, e.get(), d_ids, flags));
     }
     *out = e.release();
@@ -1694,12 +1740,12 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
     if (e->nbatches) {  // batch records: built once per object, on its first bulk decode (its time is part of that decode's)
         g.lock();
         if (!e->recs_ready) {
-            VIDC_TRY(e->d_recs.alloc(e->nbatches, ctx->dpool));
+            VIDC_TRY(e->d_recs.alloc(e->nbatches + 1, ctx->dpool));  // (+1: see EfRec)
             // The decode kernel's LDS table is sized by the largest batch.  A small object whose longest list bounds it well
             // (no batch holds more elements than its list) takes that bound: the records are built and used back to back,
             // without the read-back of the exact maximum and its synchronisation (S1-sized calls: two launches of ~5 + ~12 us
             // instead of fill + build + copy + wait + decode).  Large objects keep the exact value (occupancy of a 2 ms kernel).
-            const bool bounded = e->max_list && e->nbatches < (1u << 18);
+            const bool bounded = e->max_list && e->nbatches < EF_ENC_RECS_MAX;
             VIDC_HIP(hipEventRecord(ctx->ev_chain[0], ctx->stream));
             Scratch s_mx;
             Pinned h_mx;
@@ -1721,7 +1767,7 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
                 publish_after_sync = true;
             } else {
                 VIDC_HIP(hipMemcpyAsync(h_mx.p, s_mx.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-                VIDC_HIP(hipStreamSynchronize(ctx->stream));  // another context may use the records next
+                VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));  // another context may use the records next
                 e->recs_max_cnt = *h_mx.as<unsigned int>();
                 e->recs_ready = true;
             }
@@ -1749,7 +1795,7 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
     }
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     if (publish_after_sync) { e->recs_ready = true; g.unlock(); }
@@ -1792,7 +1838,7 @@ static int ef_decode_some(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uin
                            d_l, out_off_host ? s_o.as<uint64_t>() : nullptr, d_out, d_rows, K);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->last_kernel_ms = ms;
@@ -1873,7 +1919,7 @@ int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_
         fn();
         VIDC_HIP(hipGetLastError());
         VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-        VIDC_HIP(hipEventSynchronize(ctx->ev1));
+        VIDC_HIP(vidc::vidc_event_wait(ctx->ev1));
         float ms = 0;
         (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
         kernel_ms += ms;
@@ -1905,7 +1951,7 @@ int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_
     VIDC_HIP(hipMemcpyAsync(t + 2, e->d_high_off.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipMemcpyAsync(t + 3, e->d_batch_off.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(hipMemcpyAsync(t + 4, s_tot.p, 32, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     if ((uint32_t)(t[6] & 0xffffffffu)) { set_error("EF rows: negative neighbour id before the -1 terminator"); return VIDC_ERR_DOMAIN; }
     e->ntotal = t[0];
     const uint64_t low_words = t[1], high_words = t[2];
@@ -1932,7 +1978,7 @@ int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_
             if (e->nbatches)
                 launch_fill_items(ctx->stream, e->d_batch_off.p, n32, 1u, e->d_batches.p, e->nbatches, (uint32_t)ctx->num_cu);
         }));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     ctx->last_kernel_ms = kernel_ms;
     *out = e.release();
     return VIDC_OK;
@@ -1960,7 +2006,7 @@ int vidc_ef_get(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *lis
                        s_l.as<uint64_t>(), s_o.as<uint64_t>(), s_r.as<int64_t>());
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipMemcpyAsync(ids_out, s_r.p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     return VIDC_OK;
 }
 
@@ -2070,7 +2116,7 @@ int vidc_ef_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
                            e->d_batch_off.p, (uint32_t)nlist, e->d_hrank.p);
         VIDC_HIP(hipGetLastError());
     }
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     *out = e.release();
     return VIDC_OK;
 }

@@ -335,7 +335,7 @@ int vidc_compact_rows_encode(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_
     }
     uint32_t err = 0;
     VIDC_HIP(hipMemcpyAsync(&err, s_err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     if (N) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
@@ -379,7 +379,7 @@ int vidc_compact_rows_decode(vidc_ctx *ctx, const vidc_compact *c, uint64_t m, c
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     if (counts) VIDC_HIP(hipMemcpyAsync(h_io.p, s_c.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     if (counts) std::memcpy(counts, h_io.p, m * 4);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
@@ -438,7 +438,7 @@ static int packed_setup(vidc_ctx *ctx, vidc_packed *p, uint64_t nlist, const uin
     if (p->nchunks)
         launch_fill_items(ctx->stream, s_coff.as<uint64_t>(), nl32, CHUNK_IDS, p->d_chunks.p, p->nchunks, (uint32_t)ctx->num_cu);
     VIDC_HIP(hipGetLastError());
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));  // scratch of this scope is released on return
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));  // scratch of this scope is released on return
     return VIDC_OK;
 }
 
@@ -474,7 +474,7 @@ int vidc_packed_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, c
     }
     uint32_t err = 0;
     VIDC_HIP(hipMemcpyAsync(&err, s_err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     if (p->total_words) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
@@ -533,7 +533,7 @@ int vidc_packed_decode_all(vidc_ctx *ctx, const vidc_packed *p, uint64_t *d_out)
                            p->d_offsets.p, p->d_word_off.p, p->d_chunks.p, p->nchunks, (uint32_t)p->bits, d_out);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->last_kernel_ms = ms;
@@ -567,7 +567,7 @@ int vidc_packed_decode_lists(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, co
                        (uint32_t)p->bits, d_out);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));  // the staging vectors above are pageable host memory
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));  // the staging vectors above are pageable host memory
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->last_kernel_ms = ms;
@@ -595,7 +595,7 @@ int vidc_packed_get(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, const uint6
                        s_r.as<int64_t>());
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipMemcpyAsync(ids_out, s_r.p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     return VIDC_OK;
 }
 

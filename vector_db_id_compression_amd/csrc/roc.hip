@@ -185,7 +185,7 @@ int download(vidc_ctx *ctx, std::vector<T> &dst, const T *d_src, size_t count) {
     Pinned st;
     VIDC_TRY(st.get(ctx, count * sizeof(T)));
     VIDC_HIP(hipMemcpyAsync(st.p, d_src, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     std::memcpy(dst.data(), st.p, count * sizeof(T));
     return VIDC_OK;
 }
@@ -228,7 +228,7 @@ struct EventTimer {
     explicit EventTimer(vidc_ctx *ctx) : c(ctx) { (void)hipEventRecord(c->ev0, c->stream); }
     double stop() {
         (void)hipEventRecord(c->ev1, c->stream);
-        (void)hipEventSynchronize(c->ev1);
+        (void)vidc::vidc_event_wait(c->ev1);
         float ms = 0;
         (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
         return ms;
@@ -352,8 +352,8 @@ struct EncodeTail {
 int finish_prepare(vidc_ctx *ctx, const vidc_roc *r, EncodeTail &e) {
     if (r->rows || !r->nlist) return VIDC_OK;
     const uint32_t ntiles = (uint32_t)(r->nlist / VIDC_TAIL_TILE + 1u);
-    VIDC_TRY(e.s_state.get(ctx, ((size_t)ntiles + 1) * 8));  // (+ the tile counter)
-    VIDC_HIP(hipMemsetAsync(e.s_state.p, 0, ((size_t)ntiles + 1) * 8, ctx->stream));
+    VIDC_TRY(e.s_state.get(ctx, ((size_t)ntiles + 10) * 8));  // (+ the tile counter, the tiles-done counter, the summary)
+    VIDC_HIP(hipMemsetAsync(e.s_state.p, 0, ((size_t)ntiles + 10) * 8, ctx->stream));
     e.state_zeroed = true;
     return VIDC_OK;
 }
@@ -362,22 +362,21 @@ int finish_enqueue(vidc_ctx *ctx, vidc_roc *r, EncodeTail &e, Scratch &d_status_
     VIDC_TRY(e.tail.get(ctx, 128));
     unsigned long long *t = e.t = e.tail.as<unsigned long long>();
     t[0] = ~0ull; t[1] = 0; t[2] = 0; t[3] = 0; t[4] = 0; t[5] = 0; t[6] = 0; t[7] = 0;
-    VIDC_TRY(e.s_sum.get(ctx, 64));
-    VIDC_HIP(hipMemcpyAsync(e.s_sum.p, t, 64, hipMemcpyHostToDevice, ctx->stream));
     VIDC_TRY(r->d_word_off.alloc(nlist + 1, ctx->dpool));
-    if (nlist && !r->rows) {  // summary + word offsets + total in one launch and one copy (k_roc_tail)
+    if (nlist && !r->rows) {  // summary + word offsets + total in one launch; its last workgroup stores the results into `t`
         const uint32_t ntiles = (uint32_t)(nlist / VIDC_TAIL_TILE + 1u);
         if (!e.state_zeroed) {
-            VIDC_TRY(e.s_state.get(ctx, ((size_t)ntiles + 1) * 8));
-            VIDC_HIP(hipMemsetAsync(e.s_state.p, 0, ((size_t)ntiles + 1) * 8, ctx->stream));
+            VIDC_TRY(e.s_state.get(ctx, ((size_t)ntiles + 10) * 8));
+            VIDC_HIP(hipMemsetAsync(e.s_state.p, 0, ((size_t)ntiles + 10) * 8, ctx->stream));
         }
         e.state_zeroed = false;  // (used up)
         hipLaunchKernelGGL(k_roc_tail, dim3(ntiles), dim3(256), 0, ctx->stream, r->d_nwords.p, (uint32_t)nlist, r->d_word_off.p,
-                           d_status_buf.as<uint32_t>(), e.s_state.as<unsigned long long>(), e.s_sum.as<unsigned long long>());
+                           d_status_buf.as<uint32_t>(), e.s_state.as<unsigned long long>(), t);
         VIDC_HIP(hipGetLastError());
-        VIDC_HIP(hipMemcpyAsync(t, e.s_sum.p, 40, hipMemcpyDeviceToHost, ctx->stream));
         return VIDC_OK;
     }
+    VIDC_TRY(e.s_sum.get(ctx, 64));
+    VIDC_HIP(hipMemcpyAsync(e.s_sum.p, t, 64, hipMemcpyHostToDevice, ctx->stream));
     if (nlist) {
         hipLaunchKernelGGL(k_roc_status_summary, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 1024)), dim3(256),
                            0, ctx->stream, d_status_buf.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t)nlist,
@@ -422,6 +421,10 @@ int finish_complete(vidc_ctx *ctx, vidc_roc *r, EncodeTail &e, const uint32_t *d
             const uint32_t grid = (uint32_t)std::min<uint64_t>((nlist + 63) / 64, (uint64_t)ctx->num_cu * 64);
             hipLaunchKernelGGL(k_roc_compact_groups, dim3(grid), dim3(64), 0, ctx->stream, d_arena, d_off, arena_stride,
                                r->d_word_off.p, r->d_words.p, (uint32_t)nlist);
+        } else if (r->total_words / nlist < 200 && !env_on("VIDC_COMPACT_BLOCKS")) {  // a wavefront per four lists (k_roc_compact_waves)
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((nlist + 15) / 16, (uint64_t)ctx->num_cu * 8);
+            hipLaunchKernelGGL(k_roc_compact_waves, dim3(grid), dim3(256), 0, ctx->stream, d_arena, d_off, arena_stride,
+                               r->d_word_off.p, r->d_words.p, (uint32_t)nlist);
         } else {
             const uint32_t grid = (uint32_t)std::min<uint64_t>(nlist, (uint64_t)ctx->num_cu * 16);
             hipLaunchKernelGGL(k_roc_compact, dim3(grid), dim3(256), 0, ctx->stream, d_arena, d_off, arena_stride,
@@ -432,7 +435,7 @@ int finish_complete(vidc_ctx *ctx, vidc_roc *r, EncodeTail &e, const uint32_t *d
         ctx->phase_ms[VIDC_PHASE_ROC_COMPACT] = ms;
         kernel_ms += ms;
     } else {
-        VIDC_HIP(hipStreamSynchronize(ctx->stream));
+        VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     }
     return VIDC_OK;
 }
@@ -519,7 +522,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                         // (declared behind them: destroyed first)
         vidc_ctx *c;
         bool armed = false;
-        ~SyncOnExit() { if (armed) (void)hipStreamSynchronize(c->stream); }
+        ~SyncOnExit() { if (armed) (void)vidc::vidc_stream_wait(c->stream); }
     } pre_guard{ctx};
     const uint32_t arena_stride = rows ? (uint32_t)arena_words_for(K) : 0u;
     uint64_t arena_words = 0, nonempty = 0, ntiny = 0;
@@ -705,7 +708,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 t.mark();
                 VIDC_HIP(hipMemcpyAsync(h_pre.p, s_maxid.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
                 VIDC_HIP(hipMemcpyAsync(h_pre.as<uint32_t>() + nlist, s_flags.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
-                VIDC_HIP(hipStreamSynchronize(ctx->stream));
+                VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
                 pre_guard.armed = false;
                 kernel_ms += t.elapsed();
                 maxid = h_pre.as<uint32_t>();
@@ -1266,7 +1269,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         t.mark();
         VIDC_TRY(finish_enqueue(ctx, r.get(), tail, s_status, s_sizes.as<uint32_t>()));
         if (pre_deferred) {  // the maxima of the lists: precisions and bucket geometry for the decode planner
-            VIDC_HIP(hipEventSynchronize(ctx->ev_pre[2]));
+            VIDC_HIP(vidc::vidc_event_wait(ctx->ev_pre[2]));
             const uint32_t *mx = h_pre.as<uint32_t>();
             r->umax.assign(mx, mx + nlist);
             for (uint64_t l = 0; l < nlist; l++) {
@@ -1307,7 +1310,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             }
         }
         // ONE wait for the kernels, the status summary and the sizes (queued behind the kernels above)
-        VIDC_HIP(hipStreamSynchronize(ctx->stream));
+        VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
         pre_guard.armed = false;
         kernel_ms += t.elapsed();
         if (ctx->chain_info[0][3]) {  // (the main stream joined the auxiliary ones)
@@ -1354,7 +1357,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             EventTimer t2(ctx);
             VIDC_TRY(launch_gen(s_pend.as<uint32_t>(), (uint32_t)pend.size(), rl_max));
             kernel_ms += t2.stop();
-            VIDC_HIP(hipStreamSynchronize(ctx->stream));  // scratch of this scope is released below
+            VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));  // scratch of this scope is released below
             if (light_prepass) {
                 // the precision of these lists came from their last id, which was not their maximum if they were not
                 // ascending: the general kernel stored the real one
@@ -1365,7 +1368,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             }
             // statuses and word counts of the redone lists: summary and offsets again
             VIDC_TRY(finish_enqueue(ctx, r.get(), tail, s_status, s_sizes.as<uint32_t>()));
-            VIDC_HIP(hipStreamSynchronize(ctx->stream));
+            VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
         }
     }
     // bitmap-kernel lists wrote sampled ids into the perm buffer: turn them into input positions
@@ -1781,8 +1784,8 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     }
     VIDC_TRY(s_scr.get(ctx, p.scratch_words * 4));
     VIDC_TRY(s_slots.get(ctx, p.slots_words * 4));
-    VIDC_TRY(s_end.get(ctx, r->nlist * 8));  // end states | statuses: one block, one memset
-    VIDC_HIP(hipMemsetAsync(s_end.p, 0, r->nlist * 8, ctx->stream));
+    VIDC_TRY(s_end.get(ctx, r->nlist * 8 + 64));  // end states | statuses | summary accumulators: one block, one memset
+    VIDC_HIP(hipMemsetAsync(s_end.p, 0, r->nlist * 8 + 64, ctx->stream));
     uint32_t *const d_status = s_end.as<uint32_t>() + r->nlist;
     tr.mark("scratch + uploads");
     RocDecArgs a{};
@@ -2076,15 +2079,12 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     VIDC_TRY(h_sum.get(ctx, 64));
     unsigned long long *sum = h_sum.as<unsigned long long>();
     sum[0] = ~0ull; sum[1] = 0; sum[2] = 0; sum[3] = 0;
-    VIDC_TRY(s_sum.get(ctx, 32));
-    VIDC_HIP(hipMemcpyAsync(s_sum.p, sum, 32, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_roc_status_summary, dim3((uint32_t)std::min<uint64_t>((r->nlist + 255) / 256, 1024)), dim3(256),
+    // (the kernel's last workgroup stores the summary into the pinned block itself: no copy up, no copy down)
+    hipLaunchKernelGGL(k_roc_status_summary_host, dim3((uint32_t)std::min<uint64_t>((r->nlist + 255) / 256, 1024)), dim3(256),
                        0, ctx->stream, d_status, s_end.as<uint32_t>(), (uint32_t)r->nlist,
-                       s_sum.as<unsigned long long>());
+                       (unsigned long long *)(s_end.as<uint32_t>() + 2 * r->nlist), sum);
     VIDC_HIP(hipGetLastError());
-    VIDC_HIP(hipMemcpyAsync(sum + 4, s_sum.p, 24, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
-    sum += 4;
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     ctx->last_kernel_ms = t.elapsed();
     ctx->phase_ms[VIDC_PHASE_ROC_DECODE] = ctx->last_kernel_ms;
     if (chain_class >= 0) {
@@ -2249,7 +2249,7 @@ int vidc_roc_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, cons
     VIDC_TRY(r->d_words.alloc(r->total_words + 16, ctx->dpool));  // + padding: the look-ahead of the lane / row decoders reads up to 15 words past the last stream
     if (r->total_words)
         VIDC_HIP(hipMemcpyAsync(r->d_words.p, words_concat, r->total_words * 4, hipMemcpyHostToDevice, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     r->meta_host = true;
     r->offsets_host = true;
     *out = r.release();
@@ -2288,7 +2288,7 @@ int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out) {
         VIDC_TRY(upload(ctx, c->d_scratch_off, c->plan.scratch_off));
         VIDC_TRY(upload(ctx, c->d_slots_off, c->plan.slots_off));
         tr.mark("plan upload");
-        VIDC_HIP(hipStreamSynchronize(ctx->stream));  // another context may use the cached plan next
+        VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));  // another context may use the cached plan next
         std::lock_guard<std::mutex> g(r->mu);
         if (!r->plan_all) r->plan_all = c;
         plan = r->plan_all;

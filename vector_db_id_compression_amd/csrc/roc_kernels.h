@@ -593,6 +593,36 @@ __global__ void k_roc_status_summary(const uint32_t *status, const uint32_t *end
     if (pending) atomicAdd(&out[3], pending);
 }
 
+// The same summary for the end of a decode call, delivered by the kernel itself: `acc` (device, zeroed with the call's status block:
+// [0] = max over bad lists of ~list, [1..3] as above, [4] = workgroups done) is summed up by atomics, and the LAST workgroup to
+// finish stores the four values into `host` -- pinned host memory, read by the host behind the one synchronisation of the call.
+// A copy engine between the last kernel and the host's wake-up (init copy up, result copy down) cost more than the kernel.
+__global__ void k_roc_status_summary_host(const uint32_t *status, const uint32_t *end_state, uint32_t nlist,
+                                          unsigned long long *acc, unsigned long long *host) {
+    unsigned long long bad = ~0ull, nonclean = 0, retry = 0, pending = 0;
+    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x) {
+        const uint32_t s = status[l];
+        if (s == 5u) retry++;  // VIDC_ST_RETRY (roc_lane.h)
+        else if (s != VIDC_ST_OK && (unsigned long long)l < bad) bad = l;
+        if (s == VIDC_ST_PENDING_SORT) pending++;
+        if (end_state) nonclean += end_state[l];
+    }
+    if (bad != ~0ull) atomicMax(&acc[0], ~bad);
+    if (nonclean) atomicAdd(&acc[1], nonclean);
+    if (retry) atomicAdd(&acc[2], retry);
+    if (pending) atomicAdd(&acc[3], pending);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&acc[4], 1ull) == (unsigned long long)gridDim.x - 1ull) {
+        __threadfence();
+        const unsigned long long b = atomicAdd(&acc[0], 0ull);
+        host[0] = b ? ~b : ~0ull;
+        host[1] = atomicAdd(&acc[1], 0ull);
+        host[2] = atomicAdd(&acc[2], 0ull);
+        host[3] = atomicAdd(&acc[3], 0ull);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The tail of an encode call in ONE launch (lists of an IVF object): status summary (as k_roc_status_summary) + exclusive scan
 // of the word counts into word_off[0..n] + the total to sum[4].  A single-pass chained scan: tile t (4096 lists) publishes its
@@ -600,10 +630,14 @@ __global__ void k_roc_status_summary(const uint32_t *status, const uint32_t *end
 // numbers are handed out by a counter (state[gridDim.x]) in the order the workgroups START, not taken from blockIdx: a
 // workgroup only waits for tiles whose workgroups are already running -- so the wait always ends, whatever the dispatch order.  The four launches this replaces (summary, tile sums, scan of the
 // tiles, apply) were ~25 us between the end of a 65 536-list call's encode kernel and the host's wake-up.
+// state: [gridDim.x tile sums | tile counter | tiles done | sum[8]], all zero at the launch; sum[0] = max over bad lists of ~list,
+// sum[2] / [3] = retries / pending sorts, sum[4] = total words.  The last tile to finish stores {first bad list or ~0, 0, retries,
+// pending, total} into `host` (pinned host memory: no copy engine between this kernel and the host's wake-up).
 #define VIDC_TAIL_TILE 4096u
 __global__ void __launch_bounds__(256) k_roc_tail(const uint32_t *__restrict__ nwords, uint32_t n, uint64_t *__restrict__ word_off,
                                                   const uint32_t *__restrict__ status, unsigned long long *state,
-                                                  unsigned long long *sum) {
+                                                  unsigned long long *host) {
+    unsigned long long *const sum = state + gridDim.x + 2;
     __shared__ uint64_t sh[256];
     __shared__ uint64_t tile_off_s;
     __shared__ uint32_t tile_s;
@@ -664,9 +698,20 @@ __global__ void __launch_bounds__(256) k_roc_tail(const uint32_t *__restrict__ n
         acc += v[j];
     }
     // status summary: few lists ever report anything
-    if (bad != ~0ull) atomicMin(&sum[0], bad);
+    if (bad != ~0ull) atomicMax(&sum[0], ~bad);
     if (retry) atomicAdd(&sum[2], retry);
     if (pending) atomicAdd(&sum[3], pending);
+    __threadfence();
+    __syncthreads();
+    if (t == 0 && atomicAdd(&state[gridDim.x + 1], 1ull) == (unsigned long long)gridDim.x - 1ull) {
+        __threadfence();
+        const unsigned long long b = atomicAdd(&sum[0], 0ull);
+        host[0] = b ? ~b : ~0ull;
+        host[1] = 0ull;
+        host[2] = atomicAdd(&sum[2], 0ull);
+        host[3] = atomicAdd(&sum[3], 0ull);
+        host[4] = atomicAdd(&sum[4], 0ull);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -678,6 +723,43 @@ __global__ void k_roc_compact(const uint32_t *arena, const uint64_t *offsets, ui
         uint32_t *dst = words + word_off[l];
         uint32_t nw = (uint32_t)(word_off[l + 1] - word_off[l]);
         for (uint32_t j = threadIdx.x; j < nw; j += blockDim.x) dst[j] = src[j];
+    }
+}
+
+// The same for lists of ~64 .. 256 words (65 536 lists of 256 ids: 84 words each): a wavefront per FOUR consecutive lists, their
+// headers loaded together and the first 128 words of each requested before anything is stored.  A workgroup per list spent a
+// round trip on three header words and another on 84 words of payload, sixteen times in a row: 33 us for 22 MB.
+__global__ void __launch_bounds__(256) k_roc_compact_waves(const uint32_t *__restrict__ arena, const uint64_t *__restrict__ offsets,
+                                                           uint32_t stride, const uint64_t *__restrict__ word_off,
+                                                           uint32_t *__restrict__ words, uint32_t nlist) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = gridDim.x * 4u;
+    for (uint64_t l0 = (uint64_t)wave * 4u; l0 < nlist; l0 += (uint64_t)nwaves * 4u) {
+        uint64_t so[4], dof[5];
+#pragma unroll
+        for (uint32_t k = 0; k < 5; k++) dof[k] = word_off[l0 + k <= nlist ? l0 + k : nlist];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) so[k] = roc_arena_at(offsets, stride, l0 + k < nlist ? l0 + k : nlist - 1u);
+        uint32_t v[4][2];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t nw = (uint32_t)(dof[k + 1] - dof[k]);
+#pragma unroll
+            for (uint32_t j = 0; j < 2; j++) {
+                const uint32_t i = lane + 64u * j;
+                v[k][j] = i < nw ? arena[so[k] + i] : 0u;
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t nw = (uint32_t)(dof[k + 1] - dof[k]);
+#pragma unroll
+            for (uint32_t j = 0; j < 2; j++) {
+                const uint32_t i = lane + 64u * j;
+                if (i < nw) words[dof[k] + i] = v[k][j];
+            }
+            for (uint32_t i = lane + 128u; i < nw; i += 64u) words[dof[k] + i] = arena[so[k] + i];
+        }
     }
 }
 

@@ -736,22 +736,106 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const 
             const bool mine = ((lane ^ i) & ((uint32_t)LPL - 1u)) == 0u;
             if (sl < (uint32_t)EL) {
                 // The lanes of the other parity are masked off by exec, as in the one-lane-per-list kernel.  The first version wrote
-                // the slot with "v_cndmask_b32_e64 v64, v64, x, mask" under s_set_gpr_idx_on ..., gpr_idx(SRC0,DST): bit-exact by
-                // itself, but with it running, S2-sized decodes came back with a wrong list of ANOTHER kernel class in ~10 % of the
-                // calls (also when this kernel stored nothing to memory; 0 of 100 with this form) -- the SRC0-relative VOP3 write
-                // appears to land outside the wavefront's own registers.  DESIGN section 10.
+                // the slot with "v_cndmask_b32_e64 v64, v64, x, mask" right behind "s_set_gpr_idx_on i, gpr_idx(SRC0,DST)": bit-exact by
+                // itself, but S2-sized decodes came back with wrong lists of OTHER kernel classes in ~2 % of the calls (16 / 32 / 48
+                // lists of a lane<64> wavefront, single general-decoder lists, once a memory fault).  Round 4 took the construct apart
+                // (the forms below, tools/pair_forms.sh, 600 S2 decodes each, profiles/r04c_pair_forms.txt): every form that issues a
+                // VOP3 instruction with an SRC0-relative register IMMEDIATELY behind s_set_gpr_idx_on fails (9-17 of 600, whatever
+                // produces the mask, also with wait states in front of the switch or behind the switch back); the same instruction
+                // with s_nop 4 between the switch and itself: 0 of 1400; the compiler's own pattern -- a VOP1 v_mov under the index
+                // mode -- with or without the exec mask: 0 of 400 (and of the thousands of stress decodes of the shipped kernels).
+                // So gfx950 wants wait states between s_set_gpr_idx_on and a VOP3 instruction that reads a register through the
+                // index; without them the instruction can address registers outside its wavefront (the victims are wavefronts of
+                // other kernels on the same SIMD, hit in quarter-wave groups of lanes).  Not reproducible with ALU-only victims
+                // outside the library (tools/hw_gpr_idx_probe.hip).  The shipped statements keep to the VOP1 pattern and put a wait
+                // state behind the switch all the same.  DESIGN sections 10 and 11.
+#ifdef VIDC_PAIR_OLD_FORM  // (investigations only, tools/pair_forms.sh: 1 = the round-3 form, 2.. = variants that take it apart; failures of 600 S2 decodes
+                          //  1: 10, 4: 15, 7: 9, 8: 17, 10: memory fault, 11: 11 | 5: 0, 9: 0 | of 200: 2: 0, 3: 0, 6: 0)
+                const uint64_t m = __ballot(mine);
+#if VIDC_PAIR_OLD_FORM == 1
+                asm volatile("s_set_gpr_idx_on %[i], gpr_idx(SRC0,DST)\n\tv_cndmask_b32_e64 v64, v64, %[x], %[m]\n\ts_set_gpr_idx_off"
+                             : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5)
+                             : [x] "v"(x), [i] "s"(sl), [m] "s"(m));
+#elif VIDC_PAIR_OLD_FORM == 2  // no VOP3 under the index mode: indexed read, plain select, indexed write
+                uint32_t t_;
+                asm volatile("s_set_gpr_idx_on %[i], gpr_idx(SRC0)\n\tv_mov_b32 %[t], v64\n\ts_set_gpr_idx_off"
+                             : [t] "=v"(t_), "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5) : [i] "s"(sl));
+                t_ = mine ? x : t_;
+                asm volatile("s_set_gpr_idx_on %[i], gpr_idx(DST)\n\tv_mov_b32 v64, %[t]\n\ts_set_gpr_idx_off"
+                             : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5) : [t] "v"(t_), [i] "s"(sl));
+#elif VIDC_PAIR_OLD_FORM == 3  // VOP3 under the index mode, DST relative only
+                uint32_t t_;
+                asm volatile("s_set_gpr_idx_on %[i], gpr_idx(SRC0)\n\tv_mov_b32 %[t], v64\n\ts_set_gpr_idx_off"
+                             : [t] "=v"(t_), "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5) : [i] "s"(sl));
+                asm volatile("s_set_gpr_idx_on %[i], gpr_idx(DST)\n\tv_cndmask_b32_e64 v64, %[t], %[x], %[m]\n\ts_set_gpr_idx_off"
+                             : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5) : [t] "v"(t_), [x] "v"(x), [i] "s"(sl), [m] "s"(m));
+#elif VIDC_PAIR_OLD_FORM == 4  // VOP3 under the index mode, SRC0 relative only
+                uint32_t t_;
+                asm volatile("s_set_gpr_idx_on %[i], gpr_idx(SRC0)\n\tv_cndmask_b32_e64 %[t], v64, %[x], %[m]\n\ts_set_gpr_idx_off"
+                             : [t] "=v"(t_), "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5) : [x] "v"(x), [i] "s"(sl), [m] "s"(m));
+                asm volatile("s_set_gpr_idx_on %[i], gpr_idx(DST)\n\tv_mov_b32 v64, %[t]\n\ts_set_gpr_idx_off"
+                             : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5) : [t] "v"(t_), [i] "s"(sl));
+#elif VIDC_PAIR_OLD_FORM == 5  // the round-3 form between wait states
+                asm volatile("s_nop 4\n\ts_set_gpr_idx_on %[i], gpr_idx(SRC0,DST)\n\ts_nop 4\n\tv_cndmask_b32_e64 v64, v64, %[x], %[m]\n\ts_nop 4\n\ts_set_gpr_idx_off\n\ts_nop 4"
+                             : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5)
+                             : [x] "v"(x), [i] "s"(sl), [m] "s"(m));
+#elif VIDC_PAIR_OLD_FORM == 6  // the shipped instruction (v_mov, DST relative) without the exec mask: the select is done on plain registers first
+                uint32_t t_;
+                asm volatile("s_set_gpr_idx_on %[i], gpr_idx(SRC0)\n\tv_mov_b32 %[t], v64\n\ts_set_gpr_idx_off"
+                             : [t] "=v"(t_), "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5) : [i] "s"(sl));
+                asm volatile("v_cndmask_b32_e64 %[t], %[t], %[x], %[m]\n\ts_set_gpr_idx_on %[i], gpr_idx(DST)\n\tv_mov_b32 v64, %[t]\n\ts_set_gpr_idx_off"
+                             : [t] "+v"(t_), "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5) : [x] "v"(x), [i] "s"(sl), [m] "s"(m));
+#elif VIDC_PAIR_OLD_FORM == 7  // the round-3 form with the two wait states gfx940+ want between a VALU that writes an SGPR pair and a VALU that reads it as a mask
+                asm volatile("s_nop 1\n\ts_set_gpr_idx_on %[i], gpr_idx(SRC0,DST)\n\tv_cndmask_b32_e64 v64, v64, %[x], %[m]\n\ts_set_gpr_idx_off"
+                             : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5)
+                             : [x] "v"(x), [i] "s"(sl), [m] "s"(m));
+#elif VIDC_PAIR_OLD_FORM == 8  // the round-3 form with a mask that comes from the scalar unit (lane pairs: a constant per parity of the step)
+                const uint64_t m8 = LPL == 2 ? ((i & 1u) ? 0xaaaaaaaaaaaaaaaaull : 0x5555555555555555ull) : m;
+                asm volatile("s_set_gpr_idx_on %[i], gpr_idx(SRC0,DST)\n\tv_cndmask_b32_e64 v64, v64, %[x], %[m]\n\ts_set_gpr_idx_off"
+                             : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5)
+                             : [x] "v"(x), [i] "s"(sl), [m] "s"(m8));
+#elif VIDC_PAIR_OLD_FORM == 9  // wait states between the mode switch and the VOP3 instruction only
+                asm volatile("s_set_gpr_idx_on %[i], gpr_idx(SRC0,DST)\n\ts_nop 4\n\tv_cndmask_b32_e64 v64, v64, %[x], %[m]\n\ts_set_gpr_idx_off"
+                             : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5)
+                             : [x] "v"(x), [i] "s"(sl), [m] "s"(m));
+#elif VIDC_PAIR_OLD_FORM == 10  // wait states between the VOP3 instruction and the switch back only
+                asm volatile("s_set_gpr_idx_on %[i], gpr_idx(SRC0,DST)\n\tv_cndmask_b32_e64 v64, v64, %[x], %[m]\n\ts_nop 4\n\ts_set_gpr_idx_off"
+                             : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5)
+                             : [x] "v"(x), [i] "s"(sl), [m] "s"(m));
+#elif VIDC_PAIR_OLD_FORM == 11  // wait states behind the switch back only
+                asm volatile("s_set_gpr_idx_on %[i], gpr_idx(SRC0,DST)\n\tv_cndmask_b32_e64 v64, v64, %[x], %[m]\n\ts_set_gpr_idx_off\n\ts_nop 4"
+                             : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
+                               "+{v[224:255]}"(e5)
+                             : [x] "v"(x), [i] "s"(sl), [m] "s"(m));
+#endif
+#else
                 if (mine) {
-                    asm volatile("s_set_gpr_idx_on %[i], gpr_idx(DST)\n\tv_mov_b32 v64, %[x]\n\ts_set_gpr_idx_off"
+                    asm volatile("s_set_gpr_idx_on %[i], gpr_idx(DST)\n\ts_nop 0\n\tv_mov_b32 v64, %[x]\n\ts_set_gpr_idx_off"
                                  : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
                                    "+{v[224:255]}"(e5)
                                  : [x] "v"(x), [i] "s"(sl));
                 }
+#endif
             } else if (act && mine) {
                 const uint32_t sidx = sl - (uint32_t)EL;
                 tail1[(sidx >> 2) * 256u + (sidx & 3u)] = x;
             }
         } else if (i < (uint32_t)EL) {
-            asm volatile("s_set_gpr_idx_on %[i], gpr_idx(DST)\n\tv_mov_b32 v64, %[x]\n\ts_set_gpr_idx_off"
+            asm volatile("s_set_gpr_idx_on %[i], gpr_idx(DST)\n\ts_nop 0\n\tv_mov_b32 v64, %[x]\n\ts_set_gpr_idx_off"
                          : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1), "+{v[128:159]}"(e2), "+{v[160:191]}"(e3), "+{v[192:223]}"(e4),
                            "+{v[224:255]}"(e5)
                          : [x] "v"(x), [i] "s"(i));
@@ -997,7 +1081,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
             if (sp + i < VIDC_TINY_STRIP) buf[(VIDC_TINY_STRIP - 1u - i) * VIDC_TINY_LD + lane] = x; else err |= 1u;
         }
         // slot i = x (uniform register index; lanes past their list write an empty slot they never read)
-        asm volatile("s_set_gpr_idx_on %[i], gpr_idx(DST)\n\tv_mov_b32 v64, %[x]\n\ts_set_gpr_idx_off"
+        asm volatile("s_set_gpr_idx_on %[i], gpr_idx(DST)\n\ts_nop 0\n\tv_mov_b32 v64, %[x]\n\ts_set_gpr_idx_off"
                      : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1)
                      : [x] "v"(xs), [i] "s"(i));
     }

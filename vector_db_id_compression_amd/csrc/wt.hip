@@ -676,7 +676,7 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
         VIDC_TRY(w->d_binom.alloc(64 * 64 + 8));
         VIDC_HIP(hipMemcpyAsync(w->d_binom.p, bn.data(), 64 * 64 * 8, hipMemcpyHostToDevice, ctx->stream));
         VIDC_HIP(hipMemcpyAsync(w->d_binom.p + 64 * 64, tab.ow, 64, hipMemcpyHostToDevice, ctx->stream));
-        VIDC_HIP(hipStreamSynchronize(ctx->stream));  // (bn leaves scope)
+        VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));  // (bn leaves scope)
         w->rrr_off_base.assign(L + 1, 0);
     }
     VIDC_TRY(w->d_nrank.alloc(wt_nrank_base(L) + 1));
@@ -695,7 +695,7 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
     }
     uint32_t err = 0;
     VIDC_HIP(hipMemcpyAsync(&err, s_err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     if (err) {
         set_error("wavelet tree: ids must be a permutation of 0..ntotal-1, ascending inside every list "
                   "(asserts at custom_invlists_impl.cpp:359-360)");
@@ -732,7 +732,7 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
                                w->d_rs.p + (uint64_t)level * (nsamp + 1));
             VIDC_HIP(hipGetLastError());
             VIDC_HIP(hipMemcpyAsync(&lvl_bits[level], s_bitpos.as<uint64_t>() + nblk, 8, hipMemcpyDeviceToHost, ctx->stream));
-            VIDC_HIP(hipStreamSynchronize(ctx->stream));  // (the scratch of the level is reused by the next one)
+            VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));  // (the scratch of the level is reused by the next one)
         }
     }
     if (rrr) {  // the exact-size offset streams, level after level (+ one pad word each: two-word reads)
@@ -752,7 +752,7 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
         w->size_bytes = (off_bits + 7) / 8 + (uint64_t)L * ((6 * nblk + 7) / 8) + (uint64_t)L * (nsamp + 1) * 8 + (nlist + 1) * 8;
     }
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->last_kernel_ms = ms;
@@ -788,7 +788,7 @@ int vidc_wt_select(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint64_t *
                            (uint32_t)w->nlist, w->L, m, s_l.as<uint64_t>(), s_o.as<uint64_t>(), s_r.as<int64_t>());
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipMemcpyAsync(ids_out, s_r.p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     return VIDC_OK;
 }
 
@@ -819,7 +819,7 @@ int vidc_wt_decode_lists(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint
                            s_l.as<uint64_t>(), s_o.as<uint64_t>(), total, d_out);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->last_kernel_ms = ms;
@@ -875,7 +875,7 @@ int vidc_wt_decode_all(vidc_ctx *ctx, const vidc_wt *w, uint64_t *d_out) {
         }
         VIDC_HIP(hipGetLastError());
         VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-        VIDC_HIP(hipStreamSynchronize(ctx->stream));  // the scratch of this scope goes back to the pool below
+        VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));  // the scratch of this scope goes back to the pool below
         float ms2 = 0;
         (void)hipEventElapsedTime(&ms2, ctx->ev0, ctx->ev1);
         ctx->last_kernel_ms = ms2;
@@ -883,7 +883,7 @@ int vidc_wt_decode_all(vidc_ctx *ctx, const vidc_wt *w, uint64_t *d_out) {
     }
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    VIDC_HIP(hipStreamSynchronize(ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->last_kernel_ms = ms;
