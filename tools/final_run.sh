@@ -48,6 +48,9 @@ for c in roc ef packed; do GPU_MAX_HW_QUEUES=8 bash tools/pmc_workload.sh $R s2 
 GPU_MAX_HW_QUEUES=8 bash tools/pmc_workload.sh $R uniform_16m roc > /dev/null 2>&1
 bash tools/pmc_s1.sh $R > /dev/null 2>&1
 bash tools/prof_ef_s2.sh $R > gpurun_out/$R/prof_ef_s2.txt 2>&1
+# host-side phases of a 65 536-list call; the register-index construct of DESIGN section 11 outside the library
+python tools/trace_host.py uniform_16m 2>&1 | tail -14 > gpurun_out/$R/trace_u16.txt
+(hipcc --offload-arch=gfx950 -O2 tools/hw_gpr_idx_probe.hip -o /tmp/probe 2>&1 | tail -3; GPU_MAX_HW_QUEUES=8 timeout 400 /tmp/probe 10 4096 8192 10000 200000 100000) > gpurun_out/$R/hw_gpr_idx_probe.txt 2>&1
 cat gpurun_out/$R/s2_ab.txt gpurun_out/$R/pytest_lane_loop.txt gpurun_out/$R/pytest_no_length_classes.txt gpurun_out/$R/pytest_force_grp.txt gpurun_out/$R/pytest_wide.txt gpurun_out/$R/pytest_no_lane_pair.txt gpurun_out/$R/s2_repeated_decodes.txt gpurun_out/$R/s2_timeline.txt gpurun_out/$R/probe_grp.txt
 cat gpurun_out/$R/pytest_gpu.txt gpurun_out/$R/pytest_force_general.txt gpurun_out/$R/pytest_no_lane.txt gpurun_out/$R/pytest_force_lane.txt gpurun_out/$R/pytest_old_u.txt gpurun_out/$R/pytest_full_prepass_no_lane_reg.txt gpurun_out/$R/fuzz_chain.txt gpurun_out/$R/fuzz_chain_wide.txt gpurun_out/$R/chain_probe.txt gpurun_out/$R/fuzz_families.txt gpurun_out/$R/fuzz_ef_packed.txt gpurun_out/$R/bench_wt.txt gpurun_out/$R/smoke.txt
 python - <<PY

@@ -32,11 +32,11 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 // Waiting for a stream / an event.  hipStreamSynchronize spins on the completion signal for 100 us and then sleeps until the
-// interrupt, which hands the thread back 20-40 us after the work has finished: a tenth of an encode + decode call of 65 536 short
-// lists (0.4 ms of kernels per direction, two waits per encode, one per decode).  These poll the state for up to VIDC_SPIN_US
-// (default 3000 us; 0: the runtime's wait at once) and only then block: millisecond calls never sleep, long calls sleep as before.
+// interrupt.  VIDC_SPIN_US=n makes these poll the state for up to n us before they block (measurements: 3000 us did not move a
+// 1 ms encode + decode call of 65 536 lists -- 1.076 against 1.054 ms, inside the box-to-box spread -- so the default is 0: the
+// runtime's wait at once).
 inline long vidc_spin_us() {
-    static const long us = [] { const char *e = std::getenv("VIDC_SPIN_US"); return e ? std::atol(e) : 3000L; }();
+    static const long us = [] { const char *e = std::getenv("VIDC_SPIN_US"); return e ? std::atol(e) : 0L; }();
     return us;
 }
 template <typename Query>

@@ -22,7 +22,7 @@ struct vidc_packed {
     uint64_t nlist = 0, ntotal = 0;
     int bits = 0;
     uint64_t compressed_bytes = 0, total_words = 0;
-    std::vector<uint64_t> offsets, word_off;
+    std::vector<uint64_t> offsets;
     DevBuf<uint64_t> d_offsets, d_word_off, d_words;
     DevBuf<Chunk> d_chunks;
     uint64_t nchunks = 0;
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(64) k_packed_encode(const uint64_t *ids, const
                 if (sh + bits > 64u) atomicOr(&img[(pos >> 6) + 1u], x >> (64u - sh));
             }
         }
-        if (__ballot(bad) && lane == 0) atomicOr(err, 1u);
+        if (__ballot(bad) && lane == 0) *(volatile uint32_t *)err = 1u;  // (every writer stores the same value: device or pinned host memory)
         __syncthreads();
         uint64_t *dst = words + word_off[ch.list] + w0;
         for (uint32_t w = lane; w < nw; w += 64) dst[w] = img[w];
@@ -82,11 +82,84 @@ __global__ void __launch_bounds__(64) k_packed_encode(const uint64_t *ids, const
     }
 }
 
-// the padding word behind every list (the only words the encoder's chunks do not write): zeroing the whole stream
-// first cost a quarter of the encode time
-__global__ void k_packed_zero_pads(const uint64_t *word_off, uint32_t nlist, uint64_t *words) {
-    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x)
-        words[word_off[l + 1] - 1] = 0ull;
+// The geometry of an object in ONE launch: chunk table, word offsets and the zeroed padding word of every list.  (Chunk counts -> scan
+// -> fill, a host-built word-offset array and the padding kernel were six dependent launches and a second 8-byte-per-list upload:
+// 25 us of a 60 us encode of 16 M ids.)  A tile of 4096 lists counts its chunks and words, takes its place in a chained scan -- tile
+// numbers handed out by a counter in the order the workgroups start, so a tile only waits for tiles that are already running (as
+// k_roc_tail) -- and writes its part.  state: [gridDim.x chunk sums | gridDim.x word sums | tile counter], zero at the launch.
+__global__ void __launch_bounds__(256) k_packed_table(const uint64_t *__restrict__ offsets, uint32_t nlist, uint32_t bits,
+                                                      unsigned long long *state, Chunk *__restrict__ chunks,
+                                                      uint64_t *__restrict__ word_off, uint64_t *__restrict__ words) {
+    __shared__ uint64_t sh[2][256];
+    __shared__ uint64_t tile_off_s[2];
+    __shared__ uint32_t tile_s;
+    const uint32_t t = threadIdx.x, nt = gridDim.x;
+    if (nt > 1u) {  // (an object of one tile needs neither the counter nor a cleared state)
+        if (t == 0) tile_s = (uint32_t)atomicAdd(&state[2 * nt], 1ull);
+        __syncthreads();
+    }
+    const uint32_t tile = nt > 1u ? tile_s : 0u;
+    const uint64_t base = (uint64_t)tile * 4096u + t * 16u;
+    uint32_t cnt[16];
+    uint64_t wc[16];
+    uint64_t s0 = 0, s1 = 0;
+    uint64_t prev = offsets[base < nlist ? base : nlist];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint64_t l = base + j;
+        const uint64_t next = offsets[l + 1 < nlist ? l + 1 : nlist];
+        const uint64_t n = next - prev;
+        cnt[j] = l < nlist ? (uint32_t)((n + CHUNK_IDS - 1u) / CHUNK_IDS) : 0u;
+        wc[j] = l < nlist ? (n * bits + 63) / 64 + 1 : 0ull;  // +1: read_bits may touch the next word
+        prev = next;
+        s0 += cnt[j];
+        s1 += wc[j];
+    }
+    sh[0][t] = s0;
+    sh[1][t] = s1;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256; o <<= 1) {
+        const uint64_t x0 = t >= o ? sh[0][t - o] : 0, x1 = t >= o ? sh[1][t - o] : 0;
+        __syncthreads();
+        sh[0][t] += x0;
+        sh[1][t] += x1;
+        __syncthreads();
+    }
+    const uint64_t incl0 = sh[0][t], incl1 = sh[1][t];
+    if (t == 0 && nt > 1u) {
+        const uint64_t sum0 = sh[0][255], sum1 = sh[1][255];
+        __threadfence();
+        atomicExch(&state[tile], (1ull << 63) | sum0);
+        atomicExch(&state[nt + tile], (1ull << 63) | sum1);
+    }
+    uint64_t b0 = 0, b1 = 0;
+    for (uint32_t k = t; k < tile; k += 256u) {
+        unsigned long long x;
+        do { x = atomicAdd(&state[k], 0ull); } while (!(x >> 63));
+        b0 += x & ~(1ull << 63);
+        do { x = atomicAdd(&state[nt + k], 0ull); } while (!(x >> 63));
+        b1 += x & ~(1ull << 63);
+    }
+    __syncthreads();
+    sh[0][t] = b0;
+    sh[1][t] = b1;
+    __syncthreads();
+    for (uint32_t o = 128; o > 0; o >>= 1) {
+        if (t < o) { sh[0][t] += sh[0][t + o]; sh[1][t] += sh[1][t + o]; }
+        __syncthreads();
+    }
+    if (t == 0) { tile_off_s[0] = sh[0][0]; tile_off_s[1] = sh[1][0]; }
+    __syncthreads();
+    uint64_t a0 = tile_off_s[0] + incl0 - s0, a1 = tile_off_s[1] + incl1 - s1;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint64_t l = base + j;
+        if (l <= nlist) word_off[l] = a1;  // (index nlist receives the total)
+        for (uint32_t c = 0; c < cnt[j]; c++) chunks[a0 + c] = Chunk{(uint32_t)l, c * CHUNK_IDS};
+        a0 += cnt[j];
+        a1 += wc[j];
+        if (l < nlist) words[a1 - 1] = 0ull;  // the padding word behind the list's stream
+    }
 }
 
 // one wavefront per chunk: lane t decodes ids t, t+64, ... (coalesced 8-byte stores).  Both words an id can touch
@@ -182,7 +255,7 @@ __global__ void __launch_bounds__(64) k_compact_rows_encode(const int32_t *rows,
         const uint64_t endm = __ballot(e == -1);
         const uint32_t n = endm ? (uint32_t)__builtin_ctzll(endm) : 64u;  // edges before the first -1
         const bool bad = lane < n && (e < 0 || (uint64_t)e >= N);
-        if (__ballot(bad) && lane == 0) atomicOr(err, 1u);
+        if (__ballot(bad) && lane == 0) *(volatile uint32_t *)err = 1u;  // (every writer stores the same value: device or pinned host memory)
         // values 0..n-1 are neighbours; value n (if n < K) is the sentinel N; nothing after it (:31-36)
         if (lane <= n && lane < K) {
             const uint64_t v = lane == n ? N : (uint64_t)(uint32_t)e;
@@ -259,7 +332,7 @@ __global__ void __launch_bounds__(64) k_compact_rows_encode_wide(const int32_t *
             atomicOr(&wimg[pos >> 5], (uint32_t)sh);
             if ((pos & 31) + bits > 32) atomicOr(&wimg[(pos >> 5) + 1], (uint32_t)(sh >> 32));
         }
-        if (__ballot(bad) && lane == 0) atomicOr(err, 1u);
+        if (__ballot(bad) && lane == 0) *(volatile uint32_t *)err = 1u;  // (every writer stores the same value: device or pinned host memory)
         __syncthreads();
         const uint8_t *b = (const uint8_t *)wimg;
         for (uint32_t t = lane; t < stride; t += 64) out[row * stride + t] = b[t];
@@ -398,47 +471,44 @@ int vidc_packed_bits_for(uint64_t ntotal) {  // custom_invlists_impl.cpp:68-70
     return bits;
 }
 
-// geometry, offsets / word offsets on the device, chunk table (shared by encode and import)
-static int packed_setup(vidc_ctx *ctx, vidc_packed *p, uint64_t nlist, const uint64_t *offsets, int bits) {
+// geometry, offsets / word offsets on the device, chunk table (shared by encode and import).  Nothing is waited for here: the staging
+// block and the scan state live in `keep` until the caller has synchronised.
+struct PackedSetupKeep {
+    Pinned h_up;
+    Scratch s_state;
+};
+static int packed_setup(vidc_ctx *ctx, vidc_packed *p, uint64_t nlist, const uint64_t *offsets, int bits, PackedSetupKeep &keep) {
     p->device = ctx->device;
     p->nlist = nlist;
     p->bits = bits;
-    p->offsets.assign(nlist + 1, 0);
     if (nlist) p->offsets.assign(offsets, offsets + nlist + 1);
+    else p->offsets.assign(1, 0);
     p->ntotal = p->offsets[nlist];
-    p->word_off.assign(nlist + 1, 0);
     for (uint64_t l = 0; l < nlist; l++) {
         if (p->offsets[l + 1] < p->offsets[l]) { set_error("offsets not monotone"); return VIDC_ERR_INVALID; }
         uint64_t n = p->offsets[l + 1] - p->offsets[l];
-        p->compressed_bytes += (n * bits + 7) / 8;                       // ids_all[list_no].resize((ls*bits+7)/8), :80
-        p->word_off[l + 1] = p->word_off[l] + (n * bits + 63) / 64 + 1;  // +1: read_bits may touch the next word
+        p->compressed_bytes += (n * bits + 7) / 8;              // ids_all[list_no].resize((ls*bits+7)/8), :80
+        p->total_words += (n * bits + 63) / 64 + 1;             // +1: read_bits may touch the next word
         p->nchunks += (n + CHUNK_IDS - 1) / CHUNK_IDS;
         p->max_list = std::max(p->max_list, n);
     }
-    p->total_words = p->word_off[nlist];
-    // offsets / word offsets through pinned staging; chunk table built on the device
-    Pinned h_up;
-    Scratch s_cnt, s_coff, s_tmp;
-    VIDC_TRY(h_up.get(ctx, (nlist + 1) * 16 + 16));
-    uint64_t *h64 = h_up.as<uint64_t>();
+    // offsets through pinned staging; word offsets, chunk table and padding words on the device (k_packed_table)
+    VIDC_TRY(keep.h_up.get(ctx, (nlist + 1) * 8 + 16));
+    uint64_t *h64 = keep.h_up.as<uint64_t>();
     std::memcpy(h64, p->offsets.data(), (nlist + 1) * 8);
-    std::memcpy(h64 + nlist + 1, p->word_off.data(), (nlist + 1) * 8);
     VIDC_TRY(p->d_offsets.alloc(nlist + 1, ctx->dpool));
     VIDC_TRY(p->d_word_off.alloc(nlist + 1, ctx->dpool));
     VIDC_TRY(p->d_words.alloc(p->total_words ? p->total_words : 1, ctx->dpool));
-    VIDC_HIP(hipMemcpyAsync(p->d_offsets.p, h64, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    VIDC_HIP(hipMemcpyAsync(p->d_word_off.p, h64 + nlist + 1, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    const uint32_t nl32 = (uint32_t)nlist;
-    VIDC_TRY(s_cnt.get(ctx, (nlist + 1) * 4));
-    VIDC_TRY(s_coff.get(ctx, (nlist + 1) * 8));
-    hipLaunchKernelGGL(k_count_chunks, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256 + 1, 2048)), dim3(256), 0,
-                       ctx->stream, p->d_offsets.p, nl32, s_cnt.as<uint32_t>());
-    VIDC_TRY(device_exscan(ctx, s_cnt.as<uint32_t>(), nl32, s_coff.as<uint64_t>(), s_tmp));
     VIDC_TRY(p->d_chunks.alloc(p->nchunks ? p->nchunks : 1, ctx->dpool));
-    if (p->nchunks)
-        launch_fill_items(ctx->stream, s_coff.as<uint64_t>(), nl32, CHUNK_IDS, p->d_chunks.p, p->nchunks, (uint32_t)ctx->num_cu);
+    const uint32_t ntiles = (uint32_t)(nlist / 4096u + 1u);
+    VIDC_TRY(keep.s_state.get(ctx, ((size_t)2 * ntiles + 1) * 8));
+    VIDC_HIP(hipMemcpyAsync(p->d_offsets.p, h64, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    // (the device work of the set-up is part of the encode's kernel time: the caller reads ev0 .. ev1)
+    VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    if (ntiles > 1u) VIDC_HIP(hipMemsetAsync(keep.s_state.p, 0, ((size_t)2 * ntiles + 1) * 8, ctx->stream));
+    hipLaunchKernelGGL(k_packed_table, dim3(ntiles), dim3(256), 0, ctx->stream, p->d_offsets.p, (uint32_t)nlist, (uint32_t)bits,
+                       keep.s_state.as<unsigned long long>(), p->d_chunks.p, p->d_word_off.p, p->d_words.p);
     VIDC_HIP(hipGetLastError());
-    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));  // scratch of this scope is released on return
     return VIDC_OK;
 }
 
@@ -449,37 +519,42 @@ int vidc_packed_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, c
     if (nlist >= 0xffffffffull) return VIDC_ERR_INVALID;
     VIDC_HIP(hipSetDevice(ctx->device));
     std::unique_ptr<vidc_packed> p(new vidc_packed());
-    VIDC_TRY(packed_setup(ctx, p.get(), nlist, offsets, bits));
+    PackedSetupKeep keep;
+    struct SyncOnExit {  // (an early return must not release the staging block of copies still in flight)
+        vidc_ctx *c;
+        bool armed = true;
+        ~SyncOnExit() { if (armed) (void)vidc::vidc_stream_wait(c->stream); }
+    } guard{ctx};
+    VIDC_TRY(packed_setup(ctx, p.get(), nlist, offsets, bits, keep));
     if (p->ntotal && !d_ids) return VIDC_ERR_INVALID;
-    Scratch s_err;
-    VIDC_TRY(s_err.get(ctx, 4));
-    VIDC_HIP(hipMemsetAsync(s_err.p, 0, 4, ctx->stream));
+    // the "an id does not fit" flag is stored by the kernels into pinned memory (no copy engine behind the last kernel)
+    Pinned h_err;
+    VIDC_TRY(h_err.get(ctx, 64));
+    volatile uint32_t *err_flag = h_err.as<uint32_t>();
+    *err_flag = 0u;
     if (p->total_words) {
-        VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-        hipLaunchKernelGGL(k_packed_zero_pads, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 2048)), dim3(256), 0,
-                           ctx->stream, p->d_word_off.p, (uint32_t)nlist, p->d_words.p);
         uint32_t grid = (uint32_t)std::min<uint64_t>(p->nchunks, (uint64_t)ctx->num_cu * 256);
         // ids must fit the field (FAISS_THROW_IF_NOT(ids_in[i] >= 0 && ids_in[i] < ntotal), :87)
         uint64_t limit = ~0ull;
         if (p->nchunks && p->max_list <= 256)
             hipLaunchKernelGGL(k_packed_encode<4>, dim3(grid), dim3(64), 0, ctx->stream, d_ids, p->d_offsets.p,
                                p->d_word_off.p, p->d_chunks.p, p->nchunks, (uint32_t)bits, limit, p->d_words.p,
-                               s_err.as<uint32_t>());
+                               h_err.as<uint32_t>());
         else if (p->nchunks)
             hipLaunchKernelGGL(k_packed_encode<CHUNK_IDS / 64>, dim3(grid), dim3(64), 0, ctx->stream, d_ids, p->d_offsets.p,
                                p->d_word_off.p, p->d_chunks.p, p->nchunks, (uint32_t)bits, limit, p->d_words.p,
-                               s_err.as<uint32_t>());
+                               h_err.as<uint32_t>());
         VIDC_HIP(hipGetLastError());
-        VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     }
-    uint32_t err = 0;
-    VIDC_HIP(hipMemcpyAsync(&err, s_err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    guard.armed = false;
     VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
-    if (p->total_words) {
+    {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
         ctx->last_kernel_ms = ms;
     }
+    const uint32_t err = *err_flag;
     if (err) {
         set_error("packed bits: an id does not fit %d bits (reference: FAISS_THROW_IF_NOT(ids_in[i] >= 0 && "
                   "ids_in[i] < ntotal), custom_invlists_impl.cpp:87)", bits);
@@ -504,7 +579,12 @@ int vidc_packed_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, i
     if (nlist >= 0xffffffffull) return VIDC_ERR_INVALID;
     VIDC_HIP(hipSetDevice(ctx->device));
     std::unique_ptr<vidc_packed> p(new vidc_packed());
-    VIDC_TRY(packed_setup(ctx, p.get(), nlist, offsets, bits));
+    PackedSetupKeep keep;
+    {
+        const int st = packed_setup(ctx, p.get(), nlist, offsets, bits, keep);
+        VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));  // (the staging block / scan state of the set-up)
+        VIDC_TRY(st);
+    }
     if (nwords != p->total_words || (nwords && !words)) {
         set_error("packed import: %llu words given, the offsets need %llu", (unsigned long long)nwords,
                   (unsigned long long)p->total_words);
@@ -604,7 +684,9 @@ int vidc_packed_export(vidc_ctx *ctx, const vidc_packed *p, uint64_t list_no, ui
     uint64_t n = p->offsets[list_no + 1] - p->offsets[list_no];
     uint64_t nb = (n * p->bits + 7) / 8;
     if (nb > cap) { set_error("export buffer too small"); return VIDC_ERR_INVALID; }
-    return vidc_copy_d2h(ctx, bytes, p->d_words.p + p->word_off[list_no], nb);
+    uint64_t w0 = 0;  // (the word offsets live on the device)
+    VIDC_TRY(vidc_copy_d2h(ctx, &w0, p->d_word_off.p + list_no, 8));
+    return vidc_copy_d2h(ctx, bytes, p->d_words.p + w0, nb);
 }
 
 }  // extern "C"
