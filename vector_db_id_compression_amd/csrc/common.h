@@ -76,6 +76,50 @@ inline hipError_t vidc_event_wait(hipEvent_t ev) {
         if (_s != VIDC_OK) return _s; \
     } while (0)
 
+// Emptied std::vectors kept with their capacity (process-wide, bounded): the host arrays of a 10^6-list object are 4-8 MB each, beyond
+// the allocator's mmap threshold, so every encode call page-faulted ~50 MB in and every destroyed object unmapped it again (S2: 2 ms per
+// destroyed ROC object, 1-2 ms spread over the host phases of the next encode).  take(n): an empty vector of capacity >= n.
+template <typename T>
+struct VecPool {
+    static constexpr size_t MIN_BYTES = 1u << 20, MAX_TOTAL = 768u << 20, MAX_COUNT = 96;
+    std::mutex m;
+    std::vector<std::vector<T>> free_;
+    size_t bytes = 0;
+    std::vector<T> take(size_t n) {
+        if (n * sizeof(T) >= MIN_BYTES) {
+            std::lock_guard<std::mutex> g(m);
+            size_t best = free_.size();
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].capacity() >= n && (best == free_.size() || free_[i].capacity() < free_[best].capacity())) best = i;
+            if (best != free_.size() && free_[best].capacity() <= 2 * n + (MIN_BYTES / sizeof(T))) {
+                std::vector<T> v = std::move(free_[best]);
+                free_[best] = std::move(free_.back());
+                free_.pop_back();
+                bytes -= v.capacity() * sizeof(T);
+                return v;
+            }
+        }
+        std::vector<T> v;
+        v.reserve(n);
+        return v;
+    }
+    void give(std::vector<T> &&v) {
+        const size_t b = v.capacity() * sizeof(T);
+        if (b < MIN_BYTES) return;
+        v.clear();
+        std::lock_guard<std::mutex> g(m);
+        if (free_.size() < MAX_COUNT && bytes + b <= MAX_TOTAL) {
+            bytes += b;
+            free_.push_back(std::move(v));
+        }
+    }
+};
+template <typename T>
+inline VecPool<T> &vec_pool() {
+    static VecPool<T> *p = new VecPool<T>();  // (never destroyed: objects may outlive static destruction order)
+    return *p;
+}
+
 // Cached device blocks shared by a context and the objects created through it: steady-state encode / decode calls
 // neither hipMalloc nor hipFree (hipFree synchronises the device).  Blocks go back to the pool when their owner
 // dies and are released when the last holder of the pool (context or object) is gone.

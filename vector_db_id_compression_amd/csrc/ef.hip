@@ -52,6 +52,10 @@ struct vidc_ef {
     mutable uint32_t recs_max_cnt = 0;  // largest element count of a batch: sizes the decode kernel's LDS table
     uint64_t max_list = 0;              // longest list (0: unknown): an upper bound of that count, known without a read-back
     bool narrow = false;  // every id < 2^32 and every list < 2^30 ids (known from the encoder): 32-bit decode kernel
+    ~vidc_ef() {  // the large host arrays go back to the process-wide vector cache (common.h)
+        for (auto *v : {&offsets, &low_off, &high_off, &universe, &high_nbits}) vidc::vec_pool<uint64_t>().give(std::move(*v));
+        vidc::vec_pool<uint32_t>().give(std::move(lbits));
+    }
 };
 
 // Everything a wavefront needs to decode one batch of 64 high words, in one 48-byte record: with the CSR arrays
@@ -1681,8 +1685,9 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     std::unique_ptr<vidc_ef> e(new vidc_ef());
     e->device = ctx->device;
     e->nlist = nlist;
-    e->offsets.assign(nlist + 1, 0);
+    e->offsets = vec_pool<uint64_t>().take(nlist + 1);
     if (nlist) e->offsets.assign(offsets, offsets + nlist + 1);
+    else e->offsets.assign(1, 0);
     e->offsets_host = true;
     e->ntotal = e->offsets[nlist];
     uint64_t nchunks = 0, max_list = 0;

@@ -27,6 +27,7 @@ struct vidc_packed {
     DevBuf<Chunk> d_chunks;
     uint64_t nchunks = 0;
     uint64_t max_list = 0;  // ids of the longest list: objects without a list of more than 256 ids take the four-register kernels
+    ~vidc_packed() { vidc::vec_pool<uint64_t>().give(std::move(offsets)); }  // (back to the process-wide vector cache, common.h)
 };
 
 namespace {
@@ -481,6 +482,7 @@ static int packed_setup(vidc_ctx *ctx, vidc_packed *p, uint64_t nlist, const uin
     p->device = ctx->device;
     p->nlist = nlist;
     p->bits = bits;
+    p->offsets = vec_pool<uint64_t>().take(nlist + 1);
     if (nlist) p->offsets.assign(offsets, offsets + nlist + 1);
     else p->offsets.assign(1, 0);
     p->ntotal = p->offsets[nlist];

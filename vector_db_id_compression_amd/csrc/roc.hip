@@ -54,6 +54,11 @@ struct vidc_roc {
     mutable std::shared_ptr<struct DecPlanCache> plan_all;
     // the same plan without its device arrays, built by the encoder while its kernels run (the host would only wait)
     mutable std::shared_ptr<struct DecPlanCache> plan_ahead;
+    ~vidc_roc() {  // the large host arrays go back to the process-wide vector cache (common.h)
+        vec_pool<uint64_t>().give(std::move(offsets)); vec_pool<uint64_t>().give(std::move(heads)); vec_pool<uint64_t>().give(std::move(word_off));
+        vec_pool<uint32_t>().give(std::move(prec)); vec_pool<uint32_t>().give(std::move(nwords)); vec_pool<uint32_t>().give(std::move(draws));
+        vec_pool<uint32_t>().give(std::move(umax)); vec_pool<uint32_t>().give(std::move(order_desc));
+    }
 };
 
 namespace {
@@ -307,7 +312,9 @@ void sort_desc(std::vector<uint32_t> &wl, const std::vector<uint64_t> &offsets) 
         });
         return;
     }
-    std::vector<uint32_t> out(wl.size());
+    std::vector<uint32_t> out = vec_pool<uint32_t>().take(wl.size());
+    out.resize(wl.size());
+    struct Back { std::vector<uint32_t> &v; ~Back() { vec_pool<uint32_t>().give(std::move(v)); } } out_back{out};  // (holds wl's old array after the swap)
     const unsigned parts = maxlen <= 65536 ? par_parts(wl.size()) : 1;
     if (parts > 1) {  // the same stable counting sort, histogram and scatter per contiguous part of the work list
         const size_t nb = maxlen + 1;
@@ -462,6 +469,15 @@ struct DecPlan {
     bool tiny_lane = false;          // DC_TINY items run on the lane-per-list kernel
     bool gsmall_lrows = false;       // DC_GSMALL items keep their member rows in LDS (33 KiB each: only for few lists)
     uint64_t implicit = 0;           // lean plan without a work list: items are rows 0..implicit-1
+    DecPlan() = default;
+    DecPlan(const DecPlan &) = default;
+    DecPlan(DecPlan &&) = default;
+    DecPlan &operator=(const DecPlan &) = default;
+    DecPlan &operator=(DecPlan &&) = default;
+    ~DecPlan() {
+        vec_pool<uint32_t>().give(std::move(wl)); vec_pool<uint32_t>().give(std::move(item));
+        vec_pool<uint64_t>().give(std::move(scratch_off)); vec_pool<uint64_t>().give(std::move(slots_off));
+    }
 };
 
 }  // namespace
@@ -542,6 +558,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         // classification, the first reader
         std::thread offsets_copy;
         struct JoinOnExit { std::thread &t; ~JoinOnExit() { if (t.joinable()) t.join(); } } offsets_copy_guard{offsets_copy};
+        r->offsets = vec_pool<uint64_t>().take(nlist + 1);
         if (par_parts(nlist) > 1) offsets_copy = std::thread([&] { r->offsets.assign(offsets, offsets + nlist + 1); });
         else r->offsets.assign(offsets, offsets + nlist + 1);
         r->offsets_host = true;
@@ -693,6 +710,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 VIDC_HIP(hipMemcpyAsync(h_pre.p, s_maxid.p, nlist * 4, hipMemcpyDeviceToHost, ctx->stream));
                 VIDC_HIP(hipEventRecord(ctx->ev_pre[2], ctx->stream));
                 pre_guard.armed = true;
+                r->prec = vec_pool<uint32_t>().take(nlist);
                 r->prec.resize(nlist);
                 tr.mark("prepass kernel (read back later)");
             } else {
@@ -716,7 +734,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 tr.mark("prepass kernel + d2h");
                 // what the decode planner needs later (kernel class, bucket geometry) is known right here
                 // (the precisions are filled in by the classification loop below: one pass over the lists instead of two)
+                r->prec = vec_pool<uint32_t>().take(nlist);
                 r->prec.resize(nlist);
+                r->umax = vec_pool<uint32_t>().take(nlist);
                 r->umax.assign(maxid, maxid + nlist);
             }
         } else {
@@ -735,7 +755,8 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             // dozen push_back targets and the per-class sorts behind it were 0.13 + 0.02 ms of a 65 536-list call.
             const bool by_length = !maxid && !pflags && parts == 1 && !f_general && !env_on("VIDC_NO_LENGTH_CLASSES");
             if (by_length) {
-                std::vector<uint32_t> order(nlist);
+                std::vector<uint32_t> order = vec_pool<uint32_t>().take(nlist);
+                order.resize(nlist);
                 if (all_desc) {
                     std::iota(order.begin(), order.end(), 0u);
                 } else {
@@ -1671,10 +1692,10 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     // passes with push_back this replaces were half of the planner's time)
     size_t total_items = 0;
     for (int c = 0; c < DC_COUNT; c++) total_items += cls[c].size();
-    p.item.resize(total_items);
-    p.wl.resize(total_items);
-    p.scratch_off.resize(total_items);
-    p.slots_off.resize(total_items);
+    p.item = vec_pool<uint32_t>().take(total_items); p.item.resize(total_items);
+    p.wl = vec_pool<uint32_t>().take(total_items); p.wl.resize(total_items);
+    p.scratch_off = vec_pool<uint64_t>().take(total_items); p.scratch_off.resize(total_items);
+    p.slots_off = vec_pool<uint64_t>().take(total_items); p.slots_off.resize(total_items);
     uint64_t so = 0, sl = 0;
     size_t k = 0;
     const uint64_t *offs = r->offsets.data();
@@ -2076,13 +2097,14 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     // ONE wait for both
     t.mark();
     Pinned h_sum;
-    VIDC_TRY(h_sum.get(ctx, 64));
+    constexpr uint32_t RETRY_SLOTS = 504;  // list numbers of handed-back lists behind the eight summary words
+    VIDC_TRY(h_sum.get(ctx, (8 + RETRY_SLOTS) * 8));
     unsigned long long *sum = h_sum.as<unsigned long long>();
     sum[0] = ~0ull; sum[1] = 0; sum[2] = 0; sum[3] = 0;
     // (the kernel's last workgroup stores the summary into the pinned block itself: no copy up, no copy down)
     hipLaunchKernelGGL(k_roc_status_summary_host, dim3((uint32_t)std::min<uint64_t>((r->nlist + 255) / 256, 1024)), dim3(256),
                        0, ctx->stream, d_status, s_end.as<uint32_t>(), (uint32_t)r->nlist,
-                       (unsigned long long *)(s_end.as<uint32_t>() + 2 * r->nlist), sum);
+                       (unsigned long long *)(s_end.as<uint32_t>() + 2 * r->nlist), sum, (out_off_host || r->rows) ? 0u : RETRY_SLOTS);
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     ctx->last_kernel_ms = t.elapsed();
@@ -2095,20 +2117,33 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     const double first_ms = ctx->last_kernel_ms;
     uint64_t nonclean = sum[1];
     if (sum[0] != ~0ull || sum[2]) {
-        std::vector<uint32_t> status(r->nlist);
-        VIDC_HIP(hipMemcpy(status.data(), d_status, r->nlist * 4, hipMemcpyDeviceToHost));
+        // (a few handed-back lists and nothing else to report: their numbers came with the summary; otherwise the statuses are fetched)
+        const bool listed = sum[0] == ~0ull && !out_off_host && !r->rows && sum[2] <= RETRY_SLOTS;
+        std::vector<uint32_t> status(listed ? 0 : r->nlist);
+        if (!listed) VIDC_HIP(hipMemcpy(status.data(), d_status, r->nlist * 4, hipMemcpyDeviceToHost));
         if (sum[2]) {
             // lists the lane-per-list decoder handed back (a full bucket row on skewed ids): redo them with the
             // wave-per-list kernels, into the same output slots
             std::vector<uint32_t> lists2;
             std::vector<uint64_t> off2;
+            if (listed) {
+                for (uint64_t k = 0; k < sum[2]; k++) lists2.push_back((uint32_t)sum[8 + k]);
+                std::sort(lists2.begin(), lists2.end());
+                for (uint32_t l : lists2) off2.push_back(r->offsets[l]);
+            } else
             for (size_t k = base[DC_LANE]; k < p.wl.size(); k++) {  // lane classes, B2, row-per-list classes
                 if (status[p.wl[k]] != VIDC_ST_RETRY) continue;
                 lists2.push_back(p.wl[k]);
                 off2.push_back(out_off_host ? out_off_host[k] : r->offsets[p.wl[k]]);
             }
-            for (uint32_t l : lists2) status[l] = VIDC_ST_OK;
-            VIDC_TRY(check_status(status, "roc decode"));
+            if (!listed) for (uint32_t l : lists2) status[l] = VIDC_ST_OK;
+            if (tr.on) {
+                uint64_t mx = 0, mn = ~0ull;
+                for (uint32_t l : lists2) { const uint64_t n = r->offsets[l + 1] - r->offsets[l]; mx = std::max(mx, n); mn = std::min(mn, n); }
+                fprintf(stderr, "[vidc] roc decode: %zu lists handed back by the lane decoders (%llu .. %llu ids)\n", lists2.size(),
+                        (unsigned long long)mn, (unsigned long long)mx);
+            }
+            if (!listed) VIDC_TRY(check_status(status, "roc decode"));
             DecPlan p2;
             plan_decode(r, lists2, false, p2, ctx->wide, false, false);
             std::vector<uint64_t> out_off2(lists2.size());

@@ -598,7 +598,7 @@ __global__ void k_roc_status_summary(const uint32_t *status, const uint32_t *end
 // finish stores the four values into `host` -- pinned host memory, read by the host behind the one synchronisation of the call.
 // A copy engine between the last kernel and the host's wake-up (init copy up, result copy down) cost more than the kernel.
 __global__ void k_roc_status_summary_host(const uint32_t *status, const uint32_t *end_state, uint32_t nlist,
-                                          unsigned long long *acc, unsigned long long *host) {
+                                          unsigned long long *acc, unsigned long long *host, uint32_t retry_cap) {
     unsigned long long bad = ~0ull, nonclean = 0, retry = 0, pending = 0;
     for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x) {
         const uint32_t s = status[l];
@@ -611,6 +611,13 @@ __global__ void k_roc_status_summary_host(const uint32_t *status, const uint32_t
     if (nonclean) atomicAdd(&acc[1], nonclean);
     if (retry) atomicAdd(&acc[2], retry);
     if (pending) atomicAdd(&acc[3], pending);
+    if (retry && retry_cap) {  // the handed-back lists themselves (a handful per 10^6): the host redoes them without fetching nlist statuses
+        for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x)
+            if (status[l] == 5u) {
+                const unsigned long long k = atomicAdd(&acc[5], 1ull);
+                if (k < retry_cap) host[8 + k] = l;  // (pinned memory: each slot has one writer)
+            }
+    }
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0 && atomicAdd(&acc[4], 1ull) == (unsigned long long)gridDim.x - 1ull) {
