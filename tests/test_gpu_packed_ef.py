@@ -51,6 +51,35 @@ def test_packed_bits_widths(oracle, bits):
     assert np.array_equal(pk.export_bytes(0), oracle.packed_encode(ids[:300], bits))
 
 
+@pytest.mark.parametrize("nlist", [1, 4095, 4096, 4097, 8192, 12289, 70000])
+def test_packed_geometry_kernel_list_counts(oracle, nlist):
+    """One launch builds chunk table, word offsets and padding words by a chained scan over 4096-list tiles (k_packed_table):
+    list counts on and around the tile size, empty lists, lists of several chunks; per-list byte image against the oracle."""
+    from vector_db_id_compression_amd.codecs import PackedLists
+
+    rng = np.random.default_rng(1000 + nlist)
+    sizes = rng.integers(0, 40, size=nlist)
+    sizes[rng.integers(0, nlist, size=max(1, nlist // 50))] = 0
+    for k in rng.integers(0, nlist, size=min(nlist, 6)):
+        sizes[k] = int(rng.integers(500, 3000))  # several 512-id chunks
+    ntotal = int(sizes.sum())
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    ids = rng.permutation(max(ntotal, 1))[:ntotal].astype(np.uint64)
+    pk = PackedLists.encode(off, ids)
+    bits = pk.bits
+    assert pk.compressed_bytes == int(sum((int(s) * bits + 7) // 8 for s in sizes))
+    assert np.array_equal(pk.decode_all().cpu().numpy().view(np.uint64), ids)
+    for l in list(rng.integers(0, nlist, size=min(nlist, 40))) + [0, nlist - 1, int(np.argmax(sizes))]:
+        li = ids[int(off[l]):int(off[l + 1])]
+        assert np.array_equal(pk.export_bytes(int(l)), oracle.packed_encode(li, bits)), f"list {l}"
+    if ntotal:
+        ql = rng.integers(0, nlist, size=64).astype(np.uint64)
+        ql = ql[sizes[ql.astype(np.int64)] > 0]
+        qo = np.array([rng.integers(0, sizes[int(l)]) for l in ql], dtype=np.uint64)
+        want = [int(ids[int(off[int(l)]) + int(o)]) for l, o in zip(ql, qo)]
+        assert pk.get(ql, qo).tolist() == want
+
+
 def test_packed_domain_error():
     from vector_db_id_compression_amd import VidcError
     from vector_db_id_compression_amd.codecs import PackedLists
@@ -119,6 +148,43 @@ def test_elias_fano_single_pass_encoder_list_counts(oracle, nlist):
     ef = EfLists.encode(off, ids)
     sample = np.unique(np.concatenate([big, [0, nlist - 1], np.arange(min(nlist, 50)), rng.integers(0, nlist, size=100)]))
     _check_ef_lists(oracle, ef, off, ids, sample)
+
+
+def test_elias_fano_decode_records_from_the_encoder_and_from_the_lazy_build(monkeypatch):
+    """Objects below 2^18 batches get their bulk-decode records from the encoder's chunk wavefronts (ef_store_rec); the others --
+    and every object under VIDC_EF_LAZY_RECS=1 -- build them on the first decode_all (k_ef_build_recs).  Both must decode alike:
+    dense lists (many batches per list), sparse lists (a chunk spanning many batches), empty lists, 64-bit ids."""
+    import torch
+    from vector_db_id_compression_amd.codecs import EfLists
+
+    rng = np.random.default_rng(77)
+    for wide in (False, True):
+        sizes = np.concatenate([rng.integers(0, 300, size=3000), [0, 0, 70000, 1, 513, 512, 511, 20000]])
+        rng.shuffle(sizes)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        parts = []
+        for s in sizes:
+            s = int(s)
+            if s == 0:
+                continue
+            if s >= 20000:  # dense: consecutive ids with a few gaps
+                li = np.cumsum(rng.integers(1, 3, size=s)).astype(np.uint64)
+            else:  # sparse
+                li = np.sort(rng.choice(1 << 28, size=s, replace=False)).astype(np.uint64)
+            parts.append(li + (np.uint64(1) << np.uint64(40) if wide else np.uint64(0)))
+        ids = torch.from_numpy(np.concatenate(parts).view(np.int64)).cuda()
+        outs = []
+        for lazy in (False, True):
+            if lazy:
+                monkeypatch.setenv("VIDC_EF_LAZY_RECS", "1")
+            else:
+                monkeypatch.delenv("VIDC_EF_LAZY_RECS", raising=False)
+            e = EfLists.encode(off, ids)
+            a = e.decode_all().clone()
+            b = e.decode_all().clone()  # (second call: the records are there either way)
+            assert torch.equal(a, ids) and torch.equal(b, ids), (wide, lazy)
+            outs.append(e.compressed_bytes)
+        assert outs[0] == outs[1]
 
 
 def test_elias_fano_sparse_chunk_owns_many_directory_entries(oracle):
