@@ -1060,7 +1060,11 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
         if (!tot) continue;
         const LW keep = b ? (LW)(((b >= WB ? (LW)0 : ((LW)1 << b))) - (LW)1) : (LW)0;
         const LW *lw = (const LW *)(low + low_base);
-        uint64_t word = lane < nw ? high[hw_base + lane] : 0ull;
+        // A batch of few high words spreads every word over 2 / 4 / 8 lanes (32- / 16- / 8-bit pieces): with a word per lane a 256-id
+        // list's ~10 words kept 10 lanes busy for ~25 set bits each while 54 idled (16 M ids in lists of 256: 46 -> 36 us).
+        const uint32_t sh = nw <= 8u ? 3u : (nw <= 16u ? 2u : (nw <= 32u ? 1u : 0u));
+        const uint32_t wi_ = lane >> sh, pw = 64u >> sh, sub = lane & ((1u << sh) - 1u);
+        const uint64_t word = wi_ < nw ? high[hw_base + wi_] : 0ull;
         LW a[R], bw[R];
 #pragma unroll
         for (uint32_t k = 0; k < R; k++) {  // both words, unconditionally (a padding word follows every stream)
@@ -1069,18 +1073,14 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
             a[k] = b ? lw[bp >> WSH] : (LW)0;
             bw[k] = b ? lw[(bp >> WSH) + 1] : (LW)0;
         }
-        const uint32_t c = popc64(word);
-        uint32_t incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
-            if (lane >= (uint32_t)o) incl += v;
-        }
-        uint32_t r = incl - c;
-        {   // transpose: position of every set bit, indexed by its rank inside the batch (32-bit halves: one
+        {
+            const uint64_t piece = sh ? (word >> (pw * sub)) & ((1ull << pw) - 1ull) : word;
+            const uint32_t c = popc64(piece);
+            uint32_t r = wave_scan32(c) - c;
+            // transpose: position of every set bit, indexed by its rank inside the batch (32-bit halves: one
             // v_ffbl + two ALU ops per bit instead of the 64-bit sequence)
-            uint32_t h0 = (uint32_t)word, h1 = (uint32_t)(word >> 32);
-            const uint32_t p0 = lane * 64u;
+            uint32_t h0 = (uint32_t)piece, h1 = (uint32_t)(piece >> 32);
+            const uint32_t p0 = wi_ * 64u + pw * sub;
             while (h0) {
                 spos[r++] = (uint16_t)(p0 + (uint32_t)__builtin_ctz(h0));
                 h0 &= h0 - 1u;
