@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) k_packed_table(const uint64_t *__restrict
     const uint64_t incl0 = sh[0][t], incl1 = sh[1][t];
     if (t == 0 && nt > 1u) {
         const uint64_t sum0 = sh[0][255], sum1 = sh[1][255];
-        __threadfence();
+        // (no fence in front: the published values are the exchanges' own operands; a device-scope release writes back the XCD's whole L2)
         atomicExch(&state[tile], (1ull << 63) | sum0);
         atomicExch(&state[nt + tile], (1ull << 63) | sum1);
     }

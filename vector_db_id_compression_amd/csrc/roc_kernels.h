@@ -677,10 +677,8 @@ __global__ void __launch_bounds__(256) k_roc_tail(const uint32_t *__restrict__ n
         __syncthreads();
     }
     const uint64_t incl = sh[t], tile_sum = sh[255];
-    if (t == 0) {
-        __threadfence();
-        atomicExch(&state[tile], (1ull << 63) | tile_sum);
-    }
+    // (no fence in front: the published value is the exchange's own operand, and a device-scope release writes back the XCD's whole L2)
+    if (t == 0) atomicExch(&state[tile], (1ull << 63) | tile_sum);
     // sums of the tiles before this one (they were dispatched earlier: every wait ends)
     uint64_t before = 0;
     for (uint32_t k = t; k < tile; k += 256u) {
