@@ -519,6 +519,26 @@ def test_lane_decoder_hands_back_skewed_lists(roc, oracle, force_lane):
         assert np.array_equal(sub[int(sub_off[i]):int(sub_off[i + 1])], dec[int(off[l]):int(off[l + 1])])
 
 
+def test_lane_decoder_hands_back_more_lists_than_the_summary_lists(roc, force_lane):
+    """The decode summary names up to 504 handed-back lists; beyond that the host fetches the statuses: 700 clustered lists
+    next to 300 clean ones, every list identical to the decode of the wave-per-list kernels' path."""
+    rng = np.random.default_rng(81)
+    lists = []
+    for k in range(1000):
+        if k % 10 < 7:
+            body = np.sort(rng.choice(12000, size=599, replace=False)).astype(np.uint64) + 3  # (bucket-row class: one full bucket)
+            lists.append(np.concatenate([body, [(1 << 20) - 1 - k]]).astype(np.uint64))
+        else:
+            lists.append(np.sort(rng.choice(1 << 20, size=620, replace=False)).astype(np.uint64))
+    off = np.concatenate([[0], np.cumsum([li.size for li in lists])]).astype(np.uint64)
+    ids = np.concatenate(lists)
+    r = roc.encode(off, ids)
+    dec = r.decode_all().cpu().numpy().view(np.uint64)
+    assert r.last_decode_nonclean == 0
+    for l, li in enumerate(lists):
+        assert np.array_equal(np.sort(dec[int(off[l]):int(off[l + 1])]), li), l
+
+
 def test_lane_kernels_match_wave_kernels(roc, monkeypatch):
     """Same streams from the two kernel families (VIDC_FORCE_LANE / VIDC_NO_LANE test hooks) on 3000 ragged lists,
     and from the automatic choice on a batch large enough to take the lane kernels by itself."""
