@@ -1691,7 +1691,11 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     e->offsets_host = true;
     e->ntotal = e->offsets[nlist];
     uint64_t nchunks = 0, max_list = 0;
-    for (uint64_t l = 0; l < nlist; l++) {
+    static_assert((EF_CHUNK & (EF_CHUNK - 1u)) == 0u, "the pass below counts chunks by a shift");
+    const LengthsPass lp = lengths_pass(offsets, nlist, (uint32_t)__builtin_ctz(EF_CHUNK), 0u);  // (four lists per instruction where the host can)
+    if (!lp.wide && lp.max_n <= 0xfffffff0ull) { nchunks = lp.nchunks; max_list = lp.max_n; }
+    else
+    for (uint64_t l = 0; l < nlist; l++) {  // (some length of 2^32 or more, or offsets that decrease: list by list, with the message)
         if (e->offsets[l + 1] < e->offsets[l] || e->offsets[l + 1] - e->offsets[l] > 0xfffffff0ull) {
             set_error("bad offsets at list %llu", (unsigned long long)l);
             return VIDC_ERR_INVALID;

@@ -499,7 +499,11 @@ static int packed_setup(vidc_ctx *ctx, vidc_packed *p, uint64_t nlist, const uin
     if (nlist) p->offsets.assign(offsets, offsets + nlist + 1);
     else p->offsets.assign(1, 0);
     p->ntotal = p->offsets[nlist];
-    for (uint64_t l = 0; l < nlist; l++) {
+    const LengthsPass lp = lengths_pass(p->offsets.data(), nlist, 9u, (uint32_t)bits);  // (four lists per instruction where the host can)
+    static_assert(CHUNK_IDS == 512, "the pass above counts chunks of 2^9 ids");
+    if (!lp.wide) { p->compressed_bytes += lp.bytes; p->total_words += lp.words; p->nchunks += lp.nchunks; p->max_list = std::max(p->max_list, lp.max_n); }
+    else
+    for (uint64_t l = 0; l < nlist; l++) {  // (a list of 2^32 ids or more, or offsets that decrease: list by list)
         if (p->offsets[l + 1] < p->offsets[l]) { set_error("offsets not monotone"); return VIDC_ERR_INVALID; }
         uint64_t n = p->offsets[l + 1] - p->offsets[l];
         p->compressed_bytes += (n * bits + 7) / 8;              // ids_all[list_no].resize((ls*bits+7)/8), :80

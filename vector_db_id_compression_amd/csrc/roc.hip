@@ -8,12 +8,11 @@
 #include <mutex>
 #include <numeric>
 #include <thread>
-#if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(_M_X64))
-#include <immintrin.h>
-#define VIDC_X86_HOST 1
-#endif
 
 #include "common.h"
+#ifdef VIDC_X86_HOST_COMMON
+#define VIDC_X86_HOST 1
+#endif
 #include "roc_kernels.h"
 #include "roc_u.h"
 #include "roc_u2.h"
