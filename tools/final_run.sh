@@ -14,6 +14,7 @@ GPU_MAX_HW_QUEUES=8 VIDC_WIDE_STREAMS=1 timeout 1200 python -m pytest tests/test
 VIDC_NO_LANE_PAIR=1 VIDC_FORCE_LANE=1 timeout 900 python -m pytest tests/test_gpu_roc.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_no_lane_pair.txt
 # round 4: the loop form of the bucket-row lane decoders + 256 buckets for 1025..2048 ids; per-list classification instead of the length order
 VIDC_LANE_LOOP=1 VIDC_NO_LANE128=1 VIDC_FORCE_LANE=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_lane_loop.txt
+VIDC_NO_AVX2=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_packed_ef.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_no_avx2.txt
 VIDC_NO_LENGTH_CLASSES=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_no_length_classes.txt
 # S2 decoded 100 times per mode and compared with the first decode (the list-level flake hunt of round 3)
 (GPU_MAX_HW_QUEUES=8 NQS=4,8,5,6 ITERS=100 timeout 200 python tools/repro_s2b.py "X=1" 2>&1 | grep "differs\|it 99" | cut -c1-160; GPU_MAX_HW_QUEUES=4 NQS=3 ITERS=100 timeout 200 python tools/repro_s2b.py "X=1" 2>&1 | grep "differs\|it 99" | cut -c1-160) > gpurun_out/$R/s2_repeated_decodes.txt

@@ -16,10 +16,7 @@
 
 #include "../../include/vidc.h"
 
-#if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(_M_X64))
-#include <immintrin.h>
-#define VIDC_X86_HOST_COMMON 1
-#endif
+#include "host_passes.h"
 
 struct vidc_ctx;
 
@@ -81,69 +78,6 @@ inline hipError_t vidc_event_wait(hipEvent_t ev) {
         int _s = (expr);            \
         if (_s != VIDC_OK) return _s; \
     } while (0)
-
-// One pass over the CSR offsets of an Elias-Fano / packed-bits encode call: longest list, chunks of 2^unit_shift ids, and for packed
-// bits the byte and word counts of every list's `bits`-wide fields.  The scalar loops were 1-2 ns per list -- more than the kernels of a
-// 65 536-list call, 1-2 ms of a 10^6-list one; with AVX2 four lists per instruction.  `wide` = some length of 2^32 or more (or offsets
-// that decrease): the caller then takes its own scalar loop, which validates and reports list by list.
-struct LengthsPass {
-    uint64_t max_n = 0, nchunks = 0, bytes = 0, words = 0;  // bytes = sum (n*bits+7)/8, words = sum ((n*bits+63)/64 + 1)
-    bool wide = false;
-};
-inline void lengths_pass_scalar(const uint64_t *off, uint64_t la, uint64_t lb, uint32_t unit_shift, uint32_t bits, LengthsPass &x) {
-    const uint64_t unit_m1 = (1ull << unit_shift) - 1ull;
-    for (uint64_t l = la; l < lb; l++) {
-        const uint64_t n = off[l + 1] - off[l];
-        if (n >> 32) { x.wide = true; continue; }
-        x.max_n = n > x.max_n ? n : x.max_n;
-        x.nchunks += (n + unit_m1) >> unit_shift;
-        const uint64_t nb = n * bits;
-        x.bytes += (nb + 7) >> 3;
-        x.words += ((nb + 63) >> 6) + 1;
-    }
-}
-#ifdef VIDC_X86_HOST_COMMON
-__attribute__((target("avx2"))) inline void lengths_pass_avx2(const uint64_t *off, uint64_t nlist, uint32_t unit_shift, uint32_t bits,
-                                                               LengthsPass &x) {
-    uint64_t l = 0;
-    __m256i vor = _mm256_setzero_si256(), vmax = _mm256_setzero_si256(), vch = _mm256_setzero_si256(), vby = _mm256_setzero_si256(),
-            vwo = _mm256_setzero_si256();
-    const __m256i um1 = _mm256_set1_epi64x((long long)((1ull << unit_shift) - 1ull)), vbits = _mm256_set1_epi64x((long long)bits);
-    const __m256i c7 = _mm256_set1_epi64x(7), c63 = _mm256_set1_epi64x(63);
-    const __m128i sh_unit = _mm_cvtsi32_si128((int)unit_shift);
-    for (; l + 4 <= nlist; l += 4) {
-        const __m256i o0 = _mm256_loadu_si256((const __m256i *)(off + l)), o1 = _mm256_loadu_si256((const __m256i *)(off + l + 1));
-        const __m256i n = _mm256_sub_epi64(o1, o0);
-        vor = _mm256_or_si256(vor, n);
-        vmax = _mm256_blendv_epi8(vmax, n, _mm256_cmpgt_epi64(n, vmax));  // (only used when no length has bits above 2^32)
-        vch = _mm256_add_epi64(vch, _mm256_srl_epi64(_mm256_add_epi64(n, um1), sh_unit));
-        const __m256i nb = _mm256_mul_epu32(n, vbits);  // n < 2^32, bits <= 64: the product fits 64 bits
-        vby = _mm256_add_epi64(vby, _mm256_srli_epi64(_mm256_add_epi64(nb, c7), 3));
-        vwo = _mm256_add_epi64(vwo, _mm256_srli_epi64(_mm256_add_epi64(nb, c63), 6));
-    }
-    alignas(32) uint64_t t[4];
-    _mm256_store_si256((__m256i *)t, vor);
-    if ((t[0] | t[1] | t[2] | t[3]) >> 32) { x.wide = true; return; }
-    _mm256_store_si256((__m256i *)t, vmax);
-    x.max_n = std::max(std::max(t[0], t[1]), std::max(t[2], t[3]));
-    _mm256_store_si256((__m256i *)t, vch);
-    x.nchunks = t[0] + t[1] + t[2] + t[3];
-    _mm256_store_si256((__m256i *)t, vby);
-    x.bytes = t[0] + t[1] + t[2] + t[3];
-    _mm256_store_si256((__m256i *)t, vwo);
-    x.words = t[0] + t[1] + t[2] + t[3] + l;  // (+1 padding word per list)
-    lengths_pass_scalar(off, l, nlist, unit_shift, bits, x);
-}
-#endif
-inline LengthsPass lengths_pass(const uint64_t *off, uint64_t nlist, uint32_t unit_shift, uint32_t bits) {
-    LengthsPass x;
-#ifdef VIDC_X86_HOST_COMMON
-    static const bool avx2 = __builtin_cpu_supports("avx2") && !std::getenv("VIDC_NO_AVX2");
-    if (avx2) { lengths_pass_avx2(off, nlist, unit_shift, bits, x); return x; }
-#endif
-    lengths_pass_scalar(off, 0, nlist, unit_shift, bits, x);
-    return x;
-}
 
 // Emptied std::vectors kept with their capacity (process-wide, bounded): the host arrays of a 10^6-list object are 4-8 MB each, beyond
 // the allocator's mmap threshold, so every encode call page-faulted ~50 MB in and every destroyed object unmapped it again (S2: 2 ms per
