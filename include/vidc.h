@@ -78,6 +78,10 @@ int vidc_dev_alloc(vidc_ctx *ctx, size_t bytes, void **dev_ptr);
 int vidc_dev_free(vidc_ctx *ctx, void *dev_ptr);
 int vidc_copy_h2d(vidc_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
 int vidc_copy_d2h(vidc_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+/* Bytes of id payload this context has copied device -> host so far (vidc_copy_d2h, the *_get selects, *_decode_gather):
+ * what a deferred search costs on PCIe -- 8 bytes per result through *_decode_gather, whole lists through
+ * *_decode_lists + vidc_copy_d2h.  Metadata read-backs (sizes, status words, list_info) are not counted. */
+uint64_t vidc_ctx_d2h_bytes(const vidc_ctx *ctx);
 
 /* ------------------------------------------------------- ROC (bits-back ANS) */
 /* Replaces: ANSState (codec.h:13-45), compress/decompress (codec.cpp:123-152),
@@ -130,6 +134,13 @@ int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out);
 /* Decode m selected lists back to back into d_out; out_offsets (host, m+1) receives the packing. */
 int vidc_roc_decode_lists(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *list_nos,
                           uint64_t *d_out, uint64_t *out_offsets);
+/* The decode section of the deferred search in ONE call (custom_invlists_impl.cpp:508-525: `ids = get_ids(list_no)` per touched
+ * list, then `labels[r] = ids[lo_offset(labels[r])]`): the m touched lists are decoded into device staging owned by the
+ * context, the n_items requested ids are picked ON THE DEVICE (item i = list_nos[item_slot[i]][item_off[i]]) and only those
+ * cross PCIe: 8 * n_items bytes into ids_out (host int64[n_items]).  Items outside their list -> VIDC_ERR_INVALID.
+ * Same signature for the four containers (vidc_ef_decode_gather, vidc_packed_decode_gather, vidc_wt_decode_gather). */
+int vidc_roc_decode_gather(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *list_nos, uint64_t n_items,
+                           const uint64_t *item_slot, const uint64_t *item_off, int64_t *ids_out);
 /* Graph flavour: d_out device int32[m*K]; rows padded with -1; counts (host, m, may be NULL) = num edges.
  * nodes == NULL selects nodes 0..m-1 (no index array is built or uploaded). */
 int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *nodes, uint32_t K,
@@ -153,6 +164,9 @@ int vidc_packed_decode_all(vidc_ctx *ctx, const vidc_packed *p, uint64_t *d_out)
  * out_offsets: host uint64[m + 1] */
 int vidc_packed_decode_lists(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, const uint64_t *list_nos, uint64_t *d_out,
                              uint64_t *out_offsets);
+/* decode of the touched lists + device-side pick of the n_items requested ids (see vidc_roc_decode_gather) */
+int vidc_packed_decode_gather(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, const uint64_t *list_nos, uint64_t n_items,
+                              const uint64_t *item_slot, const uint64_t *item_off, int64_t *ids_out);
 /* m random accesses (get_single_id, :108-113): host arrays of list numbers / offsets -> host ids */
 int vidc_packed_get(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, const uint64_t *list_nos,
                     const uint64_t *offs, int64_t *ids_out);
@@ -204,6 +218,9 @@ int vidc_ef_decode_rows(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint6
 /* decode m selected lists back to back (get_ids per touched list, custom_invlists_impl.cpp:508-525) */
 int vidc_ef_decode_lists(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *list_nos, uint64_t *d_out,
                          uint64_t *out_offsets);
+/* decode of the touched lists + device-side pick of the n_items requested ids (see vidc_roc_decode_gather) */
+int vidc_ef_decode_gather(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *list_nos, uint64_t n_items,
+                          const uint64_t *item_slot, const uint64_t *item_off, int64_t *ids_out);
 /* word images of one list's low / high streams (64-bit words, LSB-first) */
 int vidc_ef_export(vidc_ctx *ctx, const vidc_ef *e, uint64_t list_no, uint64_t *low, size_t low_cap,
                    uint64_t *high, size_t high_cap, uint64_t *low_nbits, uint64_t *high_nbits);
@@ -233,6 +250,9 @@ int vidc_wt_decode_all(vidc_ctx *ctx, const vidc_wt *w, uint64_t *d_out);
 /* get_ids of m selected lists back to back (custom_invlists_impl.cpp:381-392 per list); out_offsets: host uint64[m + 1] */
 int vidc_wt_decode_lists(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint64_t *list_nos, uint64_t *d_out,
                          uint64_t *out_offsets);
+/* decode of the touched lists + device-side pick of the n_items requested ids (see vidc_roc_decode_gather) */
+int vidc_wt_decode_gather(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint64_t *list_nos, uint64_t n_items,
+                          const uint64_t *item_slot, const uint64_t *item_off, int64_t *ids_out);
 
 /* ------------------------------------------------------ introspection / timing */
 /* Milliseconds spent inside the kernels of the most recent encode / decode call on this context,

@@ -14,7 +14,8 @@
  *   CompactBitNSGGraph / EliasFanoNSGGraph / ROCNSGGraph          vidc_faiss::CompactBitGraph / EliasFanoGraph / ROCGraph
  *   (altid_impl.cpp:20-165)
  *   search_IVF_defer_id_decoding          (.cpp:407-526)          vidc_faiss::search_IVF_defer_id_decoding: the OpenMP loop
- *                                                                 over touched lists (:508-525) is ONE vidc_*_decode_lists call,
+ *                                                                 over touched lists (:508-525) is ONE vidc_*_decode_gather call
+ *                                                                 (device decode + device-side labels[r] = ids[offset]),
  *                                                                 the OpenMP loop of decode_1by1 (:464-474) ONE vidc_*_get call
  *
  * With VIDC_FAISS_REFERENCE_NAMES defined before the include, the reference's own class names exist at global scope
@@ -167,6 +168,11 @@ struct CompressedInvertedLists : faiss::ReadOnlyInvertedLists {
     virtual int decode_lists_device(vidc_ctx* ctx, uint64_t m, const uint64_t* list_nos, uint64_t* d_out,
                                     uint64_t* out_off) const = 0;
 
+    /* the decode section of the deferred search in ONE library call (vidc_*_decode_gather): the m touched lists are decoded into
+     * device staging owned by the context, the n_items requested ids are picked on the device, 8 * n_items bytes come back */
+    virtual int decode_gather_device(vidc_ctx* ctx, uint64_t m, const uint64_t* list_nos, uint64_t n_items, const uint64_t* item_slot,
+                                     const uint64_t* item_off, int64_t* ids_out) const = 0;
+
     /* get_ids: new idx_t[list_size], nullptr for an empty list (:212-214,294-296) */
     const faiss::idx_t* get_ids(size_t l) const override {
         size_t n = list_size(l);
@@ -194,23 +200,33 @@ struct CompressedInvertedLists : faiss::ReadOnlyInvertedLists {
         VIDC_FAISS_CHECK(decode_lists_device(t.ctx(), m, list_nos, d, out_off.data()));
         VIDC_FAISS_CHECK(vidc_copy_d2h(t.ctx(), ids.data(), d, total * 8));
     }
+    /* ids_out[i] = list_nos[item_slot[i]][item_off[i]] for n_items results over m touched lists (labels[r] = ids[offset],
+     * custom_invlists_impl.cpp:517-523): device decode + device-side pick, only the results cross PCIe */
+    void gather_ids_host(uint64_t m, const uint64_t* list_nos, uint64_t n_items, const uint64_t* item_slot, const uint64_t* item_off,
+                         faiss::idx_t* ids_out) const {
+        if (!n_items) return;
+        ThreadCtx& t = thread_ctx();
+        t.device_calls++;
+        VIDC_FAISS_CHECK(decode_gather_device(t.ctx(), m, list_nos, n_items, item_slot, item_off, (int64_t*)ids_out));
+    }
     /* m random accesses ids_out[i] = get_single_id(list_nos[i], offs[i]) in ONE library call (the OpenMP loop of
      * decode_1by1, custom_invlists_impl.cpp:464-474).  Containers with a select (Elias-Fano, packed bits, wavelet tree)
      * override it with their vidc_*_get; the default -- ROC, whose get_single_id IS get_ids()[offset] in the reference
-     * (faiss::InvertedLists::get_single_id) -- decodes the touched lists once and indexes them. */
+     * (faiss::InvertedLists::get_single_id) -- decodes the touched lists once and indexes them ON THE DEVICE. */
     virtual void get_single_ids(uint64_t m, const uint64_t* list_nos, const uint64_t* offs, faiss::idx_t* ids_out) const {
         /* (scratch of the calling thread, reused from call to call) */
         thread_local std::unordered_map<uint64_t, size_t> slot;
-        thread_local std::vector<uint64_t> lists, out_off;
-        thread_local std::vector<faiss::idx_t> ids;
+        thread_local std::vector<uint64_t> lists, item_slot;
         slot.clear();
         lists.clear();
+        item_slot.resize(m);
         for (uint64_t i = 0; i < m; i++) {
             FAISS_THROW_IF_NOT_MSG(list_nos[i] < nlist && offs[i] < list_size(list_nos[i]), "get_single_ids: (list, offset) out of range");
-            if (slot.emplace(list_nos[i], lists.size()).second) lists.push_back(list_nos[i]);
+            auto it = slot.emplace(list_nos[i], lists.size());
+            if (it.second) lists.push_back(list_nos[i]);
+            item_slot[i] = it.first->second;
         }
-        decode_lists_host(lists.size(), lists.data(), ids, out_off);
-        for (uint64_t i = 0; i < m; i++) ids_out[i] = ids[out_off[slot[list_nos[i]]] + offs[i]];
+        gather_ids_host(lists.size(), lists.data(), m, item_slot.data(), offs, ids_out);
     }
 };
 
@@ -239,6 +255,10 @@ struct ROCInvertedLists : CompressedInvertedLists {
     int decode_lists_device(vidc_ctx* ctx, uint64_t m, const uint64_t* ln, uint64_t* d_out, uint64_t* off) const override {
         return vidc_roc_decode_lists(ctx, roc, m, ln, d_out, off);
     }
+    int decode_gather_device(vidc_ctx* ctx, uint64_t m, const uint64_t* ln, uint64_t n_items, const uint64_t* slot, const uint64_t* off,
+                             int64_t* out) const override {
+        return vidc_roc_decode_gather(ctx, roc, m, ln, n_items, slot, off, out);
+    }
     /* get_single_id is not overridden in the reference: InvertedLists::get_single_id = get_ids()[offset] */
 };
 
@@ -261,6 +281,10 @@ struct EliasFanoInvertedLists : CompressedInvertedLists {
     ~EliasFanoInvertedLists() override { vidc_ef_destroy(ef); }
     int decode_lists_device(vidc_ctx* ctx, uint64_t m, const uint64_t* ln, uint64_t* d_out, uint64_t* off) const override {
         return vidc_ef_decode_lists(ctx, ef, m, ln, d_out, off);
+    }
+    int decode_gather_device(vidc_ctx* ctx, uint64_t m, const uint64_t* ln, uint64_t n_items, const uint64_t* slot, const uint64_t* off,
+                             int64_t* out) const override {
+        return vidc_ef_decode_gather(ctx, ef, m, ln, n_items, slot, off, out);
     }
     faiss::idx_t get_single_id(size_t l, size_t offset) const override { /* ef->select(offset), :314-318 */
         uint64_t ln = l, of = offset;
@@ -292,6 +316,10 @@ struct PackedBitsInvertedLists : CompressedInvertedLists {
     int decode_lists_device(vidc_ctx* ctx, uint64_t m, const uint64_t* ln, uint64_t* d_out, uint64_t* off) const override {
         return vidc_packed_decode_lists(ctx, pk, m, ln, d_out, off);
     }
+    int decode_gather_device(vidc_ctx* ctx, uint64_t m, const uint64_t* ln, uint64_t n_items, const uint64_t* slot, const uint64_t* off,
+                             int64_t* out) const override {
+        return vidc_packed_decode_gather(ctx, pk, m, ln, n_items, slot, off, out);
+    }
     faiss::idx_t get_single_id(size_t l, size_t offset) const override { /* :108-113 */
         uint64_t ln = l, of = offset;
         int64_t id = -1;
@@ -320,6 +348,10 @@ struct WaveletTreeInvertedLists : CompressedInvertedLists {
     ~WaveletTreeInvertedLists() override { vidc_wt_destroy(wt); }
     int decode_lists_device(vidc_ctx* ctx, uint64_t m, const uint64_t* ln, uint64_t* d_out, uint64_t* off) const override {
         return vidc_wt_decode_lists(ctx, wt, m, ln, d_out, off);
+    }
+    int decode_gather_device(vidc_ctx* ctx, uint64_t m, const uint64_t* ln, uint64_t n_items, const uint64_t* slot, const uint64_t* off,
+                             int64_t* out) const override {
+        return vidc_wt_decode_gather(ctx, wt, m, ln, n_items, slot, off, out);
     }
     faiss::idx_t get_single_id(size_t l, size_t offset) const override { /* wt.select(offset + 1, list_no), :377-379 */
         uint64_t ln = l, of = offset;
@@ -390,11 +422,19 @@ inline void search_IVF_defer_id_decoding(const faiss::IndexIVF& index, faiss::id
         if (labels[i] >= 0 && slot.emplace(faiss::lo_listno(labels[i]), lists.size()).second)
             lists.push_back((uint64_t)faiss::lo_listno(labels[i]));
     if (auto* comp = dynamic_cast<const CompressedInvertedLists*>(invlists)) {
-        std::vector<idx_t> ids;
-        std::vector<uint64_t> out_off;
-        comp->decode_lists_host(lists.size(), lists.data(), ids, out_off); /* ONE decode call (:508-525) */
+        /* ONE library call (:508-525): the touched lists are decoded on the device, labels[r] = ids[offset] is a device-side
+         * gather, and 8 bytes per valid result cross PCIe instead of every touched list */
+        std::vector<uint64_t> item_slot, item_off;
+        std::vector<idx_t> where, got;
         for (idx_t i = 0; i < n * k; i++)
-            if (labels[i] >= 0) labels[i] = ids[out_off[slot[faiss::lo_listno(labels[i])]] + faiss::lo_offset(labels[i])];
+            if (labels[i] >= 0) {
+                item_slot.push_back(slot[faiss::lo_listno(labels[i])]);
+                item_off.push_back((uint64_t)faiss::lo_offset(labels[i]));
+                where.push_back(i);
+            }
+        got.resize(where.size());
+        comp->gather_ids_host(lists.size(), lists.data(), where.size(), item_slot.data(), item_off.data(), got.data());
+        for (size_t j = 0; j < where.size(); j++) labels[where[j]] = got[j];
         return;
     }
     for (idx_t i = 0; i < n * k; i++) { /* foreign container: one get_ids per touched list like the reference */

@@ -54,8 +54,14 @@ static int check_container(faiss::IndexIVF& index, const faiss::ArrayInvertedLis
     for (int one_by_one = 0; one_by_one < 2; one_by_one++) {  // test_compressed_ivfs.py:128-156
         std::fill(I.begin(), I.end(), -7);
         const size_t calls0 = vidc_faiss::thread_ctx().device_calls;
+        const uint64_t d2h0 = vidc_ctx_d2h_bytes(vidc_faiss::thread_ctx().ctx());
         vidc_faiss::search_IVF_defer_id_decoding(index, nq, xq.data(), k, D.data(), I.data(), one_by_one != 0);
         REQUIRE(I == Iref && D == Dref);
+        // the scatter labels[r] = ids[offset] runs on the device; what crosses PCIe is 8 bytes per valid result
+        // (every touched list came down before: custom_invlists_impl.cpp:508-525 restated with whole-list copies)
+        size_t valid = 0;
+        for (idx_t v : Iref) valid += v >= 0;
+        REQUIRE(vidc_ctx_d2h_bytes(vidc_faiss::thread_ctx().ctx()) - d2h0 == 8 * valid);
         // the n * k selects of decode_1by1 (custom_invlists_impl.cpp:464-474) and the touched lists of the batched form are ONE
         // library call each, not one launch per result
         REQUIRE(vidc_faiss::thread_ctx().device_calls - calls0 <= 1);

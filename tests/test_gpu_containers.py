@@ -591,3 +591,43 @@ def test_bench_gpus_flag_launches_the_ranks_itself(tmp_path):
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["verified_roundtrip"] is True
     assert d["config"]["ids_per_gpu"] == 1_000_000
+
+
+@pytest.mark.parametrize("which", range(5))
+def test_decode_gather_is_decode_lists_plus_indexing_and_copies_only_the_results(which):
+    """SURVEY 8(f)-1 / custom_invlists_impl.cpp:508-525: `ids = get_ids(list)` per touched list + `labels[r] = ids[offset]` as ONE
+    library call with the scatter on the device.  Same ids as decode_lists + host indexing; 8 bytes per result cross PCIe;
+    items outside their list, slots outside the request and list numbers outside the object are errors."""
+    from vector_db_id_compression_amd import VidcError
+    from vector_db_id_compression_amd.ivf import IVFIndex
+
+    xt, xb, _ = _dataset(8, 2000, 30000, 1, seed=3)
+    index = IVFIndex(8, 64, "Flat")
+    index.train(xt)
+    index.add(xb)
+    comp = _classes()[which](index.invlists)
+    rng = np.random.default_rng(which)
+    sizes = np.array([comp.list_size(l) for l in range(64)])
+    touched = rng.permutation(np.nonzero(sizes)[0])[:23].astype(np.uint64)  # an arbitrary order, not ascending
+    n_items = 5000
+    slot = rng.integers(0, touched.size, n_items).astype(np.uint64)
+    off = (rng.random(n_items) * sizes[touched.astype(np.int64)][slot.astype(np.int64)]).astype(np.uint64)
+    ids, out_off = comp.decode_lists(touched)
+    want = ids.cpu().numpy()[out_off[slot.astype(np.int64)].astype(np.int64) + off.astype(np.int64)]
+    ctx = comp._c.ctx
+    before = ctx.d2h_bytes()
+    got = comp.decode_gather(touched, slot, off)
+    assert ctx.d2h_bytes() - before == 8 * n_items
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(comp.get_single_ids(touched[slot.astype(np.int64)], off), want)
+    assert comp.decode_gather(touched, [], []).size == 0
+    bad_off = off.copy()
+    bad_off[17] = sizes[int(touched[int(slot[17])])]
+    with pytest.raises(VidcError):
+        comp.decode_gather(touched, slot, bad_off)
+    bad_slot = slot.copy()
+    bad_slot[3] = touched.size
+    with pytest.raises(VidcError):
+        comp.decode_gather(touched, bad_slot, off)
+    with pytest.raises(VidcError):
+        comp.decode_gather(np.array([64], np.uint64), [0], [0])

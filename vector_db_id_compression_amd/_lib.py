@@ -50,6 +50,7 @@ def _declare(lib):
     f("vidc_dev_free", C.c_int, _vp, _vp)
     f("vidc_copy_h2d", C.c_int, _vp, _vp, _vp, C.c_size_t)
     f("vidc_copy_d2h", C.c_int, _vp, _vp, _vp, C.c_size_t)
+    f("vidc_ctx_d2h_bytes", _u64, _vp)
     f("vidc_ctx_last_kernel_ms", C.c_double, _vp)
     f("vidc_ctx_phase_ms", C.c_double, _vp, C.c_int)
     f("vidc_ctx_chain_info", C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp)
@@ -69,6 +70,7 @@ def _declare(lib):
     f("vidc_roc_import", C.c_int, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _P(_vp))
     f("vidc_roc_decode_all", C.c_int, _vp, _vp, _vp)
     f("vidc_roc_decode_lists", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
+    f("vidc_roc_decode_gather", C.c_int, _vp, _vp, _u64, _vp, _u64, _vp, _vp, _vp)
     f("vidc_roc_decode_rows", C.c_int, _vp, _vp, _u64, _vp, _u32, _vp, _vp)
     f("vidc_roc_last_decode_nonclean", _u64, _vp)
     # packed bits
@@ -79,6 +81,7 @@ def _declare(lib):
     f("vidc_packed_bits", C.c_int, _vp)
     f("vidc_packed_decode_all", C.c_int, _vp, _vp, _vp)
     f("vidc_packed_decode_lists", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
+    f("vidc_packed_decode_gather", C.c_int, _vp, _vp, _u64, _vp, _u64, _vp, _vp, _vp)
     f("vidc_packed_get", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
     f("vidc_packed_export", C.c_int, _vp, _vp, _u64, _vp, C.c_size_t)
     f("vidc_packed_total_words", _u64, _vp)
@@ -99,6 +102,7 @@ def _declare(lib):
     f("vidc_ef_encode_rows", C.c_int, _vp, _u64, _u32, _vp, _P(_vp))
     f("vidc_ef_decode_rows", C.c_int, _vp, _vp, _u64, _vp, _u32, _vp, _vp)
     f("vidc_ef_decode_lists", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
+    f("vidc_ef_decode_gather", C.c_int, _vp, _vp, _u64, _vp, _u64, _vp, _vp, _vp)
     # compact graph rows
     f("vidc_compact_rows_encode", C.c_int, _vp, _u64, _u32, _vp, _P(_vp))
     f("vidc_compact_destroy", None, _vp)
@@ -115,26 +119,27 @@ def _declare(lib):
     f("vidc_wt_select", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
     f("vidc_wt_decode_all", C.c_int, _vp, _vp, _vp)
     f("vidc_wt_decode_lists", C.c_int, _vp, _vp, _u64, _vp, _vp, _vp)
+    f("vidc_wt_decode_gather", C.c_int, _vp, _vp, _u64, _vp, _u64, _vp, _vp, _vp)
 
 
 #: every symbol include/vidc.h declares (checked by the CPU test-suite against the built library)
 EXPORTED_SYMBOLS = [
     "vidc_last_error", "vidc_version", "vidc_ctx_create", "vidc_ctx_destroy", "vidc_ctx_set_stream", "vidc_ctx_reset_stream",
-    "vidc_ctx_synchronize", "vidc_ctx_trim", "vidc_ctx_class_streams", "vidc_dev_alloc", "vidc_dev_free", "vidc_copy_h2d", "vidc_copy_d2h",
+    "vidc_ctx_synchronize", "vidc_ctx_trim", "vidc_ctx_class_streams", "vidc_dev_alloc", "vidc_dev_free", "vidc_copy_h2d", "vidc_copy_d2h", "vidc_ctx_d2h_bytes",
     "vidc_ctx_last_kernel_ms", "vidc_ctx_phase_ms", "vidc_ctx_chain_info",
     "vidc_roc_encode", "vidc_roc_encode_rows", "vidc_roc_destroy", "vidc_roc_nlist", "vidc_roc_ntotal",
     "vidc_roc_compressed_bytes", "vidc_roc_total_words", "vidc_roc_list_info", "vidc_roc_export_words", "vidc_roc_export_all_words",
-    "vidc_roc_perm", "vidc_roc_perm_dev", "vidc_roc_import", "vidc_roc_decode_all", "vidc_roc_decode_lists",
+    "vidc_roc_perm", "vidc_roc_perm_dev", "vidc_roc_import", "vidc_roc_decode_all", "vidc_roc_decode_lists", "vidc_roc_decode_gather",
     "vidc_roc_decode_rows", "vidc_roc_last_decode_nonclean",
     "vidc_packed_bits_for", "vidc_packed_encode", "vidc_packed_destroy", "vidc_packed_compressed_bytes",
-    "vidc_packed_bits", "vidc_packed_decode_all", "vidc_packed_decode_lists", "vidc_packed_get", "vidc_packed_export", "vidc_packed_total_words", "vidc_packed_export_all", "vidc_packed_import",
+    "vidc_packed_bits", "vidc_packed_decode_all", "vidc_packed_decode_lists", "vidc_packed_decode_gather", "vidc_packed_get", "vidc_packed_export", "vidc_packed_total_words", "vidc_packed_export_all", "vidc_packed_import",
     "vidc_ef_encode", "vidc_ef_destroy", "vidc_ef_compressed_bytes", "vidc_ef_list_info", "vidc_ef_decode_all",
     "vidc_ef_get", "vidc_ef_perm", "vidc_ef_export", "vidc_ef_stream_words", "vidc_ef_export_all", "vidc_ef_import",
-    "vidc_ef_encode_rows", "vidc_ef_decode_rows", "vidc_ef_decode_lists",
+    "vidc_ef_encode_rows", "vidc_ef_decode_rows", "vidc_ef_decode_lists", "vidc_ef_decode_gather",
     "vidc_compact_rows_encode", "vidc_compact_destroy", "vidc_compact_bits", "vidc_compact_stride",
     "vidc_compact_size_in_bytes", "vidc_compact_rows_decode", "vidc_compact_export_row",
     "vidc_wt_build", "vidc_wt_destroy", "vidc_wt_size_in_bytes", "vidc_wt_levels", "vidc_wt_select",
-    "vidc_wt_decode_all", "vidc_wt_decode_lists",
+    "vidc_wt_decode_all", "vidc_wt_decode_lists", "vidc_wt_decode_gather",
 ]
 
 
@@ -205,6 +210,10 @@ class Context:
     def class_streams(self):
         """Streams the kernel classes of a large ROC call are spread over: 8 if the process started with GPU_MAX_HW_QUEUES >= 8, else 4."""
         return int(lib().vidc_ctx_class_streams(self.h))
+
+    def d2h_bytes(self):
+        """Id payload this context has copied device -> host so far (vidc_ctx_d2h_bytes)."""
+        return int(lib().vidc_ctx_d2h_bytes(self.h))
 
     def last_kernel_ms(self):
         return float(lib().vidc_ctx_last_kernel_ms(self.h))

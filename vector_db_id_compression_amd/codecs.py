@@ -35,6 +35,19 @@ def _dev_ids(ids, ntotal):
     return ids
 
 
+
+def _decode_gather(fn, obj, list_nos, item_slot, item_off):
+    """vidc_*_decode_gather: decode the touched lists on the device, pick the requested ids there, copy 8 bytes per item
+    (the decode section of the deferred search, custom_invlists_impl.cpp:508-525) -> numpy int64[n_items]."""
+    ln = np.ascontiguousarray(list_nos, dtype=np.uint64)
+    sl = np.ascontiguousarray(item_slot, dtype=np.uint64)
+    of = np.ascontiguousarray(item_off, dtype=np.uint64)
+    assert sl.size == of.size
+    out = np.zeros(max(sl.size, 1), np.int64)
+    check(fn(obj.ctx.h, obj.h, ln.size, ptr(ln), sl.size, ptr(sl), ptr(of), ptr(out)))
+    return out[: sl.size]
+
+
 class RocLists:
     """ROC-compressed lists (vidc_roc): bit-identical streams to codec.cpp."""
 
@@ -182,6 +195,11 @@ class RocLists:
         check(lib().vidc_roc_decode_lists(self.ctx.h, self.h, ln.size, ptr(ln), ptr(out), ptr(out_off)))
         return out[:total], out_off
 
+    def decode_gather(self, list_nos, item_slot, item_off):
+        """ids[i] = list_nos[item_slot[i]][item_off[i]]: the touched lists decoded and the results picked on the device,
+        8 bytes per result copied to the host (vidc_roc_decode_gather)."""
+        return _decode_gather(lib().vidc_roc_decode_gather, self, list_nos, item_slot, item_off)
+
     def decode_rows(self, nodes, K=None, want_counts=True):
         """-> (int32 [m, K] CUDA tensor, -1 padded; edge counts or None).  `want_counts=False` keeps the per-node
         edge counts on the device (no metadata crosses PCIe)."""
@@ -263,6 +281,11 @@ class PackedLists:
         out_off = np.zeros(ln.size + 1, np.uint64)
         check(lib().vidc_packed_decode_lists(self.ctx.h, self.h, ln.size, ptr(ln), ptr(out), ptr(out_off)))
         return out[:total], out_off
+
+    def decode_gather(self, list_nos, item_slot, item_off):
+        """ids[i] = list_nos[item_slot[i]][item_off[i]]: the touched lists decoded and the results picked on the device,
+        8 bytes per result copied to the host (vidc_packed_decode_gather)."""
+        return _decode_gather(lib().vidc_packed_decode_gather, self, list_nos, item_slot, item_off)
 
     def get(self, list_nos, offs):
         ln = np.ascontiguousarray(list_nos, dtype=np.uint64)
@@ -410,6 +433,11 @@ class EfLists:
         check(lib().vidc_ef_decode_lists(self.ctx.h, self.h, ln.size, ptr(ln), ptr(out), ptr(out_off)))
         return out[:total], out_off
 
+    def decode_gather(self, list_nos, item_slot, item_off):
+        """ids[i] = list_nos[item_slot[i]][item_off[i]]: the touched lists decoded and the results picked on the device,
+        8 bytes per result copied to the host (vidc_ef_decode_gather)."""
+        return _decode_gather(lib().vidc_ef_decode_gather, self, list_nos, item_slot, item_off)
+
     # -- flat on-disk / wire image (the reference keeps compressed lists in memory only, SURVEY 5)
     def save(self, path):
         lw, hw = C.c_uint64(), C.c_uint64()
@@ -554,6 +582,11 @@ class WaveletTreeLists:
         out_off = np.zeros(ln.size + 1, np.uint64)
         check(lib().vidc_wt_decode_lists(self.ctx.h, self.h, ln.size, ptr(ln), ptr(out), ptr(out_off)))
         return out[:total], out_off
+
+    def decode_gather(self, list_nos, item_slot, item_off):
+        """ids[i] = list_nos[item_slot[i]][item_off[i]]: the touched lists decoded and the results picked on the device,
+        8 bytes per result copied to the host (vidc_wt_decode_gather)."""
+        return _decode_gather(lib().vidc_wt_decode_gather, self, list_nos, item_slot, item_off)
 
     def select(self, list_nos, offs):
         ln = np.ascontiguousarray(list_nos, dtype=np.uint64)

@@ -215,6 +215,12 @@ struct Pinned {
     T *as() const { return (T *)p; }
 };
 
+// The device-side scatter of the deferred search (custom_invlists_impl.cpp:508-525: labels[r] = ids[offset]): d_ids holds m decoded
+// lists back to back (list_off[m + 1], host), item i names (slot in the request, offset in that list); the n_items ids are
+// picked on the device and ONLY they cross PCIe (8 * n_items bytes into host_out).  Bounds-checked on the host.
+int gather_to_host(::vidc_ctx *c, const uint64_t *d_ids, const uint64_t *list_off, uint64_t m, uint64_t n_items,
+                   const uint64_t *item_slot, const uint64_t *item_off, int64_t *host_out);
+
 }  // namespace vidc
 
 // mt19937(1234) words available to the kernels for ANS stack underflow (codec.h:16-18,32-40).
@@ -267,7 +273,30 @@ struct vidc_ctx {
     double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // see VIDC_PHASE_* in vidc.h
     // what the chain launch of the last ROC encode [0] / decode [1] held: ids, lists, longest list, universe bits (0 = none)
     uint64_t chain_info[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    // id payload copied device -> host through this context (vidc_copy_d2h, *_get, *_decode_gather): see vidc_ctx_d2h_bytes
+    uint64_t d2h_bytes = 0;
 };
+
+// vidc_*_decode_gather (include/vidc.h): decode the m touched lists into staging from the context's block cache, pick the
+// requested ids on the device, copy 8 * n_items bytes.  size_of(list) = ids of a list, decode(d_out, list_off) = the codec's
+// own decode_lists.
+template <typename SizeOf, typename Decode>
+inline int vidc_decode_gather_impl(vidc_ctx *ctx, uint64_t nlist, uint64_t m, const uint64_t *list_nos, uint64_t n_items,
+                                   const uint64_t *item_slot, const uint64_t *item_off, int64_t *ids_out, SizeOf &&size_of,
+                                   Decode &&decode) {
+    if (!n_items) return VIDC_OK;
+    if (!m || !list_nos || !item_slot || !item_off || !ids_out) return VIDC_ERR_INVALID;
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < m; i++) {
+        if (list_nos[i] >= nlist) { vidc::set_error("decode_gather: list number %llu out of range", (unsigned long long)list_nos[i]); return VIDC_ERR_INVALID; }
+        total += size_of(list_nos[i]);
+    }
+    vidc::Scratch staging;
+    VIDC_TRY(staging.get(ctx, (total ? total : 1) * 8));
+    std::vector<uint64_t> list_off(m + 1, 0);
+    VIDC_TRY(decode(staging.as<uint64_t>(), list_off.data()));
+    return vidc::gather_to_host(ctx, staging.as<uint64_t>(), list_off.data(), m, n_items, item_slot, item_off, ids_out);
+}
 
 // Kernel time of a call made of several phases: every phase is bracketed by an event pair on the context's stream
 // and the elapsed times are summed when the call synchronises anyway (an event synchronisation per phase cost

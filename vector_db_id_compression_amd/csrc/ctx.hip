@@ -113,6 +113,42 @@ void Pinned::release() {
     p = nullptr;
     bytes = 0;
 }
+
+// one thread per requested id: a plain indexed load (the positions are scattered over the decoded lists) and a coalesced store
+__global__ void k_gather_ids(const uint64_t *__restrict__ ids, const uint64_t *__restrict__ pos, uint64_t n, int64_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int64_t)ids[pos[i]];
+}
+
+int gather_to_host(::vidc_ctx *c, const uint64_t *d_ids, const uint64_t *list_off, uint64_t m, uint64_t n_items,
+                   const uint64_t *item_slot, const uint64_t *item_off, int64_t *host_out) {
+    if (!n_items) return VIDC_OK;
+    Pinned h_pos, h_out;
+    VIDC_TRY(h_pos.get(c, n_items * 8));
+    VIDC_TRY(h_out.get(c, n_items * 8));
+    uint64_t *pos = h_pos.as<uint64_t>();
+    for (uint64_t i = 0; i < n_items; i++) {
+        const uint64_t s = item_slot[i];
+        if (s >= m || item_off[i] >= list_off[s + 1] - list_off[s]) {
+            set_error("decode_gather: item %llu names (slot %llu, offset %llu) outside the requested lists", (unsigned long long)i,
+                      (unsigned long long)s, (unsigned long long)item_off[i]);
+            return VIDC_ERR_INVALID;
+        }
+        pos[i] = list_off[s] + item_off[i];
+    }
+    Scratch s_pos, s_out;
+    VIDC_TRY(s_pos.get(c, n_items * 8));
+    VIDC_TRY(s_out.get(c, n_items * 8));
+    VIDC_HIP(hipMemcpyAsync(s_pos.p, pos, n_items * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_gather_ids, dim3((uint32_t)((n_items + 255) / 256)), dim3(256), 0, c->stream, d_ids, s_pos.as<uint64_t>(),
+                       n_items, s_out.as<int64_t>());
+    VIDC_HIP(hipGetLastError());
+    VIDC_HIP(hipMemcpyAsync(h_out.p, s_out.p, n_items * 8, hipMemcpyDeviceToHost, c->stream));
+    VIDC_HIP(vidc_stream_wait(c->stream));
+    std::memcpy(host_out, h_out.p, n_items * 8);
+    c->d2h_bytes += n_items * 8;
+    return VIDC_OK;
+}
 }  // namespace vidc
 
 extern "C" {
@@ -288,9 +324,11 @@ int vidc_copy_d2h(vidc_ctx *c, void *h, const void *d, size_t bytes) {
     if (bytes) {
         VIDC_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
         VIDC_HIP(vidc::vidc_stream_wait(c->stream));
+        c->d2h_bytes += bytes;
     }
     return VIDC_OK;
 }
+uint64_t vidc_ctx_d2h_bytes(const vidc_ctx *c) { return c ? c->d2h_bytes : 0; }
 
 double vidc_ctx_last_kernel_ms(const vidc_ctx *c) { return c ? c->last_kernel_ms : 0.0; }
 int vidc_ctx_chain_info(const vidc_ctx *c, int which, uint64_t *ids, uint64_t *lists, uint64_t *longest, uint32_t *universe_bits) {

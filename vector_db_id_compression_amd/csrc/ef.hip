@@ -1868,6 +1868,15 @@ int vidc_ef_decode_lists(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint
     return ef_decode_some(ctx, e, m, list_nos, out_offsets, d_out, nullptr, 0);
 }
 
+int vidc_ef_decode_gather(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *list_nos, uint64_t n_items,
+                          const uint64_t *item_slot, const uint64_t *item_off, int64_t *ids_out) {
+    if (!ctx || !e) return VIDC_ERR_INVALID;
+    VIDC_TRY(ef_ensure_offsets(e));
+    return vidc_decode_gather_impl(ctx, e->nlist, m, list_nos, n_items, item_slot, item_off, ids_out,
+                                   [&](uint64_t l) { return e->offsets[l + 1] - e->offsets[l]; },
+                                   [&](uint64_t *d, uint64_t *lo) { return vidc_ef_decode_lists(ctx, e, m, list_nos, d, lo); });
+}
+
 int vidc_ef_decode_rows(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *nodes, uint32_t K, int32_t *d_out,
                         uint32_t *counts) {
     if (!ctx || !e || (m && !d_out) || K == 0) return VIDC_ERR_INVALID;
@@ -2016,6 +2025,7 @@ int vidc_ef_get(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *lis
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipMemcpyAsync(ids_out, s_r.p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
+    ctx->d2h_bytes += m * 8;
     return VIDC_OK;
 }
 

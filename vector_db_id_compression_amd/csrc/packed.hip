@@ -673,6 +673,14 @@ int vidc_packed_decode_lists(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, co
     return VIDC_OK;
 }
 
+int vidc_packed_decode_gather(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, const uint64_t *list_nos, uint64_t n_items,
+                              const uint64_t *item_slot, const uint64_t *item_off, int64_t *ids_out) {
+    if (!ctx || !p) return VIDC_ERR_INVALID;
+    return vidc_decode_gather_impl(ctx, p->nlist, m, list_nos, n_items, item_slot, item_off, ids_out,
+                                   [&](uint64_t l) { return p->offsets[l + 1] - p->offsets[l]; },
+                                   [&](uint64_t *d, uint64_t *lo) { return vidc_packed_decode_lists(ctx, p, m, list_nos, d, lo); });
+}
+
 int vidc_packed_get(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, const uint64_t *list_nos, const uint64_t *offs,
                     int64_t *ids_out) {
     if (!ctx || !p || (m && (!list_nos || !offs || !ids_out))) return VIDC_ERR_INVALID;
@@ -695,6 +703,7 @@ int vidc_packed_get(vidc_ctx *ctx, const vidc_packed *p, uint64_t m, const uint6
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipMemcpyAsync(ids_out, s_r.p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
+    ctx->d2h_bytes += m * 8;
     return VIDC_OK;
 }
 

@@ -2350,6 +2350,15 @@ int vidc_roc_decode_lists(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const ui
     return decode_impl(ctx, r, p, out_off.data(), d_out, nullptr, 0);
 }
 
+int vidc_roc_decode_gather(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *list_nos, uint64_t n_items,
+                           const uint64_t *item_slot, const uint64_t *item_off, int64_t *ids_out) {
+    if (!ctx || !r) return VIDC_ERR_INVALID;
+    VIDC_TRY(r->prec.size() == r->nlist ? ensure_offsets(r) : ensure_meta(r));
+    return vidc_decode_gather_impl(ctx, r->nlist, m, list_nos, n_items, item_slot, item_off, ids_out,
+                                   [&](uint64_t l) { return r->offsets[l + 1] - r->offsets[l]; },
+                                   [&](uint64_t *d, uint64_t *lo) { return vidc_roc_decode_lists(ctx, r, m, list_nos, d, lo); });
+}
+
 int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *nodes, uint32_t K,
                          int32_t *d_out, uint32_t *counts) {
     if (!ctx || !r || (m && !d_out)) return VIDC_ERR_INVALID;

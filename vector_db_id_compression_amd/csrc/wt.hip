@@ -789,6 +789,7 @@ int vidc_wt_select(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint64_t *
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipMemcpyAsync(ids_out, s_r.p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
     VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
+    ctx->d2h_bytes += m * 8;
     return VIDC_OK;
 }
 
@@ -824,6 +825,14 @@ int vidc_wt_decode_lists(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->last_kernel_ms = ms;
     return VIDC_OK;
+}
+
+int vidc_wt_decode_gather(vidc_ctx *ctx, const vidc_wt *w, uint64_t m, const uint64_t *list_nos, uint64_t n_items,
+                          const uint64_t *item_slot, const uint64_t *item_off, int64_t *ids_out) {
+    if (!ctx || !w) return VIDC_ERR_INVALID;
+    return vidc_decode_gather_impl(ctx, w->nlist, m, list_nos, n_items, item_slot, item_off, ids_out,
+                                   [&](uint64_t l) { return w->offsets[l + 1] - w->offsets[l]; },
+                                   [&](uint64_t *d, uint64_t *lo) { return vidc_wt_decode_lists(ctx, w, m, list_nos, d, lo); });
 }
 
 int vidc_wt_decode_all(vidc_ctx *ctx, const vidc_wt *w, uint64_t *d_out) {

@@ -84,6 +84,11 @@ class InvertedListsArrayCodes:
         """Every list decoded on the device: int64 CUDA tensor in CSR order."""
         raise NotImplementedError
 
+    def decode_gather(self, list_nos, item_slot, item_off):
+        """The decode section of the deferred search in one library call (custom_invlists_impl.cpp:508-525): ids of the
+        (slot in list_nos, offset) items, picked on the device; numpy int64."""
+        return self._c.decode_gather(np.asarray(list_nos, dtype=np.uint64), item_slot, item_off)
+
 
 class CompressedIDInvertedListsPackedBits(InvertedListsArrayCodes):
     """custom_invlists_impl.cpp:64-118."""
@@ -134,11 +139,10 @@ class CompressedIDInvertedListsFenwickTree(InvertedListsArrayCodes):
 
     def get_single_ids(self, list_nos, offsets):
         # not overridden in the reference: InvertedLists::get_single_id = get_ids()[offset]
+        # (one library call: the touched lists are decoded and indexed on the device, 8 bytes per result come back)
         ln = np.asarray(list_nos, dtype=np.uint64)
         uniq, inv = np.unique(ln, return_inverse=True)
-        ids, off = self._c.decode_lists(uniq)
-        ids = ids.cpu().numpy()
-        return ids[off[inv].astype(np.int64) + np.asarray(offsets, dtype=np.int64)]
+        return self._c.decode_gather(uniq, inv, offsets)
 
 
 class CompressedIDInvertedListsEliasFano(InvertedListsArrayCodes):

@@ -185,7 +185,9 @@ class IVFIndex:
                 I[valid] = [il.get_single_id(int(l), int(o)) for l, o in zip(lists, offs)]
         else:
             uniq, inv = np.unique(lists, return_inverse=True)  # touched lists (:477-502)
-            if hasattr(il, "decode_lists"):  # ONE batched device decode instead of the OpenMP loop (:508-525)
+            if hasattr(il, "decode_gather"):  # ONE library call: batched device decode + device-side scatter (:508-525)
+                I[valid] = il.decode_gather(uniq, inv, offs)
+            elif hasattr(il, "decode_lists"):  # a container with a batched decode only: index on the device with torch
                 ids, out_off = il.decode_lists(uniq)
                 pos = torch.from_numpy((out_off[inv].astype(np.int64) + offs.astype(np.int64))).cuda()
                 I[valid] = ids[pos].cpu().numpy()
