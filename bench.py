@@ -12,7 +12,16 @@ lists partitioned over the ranks by total length (sharding.ShardedInvLists), eve
 then a search-shaped request (nq * nprobe touched lists) is decoded by the owners and gathered on rank 0 over
 RCCL send/recv; the line reports the per-rank time spread and the gather time.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+With `--gpus N > 1` the ONE launch (one process group) answers both multi-GPU questions: the weak aggregate as `value`, and
+`extra.sharded_c5` = the strong-scaling form run right behind it by the same ranks (per-rank codec ms, spread, gather ms and
+bytes); `rccl` names the backend, world size and devices the collectives ran on.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.  The line is kept short
+enough for the driver's log tail (numbers rounded to 5 significant digits, `extra` entries under short keys: `extra_legend`);
+the unabridged measurements go to gpurun_out/bench_detail.json.
+
+`--dry-run` (tests/test_bench_cpu.py, no GPU): the same control flow, process group (gloo) and line assembly with a
+pass-through stand-in for the codec; it prints `"dry_run": true` and `"value": null` -- it measures nothing.
 """
 import argparse
 import json
@@ -31,6 +40,78 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def sig(x, n=5):
+    """Numbers of the printed line rounded to n significant digits (recursively); everything else untouched."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        return float(f"{x:.{n}g}") if np.isfinite(x) else None
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, dict):
+        return {k: sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [sig(v, n) for v in x]
+    return x
+
+
+EXTRA_LEGEND = ("per entry: ids_per_s, ms = wall ms per encode+decode step (median), k_ms = [encode, decode] kernel ms (hipEvents), "
+                "host_ms = ms - sum(k_ms), bits = bits/id, frac = (16+2c) B/id x ids / kernel time / 8 TB/s, frac_wall = the same over "
+                "ms, traffic_x = PMC FETCH+WRITE bytes / algorithmic bytes (profiles/pmc_traffic_*.json), chain_ms = longest list "
+                "alone [encode, decode], ok = per-list round trip of 4 passes")
+
+
+def compact(r2):
+    """A `secondary()` result under short keys (the driver keeps the last ~8000 characters of the line)."""
+    if not isinstance(r2, dict) or "kernel_ms" not in r2:
+        return r2
+    c = {"ids_per_s": r2["ids_per_s"], "ms": r2["ms_per_step"], "k_ms": [r2["kernel_ms"]["encode"], r2["kernel_ms"]["decode"]],
+         "host_ms": r2["host_ms_per_step"], "bits": r2["bits_per_id"], "frac": r2["frac_of_hbm_peak"],
+         "frac_wall": r2["frac_of_hbm_peak_wall"], "nlist": r2["nlist"], "max_list": r2["max_list"], "ok": r2["per_list_roundtrip_ok"]}
+    if r2.get("traffic_over_algorithmic") is not None:
+        c["traffic_x"] = r2["traffic_over_algorithmic"]
+    if "chain_floor" in r2:
+        c["chain_ms"] = [r2["chain_floor"]["encode_ms"], r2["chain_floor"]["decode_ms"]]
+    return c
+
+
+def write_detail(res):
+    """The unabridged measurements next to the printed line (scratch directory of the GPU box; never part of the contract)."""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as f:
+            json.dump(res, f)
+        return "gpurun_out/bench_detail.json"
+    except Exception:
+        return None
+
+
+class DryLists:
+    """`--dry-run` only (tests/test_bench_cpu.py, no GPU): a pass-through stand-in with the codec objects' call shape, so that the
+    bench's control flow, process group and line assembly can be exercised on CPU.  It encodes nothing and the line says so."""
+
+    def __init__(self, offsets, ids):
+        import torch
+
+        self.offsets = np.asarray(offsets, dtype=np.uint64)
+        self.ids = ids if hasattr(ids, "numel") else torch.from_numpy(np.ascontiguousarray(ids).view(np.int64))
+        self.compressed_bytes = 8 * int(self.offsets[-1])
+
+    def decode_all(self, out):
+        out.copy_(self.ids)
+        return out
+
+    def decode_lists(self, list_nos):
+        import torch
+
+        ln = np.asarray(list_nos, dtype=np.int64)
+        a, b = self.offsets[ln].astype(np.int64), self.offsets[ln + 1].astype(np.int64)
+        parts = [self.ids[int(x):int(y)] for x, y in zip(a, b)]
+        off = np.concatenate([[0], np.cumsum(b - a)]).astype(np.uint64)
+        return (torch.cat(parts) if parts else self.ids[:0]), off
 
 
 def cpu_baseline(offsets, ids, budget_s=20.0):
@@ -99,48 +180,60 @@ def per_list_multisets_equal(offsets, got, want, chunk=1 << 27):
     return True
 
 
-def sharded_main(args, ctx, dist, rank, world):
-    """Strong scaling of one index (BASELINE configs[4] shape): shard, encode + decode per rank, search-shaped gather."""
+def sharded_measure(args, ctx, dist, rank, world, steps, warmup, workload="c5", device="cuda"):
+    """Strong scaling of one index (BASELINE configs[4] shape): shard, encode + decode per rank, search-shaped gather.
+    -> the result dict on rank 0, None elsewhere.  `ctx` None = --dry-run (DryLists stands in for the codec, device cpu)."""
     import torch
 
     from vector_db_id_compression_amd import synth
-    from vector_db_id_compression_amd.codecs import RocLists
     from vector_db_id_compression_amd.sharding import ShardedInvLists
 
-    wl = synth.workload(args.workload if args.workload != "s1" else "c5", seed=42)  # the SAME index on every rank
+    wl = synth.workload(workload, seed=42)  # the SAME index on every rank
     offsets, ids_host = wl["offsets"], wl["ids"]
     want_perm = not args.no_perm
+    dry = ctx is None
+    if not dry:
+        from vector_db_id_compression_amd.codecs import RocLists
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     t_sh = time.perf_counter()
-    sh = ShardedInvLists(offsets, ids_host, rank, world, lambda o, i: (o, torch.from_numpy(np.ascontiguousarray(i).view(np.int64)).cuda()),
-                         device="cuda")
+    sh = ShardedInvLists(offsets, ids_host, rank, world,
+                         lambda o, i: (o, torch.from_numpy(np.ascontiguousarray(i).view(np.int64)).to(device)), device=device)
     loc_off, loc_ids = sh.codec  # (the "codec" slot holds the raw shard until the first timed encode)
     t_sh = time.perf_counter() - t_sh
-    out = torch.empty(int(loc_off[-1]), dtype=torch.int64, device="cuda")
+    out = torch.empty(int(loc_off[-1]), dtype=torch.int64, device=device)
     rng = np.random.default_rng(7)
     nq, nprobe = 1000, 16
     req = rng.integers(0, wl["nlist"], size=nq * nprobe).astype(np.int64)  # lists a batch of searches touched
 
     def step():
+        if dry:
+            sh.codec = DryLists(loc_off, loc_ids)
+            sh.codec.decode_all(out)
+            return 0.0, 0.0
         sh.codec = RocLists.encode(loc_off, loc_ids, ctx=ctx, want_perm=want_perm)
         ke = ctx.phase_ms(0) + ctx.phase_ms(1)
         sh.codec.decode_all(out)
         return ke, ctx.phase_ms(2)
 
-    for _ in range(args.warmup):
+    for _ in range(max(warmup, 1)):
         step()
         sh.gather_ids(req, dst=0)
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     k_enc = k_dec = t_codec = t_gather = 0.0
-    for _ in range(args.steps):
+    for _ in range(steps):
         ta = time.perf_counter()
         ke, kd = step()
-        torch.cuda.synchronize()
+        sync()
         tb = time.perf_counter()
         got, goff = sh.gather_ids(req, dst=0)
-        torch.cuda.synchronize()
+        sync()
         tc = time.perf_counter()
         k_enc += ke
         k_dec += kd
@@ -149,45 +242,77 @@ def sharded_main(args, ctx, dist, rank, world):
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    per_rank = torch.tensor([t_codec / args.steps, t_gather / args.steps, float(loc_off[-1]), k_enc / args.steps, k_dec / args.steps],
-                            dtype=torch.float64, device="cuda")
+    per_rank = torch.tensor([t_codec / steps, t_gather / steps, float(loc_off[-1]), k_enc / steps, k_dec / steps],
+                            dtype=torch.float64, device=device)
     allr = [per_rank.clone() for _ in range(world)]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.all_gather(allr, per_rank)
+    if rank != 0:
+        return None
+    # the gathered ids are the decoded lists in request order: check them against the index itself (as sets per list)
+    sizes = (offsets[1:] - offsets[:-1]).astype(np.int64)
+    ok = int(goff[-1]) == int(sizes[req].sum())
+    for i in rng.integers(0, req.size, size=64):
+        l = int(req[i])
+        a = np.sort(got[int(goff[i]):int(goff[i + 1])].cpu().numpy().astype(np.uint64))
+        ok = ok and np.array_equal(a, np.sort(np.asarray(ids_host[int(offsets[l]):int(offsets[l + 1])]).astype(np.uint64)))
+    rows = [x.cpu().numpy() for x in allr]
+    codec_ms = [1e3 * float(x[0]) for x in rows]
+    return {
+        "metric": "IDs encoded+decoded / sec (ROC/ANS, bit-exact vs codec.cpp), one index sharded over the GPUs",
+        "value": None if dry else wl["ntotal"] * steps / elapsed, "unit": "IDs/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": wl["describe"], "codec": "roc", "nlist": wl["nlist"], "max_list": wl["max_list"],
+                   "median_list": wl["median_list"], "container_path": "stream + sampling permutation" if want_perm else "stream only",
+                   "parallelism": f"{wl['nlist']} lists partitioned over {world} GPU(s) by total length (LPT); per step: "
+                                  f"encode + decode of the shard, then the {nq * nprobe} lists of {nq} searches x nprobe {nprobe} "
+                                  f"decoded by their owners and gathered on rank 0 (send/recv)"},
+        "per_rank": {"ids": [int(x[2]) for x in rows], "codec_ms": codec_ms, "gather_ms": [1e3 * float(x[1]) for x in rows],
+                     "kernel_ms_encode": [float(x[3]) for x in rows], "kernel_ms_decode": [float(x[4]) for x in rows],
+                     "codec_ms_spread": max(codec_ms) - min(codec_ms)},
+        "gather_bytes": int(goff[-1]) * 8, "gather_lists": int(req.size),
+        "shard_setup_s": t_sh, "gather_verified": bool(ok),
+    }
+
+
+def rccl_info(dist, world, device):
+    """What the collectives of this launch ran on: backend (nccl = RCCL on ROCm), world size, one device name per rank."""
+    import torch
+
+    name = "cpu" if device == "cpu" else f"{torch.cuda.get_device_name(torch.cuda.current_device())} (cuda:{torch.cuda.current_device()})"
+    names = [name]
+    if dist is not None and world > 1:
+        names = [None] * world
+        dist.all_gather_object(names, name)
+    ver = None
+    if device != "cpu" and dist is not None:
+        try:
+            ver = ".".join(map(str, torch.cuda.nccl.version()))
+        except Exception:
+            ver = None
+    return {"world": dist.get_world_size() if dist is not None else 1, "backend": dist.get_backend() if dist is not None else None,
+            "devices": names, "rccl_version": ver}
+
+
+def sharded_main(args, ctx, dist, rank, world, device="cuda"):
+    """`--sharded`: the strong-scaling form as the printed line."""
+    res = sharded_measure(args, ctx, dist, rank, world, args.steps, args.warmup,
+                          workload=args.workload if args.workload != "s1" else "c5", device=device)
+    info = rccl_info(dist, world, device)
     if rank == 0:
-        # the gathered ids are the decoded lists in request order: check them against the index itself (as sets per list)
-        sizes = (offsets[1:] - offsets[:-1]).astype(np.int64)
-        ok = int(goff[-1]) == int(sizes[req].sum())
-        for i in rng.integers(0, req.size, size=64):
-            l = int(req[i])
-            a = np.sort(got[int(goff[i]):int(goff[i + 1])].cpu().numpy().astype(np.uint64))
-            ok = ok and np.array_equal(a, np.sort(np.asarray(ids_host[int(offsets[l]):int(offsets[l + 1])]).astype(np.uint64)))
-        rows = [x.cpu().numpy() for x in allr]
-        codec_ms = [1e3 * float(x[0]) for x in rows]
-        res = {
-            "metric": "IDs encoded+decoded / sec (ROC/ANS, bit-exact vs codec.cpp), one index sharded over the GPUs",
-            "value": wl["ntotal"] * args.steps / elapsed, "unit": "IDs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": wl["describe"], "codec": "roc", "nlist": wl["nlist"], "max_list": wl["max_list"],
-                       "median_list": wl["median_list"], "container_path": "stream + sampling permutation" if want_perm else "stream only",
-                       "parallelism": f"{wl['nlist']} lists partitioned over {world} GPU(s) by total length (LPT); per step: "
-                                      f"encode + decode of the shard, then the {nq * nprobe} lists of {nq} searches x nprobe {nprobe} "
-                                      f"decoded by their owners and gathered on rank 0 (send/recv, {int(goff[-1]) * 8} bytes)"},
-            "per_rank": {"ids": [int(x[2]) for x in rows], "codec_ms": codec_ms, "gather_ms": [1e3 * float(x[1]) for x in rows],
-                         "kernel_ms_encode": [float(x[3]) for x in rows], "kernel_ms_decode": [float(x[4]) for x in rows],
-                         "codec_ms_spread": max(codec_ms) - min(codec_ms)},
-            "shard_setup_s": t_sh, "gather_verified": bool(ok),
-        }
-        print(json.dumps(res), flush=True)
+        res["rccl"] = info
+        if ctx is None:
+            res["dry_run"] = True
+        print(json.dumps(sig(res)), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
-def launch_ranks(n):
+def launch_ranks(n, dry=False):
     """Re-run this command as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same args>`
     (one rank per GPU, rank r bound to GPU r through LOCAL_RANK, nccl = RCCL).  Fails loudly when the node has fewer GPUs."""
     import socket
@@ -196,7 +321,7 @@ def launch_ranks(n):
     import torch
 
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not dry:
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node")
     with socket.socket() as s:  # a free rendezvous port
         s.bind(("127.0.0.1", 0))
@@ -224,45 +349,69 @@ def main():
     ap.add_argument("--no-s2", action="store_true", help="skip the 1 B-id workload in `extra` (takes ~1 min)")
     ap.add_argument("--sharded", action="store_true", help="strong scaling: one index sharded over the ranks + gather")
     ap.add_argument("--no-perm", action="store_true", help="encode the streams only (no sampling permutation)")
+    ap.add_argument("--no-sharded-extra", action="store_true", help="with --gpus N > 1: skip extra.sharded_c5")
+    ap.add_argument("--sharded-workload", default="c5", help="the ONE index of extra.sharded_c5 (a synth.workload name)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU (tests): gloo, cpu tensors, a pass-through stand-in for the codec; prints value null")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, RCCL), exactly the
         # command the driver would have used; rank 0 of the children prints the JSON line
-        return launch_ranks(args.gpus)
+        return launch_ranks(args.gpus, dry=args.dry_run)
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    dry = args.dry_run
+    device = "cpu" if dry else "cuda"
+    if not dry:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also exercised at world size 1)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from vector_db_id_compression_amd import _lib, synth
-    from vector_db_id_compression_amd.codecs import EfLists, PackedLists, RocLists
+    from vector_db_id_compression_amd import synth
 
-    ctx = _lib.default_context(local_rank)  # bound to torch's current stream
+    if dry:
+        ctx = None
+        RocLists = EfLists = PackedLists = DryLists
+    else:
+        from vector_db_id_compression_amd import _lib
+        from vector_db_id_compression_amd.codecs import EfLists, PackedLists, RocLists
+
+        ctx = _lib.default_context(local_rank)  # bound to torch's current stream
     if args.sharded:
-        return sharded_main(args, ctx, dist, rank, world)
+        return sharded_main(args, ctx, dist, rank, world, device=device)
     want_perm = not args.no_perm
     wl = synth.workload(args.workload, seed=42 + rank)
     offsets = wl["offsets"]
     ids_host = wl["ids"] if isinstance(wl["ids"], np.ndarray) else None
-    d_ids = torch.from_numpy(ids_host.view(np.int64)).cuda() if ids_host is not None else wl["ids"]
+    d_ids = torch.from_numpy(ids_host.view(np.int64)).to(device) if ids_host is not None else wl["ids"]
     ntotal = wl["ntotal"]
-    out = torch.empty(ntotal, dtype=torch.int64, device="cuda")
+    out = torch.empty(ntotal, dtype=torch.int64, device=device)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     chain_ms = [0.0, 0.0]  # hipEvent time of the launch holding the longest chains (encode, decode), summed over steps
 
     def step():
+        if dry:  # (stand-in: nothing is encoded)
+            r = DryLists(offsets, d_ids)
+            r.decode_all(out)
+            return r, 0.0, 0.0
         if args.codec == "roc":
             r = RocLists.encode(offsets, d_ids, ctx=ctx, want_perm=want_perm)
             t_enc = ctx.phase_ms(0) + ctx.phase_ms(1)
@@ -282,7 +431,7 @@ def main():
             t_dec = ctx.last_kernel_ms()
         return r, t_enc, t_dec
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1) if dry else args.warmup):
         r, _, _ = step()
     # correctness gate inside the bench: every list must come back as the same set of ids
     verified = None
@@ -291,7 +440,7 @@ def main():
 
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     chain_ms[0] = chain_ms[1] = 0.0
     t0 = time.perf_counter()
     k_enc = k_dec = 0.0
@@ -299,14 +448,14 @@ def main():
         r, te, td = step()
         k_enc += te
         k_dec += td
-    torch.cuda.synchronize()
+    sync()
     t_own = time.perf_counter()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed_own = t_own - t0  # this rank's K steps, before the closing barrier
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if verified is not None:  # the output of the LAST timed step too (outside the timed region)
@@ -332,8 +481,7 @@ def main():
                 "algorithmic_bytes_per_launch": enc_bytes, "achieved_GBs": enc_bytes / e_ms / 1e6, "frac": enc_bytes / e_ms / 1e6 / HBM_PEAK_GBS,
                 "second": {"name": f"k_roc_decode_u2<{cd['universe_bits']}>", "launch_ms": d_ms, "ids": cd["ids"],
                            "algorithmic_bytes_per_launch": dec_bytes, "achieved_GBs": dec_bytes / d_ms / 1e6 if d_ms else None,
-                           "frac": dec_bytes / d_ms / 1e6 / HBM_PEAK_GBS if d_ms else None},
-                "note": "one wavefront per list: the launch lasts as long as its longest list's chain of dependent codec steps"}
+                           "frac": dec_bytes / d_ms / 1e6 / HBM_PEAK_GBS if d_ms else None}}
         except Exception as e:
             dominant = {"error": str(e)}
 
@@ -412,6 +560,8 @@ def main():
                 # wall clock of a step minus the hipEvent time of its kernels: host planning, launches, synchronisations
                 "host_ms_per_step": 1e3 * t_wall / steps - (ke + kd) / steps,
                 "bits_per_id": 8.0 * c2, "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+                # the same algorithmic bytes over the WALL clock of a step (host planning, launches, waits included)
+                "frac_of_hbm_peak_wall": (16.0 + 2.0 * c2) * w2["ntotal"] / (t_wall / steps) / 1e9 / HBM_PEAK_GBS,
                 "per_list_roundtrip_ok": ok, "passes_checked": 4}
         if traffic_tag:
             alg2 = (16.0 + 2.0 * c2 + (4.0 if (codec == "roc" and want_perm) else 0.0)) * w2["ntotal"]
@@ -461,37 +611,47 @@ def main():
 
     comp_bytes = r.compressed_bytes
     c = comp_bytes / ntotal  # compressed bytes per id
-    # enc 8 B read + c written, dec c read + 8 B written; the container path also writes the 4-byte
-    # position of every sampled id (custom_invlists_impl.cpp:188-193)
-    alg_per_id = 16.0 + 2.0 * c + (4.0 if (want_perm and args.codec == "roc") else 0.0)
+    # enc 8 B read + c written, dec c read + 8 B written = 16 + 2c B/id: that is `roofline.achieved` / `frac`.
+    # The container path also writes the 4-byte position of every sampled id (custom_invlists_impl.cpp:188-193), which 8(d)
+    # does not define: printed beside it as `frac_with_perm`.
+    alg_per_id = 16.0 + 2.0 * c
+    perm_per_id = 4.0 if (want_perm and args.codec == "roc") else 0.0
     alg_bytes = alg_per_id * ntotal
     kern_s = (k_enc + k_dec) / args.steps / 1e3
     achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
+    achieved_perm = (alg_per_id + perm_per_id) * ntotal / kern_s / 1e9 if kern_s > 0 else 0.0
 
     # HBM-side traffic of one step from the PMC counters: collected offline (rocprofv3 cannot wrap its own caller),
     # separate FETCH_SIZE / WRITE_SIZE passes of this very command (tools/pmc_s1.sh -> profiles/pmc_traffic_s1.json)
     traffic = None
-    traffic_note = None
-    if args.codec == "roc" and args.workload == "s1":
-        pt = committed_traffic("s1", alg_bytes)
+    if args.codec == "roc" and args.workload == "s1" and not dry:
+        pt = committed_traffic("s1", (alg_per_id + perm_per_id) * ntotal)
         if pt:
             traffic = pt["traffic"]
-            traffic_note = ("bytes per step, FETCH_SIZE + WRITE_SIZE summed over the ROC kernels of a step (rocprofv3 --pmc, "
-                            "separate passes, raw counters: gfx950 counts wide coalesced reads at half their bytes)")
 
     # per-rank step time (weak scaling): what the ">= 6x at 8 GPUs" target is read from the day a multi-GPU run exists
     per_rank_ms = [1e3 * elapsed_own / args.steps]
     if dist is not None and world > 1:
-        mine = torch.tensor([per_rank_ms[0]], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([per_rank_ms[0]], dtype=torch.float64, device=device)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank_ms = [float(x.item()) for x in allr]
+
+    # one launch answers both multi-GPU questions: behind the weak steps the SAME ranks shard ONE index (strong form)
+    sharded = None
+    if world > 1 and not args.no_sharded_extra and args.codec == "roc":
+        try:
+            sharded = sharded_measure(args, ctx, dist, rank, world, steps=min(args.steps, 5), warmup=1,
+                                      workload=args.sharded_workload, device=device)
+        except Exception as e:  # (every rank takes the same path: a failure here is reported, not fatal for `value`)
+            sharded = {"error": str(e)}
+    info = rccl_info(dist, world, device) if dist is not None else None
 
     if rank == 0:
         res = {
             "metric": "IDs encoded+decoded / sec (ROC/ANS, bit-exact vs codec.cpp)" if args.codec == "roc"
             else f"IDs encoded+decoded / sec ({args.codec})",
-            "value": world * ntotal * args.steps / elapsed,
+            "value": None if dry else world * ntotal * args.steps / elapsed,
             "unit": "IDs/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -512,61 +672,79 @@ def main():
             "host_ms_per_step": 1e3 * elapsed / args.steps - (k_enc + k_dec) / args.steps,
             # every rank's own K steps (max over ranks + the closing barrier = ms_per_step): load balance of the weak form
             "per_rank": {"ms_per_step": per_rank_ms, "spread_ms": max(per_rank_ms) - min(per_rank_ms),
-                         "class_streams": ctx.class_streams()},
+                         "class_streams": ctx.class_streams() if ctx is not None else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
-                         "algorithmic_bytes_per_step": alg_bytes,
-                         "formula": "achieved = algorithmic_bytes_per_id x ids / (encode + compaction + decode kernel time, hipEvents on the "
-                                    "library's streams); algorithmic_bytes_per_id = 16 + 2 c (SURVEY 8d: ids read + written, stream "
-                                    "written + read, c = compressed bytes per id)" + (" + 4 (the sampling permutation the container path writes)"
-                                                                                       if (want_perm and args.codec == "roc") else ""),
-                         "kernels": "k_roc_encode_* + k_roc_compact + k_roc_decode_*" if args.codec == "roc" else args.codec,
-                         "algorithmic_bytes_per_id": alg_per_id},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_over_algorithmic": (traffic / ((alg_per_id + perm_per_id) * ntotal)) if traffic else None,
+                         "algorithmic_bytes_per_id": alg_per_id, "algorithmic_bytes_per_step": alg_bytes,
+                         # the container path's extra 4 B/id (sampling permutation) counted too
+                         "frac_with_perm": achieved_perm / HBM_PEAK_GBS, "algorithmic_bytes_per_id_with_perm": alg_per_id + perm_per_id,
+                         "formula": "(16 + 2c) B/id x ids / (encode + compaction + decode kernel ms, hipEvents); traffic = PMC "
+                                    "FETCH_SIZE + WRITE_SIZE per step (profiles/pmc_traffic_s1.json, separate passes) vs the bytes incl. perm"},
         }
+        if dry:
+            res["dry_run"] = True
+        if info is not None:
+            res["rccl"] = info
+        full = None  # the unabridged secondary measurements (detail file)
         if dominant is not None:
             res["roofline"]["dominant_kernel"] = dominant
-        if world == 1 and not args.no_extra and args.codec == "roc" and args.workload == "s1":
+        if world == 1 and not args.no_extra and args.codec == "roc" and args.workload == "s1" and not dry:
             # other regimes of the same kernels, for context only (never part of `value`): many equal lists
             # (no long serial chain) and the two bandwidth-bound codecs of the same plugin surface
+            full = {}
             try:
-                res["extra"] = {
-                    "roc_many_equal_lists": secondary("uniform_16m", "roc", traffic_tag="uniform_16m_roc"),
-                    "packed_bits": secondary("uniform_16m", "packed"),
-                    "elias_fano": secondary("uniform_16m", "ef"),
-                    "graph_rows": secondary_graph(),
-                    "c5": secondary("c5", "roc", floor=True),
-                    # the size a search issues (S1: 1 M ids / 1024 lists): launch-bound, a few kernels of ~10 us each
-                    "s1_elias_fano": secondary(wl, "ef"),
-                    "s1_packed_bits": secondary(wl, "packed"),
-                }
                 if not args.no_s2:  # BASELINE north_star's roofline workload: 1 B ids on one GPU, through the three codecs
                     torch.cuda.empty_cache()
                     ws2 = synth.workload("s2", seed=1042 + rank)
-                    res["extra"]["s2"] = secondary(ws2, "roc", steps=3, floor=True, traffic_tag="s2_roc")
-                    res["extra"]["s2_elias_fano"] = secondary(ws2, "ef", steps=3, traffic_tag="s2_ef")
-                    res["extra"]["s2_packed_bits"] = secondary(ws2, "packed", steps=3, traffic_tag="s2_packed")
+                    full["s2"] = secondary(ws2, "roc", steps=3, floor=True, traffic_tag="s2_roc")
+                    full["s2_elias_fano"] = secondary(ws2, "ef", steps=3, traffic_tag="s2_ef")
+                    full["s2_packed_bits"] = secondary(ws2, "packed", steps=3, traffic_tag="s2_packed")
                     del ws2
+                    ctx.trim()
+                    torch.cuda.empty_cache()
+                full["roc_many_equal_lists"] = secondary("uniform_16m", "roc", traffic_tag="uniform_16m_roc")
+                full["packed_bits"] = secondary("uniform_16m", "packed")
+                full["elias_fano"] = secondary("uniform_16m", "ef")
+                # the size a search issues (S1: 1 M ids / 1024 lists): launch-bound, a few kernels of ~10 us each
+                full["s1_elias_fano"] = secondary(wl, "ef")
+                full["s1_packed_bits"] = secondary(wl, "packed")
+                full["c5"] = secondary("c5", "roc", floor=True)
+                full["graph_rows"] = secondary_graph()
+                res["extra"] = {k: compact(v) for k, v in full.items()}
+                g = full["graph_rows"]
+                res["extra"]["graph_rows"] = {"workload": g["workload"], **{
+                    n: {"edges_per_s": g[n]["edges_per_s"], "ms": g[n]["ms_per_step"],
+                        "k_ms": [g[n]["kernel_ms"]["encode"], g[n]["kernel_ms"]["decode"]], "bits": g[n]["bits_per_edge"],
+                        "ok": g[n]["edge_count_ok"]} for n in ("roc", "elias_fano")}}
+                res["extra_legend"] = EXTRA_LEGEND
             except Exception as e:
-                res["extra"] = {"error": str(e)}
-        if world == 1 and args.codec == "roc" and not args.no_extra:
+                res["extra"] = {"error": str(e), **{k: compact(v) for k, v in full.items()}}
+        if sharded is not None:
+            res.setdefault("extra", {})["sharded_c5"] = (sharded if "error" in sharded else {
+                "workload": sharded["config"]["workload"], "ids_per_s": sharded["value"], "ms": sharded["ms_per_step"],
+                "steps": sharded["steps"], "per_rank": sharded["per_rank"], "gather_bytes": sharded["gather_bytes"],
+                "gather_lists": sharded["gather_lists"], "gather_verified": sharded["gather_verified"], "scaling": "strong"})
+        if world == 1 and args.codec == "roc" and not args.no_extra and not dry:
             try:
                 cf = chain_floor(wl, d_ids)
                 cf["chain_floor_ms"] = cf["encode_ms"] + cf["decode_ms"]
                 cf["share_of_kernel_time"] = cf["chain_floor_ms"] / (1e3 * kern_s)
                 res["roofline"]["chain_floor"] = cf
-                res["roofline"]["note"] = ("latency bound, not bandwidth bound: the batch cannot finish before its longest list's "
-                                           "chain of dependent codec steps (chain_floor); frac is reported against the HBM peak as "
-                                           "the contract asks")
+                res["roofline"]["note"] = "latency bound: the batch cannot finish before its longest list's chain of dependent codec steps (chain_floor)"
             except Exception as e:
                 res["roofline"]["chain_floor"] = {"error": str(e)}
-        if world == 1 and not args.no_cpu_baseline and args.codec == "roc" and ids_host is not None:
+        if world == 1 and not args.no_cpu_baseline and args.codec == "roc" and ids_host is not None and not dry:
             try:
                 res["cpu_baseline"] = cpu_baseline(offsets, ids_host)
             except Exception as e:  # the checker libraries are optional at bench time
                 res["cpu_baseline"] = {"value": None, "unit": "IDs/s (encode+decode)", "cores": 0, "kind": "port",
                                        "sample": f"unavailable: {e}"}
-        print(json.dumps(res), flush=True)
+        if full:
+            detail = dict(res)
+            detail["extra_full"] = full
+            res["detail"] = write_detail(detail)
+        print(json.dumps(sig(res)), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

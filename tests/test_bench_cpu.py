@@ -84,3 +84,33 @@ def test_child_failure_is_the_parents_exit_code(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 3
+
+
+def test_two_rank_line_carries_the_weak_aggregate_the_sharded_index_and_what_the_collectives_ran_on():
+    """`bench.py --gpus 2` as ONE launch / one process group (here: --dry-run = gloo, cpu tensors, a pass-through stand-in for
+    the codec, `value` null): rank 0's line must carry (i) the weak form with every rank's step time, (ii) `extra.sharded_c5` =
+    ONE index partitioned over the ranks with per-rank codec ms, their spread, gather ms and bytes, the gather verified against
+    the index, (iii) `rccl` = backend, world size, one device per rank.  The day a multi-GPU node exists the same command
+    without --dry-run answers both scaling questions."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1",
+                        "--sharded-workload", "s1"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # one line, from rank 0
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["value"] is None  # a dry run measures nothing and says so
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
+    assert len(d["per_rank"]["ms_per_step"]) == 2 and d["per_rank"]["spread_ms"] >= 0
+    assert d["rccl"] == {"world": 2, "backend": "gloo", "devices": ["cpu", "cpu"], "rccl_version": None}
+    sh = d["extra"]["sharded_c5"]
+    assert sh["scaling"] == "strong" and sh["gather_verified"] is True
+    pr = sh["per_rank"]
+    for key in ("ids", "codec_ms", "gather_ms", "kernel_ms_encode", "kernel_ms_decode"):
+        assert len(pr[key]) == 2, key
+    assert sum(pr["ids"]) == 1_000_000 and abs(pr["ids"][0] - pr["ids"][1]) <= 52114  # LPT: within the longest list
+    assert pr["codec_ms_spread"] >= 0 and sh["gather_lists"] == 16000 and sh["gather_bytes"] > 0
+    assert len(lines[0]) < 7000  # the driver keeps the last ~8000 characters of stdout
