@@ -45,3 +45,35 @@ of = (rng.random(ln.size) * sizes[ln.astype(np.int64)]).astype(np.uint64)
 for name, fn in (("elias-fano", lambda: objs["elias-fano"].get(ln, of)), ("packed-bits", lambda: objs["packed-bits"].get(ln, of)),
                  ("wavelet-tree", lambda: objs["wavelet-tree"].select(ln, of))):
     print(f"single ids   {name:12s} m={ln.size:5d} {timeit(fn):8.3f} ms", flush=True)
+
+# The decode section of a deferred search (custom_invlists_impl.cpp:508-525) on the C3 shape (IVF1024, 1 M vectors): nq = 10^4
+# queries x nprobe 16, k = 20 results each.  "lists to host" = what the adapter did until round 4 (decode the touched lists, copy
+# EVERY touched list over PCIe, index on the host); "device gather" = vidc_*_decode_gather (the scatter labels[r] = ids[offset] on
+# the device, 8 bytes per result over PCIe).
+nq, nprobe, k = 10_000, 16, 20
+probes = rng.choice(off.size - 1, size=(nq, nprobe), replace=True, p=sizes / sizes.sum())
+pick = probes[np.arange(nq)[:, None], rng.integers(0, nprobe, size=(nq, k))]  # the list each result came from
+res_off = (rng.random((nq, k)) * sizes[pick]).astype(np.uint64)
+touched, inv = np.unique(pick.ravel(), return_inverse=True)
+touched = touched.astype(np.uint64)
+slot = inv.astype(np.uint64)
+flat_off = res_off.ravel()
+n_touched_ids = int(sizes[touched.astype(np.int64)].sum())
+print(f"deferred search, decode section: {nq} queries x k {k} = {slot.size} results from {touched.size} touched lists ({n_touched_ids} ids)")
+for name in ("roc", "elias-fano", "packed-bits", "wavelet-tree"):
+    o = objs[name]
+
+    def lists_to_host():
+        ids_d, lo = o.decode_lists(touched)
+        h = ids_d.cpu().numpy()
+        return h[lo[inv].astype(np.int64) + flat_off.astype(np.int64)]
+
+    def device_gather():
+        return o.decode_gather(touched, slot, flat_off)
+
+    a, b = lists_to_host(), device_gather()
+    assert np.array_equal(a, b)
+    d0 = o.ctx.d2h_bytes()
+    device_gather()
+    print(f"  {name:12s} lists to host {timeit(lists_to_host, 10):8.3f} ms ({8 * n_touched_ids} B over PCIe)   device gather "
+          f"{timeit(device_gather, 10):8.3f} ms ({o.ctx.d2h_bytes() - d0} B over PCIe)", flush=True)
