@@ -65,7 +65,9 @@ int vidc_ctx_synchronize(vidc_ctx *ctx);
 /* A context caches the device and pinned-host blocks its calls used (steady-state encode / decode calls neither
  * allocate nor free; a 10^9-id decode leaves several GB of scratch behind).  vidc_ctx_trim synchronises the
  * context's stream and releases every cached block that is not in use; *freed_bytes (optional) = device + pinned
- * bytes returned to the driver.  Blocks held by live objects are untouched. */
+ * bytes returned to the driver.  Blocks held by live objects are untouched.  The process-wide cache of emptied host arrays
+ * (kept so that the next 10^6-list encode does not page-fault ~50 MB in again; bounded at 256 MB per element type) is
+ * released as well. */
 int vidc_ctx_trim(vidc_ctx *ctx, uint64_t *freed_bytes);
 /* Streams the kernel classes of one large ROC call are spread over: 8 when the PROCESS was started with the ROCm runtime
  * variable GPU_MAX_HW_QUEUES >= 8 (HIP multiplexes a process's streams onto that many hardware queues, default 4, and reads

@@ -328,3 +328,59 @@ def test_save_load_roundtrip(tmp_path):
     assert np.array_equal(pk2.get(ql, qo), pk.get(ql, qo))
     for l in (3, 7, 9):
         assert np.array_equal(pk2.export_bytes(l), pk.export_bytes(l))
+
+
+def test_streams_from_dirty_pool_blocks_equal_streams_from_fresh_ones(monkeypatch, tmp_path):
+    """The high stream of an Elias-Fano object up to 64 MB is not cleared before the chunk kernels write it (every high word has ONE
+    owning chunk, empty words included), the encoder writes the decode records, packed bits writes its own padding words, ROC its
+    arenas: all into blocks from the context's pool, which hold whatever an earlier call left there.  VIDC_POOL_POISON=1 fills every
+    block handed out with 0xFF; the word images (Elias-Fano low / high, packed words, ROC stack words) and the decoded ids must be
+    the ones a cleared stream (VIDC_EF_MEMSET=1) / a fresh block gives.  Zipf lists, empty lists, lists whose high stream spans
+    more than a chunk's LDS window, a sparse tail, 64-bit ids."""
+    import torch
+    from vector_db_id_compression_amd import synth
+    from vector_db_id_compression_amd.codecs import EfLists, PackedLists, RocLists
+
+    rng = np.random.default_rng(99)
+    cases = []
+    off, ids = synth.make_lists_numpy(300_000, 700, 0.75, seed=3)
+    cases.append(("zipf", off, ids))
+    sizes = np.concatenate([rng.integers(0, 40, size=5000), [0, 0, 0, 2000, 513, 512, 1]])
+    rng.shuffle(sizes)
+    off2 = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    # few ids over a universe of 2^31 (long runs of empty high words) and a dense run with a far outlier behind it
+    parts = [np.sort(rng.choice(1 << 31, size=int(s), replace=False)).astype(np.uint64) if s != 2000
+             else np.concatenate([np.arange(1999, dtype=np.uint64), [np.uint64((1 << 31) - 5)]]) for s in sizes if s]
+    cases.append(("sparse + empty lists", off2, np.concatenate(parts)))
+    sz3 = np.array([30000, 0, 700, 9], dtype=np.int64)
+    off3 = np.concatenate([[0], np.cumsum(sz3)]).astype(np.uint64)
+    ids3 = np.concatenate([np.sort(rng.choice(1 << 40, size=int(s), replace=False)).astype(np.uint64) for s in sz3 if s])
+    cases.append(("64-bit ids", off3, ids3))
+
+    def images(tag):
+        out = {}
+        for name, o, x in cases:
+            d = torch.from_numpy(x.view(np.int64)).cuda()
+            e = EfLists.encode(o, d)
+            e.save(tmp_path / f"ef_{tag}.npz")
+            z = np.load(tmp_path / f"ef_{tag}.npz")
+            out[name, "ef"] = (z["low"].copy(), z["high"].copy(), e.decode_all().cpu().numpy().copy(), e.compressed_bytes)
+            if int(x.max()) < (1 << 31):
+                p = PackedLists.encode(o, d, bits=32)
+                p.save(tmp_path / f"pk_{tag}.npz")
+                out[name, "packed"] = (np.load(tmp_path / f"pk_{tag}.npz")["words"].copy(), p.decode_all().cpu().numpy().copy())
+                r = RocLists.encode(o, d, want_perm=True)
+                out[name, "roc"] = (r.all_words().copy(), r.info()["heads"].copy(), r.perm().copy(), r.decode_all().cpu().numpy().copy())
+        return out
+
+    monkeypatch.delenv("VIDC_POOL_POISON", raising=False)
+    monkeypatch.setenv("VIDC_EF_MEMSET", "1")
+    clean = images("clean")
+    monkeypatch.delenv("VIDC_EF_MEMSET", raising=False)
+    monkeypatch.setenv("VIDC_POOL_POISON", "1")
+    dirty = images("dirty")
+    dirty2 = images("dirty2")  # (blocks released by the first poisoned pass, poisoned again)
+    assert clean.keys() == dirty.keys()
+    for key in clean:
+        for i, (a, b, c) in enumerate(zip(clean[key], dirty[key], dirty2[key])):
+            assert np.array_equal(a, b) and np.array_equal(a, c), (key, i)

@@ -84,7 +84,7 @@ inline hipError_t vidc_event_wait(hipEvent_t ev) {
 // destroyed ROC object, 1-2 ms spread over the host phases of the next encode).  take(n): an empty vector of capacity >= n.
 template <typename T>
 struct VecPool {
-    static constexpr size_t MIN_BYTES = 1u << 20, MAX_TOTAL = 768u << 20, MAX_COUNT = 96;
+    static constexpr size_t MIN_BYTES = 1u << 20, MAX_TOTAL = 256u << 20, MAX_COUNT = 96;
     std::mutex m;
     std::vector<std::vector<T>> free_;
     size_t bytes = 0;
@@ -95,8 +95,8 @@ struct VecPool {
             for (size_t i = 0; i < free_.size(); i++)
                 if (free_[i].capacity() >= n && (best == free_.size() || free_[i].capacity() < free_[best].capacity())) best = i;
             if (best != free_.size() && free_[best].capacity() <= 2 * n + (MIN_BYTES / sizeof(T))) {
-                std::vector<T> v = std::move(free_[best]);
-                free_[best] = std::move(free_.back());
+                if (best != free_.size() - 1) std::swap(free_[best], free_.back());
+                std::vector<T> v = std::move(free_.back());
                 free_.pop_back();
                 bytes -= v.capacity() * sizeof(T);
                 return v;
@@ -105,6 +105,15 @@ struct VecPool {
         std::vector<T> v;
         v.reserve(n);
         return v;
+    }
+    // release everything that is cached (vidc_ctx_trim): -> bytes returned to the allocator
+    size_t drain() {
+        std::lock_guard<std::mutex> g(m);
+        const size_t b = bytes;
+        free_.clear();
+        free_.shrink_to_fit();
+        bytes = 0;
+        return b;
     }
     void give(std::vector<T> &&v) {
         const size_t b = v.capacity() * sizeof(T);
@@ -137,6 +146,7 @@ struct DevPool {
     int device = 0;
     ~DevPool();
     int get(size_t nbytes, void **p, size_t *bytes);
+    int get_raw(size_t nbytes, void **p, size_t *bytes);
     void put(void *p);
 };
 

@@ -18,7 +18,23 @@ DevPool::~DevPool() {
     for (auto &b : blocks)
         if (b.p) (void)hipFree(b.p);
 }
+// VIDC_POOL_POISON=1 (tests): every block handed out is filled with 0xFF first.  Kernels that own every word they are
+// supposed to write (Elias-Fano high words without a memset, packed-bits padding words, encoder-written decode records, ROC
+// arenas) must produce the same bits from dirty blocks as from fresh ones; stale data from an earlier call is what a pooled
+// block normally holds.
+static int poison(void *p, size_t bytes) {
+    const char *e = std::getenv("VIDC_POOL_POISON");
+    if (!e || e[0] != '1') return VIDC_OK;
+    VIDC_HIP(hipDeviceSynchronize());
+    VIDC_HIP(hipMemset(p, 0xFF, bytes));
+    VIDC_HIP(hipDeviceSynchronize());
+    return VIDC_OK;
+}
 int DevPool::get(size_t nbytes, void **out, size_t *out_bytes) {
+    VIDC_TRY(get_raw(nbytes, out, out_bytes));
+    return poison(*out, *out_bytes);
+}
+int DevPool::get_raw(size_t nbytes, void **out, size_t *out_bytes) {
     std::lock_guard<std::mutex> g(m);
     if (nbytes == 0) nbytes = 16;
     // best fit among free blocks that are large enough but not wastefully large
@@ -296,6 +312,10 @@ int vidc_ctx_trim(vidc_ctx *c, uint64_t *freed_bytes) {
             b.p = nullptr;
             b.bytes = 0;
         }
+    // the process-wide cache of emptied host vectors (VecPool, common.h) goes too: a process that encoded one large index and
+    // destroyed it would otherwise hold those arrays until exit (not counted in *freed_bytes: device + pinned bytes)
+    (void)vidc::vec_pool<uint32_t>().drain();
+    (void)vidc::vec_pool<uint64_t>().drain();
     if (freed_bytes) *freed_bytes = freed;
     return VIDC_OK;
 }

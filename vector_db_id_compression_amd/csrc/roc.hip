@@ -1254,6 +1254,14 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             }
             for (size_t i = 0; i < L.size(); i++)
                 if (sch_stream[i] < 0) order_l.push_back((int)i);
+            // dependency events: the 24 PhaseTimer events of the context double as "launch i has been queued" markers, so a schedule
+            // can only name the first 24 launches as something to wait for (others are dropped, not aliased), and an event is only
+            // recorded for a launch that something waits for (no VIDC_ENC_SCHED: none at all)
+            std::vector<char> waited_on(L.size(), 0);
+            for (auto &dv : deps) {
+                dv.erase(std::remove_if(dv.begin(), dv.end(), [](int d) { return d >= 24; }), dv.end());
+                for (int d : dv) waited_on[d] = 1;
+            }
             std::vector<char> done(L.size(), 0);
             size_t left = L.size();
             while (left) {
@@ -1268,9 +1276,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                         if (!(aux_used >> x & 1u)) { (void)hipStreamWaitEvent(ctx->aux[x], ctx->ev_fork, 0); aux_used |= 1u << x; }
                         return ctx->aux[x];
                     }()) : stream_no(L[i].def_stream));
-                    for (int d : deps[i]) VIDC_HIP(hipStreamWaitEvent(st_, ctx->tev[d % 24], 0));
+                    for (int d : deps[i]) VIDC_HIP(hipStreamWaitEvent(st_, ctx->tev[d], 0));
                     VIDC_TRY(L[i].fn(st_));
-                    if ((size_t)i < 24) VIDC_HIP(hipEventRecord(ctx->tev[i], st_));
+                    if (waited_on[i]) VIDC_HIP(hipEventRecord(ctx->tev[i], st_));
                     done[i] = 1;
                     left--;
                 }
