@@ -18,7 +18,8 @@ for c, name in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
 try:
     line = [l for l in open("gpurun_out/$R/pmcw_FETCH_SIZE.out") if l.startswith("{")][-1]
     d = json.loads(line)
-    out["algorithmic_bytes_per_step"] = d["roofline"]["algorithmic_bytes_per_step"]
+    # (16 + 2c B/id of SURVEY 8d + the 4 B/id of the sampling permutation the container path writes: what the kernels move by design)
+    out["algorithmic_bytes_per_step"] = d["roofline"]["algorithmic_bytes_per_id_with_perm"] * d["config"]["ids_per_gpu"]
     out["traffic_over_algorithmic"] = 1024.0 * (out["fetch_KiB_per_step"] + out["write_KiB_per_step"]) / out["algorithmic_bytes_per_step"]
 except Exception as e:
     out["note"] = str(e)
