@@ -75,5 +75,7 @@ for name in ("roc", "elias-fano", "packed-bits", "wavelet-tree"):
     assert np.array_equal(a, b)
     d0 = o.ctx.d2h_bytes()
     device_gather()
-    print(f"  {name:12s} lists to host {timeit(lists_to_host, 10):8.3f} ms ({8 * n_touched_ids} B over PCIe)   device gather "
-          f"{timeit(device_gather, 10):8.3f} ms ({o.ctx.d2h_bytes() - d0} B over PCIe)", flush=True)
+    moved = o.ctx.d2h_bytes() - d0
+    t_old, t_new = timeit(lists_to_host, 10), timeit(device_gather, 10)
+    print(f"  {name:12s} lists to host {t_old:8.3f} ms ({8 * n_touched_ids} B over PCIe)   device gather {t_new:8.3f} ms "
+          f"({moved} B over PCIe)", flush=True)

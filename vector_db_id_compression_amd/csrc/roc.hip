@@ -456,6 +456,7 @@ enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID
                 DC_LANEP, DC_LANEQ, DC_COUNT };        // 257..512 / 513..1024 ids on a pair / quad of lanes, ids in registers (k_roc_decode_lane_reg<.., 2 / 4>)
 constexpr uint64_t B2_MIN_LIST = 4096;
 constexpr size_t B2_CAP = 1024;      // chains of k_roc_decode_b2 per call (four per CU of an MI355X: 1 MiB of member rows each)
+constexpr uint32_t B2_PF_MIN_CHAINS = 512;  // k_roc_decode_b2 launches of at least this many chains request the next step's rows one step ahead
 constexpr size_t B2_TOP_CAP = 5120;  // ... of a call with more long chains than that: every list beyond 16 384 ids (comment at the planner)
 
 struct DecPlan {
@@ -1457,6 +1458,7 @@ inline DecClass grp_dec_class(uint64_t n) {
 struct DecEnv {
     bool nb256, pair, quad;
     bool nb128, mid128;
+    uint64_t pair_min = VIDC_LANE_REG_MAX;  // lists of more than this many ids (up to 512) decode on a PAIR of lanes
     DecEnv() : nb256(env_on("VIDC_LANE_NB256")),  // measurements: 256 buckets for the 257..1024-id lists too
                pair(!env_on("VIDC_NO_LANE_PAIR") && !env_on("VIDC_NO_LANE_REG")),
                // (quads of lanes for 513..1024 ids: opt-in.  Measured slower than the bucket rows: 65 536 x 1024 ids decode in 5.6
@@ -1464,6 +1466,9 @@ struct DecEnv {
                quad(env_on("VIDC_LANE_QUAD") && !env_on("VIDC_NO_LANE_PAIR") && !env_on("VIDC_NO_LANE_REG")) {
         nb128 = !env_on("VIDC_NO_LANE128");  // lists of 1025..2048 ids on 128 buckets (VIDC_NO_LANE128=1: 256, as before round 4)
         mid128 = env_on("VIDC_LANE_MID128");  // measurements: the bucket-row lists of up to 1024 ids on 128 buckets
+        // VIDC_PAIR_MIN=n (64 .. 256): lists of n+1 .. 256 ids on lane pairs too -- 32 lists per wavefront, i.e. two wavefronts
+        // per SIMD where a call of 65 536 lists has one (measurements: DESIGN section 12)
+        if (const char *e = std::getenv("VIDC_PAIR_MIN")) pair_min = std::min<uint64_t>(VIDC_LANE_REG_MAX, std::max<uint64_t>(TINY_MAX, (uint64_t)std::atoll(e)));
     }
 };
 inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general, bool allow_lane, bool allow_lane64,
@@ -1477,7 +1482,7 @@ inline DecClass dec_class(uint64_t n, uint32_t P, uint64_t u_min, bool f_general
     }
     if (grp_ok) return grp_dec_class(n);
     // lists of 257..512 ids: the register decoder on lane pairs (VIDC_NO_LANE_PAIR=1: the bucket-row decoder)
-    if (allow_lane && env.pair && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_PAIR_MAX) return DC_LANEP;
+    if (allow_lane && env.pair && n > env.pair_min && n <= VIDC_LANE_PAIR_MAX) return DC_LANEP;
     if (allow_lane && env.quad && n > VIDC_LANE_PAIR_MAX && n <= VIDC_LANE_QUAD_MAX) return DC_LANEQ;
     if (allow_lane && env.nb256 && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_MAX) return DC_LANE64;
     if (allow_lane && env.mid128 && n > VIDC_LANE_REG_MAX && n <= VIDC_LANE_MAX) return DC_LANE128;
@@ -1538,7 +1543,7 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             return lo;
         };
         const size_t e4096 = 0, e2048 = first_le(VIDC_LANE_MAX128), e1024 = first_le(VIDC_LANE_MAX), e512 = first_le(VIDC_LANE_PAIR_MAX),
-                     e256 = first_le(VIDC_LANE_REG_MAX), e64 = first_le(TINY_MAX);
+                     e256 = first_le(denv.pair ? denv.pair_min : VIDC_LANE_REG_MAX), e64 = first_le(TINY_MAX);
         const uint64_t n_mid64 = e1024 - e4096, n_mid = e64 - e1024, n_tiny = nl - e64;
         allow_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
         allow_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
@@ -1968,9 +1973,16 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 hipLaunchKernelGGL((k_roc_decode_lane<128, true>), dim3(lane_grid((b.nwork + b.lpw - 1u) / b.lpw)), dim3(64), 0, st_, b,
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
-            case DC_B2:
-                hipLaunchKernelGGL(k_roc_decode_b2<0>, dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
+            case DC_B2: {
+                // hundreds of chains: their rows (1 MiB per list) come from HBM and the step is one memory round trip -- the next
+                // step's candidate rows are requested one step ahead (roc_u2.h, U2B_DEC_PF).  Few chains: the rows stay in the
+                // L2 and the look-ahead's ~20 instructions per step only cost.  VIDC_B2_PF=0 / 1: never / always.
+                const char *pfe = std::getenv("VIDC_B2_PF");
+                const bool pf = pfe ? pfe[0] == '1' : b.nwork >= B2_PF_MIN_CHAINS;
+                if (pf) hipLaunchKernelGGL((k_roc_decode_b2<0, true>), dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
+                else hipLaunchKernelGGL(k_roc_decode_b2<0>, dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
                 break;
+            }
             case DC_B2T:  // 32 buckets, 8.3 KiB of LDS
                 hipLaunchKernelGGL(k_roc_decode_b2<32>, dim3(b.nwork), dim3(64), VIDC_B2L_LDS_BYTES(32u), st_, b, (const U2Div *)ctx->d_u2tab);
                 break;

@@ -1295,6 +1295,8 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
 #define U2B_DEC_RANK \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
     "v_readfirstlane_b32 s47, v30\n"                   /* members of the bucket */ \
+    U2B_DEC_RANK_TAIL
+#define U2B_DEC_RANK_TAIL \
     "v_cmp_gt_u32 s[66:67], s40, v31\n"                /* row member below x */ \
     "v_mov_b32 v27, s40\n" \
     "s_sub_u32 s65, s47, s64\n"                        /* members visible in memory: not those of this block */ \
@@ -1318,6 +1320,42 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
     "s_mov_b64 exec, -1\n" \
     U2_DEC_AFTER_RANK
 
+// Round 5: the row of the NEXT step requested one step ahead (PF = true; calls with hundreds of such chains, whose rows -- 1 MiB
+// per list -- come from HBM: the step then lasts one memory round trip, 0.7 us with the chains alone and 1.1 us next to the other
+// classes of an S2-sized call).  head' = H * nmax + r, and the next id's high slice is head' mod 2^p1 (codec.cpp:107-121: the high
+// slice is popped first, from the low bits of the head): everything but the rank INSIDE x's bucket is known from the on-chip
+// counters before this step's row arrives -- r lies in [r_e, r_e + c] with r_e = ids in smaller buckets and c = members of x's
+// bucket --, so the next high slice is one of c + 1 CONSECUTIVE values and the next bucket (high slice >> (bsh - 16), P >= 28)
+// one of ((v0 & m) + c >> sh) + 1 consecutive rows.  Those rows are touched now -- one dword per 64-byte line, 4 lanes per
+// row, result never read -- so that the demand load of the next step finds them in (or on their way to) the L2: two steps per
+// memory round trip instead of one.  No effect on what is computed.
+//   s90 bsh - 16   s[92:93] lanes allowed to prefetch (all, or lane 0 for P < 28)   v34 address   v35 dummy
+#define U2B_DEC_PF \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "v_readfirstlane_b32 s47, v30\n"                   /* members of the bucket */ \
+    "s_add_u32 s65, s52, s72\n"                        /* low word of the smallest head' this step can produce */ \
+    "s_and_b32 s65, s65, s73\n"                        /* ... its high slice = the next id's */ \
+    "s_bfm_b32 s68, s90, 0\n" \
+    "s_and_b32 s68, s65, s68\n" \
+    "s_add_u32 s68, s68, s47\n" \
+    "s_lshr_b32 s68, s68, s90\n"                       /* candidate rows beyond the first */ \
+    "s_min_u32 s68, s68, 7\n" \
+    "s_lshl_b32 s68, s68, 2\n" \
+    "s_add_u32 s68, s68, 4\n"                          /* 4 lanes (64-byte lines) per row */ \
+    "s_bfm_b64 s[80:81], s68, 0\n" \
+    "s_and_b64 s[80:81], s[80:81], s[92:93]\n" \
+    "s_lshr_b32 s65, s65, s90\n"                       /* first candidate bucket */ \
+    "s_lshl_b32 s65, s65, 8\n" \
+    "v_lshl_add_u32 v34, v2, 6, s65\n" \
+    "v_and_b32 v34, 0xfffff, v34\n"                    /* (wraps inside the list's 4096 rows) */ \
+    "s_mov_b64 exec, s[80:81]\n" \
+    "global_load_dword v35, v34, s[82:83]\n" \
+    "s_mov_b64 exec, -1\n"
+// (the prefetch is the youngest vector-memory operation: everything older, this step's row included, has returned at vmcnt(1))
+#define U2B_DEC_RANK_PF \
+    U2B_DEC_PF \
+    "s_waitcnt vmcnt(1)\n" \
+    U2B_DEC_RANK_TAIL
 // The same with the member rows in LDS (short lists: 128 or 256 buckets x 64 members behind the bucket sizes, 33 / 66 KiB --
 // few large rows rather than many small ones: a row must practically never overflow, because ONE list handed back costs the
 // call a whole serial chain on the general kernel afterwards): LDS operations of a wavefront are ordered, so a member is
@@ -1423,8 +1461,9 @@ __device__ __forceinline__ uint32_t u2b_slow_dec_step(uint64_t &head, WStack &st
 #define VIDC_B2L_LOAD 30u             // ids per bucket (Poisson(30) exceeds 64 once in ~10^8 buckets)
 #define VIDC_B2L_LDS_BYTES(BK) ((BK) * 2u + (BK) * VIDC_B2L_CAP * 4u)
 // BK = 0: 4096 buckets, member rows in global memory; BK = 32 / 64 / 128 / 256: that many buckets, rows in LDS
-template <int BK>
+template <int BK, bool PF = false>
 __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div *__restrict__ dtab) {
+    static_assert(!PF || BK == 0, "the look-ahead is for rows in global memory");
     constexpr bool LROWS = BK != 0;
     constexpr uint32_t VIDC_B2L_BUCKETS = LROWS ? (uint32_t)BK : 4096u;
     // (dynamic LDS, the kernel's only allocation: the asm addresses the bucket sizes from LDS offset 0, like the bitmap of
@@ -1477,18 +1516,21 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
         st.sp = rfl(st.sp);
         st.lo = rfl(st.lo);
         const uint64_t rowbase = LROWS ? (uint64_t)(VIDC_B2L_BUCKETS * 2u) : rfl64((uint64_t)rows);
+        const uint32_t pf_sh = bsh > 16u ? bsh - 16u : 0u;              // next bucket = next high slice >> pf_sh (P >= 28)
+        const uint64_t pf_lanes = rfl64(bsh >= 16u ? ~0ull : 1ull);     // (P < 28: the candidates are not rows in a run; one harmless line)
         // clang-format off
 #define U2B_DEC_ASM(BODY)                                                                                                 \
         asm volatile(BODY                                                                                                 \
             : "+{v4}"(E1), "+{v5}"(st.win), "+{v[6:7]}"(oring), "+{v[64:95]}"(ra), "+{v[96:127]}"(rb),                    \
               "+{s[58:59]}"(s_h), "+{s60}"(st.sp), "+{s69}"(s_t), "+{s85}"(s_N0), "+{s86}"(s_left), "+{s87}"(s_oidx), "+{s79}"(s_ovf)\
             : "{v2}"(lane), "{v3}"(l3off), "{s61}"(st.lo), "{s73}"(M1), "{s74}"(M0), "{s76}"(p0), "{s77}"(p1),            \
-              "{s[88:89]}"(out), "{s[94:95]}"(dtab), "{s78}"(bsh), "{s[82:83]}"(rowbase)                                  \
+              "{s[88:89]}"(out), "{s[94:95]}"(dtab), "{s78}"(bsh), "{s[82:83]}"(rowbase), "{s90}"(pf_sh), "{s[92:93]}"(pf_lanes)\
             : "memory", "vcc", "scc", "v10", "v13", "v26", "v27", "v28", "v30", "v31", "v32", "v33", "v34", "v35", "v36", \
               "v37", "v54", "v55", "v56", "v57", "v58", "v59", "s40", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",\
               "s51", "s52", "s53", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s70", "s71", "s72", "s75", "s80", "s81",\
               "s96", "s97", "s98", "s99")
         if (LROWS) U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP2(U2L_DEC_IDX, U2L_DEC_MID, U2L_DEC_RANK) U2_DEC_OUTER);
+        else if (PF) U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP2(U2B_DEC_IDX, U2B_DEC_MID, U2B_DEC_RANK_PF) U2_DEC_OUTER);
         else U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP2(U2B_DEC_IDX, U2B_DEC_MID, U2B_DEC_RANK) U2_DEC_OUTER);
 #undef U2B_DEC_ASM
         // clang-format on
