@@ -456,7 +456,6 @@ enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID
                 DC_LANEP, DC_LANEQ, DC_COUNT };        // 257..512 / 513..1024 ids on a pair / quad of lanes, ids in registers (k_roc_decode_lane_reg<.., 2 / 4>)
 constexpr uint64_t B2_MIN_LIST = 4096;
 constexpr size_t B2_CAP = 1024;      // chains of k_roc_decode_b2 per call (four per CU of an MI355X: 1 MiB of member rows each)
-constexpr uint32_t B2_PF_MIN_CHAINS = 512;  // k_roc_decode_b2 launches of at least this many chains request the next step's rows one step ahead
 constexpr size_t B2_TOP_CAP = 5120;  // ... of a call with more long chains than that: every list beyond 16 384 ids (comment at the planner)
 
 struct DecPlan {
@@ -1974,11 +1973,14 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
             case DC_B2: {
-                // hundreds of chains: their rows (1 MiB per list) come from HBM and the step is one memory round trip -- the next
-                // step's candidate rows are requested one step ahead (roc_u2.h, U2B_DEC_PF).  Few chains: the rows stay in the
-                // L2 and the look-ahead's ~20 instructions per step only cost.  VIDC_B2_PF=0 / 1: never / always.
+                // VIDC_B2_PF=1 (measurement switch, off by default): the next step's candidate rows requested one step ahead
+                // (roc_u2.h, U2B_DEC_PF).  Measured on S2 (4420 chains): 45.7 against 47.5 ms with the class alone, 72.9 against
+                // 72.2 ms for the whole decode -- the candidates are right (100 % in the host-side replay), the demand load behind
+                // an in-flight prefetch of its line still takes a memory round trip.
                 const char *pfe = std::getenv("VIDC_B2_PF");
-                const bool pf = pfe ? pfe[0] == '1' : b.nwork >= B2_PF_MIN_CHAINS;
+                const bool pf = pfe && pfe[0] == '1';
+                // VIDC_CHAIN_PRIO=1: s_setprio by chain length (roc_u2.h)
+                if (env_on("VIDC_CHAIN_PRIO")) b.lpw = (uint32_t)p.max_n[DC_B2];
                 if (pf) hipLaunchKernelGGL((k_roc_decode_b2<0, true>), dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
                 else hipLaunchKernelGGL(k_roc_decode_b2<0>, dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
                 break;

@@ -1073,12 +1073,17 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     U2_DEC_TOP_L("30", "31", "32", "33") IDX MID RANK U2_DEC_BOT_CORE "s_cbranch_scc1 1b\n s_branch 2f\n" \
     U2_DEC_SIDE("20", "21", "22", "23") U2_DEC_SIDE("30", "31", "32", "33") "2:\n"
 // store output-ring lanes [0, s72) at out[s87 - lane]; s87 -= s72
+#if defined(VIDC_B2_DBG) && (VIDC_B2_DBG & 4)
+#define U2_OUT_STORE ""
+#else
+#define U2_OUT_STORE "global_store_dwordx2 v58, v[6:7], s[88:89]\n"
+#endif
 #define U2_DEC_FLUSH \
     "v_cmp_gt_u32 vcc, s72, v2\n" \
     "v_sub_u32 v58, s87, v2\n" \
     "v_lshlrev_b32 v58, 3, v58\n" \
     "s_and_saveexec_b64 s[96:97], vcc\n" \
-    "global_store_dwordx2 v58, v[6:7], s[88:89]\n" \
+    U2_OUT_STORE \
     "s_mov_b64 exec, s[96:97]\n" \
     "s_sub_u32 s87, s87, s72\n"
 #define U2_DEC_OUTER U2_DEC_OUTER_T("-2", "59")
@@ -1247,6 +1252,20 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
 //   additional registers: s78 bucket shift (P - 12)  s79 overflow flag  s[80:81] scratch mask  s[82:83] member rows
 //   s48 bucket  s47 its size  s46 ring members below x  s64 ring members of the bucket, then all members below x
 //   v26 LDS address of the bucket size  v30 size  v31 row member of the lane  v33 buckets of the ring ids
+// (timing experiments only, -DVIDC_B2_DBG=bits: 1 = no row load, 2 = no member store, 4 = no output stores; results are wrong)
+#ifndef VIDC_B2_DBG
+#define VIDC_B2_DBG 0
+#endif
+#if VIDC_B2_DBG & 1
+#define U2B_ROW_LOAD "v_mov_b32 v31, 0\n"
+#else
+#define U2B_ROW_LOAD "global_load_dword v31, v28, s[82:83]\n"           /* lane j: member j of the bucket's row */
+#endif
+#if VIDC_B2_DBG & 2
+#define U2B_MEMBER_STORE ""
+#else
+#define U2B_MEMBER_STORE "global_store_dword v28, v27, s[82:83]\n"
+#endif
 #define U2B_DEC_IDX \
     "s_lshr_b32 s48, s40, s78\n"                       /* bucket */ \
     "s_lshl_b32 s65, s48, 1\n" \
@@ -1254,7 +1273,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
     "ds_read_u16 v30, v26\n"                           /* members of the bucket so far */ \
     "s_lshl_b32 s47, s48, 8\n" \
     "v_lshl_add_u32 v28, v2, 2, s47\n" \
-    "global_load_dword v31, v28, s[82:83]\n"           /* lane j: member j of the bucket's row */ \
+    U2B_ROW_LOAD \
     "s_xor_b32 s45, s48, 0xfff\n"                      /* entry (reversed) */
 #define U2B_DEC_MID \
     "s_lshr_b32 s43, s45, 6\n"                         /* L1 */ \
@@ -1315,7 +1334,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
     "s_add_u32 s47, s47, 1\n" \
     "v_mov_b32 v32, s47\n" \
     "s_mov_b64 exec, 1\n" \
-    "global_store_dword v28, v27, s[82:83]\n" \
+    U2B_MEMBER_STORE \
     "ds_write_b16 v26, v32\n" \
     "s_mov_b64 exec, -1\n" \
     U2_DEC_AFTER_RANK
@@ -1326,10 +1345,10 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
 // slice is popped first, from the low bits of the head): everything but the rank INSIDE x's bucket is known from the on-chip
 // counters before this step's row arrives -- r lies in [r_e, r_e + c] with r_e = ids in smaller buckets and c = members of x's
 // bucket --, so the next high slice is one of c + 1 CONSECUTIVE values and the next bucket (high slice >> (bsh - 16), P >= 28)
-// one of ((v0 & m) + c >> sh) + 1 consecutive rows.  Those rows are touched now -- one dword per 64-byte line, 4 lanes per
-// row, result never read -- so that the demand load of the next step finds them in (or on their way to) the L2: two steps per
+// one of ((v0 & m) + c >> sh) + 1 consecutive rows.  The first two of them are requested now -- every byte, 8 per lane, result
+// never read -- so that the demand load of the next step finds them in (or on their way to) the L2: two steps per
 // memory round trip instead of one.  No effect on what is computed.
-//   s90 bsh - 16   s[92:93] lanes allowed to prefetch (all, or lane 0 for P < 28)   v34 address   v35 dummy
+//   s90 bsh - 16   s[92:93] lanes allowed to prefetch (all, or lane 0 for P < 28)   v34 address   v[36:37] dummy
 #define U2B_DEC_PF \
     "s_waitcnt lgkmcnt(0)\n" \
     "v_readfirstlane_b32 s47, v30\n"                   /* members of the bucket */ \
@@ -1339,17 +1358,19 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
     "s_and_b32 s68, s65, s68\n" \
     "s_add_u32 s68, s68, s47\n" \
     "s_lshr_b32 s68, s68, s90\n"                       /* candidate rows beyond the first */ \
-    "s_min_u32 s68, s68, 7\n" \
-    "s_lshl_b32 s68, s68, 2\n" \
-    "s_add_u32 s68, s68, 4\n"                          /* 4 lanes (64-byte lines) per row */ \
+    "s_min_u32 s68, s68, 1\n"                          /* (two rows at most: every byte of a row is requested, 8 per lane) */ \
+    "s_lshl_b32 s68, s68, 5\n" \
+    "s_add_u32 s68, s68, 31\n"                         /* 32 lanes per row; 63 -> all lanes */ \
     "s_bfm_b64 s[80:81], s68, 0\n" \
+    "s_lshl_b64 s[80:81], s[80:81], 1\n" \
+    "s_or_b32 s80, s80, 1\n" \
     "s_and_b64 s[80:81], s[80:81], s[92:93]\n" \
     "s_lshr_b32 s65, s65, s90\n"                       /* first candidate bucket */ \
     "s_lshl_b32 s65, s65, 8\n" \
-    "v_lshl_add_u32 v34, v2, 6, s65\n" \
+    "v_lshl_add_u32 v34, v2, 3, s65\n" \
     "v_and_b32 v34, 0xfffff, v34\n"                    /* (wraps inside the list's 4096 rows) */ \
     "s_mov_b64 exec, s[80:81]\n" \
-    "global_load_dword v35, v34, s[82:83]\n" \
+    "global_load_dwordx2 v[36:37], v34, s[82:83]\n" \
     "s_mov_b64 exec, -1\n"
 // (the prefetch is the youngest vector-memory operation: everything older, this step's row included, has returned at vmcnt(1))
 #define U2B_DEC_RANK_PF \
@@ -1479,6 +1500,15 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
     {
         uint4 *z = (uint4 *)cnt16;
         for (uint32_t w = lane; w < (LROWS ? VIDC_B2L_BUCKETS : 4096u + 8u) * 2u / 16u; w += 64) z[w] = make_uint4(0, 0, 0, 0);
+    }
+    if (!LROWS && a.lpw) {
+        // a.lpw (unused by wave-per-list kernels otherwise) = the longest list of the launch: the wavefronts of the longest chains
+        // win the instruction arbitration of their SIMD against shorter chains and the other kernel classes of the call (the call
+        // ends with its longest chain; with four or more wavefronts per SIMD a chain step is scalar-issue bound)
+        const uint32_t top = rfl(a.lpw);
+        if (4u * n >= 3u * top) __builtin_amdgcn_s_setprio(3);
+        else if (2u * n >= top) __builtin_amdgcn_s_setprio(2);
+        else if (4u * n >= top) __builtin_amdgcn_s_setprio(1);
     }
     const uint32_t P = rfl(a.prec[l]);
     const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
