@@ -51,6 +51,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -119,7 +120,20 @@ struct DeviceArray {
 /* ---------------------------------------------------------------------------------------------------------------
  * InvertedListsArrayCodes (custom_invlists_impl.h:22-33): CSR of the list sizes + the vector codes, optionally
  * re-ordered; plus the batched decode every subclass provides for the deferred search.                          */
+#ifndef VIDC_FAISS_PREFETCH_MAX_IDS
+#define VIDC_FAISS_PREFETCH_MAX_IDS (size_t(1) << 24) /* ids of announced lists kept decoded on the host (128 MB) */
+#endif
 struct CompressedInvertedLists : faiss::ReadOnlyInvertedLists {
+#ifndef SWIG
+    struct Prefetch { /* one announcement of IndexIVF::search_preassigned */
+        std::vector<uint64_t> lists;
+        std::unordered_map<uint64_t, size_t> slot;
+        std::once_flag once; /* the first get_ids of an announced list decodes them all */
+        std::vector<faiss::idx_t> ids;
+        std::vector<uint64_t> off;
+    };
+    mutable std::shared_ptr<Prefetch> prefetch_; /* (std::atomic_load / atomic_store: searches may run concurrently) */
+#endif
     std::vector<uint64_t> offsets;                /* [nlist + 1] */
     std::vector<std::vector<uint8_t>> codes_all;  /* per list, in the container's order */
     size_t compressed_ids_size_in_bytes = 0, overhead_in_bytes = 0, codes_size_in_bytes = 0;
@@ -173,11 +187,44 @@ struct CompressedInvertedLists : faiss::ReadOnlyInvertedLists {
     virtual int decode_gather_device(vidc_ctx* ctx, uint64_t m, const uint64_t* list_nos, uint64_t n_items, const uint64_t* item_slot,
                                      const uint64_t* item_off, int64_t* ids_out) const = 0;
 
+    /* Faiss announces the lists a search will visit (InvertedLists::prefetch_lists, called by IndexIVF::search_preassigned before
+     * the scan; the reference's containers inherit the no-op).  Here the announcement is only RECORDED: the first get_ids of an
+     * announced list decodes ALL of them with one library call into a host cache the scan threads then read -- a search with
+     * nprobe x nq probed lists costs one launch + one copy instead of one per probed list and thread.  A deferred search
+     * (store_pairs) never calls get_ids, so its announcement costs nothing.  At most VIDC_FAISS_PREFETCH_MAX_IDS ids are cached
+     * (the decoded lists are 8 bytes per id: the point of the container is not to hold them); larger announcements and lists
+     * outside the announcement take the per-list path.  clear_prefetch() drops the cache. */
+    void prefetch_lists(const faiss::idx_t* list_nos, int n) const override {
+        std::shared_ptr<Prefetch> st;
+        if (n > 1) {
+            st = std::make_shared<Prefetch>();
+            size_t total = 0;
+            for (int i = 0; i < n && total <= VIDC_FAISS_PREFETCH_MAX_IDS; i++) {
+                if (list_nos[i] < 0 || (size_t)list_nos[i] >= nlist || !list_size(list_nos[i])) continue;
+                if (st->slot.emplace((uint64_t)list_nos[i], st->lists.size()).second) {
+                    st->lists.push_back((uint64_t)list_nos[i]);
+                    total += list_size(list_nos[i]);
+                }
+            }
+            if (total > VIDC_FAISS_PREFETCH_MAX_IDS || st->lists.size() < 2) st.reset();
+        }
+        std::atomic_store(&prefetch_, st);
+    }
+    void clear_prefetch() const { std::atomic_store(&prefetch_, std::shared_ptr<Prefetch>()); }
+
     /* get_ids: new idx_t[list_size], nullptr for an empty list (:212-214,294-296) */
     const faiss::idx_t* get_ids(size_t l) const override {
         size_t n = list_size(l);
         if (n == 0) return nullptr;
         std::unique_ptr<faiss::idx_t[]> out(new faiss::idx_t[n]);
+        if (std::shared_ptr<Prefetch> st = std::atomic_load(&prefetch_)) {
+            auto it = st->slot.find((uint64_t)l);
+            if (it != st->slot.end()) {
+                std::call_once(st->once, [&] { decode_lists_host(st->lists.size(), st->lists.data(), st->ids, st->off); });
+                std::memcpy(out.get(), st->ids.data() + st->off[it->second], n * sizeof(faiss::idx_t));
+                return out.release();
+            }
+        }
         ThreadCtx& t = thread_ctx();
         uint64_t off[2], ln = l;
         uint64_t* d = (uint64_t*)t.staging(n * 8);

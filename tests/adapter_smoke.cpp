@@ -49,8 +49,22 @@ static int check_container(faiss::IndexIVF& index, const faiss::ArrayInvertedLis
     index.replace_invlists(&comp, false);
     std::vector<idx_t> I(nq * k);
     std::vector<float> D(nq * k);
-    index.search(nq, xq.data(), k, D.data(), I.data());  // non-deferred: get_ids of the probed lists, from OpenMP threads in Faiss
-    REQUIRE(I == Iref && D == Dref);
+    {
+        // non-deferred: get_ids of the probed lists (from OpenMP threads in Faiss).  search_preassigned announces them
+        // (prefetch_lists), the first get_ids decodes all of them: ONE library call for the nq * nprobe probed lists
+        const size_t calls0 = vidc_faiss::thread_ctx().device_calls;
+        index.search(nq, xq.data(), k, D.data(), I.data());
+        REQUIRE(I == Iref && D == Dref);
+        REQUIRE(vidc_faiss::thread_ctx().device_calls - calls0 == 1);
+        // a list outside the announcement and a cleared announcement take the per-list path
+        comp.clear_prefetch();
+        const size_t calls1 = vidc_faiss::thread_ctx().device_calls;
+        size_t l0 = 0;
+        while (ref.list_size(l0) == 0) l0++;
+        const idx_t* ids = comp.get_ids(l0);
+        REQUIRE(vidc_faiss::thread_ctx().device_calls - calls1 == 1);
+        comp.release_ids(l0, ids);
+    }
     for (int one_by_one = 0; one_by_one < 2; one_by_one++) {  // test_compressed_ivfs.py:128-156
         std::fill(I.begin(), I.end(), -7);
         const size_t calls0 = vidc_faiss::thread_ctx().device_calls;

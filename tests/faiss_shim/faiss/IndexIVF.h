@@ -74,6 +74,7 @@ struct IndexIVF : Index {  // "IVFx,Flat": codes are the float32 vectors
     }
     void search_preassigned(idx_t n, const float* x, idx_t k, const idx_t* assign, const float* /*centroid_dis*/,
                             float* distances, idx_t* labels, bool store_pairs) const {
+        invlists->prefetch_lists(assign, (int)(n * nprobe));  // (Faiss announces the probed lists before scanning them)
         for (idx_t q = 0; q < n; q++) {
             std::vector<std::pair<float, idx_t>> cand;
             for (size_t p = 0; p < nprobe; p++) {

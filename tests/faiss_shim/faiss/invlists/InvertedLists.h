@@ -20,6 +20,8 @@ struct InvertedLists {
     virtual const idx_t* get_ids(size_t list_no) const = 0;
     virtual void release_codes(size_t, const uint8_t*) const {}
     virtual void release_ids(size_t, const idx_t*) const {}
+    /* the lists a search is about to visit (IndexIVF::search_preassigned announces them before it scans); default: nothing */
+    virtual void prefetch_lists(const idx_t* /*list_nos*/, int /*nlist*/) const {}
     virtual idx_t get_single_id(size_t list_no, size_t offset) const {
         const idx_t* ids = get_ids(list_no);
         idx_t id = ids[offset];
