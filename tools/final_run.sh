@@ -16,6 +16,10 @@ VIDC_NO_LANE_PAIR=1 VIDC_FORCE_LANE=1 timeout 900 python -m pytest tests/test_gp
 VIDC_LANE_LOOP=1 VIDC_NO_LANE128=1 VIDC_FORCE_LANE=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_lane_loop.txt
 VIDC_NO_AVX2=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_packed_ef.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_no_avx2.txt
 VIDC_NO_LENGTH_CLASSES=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_no_length_classes.txt
+# round 5: the measurement switches of DESIGN section 12 must not change a bit (look-ahead rows, chain priority, 65..256-id lists on lane pairs)
+VIDC_B2_PF=1 VIDC_CHAIN_PRIO=1 VIDC_PAIR_MIN=64 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_r5_switches.txt
+VIDC_POOL_POISON=1 timeout 1200 python -m pytest tests/test_gpu_roc.py tests/test_gpu_packed_ef.py tests/test_gpu_containers.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_pool_poison.txt
+timeout 300 python tools/bench_search_paths.py 2>&1 | tail -12 > gpurun_out/$R/search_paths.txt
 # S2 decoded 100 times per mode and compared with the first decode (the list-level flake hunt of round 3)
 (GPU_MAX_HW_QUEUES=8 NQS=4,8,5,6 ITERS=100 timeout 200 python tools/repro_s2b.py "X=1" 2>&1 | grep "differs\|it 99" | cut -c1-160; GPU_MAX_HW_QUEUES=4 NQS=3 ITERS=100 timeout 200 python tools/repro_s2b.py "X=1" 2>&1 | grep "differs\|it 99" | cut -c1-160) > gpurun_out/$R/s2_repeated_decodes.txt
 timeout 300 python tools/fuzz_chain.py 11 60 2>&1 | tail -1 > gpurun_out/$R/fuzz_chain.txt
@@ -43,7 +47,7 @@ timeout 600 python tools/probe_grp.py 2>&1 | tail -10 > gpurun_out/$R/probe_grp.
 MIN_NS=500000 GPU_MAX_HW_QUEUES=8 bash tools/prof_s2.sh s2 2>&1 | grep "start" | grep -v "^\[" > gpurun_out/$R/s2_timeline.txt
 VIDC_SERIAL=1 MIN_NS=500000 GPU_MAX_HW_QUEUES=8 bash tools/prof_s2.sh s2 2>&1 | grep "start" | grep -v "^\[" > gpurun_out/$R/s2_timeline_serial.txt
 # S2 step (encode + decode of a fresh object) over 10 rounds, defaults against the round-3 policies (interleaved)
-ROUNDS=10 timeout 900 python tools/s2_ab.py - VIDC_B2_TOP_OLD=1,VIDC_LANE_LOOP=1,VIDC_NO_LANE128=1 2>&1 | grep -v amdgpu > gpurun_out/$R/s2_ab.txt
+ROUNDS=10 timeout 900 python tools/s2_ab.py - VIDC_B2_PF=1 VIDC_CHAIN_PRIO=1 2>&1 | grep -v amdgpu > gpurun_out/$R/s2_ab.txt
 # HBM-side traffic (PMC) of S2 through the three codecs and of the 16 M-id call; kernel stats of the Elias-Fano / packed-bits benches
 for c in roc ef packed; do GPU_MAX_HW_QUEUES=8 bash tools/pmc_workload.sh $R s2 $c > /dev/null 2>&1; done
 GPU_MAX_HW_QUEUES=8 bash tools/pmc_workload.sh $R uniform_16m roc > /dev/null 2>&1
@@ -52,6 +56,7 @@ bash tools/prof_ef_s2.sh $R > gpurun_out/$R/prof_ef_s2.txt 2>&1
 # host-side phases of a 65 536-list call; the register-index construct of DESIGN section 11 outside the library
 python tools/trace_host.py uniform_16m 2>&1 | tail -14 > gpurun_out/$R/trace_u16.txt
 (hipcc --offload-arch=gfx950 -O2 tools/hw_gpr_idx_probe.hip -o /tmp/probe 2>&1 | tail -3; GPU_MAX_HW_QUEUES=8 timeout 400 /tmp/probe 10 4096 8192 10000 200000 100000) > gpurun_out/$R/hw_gpr_idx_probe.txt 2>&1
+cat gpurun_out/$R/pytest_r5_switches.txt gpurun_out/$R/pytest_pool_poison.txt gpurun_out/$R/search_paths.txt
 cat gpurun_out/$R/s2_ab.txt gpurun_out/$R/pytest_lane_loop.txt gpurun_out/$R/pytest_no_length_classes.txt gpurun_out/$R/pytest_force_grp.txt gpurun_out/$R/pytest_wide.txt gpurun_out/$R/pytest_no_lane_pair.txt gpurun_out/$R/s2_repeated_decodes.txt gpurun_out/$R/s2_timeline.txt gpurun_out/$R/probe_grp.txt
 cat gpurun_out/$R/pytest_gpu.txt gpurun_out/$R/pytest_force_general.txt gpurun_out/$R/pytest_no_lane.txt gpurun_out/$R/pytest_force_lane.txt gpurun_out/$R/pytest_old_u.txt gpurun_out/$R/pytest_full_prepass_no_lane_reg.txt gpurun_out/$R/fuzz_chain.txt gpurun_out/$R/fuzz_chain_wide.txt gpurun_out/$R/chain_probe.txt gpurun_out/$R/fuzz_families.txt gpurun_out/$R/fuzz_ef_packed.txt gpurun_out/$R/bench_wt.txt gpurun_out/$R/smoke.txt
 python - <<PY
@@ -60,5 +65,5 @@ for line in open("gpurun_out/$R/bench_other.jsonl"):
     d = json.loads(line)
     print(d["config"]["workload"][:60], d["config"]["codec"], round(d["ms_per_step"], 3), "ms/step", {k: round(v, 3) for k, v in d["kernel_ms"].items()}, round(d["value"] / 1e6, 1), "M IDs/s", "frac", round(d["roofline"]["frac"], 5), "bits", round(d["bits_per_id"], 3), d["verified_roundtrip"])
 PY
-cut -c1-900 gpurun_out/$R/bench.json
+cat gpurun_out/$R/bench.json
 cat gpurun_out/$R/bench_graph.json

@@ -1311,28 +1311,25 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
     "v_mov_b32 v64, v13\n" \
     "s_set_gpr_idx_off\n" \
     "s_mov_b32 m0, s69\n"
+// (round 5: the bucket's member count stays in the VGPR the LDS read left it in -- every lane holds it --, so the slot address, the
+// new count, the "visible in memory" bound and the overflow test are vector instructions: 5 scalar instructions instead of 15 in this
+// tail.  A chain alone pays four cycles per instruction of either kind, but with four chains per SIMD the scalar slot is the one they
+// queue for, DESIGN section 12.  v29 = largest count seen: the row is full when it passes 63, tested once behind the loop.)
 #define U2B_DEC_RANK \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
-    "v_readfirstlane_b32 s47, v30\n"                   /* members of the bucket */ \
     U2B_DEC_RANK_TAIL
 #define U2B_DEC_RANK_TAIL \
     "v_cmp_gt_u32 s[66:67], s40, v31\n"                /* row member below x */ \
+    "v_subrev_u32 v33, s64, v30\n"                     /* members visible in memory: not those of this block */ \
+    "v_min_u32 v32, 63, v30\n"                         /* slot of x in the row */ \
+    "v_cmp_gt_u32 vcc, v33, v2\n"                      /* the lane holds a visible member */ \
     "v_mov_b32 v27, s40\n" \
-    "s_sub_u32 s65, s47, s64\n"                        /* members visible in memory: not those of this block */ \
-    "v_cmp_gt_u32 vcc, s65, v2\n"                      /* the lane holds one of them */ \
-    "s_min_u32 s68, s47, 63\n"                         /* slot of x in the row */ \
-    "s_lshl_b32 s68, s68, 2\n" \
-    "s_lshl_b32 s65, s48, 8\n" \
-    "s_add_u32 s68, s68, s65\n" \
-    "v_mov_b32 v28, s68\n" \
+    "v_lshl_add_u32 v28, v32, 2, v28\n"                /* lane 0: row + 4 * slot */ \
+    "v_max_u32 v29, v29, v30\n" \
     "s_and_b64 vcc, vcc, s[66:67]\n" \
+    "v_add_u32 v32, 1, v30\n" \
     "s_bcnt1_i32_b64 s64, vcc\n" \
     "s_add_u32 s64, s64, s46\n"                        /* members of the bucket below x */ \
-    "s_cmp_gt_u32 s47, 63\n" \
-    "s_cselect_b32 s68, 1, 0\n" \
-    "s_or_b32 s79, s79, s68\n"                         /* the row is full: the list is decoded again by the general kernel */ \
-    "s_add_u32 s47, s47, 1\n" \
-    "v_mov_b32 v32, s47\n" \
     "s_mov_b64 exec, 1\n" \
     U2B_MEMBER_STORE \
     "ds_write_b16 v26, v32\n" \
@@ -1532,9 +1529,17 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
     wave_sync();
 
     uint32_t i = 0;  // ids decoded so far
+    // rows in global memory: the eight-copy loop of the bitmap kernels (ring tested by the last copy only, U2_DEC_RING_LO .. HI words
+    // on entry) -- four scalar instructions less in seven steps out of eight; rows in LDS keep the two-copy loop
+    constexpr uint32_t RING_LO = LROWS ? 2u : U2_DEC_RING_LO, RING_HI = LROWS ? 61u : U2_DEC_RING_HI;
     while (i < n) {
-        ws_prepare(st);
-        if (lt_2p31(head) || st.sp - st.lo < 2u || st.sp - st.lo > 61u) {  // generic step
+        if (LROWS) ws_prepare(st);
+        else {
+            const uint32_t res = st.sp - st.lo;
+            if (res > 56u) ws_spill32(st);
+            else if (res < 22u && st.lo != 0u) ws_refill32(st);
+        }
+        if (lt_2p31(head) || st.sp - st.lo < RING_LO || st.sp - st.lo > RING_HI) {  // generic step
             const uint32_t x = u2b_slow_dec_step(head, st, i + 1u, E1, ra, rb, cnt16, rows, bsh, p0, p1, ovf,
                                                  LROWS ? VIDC_B2L_BUCKETS : 4096u, LROWS ? VIDC_B2L_CAP : 64u);
             if (lane == 0) out[n - 1u - i] = (uint64_t)x;
@@ -1543,6 +1548,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
         }
         uint32_t s_t = 0, s_N0 = rfl(i + 1u), s_left = rfl(n - i), s_oidx = rfl(n - 1u - i), s_ovf = rfl(ovf);
         uint64_t s_h = rfl64(head), oring = 0;
+        uint32_t vmaxc = 0;  // (rows in global memory: the largest member count a step found in its bucket)
         st.sp = rfl(st.sp);
         st.lo = rfl(st.lo);
         const uint64_t rowbase = LROWS ? (uint64_t)(VIDC_B2L_BUCKETS * 2u) : rfl64((uint64_t)rows);
@@ -1551,7 +1557,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
         // clang-format off
 #define U2B_DEC_ASM(BODY)                                                                                                 \
         asm volatile(BODY                                                                                                 \
-            : "+{v4}"(E1), "+{v5}"(st.win), "+{v[6:7]}"(oring), "+{v[64:95]}"(ra), "+{v[96:127]}"(rb),                    \
+            : "+{v4}"(E1), "+{v5}"(st.win), "+{v[6:7]}"(oring), "+{v[64:95]}"(ra), "+{v[96:127]}"(rb), "+{v29}"(vmaxc),   \
               "+{s[58:59]}"(s_h), "+{s60}"(st.sp), "+{s69}"(s_t), "+{s85}"(s_N0), "+{s86}"(s_left), "+{s87}"(s_oidx), "+{s79}"(s_ovf)\
             : "{v2}"(lane), "{v3}"(l3off), "{s61}"(st.lo), "{s73}"(M1), "{s74}"(M0), "{s76}"(p0), "{s77}"(p1),            \
               "{s[88:89]}"(out), "{s[94:95]}"(dtab), "{s78}"(bsh), "{s[82:83]}"(rowbase), "{s90}"(pf_sh), "{s[92:93]}"(pf_lanes)\
@@ -1560,11 +1566,11 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
               "s51", "s52", "s53", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s70", "s71", "s72", "s75", "s80", "s81",\
               "s96", "s97", "s98", "s99")
         if (LROWS) U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP2(U2L_DEC_IDX, U2L_DEC_MID, U2L_DEC_RANK) U2_DEC_OUTER);
-        else if (PF) U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP2(U2B_DEC_IDX, U2B_DEC_MID, U2B_DEC_RANK_PF) U2_DEC_OUTER);
-        else U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP2(U2B_DEC_IDX, U2B_DEC_MID, U2B_DEC_RANK) U2_DEC_OUTER);
+        else if (PF) U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP8(U2B_DEC_IDX, U2B_DEC_MID, U2B_DEC_RANK_PF) U2_DEC_OUTER_T("-18", "35"));
+        else U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP8(U2B_DEC_IDX, U2B_DEC_MID, U2B_DEC_RANK) U2_DEC_OUTER_T("-18", "35"));
 #undef U2B_DEC_ASM
         // clang-format on
-        ovf = s_ovf;
+        ovf = s_ovf | (rfl(vmaxc) > 63u ? 1u : 0u);  // a full row: the list is decoded again by the general kernel
         head = s_h;
         ws_window(st);
         if (__builtin_expect(lt_2p31(head), 0)) {  // second half of the last index push (codec.cpp:59-61)
