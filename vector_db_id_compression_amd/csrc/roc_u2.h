@@ -1417,25 +1417,18 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
     "v_mov_b32 v64, v13\n" \
     "s_set_gpr_idx_off\n" \
     "s_mov_b32 m0, s69\n"
+// (round 5: the member count stays in its VGPR as in U2B_DEC_RANK_TAIL -- 4 scalar instructions instead of 14; v29 = largest count)
 #define U2L_DEC_RANK \
     "s_waitcnt lgkmcnt(0)\n" \
-    "v_readfirstlane_b32 s47, v30\n"                   /* members of the bucket */ \
     "v_cmp_gt_u32 s[66:67], s40, v31\n"                /* row member below x */ \
+    "v_min_u32 v32, 63, v30\n"                         /* slot of x in the row */ \
+    "v_cmp_gt_u32 vcc, v30, v2\n"                      /* the lane holds a member */ \
     "v_mov_b32 v27, s40\n" \
-    "v_cmp_gt_u32 vcc, s47, v2\n"                      /* the lane holds a member */ \
-    "s_min_u32 s68, s47, 63\n"                         /* slot of x in the row */ \
-    "s_lshl_b32 s68, s68, 2\n" \
-    "s_lshl_b32 s65, s48, 8\n" \
-    "s_add_u32 s68, s68, s65\n" \
-    "s_add_u32 s68, s68, s82\n" \
-    "v_mov_b32 v28, s68\n" \
+    "v_lshl_add_u32 v28, v32, 2, v28\n"                /* lane 0: row + 4 * slot */ \
+    "v_max_u32 v29, v29, v30\n" \
     "s_and_b64 vcc, vcc, s[66:67]\n" \
+    "v_add_u32 v32, 1, v30\n" \
     "s_bcnt1_i32_b64 s64, vcc\n"                       /* members of the bucket below x */ \
-    "s_cmp_gt_u32 s47, 63\n" \
-    "s_cselect_b32 s68, 1, 0\n" \
-    "s_or_b32 s79, s79, s68\n"                         /* the row is full: the list is decoded again by the general kernel */ \
-    "s_add_u32 s47, s47, 1\n" \
-    "v_mov_b32 v32, s47\n" \
     "s_mov_b64 exec, 1\n" \
     "ds_write_b32 v28, v27\n" \
     "ds_write_b16 v26, v32\n" \
@@ -1529,12 +1522,11 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
     wave_sync();
 
     uint32_t i = 0;  // ids decoded so far
-    // rows in global memory: the eight-copy loop of the bitmap kernels (ring tested by the last copy only, U2_DEC_RING_LO .. HI words
-    // on entry) -- four scalar instructions less in seven steps out of eight; rows in LDS keep the two-copy loop
-    constexpr uint32_t RING_LO = LROWS ? 2u : U2_DEC_RING_LO, RING_HI = LROWS ? 61u : U2_DEC_RING_HI;
+    // the eight-copy loop of the bitmap kernels (ring tested by the last copy only, U2_DEC_RING_LO .. HI words on entry): four scalar
+    // instructions less in seven steps out of eight
+    constexpr uint32_t RING_LO = U2_DEC_RING_LO, RING_HI = U2_DEC_RING_HI;
     while (i < n) {
-        if (LROWS) ws_prepare(st);
-        else {
+        {
             const uint32_t res = st.sp - st.lo;
             if (res > 56u) ws_spill32(st);
             else if (res < 22u && st.lo != 0u) ws_refill32(st);
@@ -1548,7 +1540,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
         }
         uint32_t s_t = 0, s_N0 = rfl(i + 1u), s_left = rfl(n - i), s_oidx = rfl(n - 1u - i), s_ovf = rfl(ovf);
         uint64_t s_h = rfl64(head), oring = 0;
-        uint32_t vmaxc = 0;  // (rows in global memory: the largest member count a step found in its bucket)
+        uint32_t vmaxc = 0;  // the largest member count a step found in its bucket
         st.sp = rfl(st.sp);
         st.lo = rfl(st.lo);
         const uint64_t rowbase = LROWS ? (uint64_t)(VIDC_B2L_BUCKETS * 2u) : rfl64((uint64_t)rows);
@@ -1565,7 +1557,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
               "v37", "v54", "v55", "v56", "v57", "v58", "v59", "s40", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",\
               "s51", "s52", "s53", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s70", "s71", "s72", "s75", "s80", "s81",\
               "s96", "s97", "s98", "s99")
-        if (LROWS) U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP2(U2L_DEC_IDX, U2L_DEC_MID, U2L_DEC_RANK) U2_DEC_OUTER);
+        if (LROWS) U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP8(U2L_DEC_IDX, U2L_DEC_MID, U2L_DEC_RANK) U2_DEC_OUTER_T("-18", "35"));
         else if (PF) U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP8(U2B_DEC_IDX, U2B_DEC_MID, U2B_DEC_RANK_PF) U2_DEC_OUTER_T("-18", "35"));
         else U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP8(U2B_DEC_IDX, U2B_DEC_MID, U2B_DEC_RANK) U2_DEC_OUTER_T("-18", "35"));
 #undef U2B_DEC_ASM
