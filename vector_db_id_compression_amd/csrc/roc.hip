@@ -485,6 +485,7 @@ struct DecPlan {
 // device copy of a plan, kept with the compressed object for repeated decode_all calls
 struct DecPlanCache {
     DecPlan plan;
+    bool wide = false;  // the stream mode the plan was built for (a context of the other mode builds its own: ADVICE round 4)
     DevBuf<uint32_t> d_wl;
     DevBuf<uint64_t> d_scratch_off, d_slots_off;
 };
@@ -1084,7 +1085,8 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             // must overlap: they alternate between the first and the third auxiliary stream (the lane classes own the second).
             // VIDC_GRP_STREAMS="1313": stream digit per segment (0 = main, 1..3 = auxiliary), measurements.
             const char *gmap = std::getenv("VIDC_GRP_STREAMS");
-            if (!gmap || !*gmap) gmap = ctx->wide ? "4567" : "13";
+            // (wide: the last auxiliary stream is the plan upload's: ADVICE round 4)
+            if (!gmap || !*gmap) gmap = ctx->wide ? "456" : "13";
             const size_t gmap_n = std::strlen(gmap);
             size_t seg_no = 0;
             auto add_grp = [&](const std::vector<uint32_t> &w, size_t wbase, bool lev3) {
@@ -2318,6 +2320,7 @@ std::shared_ptr<DecPlanCache> plan_ahead_build(const vidc_roc *r, bool wide) {
     std::vector<uint32_t> all(r->nlist);
     std::iota(all.begin(), all.end(), 0u);
     auto c = std::make_shared<DecPlanCache>();
+    c->wide = wide;
     plan_decode(r, all, false, c->plan, wide, true, true, false, /*whole_sorted=*/true);
     return c;
 }
@@ -2331,6 +2334,22 @@ int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out) {
         std::lock_guard<std::mutex> g(r->mu);
         plan = r->plan_all;
     }
+    if (plan && plan->wide != ctx->wide) {
+        // the cached plan is for the other stream mode (8 against 4 class streams): this call plans for its own context and
+        // leaves the cache to the contexts of the mode that built it
+        HostTrace tr("roc decode_all (plan of the other stream mode)");
+        auto c = plan_ahead_build(r, ctx->wide);
+        VIDC_HIP(hipSetDevice(ctx->device));
+        VIDC_TRY(upload(ctx, c->d_wl, c->plan.wl));
+        VIDC_TRY(upload(ctx, c->d_scratch_off, c->plan.scratch_off));
+        VIDC_TRY(upload(ctx, c->d_slots_off, c->plan.slots_off));
+        const int st = decode_impl(ctx, r, c->plan, nullptr, d_out, nullptr, 0, c.get());
+        if (st == VIDC_OK) {
+            std::lock_guard<std::mutex> g(r->mu);
+            if (r->plan_all == plan && ctx->wide) r->plan_all = c;  // (the wide plan is the better one to keep)
+        }
+        return st;
+    }
     if (!plan) {
         HostTrace tr("roc decode_all");
         std::shared_ptr<DecPlanCache> c;
@@ -2338,6 +2357,7 @@ int vidc_roc_decode_all(vidc_ctx *ctx, const vidc_roc *r, uint64_t *d_out) {
             std::lock_guard<std::mutex> g(r->mu);
             c = std::move(r->plan_ahead);
         }
+        if (c && c->wide != ctx->wide) c.reset();
         if (!c) c = plan_ahead_build(r, ctx->wide);
         tr.mark("plan");
         VIDC_HIP(hipSetDevice(ctx->device));
