@@ -384,3 +384,33 @@ def test_streams_from_dirty_pool_blocks_equal_streams_from_fresh_ones(monkeypatc
     for key in clean:
         for i, (a, b, c) in enumerate(zip(clean[key], dirty[key], dirty2[key])):
             assert np.array_equal(a, b) and np.array_equal(a, c), (key, i)
+
+
+def test_elias_fano_decode_lists_shares_long_lists_between_workgroups():
+    """decode_lists of a few long lists (what a search with nprobe 16 touches) spreads every list's 64-word batches over several
+    workgroups (k_ef_decode, nsplit > 1): lists of 1 .. 200 000 ids, dense and sparse, repeated and empty lists in the request,
+    against slices of decode_all."""
+    import torch
+    from vector_db_id_compression_amd.codecs import EfLists
+
+    rng = np.random.default_rng(5)
+    sizes = np.array([200000, 0, 1, 52114, 4097, 63, 70000, 2048, 9], dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    parts = []
+    for i, s in enumerate(sizes):
+        if s == 0:
+            continue
+        if i % 2 == 0:  # dense: consecutive ids with small gaps (many ids per high word)
+            parts.append(np.cumsum(rng.integers(1, 3, size=int(s))).astype(np.uint64))
+        else:           # sparse over 2^31
+            parts.append(np.sort(rng.choice(1 << 31, size=int(s), replace=False)).astype(np.uint64))
+    ids = np.concatenate(parts)
+    ef = EfLists.encode(off, ids)
+    full = ef.decode_all().cpu().numpy().view(np.uint64)
+    assert np.array_equal(full, ids)
+    for req in ([0], [3, 0, 6], [6, 6, 1, 2, 0, 8, 5, 4, 7, 3], list(range(9))):
+        got, goff = ef.decode_lists(np.array(req, dtype=np.uint64))
+        got = got.cpu().numpy().view(np.uint64)
+        assert int(goff[-1]) == int(sizes[req].sum())
+        for k, l in enumerate(req):
+            assert np.array_equal(got[int(goff[k]):int(goff[k + 1])], ids[int(off[l]):int(off[l + 1])]), (req, k)

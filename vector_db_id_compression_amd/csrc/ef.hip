@@ -908,14 +908,17 @@ __global__ void __launch_bounds__(64) k_ef_decode(const uint64_t *low, const uin
                                                   const uint32_t *lbits, const uint64_t *batch_off,
                                                   const uint32_t *hrank, uint32_t nwork, const Chunk *items,
                                                   const uint64_t *worklist, const uint64_t *out_off, uint64_t *out,
-                                                  int32_t *out_rows, uint32_t K) {
+                                                  int32_t *out_rows, uint32_t K, uint32_t nsplit) {
     __shared__ uint16_t spos[EF_BATCH_BITS];  // bit position (inside the batch) of the element with in-batch rank r
     const uint32_t lane = lane_id();
-    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    // nsplit > 1 (decode_lists of few long lists): `nsplit` workgroups share a list, workgroup s takes its batches s, s + nsplit, ...
+    // (a search that touched 16 lists of up to 52 000 ids had 16 wavefronts walk up to 102 batches each: 0.16 ms for 97 000 ids)
+    for (uint32_t vi = blockIdx.x; vi < nwork * nsplit; vi += gridDim.x) {
+        const uint32_t wi = vi / nsplit, split = vi - wi * nsplit;
         const uint64_t l = items ? items[wi].list : (worklist ? worklist[wi] : wi);
         const uint64_t off = out_rows ? (uint64_t)wi * K : (out_off ? out_off[wi] : offsets[l]);
         const uint64_t m = offsets[l + 1] - offsets[l];
-        if (out_rows) {
+        if (out_rows && split == 0) {
             for (uint32_t j = lane; j < K; j += 64)
                 if (j >= m) out_rows[off + j] = -1;
         }
@@ -927,7 +930,7 @@ __global__ void __launch_bounds__(64) k_ef_decode(const uint64_t *low, const uin
         const uint64_t nhw = high_off[l + 1] - high_off[l];
         const uint64_t nb = batch_off[l + 1] - batch_off[l];
         const uint64_t b_first = items ? items[wi].start : 0, b_last = items ? b_first + 1 : nb;
-        for (uint64_t bt = b_first; bt < b_last; bt++) {
+        for (uint64_t bt = b_first + split; bt < b_last; bt += nsplit) {
             const uint64_t done = hrank[batch_off[l] + bt];
             if (done >= m) break;
             const uint64_t wi64 = bt * 64 + lane;
@@ -1840,11 +1843,23 @@ static int ef_decode_some(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uin
         hipLaunchKernelGGL(k_ef_decode_rows_lane, dim3((uint32_t)((m + 63) / 64)), dim3(64), 0, ctx->stream, e->d_low.p,
                            e->d_high.p, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p, e->d_lbits.p, m,
                            d_l, d_rows, K);
-    else
-        hipLaunchKernelGGL(k_ef_decode, dim3((uint32_t)std::min<uint64_t>(m, (uint64_t)ctx->num_cu * 64)), dim3(64), 0,
+    else {
+        // few lists: several workgroups per list (by the longest requested list, ~2048 ids per workgroup; the host knows the sizes
+        // whenever it knows the output offsets)
+        uint32_t nsplit = 1;
+        if (out_off_host && m < (uint64_t)ctx->num_cu * 8) {
+            uint64_t longest = 0;
+            for (uint64_t i = 0; i < m; i++) {
+                const uint64_t l = list_nos ? list_nos[i] : i;
+                longest = std::max(longest, e->offsets[l + 1] - e->offsets[l]);
+            }
+            nsplit = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, longest / 2048), std::max<uint64_t>(1, (uint64_t)ctx->num_cu * 16 / m));
+        }
+        hipLaunchKernelGGL(k_ef_decode, dim3((uint32_t)std::min<uint64_t>(m * nsplit, (uint64_t)ctx->num_cu * 64)), dim3(64), 0,
                            ctx->stream, e->d_low.p, e->d_high.p, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p,
                            e->d_lbits.p, e->d_batch_off.p, e->d_hrank.p, (uint32_t)m, (const Chunk *)nullptr,
-                           d_l, out_off_host ? s_o.as<uint64_t>() : nullptr, d_out, d_rows, K);
+                           d_l, out_off_host ? s_o.as<uint64_t>() : nullptr, d_out, d_rows, K, nsplit);
+    }
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
