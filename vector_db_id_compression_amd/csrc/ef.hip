@@ -432,6 +432,10 @@ __global__ void __launch_bounds__(NT) k_ef_offsets(const uint64_t *ids, const ui
                                                     uint64_t *high_off, uint64_t *batch_off, EfChunkRec *recs,
                                                     EfSummary *sum, EfBigList *big, uint32_t *nbig) {
     constexpr uint32_t TILE = NT * E;
+    // lists of more than BIGC chunks leave their records to k_ef_big_recs (S2: the tile of the 1024 longest lists wrote 130 000 records
+    // with 256 threads).  A single-tile object has no such launch: its <= NT * E lists are balanced by the binary search below whatever
+    // their sizes, and the call saves a fill, a launch and the gap in front of it (S1-sized calls: 24.7 -> ~19 us of kernels)
+    constexpr uint32_t BIGC = SINGLE ? 0xffffffffu : (uint32_t)EF_BIG_CHUNKS;
     __shared__ uint64_t sh[6 * (NT / 64)];
     __shared__ EfListInfo info[TILE];
     const uint32_t tile = blockIdx.x, t = threadIdx.x;
@@ -464,7 +468,7 @@ __global__ void __launch_bounds__(NT) k_ef_offsets(const uint64_t *ids, const ui
 #pragma unroll
     for (uint32_t j = 0; j < E; j++) {
         a[0] += r[j].lw; a[1] += r[j].hw; a[2] += r[j].nb; a[3] += r[j].cnt;
-        a[4] += (r[j].cnt && r[j].cnt <= EF_BIG_CHUNKS) ? r[j].cnt - 1 : 0;
+        a[4] += (r[j].cnt && r[j].cnt <= BIGC) ? r[j].cnt - 1 : 0;
     }
     block_exscan<5, NT / 64>(a, tot, sh);
     a[0] += P[0]; a[1] += P[1]; a[2] += P[2];
@@ -478,7 +482,7 @@ __global__ void __launch_bounds__(NT) k_ef_offsets(const uint64_t *ids, const ui
         const uint32_t m = (uint32_t)(o[j + 1] - o[j]);
         if (l < nlist) { low_off[l] = a[0]; high_off[l] = a[1]; batch_off[l] = a[2]; }
         if (r[j].cnt) recs[P[3] + a[3]] = ef_make_rec(l, 0, o[j], m, u[j], lb[j], a[0], a[1], a[2]);
-        if (r[j].cnt > EF_BIG_CHUNKS) {
+        if (r[j].cnt > BIGC) {
             EfBigList bl;
             bl.o0 = o[j]; bl.u = u[j]; bl.lw = a[0]; bl.hw = a[1]; bl.nb = a[2]; bl.rec0 = P[3] + a[3];
             bl.l = l; bl.m = m; bl.lb = lb[j]; bl.pad = 0;
@@ -489,7 +493,7 @@ __global__ void __launch_bounds__(NT) k_ef_offsets(const uint64_t *ids, const ui
         li.m = m; li.lb = lb[j];
         info[t * E + j] = li;  // (lists past the end: no chunks, x0 = the tile's count)
         a[0] += r[j].lw; a[1] += r[j].hw; a[2] += r[j].nb; a[3] += r[j].cnt;
-        a[4] += (r[j].cnt && r[j].cnt <= EF_BIG_CHUNKS) ? r[j].cnt - 1 : 0;
+        a[4] += (r[j].cnt && r[j].cnt <= BIGC) ? r[j].cnt - 1 : 0;
         if (l + 1u == nlist) {  // (exactly one thread of the last tile): the entries behind the last list, the totals
             low_off[nlist] = a[0]; high_off[nlist] = a[1]; batch_off[nlist] = a[2];
             EfSummary out;
@@ -1557,7 +1561,7 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
     VIDC_TRY(s_big.get(ctx, big_cap * sizeof(EfBigList) + 16));
     EfBigList *d_big = (EfBigList *)((char *)s_big.p + 16);
     uint32_t *d_nbig = s_big.as<uint32_t>();
-    VIDC_HIP(hipMemsetAsync(d_nbig, 0, 16, ctx->stream));
+    if (ntiles != 1u) VIDC_HIP(hipMemsetAsync(d_nbig, 0, 16, ctx->stream));  // (a single tile writes every record itself)
     VIDC_TRY(e->d_low_off.alloc(nlist + 1, ctx->dpool)); VIDC_TRY(e->d_high_off.alloc(nlist + 1, ctx->dpool));
     VIDC_TRY(e->d_batch_off.alloc(nlist + 1, ctx->dpool));
     VIDC_TRY(e->d_lbits.alloc(nlist ? nlist : 1, ctx->dpool)); VIDC_TRY(e->d_universe.alloc(nlist ? nlist : 1, ctx->dpool));
@@ -1583,7 +1587,7 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
                            e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
                            hs, d_big, d_nbig);
     }
-    if (max_list > (uint64_t)EF_CHUNK * EF_BIG_CHUNKS)  // (some list is that long)
+    if (ntiles != 1u && max_list > (uint64_t)EF_CHUNK * EF_BIG_CHUNKS)  // (some list is that long)
         hipLaunchKernelGGL(k_ef_big_recs, dim3((uint32_t)std::min<uint64_t>(big_cap, (uint64_t)ctx->num_cu * 32)), dim3(64), 0, ctx->stream,
                            d_big, d_nbig, s_recs.as<EfChunkRec>());
     VIDC_HIP(hipGetLastError());

@@ -909,14 +909,12 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
 #define U2_DEC_TOP_L(LA, LB, LC, LD)                   /* (labels of the two refill side paths and their returns) */ \
     "s_and_b32 s46, s58, s73\n"                        /* slice 1: x_hi (codec.cpp:78-90) */ \
     "s_lshr_b64 s[58:59], s[58:59], s77\n" \
-    "s_lshr_b32 s68, s58, 31\n" \
-    "s_or_b32 s68, s68, s59\n" \
+    "s_lshr_b64 s[98:99], s[58:59], 31\n"             /* (SCC = head >= 2^31: one instruction instead of shift + or, round 5) */ \
     "s_cbranch_scc0 " LA "f\n"                         /* head < 2^31: refill */ \
     LB ":\n" \
     "s_and_b32 s40, s58, s74\n"                        /* slice 0: x_lo */ \
     "s_lshr_b64 s[58:59], s[58:59], s76\n" \
-    "s_lshr_b32 s68, s58, 31\n" \
-    "s_or_b32 s68, s68, s59\n" \
+    "s_lshr_b64 s[98:99], s[58:59], 31\n" \
     "s_cbranch_scc0 " LC "f\n" \
     LD ":\n" \
     "s_lshl_b32 s46, s46, 16\n" \
@@ -1016,8 +1014,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     "s_addc_u32 s59, s53, 0\n" \
     "s_cmp_gt_u32 s68, " RSPAN "\n" \
     "s_cselect_b32 s71, 0, s70\n" \
-    "s_lshr_b32 s68, s58, 31\n"                        /* head' < 2^31: the push refills (generic code) */ \
-    "s_or_b32 s68, s68, s59\n" \
+    "s_lshr_b64 s[98:99], s[58:59], 31\n"             /* head' < 2^31: the push refills (generic code) */ \
     "s_cselect_b32 s71, s71, 0\n" \
     "s_cmp_lt_u32 s69, s71\n"
 // the same without the ring test: copies of the loop body whose ring state the last copy (or the entry) has vouched for
@@ -1027,8 +1024,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     "s_add_u32 s72, s72, s64\n"                        /* rank */ \
     "s_add_u32 s58, s52, s72\n"                        /* head' = H * nmax + rank */ \
     "s_addc_u32 s59, s53, 0\n" \
-    "s_lshr_b32 s68, s58, 31\n"                        /* head' < 2^31: the push refills (generic code) */ \
-    "s_or_b32 s68, s68, s59\n" \
+    "s_lshr_b64 s[98:99], s[58:59], 31\n"             /* head' < 2^31: the push refills (generic code) */ \
     "s_cselect_b32 s71, s70, 0\n" \
     "s_cmp_lt_u32 s69, s71\n"
 // Ring of the eight-copy loop: a step pops at most two words and pushes at most one, so eight steps are safe while the ring
@@ -1088,8 +1084,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     "s_sub_u32 s87, s87, s72\n"
 #define U2_DEC_OUTER U2_DEC_OUTER_T("-2", "59")
 #define U2_DEC_OUTER_T(RLO, RSPAN) \
-    "s_lshr_b32 s68, s58, 31\n" \
-    "s_or_b32 s68, s68, s59\n" \
+    "s_lshr_b64 s[98:99], s[58:59], 31\n" \
     "s_cselect_b32 s99, 0, 1\n"                        /* head < 2^31 */ \
     "s_sub_u32 s68, s60, s61\n" \
     "s_add_u32 s68, s68, " RLO "\n" \
