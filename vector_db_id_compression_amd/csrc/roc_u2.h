@@ -321,18 +321,17 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "s_set_gpr_idx_on s43, gpr_idx(DST)\n" \
     "v_mov_b32 v64, v13\n" \
     "s_set_gpr_idx_off\n" U2P(142) \
-    LSHR                                               /* next index pop must not renormalise (U2_SAFE_HI): s68 = B_lo >> 31 */ \
-    "s_add_u32 s68, s68, s59\n" \
-    "s_add_u32 s68, s68, -1\n" \
-    "s_cmp_ge_u32 s68, 0x7ff80000\n" \
-    "s_cselect_b32 s71, 0, s70\n" \
+    LSHR                                               /* next index pop must not renormalise (u2_needs_generic): SCC = B >= 2^31 */ \
+    "s_cselect_b32 s71, s70, 0\n" \
+    "s_cmp_ge_u32 s59, 0x7ff80000\n" \
+    "s_cselect_b32 s71, 0, s71\n" \
     RING \
     "s_add_u32 s69, s69, 1\n" U2P(143) \
     "s_cmp_lt_u32 s69, s71\n" \
     TAIL
 #define U2_ENC_ORDER \
     "s_mov_b32 m0, s69\n" \
-    "s_lshr_b32 s68, s58, 31\n"                        /* (first instruction of the exit test: m0 settles meanwhile) */ \
+    "s_lshr_b64 s[98:99], s[58:59], 31\n"             /* (first instruction of the exit test, SCC = B >= 2^31: m0 settles meanwhile) */ \
     "v_writelane_b32 v6, s40, m0\n"
 
 // store order-ring lanes [0, s72) at order[s87 ...]; s87 += s72
@@ -347,11 +346,10 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
 
 // what the fast loop falls into: ring spill, block change, and the decision to go on
 #define U2_ENC_OUTER(FLUSH) \
-    "s_lshr_b32 s68, s58, 31\n"                        /* the index-pop test of the next step */ \
-    "s_add_u32 s68, s68, s59\n" \
-    "s_add_u32 s68, s68, -1\n" \
-    "s_cmp_ge_u32 s68, 0x7ff80000\n" \
-    "s_cselect_b32 s99, 1, 0\n" \
+    "s_lshr_b64 s[98:99], s[58:59], 31\n"             /* the index-pop test of the next step */ \
+    "s_cselect_b32 s99, 0, 1\n" \
+    "s_cmp_ge_u32 s59, 0x7ff80000\n" \
+    "s_cselect_b32 s99, 1, s99\n" \
     "s_sub_u32 s68, s60, s61\n" \
     "s_cmp_lt_u32 s68, 48\n"                           /* (U2_RING_ROOM) */ \
     "s_cbranch_scc1 3f\n" \
@@ -398,13 +396,13 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "s_waitcnt vmcnt(0)\n"
 
 // The index pop of a step renormalises when head_hi >= nmax * floor(2^31 / nmax) (push) or head < 2^31 (refill)
-// (codec.cpp:27-35).  nmax * floor(2^31 / nmax) > 2^31 - nmax >= 2^31 - 2^18, so with t = head_hi + (head_lo >> 31) - 1
-// (0xffffffff exactly when head < 2^31) "t < 2^31 - 2^19" is a sufficient test for the fast path that needs no
-// per-divisor constant; the few extra heads it rejects take the generic step.  Heads in [2^31, 2^32) are common (3 % of
+// (codec.cpp:27-35).  nmax * floor(2^31 / nmax) > 2^31 - nmax >= 2^31 - 2^18, so "head >= 2^31 and head_hi < 2^31 - 2^19"
+// is a sufficient test for the fast path that needs no per-divisor constant (the loops test B = head - c(x), c(x) < 2^31: B_hi
+// is at most one below head_hi); the few extra heads it rejects take the generic step.  Heads in [2^31, 2^32) are common (3 % of
 // the steps of a 20-bit list: every fourth renormalisation of the second slice leaves one) and stay on the fast path.
 #define U2_SAFE_HI 0x7ff80000u
 __device__ __forceinline__ bool u2_needs_generic(uint64_t head) {
-    return (uint32_t)(head >> 32) + ((uint32_t)head >> 31) - 1u >= U2_SAFE_HI;
+    return (head >> 31) == 0ull || (uint32_t)(head >> 32) >= U2_SAFE_HI;  // (round 5: the form the loops test with one 64-bit shift)
 }
 template <int UB, bool WANT_ORDER>
 __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div *__restrict__ dtab) {
@@ -540,16 +538,16 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
 #define U2_STEP_X(ORDER, LSHR) U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT_T(ORDER, LSHR, "", "s_cbranch_scc0 7f\n")
             if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY "1:\n" U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "")
                                        U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT(U2_ENC_ORDER, "") "7:\n" U2_ENC_OUTER(U2_ORDER_FLUSH));
-            else U2_ENC_ASM(U2_ENC_ENTRY "1:\n" U2_STEP_X("", "s_lshr_b32 s68, s58, 31\n") U2_STEP_X("", "s_lshr_b32 s68, s58, 31\n") U2_STEP_X("", "s_lshr_b32 s68, s58, 31\n")
-                            U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT("", "s_lshr_b32 s68, s58, 31\n") "7:\n" U2_ENC_OUTER(""));
+            else U2_ENC_ASM(U2_ENC_ENTRY "1:\n" U2_STEP_X("", "s_lshr_b64 s[98:99], s[58:59], 31\n") U2_STEP_X("", "s_lshr_b64 s[98:99], s[58:59], 31\n") U2_STEP_X("", "s_lshr_b64 s[98:99], s[58:59], 31\n")
+                            U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT("", "s_lshr_b64 s[98:99], s[58:59], 31\n") "7:\n" U2_ENC_OUTER(""));
 #undef U2_STEP_X
         } else {
             // (round 4: the 18-bit bodies in eight / four copies with the ring test in the last one, like the 20-bit ones)
 #define U2_STEP_X1(ORDER, LSHR) U2_ENC_TOP_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT_T(ORDER, LSHR, "", "s_cbranch_scc0 7f\n")
             if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY "1:\n" U2_STEP_X1(U2_ENC_ORDER, "") U2_STEP_X1(U2_ENC_ORDER, "") U2_STEP_X1(U2_ENC_ORDER, "") U2_STEP_X1(U2_ENC_ORDER, "") U2_STEP_X1(U2_ENC_ORDER, "") U2_STEP_X1(U2_ENC_ORDER, "") U2_STEP_X1(U2_ENC_ORDER, "")
                                        U2_ENC_TOP_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT(U2_ENC_ORDER, "") "7:\n" U2_ENC_OUTER(U2_ORDER_FLUSH));
-            else U2_ENC_ASM(U2_ENC_ENTRY "1:\n" U2_STEP_X1("", "s_lshr_b32 s68, s58, 31\n") U2_STEP_X1("", "s_lshr_b32 s68, s58, 31\n") U2_STEP_X1("", "s_lshr_b32 s68, s58, 31\n")
-                            U2_ENC_TOP_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT("", "s_lshr_b32 s68, s58, 31\n") "7:\n" U2_ENC_OUTER(""));
+            else U2_ENC_ASM(U2_ENC_ENTRY "1:\n" U2_STEP_X1("", "s_lshr_b64 s[98:99], s[58:59], 31\n") U2_STEP_X1("", "s_lshr_b64 s[98:99], s[58:59], 31\n") U2_STEP_X1("", "s_lshr_b64 s[98:99], s[58:59], 31\n")
+                            U2_ENC_TOP_NL U2_ENC_MID_G1 U2_ENC_SLICE1("6") U2_ENC_L3_G1 U2_ENC_BOT("", "s_lshr_b64 s[98:99], s[58:59], 31\n") "7:\n" U2_ENC_OUTER(""));
 #undef U2_STEP_X1
         }
 #undef U2_ENC_ASM
@@ -667,11 +665,10 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
     "s_set_gpr_idx_on s43, gpr_idx(DST)\n" \
     "v_mov_b32 v64, v13\n" \
     "s_set_gpr_idx_off\n" \
-    LSHR                                               /* next index pop must not renormalise (U2_SAFE_HI): s68 = B_lo >> 31 */ \
-    "s_add_u32 s68, s68, s59\n" \
-    "s_add_u32 s68, s68, -1\n" \
-    "s_cmp_ge_u32 s68, 0x7ff80000\n" \
-    "s_cselect_b32 s71, 0, s70\n" \
+    LSHR                                               /* next index pop must not renormalise (u2_needs_generic): SCC = B >= 2^31 */ \
+    "s_cselect_b32 s71, s70, 0\n" \
+    "s_cmp_ge_u32 s59, 0x7ff80000\n" \
+    "s_cselect_b32 s71, 0, s71\n" \
     "s_sub_u32 s68, s60, s61\n"                        /* ring nearly full */ \
     "s_cmp_ge_u32 s68, 62\n" \
     "s_cselect_b32 s71, 0, s71\n" \
@@ -841,8 +838,8 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
 #define U2R_BODY(XORC)                                                                                                                      \
         if (WANT_ORDER) U2R_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP_R U2_ENC_MID_G1 U2_ENC_SLICE1_X("6", XORC) U2_ENC_L3_G1 U2_ENC_BOT_R_T(U2_ENC_ORDER, "", "s_cbranch_scc0 7f\n") \
                                     U2_ENC_TOP_R_NL U2_ENC_MID_G1 U2_ENC_SLICE1_X("6", XORC) U2_ENC_L3_G1 U2_ENC_BOT_R(U2_ENC_ORDER, "") "7:\n" U2_ENC_OUTER(U2_ORDER_FLUSH)); \
-        else U2R_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP_R U2_ENC_MID_G1 U2_ENC_SLICE1_X("6", XORC) U2_ENC_L3_G1 U2_ENC_BOT_R_T("", "s_lshr_b32 s68, s58, 31\n", "s_cbranch_scc0 7f\n") \
-                         U2_ENC_TOP_R_NL U2_ENC_MID_G1 U2_ENC_SLICE1_X("6", XORC) U2_ENC_L3_G1 U2_ENC_BOT_R("", "s_lshr_b32 s68, s58, 31\n") "7:\n" U2_ENC_OUTER(""))
+        else U2R_ENC_ASM(U2_ENC_ENTRY U2_ENC_TOP_R U2_ENC_MID_G1 U2_ENC_SLICE1_X("6", XORC) U2_ENC_L3_G1 U2_ENC_BOT_R_T("", "s_lshr_b64 s[98:99], s[58:59], 31\n", "s_cbranch_scc0 7f\n") \
+                         U2_ENC_TOP_R_NL U2_ENC_MID_G1 U2_ENC_SLICE1_X("6", XORC) U2_ENC_L3_G1 U2_ENC_BOT_R("", "s_lshr_b64 s[98:99], s[58:59], 31\n") "7:\n" U2_ENC_OUTER(""))
         if (NEB == 12) { U2R_BODY("0xfff"); } else { U2R_BODY("0x3ff"); }
 #undef U2R_BODY
 #undef U2R_ENC_ASM
