@@ -278,8 +278,7 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "s_ff1_i32_b64 s47, vcc\n" \
     "s_lshl_b32 s68, s47, 6\n" \
     "s_or_b32 s46, s46, s68\n" \
-    "s_lshl_b32 s65, s45, 2\n" \
-    "s_add_u32 s65, s65, s47\n" \
+    "s_lshl2_add_u32 s65, s45, s47\n"                  /* (entry * 4 + word) * 8 */ \
     "s_lshl_b32 s65, s65, 3\n" \
     "v_readlane_b32 s64, v35, s47\n" \
     "v_readlane_b32 s66, v30, s47\n" \
@@ -923,8 +922,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     "ds_read_b64 v[30:31], v28\n" \
     "s_bfe_u32 s47, s40, 0x20006\n"                    /* g */ \
     "s_bfe_u32 s65, s40, 0x30005\n"                    /* 32-bit half of the entry holding x */ \
-    "s_lshl_b32 s68, s45, 3\n" \
-    "s_or_b32 s65, s65, s68\n" \
+    "s_lshl3_add_u32 s65, s45, s65\n" \
     "s_lshl_b32 s65, s65, 2\n"
 #define U2_DEC_IDX_G1 \
     "s_lshr_b32 s45, s40, 6\n" \
@@ -932,8 +930,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     "v_lshlrev_b32_e64 v28, 3, s45\n" \
     "ds_read_b64 v[30:31], v28\n" \
     "s_bfe_u32 s65, s40, 0x10005\n" \
-    "s_lshl_b32 s68, s45, 1\n" \
-    "s_or_b32 s65, s65, s68\n" \
+    "s_lshl1_add_u32 s65, s45, s65\n" \
     "s_lshl_b32 s65, s65, 2\n"
 #define U2_DEC_MID \
     "s_lshr_b32 s43, s45, 6\n"                         /* L1 */ \
@@ -1260,11 +1257,9 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
 #endif
 #define U2B_DEC_IDX \
     "s_lshr_b32 s48, s40, s78\n"                       /* bucket */ \
-    "s_lshl_b32 s65, s48, 1\n" \
-    "v_mov_b32 v26, s65\n" \
+    "v_lshlrev_b32_e64 v26, 1, s48\n" \
     "ds_read_u16 v30, v26\n"                           /* members of the bucket so far */ \
-    "s_lshl_b32 s47, s48, 8\n" \
-    "v_lshl_add_u32 v28, v2, 2, s47\n" \
+    "v_lshl_add_u32 v28, s48, 8, v3\n"                 /* v3 = 4 * lane: the lane's member of the 256-byte row */ \
     U2B_ROW_LOAD \
     "s_xor_b32 s45, s48, 0xfff\n"                      /* entry (reversed) */
 #define U2B_DEC_MID \
@@ -1373,12 +1368,9 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
 //   s82 byte offset of the rows in LDS (= 2 x buckets)
 #define U2L_DEC_IDX \
     "s_lshr_b32 s48, s40, s78\n"                       /* bucket */ \
-    "s_lshl_b32 s65, s48, 1\n" \
-    "v_mov_b32 v26, s65\n" \
+    "v_lshlrev_b32_e64 v26, 1, s48\n" \
     "ds_read_u16 v30, v26\n"                           /* members of the bucket so far */ \
-    "s_lshl_b32 s47, s48, 8\n" \
-    "s_add_u32 s47, s47, s82\n" \
-    "v_lshl_add_u32 v28, v2, 2, s47\n" \
+    "v_lshl_add_u32 v28, s48, 8, v3\n"                 /* v3 = start of the rows in LDS + 4 * lane */ \
     "ds_read_b32 v31, v28\n"                           /* lane j: member j of the bucket's row */ \
     "s_xor_b32 s45, s48, 0xfff\n"                      /* entry (reversed) */
 #define U2L_DEC_MID \
@@ -1506,7 +1498,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
     v32u ra, rb;
 #pragma unroll
     for (int c = 0; c < 32; c++) { ra[c] = 0u; rb[c] = 0u; }
-    const uint32_t l3off = 0u;
+    const uint32_t l3off = lane * 4u + (LROWS ? VIDC_B2L_BUCKETS * 2u : 0u);  // (v3 of the loop: the lane's member inside a row)
     const uint32_t M1 = (1u << p1) - 1u, M0 = (1u << p0) - 1u;
     uint64_t *out = a.out + ooff;
     uint32_t *rows = LROWS ? (uint32_t *)(smem + VIDC_B2L_BUCKETS * 2u) : a.slots + rfl64(a.slots_off[wi]);
