@@ -242,8 +242,11 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "v_lshlrev_b32_e64 v28, 3, s45\n" \
     "ds_read_b64 v[30:31], v28\n"
 
-#define U2_ENC_SLICE1(XSH) U2_ENC_SLICE1_X(XSH, "0xfff")
-#define U2_ENC_SLICE1_X(XSH, XORC)                     /* XORC: entries of the bitmap - 1 (reversed entry order) */ \
+#define U2_ENC_SLICE1(XSH) U2_ENC_SLICE1_S("s_lshl_b32 s46, s46, " XSH "\n", "0xfff")
+#define U2_ENC_SLICE1_X(XSH, XORC) U2_ENC_SLICE1_S("s_lshl_b32 s46, s46, " XSH "\n", XORC)
+// four words per entry: the entry's id bits are shifted together with the word number in U2_ENC_L3_G4 (one fused shift-add)
+#define U2_ENC_SLICE1_G4 U2_ENC_SLICE1_S("", "0xfff")
+#define U2_ENC_SLICE1_S(SHIFT, XORC)                   /* XORC: entries of the bitmap - 1 (reversed entry order) */ \
     "s_and_b32 s62, s60, 63\n"                         /* slice 1 */ \
     "s_cmp_ge_u32 s55, s74\n" \
     "s_cselect_b32 s41, 0, s75\n" \
@@ -252,7 +255,7 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "s_addc_u32 s60, s60, 0\n" \
     "s_lshl_b64 s[58:59], s[56:57], s77\n"             /* B */ \
     "s_xor_b32 s46, s45, " XORC "\n" \
-    "s_lshl_b32 s46, s46, " XSH "\n"                   /* id bits of the entry */ \
+    SHIFT                                              /* id bits of the entry */ \
     "v_readlane_b32 s63, v13, s44\n" \
     "v_subrev_u32 v59, s44, v2\n"                      /* lane - L2 */ \
     "v_subrev_u32 v12, s63, v12\n" \
@@ -276,8 +279,8 @@ __device__ __forceinline__ uint32_t u2_slow_step(uint64_t &head, WStack &st, uin
     "v_mul_lo_u32 v48, v46, v9\n" \
     "v_add_u32 v13, v13, v59\n"                        /* row -= 1 in lanes below L2 */ \
     "s_ff1_i32_b64 s47, vcc\n" \
-    "s_lshl_b32 s68, s47, 6\n" \
-    "s_or_b32 s46, s46, s68\n" \
+    "s_lshl2_add_u32 s46, s46, s47\n"                  /* (entry, word) */ \
+    "s_lshl_b32 s46, s46, 6\n" \
     "s_lshl2_add_u32 s65, s45, s47\n"                  /* (entry * 4 + word) * 8 */ \
     "s_lshl_b32 s65, s65, 3\n" \
     "v_readlane_b32 s64, v35, s47\n" \
@@ -534,11 +537,11 @@ __global__ void __launch_bounds__(64) k_roc_encode_u2(RocEncArgs a, const U2Div 
               "s97", "s98", "s99")
         if (U::G == 4u) {
             // four steps per loop iteration: the taken branch at the end of a step costs ~6 cycles of instruction-buffer refill
-#define U2_STEP_X(ORDER, LSHR) U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT_T(ORDER, LSHR, "", "s_cbranch_scc0 7f\n")
+#define U2_STEP_X(ORDER, LSHR) U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1_G4 U2_ENC_L3_G4 U2_ENC_BOT_T(ORDER, LSHR, "", "s_cbranch_scc0 7f\n")
             if (WANT_ORDER) U2_ENC_ASM(U2_ENC_ENTRY "1:\n" U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "") U2_STEP_X(U2_ENC_ORDER, "")
-                                       U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT(U2_ENC_ORDER, "") "7:\n" U2_ENC_OUTER(U2_ORDER_FLUSH));
+                                       U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1_G4 U2_ENC_L3_G4 U2_ENC_BOT(U2_ENC_ORDER, "") "7:\n" U2_ENC_OUTER(U2_ORDER_FLUSH));
             else U2_ENC_ASM(U2_ENC_ENTRY "1:\n" U2_STEP_X("", "s_lshr_b64 s[98:99], s[58:59], 31\n") U2_STEP_X("", "s_lshr_b64 s[98:99], s[58:59], 31\n") U2_STEP_X("", "s_lshr_b64 s[98:99], s[58:59], 31\n")
-                            U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1("8") U2_ENC_L3_G4 U2_ENC_BOT("", "s_lshr_b64 s[98:99], s[58:59], 31\n") "7:\n" U2_ENC_OUTER(""));
+                            U2_ENC_TOP_NL U2_ENC_MID_G4 U2_ENC_SLICE1_G4 U2_ENC_L3_G4 U2_ENC_BOT("", "s_lshr_b64 s[98:99], s[58:59], 31\n") "7:\n" U2_ENC_OUTER(""));
 #undef U2_STEP_X
         } else {
             // (round 4: the 18-bit bodies in eight / four copies with the ring test in the last one, like the 20-bit ones)
@@ -913,8 +916,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     "s_lshr_b64 s[98:99], s[58:59], 31\n" \
     "s_cbranch_scc0 " LC "f\n" \
     LD ":\n" \
-    "s_lshl_b32 s46, s46, 16\n" \
-    "s_or_b32 s40, s40, s46\n"                         /* x */
+    "s_pack_ll_b32_b16 s40, s40, s46\n"                /* x = x_hi : x_lo (one instruction, round 5) */
 #define U2_DEC_IDX_G4 \
     "s_lshr_b32 s45, s40, 8\n" \
     "s_xor_b32 s45, s45, 0xfff\n"                      /* entry (reversed) */ \
@@ -922,25 +924,22 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
     "ds_read_b64 v[30:31], v28\n" \
     "s_bfe_u32 s47, s40, 0x20006\n"                    /* g */ \
     "s_bfe_u32 s65, s40, 0x30005\n"                    /* 32-bit half of the entry holding x */ \
-    "s_lshl3_add_u32 s65, s45, s65\n" \
-    "s_lshl_b32 s65, s65, 2\n"
+    "s_lshl3_add_u32 s65, s45, s65\n"                  /* (dword of the bitmap; U2_DEC_MID shifts it to a byte address) */
 #define U2_DEC_IDX_G1 \
     "s_lshr_b32 s45, s40, 6\n" \
     "s_xor_b32 s45, s45, 0xfff\n" \
     "v_lshlrev_b32_e64 v28, 3, s45\n" \
     "ds_read_b64 v[30:31], v28\n" \
     "s_bfe_u32 s65, s40, 0x10005\n" \
-    "s_lshl1_add_u32 s65, s45, s65\n" \
-    "s_lshl_b32 s65, s65, 2\n"
+    "s_lshl1_add_u32 s65, s45, s65\n"
 #define U2_DEC_MID \
     "s_lshr_b32 s43, s45, 6\n"                         /* L1 */ \
     "s_and_b32 s44, s45, 63\n"                         /* L2 */ \
     "s_set_gpr_idx_on s43, gpr_idx(SRC0)\n" \
     "v_mov_b32 v13, v64\n" \
     "s_set_gpr_idx_off\n" \
-    "s_and_b32 s48, s40, 63\n"                         /* b */ \
-    "s_bfm_b64 s[66:67], s48, 0\n"                     /* bits below b */ \
-    "v_mov_b32 v26, s65\n"                             /* insertion of x: after the read in LDS order */ \
+    "s_bfm_b64 s[66:67], s40, 0\n"                     /* bits below b = x mod 64 (the instruction reads six bits of its width operand) */ \
+    "v_lshlrev_b32_e64 v26, 2, s65\n"                  /* insertion of x: after the read in LDS order */ \
     "v_lshlrev_b32_e64 v27, s40, 1\n" \
     "s_mov_b64 exec, 1\n" \
     "ds_or_b32 v26, v27\n" \
