@@ -1752,6 +1752,7 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
     VIDC_HIP(hipSetDevice(ctx->device));
     double recs_ms = 0;
     bool recs_timed = false, publish_after_sync = false;
+    uint32_t pending_max_cnt = 0;
     std::unique_lock<std::mutex> g(e->mu, std::defer_lock);
     if (e->nbatches) {  // batch records: built once per object, on its first bulk decode (its time is part of that decode's)
         g.lock();
@@ -1779,7 +1780,10 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
             if (bounded) {
                 // (the records are published -- other contexts may use them -- when this call has synchronised; until then the
                 // object's lock stays with this call)
-                e->recs_max_cnt = (uint32_t)std::min<uint64_t>(e->max_list, EF_BATCH_BITS);
+                // (the bound is written to the object only when the records are published, so a call that fails
+                // between here and its wait leaves the object as it found it; the lock is held for the ~20 us of a small object's
+                // first decode -- only objects below EF_ENC_RECS_MAX batches come this way)
+                pending_max_cnt = (uint32_t)std::min<uint64_t>(e->max_list, EF_BATCH_BITS);
                 publish_after_sync = true;
             } else {
                 VIDC_HIP(hipMemcpyAsync(h_mx.p, s_mx.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1794,8 +1798,9 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     if (e->nbatches) {
         const dim3 grid((uint32_t)std::min<uint64_t>(e->nbatches, (uint64_t)ctx->num_cu * 256));
-        const uint32_t lds = std::min<uint32_t>(EF_BATCH_BITS, (e->recs_max_cnt + 63u) & ~63u) * 2;
-        const bool small = e->recs_max_cnt <= 256;
+        const uint32_t max_cnt = publish_after_sync ? pending_max_cnt : e->recs_max_cnt;
+        const uint32_t lds = std::min<uint32_t>(EF_BATCH_BITS, (max_cnt + 63u) & ~63u) * 2;
+        const bool small = max_cnt <= 256;
         if (e->narrow && small)
             hipLaunchKernelGGL((k_ef_decode_rec<uint32_t, 4>), grid, dim3(64), lds, ctx->stream, e->d_low.p, e->d_high.p,
                                e->d_recs.p, (uint32_t)e->nbatches, d_out);
@@ -1814,7 +1819,7 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
     VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-    if (publish_after_sync) { e->recs_ready = true; g.unlock(); }
+    if (publish_after_sync) { e->recs_max_cnt = pending_max_cnt; e->recs_ready = true; g.unlock(); }
     if (recs_timed) {
         float rms = 0;
         if (hipEventElapsedTime(&rms, ctx->ev_chain[0], ctx->ev_chain[1]) == hipSuccess) recs_ms = rms;

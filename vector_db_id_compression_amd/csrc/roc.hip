@@ -455,6 +455,8 @@ enum DecClass { DC_TINY = 0, DC_U18, DC_U20, DC_GSMALL, DC_G8K, DC_G16K, DC_GMID
                 DC_GRP0, DC_GRP2, DC_GRP3, DC_GRP4,   // row-per-list decoder by bucket bits 8 + F (roc_grp.h)
                 DC_LANEP, DC_LANEQ, DC_COUNT };        // 257..512 / 513..1024 ids on a pair / quad of lanes, ids in registers (k_roc_decode_lane_reg<.., 2 / 4>)
 constexpr uint64_t B2_MIN_LIST = 4096;
+#define VIDC_LANE_ALIGN_DEFAULT 16u        // bucket rows of the lane decoders on 64-byte boundaries (S2 decode 70.9 -> 69.8 ms: DESIGN section 13)
+constexpr uint32_t B2_MASK_MIN_CHAINS = 512;  // k_roc_decode_b2 launches of this many chains size their row loads by the member count
 constexpr size_t B2_CAP = 1024;      // chains of k_roc_decode_b2 per call (four per CU of an MI355X: 1 MiB of member rows each)
 constexpr size_t B2_TOP_CAP = 5120;  // ... of a call with more long chains than that: every list beyond 16 384 ids (comment at the planner)
 
@@ -468,6 +470,7 @@ struct DecPlan {
     bool lean = false;               // graph rows, lane decoder: item k == request k, no scratch / offset arrays
     bool tiny_lane = false;          // DC_TINY items run on the lane-per-list kernel
     bool gsmall_lrows = false;       // DC_GSMALL items keep their member rows in LDS (33 KiB each: only for few lists)
+    uint32_t lane_align = 4;         // slots a bucket row of the lane decoders is aligned / padded to (roc_lane_cap_nb)
     uint64_t implicit = 0;           // lean plan without a work list: items are rows 0..implicit-1
     DecPlan() = default;
     DecPlan(const DecPlan &) = default;
@@ -1712,6 +1715,11 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
     p.slots_off = vec_pool<uint64_t>().take(total_items); p.slots_off.resize(total_items);
     uint64_t so = 0, sl = 0;
     size_t k = 0;
+    {   // VIDC_LANE_ALIGN=4 / 16 (measurement switch): bucket rows of the lane decoders on 16- / 64-byte boundaries
+        const char *ae = std::getenv("VIDC_LANE_ALIGN");
+        p.lane_align = ae ? (std::atoi(ae) >= 16 ? 16u : 4u) : VIDC_LANE_ALIGN_DEFAULT;
+    }
+    const uint64_t la = p.lane_align;
     const uint64_t *offs = r->offsets.data();
     const bool have_nwords = r->meta_host;
     for (int c = 0; c < DC_COUNT; c++) {
@@ -1733,17 +1741,17 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             if (c == DC_LANEP || c == DC_LANEQ) {
                 slot = 0;  // no scratch of any kind
             } else if (c == DC_LANE) {
-                sl = (sl + 3) & ~(uint64_t)3;  // rows are read as uint4
+                sl = (sl + la - 1) & ~(la - 1);  // rows are read as uint4
                 slot = sl;
-                sl += 64ull * roc_lane_cap((uint32_t)n);
+                sl += 64ull * roc_lane_cap_nb<64>((uint32_t)n, p.lane_align);
             } else if (c == DC_LANE64) {
-                sl = (sl + 3) & ~(uint64_t)3;
+                sl = (sl + la - 1) & ~(la - 1);
                 slot = sl;
-                sl += 256ull * roc_lane_cap_nb<256>((uint32_t)n);
+                sl += 256ull * roc_lane_cap_nb<256>((uint32_t)n, p.lane_align);
             } else if (c == DC_LANE128) {
-                sl = (sl + 3) & ~(uint64_t)3;
+                sl = (sl + la - 1) & ~(la - 1);
                 slot = sl;
-                sl += 128ull * roc_lane_cap_nb<128>((uint32_t)n);
+                sl += 128ull * roc_lane_cap_nb<128>((uint32_t)n, p.lane_align);
             } else if (c >= DC_GRP0) {
                 sl = (sl + 15) & ~(uint64_t)15;  // member rows of 32 .. 96 u32: 64-byte aligned
                 slot = sl;
@@ -1901,6 +1909,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         b.out_off = (out_off_host && !p.lean) ? s_out_off.as<uint64_t>() + base[c] : nullptr;
         b.scratch_off = d_scr_off ? d_scr_off + base[c] : nullptr;
         b.slots_off = d_slots_off ? d_slots_off + base[c] : nullptr;
+        b.row_align = p.lane_align;
         switch (c) {
             case DC_TINY:
                 if (p.tiny_lane) {  // one list per lane (roc_lane.h)
@@ -1983,7 +1992,12 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                 const bool pf = pfe && pfe[0] == '1';
                 // VIDC_CHAIN_PRIO=1: s_setprio by chain length (roc_u2.h)
                 if (env_on("VIDC_CHAIN_PRIO")) b.lpw = (uint32_t)p.max_n[DC_B2];
-                if (pf) hipLaunchKernelGGL((k_roc_decode_b2<0, true>), dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
+                // VIDC_B2_MASK=1 / 0: the row load under exec = lanes below the bucket's member count (roc_u2.h, U2B_DEC_IDX_MC: a third
+                // of the sectors, a later load) / the whole row at once.  Default: calls of many chains, whose rows come from HBM.
+                const char *mke = std::getenv("VIDC_B2_MASK");
+                const bool mk = mke ? mke[0] == '1' : b.nwork >= B2_MASK_MIN_CHAINS;
+                if (pf) hipLaunchKernelGGL((k_roc_decode_b2<0, 1>), dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
+                else if (mk) hipLaunchKernelGGL((k_roc_decode_b2<0, 2>), dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
                 else hipLaunchKernelGGL(k_roc_decode_b2<0>, dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
                 break;
             }

@@ -95,6 +95,7 @@ struct RocDecArgs {
     uint32_t *status;           // [nlist]
     const uint32_t *mt;
     uint32_t lpw;               // lane-per-list kernels: lists per wavefront (0 = 64)
+    uint32_t row_align;         // bucket-row lane decoders: rows are aligned to / padded to this many slots (0 / 4 or 16: the plan's)
 };
 
 #define VIDC_DEC_CAP 16u       // members per fine bucket before spilling to the overflow list (lists <= 32768)

@@ -422,6 +422,13 @@ __host__ __device__ inline uint32_t roc_lane_cap_nb(uint32_t n) {
     // and the pass that redoes them on the wave-per-list kernels waited for the whole decode first: 2.5 ms behind a 71 ms call)
     return (((n / (uint32_t)NB) * 2u + 16u) + 3u) & ~3u;
 }
+// align = 16 (round 5, RocDecArgs::row_align): rows start on 64-byte boundaries and are a multiple of 64 bytes long, so the four
+// 16-byte chunks a step requests together lie in ONE 64-byte sector -- at align = 4 a row starts anywhere and they straddle two
+// sectors three times out of four (S2: 1.45 sectors fetched per decoded id of the lane classes)
+template <int NB>
+__host__ __device__ inline uint32_t roc_lane_cap_nb(uint32_t n, uint32_t align) {
+    return align > 4u ? (roc_lane_cap_nb<NB>(n) + align - 1u) & ~(align - 1u) : roc_lane_cap_nb<NB>(n);
+}
 __host__ __device__ inline uint32_t roc_lane_cap(uint32_t n) { return roc_lane_cap_nb<64>(n); }
 
 // sum of the bytes j < t (t <= 8) of the 8-byte value v
@@ -484,7 +491,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane(RocDecArgs a, const Lane
     const uint32_t P = have ? a.prec[l] : 0u;
     const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
     const uint32_t bsh = P > G::BITS ? P - G::BITS : 0u;
-    const uint32_t cap = roc_lane_cap_nb<NB>(n);
+    const uint32_t cap = roc_lane_cap_nb<NB>(n, a.row_align);
 #pragma unroll
     for (int g = 0; g < (int)G::NG; g++) cnt4[g * 64 + lane] = make_uint4(0, 0, 0, 0);
 #pragma unroll

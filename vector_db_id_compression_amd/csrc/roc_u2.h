@@ -714,7 +714,7 @@ __device__ __forceinline__ uint32_t u2r_slow_step(uint64_t &head, WStack &st, ui
 // to 65 536 ids: sixteen blocks of 4096 positions in lanes 0..15 of the level-1 counters, rows 0..15)
 #define VIDC_R2_LDS_BYTES(NEB) ((8u << (NEB)) + 16u)
 template <bool WANT_ORDER, int NEB = 12>
-__global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div *__restrict__ dtab) {
+__device__ __forceinline__ void roc_encode_r2_body(RocEncArgs a, const U2Div *__restrict__ dtab) {
     static_assert(NEB == 12 || NEB == 10, "bitmap entries");
     constexpr uint32_t NE = 1u << NEB, NBLK = NE / 64u;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -865,6 +865,10 @@ __global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div 
         a.draws[l] = st.draws;
         a.status[l] = st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
     }
+}
+template <bool WANT_ORDER, int NEB = 12>
+__global__ void __launch_bounds__(64) k_roc_encode_r2(RocEncArgs a, const U2Div *__restrict__ dtab) {
+    roc_encode_r2_body<WANT_ORDER, NEB>(a, dtab);
 }
 
 // ===============================================================================================================
@@ -1261,7 +1265,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
     "v_lshl_add_u32 v28, s48, 8, v3\n"                 /* v3 = 4 * lane: the lane's member of the 256-byte row */ \
     U2B_ROW_LOAD \
     "s_xor_b32 s45, s48, 0xfff\n"                      /* entry (reversed) */
-#define U2B_DEC_MID \
+#define U2B_DEC_MID_1 \
     "s_lshr_b32 s43, s45, 6\n"                         /* L1 */ \
     "s_and_b32 s44, s45, 63\n"                         /* L2 */ \
     "s_set_gpr_idx_on s43, gpr_idx(SRC0)\n" \
@@ -1281,7 +1285,8 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
     "s_and_b64 s[66:67], s[66:67], vcc\n"              /* members of the bucket that are still in flight */ \
     "s_bcnt1_i32_b64 s64, s[66:67]\n" \
     "s_and_b64 s[66:67], s[66:67], s[80:81]\n" \
-    "s_bcnt1_i32_b64 s46, s[66:67]\n"                  /* ... of them below x */ \
+    "s_bcnt1_i32_b64 s46, s[66:67]\n"                  /* ... of them below x */
+#define U2B_DEC_MID_2 \
     "s_and_b32 m0, s60, 63\n"                          /* index push, first half (codec.cpp:44-63): renormalise H */ \
     "s_cmp_ge_u32 s59, s62\n" \
     "v_writelane_b32 v5, s58, m0\n" \
@@ -1297,6 +1302,28 @@ __global__ void __launch_bounds__(64) k_roc_decode_u2(RocDecArgs a, const U2Div 
     "v_mov_b32 v64, v13\n" \
     "s_set_gpr_idx_off\n" \
     "s_mov_b32 m0, s69\n"
+#define U2B_DEC_MID U2B_DEC_MID_1 U2B_DEC_MID_2
+// Round 5, second half: the row load sized by the bucket's member count (k_roc_decode_b2<0, 2>).  A step of the plain form reads the
+// whole 256-byte row -- four 64-byte sectors of a 1 MiB table that no cache holds -- although the bucket has 4 .. 16 members for most
+// of a list's life (16 385 .. 65 536 ids over 4096 buckets): 19.6 GB of S2's 134 GB fetched.  Here the load waits for the LDS read
+// of the count (~20 instructions later) and runs under exec = lanes below the count: one sector for up to 16 members, none for an
+// empty bucket.  Lanes that are not loaded keep a stale member; the rank only looks at lanes below the visible count
+// (U2B_DEC_RANK_TAIL).  A lone chain pays for the later load (0.207 -> 0.254 us per step at 30 bits) and keeps the plain form; a call of
+// hundreds of chains does not (S2 decode 70.9 against 70.9 ms interleaved) and fetches a third.  Measured next to it and dropped: lanes
+// 0 .. 15 at once as before + the lanes beyond under the count (0.227 us alone, S2 decode +1.2 ms: two more scalar instructions).
+#define U2B_DEC_IDX_MC \
+    "s_lshr_b32 s48, s40, s78\n"                       /* bucket */ \
+    "v_lshlrev_b32_e64 v26, 1, s48\n" \
+    "ds_read_u16 v30, v26\n"                           /* members of the bucket so far */ \
+    "v_lshl_add_u32 v28, s48, 8, v3\n" \
+    "s_xor_b32 s45, s48, 0xfff\n"                      /* entry (reversed) */
+#define U2B_DEC_MID_MC U2B_DEC_MID_1 \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "v_cmp_gt_u32 s[80:81], v30, v2\n"                 /* lanes holding a member */ \
+    "s_mov_b64 exec, s[80:81]\n" \
+    U2B_ROW_LOAD \
+    "s_mov_b64 exec, -1\n" \
+    U2B_DEC_MID_2
 // (round 5: the bucket's member count stays in the VGPR the LDS read left it in -- every lane holds it --, so the slot address, the
 // new count, the "visible in memory" bound and the overflow test are vector instructions: 5 scalar instructions instead of 15 in this
 // tail.  A chain alone pays four cycles per instruction of either kind, but with four chains per SIMD the scalar slot is the one they
@@ -1455,9 +1482,11 @@ __device__ __forceinline__ uint32_t u2b_slow_dec_step(uint64_t &head, WStack &st
 #define VIDC_B2L_LOAD 30u             // ids per bucket (Poisson(30) exceeds 64 once in ~10^8 buckets)
 #define VIDC_B2L_LDS_BYTES(BK) ((BK) * 2u + (BK) * VIDC_B2L_CAP * 4u)
 // BK = 0: 4096 buckets, member rows in global memory; BK = 32 / 64 / 128 / 256: that many buckets, rows in LDS
-template <int BK, bool PF = false>
-__global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div *__restrict__ dtab) {
-    static_assert(!PF || BK == 0, "the look-ahead is for rows in global memory");
+// MODE (BK = 0): 0 whole-row load, 1 look-ahead (U2B_DEC_PF), 2 row load sized by the member count (U2B_DEC_IDX_MC)
+template <int BK, int MODE = 0>
+__device__ __forceinline__ void roc_decode_b2_body(RocDecArgs a, const U2Div *__restrict__ dtab) {
+    static_assert(MODE == 0 || BK == 0, "look-ahead and sized loads are for rows in global memory");
+    constexpr bool PF = MODE == 1;
     constexpr bool LROWS = BK != 0;
     constexpr uint32_t VIDC_B2L_BUCKETS = LROWS ? (uint32_t)BK : 4096u;
     // (dynamic LDS, the kernel's only allocation: the asm addresses the bucket sizes from LDS offset 0, like the bitmap of
@@ -1542,6 +1571,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
               "s96", "s97", "s98", "s99")
         if (LROWS) U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP8(U2L_DEC_IDX, U2L_DEC_MID, U2L_DEC_RANK) U2_DEC_OUTER_T("-18", "35"));
         else if (PF) U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP8(U2B_DEC_IDX, U2B_DEC_MID, U2B_DEC_RANK_PF) U2_DEC_OUTER_T("-18", "35"));
+        else if (MODE == 2) U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP8(U2B_DEC_IDX_MC, U2B_DEC_MID_MC, U2B_DEC_RANK) U2_DEC_OUTER_T("-18", "35"));
         else U2B_DEC_ASM(U2_DEC_ENTRY U2_DEC_LOOP8(U2B_DEC_IDX, U2B_DEC_MID, U2B_DEC_RANK) U2_DEC_OUTER_T("-18", "35"));
 #undef U2B_DEC_ASM
         // clang-format on
@@ -1560,6 +1590,10 @@ __global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div 
         a.end_state[l] = (clean || retry) ? 0u : 1u;
         a.status[l] = retry ? 5u /* VIDC_ST_RETRY (roc_lane.h) */ : (st.err ? ((st.err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK);
     }
+}
+template <int BK, int MODE = 0>
+__global__ void __launch_bounds__(64) k_roc_decode_b2(RocDecArgs a, const U2Div *__restrict__ dtab) {
+    roc_decode_b2_body<BK, MODE>(a, dtab);
 }
 
 }  // namespace dev
