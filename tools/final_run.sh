@@ -18,6 +18,10 @@ VIDC_NO_AVX2=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu
 VIDC_NO_LENGTH_CLASSES=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_no_length_classes.txt
 # round 5: the measurement switches of DESIGN section 12 must not change a bit (look-ahead rows, chain priority, 65..256-id lists on lane pairs)
 VIDC_B2_PF=1 VIDC_CHAIN_PRIO=1 VIDC_PAIR_MIN=64 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_r5_switches.txt
+# round 5, last session: the forms the new defaults replaced (whole-row b2 loads, lane-decoder rows on 16-byte boundaries, no class priority) and
+# the sized row load forced for every b2 launch must not change a bit either
+VIDC_B2_MASK=0 VIDC_LANE_ALIGN=4 VIDC_ENC_PRIO=0 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_r5_old_defaults.txt
+VIDC_B2_MASK=1 VIDC_ENC_PRIO=7 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_r5_mask_prio.txt
 VIDC_POOL_POISON=1 timeout 1200 python -m pytest tests/test_gpu_roc.py tests/test_gpu_packed_ef.py tests/test_gpu_containers.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_pool_poison.txt
 timeout 300 python tools/bench_search_paths.py 2>&1 | tail -12 > gpurun_out/$R/search_paths.txt
 # S2 decoded 100 times per mode and compared with the first decode (the list-level flake hunt of round 3)
@@ -47,7 +51,7 @@ timeout 600 python tools/probe_grp.py 2>&1 | tail -10 > gpurun_out/$R/probe_grp.
 MIN_NS=500000 GPU_MAX_HW_QUEUES=8 bash tools/prof_s2.sh s2 2>&1 | grep "start" | grep -v "^\[" > gpurun_out/$R/s2_timeline.txt
 VIDC_SERIAL=1 MIN_NS=500000 GPU_MAX_HW_QUEUES=8 bash tools/prof_s2.sh s2 2>&1 | grep "start" | grep -v "^\[" > gpurun_out/$R/s2_timeline_serial.txt
 # S2 step (encode + decode of a fresh object) over 10 rounds, defaults against the round-3 policies (interleaved)
-ROUNDS=10 timeout 900 python tools/s2_ab.py - VIDC_B2_PF=1 VIDC_CHAIN_PRIO=1 2>&1 | grep -v amdgpu > gpurun_out/$R/s2_ab.txt
+ROUNDS=10 timeout 900 python tools/s2_ab.py - VIDC_B2_MASK=0 VIDC_LANE_ALIGN=4 VIDC_ENC_PRIO=0 VIDC_B2_MASK=0,VIDC_LANE_ALIGN=4,VIDC_ENC_PRIO=0 2>&1 | grep -v amdgpu > gpurun_out/$R/s2_ab.txt
 # HBM-side traffic (PMC) of S2 through the three codecs and of the 16 M-id call; kernel stats of the Elias-Fano / packed-bits benches
 for c in roc ef packed; do GPU_MAX_HW_QUEUES=8 bash tools/pmc_workload.sh $R s2 $c > /dev/null 2>&1; done
 GPU_MAX_HW_QUEUES=8 bash tools/pmc_workload.sh $R uniform_16m roc > /dev/null 2>&1
@@ -56,7 +60,7 @@ bash tools/prof_ef_s2.sh $R > gpurun_out/$R/prof_ef_s2.txt 2>&1
 # host-side phases of a 65 536-list call; the register-index construct of DESIGN section 11 outside the library
 python tools/trace_host.py uniform_16m 2>&1 | tail -14 > gpurun_out/$R/trace_u16.txt
 (hipcc --offload-arch=gfx950 -O2 tools/hw_gpr_idx_probe.hip -o /tmp/probe 2>&1 | tail -3; GPU_MAX_HW_QUEUES=8 timeout 400 /tmp/probe 10 4096 8192 10000 200000 100000) > gpurun_out/$R/hw_gpr_idx_probe.txt 2>&1
-cat gpurun_out/$R/pytest_r5_switches.txt gpurun_out/$R/pytest_pool_poison.txt gpurun_out/$R/search_paths.txt
+cat gpurun_out/$R/pytest_gpu.txt gpurun_out/$R/pytest_r5_old_defaults.txt gpurun_out/$R/pytest_r5_mask_prio.txt gpurun_out/$R/pytest_r5_switches.txt gpurun_out/$R/pytest_pool_poison.txt gpurun_out/$R/search_paths.txt
 cat gpurun_out/$R/s2_ab.txt gpurun_out/$R/pytest_lane_loop.txt gpurun_out/$R/pytest_no_length_classes.txt gpurun_out/$R/pytest_force_grp.txt gpurun_out/$R/pytest_wide.txt gpurun_out/$R/pytest_no_lane_pair.txt gpurun_out/$R/s2_repeated_decodes.txt gpurun_out/$R/s2_timeline.txt gpurun_out/$R/probe_grp.txt
 cat gpurun_out/$R/pytest_gpu.txt gpurun_out/$R/pytest_force_general.txt gpurun_out/$R/pytest_no_lane.txt gpurun_out/$R/pytest_force_lane.txt gpurun_out/$R/pytest_old_u.txt gpurun_out/$R/pytest_full_prepass_no_lane_reg.txt gpurun_out/$R/fuzz_chain.txt gpurun_out/$R/fuzz_chain_wide.txt gpurun_out/$R/chain_probe.txt gpurun_out/$R/fuzz_families.txt gpurun_out/$R/fuzz_ef_packed.txt gpurun_out/$R/bench_wt.txt gpurun_out/$R/smoke.txt
 python - <<PY

@@ -975,6 +975,12 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
     a.sid = s_sid.as<uint32_t>(); a.spos = nullptr; a.skey = nullptr; a.skey_off = nullptr;
     a.mt = ctx->d_mt;
 
+    // VIDC_ENC_PRIO=<mask>: s_setprio 3 for the general wave-per-list class (1), the 64- / 32-word lane classes (2), the
+    // position-bitmap chains (4).  Default 2: the few wavefronts of the 2049..4096-id lane classes run 4096 steps ahead of the other
+    // lane launches of their stream, and a step of theirs takes 9.5 us next to the chain classes (2.3 alone); first in their SIMD's
+    // arbitration the S2 encode is 53.5-53.9 instead of 54.7-55.6 ms (interleaved, profiles/r05v_s2_ab_enc_prio.txt; the other
+    // classes: no effect)
+    const int enc_prio = [] { const char *e = std::getenv("VIDC_ENC_PRIO"); return e ? std::atoi(e) : 2; }();
     tr.mark("alloc + upload");
     // Kernel classes run concurrently (one stream each): the longest chains on the caller's stream, shorter
     // classes on the auxiliary streams so that they fill the wave slots the long chains leave idle.
@@ -982,6 +988,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         if (!nwork) return VIDC_OK;
         RocEncArgs b = a;
         b.worklist = wl; b.nwork = nwork;
+        if (enc_prio & 1) b.lpw = 0x80000000u;
         size_t lds = (size_t)64 * rl_max * 12;
         hipLaunchKernelGGL(k_roc_encode_gen, dim3(nwork), dim3(64), lds, st_, b, rl_max);
         VIDC_HIP(hipGetLastError());
@@ -1055,6 +1062,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             L.push_back({"R2", wl_u20.empty() ? 0 : 1, [&](hipStream_t st_r2) -> int {
                 RocEncArgs b = a;
                 b.worklist = d_wl + base[9]; b.nwork = (uint32_t)wl_r2.size();
+                if (enc_prio & 4) b.lpw = 0x80000000u;
                 const U2Div *dt = (const U2Div *)ctx->d_u2tab;
                 // (the bitmap of a launch whose longest list -- the first of the work list -- has at most 65 536 positions: 8 KiB)
                 const bool small = r->offsets[wl_r2[0] + 1] - r->offsets[wl_r2[0]] <= 65536 && !env_on("VIDC_R2_BIG");
@@ -1172,13 +1180,14 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 uint32_t n_big = 0;
                 while (n_big < b.nwork && r->offsets[w[n_big] + 1] - r->offsets[w[n_big]] > 2048) n_big++;
                 n_big = std::min<uint32_t>(b.nwork, (n_big + b.lpw - 1u) / b.lpw * b.lpw);
+                if (enc_prio & 2) b.lpw |= 0x80000000u;
                 RocEncArgs b2 = b;
                 b2.worklist = b.worklist + n_big; b2.nwork = b.nwork - n_big;
                 b.nwork = n_big;
                 if (b.nwork)
                     L.push_back({"L64", 2, [&, b](hipStream_t st_) -> int {
                         const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
-                        const dim3 g1((b.nwork + b.lpw - 1u) / b.lpw);
+                        const dim3 g1((b.nwork + (b.lpw & 0xffffu) - 1u) / (b.lpw & 0xffffu));
                         if (want_perm) hipLaunchKernelGGL((k_roc_encode_lane<64, true>), g1, dim3(64), 0, st_, b, dt);
                         else hipLaunchKernelGGL((k_roc_encode_lane<64, false>), g1, dim3(64), 0, st_, b, dt);
                         VIDC_HIP(hipGetLastError());
@@ -1187,7 +1196,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 if (b2.nwork)
                     L.push_back({"L32", 2, [&, b2](hipStream_t st_) -> int {
                         const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
-                        const dim3 g2((b2.nwork + b2.lpw - 1u) / b2.lpw);
+                        const dim3 g2((b2.nwork + (b2.lpw & 0xffffu) - 1u) / (b2.lpw & 0xffffu));
                         if (want_perm) hipLaunchKernelGGL((k_roc_encode_lane<32, true>), g2, dim3(64), 0, st_, b2, dt);
                         else hipLaunchKernelGGL((k_roc_encode_lane<32, false>), g2, dim3(64), 0, st_, b2, dt);
                         VIDC_HIP(hipGetLastError());

@@ -310,6 +310,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_gen(RocEncArgs a, uint32_t rl
     uint64_t *words = (uint64_t *)smem;
     uint32_t *rowpref = (uint32_t *)(smem + (size_t)64u * rl_max * 8u);
     const uint32_t lane = lane_id();
+    if (a.lpw >> 31) __builtin_amdgcn_s_setprio(3);  // (VIDC_ENC_PRIO, roc.hip)
 
     for (uint32_t wi = blockIdx.x; wi < a.nwork; wi += gridDim.x) {
         // per-list scalars arrive through vector loads: pin them to SGPRs so the ANS chain stays scalar

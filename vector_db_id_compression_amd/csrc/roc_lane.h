@@ -258,7 +258,8 @@ __global__ void __launch_bounds__(64) k_roc_encode_lane(RocEncArgs a, const Lane
     uint64_t *gc = (uint64_t *)(smem + LaneEncGeom<NW>::BM_BYTES + LaneEncGeom<NW>::WC_BYTES);
     uint64_t *sc = (uint64_t *)(smem + LaneEncGeom<NW>::BM_BYTES + LaneEncGeom<NW>::WC_BYTES + LaneEncGeom<NW>::GC_BYTES);
     const uint32_t lane = lane_id();
-    const uint32_t lpw = a.lpw ? a.lpw : 64u;  // few lists in the launch: fewer per wavefront, more wavefronts (host)
+    if (a.lpw >> 31) __builtin_amdgcn_s_setprio(3);  // (VIDC_ENC_PRIO: this class first in its SIMD's arbitration, roc.hip)
+    const uint32_t lpw = (a.lpw & 0xffffu) ? (a.lpw & 0xffffu) : 64u;  // few lists in the launch: fewer per wavefront, more wavefronts (host)
     const uint32_t wi = blockIdx.x * lpw + lane;
     const bool have = lane < lpw && wi < a.nwork;
     const uint32_t l = have ? a.worklist[wi] : 0u;

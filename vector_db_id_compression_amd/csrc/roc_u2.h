@@ -720,6 +720,7 @@ __device__ __forceinline__ void roc_encode_r2_body(RocEncArgs a, const U2Div *__
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *bm = (uint64_t *)smem;
     const uint32_t lane = lane_id();
+    if (a.lpw >> 31) __builtin_amdgcn_s_setprio(3);  // (VIDC_ENC_PRIO, roc.hip)
     const uint32_t wi = blockIdx.x;
     if (wi >= a.nwork) return;
     const uint32_t l = rfl(a.worklist[wi]);
