@@ -88,10 +88,29 @@ __global__ void __launch_bounds__(64) k_packed_encode(const uint64_t *ids, const
 // 25 us of a 60 us encode of 16 M ids.)  A tile of 4096 lists counts its chunks and words, takes its place in a chained scan -- tile
 // numbers handed out by a counter in the order the workgroups start, so a tile only waits for tiles that are already running (as
 // k_roc_tail) -- and writes its part.  state: [gridDim.x chunk sums | gridDim.x word sums | tile counter], zero at the launch.
+// inclusive prefix sums over the 64 lanes in six DPP adds (row_shr 1 2 4 8, row_bcast 15 31); 64-bit values below 2^45 as two limbs
+__device__ __forceinline__ uint32_t pk_scan32(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+__device__ __forceinline__ uint64_t pk_scan64(uint64_t v) {
+    const uint32_t lo = pk_scan32((uint32_t)v & 0xfffffu), hi = pk_scan32((uint32_t)(v >> 20));
+    return ((uint64_t)hi << 20) + lo;
+}
+// Round 5: an object of ONE tile (up to 4095 lists: what a search-sized call holds) spreads its lists over all 256 threads -- `per`
+// lists per thread instead of 16 for the first nlist / 16 threads -- and the prefix sums over the threads are two DPP wave scans + one
+// exchange of four wave totals instead of sixteen Hillis-Steele rounds of two barriers each (1 M ids in 1024 lists: 17 -> ~8 us of a 27 us
+// encode + decode).
 __global__ void __launch_bounds__(256) k_packed_table(const uint64_t *__restrict__ offsets, uint32_t nlist, uint32_t bits,
                                                       unsigned long long *state, Chunk *__restrict__ chunks,
                                                       uint64_t *__restrict__ word_off, uint64_t *__restrict__ words) {
     __shared__ uint64_t sh[2][256];
+    __shared__ uint64_t wsum[2][4];
     __shared__ uint64_t tile_off_s[2];
     __shared__ uint32_t tile_s, qn;
     __shared__ struct { uint64_t a0; uint32_t l, cnt; } q[256];  // lists of many chunks: their items are written by the whole workgroup
@@ -102,60 +121,72 @@ __global__ void __launch_bounds__(256) k_packed_table(const uint64_t *__restrict
         __syncthreads();
     }
     const uint32_t tile = nt > 1u ? tile_s : 0u;
-    const uint64_t base = (uint64_t)tile * 4096u + t * 16u;
+    // lists (and the index nlist, which receives the total) per thread: 16 in a tile of 4096, fewer when the whole object is one tile
+    const uint32_t per = nt > 1u ? 16u : (nlist + 1u + 255u) / 256u;
+    const uint64_t base = (uint64_t)tile * 4096u + t * per;
     uint32_t cnt[16];
     uint64_t wc[16];
     uint64_t s0 = 0, s1 = 0;
     uint64_t prev = offsets[base < nlist ? base : nlist];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        const uint64_t l = base + j;
-        const uint64_t next = offsets[l + 1 < nlist ? l + 1 : nlist];
-        const uint64_t n = next - prev;
-        cnt[j] = l < nlist ? (uint32_t)((n + CHUNK_IDS - 1u) / CHUNK_IDS) : 0u;
-        wc[j] = l < nlist ? (n * bits + 63) / 64 + 1 : 0ull;  // +1: read_bits may touch the next word
-        prev = next;
-        s0 += cnt[j];
-        s1 += wc[j];
+        cnt[j] = 0u;
+        wc[j] = 0ull;
+        if ((uint32_t)j < per) {
+            const uint64_t l = base + j;
+            const uint64_t next = offsets[l + 1 < nlist ? l + 1 : nlist];
+            const uint64_t n = next - prev;
+            cnt[j] = l < nlist ? (uint32_t)((n + CHUNK_IDS - 1u) / CHUNK_IDS) : 0u;
+            wc[j] = l < nlist ? (n * bits + 63) / 64 + 1 : 0ull;  // +1: read_bits may touch the next word
+            prev = next;
+            s0 += cnt[j];
+            s1 += wc[j];
+        }
     }
-    sh[0][t] = s0;
-    sh[1][t] = s1;
+    // inclusive prefixes over the workgroup's threads (chunk / word counts of a tile stay far below 2^45)
+    uint64_t incl0 = pk_scan64(s0), incl1 = pk_scan64(s1);
+    if ((t & 63u) == 63u) { wsum[0][t >> 6] = incl0; wsum[1][t >> 6] = incl1; }
     __syncthreads();
-    for (uint32_t o = 1; o < 256; o <<= 1) {
-        const uint64_t x0 = t >= o ? sh[0][t - o] : 0, x1 = t >= o ? sh[1][t - o] : 0;
-        __syncthreads();
-        sh[0][t] += x0;
-        sh[1][t] += x1;
-        __syncthreads();
+    uint64_t sum0 = 0, sum1 = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4u; w++) {
+        const uint64_t x0 = wsum[0][w], x1 = wsum[1][w];
+        if (w < (t >> 6)) { incl0 += x0; incl1 += x1; }
+        sum0 += x0;
+        sum1 += x1;
     }
-    const uint64_t incl0 = sh[0][t], incl1 = sh[1][t];
     if (t == 0 && nt > 1u) {
-        const uint64_t sum0 = sh[0][255], sum1 = sh[1][255];
         // (no fence in front: the published values are the exchanges' own operands; a device-scope release writes back the XCD's whole L2)
         atomicExch(&state[tile], (1ull << 63) | sum0);
         atomicExch(&state[nt + tile], (1ull << 63) | sum1);
     }
-    uint64_t b0 = 0, b1 = 0;
-    for (uint32_t k = t; k < tile; k += 256u) {
-        unsigned long long x;
-        do { x = atomicAdd(&state[k], 0ull); } while (!(x >> 63));
-        b0 += x & ~(1ull << 63);
-        do { x = atomicAdd(&state[nt + k], 0ull); } while (!(x >> 63));
-        b1 += x & ~(1ull << 63);
-    }
-    __syncthreads();
-    sh[0][t] = b0;
-    sh[1][t] = b1;
-    __syncthreads();
-    for (uint32_t o = 128; o > 0; o >>= 1) {
-        if (t < o) { sh[0][t] += sh[0][t + o]; sh[1][t] += sh[1][t + o]; }
+    uint64_t t_off0 = 0, t_off1 = 0;
+    if (nt > 1u) {  // (uniform) sums of the tiles before this one
+        uint64_t b0 = 0, b1 = 0;
+        for (uint32_t k = t; k < tile; k += 256u) {
+            unsigned long long x;
+            do { x = atomicAdd(&state[k], 0ull); } while (!(x >> 63));
+            b0 += x & ~(1ull << 63);
+            do { x = atomicAdd(&state[nt + k], 0ull); } while (!(x >> 63));
+            b1 += x & ~(1ull << 63);
+        }
         __syncthreads();
+        sh[0][t] = b0;
+        sh[1][t] = b1;
+        __syncthreads();
+        for (uint32_t o = 128; o > 0; o >>= 1) {
+            if (t < o) { sh[0][t] += sh[0][t + o]; sh[1][t] += sh[1][t + o]; }
+            __syncthreads();
+        }
+        if (t == 0) { tile_off_s[0] = sh[0][0]; tile_off_s[1] = sh[1][0]; }
+        __syncthreads();
+        t_off0 = tile_off_s[0];
+        t_off1 = tile_off_s[1];
     }
-    if (t == 0) { tile_off_s[0] = sh[0][0]; tile_off_s[1] = sh[1][0]; }
-    __syncthreads();
-    uint64_t a0 = tile_off_s[0] + incl0 - s0, a1 = tile_off_s[1] + incl1 - s1;
+    uint64_t a0 = t_off0 + incl0 - s0, a1 = t_off1 + incl1 - s1;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
+        if ((uint32_t)j >= per) continue;
         const uint64_t l = base + j;
         if (l <= nlist) word_off[l] = a1;  // (index nlist receives the total)
         // (an index stored longest list first puts 16 lists of 128 chunks each into one thread: 10 M ids in 65 536 Zipf lists spent 40 us here)
