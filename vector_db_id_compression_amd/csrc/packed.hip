@@ -108,7 +108,7 @@ __device__ __forceinline__ uint64_t pk_scan64(uint64_t v) {
 // encode + decode).
 __global__ void __launch_bounds__(256) k_packed_table(const uint64_t *__restrict__ offsets, uint32_t nlist, uint32_t bits,
                                                       unsigned long long *state, Chunk *__restrict__ chunks,
-                                                      uint64_t *__restrict__ word_off, uint64_t *__restrict__ words) {
+                                                      uint64_t *__restrict__ word_off, uint64_t *__restrict__ words, uint32_t per) {
     __shared__ uint64_t sh[2][256];
     __shared__ uint64_t wsum[2][4];
     __shared__ uint64_t tile_off_s[2];
@@ -121,9 +121,8 @@ __global__ void __launch_bounds__(256) k_packed_table(const uint64_t *__restrict
         __syncthreads();
     }
     const uint32_t tile = nt > 1u ? tile_s : 0u;
-    // lists (and the index nlist, which receives the total) per thread: 16 in a tile of 4096, fewer when the whole object is one tile
-    const uint32_t per = nt > 1u ? 16u : (nlist + 1u + 255u) / 256u;
-    const uint64_t base = (uint64_t)tile * 4096u + t * per;
+    // `per` lists (and the index nlist, which receives the total) per thread, 256 * per in a tile (packed_table_per)
+    const uint64_t base = (uint64_t)tile * (256u * per) + t * per;
     uint32_t cnt[16];
     uint64_t wc[16];
     uint64_t s0 = 0, s1 = 0;
@@ -550,14 +549,21 @@ static int packed_setup(vidc_ctx *ctx, vidc_packed *p, uint64_t nlist, const uin
     VIDC_TRY(p->d_word_off.alloc(nlist + 1, ctx->dpool));
     VIDC_TRY(p->d_words.alloc(p->total_words ? p->total_words : 1, ctx->dpool));
     VIDC_TRY(p->d_chunks.alloc(p->nchunks ? p->nchunks : 1, ctx->dpool));
-    const uint32_t ntiles = (uint32_t)(nlist / 4096u + 1u);
+    // lists per thread of k_packed_table (256 threads per tile): an object of up to 4095 lists is ONE tile (no chained scan, no cleared
+    // state), larger ones aim at ~1024 tiles -- 65 536 lists ran as 17 tiles of 4096 on 17 of the 256 CUs (16.3 us of a 102 us
+    // encode + decode of 16 M ids), 2^20 lists as 257
+    // (VIDC_PACKED_TILE16=1, comparisons: tiles of 4096 lists whatever the object)
+    const uint32_t per = nlist + 1 <= 4096u ? (uint32_t)((nlist + 1 + 255u) / 256u)
+                         : (std::getenv("VIDC_PACKED_TILE16") ? 16u
+                            : (uint32_t)std::min<uint64_t>(16u, std::max<uint64_t>(1u, (nlist + 1 + 262143u) / 262144u)));
+    const uint32_t ntiles = (uint32_t)((nlist + 1 + 256u * per - 1u) / (256u * per));
     VIDC_TRY(keep.s_state.get(ctx, ((size_t)2 * ntiles + 1) * 8));
     VIDC_HIP(hipMemcpyAsync(p->d_offsets.p, h64, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     // (the device work of the set-up is part of the encode's kernel time: the caller reads ev0 .. ev1)
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     if (ntiles > 1u) VIDC_HIP(hipMemsetAsync(keep.s_state.p, 0, ((size_t)2 * ntiles + 1) * 8, ctx->stream));
     hipLaunchKernelGGL(k_packed_table, dim3(ntiles), dim3(256), 0, ctx->stream, p->d_offsets.p, (uint32_t)nlist, (uint32_t)bits,
-                       keep.s_state.as<unsigned long long>(), p->d_chunks.p, p->d_word_off.p, p->d_words.p);
+                       keep.s_state.as<unsigned long long>(), p->d_chunks.p, p->d_word_off.p, p->d_words.p, per);
     VIDC_HIP(hipGetLastError());
     return VIDC_OK;
 }
