@@ -263,6 +263,12 @@ def test_wide_precision_chain_kernels_match_general_kernels_and_oracle(roc, orac
         if want_perm:
             assert np.array_equal(r.perm(), r2.perm())
         _check_against_oracle(oracle, r, off, lists, r.perm() if want_perm else None, dec)
+        # (round 5: k_roc_decode_b2 launches of 512 chains or more load a bucket's row under exec = lanes below its member count,
+        # smaller launches the whole row; both forms forced here, incl. the clustered list's full row and its retry)
+        for form in ("0", "1"):
+            monkeypatch.setenv("VIDC_B2_MASK", form)
+            assert np.array_equal(r.decode_all().cpu().numpy().view(np.uint64), dec), ("VIDC_B2_MASK", form)
+        monkeypatch.delenv("VIDC_B2_MASK", raising=False)
         sel = np.array([6, 2, 0], dtype=np.uint64)  # a search's decode_lists takes the same kernels
         got, goff = r.decode_lists(sel)
         got = got.cpu().numpy().view(np.uint64)
