@@ -707,7 +707,11 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, c
 // FULL: the chunk holds exactly 64 R ids (every chunk but the last of a list; every chunk of an object of equal lists that are a
 // multiple of 64 R long): no lane predicate on the id slots -- the exec-mask arithmetic of `i < nc` for R slots in five loops was a
 // quarter of the kernel's 538 scalar instructions, and the kernel sits at the scalar AND the vector issue limit.
-template <int R, bool FULL = false>
+// V2 (round 5, last session: the kernel is bound by its vector instructions -- DESIGN section 13): the bit offset of an id's low bits is
+// lane * b (one 24-bit multiply per chunk) + a wave-uniform 64 r b instead of a full-rate-quarter 32-bit multiply per id slot; the
+// "fits 32 bits" check is one OR per slot and one test per chunk, "not beyond the universe" is tested on the chunk's last id only
+// (the chunk is ascending or it is handed back anyway).
+template <int R, bool FULL = false, bool V2 = false>
 __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const uint64_t *__restrict__ sorted_ids,
                                                    uint64_t *__restrict__ low, uint64_t *__restrict__ high,
                                                    uint32_t *__restrict__ hrank, Chunk *__restrict__ batches,
@@ -735,6 +739,7 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
     for (uint32_t w = lane; w < nlw32 + 2u; w += 64) img32[w] = 0;
     uint32_t pos[R];
     bool bad = (before64 >> 32) != 0;
+    uint32_t hi_or = 0;  // (V2)
     uint32_t carry = (uint32_t)before64;
     const uint32_t nr = FULL ? (uint32_t)R : (nc + 63u) >> 6;  // registers in use (wave-uniform: short lists skip the rest)
 #pragma unroll
@@ -746,22 +751,25 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
             const uint32_t up = lane_shr1(x);
             const uint32_t prev = lane ? up : carry;
             carry = rl(x, 63);
+            if (V2) hi_or |= (uint32_t)(v[r] >> 32);  // (slots past the chunk hold 0)
             if (FULL || i < nc) {
-                bad |= (uint32_t)(v[r] >> 32) != 0u || x > u || prev > x;
+                if (V2) bad |= prev > x;
+                else bad |= (uint32_t)(v[r] >> 32) != 0u || x > u || prev > x;
                 pos[r] = (x >> b) + (start + i);
             }
         }
     }
-    if (ballot(bad)) {
+    const uint32_t lr = (nc - 1u) >> 6, ll = (nc - 1u) & 63u;  // register / lane holding the last id
+    uint32_t last = 0, xlast = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < R; r++)
+        if (r == lr) { last = rl(pos[r], ll); if (V2) xlast = rl((uint32_t)v[r], ll); }
+    if (V2) bad |= hi_or != 0u;
+    if (ballot(bad) || (V2 && xlast > u)) {
         if (lane == 0) *(volatile uint32_t *)unsorted = 1u;  // (pinned host memory: every writer stores the same value)
         __syncthreads();
         return;  // the object is rebuilt by the general path
     }
-    const uint32_t lr = (nc - 1u) >> 6, ll = (nc - 1u) & 63u;  // register / lane holding the last id
-    uint32_t last = 0;
-#pragma unroll
-    for (uint32_t r = 0; r < R; r++)
-        if (r == lr) last = rl(pos[r], ll);
     const uint32_t wl = last >> 6;
     // word ownership as in k_ef_lowhigh: words [wlo, whi] are this chunk's
     const uint32_t before = (uint32_t)before64;
@@ -777,12 +785,13 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
     if (b) {  // low stream: the l low bits of every id into the LDS image, 32-bit halves
         __syncthreads();
         const uint32_t keep = b >= 32u ? 0xffffffffu : ((1u << b) - 1u);
+        const uint32_t lane_b = __umul24(lane, b);  // (V2)
 #pragma unroll
         for (uint32_t r = 0; r < R; r++) {
             const uint32_t i = lane + 64 * r;
             if (FULL || (r < nr && i < nc)) {
                 const uint32_t x = (uint32_t)v[r] & keep;
-                const uint32_t p = i * b, sh = p & 31u;
+                const uint32_t p = V2 ? lane_b + (64u * r) * b : i * b, sh = p & 31u;
                 atomicOr(&img32[p >> 5], x << sh);
                 if (sh + b > 32u) atomicOr(&img32[(p >> 5) + 1u], x >> (32u - sh));
             }
@@ -828,7 +837,7 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
 // (recs / sorted_ids are read-only for the whole launch: __restrict__ lets the record and the wave-uniform neighbour ids come
 // through scalar loads instead of 64 identical vector loads + v_readfirstlane each)
 // WITHFULL: full chunks take the predicate-free body (VIDC_EF_NO_FULL=1: the single-body kernels of round 3, for comparisons)
-template <int RMAX, bool SMALL, bool WITHFULL = true>
+template <int RMAX, bool SMALL, bool WITHFULL = true, bool V2 = false>
 __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *__restrict__ sorted_ids, const EfChunkRec *__restrict__ recs,
                                                      uint64_t nchunks, uint64_t *__restrict__ low, uint64_t *__restrict__ high,
                                                      uint32_t *__restrict__ hrank, Chunk *__restrict__ batches,
@@ -841,13 +850,13 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *__restrict_
         // (the predicate-free body pays for four id registers per lane -- 16 M ids in lists of 256: 66 -> 62 us, 10 M ids in 65 536
         // Zipf lists -3 % -- and not for eight: 64 M ids in lists of 1024 165 against 158 us, S2 3.19 against 3.23 ms, interleaved)
         if (!SMALL || (RMAX > 4 && nc > 256u))
-            ef_lowhigh32_chunk<RMAX>(rc, sorted_ids, low, high, hrank, batches, unsorted, drecs, win32, img32);
+            ef_lowhigh32_chunk<RMAX, false, V2>(rc, sorted_ids, low, high, hrank, batches, unsorted, drecs, win32, img32);
         else if (WITHFULL && nc == 256u)
-            ef_lowhigh32_chunk<4, true>(rc, sorted_ids, low, high, hrank, batches, unsorted, drecs, win32, img32);
+            ef_lowhigh32_chunk<4, true, V2>(rc, sorted_ids, low, high, hrank, batches, unsorted, drecs, win32, img32);
         else if (nc > 64u)
-            ef_lowhigh32_chunk<4>(rc, sorted_ids, low, high, hrank, batches, unsorted, drecs, win32, img32);
+            ef_lowhigh32_chunk<4, false, V2>(rc, sorted_ids, low, high, hrank, batches, unsorted, drecs, win32, img32);
         else
-            ef_lowhigh32_chunk<1>(rc, sorted_ids, low, high, hrank, batches, unsorted, drecs, win32, img32);
+            ef_lowhigh32_chunk<1, false, V2>(rc, sorted_ids, low, high, hrank, batches, unsorted, drecs, win32, img32);
         __syncthreads();
     }
 }
@@ -1649,7 +1658,17 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
         if (wide_ids)
             hipLaunchKernelGGL(k_ef_lowhigh, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(), nchunks,
                                e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
-        else if (const bool nofull = std::getenv("VIDC_EF_NO_FULL") != nullptr; max_list <= 256) {  // (16 M ids in lists of 256: 65 -> 57 us)
+        else if (!std::getenv("VIDC_EF_OLD_ENC") && !std::getenv("VIDC_EF_NO_FULL")) {  // the V2 bodies (VIDC_EF_OLD_ENC=1: the round-4 ones below)
+            if (max_list <= 256)
+                hipLaunchKernelGGL((k_ef_lowhigh32<4, true, true, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
+                                   nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
+            else if (e->ntotal < 256 * nchunks)
+                hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, true, true, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
+                                   s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
+            else
+                hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false, true, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
+                                   s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
+        } else if (const bool nofull = std::getenv("VIDC_EF_NO_FULL") != nullptr; max_list <= 256) {  // (16 M ids in lists of 256: 65 -> 57 us)
             if (nofull) hipLaunchKernelGGL((k_ef_lowhigh32<4, true, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
                                nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
             else hipLaunchKernelGGL((k_ef_lowhigh32<4, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
