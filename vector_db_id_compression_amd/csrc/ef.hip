@@ -1057,7 +1057,7 @@ __global__ void __launch_bounds__(256) k_ef_build_recs(const uint64_t *__restric
 // LW = uint64_t: any ids.  LW = uint32_t: objects whose ids fit 32 bits -- low bits come as 32-bit word pairs and the
 // value is assembled in one register (the 64-bit version reads 16 bytes of low words per element and does
 // two-register shifts: 0.19 vs 0.13 ms per 64 M ids).
-template <typename LW, int R>  // R: elements per lane and pass (4: no batch of the object holds more than 256)
+template <typename LW, int R, bool V2A = true>  // R: elements per lane and pass (4: no batch of the object holds more than 256)
 __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const uint64_t *high, const EfRec *recs,
                                                       uint32_t nwork, uint64_t *out) {
     extern __shared__ uint16_t spos[];  // max elements per batch of this object (<= EF_BATCH_BITS) entries
@@ -1076,25 +1076,39 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
         if (!tot) continue;
         const LW keep = b ? (LW)(((b >= WB ? (LW)0 : ((LW)1 << b))) - (LW)1) : (LW)0;
         const LW *lw = (const LW *)(low + low_base);
-        // A batch of few high words spreads every word over 2 / 4 / 8 lanes (32- / 16- / 8-bit pieces): with a word per lane a 256-id
-        // list's ~10 words kept 10 lanes busy for ~25 set bits each while 54 idled (16 M ids in lists of 256: 46 -> 36 us).
+        // V2 (LW = uint32_t, round 5): the bit offset (done + rr) * b of element rr's low bits was a 64-bit multiply per element and pass,
+        // twice (v_mad_u64_u32 + v_mul_lo_u32: quarter rate).  done * b is wave-uniform (scalar), rr * b < 2^17 is a 24-bit multiply, the
+        // word index relative to the uniform word (done * b) >> 5 fits 32 bits (uniform base + 32-bit offset loads), and the two words
+        // are joined by one v_alignbit: 517 -> 374 vector instructions (R = 8), 56 -> 44 VGPRs.  The second word's index is written
+        // (bo + 32) >> 5 on purpose: as (bo >> 5) + 1 the compiler merges the pair into ONE 8-byte load at a 4-byte boundary, which costs
+        // 30 % of the kernel, and an empty asm on the index to keep them apart costs 25 %.  VIDC_EF_DEC_V1=1
+        // (V2A = false) keeps the round-4 arithmetic.
+        constexpr bool V2 = V2A && sizeof(LW) == 4;
+        const uint64_t done_b = (uint64_t)done * b;
+        const uint32_t *lwu = (const uint32_t *)lw + (done_b >> 5);
+        const uint32_t db5 = (uint32_t)done_b & 31u;
         const uint32_t sh = nw <= 8u ? 3u : (nw <= 16u ? 2u : (nw <= 32u ? 1u : 0u));
         const uint32_t wi_ = lane >> sh, pw = 64u >> sh, sub = lane & ((1u << sh) - 1u);
         const uint64_t word = wi_ < nw ? high[hw_base + wi_] : 0ull;
         LW a[R], bw[R];
 #pragma unroll
-        for (uint32_t k = 0; k < R; k++) {  // both words, unconditionally (a padding word follows every stream)
+        for (uint32_t k = 0; k < R; k++) {
             const uint32_t rr = lane + 64 * k;
-            const uint64_t bp = ((uint64_t)done + (rr < tot ? rr : 0u)) * b;
-            a[k] = b ? lw[bp >> WSH] : (LW)0;
-            bw[k] = b ? lw[(bp >> WSH) + 1] : (LW)0;
+            if (V2) {
+                const uint32_t bo = db5 + __umul24(rr < tot ? rr : 0u, b);
+                uint32_t i1 = ((bo + 32u) >> 5);
+                a[k] = b ? (LW)lwu[bo >> 5] : (LW)0;
+                bw[k] = b ? (LW)lwu[i1] : (LW)0;
+            } else {
+                const uint64_t bp = ((uint64_t)done + (rr < tot ? rr : 0u)) * b;
+                a[k] = b ? lw[bp >> WSH] : (LW)0;
+                bw[k] = b ? lw[(bp >> WSH) + 1] : (LW)0;
+            }
         }
         {
             const uint64_t piece = sh ? (word >> (pw * sub)) & ((1ull << pw) - 1ull) : word;
             const uint32_t c = popc64(piece);
             uint32_t r = wave_scan32(c) - c;
-            // transpose: position of every set bit, indexed by its rank inside the batch (32-bit halves: one
-            // v_ffbl + two ALU ops per bit instead of the 64-bit sequence)
             uint32_t h0 = (uint32_t)piece, h1 = (uint32_t)(piece >> 32);
             const uint32_t p0 = wi_ * 64u + pw * sub;
             while (h0) {
@@ -1113,9 +1127,16 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
 #pragma unroll
                 for (uint32_t k = 0; k < R; k++) {
                     const uint32_t rr = r0 + lane + 64 * k;
-                    const uint64_t bp = ((uint64_t)done + (rr < tot ? rr : 0u)) * b;
-                    a[k] = b ? lw[bp >> WSH] : (LW)0;
-                    bw[k] = b ? lw[(bp >> WSH) + 1] : (LW)0;
+                    if (V2) {
+                        const uint32_t bo = db5 + __umul24(rr < tot ? rr : 0u, b);
+                        uint32_t i1 = ((bo + 32u) >> 5);
+                        a[k] = b ? (LW)lwu[bo >> 5] : (LW)0;
+                        bw[k] = b ? (LW)lwu[i1] : (LW)0;
+                    } else {
+                        const uint64_t bp = ((uint64_t)done + (rr < tot ? rr : 0u)) * b;
+                        a[k] = b ? lw[bp >> WSH] : (LW)0;
+                        bw[k] = b ? lw[(bp >> WSH) + 1] : (LW)0;
+                    }
                 }
             }
 #pragma unroll
@@ -1123,9 +1144,15 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
                 const uint32_t rr = r0 + lane + 64 * k;
                 if (rr < tot) {
                     const uint32_t rank = done + rr;
-                    const uint32_t sh = (uint32_t)(((uint64_t)rank * b) & (WB - 1u));
-                    const LW lo = (LW)((a[k] >> sh) | (sh ? (LW)(bw[k] << (WB - sh)) : (LW)0)) & keep;
-                    out[out_pos + rr] = (uint64_t)((LW)((LW)(pbase + spos[rr] - rank) << b) | lo);
+                    if (V2) {
+                        const uint32_t shb = (db5 + __umul24(rr, b)) & 31u;
+                        const uint32_t lo = __builtin_amdgcn_alignbit((uint32_t)bw[k], (uint32_t)a[k], shb) & (uint32_t)keep;
+                        out[out_pos + rr] = (uint64_t)((((uint32_t)pbase + spos[rr] - rank) << b) | lo);
+                    } else {
+                        const uint32_t sh = (uint32_t)(((uint64_t)rank * b) & (WB - 1u));
+                        const LW lo = (LW)((a[k] >> sh) | (sh ? (LW)(bw[k] << (WB - sh)) : (LW)0)) & keep;
+                        out[out_pos + rr] = (uint64_t)((LW)((LW)(pbase + spos[rr] - rank) << b) | lo);
+                    }
                 }
             }
         }
@@ -1820,7 +1847,14 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
         const uint32_t max_cnt = publish_after_sync ? pending_max_cnt : e->recs_max_cnt;
         const uint32_t lds = std::min<uint32_t>(EF_BATCH_BITS, (max_cnt + 63u) & ~63u) * 2;
         const bool small = max_cnt <= 256;
-        if (e->narrow && small)
+        const bool dec_v1 = std::getenv("VIDC_EF_DEC_V1") != nullptr;
+        if (e->narrow && small && dec_v1)
+            hipLaunchKernelGGL((k_ef_decode_rec<uint32_t, 4, false>), grid, dim3(64), lds, ctx->stream, e->d_low.p, e->d_high.p,
+                               e->d_recs.p, (uint32_t)e->nbatches, d_out);
+        else if (e->narrow && dec_v1)
+            hipLaunchKernelGGL((k_ef_decode_rec<uint32_t, 8, false>), grid, dim3(64), lds, ctx->stream, e->d_low.p, e->d_high.p,
+                               e->d_recs.p, (uint32_t)e->nbatches, d_out);
+        else if (e->narrow && small)
             hipLaunchKernelGGL((k_ef_decode_rec<uint32_t, 4>), grid, dim3(64), lds, ctx->stream, e->d_low.p, e->d_high.p,
                                e->d_recs.p, (uint32_t)e->nbatches, d_out);
         else if (e->narrow)
