@@ -5,6 +5,7 @@ it (libvidc.so.srchash).  A checkout, a copy to the GPU box or a `touch` therefo
 always does.  The compiler writes to a temporary file that is renamed over the library under a file lock, so ranks of
 one launch that find a stale library neither compile into each other's output nor load a half-written file.
 """
+import concurrent.futures
 import fcntl
 import glob
 import hashlib
@@ -12,6 +13,7 @@ import os
 import shutil
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -76,13 +78,26 @@ def build(force=False, verbose=False):
             if not force and not needs_build():  # another process built it while this one waited for the lock
                 return LIB
             tmp = f"{LIB}.tmp.{os.getpid()}"
-            cmd = [hipcc] + FLAGS + ["-o", tmp] + sources()
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
+            objdir = tempfile.mkdtemp(prefix="vidc_obj_")
             try:
+                # one compiler process per translation unit (they are independent), then one link
+                def compile_one(src):
+                    obj = os.path.join(objdir, os.path.basename(src) + ".o")
+                    cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+                    if verbose:
+                        print(" ".join(cmd), file=sys.stderr)
+                    subprocess.check_call(cmd)
+                    return obj
+
+                with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+                    objs = list(ex.map(compile_one, sources()))
+                cmd = [hipcc] + FLAGS + ["-o", tmp] + objs
+                if verbose:
+                    print(" ".join(cmd), file=sys.stderr)
                 subprocess.check_call(cmd)
                 os.replace(tmp, LIB)
             finally:
+                shutil.rmtree(objdir, ignore_errors=True)
                 if os.path.exists(tmp):
                     os.remove(tmp)
             with open(HASH + ".tmp", "w") as f:

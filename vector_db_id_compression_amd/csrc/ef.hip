@@ -17,6 +17,7 @@
 #include "common.h"
 #include "scan.h"
 #include "rows_csr.h"
+#include "rows_tile.h"
 #include "wave.h"
 
 using namespace vidc;
@@ -28,6 +29,14 @@ struct vidc_ef {
     uint64_t total_bits = 0;  // sum of low + high stream lengths in bits
     bool rows = false;        // built from graph rows (offsets live on the device until somebody asks)
     uint32_t K = 0;
+    // graph objects of rows up to 64 edges: a fixed-stride arena (a_lw low + a_hw high words per row) and {universe, n | l << 8}
+    // per row (see k_ef_rows_encode_tile).  The CSR members below stay empty until an entry point that works on the per-list
+    // streams (export, save, decode_lists, get, decode_all) asks for them: ef_ensure_csr (guarded by mu).
+    bool arena = false;
+    mutable bool csr_ready = true;
+    uint32_t a_lw = 0, a_hw = 0;
+    DevBuf<uint64_t> d_arena;
+    DevBuf<uint2> d_rmeta;
     // Host mirrors of the per-list geometry, filled lazily: the device arrays are authoritative (with 10^6 graph
     // nodes the PCIe crossings of these arrays used to cost 10x the kernels).  `offsets` is always valid for
     // objects built from host offsets.
@@ -1160,152 +1169,193 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
     }
 }
 
-// graph rows (<= 64 edges): one row per LANE.  A row's high stream is 3-4 words and its low stream ~100 bytes, so
-// a wavefront per row (above) leaves the machine mostly idle; here 64 rows advance per instruction.  Values are
-// staged in LDS (element e of row t at stage[e * 65 + t]) and written one row per iteration: contiguous stores.
-__global__ void __launch_bounds__(64) k_ef_decode_rows_lane(const uint64_t *low, const uint64_t *high,
-                                                            const uint64_t *offsets, const uint64_t *low_off,
-                                                            const uint64_t *high_off, const uint32_t *lbits,
-                                                            uint64_t nwork, const uint64_t *worklist, int32_t *out_rows,
-                                                            uint32_t K) {
-    __shared__ uint32_t stage[64 * 65];
+// ================================================================================================================
+// graph rows (EliasFanoNSGGraph, altid_impl.cpp:53-101; rows of <= 64 edges): one row per LANE, 64 consecutive rows per
+// wavefront (rows_tile.h).  The object is a fixed-stride ARENA: row i owns words [i * S, (i + 1) * S) of d_arena, LW low
+// words followed by HW high words, with S = LW + HW known from (K, largest id) alone:
+//     low  <= max over n <= K of n * msb(U / n) bits     (elias_fano.hpp:28: l = msb(universe / n))
+//     high =  (n + 1) + (u >> l) + 1 <= 3 n + 1 bits     (elias_fano.hpp:29; u >> l < 2 n)
+// so the encoder needs no geometry pass, no offset scan and no size read-back, a wavefront stores its 64 records as one
+// contiguous block, and a row is found by a multiplication ("fixed-stride output arena instead of 10^6 heap
+// objects").  The words of a record are bit-for-bit the words of the per-list streams (what vidc_ef_export returns); unused
+// words are zero.  Per row the arena keeps {universe, n | l << 8}.
+// ================================================================================================================
+struct EfRowsTot {  // 64 slots, summed by the host (a single counter would serialise 15 625 atomics)
+    unsigned long long bits, edges;
+};
+struct EfRowsFlags {
+    uint32_t bad, over, maxid, pad;
+};
+
+template <int KP>
+__global__ void __launch_bounds__(64) k_ef_rows_encode_tile(const int32_t *__restrict__ rows, uint64_t N, uint32_t K, uint32_t kmagic,
+                                                            uint32_t vec, uint32_t LW, uint32_t HW, uint32_t smagic, uint32_t ubound,
+                                                            uint64_t *__restrict__ arena, uint2 *__restrict__ meta, EfRowsTot *tot,
+                                                            EfRowsFlags *flags) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[RowsTile<KP>::DWORDS];
     const uint32_t lane = lane_id();
-    const uint64_t wi = (uint64_t)blockIdx.x * 64u + lane;
-    const bool have = wi < nwork;
-    const uint64_t l = have ? (worklist ? worklist[wi] : wi) : 0;
-    const uint32_t m = have ? (uint32_t)(offsets[l + 1] - offsets[l]) : 0u;
-    const uint32_t b = have ? lbits[l] : 0u;
-    const uint64_t *lw = low + (have ? low_off[l] : 0);
-    const uint64_t *hw = high + (have ? high_off[l] : 0);
-    const uint32_t nhw = have ? (uint32_t)(high_off[l + 1] - high_off[l]) : 0u;
-    uint32_t w = 0, rank = 0;
-    uint64_t word = (m && nhw) ? hw[0] : 0ull;
-    const uint32_t nmax = wave_max_u32(m);
-    for (uint32_t it = 0; it < nmax; it++) {
-        if (rank < m) {
-            while (word == 0ull && w + 1u < nhw) word = hw[++w];
-            const uint32_t bit = (uint32_t)__builtin_ctzll(word);
-            word &= word - 1;
-            const uint64_t pos = (uint64_t)w * 64u + bit;
-            stage[rank * 65u + lane] = (uint32_t)(((pos - rank) << b) | read_bits(lw, (uint64_t)rank * b, b));
-            rank++;
+    const uint64_t row0 = (uint64_t)blockIdx.x * 64u;
+    const uint32_t nrows = (uint32_t)(N - row0 < 64u ? N - row0 : 64u);
+    uint32_t r[KP];
+    tile_load_rows<KP>(rows, row0, nrows, K, kmagic, vec != 0u, lds, r);
+    bool bad;
+    uint32_t u;  // universe = the largest id of the row, taken before the sort (altid_impl.cpp:75)
+    const uint32_t n = tile_row_edges<KP>(r, K, bad, u);
+    const bool over = u > ubound;
+    lane_bitonic<KP>(r);  // altid_impl.cpp:76 (padding 0xffffffff sorts to the end)
+    uint32_t l = 0;       // elias_fano.hpp:28: msb(u / n), 0 when u / n == 0
+    if (n && u >= n) {
+        l = (uint32_t)__builtin_clz(n) - (uint32_t)__builtin_clz(u);
+        if ((n << l) > u) l--;
+    }
+    const uint32_t hb = n ? (n + 1u) + (u >> l) + 1u : 0u;  // :29; empty rows have no bitstream object (altid_impl.cpp:69-71)
+    const uint32_t S = LW + HW, S1 = S | 1u;  // LDS records at an odd word stride: any per-lane word index is conflict-free
+    uint64_t *rec64 = (uint64_t *)lds;
+    for (uint32_t f = lane; f < 64u * S1; f += 64u) rec64[f] = 0ull;
+    __syncthreads();
+    if (!(bad || over)) {
+        uint32_t *rec = lds + lane * S1 * 2u;
+        uint32_t *rech = rec + 2u * LW;
+        const uint32_t keep = (1u << l) - 1u;  // l <= 30
+        uint32_t bp = 0;
+#pragma unroll
+        for (int e = 0; e < KP; e++) {
+            if ((uint32_t)e < n) {
+                const uint32_t x = r[e];
+                if (l) {  // low stream: l bits per element, LSB first (elias_fano.hpp:40-42)
+                    const uint32_t v = x & keep, sh = bp & 31u, dw = bp >> 5;
+                    atomicOr(&rec[dw], v << sh);
+                    if (sh + l > 32u) atomicOr(&rec[dw + 1u], v >> (32u - sh));
+                }
+                const uint32_t pos = (x >> l) + (uint32_t)e;  // high stream: bit (x >> l) + e (:43)
+                atomicOr(&rech[pos >> 5], 1u << (pos & 31u));
+                bp += l;
+            }
         }
     }
     __syncthreads();
-    const uint64_t wbase = (uint64_t)blockIdx.x * 64u;
-    for (uint32_t rr = 0; rr < 64u && wbase + rr < nwork; rr++) {
-        const uint32_t m_r = rl(m, rr);
-        if (lane < K) out_rows[(wbase + rr) * K + lane] = lane < m_r ? (int32_t)stage[lane * 65u + rr] : -1;
+    {
+        uint64_t *dst = arena + row0 * S;
+        const uint32_t total = nrows * S;
+        for (uint32_t f = lane; f < total; f += 64u) {
+            const uint32_t row = tile_div(f, S, smagic);
+            dst[f] = rec64[row * S1 + (f - row * S)];
+        }
+    }
+    if (lane < nrows) meta[row0 + lane] = make_uint2(u, n | (l << 8));
+    unsigned long long bits = (unsigned long long)n * l + hb, edges = n;
+    uint32_t mx = u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        bits += __shfl_xor(bits, o, 64);
+        edges += __shfl_xor(edges, o, 64);
+        const uint32_t w = (uint32_t)__shfl_xor((int)mx, o, 64);
+        mx = mx > w ? mx : w;
+    }
+    const uint64_t anybad = ballot(bad), anyover = ballot(over);
+    if (lane == 0) {
+        if (edges) {
+            atomicAdd(&tot[blockIdx.x & 63u].bits, bits);
+            atomicAdd(&tot[blockIdx.x & 63u].edges, edges);
+        }
+        if (anybad) atomicOr(&flags->bad, 1u);
+        if (anyover) { atomicOr(&flags->over, 1u); atomicMax(&flags->maxid, mx); }
     }
 }
 
-// ---- graph rows, one row per LANE (EliasFanoNSGGraph ctor, altid_impl.cpp:61-76): the row is read as int32 (no
-// u64 copy of the graph), sorted by the lane's own register network, and both bit streams are written by the lane.
+// decode: the wavefront's 64 records come in as one block (nodes == NULL: rows w0 .. w0+63) or record by record (a node list);
+// pass 1, lane = row: the set bits of the high words are enumerated (elias_fano.hpp:233-249) and element e's high part
+// goes to stage[e * 65 + row]; pass 2, lane = element: for each row in turn the low bits are read (:235) and the row leaves
+// as one contiguous store, -1 padded.
 template <int KP>
-__device__ __forceinline__ uint32_t ef_load_row(const int32_t *rows, uint64_t row, uint32_t K, bool have, uint32_t (&r)[KP],
-                                                bool &bad) {
-    const int32_t *src = rows + row * K;
-    if ((K & 3u) == 0u) {
-#pragma unroll
-        for (int e = 0; e < KP; e += 4) {
-            int4 v = make_int4(-1, -1, -1, -1);
-            if (have && (uint32_t)e < K) v = *(const int4 *)(src + e);
-            r[e] = (uint32_t)v.x; r[e + 1] = (uint32_t)v.y; r[e + 2] = (uint32_t)v.z; r[e + 3] = (uint32_t)v.w;
-        }
+__global__ void __launch_bounds__(64) k_ef_rows_decode_tile(const uint64_t *__restrict__ arena, const uint2 *__restrict__ meta, uint64_t m,
+                                                            const uint64_t *__restrict__ nodes, uint32_t K, uint32_t LW, uint32_t HW,
+                                                            uint32_t smagic, int32_t *__restrict__ out, uint32_t *__restrict__ counts) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[KP * 65];
+    extern __shared__ __attribute__((aligned(16))) uint64_t rec64[];  // 64 records of S | 1 words
+    const uint32_t lane = lane_id();
+    const uint64_t w0 = (uint64_t)blockIdx.x * 64u;
+    const uint32_t nrows = (uint32_t)(m - w0 < 64u ? m - w0 : 64u);
+    const uint32_t S = LW + HW, S1 = S | 1u;
+    const bool have = lane < nrows;
+    uint64_t row = w0 + lane;
+    if (nodes && have) row = nodes[row];
+    const uint2 mt = have ? meta[row] : make_uint2(0u, 0u);
+    uint32_t n = mt.y & 0xffu;
+    n = n < (uint32_t)KP ? n : (uint32_t)KP;
+    const uint32_t l = (mt.y >> 8) & 0x1fu;
+    if (nodes) {
+        for (uint32_t w = 0; w < S; w++) rec64[lane * S1 + w] = have ? arena[row * S + w] : 0ull;
     } else {
-#pragma unroll
-        for (int e = 0; e < KP; e++) r[e] = (have && (uint32_t)e < K) ? (uint32_t)src[e] : 0xffffffffu;
-    }
-    uint32_t n = have ? K : 0u;
-#pragma unroll
-    for (int e = KP - 1; e >= 0; e--) n = (r[e] == 0xffffffffu && (uint32_t)e < n) ? (uint32_t)e : n;
-#pragma unroll
-    for (int e = 0; e < KP; e++) {
-        bad |= (uint32_t)e < n && (int32_t)r[e] < 0;
-        r[e] = (uint32_t)e < n ? r[e] : 0xffffffffu;
-    }
-    return n;
-}
-
-template <int KP>
-__global__ void __launch_bounds__(64) k_ef_rows_geom_lane(const int32_t *rows, uint64_t N, uint32_t K, uint32_t *sizes,
-                                                          uint32_t *lbits, uint64_t *universe, uint32_t *low_words,
-                                                          uint32_t *high_words, uint32_t *nbatch, EfTotals *tot,
-                                                          uint32_t *err) {
-    const uint32_t lane = lane_id();
-    const uint64_t row = (uint64_t)blockIdx.x * 64u + lane;
-    const bool have = row < N;
-    uint32_t r[KP];
-    bool bad = false;
-    const uint32_t n = ef_load_row<KP>(rows, row, K, have, r, bad);
-    uint32_t u = 0;
-#pragma unroll
-    for (int e = 0; e < KP; e++) u = ((uint32_t)e < n && r[e] > u) ? r[e] : u;
-    uint32_t lb = 0, lw = 0, hw = 0;
-    unsigned long long bits = 0;
-    if (n) {  // elias_fano.hpp:28-29; empty rows have no bitstream object
-        lb = (u / n) ? (uint32_t)msb64(u / n) : 0u;
-        const uint32_t hb = (n + 1u) + (u >> lb) + 1u;
-        bits = (unsigned long long)n * lb + hb;
-        lw = (n * lb + 63u) / 64u + 1u;  // +1 padding word for read_bits
-        hw = (hb + 63u) / 64u;
-    }
-    if (have) {
-        sizes[row] = n; lbits[row] = lb; universe[row] = u; low_words[row] = lw; high_words[row] = hw;
-        nbatch[row] = (hw + 63u) / 64u;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) bits += __shfl_xor(bits, o, 64);
-    if (lane == 0 && bits) atomicAdd(&tot->total_bits, bits);
-    if (ballot(bad) && lane == 0) atomicOr(err, 1u);
-}
-
-template <int KP>
-__global__ void __launch_bounds__(64) k_ef_rows_write_lane(const int32_t *rows, uint64_t N, uint32_t K,
-                                                           const uint32_t *lbits, const uint64_t *low_off,
-                                                           const uint64_t *high_off, uint64_t *low, uint64_t *high) {
-    const uint32_t lane = lane_id();
-    const uint64_t row = (uint64_t)blockIdx.x * 64u + lane;
-    const bool have = row < N;
-    uint32_t r[KP];
-    bool bad = false;
-    const uint32_t n = ef_load_row<KP>(rows, row, K, have, r, bad);
-    lane_bitonic<KP>(r);  // padding (0xffffffff) sorts to the end
-    const uint32_t lb = have ? lbits[row] : 0u;
-    uint64_t *lw = low + (have ? low_off[row] : 0);
-    uint64_t *hw = high + (have ? high_off[row] : 0);
-    // low stream: l bits per element, LSB-first (elias_fano.hpp:40-42); the streams were zeroed beforehand
-    const uint64_t keep = lb ? ((1ull << lb) - 1ull) : 0ull;
-    uint64_t acc = 0, hacc = 0;
-    uint32_t sh = 0, w = 0, hwi = 0;
-#pragma unroll
-    for (int e = 0; e < KP; e++) {
-        if ((uint32_t)e < n) {
-            const uint64_t v = r[e] & keep;
-            acc |= v << sh;
-            if (lb && sh + lb >= 64u) {
-                lw[w++] = acc;
-                acc = sh + lb > 64u ? v >> (64u - sh) : 0ull;
-                sh = sh + lb - 64u;
-            } else {
-                sh += lb;
-            }
-            // high stream: bit (x >> l) + e (elias_fano.hpp:43); positions increase strictly
-            const uint32_t pos = (r[e] >> lb) + (uint32_t)e;
-            const uint32_t pw = pos >> 6;
-            if (pw != hwi) {
-                if (hacc) hw[hwi] = hacc;
-                hacc = 0;
-                hwi = pw;
-            }
-            hacc |= 1ull << (pos & 63u);
+        const uint64_t *src = arena + w0 * S;
+        const uint32_t total = nrows * S;
+        for (uint32_t f = lane; f < total; f += 64u) {
+            const uint32_t rr = tile_div(f, S, smagic);
+            rec64[rr * S1 + (f - rr * S)] = src[f];
         }
     }
-    if (n) {
-        if (sh) lw[w] = acc;
-        if (hacc) hw[hwi] = hacc;
+    __syncthreads();
+    {
+        const uint64_t *hw = rec64 + lane * S1 + LW;
+        uint32_t e = 0;
+        for (uint32_t w = 0; w < HW; w++) {
+            uint64_t cur = e < n ? hw[w] : 0ull;
+            while (ballot(cur != 0ull)) {
+                if (cur != 0ull) {
+                    const uint32_t bit = (uint32_t)__builtin_ctzll(cur);
+                    cur &= cur - 1ull;
+                    stage[e * 65u + lane] = w * 64u + bit - e;
+                    e++;
+                    if (e >= n) cur = 0ull;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t rr = 0; rr < nrows; rr++) {
+        const uint32_t n_r = rl(n, rr), l_r = rl(l, rr);
+        if (lane < K) {
+            int32_t v = -1;
+            if (lane < n_r) {
+                const uint32_t hi = stage[lane * 65u + rr];
+                uint32_t low = 0;
+                if (l_r) {
+                    const uint32_t bp = lane * l_r;
+                    const uint32_t *rw = (const uint32_t *)(rec64 + rr * S1) + (bp >> 5);
+                    low = (uint32_t)(((((uint64_t)rw[1]) << 32) | rw[0]) >> (bp & 31u)) & ((1u << l_r) - 1u);
+                }
+                v = (int32_t)((hi << l_r) | low);
+            }
+            out[(w0 + rr) * K + lane] = v;
+        }
+    }
+    if (counts && have) counts[w0 + lane] = n;
+}
+
+// arena -> the CSR streams of a list object (ef_ensure_csr: export, save, decode_lists, get on a graph object)
+__global__ void k_ef_arena_geom(const uint2 *meta, uint64_t N, uint32_t *sizes, uint32_t *lbits, uint64_t *universe, uint32_t *low_words,
+                                uint32_t *high_words, uint32_t *nbatch) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint2 mt = meta[i];
+        const uint32_t n = mt.y & 0xffu, l = (mt.y >> 8) & 0x1fu;
+        uint32_t lw = 0, hw = 0;
+        if (n) {
+            lw = (n * l + 63u) / 64u + 1u;  // +1 padding word for read_bits
+            hw = ((n + 1u) + (mt.x >> l) + 1u + 63u) / 64u;
+        }
+        sizes[i] = n; lbits[i] = l; universe[i] = mt.x; low_words[i] = lw; high_words[i] = hw; nbatch[i] = (hw + 63u) / 64u;
     }
 }
+__global__ void k_ef_arena_to_csr(const uint64_t *arena, const uint2 *meta, uint64_t N, uint32_t LW, uint32_t HW, const uint64_t *low_off,
+                                  const uint64_t *high_off, uint64_t *low, uint64_t *high) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t *rec = arena + i * (LW + HW);
+        const uint32_t lw = (uint32_t)(low_off[i + 1] - low_off[i]), hw = (uint32_t)(high_off[i + 1] - high_off[i]);
+        for (uint32_t w = 0; w < lw; w++) low[low_off[i] + w] = w + 1u < lw ? rec[w] : 0ull;
+        for (uint32_t w = 0; w < hw; w++) high[high_off[i] + w] = rec[LW + w];
+    }
+}
+
 
 // random access (ef->select(offset), elias_fano.hpp:141-145): one wavefront per query; the select directory
 // gives the batch of 64 high words holding the wanted one, a prefix scan of popcounts finds the word
@@ -1399,7 +1449,33 @@ int ef_mirror(std::vector<T> &dst, const T *d_src, size_t count) {
     if (count) VIDC_HIP(hipMemcpy(dst.data(), d_src, count * sizeof(T), hipMemcpyDeviceToHost));
     return VIDC_OK;
 }
+// arena objects (graph rows): every host mirror at once from the per-row {universe, n | l << 8}
+int ef_arena_mirror_locked(const vidc_ef *e) {
+    if (e->offsets_host && e->meta_host) return VIDC_OK;
+    VIDC_HIP(hipSetDevice(e->device));
+    const uint64_t N = e->nlist;
+    std::vector<uint2> mt(N);
+    if (N) VIDC_HIP(hipMemcpy(mt.data(), e->d_rmeta.p, N * sizeof(uint2), hipMemcpyDeviceToHost));
+    e->offsets.assign(N + 1, 0); e->low_off.assign(N + 1, 0); e->high_off.assign(N + 1, 0);
+    e->lbits.assign(N, 0); e->universe.assign(N, 0); e->high_nbits.assign(N, 0);
+    for (uint64_t i = 0; i < N; i++) {
+        const uint32_t n = mt[i].y & 0xffu, l = (mt[i].y >> 8) & 0x1fu;
+        uint64_t lw = 0, hw = 0;
+        if (n) {
+            e->high_nbits[i] = (uint64_t)(n + 1u) + (mt[i].x >> l) + 1u;
+            lw = ((uint64_t)n * l + 63) / 64 + 1;  // (the CSR form keeps one padding word per list for read_bits)
+            hw = (e->high_nbits[i] + 63) / 64;
+        }
+        e->lbits[i] = l; e->universe[i] = mt[i].x;
+        e->offsets[i + 1] = e->offsets[i] + n;
+        e->low_off[i + 1] = e->low_off[i] + lw;
+        e->high_off[i + 1] = e->high_off[i] + hw;
+    }
+    e->offsets_host = e->meta_host = true;
+    return VIDC_OK;
+}
 int ef_ensure_offsets_locked(const vidc_ef *e) {
+    if (e->arena) return ef_arena_mirror_locked(e);
     if (e->offsets_host) return VIDC_OK;
     VIDC_HIP(hipSetDevice(e->device));
     VIDC_TRY(ef_mirror(e->offsets, (const uint64_t *)e->d_offsets.p, e->nlist + 1));
@@ -1425,6 +1501,62 @@ int ef_ensure_meta(const vidc_ef *e) {
         if (m) e->high_nbits[l] = (m + 1) + (e->universe[l] >> e->lbits[l]) + 1;
     }
     e->meta_host = true;
+    return VIDC_OK;
+}
+
+// The per-list CSR streams of an arena object, built on the device the first time an entry point needs them (export / save,
+// decode_lists, get, decode_all on a graph object: none of them is on the graph search path).
+int ef_ensure_csr(vidc_ctx *ctx, const vidc_ef *ce) {
+    if (!ce->arena) return VIDC_OK;
+    std::lock_guard<std::mutex> g(ce->mu);
+    if (ce->csr_ready) return VIDC_OK;
+    vidc_ef *e = const_cast<vidc_ef *>(ce);
+    VIDC_HIP(hipSetDevice(ctx->device));
+    const uint64_t N = e->nlist;
+    const uint32_t n32 = (uint32_t)N;
+    Scratch s_cnt, s_lw, s_hw, s_nb, s_t0;
+    Pinned tail;
+    VIDC_TRY(tail.get(ctx, 64));
+    unsigned long long *t = tail.as<unsigned long long>();
+    VIDC_TRY(s_cnt.get(ctx, (N + 1) * 4)); VIDC_TRY(s_lw.get(ctx, (N + 1) * 4));
+    VIDC_TRY(s_hw.get(ctx, (N + 1) * 4)); VIDC_TRY(s_nb.get(ctx, (N + 1) * 4));
+    VIDC_TRY(e->d_offsets.alloc(N + 1, ctx->dpool));
+    VIDC_TRY(e->d_low_off.alloc(N + 1, ctx->dpool)); VIDC_TRY(e->d_high_off.alloc(N + 1, ctx->dpool));
+    VIDC_TRY(e->d_batch_off.alloc(N + 1, ctx->dpool));
+    VIDC_TRY(e->d_lbits.alloc(N ? N : 1, ctx->dpool)); VIDC_TRY(e->d_universe.alloc(N ? N : 1, ctx->dpool));
+    const dim3 grid((uint32_t)std::min<uint64_t>((N + 255) / 256 + 1, (uint64_t)ctx->num_cu * 16));
+    hipLaunchKernelGGL(k_ef_arena_geom, grid, dim3(256), 0, ctx->stream, e->d_rmeta.p, N, s_cnt.as<uint32_t>(), e->d_lbits.p,
+                       e->d_universe.p, s_lw.as<uint32_t>(), s_hw.as<uint32_t>(), s_nb.as<uint32_t>());
+    {
+        Scan4 sc;
+        sc.in[0] = s_cnt.as<uint32_t>(); sc.in[1] = s_lw.as<uint32_t>(); sc.in[2] = s_hw.as<uint32_t>(); sc.in[3] = s_nb.as<uint32_t>();
+        sc.out[0] = e->d_offsets.p; sc.out[1] = e->d_low_off.p; sc.out[2] = e->d_high_off.p; sc.out[3] = e->d_batch_off.p;
+        VIDC_TRY(device_exscan4(ctx, sc, 4, n32, s_t0));
+    }
+    VIDC_HIP(hipMemcpyAsync(t + 1, e->d_low_off.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(t + 2, e->d_high_off.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(hipMemcpyAsync(t + 3, e->d_batch_off.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
+    const uint64_t low_words = t[1], high_words = t[2];
+    e->nbatches = t[3];
+    VIDC_TRY(e->d_low.alloc(low_words ? low_words : 1, ctx->dpool));
+    VIDC_TRY(e->d_high.alloc(high_words ? high_words : 1, ctx->dpool));
+    VIDC_TRY(e->d_chunks.alloc(1, ctx->dpool));  // chunk table: encoder-only
+    VIDC_TRY(e->d_batches.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
+    VIDC_TRY(e->d_hrank.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
+    // a row's high stream is a handful of words: one batch per row, no element before it
+    VIDC_HIP(hipMemsetAsync(e->d_hrank.p, 0, (e->nbatches ? e->nbatches : 1) * 4, ctx->stream));
+    if (!low_words) VIDC_HIP(hipMemsetAsync(e->d_low.p, 0, 8, ctx->stream));
+    if (!high_words) VIDC_HIP(hipMemsetAsync(e->d_high.p, 0, 8, ctx->stream));
+    if (N) {
+        hipLaunchKernelGGL(k_ef_arena_to_csr, grid, dim3(256), 0, ctx->stream, e->d_arena.p, e->d_rmeta.p, N, e->a_lw, e->a_hw,
+                           e->d_low_off.p, e->d_high_off.p, e->d_low.p, e->d_high.p);
+        if (e->nbatches)
+            launch_fill_items(ctx->stream, e->d_batch_off.p, n32, 1u, e->d_batches.p, e->nbatches, (uint32_t)ctx->num_cu);
+    }
+    VIDC_HIP(hipGetLastError());
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
+    e->csr_ready = true;
     return VIDC_OK;
 }
 
@@ -1795,6 +1927,7 @@ int vidc_ef_list_info(const vidc_ef *e, uint32_t *sizes, uint32_t *low_bits, uin
 int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
     if (!ctx || !e || (e->ntotal && !d_out)) return VIDC_ERR_INVALID;
     if (!e->ntotal) return VIDC_OK;
+    VIDC_TRY(ef_ensure_csr(ctx, e));
     VIDC_HIP(hipSetDevice(ctx->device));
     double recs_ms = 0;
     bool recs_timed = false, publish_after_sync = false;
@@ -1901,11 +2034,7 @@ static int ef_decode_some(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uin
         VIDC_HIP(hipMemcpyAsync(s_o.p, h_up.as<uint64_t>() + m, m * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    if (d_rows && e->rows && e->K <= 64 && K >= e->K)  // graph rows: one row per lane
-        hipLaunchKernelGGL(k_ef_decode_rows_lane, dim3((uint32_t)((m + 63) / 64)), dim3(64), 0, ctx->stream, e->d_low.p,
-                           e->d_high.p, e->d_offsets.p, e->d_low_off.p, e->d_high_off.p, e->d_lbits.p, m,
-                           d_l, d_rows, K);
-    else {
+    {
         // few lists: several workgroups per list (by the longest requested list, ~2048 ids per workgroup; the host knows the sizes
         // whenever it knows the output offsets)
         uint32_t nsplit = 1;
@@ -1935,6 +2064,7 @@ static int ef_decode_some(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uin
 int vidc_ef_decode_lists(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *list_nos, uint64_t *d_out,
                          uint64_t *out_offsets) {
     if (!ctx || !e || (m && !list_nos) || !out_offsets) return VIDC_ERR_INVALID;
+    VIDC_TRY(ef_ensure_csr(ctx, e));
     VIDC_TRY(ef_ensure_offsets(e));
     out_offsets[0] = 0;
     for (uint64_t i = 0; i < m; i++) {
@@ -1954,13 +2084,63 @@ int vidc_ef_decode_gather(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uin
                                    [&](uint64_t *d, uint64_t *lo) { return vidc_ef_decode_lists(ctx, e, m, list_nos, d, lo); });
 }
 
+// words per row of the arena of a graph object: see k_ef_rows_encode_tile
+static void ef_rows_geometry(uint32_t K, uint32_t ubound, uint32_t *LW, uint32_t *HW) {
+    uint32_t maxbits = 0;
+    for (uint32_t n = 1; n <= K; n++) {
+        const uint32_t q = ubound / n;
+        maxbits = std::max(maxbits, n * (q ? (uint32_t)msb64(q) : 0u));
+    }
+    *LW = (maxbits + 63u) / 64u;
+    *HW = (3u * K + 1u + 63u) / 64u;
+}
+
+// graph object, every requested row at most K wide: one row per lane from the arena
+static int ef_decode_rows_arena(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *nodes, uint32_t K, int32_t *d_out,
+                                uint32_t *counts) {
+    VIDC_HIP(hipSetDevice(ctx->device));
+    Scratch s_n, s_c;
+    Pinned h_io;
+    const uint64_t *d_nodes = nullptr;  // nodes == NULL: rows 0..m-1, no index array
+    if (nodes || counts) VIDC_TRY(h_io.get(ctx, m * 8));
+    if (nodes) {
+        VIDC_TRY(s_n.get(ctx, m * 8));
+        std::memcpy(h_io.p, nodes, m * 8);
+        VIDC_HIP(hipMemcpyAsync(s_n.p, h_io.p, m * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_nodes = s_n.as<uint64_t>();
+    }
+    if (counts) VIDC_TRY(s_c.get(ctx, m * 4));
+    const uint32_t S = e->a_lw + e->a_hw;
+    const size_t dyn = (size_t)64 * (S | 1u) * 8;
+    const dim3 grid((uint32_t)((m + 63) / 64));
+    VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    if (e->K <= 32)
+        hipLaunchKernelGGL(k_ef_rows_decode_tile<32>, grid, dim3(64), dyn, ctx->stream, e->d_arena.p, e->d_rmeta.p, m, d_nodes, K, e->a_lw,
+                           e->a_hw, tile_magic(S), d_out, counts ? s_c.as<uint32_t>() : nullptr);
+    else
+        hipLaunchKernelGGL(k_ef_rows_decode_tile<64>, grid, dim3(64), dyn, ctx->stream, e->d_arena.p, e->d_rmeta.p, m, d_nodes, K, e->a_lw,
+                           e->a_hw, tile_magic(S), d_out, counts ? s_c.as<uint32_t>() : nullptr);
+    VIDC_HIP(hipGetLastError());
+    VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    if (counts) VIDC_HIP(hipMemcpyAsync(h_io.p, s_c.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
+    if (counts) std::memcpy(counts, h_io.p, m * 4);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->last_kernel_ms = ms;
+    return VIDC_OK;
+}
+
 int vidc_ef_decode_rows(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *nodes, uint32_t K, int32_t *d_out,
                         uint32_t *counts) {
     if (!ctx || !e || (m && !d_out) || K == 0) return VIDC_ERR_INVALID;
     if (!nodes && m > e->nlist) { set_error("nodes == NULL selects nodes 0..m-1: m exceeds the node count"); return VIDC_ERR_INVALID; }
-    // rows of a graph object never exceed its K; edge counts of the requested nodes are gathered on the device
-    const bool lean = e->rows && K >= e->K;
-    if (!lean) VIDC_TRY(ef_ensure_offsets(e));
+    // rows of a graph object never exceed its K
+    const bool lean = e->arena && K >= e->K;
+    if (!lean) {
+        VIDC_TRY(ef_ensure_csr(ctx, e));
+        VIDC_TRY(ef_ensure_offsets(e));
+    }
     for (uint64_t i = 0; i < m && (nodes || !lean); i++) {
         const uint64_t node = nodes ? nodes[i] : i;
         if (node >= e->nlist) { set_error("node out of range"); return VIDC_ERR_INVALID; }
@@ -1970,7 +2150,8 @@ int vidc_ef_decode_rows(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint6
         if (counts) counts[i] = (uint32_t)n;
     }
     if (!m) return VIDC_OK;
-    return ef_decode_some(ctx, e, m, nodes, nullptr, nullptr, d_out, K, lean ? counts : nullptr);
+    if (lean) return ef_decode_rows_arena(ctx, e, m, nodes, K, d_out, counts);
+    return ef_decode_some(ctx, e, m, nodes, nullptr, nullptr, d_out, K, nullptr);
 }
 
 int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_rows, vidc_ef **out) {
@@ -1978,10 +2159,10 @@ int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_
     *out = nullptr;
     if (K == 0) { set_error("EF rows: K=0 unsupported"); return VIDC_ERR_UNSUPPORTED; }
     if (N >= 0xffffffffull) return VIDC_ERR_INVALID;
+    VIDC_HIP(hipSetDevice(ctx->device));
     if (K > 64) {
         // wide rows (NSG128, NSG256, ...): the rows become CSR lists and take the per-list kernels (which sort each list
         // like altid_impl.cpp:76 and use its largest id as the universe, :75,77)
-        VIDC_HIP(hipSetDevice(ctx->device));
         std::vector<uint64_t> offsets;
         Scratch s_ids;
         VIDC_TRY(rows_to_csr(ctx, N, K, d_rows, offsets, s_ids));
@@ -1989,92 +2170,59 @@ int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_
         (*out)->K = K;
         return VIDC_OK;
     }
-    VIDC_HIP(hipSetDevice(ctx->device));
     std::unique_ptr<vidc_ef> e(new vidc_ef());
     e->device = ctx->device;
     e->nlist = N;
     e->rows = true;
+    e->arena = true;
+    e->csr_ready = false;
     e->K = K;
-    const uint32_t n32 = (uint32_t)N;
-    Scratch s_cnt, s_lw, s_hw, s_nb, s_tot, s_t0;
+    e->narrow = true;
+    e->max_list = K;
+    Scratch s_tot;
     Pinned tail;
-    VIDC_TRY(tail.get(ctx, 64));
-    unsigned long long *t = tail.as<unsigned long long>();
-    VIDC_TRY(s_cnt.get(ctx, (N + 1) * 4)); VIDC_TRY(s_lw.get(ctx, (N + 1) * 4));
-    VIDC_TRY(s_hw.get(ctx, (N + 1) * 4)); VIDC_TRY(s_nb.get(ctx, (N + 1) * 4));
-    VIDC_TRY(s_tot.get(ctx, 32));  // EfTotals + error flag
-    VIDC_TRY(e->d_offsets.alloc(N + 1, ctx->dpool));
-    VIDC_TRY(e->d_low_off.alloc(N + 1, ctx->dpool)); VIDC_TRY(e->d_high_off.alloc(N + 1, ctx->dpool));
-    VIDC_TRY(e->d_batch_off.alloc(N + 1, ctx->dpool));
-    VIDC_TRY(e->d_lbits.alloc(N ? N : 1, ctx->dpool)); VIDC_TRY(e->d_universe.alloc(N ? N : 1, ctx->dpool));
-    VIDC_HIP(hipMemsetAsync(s_tot.p, 0, 32, ctx->stream));
-    double kernel_ms = 0;
-    auto timed = [&](auto &&fn) -> int {
+    const size_t tot_bytes = 64 * sizeof(EfRowsTot) + sizeof(EfRowsFlags);
+    VIDC_TRY(tail.get(ctx, tot_bytes));
+    VIDC_TRY(s_tot.get(ctx, tot_bytes));
+    VIDC_TRY(e->d_rmeta.alloc(N ? N : 1, ctx->dpool));
+    // neighbours of a graph are node numbers: ids < N bound the record size.  A row array that breaks this (a subgraph with global
+    // ids) is seen by the kernel, which reports the largest id, and the call is repeated with records sized for it.
+    uint32_t ubound = N ? (uint32_t)std::min<uint64_t>(N - 1, 0x7fffffffull) : 0u;
+    const bool vec = ((uintptr_t)d_rows & 15u) == 0;
+    for (int attempt = 0;; attempt++) {
+        ef_rows_geometry(K, ubound, &e->a_lw, &e->a_hw);
+        const uint32_t S = e->a_lw + e->a_hw;
+        if ((S | 1u) * 2u > (K <= 32 ? 33u : 65u)) { set_error("EF rows: record of %u words does not fit the tile", S); return VIDC_ERR_UNSUPPORTED; }
+        VIDC_TRY(e->d_arena.alloc(N ? N * S : 1, ctx->dpool));
+        VIDC_HIP(hipMemsetAsync(s_tot.p, 0, tot_bytes, ctx->stream));
         VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-        fn();
-        VIDC_HIP(hipGetLastError());
+        if (N) {
+            const dim3 grid((uint32_t)((N + 63) / 64));
+            EfRowsTot *d_tot = s_tot.as<EfRowsTot>();
+            EfRowsFlags *d_fl = (EfRowsFlags *)(d_tot + 64);
+            if (K <= 32)
+                hipLaunchKernelGGL(k_ef_rows_encode_tile<32>, grid, dim3(64), 0, ctx->stream, d_rows, N, K, tile_magic(K), vec ? 1u : 0u,
+                                   e->a_lw, e->a_hw, tile_magic(S), ubound, e->d_arena.p, e->d_rmeta.p, d_tot, d_fl);
+            else
+                hipLaunchKernelGGL(k_ef_rows_encode_tile<64>, grid, dim3(64), 0, ctx->stream, d_rows, N, K, tile_magic(K), vec ? 1u : 0u,
+                                   e->a_lw, e->a_hw, tile_magic(S), ubound, e->d_arena.p, e->d_rmeta.p, d_tot, d_fl);
+            VIDC_HIP(hipGetLastError());
+        }
         VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-        VIDC_HIP(vidc::vidc_event_wait(ctx->ev1));
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-        kernel_ms += ms;
-        return VIDC_OK;
-    };
-    const dim3 lgrid((uint32_t)((N + 63) / 64));
-    EfTotals *d_tot = s_tot.as<EfTotals>();
-    uint32_t *d_err = (uint32_t *)((char *)s_tot.p + 16);
-    // pass 1 (one row per lane): edge count, universe, geometry
-    if (N)
-        VIDC_TRY(timed([&] {
-            if (K <= 32)
-                hipLaunchKernelGGL(k_ef_rows_geom_lane<32>, lgrid, dim3(64), 0, ctx->stream, d_rows, N, K, s_cnt.as<uint32_t>(),
-                                   e->d_lbits.p, e->d_universe.p, s_lw.as<uint32_t>(), s_hw.as<uint32_t>(),
-                                   s_nb.as<uint32_t>(), d_tot, d_err);
-            else
-                hipLaunchKernelGGL(k_ef_rows_geom_lane<64>, lgrid, dim3(64), 0, ctx->stream, d_rows, N, K, s_cnt.as<uint32_t>(),
-                                   e->d_lbits.p, e->d_universe.p, s_lw.as<uint32_t>(), s_hw.as<uint32_t>(),
-                                   s_nb.as<uint32_t>(), d_tot, d_err);
-        }));
-    {
-        Scan4 sc;
-        sc.in[0] = s_cnt.as<uint32_t>(); sc.in[1] = s_lw.as<uint32_t>(); sc.in[2] = s_hw.as<uint32_t>(); sc.in[3] = s_nb.as<uint32_t>();
-        sc.out[0] = e->d_offsets.p; sc.out[1] = e->d_low_off.p; sc.out[2] = e->d_high_off.p; sc.out[3] = e->d_batch_off.p;
-        VIDC_TRY(device_exscan4(ctx, sc, 4, n32, s_t0));
+        VIDC_HIP(hipMemcpyAsync(tail.p, s_tot.p, tot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
+        const EfRowsTot *t = tail.as<EfRowsTot>();
+        const EfRowsFlags *fl = (const EfRowsFlags *)(t + 64);
+        if (fl->bad) { set_error("EF rows: negative neighbour id before the -1 terminator"); return VIDC_ERR_DOMAIN; }
+        if (fl->over && attempt == 0) { ubound = fl->maxid; continue; }
+        if (fl->over) { set_error("EF rows: internal: record bound exceeded twice"); return VIDC_ERR_OVERFLOW; }
+        e->ntotal = 0; e->total_bits = 0;
+        for (int i = 0; i < 64; i++) { e->ntotal += t[i].edges; e->total_bits += t[i].bits; }
+        break;
     }
-    VIDC_HIP(hipMemcpyAsync(t + 0, e->d_offsets.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipMemcpyAsync(t + 1, e->d_low_off.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipMemcpyAsync(t + 2, e->d_high_off.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipMemcpyAsync(t + 3, e->d_batch_off.p + N, 8, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(hipMemcpyAsync(t + 4, s_tot.p, 32, hipMemcpyDeviceToHost, ctx->stream));
-    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
-    if ((uint32_t)(t[6] & 0xffffffffu)) { set_error("EF rows: negative neighbour id before the -1 terminator"); return VIDC_ERR_DOMAIN; }
-    e->ntotal = t[0];
-    const uint64_t low_words = t[1], high_words = t[2];
-    e->nbatches = t[3];
-    e->total_bits = t[4];
-    VIDC_TRY(e->d_low.alloc(low_words ? low_words : 1, ctx->dpool));
-    VIDC_TRY(e->d_high.alloc(high_words ? high_words : 1, ctx->dpool));
-    VIDC_TRY(e->d_chunks.alloc(1, ctx->dpool));  // chunk table: encoder-only, not needed for rows
-    VIDC_TRY(e->d_batches.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
-    VIDC_TRY(e->d_hrank.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
-    VIDC_HIP(hipMemsetAsync(e->d_low.p, 0, (low_words ? low_words : 1) * 8, ctx->stream));
-    VIDC_HIP(hipMemsetAsync(e->d_high.p, 0, (high_words ? high_words : 1) * 8, ctx->stream));
-    // a row's high stream is a handful of words: one batch per row, no element before it
-    VIDC_HIP(hipMemsetAsync(e->d_hrank.p, 0, (e->nbatches ? e->nbatches : 1) * 4, ctx->stream));
-    if (N)
-        VIDC_TRY(timed([&] {
-            // pass 2 (one row per lane): sort the row in registers, write both streams
-            if (K <= 32)
-                hipLaunchKernelGGL(k_ef_rows_write_lane<32>, lgrid, dim3(64), 0, ctx->stream, d_rows, N, K, e->d_lbits.p,
-                                   e->d_low_off.p, e->d_high_off.p, e->d_low.p, e->d_high.p);
-            else
-                hipLaunchKernelGGL(k_ef_rows_write_lane<64>, lgrid, dim3(64), 0, ctx->stream, d_rows, N, K, e->d_lbits.p,
-                                   e->d_low_off.p, e->d_high_off.p, e->d_low.p, e->d_high.p);
-            if (e->nbatches)
-                launch_fill_items(ctx->stream, e->d_batch_off.p, n32, 1u, e->d_batches.p, e->nbatches, (uint32_t)ctx->num_cu);
-        }));
-    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
-    ctx->last_kernel_ms = kernel_ms;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->last_kernel_ms = ms;
     *out = e.release();
     return VIDC_OK;
 }
@@ -2083,6 +2231,7 @@ int vidc_ef_get(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, const uint64_t *lis
                 int64_t *ids_out) {
     if (!ctx || !e || (m && (!list_nos || !offs || !ids_out))) return VIDC_ERR_INVALID;
     if (!m) return VIDC_OK;
+    VIDC_TRY(ef_ensure_csr(ctx, e));
     VIDC_TRY(ef_ensure_offsets(e));
     for (uint64_t i = 0; i < m; i++) {
         if (list_nos[i] >= e->nlist || offs[i] >= e->offsets[list_nos[i] + 1] - e->offsets[list_nos[i]]) {
@@ -2115,6 +2264,7 @@ int vidc_ef_perm(vidc_ctx *ctx, const vidc_ef *e, uint32_t *perm_host) {
 int vidc_ef_export(vidc_ctx *ctx, const vidc_ef *e, uint64_t list_no, uint64_t *low, size_t low_cap, uint64_t *high,
                    size_t high_cap, uint64_t *low_nbits, uint64_t *high_nbits) {
     if (!ctx || !e || list_no >= e->nlist) return VIDC_ERR_INVALID;
+    VIDC_TRY(ef_ensure_csr(ctx, e));
     VIDC_TRY(ef_ensure_meta(e));
     uint64_t m = e->offsets[list_no + 1] - e->offsets[list_no];
     uint64_t lb = m * e->lbits[list_no], hb = e->high_nbits[list_no];
@@ -2136,12 +2286,19 @@ int vidc_ef_export(vidc_ctx *ctx, const vidc_ef *e, uint64_t list_no, uint64_t *
 // {offsets, l[], universe[], low[], high[]}; stream offsets follow from (count, l, universe) per list
 int vidc_ef_stream_words(const vidc_ef *e, uint64_t *low_words, uint64_t *high_words) {
     if (!e) return VIDC_ERR_INVALID;
+    if (e->arena) {  // (the CSR streams may not exist yet: their sizes follow from the per-row geometry)
+        VIDC_TRY(ef_ensure_meta(e));
+        if (low_words) *low_words = e->low_off[e->nlist] ? e->low_off[e->nlist] : 1;
+        if (high_words) *high_words = e->high_off[e->nlist] ? e->high_off[e->nlist] : 1;
+        return VIDC_OK;
+    }
     if (low_words) *low_words = e->d_low.n;
     if (high_words) *high_words = e->d_high.n;
     return VIDC_OK;
 }
 int vidc_ef_export_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *low, size_t low_cap, uint64_t *high, size_t high_cap) {
     if (!ctx || !e || !low || !high) return VIDC_ERR_INVALID;
+    VIDC_TRY(ef_ensure_csr(ctx, e));
     if (e->d_low.n > low_cap || e->d_high.n > high_cap) { set_error("export buffers too small"); return VIDC_ERR_INVALID; }
     VIDC_TRY(vidc_copy_d2h(ctx, low, e->d_low.p, e->d_low.n * 8));
     return vidc_copy_d2h(ctx, high, e->d_high.p, e->d_high.n * 8);

@@ -12,6 +12,7 @@
 #include "bits.h"
 #include "chunks.h"
 #include "common.h"
+#include "rows_tile.h"
 #include "scan.h"
 
 using namespace vidc;
@@ -350,6 +351,92 @@ __global__ void __launch_bounds__(64) k_compact_rows_decode(const uint8_t *data,
     }
 }
 
+// ---- the same two for K <= 64 rows whose stride is a whole number of dwords (every K = 32 / 64 graph), 64 consecutive rows per
+// wavefront (rows_tile.h): the rows come in as one coalesced block and are transposed through LDS; lane t packs row t -- the bit
+// position of field e is e * bits for EVERY lane, so the shifts are scalar, a row image is built in registers 32 bits at a time
+// (no atomics, no barrier per row) and goes to the lane's LDS record; the 64 records leave as one contiguous block.  Every byte of
+// the output is written (fields behind the sentinel are zero, :31-36): the buffer needs no memset.
+template <int KP>
+__global__ void __launch_bounds__(64) k_compact_rows_encode_tile(const int32_t *__restrict__ rows, uint64_t N, uint32_t K, uint32_t kmagic,
+                                                                 uint32_t vec, uint32_t bits, uint32_t SD, uint32_t sdmagic,
+                                                                 uint32_t *__restrict__ out, uint32_t *err) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[RowsTile<KP>::DWORDS];
+    const uint32_t lane = lane_id();
+    const uint64_t row0 = (uint64_t)blockIdx.x * 64u;
+    const uint32_t nrows = (uint32_t)(N - row0 < 64u ? N - row0 : 64u);
+    uint32_t r[KP];
+    tile_load_rows<KP>(rows, row0, nrows, K, kmagic, vec != 0u, lds, r);
+    bool bad;
+    uint32_t mx;
+    const uint32_t n = tile_row_edges<KP>(r, K, bad, mx);  // edges before the first -1
+    bad |= n && (uint64_t)mx >= N;
+    if (ballot(bad) && lane == 0) *(volatile uint32_t *)err = 1u;  // (every writer stores the same value)
+    const uint32_t SD1 = SD | 1u;  // odd record stride: conflict-free for any (uniform) dword index
+    uint32_t *rec = lds + lane * SD1;
+    uint64_t acc = 0;
+    uint32_t fill = 0, w = 0;  // wave-uniform
+#pragma unroll
+    for (int e = 0; e < KP; e++) {
+        if ((uint32_t)e < K) {
+            // values 0..n-1 are neighbours; value n (if n < K) is the sentinel N; nothing after it (:31-36)
+            const uint32_t v = (uint32_t)e < n ? r[e] : ((uint32_t)e == n ? (uint32_t)N : 0u);
+            acc |= (uint64_t)v << fill;
+            fill += bits;
+            if (fill >= 32u) {
+                rec[w++] = (uint32_t)acc;
+                acc >>= 32;
+                fill -= 32u;
+            }
+        }
+    }
+    if (fill) rec[w++] = (uint32_t)acc;
+    __syncthreads();
+    uint32_t *dst = out + row0 * SD;
+    const uint32_t total = nrows * SD;
+    for (uint32_t f = lane; f < total; f += 64u) {
+        const uint32_t row = tile_div(f, SD, sdmagic);
+        dst[f] = lds[row * SD1 + (f - row * SD)];
+    }
+}
+
+// decode: the 64 records come in as one block (nodes == NULL) or record by record; then, for each row in turn, lane e extracts
+// field e from the LDS record (two dwords around bit e * bits), the sentinel is found with one ballot (:43-49) and the row leaves
+// as one contiguous 4 * K-byte store, -1 padded
+__global__ void __launch_bounds__(64) k_compact_rows_decode_tile(const uint32_t *__restrict__ data, uint64_t N, uint32_t K, uint32_t bits,
+                                                                 uint32_t SD, uint32_t sdmagic, uint64_t m, const uint64_t *__restrict__ nodes,
+                                                                 int32_t *__restrict__ out, uint32_t *__restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t crec[];  // 64 records of SD | 1 dwords (+ 1 spill dword)
+    const uint32_t lane = lane_id();
+    const uint64_t w0 = (uint64_t)blockIdx.x * 64u;
+    const uint32_t nrows = (uint32_t)(m - w0 < 64u ? m - w0 : 64u);
+    const uint32_t SD1 = SD | 1u;
+    if (nodes) {
+        const uint64_t row = lane < nrows ? nodes[w0 + lane] : 0ull;
+        for (uint32_t w = 0; w < SD; w++) crec[lane * SD1 + w] = lane < nrows ? data[row * SD + w] : 0u;
+    } else {
+        const uint32_t *src = data + w0 * SD;
+        const uint32_t total = nrows * SD;
+        for (uint32_t f = lane; f < total; f += 64u) {
+            const uint32_t rr = tile_div(f, SD, sdmagic);
+            crec[rr * SD1 + (f - rr * SD)] = src[f];
+        }
+    }
+    __syncthreads();
+    const uint32_t pos = lane * bits, dw = pos >> 5, sh = pos & 31u;
+    const uint64_t mask = (1ull << bits) - 1ull;
+    uint32_t my_n = 0;
+    for (uint32_t rr = 0; rr < nrows; rr++) {
+        const uint32_t *rw = crec + rr * SD1 + dw;
+        // (the second dword of the last field may be the record's padding dword: masked out)
+        const uint64_t v = lane < K ? ((((uint64_t)rw[1] << 32) | rw[0]) >> sh) & mask : ~0ull;
+        const uint64_t endm = ballot(lane < K && v == N);
+        const uint32_t n = endm ? ff1(endm) : K;
+        if (lane < K) out[(w0 + rr) * K + lane] = lane < n ? (int32_t)v : -1;
+        my_n = lane == rr ? n : my_n;
+    }
+    if (counts && lane < nrows) counts[w0 + lane] = my_n;
+}
+
 // the same for rows of any width (K > 64: NSG128 / NSG256 graphs): the wavefront walks the row 64 values at a time; the
 // row image lives in dynamic LDS (stride bytes + one spill word)
 __global__ void __launch_bounds__(64) k_compact_rows_encode_wide(const int32_t *rows, uint64_t N, uint32_t K, uint32_t bits,
@@ -437,11 +524,22 @@ int vidc_compact_rows_encode(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_
     Scratch s_err;
     VIDC_TRY(s_err.get(ctx, 4));
     VIDC_HIP(hipMemsetAsync(s_err.p, 0, 4, ctx->stream));
-    VIDC_HIP(hipMemsetAsync(c->d_data.p, 0, N * c->stride + 8, ctx->stream));
+    const bool tile = K <= 64 && (c->stride & 3u) == 0u;  // (rows_tile.h kernels: they write every byte of every row)
+    if (tile) VIDC_HIP(hipMemsetAsync(c->d_data.p + N * c->stride, 0, 8, ctx->stream));
+    else VIDC_HIP(hipMemsetAsync(c->d_data.p, 0, N * c->stride + 8, ctx->stream));
     if (N) {
         VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
         uint32_t grid = (uint32_t)std::min<uint64_t>(N, (uint64_t)ctx->num_cu * 64);
-        if (K <= 64)
+        if (tile) {
+            const uint32_t SD = c->stride / 4u, vec = ((uintptr_t)d_rows & 15u) == 0 ? 1u : 0u;
+            const dim3 tgrid((uint32_t)((N + 63) / 64));
+            if (K <= 32)
+                hipLaunchKernelGGL(k_compact_rows_encode_tile<32>, tgrid, dim3(64), 0, ctx->stream, d_rows, N, K, dev::tile_magic(K), vec,
+                                   c->bits, SD, dev::tile_magic(SD), (uint32_t *)c->d_data.p, s_err.as<uint32_t>());
+            else
+                hipLaunchKernelGGL(k_compact_rows_encode_tile<64>, tgrid, dim3(64), 0, ctx->stream, d_rows, N, K, dev::tile_magic(K), vec,
+                                   c->bits, SD, dev::tile_magic(SD), (uint32_t *)c->d_data.p, s_err.as<uint32_t>());
+        } else if (K <= 64)
             hipLaunchKernelGGL(k_compact_rows_encode, dim3(grid), dim3(64), 0, ctx->stream, d_rows, N, K, c->bits, c->stride,
                                c->d_data.p, s_err.as<uint32_t>());
         else
@@ -477,8 +575,9 @@ int vidc_compact_rows_decode(vidc_ctx *ctx, const vidc_compact *c, uint64_t m, c
     VIDC_HIP(hipSetDevice(ctx->device));
     Scratch s_n, s_c;
     Pinned h_io;
-    VIDC_TRY(s_c.get(ctx, m * 4));
-    VIDC_TRY(h_io.get(ctx, m * 8));
+    const bool tile = c->K <= 64 && (c->stride & 3u) == 0u;
+    if (counts || !tile) VIDC_TRY(s_c.get(ctx, m * 4));
+    if (counts || nodes) VIDC_TRY(h_io.get(ctx, m * 8));
     const uint64_t *d_nodes = nullptr;  // nodes == NULL: rows 0..m-1, no index array
     if (nodes) {
         VIDC_TRY(s_n.get(ctx, m * 8));
@@ -487,7 +586,12 @@ int vidc_compact_rows_decode(vidc_ctx *ctx, const vidc_compact *c, uint64_t m, c
         d_nodes = s_n.as<uint64_t>();
     }
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    if (c->K <= 64)
+    if (tile) {
+        const uint32_t SD = c->stride / 4u;
+        hipLaunchKernelGGL(k_compact_rows_decode_tile, dim3((uint32_t)((m + 63) / 64)), dim3(64), ((size_t)64 * (SD | 1u) + 1u) * 4u, ctx->stream,
+                           (const uint32_t *)c->d_data.p, c->N, c->K, c->bits, SD, dev::tile_magic(SD), m, d_nodes, d_out,
+                           counts ? s_c.as<uint32_t>() : nullptr);
+    } else if (c->K <= 64)
         hipLaunchKernelGGL(k_compact_rows_decode, dim3((uint32_t)std::min<uint64_t>((m + 3) / 4, (uint64_t)ctx->num_cu * 256)), dim3(64), 0, ctx->stream,
                            c->d_data.p, c->N, c->K, c->bits, c->stride, m, d_nodes, d_out, s_c.as<uint32_t>());
     else
