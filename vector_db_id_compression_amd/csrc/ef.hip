@@ -1187,64 +1187,91 @@ struct EfRowsFlags {
     uint32_t bad, over, maxid, pad;
 };
 
-template <int KP>
+template <int KP, bool FULL>  // FULL: K == KP
 __global__ void __launch_bounds__(64) k_ef_rows_encode_tile(const int32_t *__restrict__ rows, uint64_t N, uint32_t K, uint32_t kmagic,
                                                             uint32_t vec, uint32_t LW, uint32_t HW, uint32_t smagic, uint32_t ubound,
                                                             uint64_t *__restrict__ arena, uint2 *__restrict__ meta, EfRowsTot *tot,
                                                             EfRowsFlags *flags) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[RowsTile<KP>::DWORDS];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // the tile image, then the 64 records: sized by the host
     const uint32_t lane = lane_id();
-    const uint64_t row0 = (uint64_t)blockIdx.x * 64u;
-    const uint32_t nrows = (uint32_t)(N - row0 < 64u ? N - row0 : 64u);
-    uint32_t r[KP];
-    tile_load_rows<KP>(rows, row0, nrows, K, kmagic, vec != 0u, lds, r);
-    bool bad;
-    uint32_t u;  // universe = the largest id of the row, taken before the sort (altid_impl.cpp:75)
-    const uint32_t n = tile_row_edges<KP>(r, K, bad, u);
-    const bool over = u > ubound;
-    lane_bitonic<KP>(r);  // altid_impl.cpp:76 (padding 0xffffffff sorts to the end)
-    uint32_t l = 0;       // elias_fano.hpp:28: msb(u / n), 0 when u / n == 0
-    if (n && u >= n) {
-        l = (uint32_t)__builtin_clz(n) - (uint32_t)__builtin_clz(u);
-        if ((n << l) > u) l--;
-    }
-    const uint32_t hb = n ? (n + 1u) + (u >> l) + 1u : 0u;  // :29; empty rows have no bitstream object (altid_impl.cpp:69-71)
-    const uint32_t S = LW + HW, S1 = S | 1u;  // LDS records at an odd word stride: any per-lane word index is conflict-free
-    uint64_t *rec64 = (uint64_t *)lds;
-    for (uint32_t f = lane; f < 64u * S1; f += 64u) rec64[f] = 0ull;
-    __syncthreads();
-    if (!(bad || over)) {
-        uint32_t *rec = lds + lane * S1 * 2u;
-        uint32_t *rech = rec + 2u * LW;
-        const uint32_t keep = (1u << l) - 1u;  // l <= 30
-        uint32_t bp = 0;
+    const bool pf = FULL && vec != 0u;
+    // LDS image: lane t's record at dword t * SDW, SDW = 2 S + 1 (odd: a per-lane dword index is conflict-free)
+    const uint32_t S = LW + HW, SDW = 2u * S + 1u;
+    const uint32_t step_rows = tile_div(64u, S, smagic), step_w = 64u - step_rows * S;
+    unsigned long long bits = 0, edges = 0;
+    uint32_t mx = 0;
+    bool anybad = false, anyover = false;
+    // One tile per wavefront (the persistent form with the next tile's block in flight, which the decoders use, measured slower here:
+    // 254 registers and a wait for the previous tile's stores at every commit -- see k_compact_rows_encode_tile).
+    {
+        const uint64_t row0 = (uint64_t)blockIdx.x * 64u;
+        const uint32_t nrows = (uint32_t)(N - row0 < 64u ? N - row0 : 64u);
+        uint32_t r[KP];
+        {
+            TileRegs<KP> pre;
+            if (pf) tile_issue_rows<KP>(rows, row0, nrows, pre);
+            tile_commit_rows<KP, FULL>(rows, row0, nrows, K, kmagic, pf, pre, lds, r);
+        }
+        bool bad;
+        uint32_t u;  // universe = the largest id of the row, taken before the sort (altid_impl.cpp:75)
+        uint32_t n = tile_row_edges<KP>(r, bad, u);
+        if (lane >= nrows) { n = 0; u = 0; bad = false; }  // (lanes behind the last row of the last tile)
+        const bool over = u > ubound;
+        lane_sort<KP>(r);  // altid_impl.cpp:76 (padding 0xffffffff sorts to the end)
+        uint32_t l = 0;    // elias_fano.hpp:28: msb(u / n), 0 when u / n == 0
+        if (n && u >= n) {
+            l = (uint32_t)__builtin_clz(n) - (uint32_t)__builtin_clz(u);
+            if ((n << l) > u) l--;
+        }
+        const uint32_t hb = n ? (n + 1u) + (u >> l) + 1u : 0u;  // :29; empty rows have no bitstream object (altid_impl.cpp:69-71)
+        {
+            uint4 *z = (uint4 *)lds;
+            const uint32_t nz = (64u * SDW + 3u) / 4u;
+            for (uint32_t f = lane; f < nz; f += 64u) z[f] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
+        {
+            // Branch-free: an element that is not one (e >= n, or a row that is reported as bad) ORs zeros, which is harmless anywhere
+            // inside the LDS image (bit e * l <= 63 * 30: dword 60 of the lane's record at most, and the host adds 64 dwords behind the records).
+            uint32_t *rec = lds + lane * SDW;
+            uint32_t *rech = rec + 2u * LW;
+            const uint32_t nn = (bad || over) ? 0u : n;
+            const uint32_t keep = (1u << l) - 1u;  // l <= 30
+            uint32_t bp = 0;
 #pragma unroll
-        for (int e = 0; e < KP; e++) {
-            if ((uint32_t)e < n) {
-                const uint32_t x = r[e];
-                if (l) {  // low stream: l bits per element, LSB first (elias_fano.hpp:40-42)
-                    const uint32_t v = x & keep, sh = bp & 31u, dw = bp >> 5;
-                    atomicOr(&rec[dw], v << sh);
-                    if (sh + l > 32u) atomicOr(&rec[dw + 1u], v >> (32u - sh));
-                }
-                const uint32_t pos = (x >> l) + (uint32_t)e;  // high stream: bit (x >> l) + e (:43)
-                atomicOr(&rech[pos >> 5], 1u << (pos & 31u));
+            for (int e = 0; e < KP; e++) {
+                const bool on = (uint32_t)e < nn;
+                const uint32_t x = on ? r[e] : 0u;
+                // low stream: l bits per element, LSB first (elias_fano.hpp:40-42)
+                const uint64_t v = (uint64_t)(x & keep) << (bp & 31u);
+                uint32_t *d = rec + (bp >> 5);
+                atomicOr(d, (uint32_t)v);
+                atomicOr(d + 1, (uint32_t)(v >> 32));
+                // high stream: bit (x >> l) + e (:43)
+                const uint32_t pos = (x >> l) + (uint32_t)e;
+                atomicOr(&rech[pos >> 5], (on ? 1u : 0u) << (pos & 31u));
                 bp += l;
             }
         }
-    }
-    __syncthreads();
-    {
-        uint64_t *dst = arena + row0 * S;
-        const uint32_t total = nrows * S;
-        for (uint32_t f = lane; f < total; f += 64u) {
-            const uint32_t row = tile_div(f, S, smagic);
-            dst[f] = rec64[row * S1 + (f - row * S)];
+        __syncthreads();
+        {
+            uint64_t *dst = arena + row0 * S;
+            const uint32_t total = nrows * S;  // S <= 32 words per row: at most 32 per lane
+            TileCursor c = tile_cursor(S, smagic);
+#pragma unroll 4
+            for (uint32_t f = lane; f < total; f += 64u) {
+                const uint32_t *q = lds + c.row * SDW + 2u * c.w;
+                dst[f] = ((uint64_t)q[1] << 32) | q[0];
+                tile_advance(c, S, step_rows, step_w);
+            }
         }
+        if (lane < nrows) meta[row0 + lane] = make_uint2(u, n | (l << 8));
+        bits += (unsigned long long)n * l + hb;
+        edges += n;
+        mx = mx > u ? mx : u;
+        anybad = anybad || bad;
+        anyover = anyover || over;
     }
-    if (lane < nrows) meta[row0 + lane] = make_uint2(u, n | (l << 8));
-    unsigned long long bits = (unsigned long long)n * l + hb, edges = n;
-    uint32_t mx = u;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         bits += __shfl_xor(bits, o, 64);
@@ -1252,84 +1279,149 @@ __global__ void __launch_bounds__(64) k_ef_rows_encode_tile(const int32_t *__res
         const uint32_t w = (uint32_t)__shfl_xor((int)mx, o, 64);
         mx = mx > w ? mx : w;
     }
-    const uint64_t anybad = ballot(bad), anyover = ballot(over);
+    const uint64_t wbad = ballot(anybad), wover = ballot(anyover);
     if (lane == 0) {
         if (edges) {
             atomicAdd(&tot[blockIdx.x & 63u].bits, bits);
             atomicAdd(&tot[blockIdx.x & 63u].edges, edges);
         }
-        if (anybad) atomicOr(&flags->bad, 1u);
-        if (anyover) { atomicOr(&flags->over, 1u); atomicMax(&flags->maxid, mx); }
+        if (wbad) atomicOr(&flags->bad, 1u);
+        if (wover) { atomicOr(&flags->over, 1u); atomicMax(&flags->maxid, mx); }
     }
 }
 
-// decode: the wavefront's 64 records come in as one block (nodes == NULL: rows w0 .. w0+63) or record by record (a node list);
-// pass 1, lane = row: the set bits of the high words are enumerated (elias_fano.hpp:233-249) and element e's high part
-// goes to stage[e * 65 + row]; pass 2, lane = element: for each row in turn the low bits are read (:235) and the row leaves
-// as one contiguous store, -1 padded.
-template <int KP>
+// decode: persistent wavefronts, 64 records per tile: they come in as one block (nodes == NULL: rows w0 .. w0+63; the next tile's
+// block is requested before this one is decoded) or record by record (a node list).
+// Pass 1, lane = row: the set bits of the row's high words are enumerated 32 bits at a time (elias_fano.hpp:233-249) and element
+// e's high part -- x >> l < 2 n <= 128: one byte -- goes to stage[row][e].  Pass 2, lane = (row of a group of four, four
+// consecutive elements): the four high parts are one LDS dword, the low bits come from the LDS record (:235), value = high << l |
+// low, -1 behind the row's edges, one 16-byte store per lane: 1 KiB of four finished rows per instruction.
+template <int KP, int HWC, bool QUAD>
 __global__ void __launch_bounds__(64) k_ef_rows_decode_tile(const uint64_t *__restrict__ arena, const uint2 *__restrict__ meta, uint64_t m,
-                                                            const uint64_t *__restrict__ nodes, uint32_t K, uint32_t LW, uint32_t HW,
-                                                            uint32_t smagic, int32_t *__restrict__ out, uint32_t *__restrict__ counts) {
-    __shared__ __attribute__((aligned(16))) uint32_t stage[KP * 65];
-    extern __shared__ __attribute__((aligned(16))) uint64_t rec64[];  // 64 records of S | 1 words
+                                                            const uint64_t *__restrict__ nodes, uint32_t K, uint32_t LW, uint32_t smagic,
+                                                            int32_t *__restrict__ out, uint32_t *__restrict__ counts) {
+    constexpr uint32_t SROW = KP + 4;  // bytes per stage row: a whole, odd number of dwords
+    __shared__ __attribute__((aligned(16))) uint8_t stage[64 * SROW];
+    __shared__ uint32_t rowmeta[64];
+    extern __shared__ __attribute__((aligned(16))) uint64_t rec64[];  // 64 records of S | 1 words (+ 1 spill word)
     const uint32_t lane = lane_id();
-    const uint64_t w0 = (uint64_t)blockIdx.x * 64u;
-    const uint32_t nrows = (uint32_t)(m - w0 < 64u ? m - w0 : 64u);
-    const uint32_t S = LW + HW, S1 = S | 1u;
-    const bool have = lane < nrows;
-    uint64_t row = w0 + lane;
-    if (nodes && have) row = nodes[row];
-    const uint2 mt = have ? meta[row] : make_uint2(0u, 0u);
-    uint32_t n = mt.y & 0xffu;
-    n = n < (uint32_t)KP ? n : (uint32_t)KP;
-    const uint32_t l = (mt.y >> 8) & 0x1fu;
-    if (nodes) {
-        for (uint32_t w = 0; w < S; w++) rec64[lane * S1 + w] = have ? arena[row * S + w] : 0ull;
-    } else {
-        const uint64_t *src = arena + w0 * S;
-        const uint32_t total = nrows * S;
-        for (uint32_t f = lane; f < total; f += 64u) {
-            const uint32_t rr = tile_div(f, S, smagic);
-            rec64[rr * S1 + (f - rr * S)] = src[f];
-        }
+    const uint64_t ntiles = (m + 63u) / 64u;
+    const uint32_t S = LW + (uint32_t)HWC, S1 = S | 1u;
+    const uint32_t step_rows = tile_div(128u, S, smagic), step_w = 128u - step_rows * S;
+    uint4 pv[16];
+    uint2 mt = make_uint2(0u, 0u);
+    uint64_t tile = blockIdx.x;
+    if (!nodes && tile < ntiles) {
+        // the block of nrows * S words as 16-byte pieces (w0 * S words is a multiple of 64 words: aligned); S <= 32: <= 16 per lane
+        const uint32_t nr = (uint32_t)(m - tile * 64u < 64u ? m - tile * 64u : 64u);
+        tile_fetch16<16>((const uint4 *)(arena + tile * 64u * S), (nr * S + 1u) >> 1, pv);  // (odd: the last piece's second word is unused)
+        if (lane < nr) mt = meta[tile * 64u + lane];
     }
-    __syncthreads();
-    {
-        const uint64_t *hw = rec64 + lane * S1 + LW;
-        uint32_t e = 0;
-        for (uint32_t w = 0; w < HW; w++) {
-            uint64_t cur = e < n ? hw[w] : 0ull;
-            while (ballot(cur != 0ull)) {
-                if (cur != 0ull) {
-                    const uint32_t bit = (uint32_t)__builtin_ctzll(cur);
-                    cur &= cur - 1ull;
-                    stage[e * 65u + lane] = w * 64u + bit - e;
-                    e++;
-                    if (e >= n) cur = 0ull;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const uint64_t w0 = tile * 64u;
+        const uint32_t nrows = (uint32_t)(m - w0 < 64u ? m - w0 : 64u);
+        const bool have = lane < nrows;
+        if (nodes) {
+            const uint64_t row = have ? nodes[w0 + lane] : 0ull;
+            mt = have ? meta[row] : make_uint2(0u, 0u);
+            for (uint32_t w = 0; w < S; w++) rec64[lane * S1 + w] = have ? arena[row * S + w] : 0ull;
+        } else {
+            const uint32_t total = nrows * S, pieces = (total + 1u) >> 1;
+            TileCursor c = tile_cursor(S, smagic, 2u * lane);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if ((uint32_t)i * 64u < pieces) {
+                    const uint32_t f = 2u * ((uint32_t)i * 64u + lane);
+                    if (f < total) rec64[c.row * S1 + c.w] = ((uint64_t)pv[i].y << 32) | pv[i].x;
+                    if (f + 1u < total) {
+                        const bool wrap = c.w + 1u == S;
+                        rec64[(wrap ? c.row + 1u : c.row) * S1 + (wrap ? 0u : c.w + 1u)] = ((uint64_t)pv[i].w << 32) | pv[i].z;
+                    }
+                    tile_advance(c, S, step_rows, step_w);
                 }
             }
         }
-    }
-    __syncthreads();
-    for (uint32_t rr = 0; rr < nrows; rr++) {
-        const uint32_t n_r = rl(n, rr), l_r = rl(l, rr);
-        if (lane < K) {
-            int32_t v = -1;
-            if (lane < n_r) {
-                const uint32_t hi = stage[lane * 65u + rr];
-                uint32_t low = 0;
-                if (l_r) {
-                    const uint32_t bp = lane * l_r;
-                    const uint32_t *rw = (const uint32_t *)(rec64 + rr * S1) + (bp >> 5);
-                    low = (uint32_t)(((((uint64_t)rw[1]) << 32) | rw[0]) >> (bp & 31u)) & ((1u << l_r) - 1u);
-                }
-                v = (int32_t)((hi << l_r) | low);
+        uint32_t n = have ? mt.y & 0xffu : 0u;
+        n = n < (uint32_t)KP ? n : (uint32_t)KP;
+        rowmeta[lane] = n | (mt.y & 0x1f00u);
+        if (!nodes) {
+            const uint64_t nt = tile + gridDim.x;
+            if (nt < ntiles) {
+                const uint32_t nr = (uint32_t)(m - nt * 64u < 64u ? m - nt * 64u : 64u);
+                tile_fetch16<16>((const uint4 *)(arena + nt * 64u * S), (nr * S + 1u) >> 1, pv);
+                mt = lane < nr ? meta[nt * 64u + lane] : make_uint2(0u, 0u);
             }
-            out[(w0 + rr) * K + lane] = v;
         }
+        __syncthreads();
+        {
+            uint32_t hd[2 * HWC];
+#pragma unroll
+            for (int w = 0; w < HWC; w++) {
+                const uint64_t h = n ? rec64[lane * S1 + LW + (uint32_t)w] : 0ull;
+                hd[2 * w] = (uint32_t)h;
+                hd[2 * w + 1] = (uint32_t)(h >> 32);
+            }
+            uint8_t *sp = stage + lane * SROW;  // -> stage[row][e]
+            uint32_t off = 0;                   // 32 j - e
+            uint32_t left = n;                  // (a record holds exactly n set bits; `left` keeps a damaged one inside the stage)
+#pragma unroll
+            for (int j = 0; j < 2 * HWC; j++) {
+                uint32_t cur = left ? hd[j] : 0u;
+                while (ballot(cur != 0u)) {
+                    if (cur != 0u) {
+                        const uint32_t bit = (uint32_t)__builtin_ctz(cur);
+                        cur &= cur - 1u;
+                        *sp++ = (uint8_t)(off + bit);
+                        off--;
+                        left--;
+                        cur = left ? cur : 0u;
+                    }
+                }
+                off += 32u;
+            }
+        }
+        __syncthreads();
+        if (QUAD) {  // K % 4 == 0, out 16-byte aligned
+            const uint32_t g = lane >> 4, q4 = (lane & 15u) * 4u;
+            const uint32_t qs = q4 < (uint32_t)KP ? q4 : 0u;
+#pragma unroll 2
+            for (uint32_t r0 = 0; r0 < nrows; r0 += 4u) {
+                const uint32_t rr = r0 + g;
+                const uint32_t rm = rowmeta[rr];
+                const uint32_t his = *(const uint32_t *)(stage + rr * SROW + qs);
+                const uint32_t n_r = rm & 0xffu, l_r = rm >> 8;
+                const uint32_t *rw = (const uint32_t *)(rec64 + rr * S1);
+                const uint32_t lmask = (1u << l_r) - 1u;
+                int32_t v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t e = q4 + (uint32_t)k;
+                    const uint32_t bp = (e < n_r ? e : 0u) * l_r;  // (slots behind the row's edges read element 0 and discard it)
+                    const uint32_t *q = rw + (bp >> 5);
+                    const uint32_t low = __builtin_amdgcn_alignbit(q[1], q[0], bp & 31u) & lmask;
+                    v[k] = e < n_r ? (int32_t)((((his >> (8 * k)) & 0xffu) << l_r) | low) : -1;
+                }
+                if (rr < nrows && q4 < K) *(int4 *)(out + (w0 + rr) * K + q4) = make_int4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+            for (uint32_t rr = 0; rr < nrows; rr++) {
+                const uint32_t rm = rowmeta[rr];
+                const uint32_t n_r = rm & 0xffu, l_r = rm >> 8;
+                if (lane < K) {
+                    int32_t v = -1;
+                    if (lane < n_r) {
+                        const uint32_t hi = stage[rr * SROW + lane];
+                        const uint32_t bp = lane * l_r;
+                        const uint32_t *q = (const uint32_t *)(rec64 + rr * S1) + (bp >> 5);
+                        v = (int32_t)((hi << l_r) | (__builtin_amdgcn_alignbit(q[1], q[0], bp & 31u) & ((1u << l_r) - 1u)));
+                    }
+                    out[(w0 + rr) * K + lane] = v;
+                }
+            }
+        }
+        if (counts && have) counts[w0 + lane] = n;
+        __syncthreads();  // (the next tile's records go to the same LDS)
     }
-    if (counts && have) counts[w0 + lane] = n;
 }
 
 // arena -> the CSR streams of a list object (ef_ensure_csr: export, save, decode_lists, get on a graph object)
@@ -2111,15 +2203,29 @@ static int ef_decode_rows_arena(vidc_ctx *ctx, const vidc_ef *e, uint64_t m, con
     }
     if (counts) VIDC_TRY(s_c.get(ctx, m * 4));
     const uint32_t S = e->a_lw + e->a_hw;
-    const size_t dyn = (size_t)64 * (S | 1u) * 8;
-    const dim3 grid((uint32_t)((m + 63) / 64));
+    const size_t dyn = ((size_t)64 * (S | 1u) + 1) * 8;
+    const dim3 grid(tile_grid(ctx->num_cu, (m + 63) / 64, (uint32_t)std::min<size_t>(16, (150u << 10) / (dyn + 4608 + 256))));
+    uint32_t *d_cnt = counts ? s_c.as<uint32_t>() : nullptr;
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    if (e->K <= 32)
-        hipLaunchKernelGGL(k_ef_rows_decode_tile<32>, grid, dim3(64), dyn, ctx->stream, e->d_arena.p, e->d_rmeta.p, m, d_nodes, K, e->a_lw,
-                           e->a_hw, tile_magic(S), d_out, counts ? s_c.as<uint32_t>() : nullptr);
-    else
-        hipLaunchKernelGGL(k_ef_rows_decode_tile<64>, grid, dim3(64), dyn, ctx->stream, e->d_arena.p, e->d_rmeta.p, m, d_nodes, K, e->a_lw,
-                           e->a_hw, tile_magic(S), d_out, counts ? s_c.as<uint32_t>() : nullptr);
+    const bool quad = (K & 3u) == 0u && ((uintptr_t)d_out & 15u) == 0;
+#define VIDC_EF_ROWS_DEC2(KP, HWC, Q)                                                                                                  \
+    hipLaunchKernelGGL((k_ef_rows_decode_tile<KP, HWC, Q>), grid, dim3(64), dyn, ctx->stream, e->d_arena.p, e->d_rmeta.p, m, d_nodes, K, \
+                       e->a_lw, tile_magic(S), d_out, d_cnt)
+#define VIDC_EF_ROWS_DEC(KP, HWC)                        \
+    do {                                                 \
+        if (quad) VIDC_EF_ROWS_DEC2(KP, HWC, true);      \
+        else VIDC_EF_ROWS_DEC2(KP, HWC, false);          \
+    } while (0)
+    if (e->K <= 32) {  // (3 K + 1 bits: K <= 21 / 32)
+        if (e->a_hw == 1) VIDC_EF_ROWS_DEC(32, 1);
+        else VIDC_EF_ROWS_DEC(32, 2);
+    } else {           // (K <= 42 / 63 / 64)
+        if (e->a_hw <= 2) VIDC_EF_ROWS_DEC(64, 2);
+        else if (e->a_hw == 3) VIDC_EF_ROWS_DEC(64, 3);
+        else VIDC_EF_ROWS_DEC(64, 4);
+    }
+#undef VIDC_EF_ROWS_DEC
+#undef VIDC_EF_ROWS_DEC2
     VIDC_HIP(hipGetLastError());
     VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     if (counts) VIDC_HIP(hipMemcpyAsync(h_io.p, s_c.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2192,20 +2298,24 @@ int vidc_ef_encode_rows(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_t *d_
     for (int attempt = 0;; attempt++) {
         ef_rows_geometry(K, ubound, &e->a_lw, &e->a_hw);
         const uint32_t S = e->a_lw + e->a_hw;
-        if ((S | 1u) * 2u > (K <= 32 ? 33u : 65u)) { set_error("EF rows: record of %u words does not fit the tile", S); return VIDC_ERR_UNSUPPORTED; }
-        VIDC_TRY(e->d_arena.alloc(N ? N * S : 1, ctx->dpool));
+        if (2u * S + 1u > (K <= 32 ? 33u : 65u)) { set_error("EF rows: record of %u words does not fit the tile", S); return VIDC_ERR_UNSUPPORTED; }
+        VIDC_TRY(e->d_arena.alloc(N * S + 2, ctx->dpool));  // (+2: the decoder reads 16-byte pieces)
         VIDC_HIP(hipMemsetAsync(s_tot.p, 0, tot_bytes, ctx->stream));
         VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
         if (N) {
             const dim3 grid((uint32_t)((N + 63) / 64));
             EfRowsTot *d_tot = s_tot.as<EfRowsTot>();
             EfRowsFlags *d_fl = (EfRowsFlags *)(d_tot + 64);
-            if (K <= 32)
-                hipLaunchKernelGGL(k_ef_rows_encode_tile<32>, grid, dim3(64), 0, ctx->stream, d_rows, N, K, tile_magic(K), vec ? 1u : 0u,
-                                   e->a_lw, e->a_hw, tile_magic(S), ubound, e->d_arena.p, e->d_rmeta.p, d_tot, d_fl);
-            else
-                hipLaunchKernelGGL(k_ef_rows_encode_tile<64>, grid, dim3(64), 0, ctx->stream, d_rows, N, K, tile_magic(K), vec ? 1u : 0u,
-                                   e->a_lw, e->a_hw, tile_magic(S), ubound, e->d_arena.p, e->d_rmeta.p, d_tot, d_fl);
+#define VIDC_EF_ROWS_ENC(KP, FULL)                                                                                                     \
+    hipLaunchKernelGGL((k_ef_rows_encode_tile<KP, FULL>), grid, dim3(64),                                                                   \
+                       4u * std::max<size_t>((FULL && vec) ? RowsTile<KP>::DWORDS_PF : RowsTile<KP>::DWORDS, 64u * (2u * S + 1u) + 64u), ctx->stream, \
+                       d_rows, N, K, tile_magic(K), vec ? 1u : 0u, e->a_lw, \
+                       e->a_hw, tile_magic(S), ubound, e->d_arena.p, e->d_rmeta.p, d_tot, d_fl)
+            if (K == 32) VIDC_EF_ROWS_ENC(32, true);
+            else if (K < 32) VIDC_EF_ROWS_ENC(32, false);
+            else if (K == 64) VIDC_EF_ROWS_ENC(64, true);
+            else VIDC_EF_ROWS_ENC(64, false);
+#undef VIDC_EF_ROWS_ENC
             VIDC_HIP(hipGetLastError());
         }
         VIDC_HIP(hipEventRecord(ctx->ev1, ctx->stream));

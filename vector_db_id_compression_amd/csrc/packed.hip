@@ -352,89 +352,187 @@ __global__ void __launch_bounds__(64) k_compact_rows_decode(const uint8_t *data,
 }
 
 // ---- the same two for K <= 64 rows whose stride is a whole number of dwords (every K = 32 / 64 graph), 64 consecutive rows per
-// wavefront (rows_tile.h): the rows come in as one coalesced block and are transposed through LDS; lane t packs row t -- the bit
-// position of field e is e * bits for EVERY lane, so the shifts are scalar, a row image is built in registers 32 bits at a time
-// (no atomics, no barrier per row) and goes to the lane's LDS record; the 64 records leave as one contiguous block.  Every byte of
-// the output is written (fields behind the sentinel are zero, :31-36): the buffer needs no memset.
-template <int KP>
+// wavefront (rows_tile.h): the rows come in as one coalesced block and are transposed through LDS; lane t packs row t -- the bit position of field e is e * bits for EVERY lane, so shift amounts and dword
+// positions are scalar, a row image is built 32 bits at a time in registers (no atomics, no barrier per row, no branch: every
+// step stores the dword it is filling, the finished image of a dword overwrites its partial ones) and goes to the lane's LDS
+// record; the 64 records leave as one contiguous block of 16-byte stores.  Every byte of the output is written (fields behind the
+// sentinel are zero, :31-36): the buffer needs no memset.
+template <int KP, bool FULL>  // FULL: K == KP
 __global__ void __launch_bounds__(64) k_compact_rows_encode_tile(const int32_t *__restrict__ rows, uint64_t N, uint32_t K, uint32_t kmagic,
                                                                  uint32_t vec, uint32_t bits, uint32_t SD, uint32_t sdmagic,
                                                                  uint32_t *__restrict__ out, uint32_t *err) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[RowsTile<KP>::DWORDS];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // the tile image, then the 64 records: sized by the host
     const uint32_t lane = lane_id();
-    const uint64_t row0 = (uint64_t)blockIdx.x * 64u;
-    const uint32_t nrows = (uint32_t)(N - row0 < 64u ? N - row0 : 64u);
-    uint32_t r[KP];
-    tile_load_rows<KP>(rows, row0, nrows, K, kmagic, vec != 0u, lds, r);
-    bool bad;
-    uint32_t mx;
-    const uint32_t n = tile_row_edges<KP>(r, K, bad, mx);  // edges before the first -1
-    bad |= n && (uint64_t)mx >= N;
-    if (ballot(bad) && lane == 0) *(volatile uint32_t *)err = 1u;  // (every writer stores the same value)
+    const bool pf = FULL && vec != 0u;
     const uint32_t SD1 = SD | 1u;  // odd record stride: conflict-free for any (uniform) dword index
-    uint32_t *rec = lds + lane * SD1;
-    uint64_t acc = 0;
-    uint32_t fill = 0, w = 0;  // wave-uniform
+    const uint32_t n32 = (uint32_t)N;
+    bool anybad = false;
+    // One tile per wavefront.  (Measured, round 6: persistent wavefronts with the next tile's block in flight -- the form the decoders
+    // use -- cost the 64 registers of the block plus a wait for the previous tile's stores at every commit (vmcnt counts loads and
+    // stores in order): 0.101 ms at 8 wavefronts per CU against 0.094 ms for this form at 9.)
+    {
+        const uint64_t row0 = (uint64_t)blockIdx.x * 64u;
+        const uint32_t nrows = (uint32_t)(N - row0 < 64u ? N - row0 : 64u);
+        uint32_t r[KP];
+        {
+            TileRegs<KP> pre;
+            if (pf) tile_issue_rows<KP>(rows, row0, nrows, pre);
+            tile_commit_rows<KP, FULL>(rows, row0, nrows, K, kmagic, pf, pre, lds, r);
+        }
+        uint32_t *rec = lds + lane * SD1;
+        bool alive = true, bad = false;  // (lane masks in scalar registers)
+        uint32_t lo = 0;                 // the bits of the dword being filled
+        uint32_t fill = 0, wofs = 0;     // wave-uniform: bits in `lo`, dword index
 #pragma unroll
-    for (int e = 0; e < KP; e++) {
-        if ((uint32_t)e < K) {
-            // values 0..n-1 are neighbours; value n (if n < K) is the sentinel N; nothing after it (:31-36)
-            const uint32_t v = (uint32_t)e < n ? r[e] : ((uint32_t)e == n ? (uint32_t)N : 0u);
-            acc |= (uint64_t)v << fill;
-            fill += bits;
-            if (fill >= 32u) {
-                rec[w++] = (uint32_t)acc;
-                acc >>= 32;
-                fill -= 32u;
+        for (int e = 0; e < KP; e++) {
+            if (FULL || (uint32_t)e < K) {
+                // values 0..n-1 are neighbours; value n (if n < K) is the sentinel N; nothing after it (:31-36)
+                const uint32_t x = r[e];
+                const bool was = alive;
+                alive = alive && x != 0xffffffffu;
+                bad = bad || (alive && x >= n32);  // (a negative id is >= 2^31 here)
+                const uint32_t v = alive ? x : (was ? n32 : 0u);
+                const uint64_t t = ((uint64_t)v << fill) | lo;
+                rec[wofs] = (uint32_t)t;
+                fill += bits;
+                const bool full = fill >= 32u;
+                lo = full ? (uint32_t)(t >> 32) : (uint32_t)t;
+                wofs += full ? 1u : 0u;
+                fill -= full ? 32u : 0u;
+            }
+        }
+        if (fill) rec[wofs] = lo;
+        anybad = anybad || (bad && lane < nrows);
+        __syncthreads();
+        uint32_t *dst = out + row0 * SD;
+        if ((SD & 3u) == 0u) {  // 16-byte pieces never straddle two rows; SD <= 64: at most 16 pieces per lane
+            const uint32_t CPR = SD >> 2, total = nrows * CPR;
+            const uint32_t cmagic = tile_magic(CPR);
+            const uint32_t step_rows = tile_div(64u, CPR, cmagic), step_w = 64u - step_rows * CPR;
+            TileCursor c = tile_cursor(CPR, cmagic);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if ((uint32_t)i * 64u < total) {
+                    const uint32_t f = (uint32_t)i * 64u + lane;
+                    const uint32_t *s = lds + c.row * SD1 + 4u * c.w;
+                    if (f < total) ((uint4 *)dst)[f] = make_uint4(s[0], s[1], s[2], s[3]);
+                    tile_advance(c, CPR, step_rows, step_w);
+                }
+            }
+        } else {
+            const uint32_t total = nrows * SD;
+            const uint32_t step_rows = tile_div(64u, SD, sdmagic), step_w = 64u - step_rows * SD;
+            TileCursor c = tile_cursor(SD, sdmagic);
+            for (uint32_t f = lane; f < total; f += 64u) {
+                dst[f] = lds[c.row * SD1 + c.w];
+                tile_advance(c, SD, step_rows, step_w);
             }
         }
     }
-    if (fill) rec[w++] = (uint32_t)acc;
-    __syncthreads();
-    uint32_t *dst = out + row0 * SD;
-    const uint32_t total = nrows * SD;
-    for (uint32_t f = lane; f < total; f += 64u) {
-        const uint32_t row = tile_div(f, SD, sdmagic);
-        dst[f] = lds[row * SD1 + (f - row * SD)];
-    }
+    if (ballot(anybad) && lane == 0) *(volatile uint32_t *)err = 1u;  // (every writer stores the same value)
 }
 
-// decode: the 64 records come in as one block (nodes == NULL) or record by record; then, for each row in turn, lane e extracts
-// field e from the LDS record (two dwords around bit e * bits), the sentinel is found with one ballot (:43-49) and the row leaves
-// as one contiguous 4 * K-byte store, -1 padded
+// decode: persistent wavefronts, 64 records per tile: they come in as one block (nodes == NULL; the next tile's block is requested
+// before this one is decoded) or record by record.  QUAD (K % 4 == 0): lane = (row of a group of four, four consecutive fields):
+// each field is the two LDS dwords around its bit position (one v_alignbit), the sentinel of a row (:43-49) is found from four
+// ballots (one per field slot) restricted to the row's 16 lanes, and a lane stores its four values, -1 behind the sentinel, as 16
+// bytes: 1 KiB of four finished rows per instruction.  Otherwise lane = field, one row per step.
+template <bool QUAD>
 __global__ void __launch_bounds__(64) k_compact_rows_decode_tile(const uint32_t *__restrict__ data, uint64_t N, uint32_t K, uint32_t bits,
                                                                  uint32_t SD, uint32_t sdmagic, uint64_t m, const uint64_t *__restrict__ nodes,
                                                                  int32_t *__restrict__ out, uint32_t *__restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) uint32_t crec[];  // 64 records of SD | 1 dwords (+ 1 spill dword)
     const uint32_t lane = lane_id();
-    const uint64_t w0 = (uint64_t)blockIdx.x * 64u;
-    const uint32_t nrows = (uint32_t)(m - w0 < 64u ? m - w0 : 64u);
+    const uint64_t ntiles = (m + 63u) / 64u;
     const uint32_t SD1 = SD | 1u;
-    if (nodes) {
-        const uint64_t row = lane < nrows ? nodes[w0 + lane] : 0ull;
-        for (uint32_t w = 0; w < SD; w++) crec[lane * SD1 + w] = lane < nrows ? data[row * SD + w] : 0u;
-    } else {
-        const uint32_t *src = data + w0 * SD;
-        const uint32_t total = nrows * SD;
-        for (uint32_t f = lane; f < total; f += 64u) {
-            const uint32_t rr = tile_div(f, SD, sdmagic);
-            crec[rr * SD1 + (f - rr * SD)] = src[f];
+    const bool blockwise = !nodes && (SD & 3u) == 0u;
+    const uint32_t CPR = SD >> 2, cmagic = tile_magic(CPR);
+    const uint32_t mask = bits >= 32u ? 0xffffffffu : (1u << bits) - 1u;
+    const uint32_t n32 = (uint32_t)N;
+    uint4 pv[16];
+    uint64_t tile = blockIdx.x;
+    if (blockwise && tile < ntiles)
+        tile_fetch16<16>((const uint4 *)(data + tile * 64u * SD), (uint32_t)(m - tile * 64u < 64u ? m - tile * 64u : 64u) * CPR, pv);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const uint64_t w0 = tile * 64u;
+        const uint32_t nrows = (uint32_t)(m - w0 < 64u ? m - w0 : 64u);
+        if (blockwise) {
+            const uint32_t total = nrows * CPR;
+            const uint32_t step_rows = tile_div(64u, CPR, cmagic), step_w = 64u - step_rows * CPR;
+            TileCursor c = tile_cursor(CPR, cmagic);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if ((uint32_t)i * 64u < total) {
+                    if ((uint32_t)i * 64u + lane < total) {
+                        uint32_t *d = crec + c.row * SD1 + 4u * c.w;
+                        d[0] = pv[i].x; d[1] = pv[i].y; d[2] = pv[i].z; d[3] = pv[i].w;
+                    }
+                    tile_advance(c, CPR, step_rows, step_w);
+                }
+            }
+            const uint64_t nt = tile + gridDim.x;
+            if (nt < ntiles)
+                tile_fetch16<16>((const uint4 *)(data + nt * 64u * SD), (uint32_t)(m - nt * 64u < 64u ? m - nt * 64u : 64u) * CPR, pv);
+        } else if (nodes) {
+            const uint64_t row = lane < nrows ? nodes[w0 + lane] : 0ull;
+            for (uint32_t w = 0; w < SD; w++) crec[lane * SD1 + w] = lane < nrows ? data[row * SD + w] : 0u;
+        } else {
+            const uint32_t *src = data + w0 * SD;
+            const uint32_t total = nrows * SD;
+            const uint32_t step_rows = tile_div(64u, SD, sdmagic), step_w = 64u - step_rows * SD;
+            TileCursor c = tile_cursor(SD, sdmagic);
+            for (uint32_t f = lane; f < total; f += 64u) {
+                crec[c.row * SD1 + c.w] = src[f];
+                tile_advance(c, SD, step_rows, step_w);
+            }
         }
+        __syncthreads();
+        if (QUAD) {
+            const uint32_t g = lane >> 4, q4 = (lane & 15u) * 4u, gsh = g * 16u;
+            uint32_t dw[4], sh[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {  // (the second dword of a row's last field may be the record's padding dword: masked out)
+                const uint32_t f = q4 + (uint32_t)k < K ? q4 + (uint32_t)k : 0u;
+                dw[k] = (f * bits) >> 5;
+                sh[k] = (f * bits) & 31u;
+            }
+            for (uint32_t r0 = 0; r0 < nrows; r0 += 4u) {
+                const uint32_t rr = r0 + g;
+                const uint32_t *rec = crec + rr * SD1;
+                uint32_t v[4], p[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t *q = rec + dw[k];
+                    v[k] = __builtin_amdgcn_alignbit(q[1], q[0], sh[k]) & mask;
+                    const uint64_t bal = ballot(q4 + (uint32_t)k < K && v[k] == n32);
+                    const uint32_t mk = (uint32_t)(bal >> gsh) & 0xffffu;       // the sentinel flags of slot k in this row's 16 lanes
+                    p[k] = ((uint32_t)__ffs((int)mk) - 1u) * 4u + (uint32_t)k;  // (none: wraps to >= 2^32 - 4)
+                }
+                uint32_t n = min(min(p[0], p[1]), min(p[2], p[3]));
+                n = n < K ? n : K;
+                if (rr < nrows && q4 < K) {
+                    int4 o;
+                    o.x = q4 + 0u < n ? (int32_t)v[0] : -1; o.y = q4 + 1u < n ? (int32_t)v[1] : -1;
+                    o.z = q4 + 2u < n ? (int32_t)v[2] : -1; o.w = q4 + 3u < n ? (int32_t)v[3] : -1;
+                    *(int4 *)(out + (w0 + rr) * K + q4) = o;
+                    if (counts && q4 == 0u) counts[w0 + rr] = n;
+                }
+            }
+        } else {
+            const uint32_t pos = (lane < K ? lane : 0u) * bits, dw = pos >> 5, sh = pos & 31u;
+            uint32_t my_n = 0;
+            for (uint32_t rr = 0; rr < nrows; rr++) {
+                const uint32_t *rw = crec + rr * SD1 + dw;
+                const uint32_t v = __builtin_amdgcn_alignbit(rw[1], rw[0], sh) & mask;
+                const uint64_t endm = ballot(lane < K && v == n32);
+                const uint32_t n = endm ? ff1(endm) : K;
+                if (lane < K) out[(w0 + rr) * K + lane] = lane < n ? (int32_t)v : -1;
+                my_n = lane == rr ? n : my_n;
+            }
+            if (counts && lane < nrows) counts[w0 + lane] = my_n;
+        }
+        __syncthreads();  // (the next tile's records go to the same LDS)
     }
-    __syncthreads();
-    const uint32_t pos = lane * bits, dw = pos >> 5, sh = pos & 31u;
-    const uint64_t mask = (1ull << bits) - 1ull;
-    uint32_t my_n = 0;
-    for (uint32_t rr = 0; rr < nrows; rr++) {
-        const uint32_t *rw = crec + rr * SD1 + dw;
-        // (the second dword of the last field may be the record's padding dword: masked out)
-        const uint64_t v = lane < K ? ((((uint64_t)rw[1] << 32) | rw[0]) >> sh) & mask : ~0ull;
-        const uint64_t endm = ballot(lane < K && v == N);
-        const uint32_t n = endm ? ff1(endm) : K;
-        if (lane < K) out[(w0 + rr) * K + lane] = lane < n ? (int32_t)v : -1;
-        my_n = lane == rr ? n : my_n;
-    }
-    if (counts && lane < nrows) counts[w0 + lane] = my_n;
 }
 
 // the same for rows of any width (K > 64: NSG128 / NSG256 graphs): the wavefront walks the row 64 values at a time; the
@@ -533,12 +631,16 @@ int vidc_compact_rows_encode(vidc_ctx *ctx, uint64_t N, uint32_t K, const int32_
         if (tile) {
             const uint32_t SD = c->stride / 4u, vec = ((uintptr_t)d_rows & 15u) == 0 ? 1u : 0u;
             const dim3 tgrid((uint32_t)((N + 63) / 64));
-            if (K <= 32)
-                hipLaunchKernelGGL(k_compact_rows_encode_tile<32>, tgrid, dim3(64), 0, ctx->stream, d_rows, N, K, dev::tile_magic(K), vec,
-                                   c->bits, SD, dev::tile_magic(SD), (uint32_t *)c->d_data.p, s_err.as<uint32_t>());
-            else
-                hipLaunchKernelGGL(k_compact_rows_encode_tile<64>, tgrid, dim3(64), 0, ctx->stream, d_rows, N, K, dev::tile_magic(K), vec,
-                                   c->bits, SD, dev::tile_magic(SD), (uint32_t *)c->d_data.p, s_err.as<uint32_t>());
+#define VIDC_COMPACT_ENC(KP, FULL)                                                                                                       \
+    hipLaunchKernelGGL((k_compact_rows_encode_tile<KP, FULL>), tgrid, dim3(64),                                                              \
+                       4u * std::max<size_t>((FULL && vec) ? dev::RowsTile<KP>::DWORDS_PF : dev::RowsTile<KP>::DWORDS, 64u * (SD | 1u)), ctx->stream, \
+                       d_rows, N, K, dev::tile_magic(K), vec, c->bits, \
+                       SD, dev::tile_magic(SD), (uint32_t *)c->d_data.p, s_err.as<uint32_t>())
+            if (K == 32) VIDC_COMPACT_ENC(32, true);
+            else if (K < 32) VIDC_COMPACT_ENC(32, false);
+            else if (K == 64) VIDC_COMPACT_ENC(64, true);
+            else VIDC_COMPACT_ENC(64, false);
+#undef VIDC_COMPACT_ENC
         } else if (K <= 64)
             hipLaunchKernelGGL(k_compact_rows_encode, dim3(grid), dim3(64), 0, ctx->stream, d_rows, N, K, c->bits, c->stride,
                                c->d_data.p, s_err.as<uint32_t>());
@@ -588,9 +690,15 @@ int vidc_compact_rows_decode(vidc_ctx *ctx, const vidc_compact *c, uint64_t m, c
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     if (tile) {
         const uint32_t SD = c->stride / 4u;
-        hipLaunchKernelGGL(k_compact_rows_decode_tile, dim3((uint32_t)((m + 63) / 64)), dim3(64), ((size_t)64 * (SD | 1u) + 1u) * 4u, ctx->stream,
-                           (const uint32_t *)c->d_data.p, c->N, c->K, c->bits, SD, dev::tile_magic(SD), m, d_nodes, d_out,
-                           counts ? s_c.as<uint32_t>() : nullptr);
+        const size_t dyn = ((size_t)64 * (SD | 1u) + 1u) * 4u;
+        const dim3 tgrid(dev::tile_grid(ctx->num_cu, (m + 63) / 64, (uint32_t)std::min<size_t>(16, (150u << 10) / dyn)));
+        uint32_t *d_cnt = counts ? s_c.as<uint32_t>() : nullptr;
+        if ((c->K & 3u) == 0u && ((uintptr_t)d_out & 15u) == 0)
+            hipLaunchKernelGGL(k_compact_rows_decode_tile<true>, tgrid, dim3(64), dyn, ctx->stream, (const uint32_t *)c->d_data.p, c->N, c->K,
+                               c->bits, SD, dev::tile_magic(SD), m, d_nodes, d_out, d_cnt);
+        else
+            hipLaunchKernelGGL(k_compact_rows_decode_tile<false>, tgrid, dim3(64), dyn, ctx->stream, (const uint32_t *)c->d_data.p, c->N, c->K,
+                               c->bits, SD, dev::tile_magic(SD), m, d_nodes, d_out, d_cnt);
     } else if (c->K <= 64)
         hipLaunchKernelGGL(k_compact_rows_decode, dim3((uint32_t)std::min<uint64_t>((m + 3) / 4, (uint64_t)ctx->num_cu * 256)), dim3(64), 0, ctx->stream,
                            c->d_data.p, c->N, c->K, c->bits, c->stride, m, d_nodes, d_out, s_c.as<uint32_t>());

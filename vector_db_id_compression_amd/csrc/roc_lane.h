@@ -940,7 +940,7 @@ __global__ void __launch_bounds__(64) k_roc_encode_tiny_lane(RocEncArgs a, const
     // graph rows are in no particular order; IVF lists normally ascend (Faiss add order)
     const bool want_perm = !ROWS && a.perm != nullptr;
     const bool pending = want_perm && unsorted;  // input positions of an unsorted list: wave-per-list kernel
-    if (ROWS || ballot(unsorted && !pending)) lane_bitonic<KP>(r);
+    if (ROWS || ballot(unsorted && !pending)) lane_sort<KP>(r);
 #pragma unroll
     for (int e = 0; e < KP; e++) sid[e * 64 + lane] = r[e];
     if (ROWS && have) a.sizes[l] = n;

@@ -18,38 +18,74 @@ namespace dev {
 template <int KP>
 struct RowsTile {
     static constexpr uint32_t LD = KP + 1;          // leading dimension of the transposed image (dwords)
-    static constexpr uint32_t DWORDS = 64u * LD;    // LDS dwords a kernel has to provide
+    static constexpr uint32_t DWORDS = 64u * LD;    // LDS dwords of the image of a whole tile (rows read 4 bytes per lane)
+    static constexpr uint32_t DWORDS_PF = 64u * 33u;  // ... of a block requested with tile_issue_rows: 32 columns at a time
 };
+
+// host: wavefronts (= workgroups) of a persistent tile kernel: `per_cu` resident per CU, never more than there are tiles
+inline uint32_t tile_grid(int num_cu, uint64_t ntiles, uint32_t per_cu) {
+    const uint64_t cap = (uint64_t)(num_cu > 0 ? num_cu : 256) * (per_cu ? per_cu : 1u);
+    return (uint32_t)(ntiles < cap ? (ntiles ? ntiles : 1u) : cap);
+}
 
 // host: ceil(2^32 / d): floor(f / d) == __umulhi(f, magic) for f * d < 2^32 (f < 2^16 is all the tiles need)
 inline __host__ __device__ uint32_t tile_magic(uint32_t d) { return d > 1u ? (uint32_t)((0x100000000ull + d - 1u) / d) : 0u; }
 __device__ __forceinline__ uint32_t tile_div(uint32_t f, uint32_t d, uint32_t magic) { return d > 1u ? __umulhi(f, magic) : f; }
 
-// rows [row0, row0 + nrows) of the int32 [N, K] array -> r[0..KP) of lane t = row row0 + t (entries >= K and rows >= nrows: -1).
-// vec: the row array starts on a 16-byte boundary (then every tile does).  Ends with the LDS free for reuse.
+// The kernels are PERSISTENT: a wavefront walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and requests the block of its NEXT
+// tile (tile_issue_rows: 16-byte loads into registers, nothing waits) before it works on the current one, so the HBM round trip of
+// a tile hides behind the arithmetic of the previous tile instead of behind other wavefronts (the LDS image of a tile allows only
+// 9 wavefronts per CU, and one-shot wavefronts also pay their launch and kernel-argument loads per tile).
 template <int KP>
-__device__ __forceinline__ void tile_load_rows(const int32_t *__restrict__ rows, uint64_t row0, uint32_t nrows, uint32_t K,
-                                               uint32_t kmagic, bool vec, uint32_t *lds, uint32_t (&r)[KP]) {
+struct TileRegs {
+    int4 v[KP / 4];
+};
+// K == KP and a 16-byte aligned row array only (the caller's `pf`): lane j requests pieces i * 64 + j of the tile's block
+template <int KP>
+__device__ __forceinline__ void tile_issue_rows(const int32_t *__restrict__ rows, uint64_t row0, uint32_t nrows, TileRegs<KP> &t) {
+    constexpr int NC = KP / 4;
+    const uint32_t lane = lane_id();
+    const int4 *src = (const int4 *)(rows + row0 * (uint64_t)KP);
+    const uint32_t nchunk = nrows * (uint32_t)NC;
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+        const uint32_t c = (uint32_t)i * 64u + lane;
+        t.v[i] = src[c < nchunk ? c : 0u];  // (a short last tile re-reads its first piece: never out of bounds)
+    }
+}
+// rows [row0, row0 + nrows) -> r[0..KP) of lane t = row row0 + t (entries >= K: -1).  FULL: K == KP.  pf: the block was requested
+// with tile_issue_rows (FULL kernels, aligned row array); otherwise it is read here, 4 bytes per lane and load.
+// Ends with the LDS free for reuse.  Lanes >= nrows (last tile only) hold whatever the LDS held: the caller discards what it
+// derives from them.
+template <int KP, bool FULL>
+__device__ __forceinline__ void tile_commit_rows(const int32_t *__restrict__ rows, uint64_t row0, uint32_t nrows, uint32_t K,
+                                                 uint32_t kmagic, bool pf, const TileRegs<KP> &t, uint32_t *lds, uint32_t (&r)[KP]) {
     constexpr uint32_t LD = RowsTile<KP>::LD;
     const uint32_t lane = lane_id();
-    const int32_t *src = rows + row0 * K;
-    if (K == (uint32_t)KP && vec) {
-        constexpr int NC = KP / 4;  // 16-byte chunks per row == chunk loads per lane
-        const uint32_t nchunk = nrows * (uint32_t)NC;
-        int4 v[NC];
+    if (FULL && pf) {
+        // 32 columns at a time (LD = 33): the image of a K = 64 tile takes 8.25 KiB instead of 16.25, which is what bounds the
+        // wavefronts per CU of the encoders
+        constexpr int NC = KP / 4, HALVES = KP / 32, LDH = 33;
 #pragma unroll
-        for (int i = 0; i < NC; i++) {
-            const uint32_t c = (uint32_t)i * 64u + lane;
-            v[i] = make_int4(-1, -1, -1, -1);
-            if (c < nchunk) v[i] = ((const int4 *)src)[c];
-        }
+        for (int h = 0; h < HALVES; h++) {
+            if (h) __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NC; i++) {
-            const uint32_t c = (uint32_t)i * 64u + lane;
-            uint32_t *d = lds + (c / (uint32_t)NC) * LD + (c % (uint32_t)NC) * 4u;
-            d[0] = (uint32_t)v[i].x; d[1] = (uint32_t)v[i].y; d[2] = (uint32_t)v[i].z; d[3] = (uint32_t)v[i].w;
+            for (int i = 0; i < NC; i++) {
+                const uint32_t c = (uint32_t)i * 64u + lane;  // piece c: row c / NC, columns 4 (c % NC) ..
+                const uint32_t col = (c % (uint32_t)NC) * 4u;
+                if (col / 32u == (uint32_t)h) {
+                    uint32_t *d = lds + (c / (uint32_t)NC) * LDH + (col & 31u);
+                    d[0] = (uint32_t)t.v[i].x; d[1] = (uint32_t)t.v[i].y; d[2] = (uint32_t)t.v[i].z; d[3] = (uint32_t)t.v[i].w;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 32; e++) r[h * 32 + e] = lds[lane * LDH + (uint32_t)e];
         }
+        __syncthreads();
+        return;
     } else {
+        const int32_t *src = rows + row0 * K;
         const uint32_t total = nrows * K;
 #pragma unroll 8
         for (int i = 0; i < KP; i++) {
@@ -62,58 +98,73 @@ __device__ __forceinline__ void tile_load_rows(const int32_t *__restrict__ rows,
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < KP; e++) r[e] = ((uint32_t)e < K && lane < nrows) ? lds[lane * LD + (uint32_t)e] : 0xffffffffu;
-    __syncthreads();
-}
-
-// the transposed image (row t, entry e at lds[t * LD + e], every entry e < K of every row t < nrows defined) -> rows
-// [row0, row0 + nrows) of the int32 [m, K] output, coalesced
-template <int KP>
-__device__ __forceinline__ void tile_store_rows(int32_t *__restrict__ out, uint64_t row0, uint32_t nrows, uint32_t K,
-                                                uint32_t kmagic, bool vec, const uint32_t *lds) {
-    constexpr uint32_t LD = RowsTile<KP>::LD;
-    const uint32_t lane = lane_id();
-    int32_t *dst = out + row0 * K;
-    if (K == (uint32_t)KP && vec) {
-        constexpr int NC = KP / 4;
-        const uint32_t nchunk = nrows * (uint32_t)NC;
+    for (int e = 0; e < KP; e++) r[e] = lds[lane * LD + (uint32_t)e];
+    if (!FULL) {
 #pragma unroll
-        for (int i = 0; i < NC; i++) {
-            const uint32_t c = (uint32_t)i * 64u + lane;
-            const uint32_t *s = lds + (c / (uint32_t)NC) * LD + (c % (uint32_t)NC) * 4u;
-            const int4 v = make_int4((int)s[0], (int)s[1], (int)s[2], (int)s[3]);
-            if (c < nchunk) ((int4 *)dst)[c] = v;
-        }
-    } else {
-        const uint32_t total = nrows * K;
-#pragma unroll 8
-        for (int i = 0; i < KP; i++) {
-            const uint32_t f = (uint32_t)i * 64u + lane;
-            if (f < total) {
-                const uint32_t row = tile_div(f, K, kmagic);
-                dst[f] = (int32_t)lds[row * LD + (f - row * K)];
-            }
-        }
+        for (int e = 0; e < KP; e++) r[e] = (uint32_t)e < K ? r[e] : 0xffffffffu;
     }
+    __syncthreads();
 }
 
 // edges of a row = entries before the first -1 (altid_impl.cpp:61-68,110-117); entries from there on become 0xffffffff.
 // bad: a negative id other than the terminator among them.  mx: the largest id (0 for an empty row).
+// (`alive` is a lane mask in a scalar register pair: its update is one v_cmp and one s_and per entry.)
 template <int KP>
-__device__ __forceinline__ uint32_t tile_row_edges(uint32_t (&r)[KP], uint32_t K, bool &bad, uint32_t &mx) {
-    uint32_t n = K;
+__device__ __forceinline__ uint32_t tile_row_edges(uint32_t (&r)[KP], bool &bad, uint32_t &mx) {
+    bool alive = true;
+    uint32_t n = 0;
 #pragma unroll
-    for (int e = KP - 1; e >= 0; e--) n = (r[e] == 0xffffffffu && (uint32_t)e < n) ? (uint32_t)e : n;
-    int32_t m = 0;
-    bad = false;
-#pragma unroll
-    for (int e = 0; e < KP; e++) {
-        r[e] = (uint32_t)e < n ? r[e] : 0xffffffffu;
-        bad |= (uint32_t)e < n && (int32_t)r[e] < 0;
-        m = (int32_t)r[e] > m ? (int32_t)r[e] : m;  // (signed: padding is -1)
+    for (int e = 0; e < KP; e++) {  // (entries e >= K are 0xffffffff)
+        alive = alive && r[e] != 0xffffffffu;
+        n += alive ? 1u : 0u;
+        r[e] = alive ? r[e] : 0xffffffffu;
     }
-    mx = (uint32_t)m;
+    // as signed values the padding is -1, any other negative id is below it and the ids are >= 0
+    int32_t hi = 0, lo = 0;
+#pragma unroll
+    for (int e = 0; e < KP; e += 2) {
+        const int32_t a = (int32_t)r[e], b = e + 1 < KP ? (int32_t)r[e + 1] : -1;
+        hi = max(hi, max(a, b));
+        lo = min(lo, min(a, b));
+    }
+    bad = lo < -1;
+    mx = (uint32_t)hi;
     return n;
+}
+
+// (record, unit) of the flat unit index i * STEP + start over records of D units, advanced without a division
+struct TileCursor {
+    uint32_t row, w;
+};
+__device__ __forceinline__ TileCursor tile_cursor(uint32_t D, uint32_t dmagic, uint32_t start) {
+    TileCursor c;
+    c.row = tile_div(start, D, dmagic);
+    c.w = start - c.row * D;
+    return c;
+}
+__device__ __forceinline__ TileCursor tile_cursor(uint32_t D, uint32_t dmagic) { return tile_cursor(D, dmagic, lane_id()); }
+__device__ __forceinline__ void tile_advance(TileCursor &c, uint32_t D, uint32_t step_rows, uint32_t step_w) {  // += step_rows * D + step_w
+    c.w += step_w;
+    c.row += step_rows;
+    const bool wrap = c.w >= D;
+    c.w -= wrap ? D : 0u;
+    c.row += wrap ? 1u : 0u;
+}
+
+// A contiguous block of `total` 16-byte pieces (total <= 64 * NMAX) into registers, every load issued before anything waits:
+// piece i * 64 + lane -> pv[i] (pieces beyond the block: zero).  A loop that loads, waits and stores one piece per trip keeps ONE
+// load in flight per wavefront: ten HBM round trips in a row for a tile of compact-bit records.
+template <int NMAX>
+__device__ __forceinline__ void tile_fetch16(const uint4 *__restrict__ src, uint32_t total, uint4 (&pv)[NMAX]) {
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int i = 0; i < NMAX; i++) {
+        pv[i] = make_uint4(0u, 0u, 0u, 0u);
+        if ((uint32_t)i * 64u < total) {  // (uniform)
+            const uint32_t f = (uint32_t)i * 64u + lane;
+            pv[i] = src[f < total ? f : total - 1u];
+        }
+    }
 }
 
 }  // namespace dev
