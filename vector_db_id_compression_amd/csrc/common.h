@@ -285,6 +285,9 @@ struct vidc_ctx {
     uint64_t chain_info[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     // id payload copied device -> host through this context (vidc_copy_d2h, *_get, *_decode_gather): see vidc_ctx_d2h_bytes
     uint64_t d2h_bytes = 0;
+    // largest list universe (last id) the Elias-Fano encoder has met on this context: sizes the streams of the next object before
+    // its ids have been looked at (ef_encode_fast)
+    uint64_t ef_universe_hint = 0;
 };
 
 // vidc_*_decode_gather (include/vidc.h): decode the m touched lists into staging from the context's block cache, pick the
@@ -307,6 +310,24 @@ inline int vidc_decode_gather_impl(vidc_ctx *ctx, uint64_t nlist, uint64_t m, co
     VIDC_TRY(decode(staging.as<uint64_t>(), list_off.data()));
     return vidc::gather_to_host(ctx, staging.as<uint64_t>(), list_off.data(), m, n_items, item_slot, item_off, ids_out);
 }
+
+// VIDC_TRACE=1 prints host-side phase times of encode / decode calls (dev aid)
+struct HostTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    const char *what;
+    explicit HostTrace(const char *w) : what(w) {
+        static const bool env_on_ = [] { const char *e = std::getenv("VIDC_TRACE"); return e && e[0] == '1'; }();
+        on = env_on_;
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    void mark(const char *phase) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[vidc] %s: %-28s %8.3f ms\n", what, phase, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 // Kernel time of a call made of several phases: every phase is bracketed by an event pair on the context's stream
 // and the elapsed times are summed when the call synchronises anyway (an event synchronisation per phase cost

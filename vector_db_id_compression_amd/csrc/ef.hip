@@ -60,6 +60,7 @@ struct vidc_ef {
     mutable bool recs_ready = false;
     mutable uint32_t recs_max_cnt = 0;  // largest element count of a batch: sizes the decode kernel's LDS table
     uint64_t max_list = 0;              // longest list (0: unknown): an upper bound of that count, known without a read-back
+    uint64_t n_low = ~0ull, n_high = ~0ull;  // words of the two streams when the buffers were allocated by a bound (else: d_low.n / d_high.n)
     bool narrow = false;  // every id < 2^32 and every list < 2^30 ids (known from the encoder): 32-bit decode kernel
     ~vidc_ef() {  // the large host arrays go back to the process-wide vector cache (common.h)
         for (auto *v : {&offsets, &low_off, &high_off, &universe, &high_nbits}) vidc::vec_pool<uint64_t>().give(std::move(*v));
@@ -275,6 +276,10 @@ struct EfRaw {     // the four per-list counts (k_ef_meta) whose prefix sums are
 struct EfTile {    // totals of one tile
     uint64_t lw, hw, nb, cnt, bits, wide;
 };
+struct EfLimits {  // sizes the host allocated ahead of the geometry kernels (all ~0 / wide_ok: it allocates after them)
+    uint64_t low_words, high_words, nbatches;
+    uint32_t wide_ok, pad;
+};
 struct EfSummary {  // what the host needs before it can allocate the streams
     uint64_t low_words, high_words, nbatches, nchunks, total_bits;
     uint32_t wide, unsorted;
@@ -439,7 +444,7 @@ __global__ void __launch_bounds__(NT) k_ef_offsets(const uint64_t *ids, const ui
                                                     uint32_t *lbits, uint64_t *universe, const EfRaw *raw,
                                                     const EfTile *tiles, uint32_t ntiles, uint64_t *low_off,
                                                     uint64_t *high_off, uint64_t *batch_off, EfChunkRec *recs,
-                                                    EfSummary *sum, EfBigList *big, uint32_t *nbig) {
+                                                    EfSummary *sum, EfBigList *big, uint32_t *nbig, EfLimits lim, uint32_t *abort) {
     constexpr uint32_t TILE = NT * E;
     // lists of more than BIGC chunks leave their records to k_ef_big_recs (S2: the tile of the 1024 longest lists wrote 130 000 records
     // with 256 threads).  A single-tile object has no such launch: its <= NT * E lists are balanced by the binary search below whatever
@@ -509,6 +514,8 @@ __global__ void __launch_bounds__(NT) k_ef_offsets(const uint64_t *ids, const ui
             out.low_words = a[0]; out.high_words = a[1]; out.nbatches = a[2]; out.nchunks = P[3] + a[3];
             out.total_bits = P[4]; out.wide = P[5] ? 1u : 0u; out.unsorted = 0u;
             *sum = out;
+            // streams allocated before this kernel ran (ef_encode_fast): the chunk kernels behind it do nothing if they do not fit
+            *abort = (a[0] > lim.low_words || a[1] > lim.high_words || a[2] > lim.nbatches || (P[5] && !lim.wide_ok)) ? 1u : 0u;
         }
     }
     if (!tot[4]) return;
@@ -591,10 +598,11 @@ __device__ inline void ef_chunk_directory(const EfChunkRec &rc, const uint64_t *
 
 __global__ void __launch_bounds__(64) k_ef_lowhigh(const uint64_t *sorted_ids, const EfChunkRec *recs,
                                                    uint64_t nchunks, uint64_t *low, uint64_t *high, uint32_t *hrank,
-                                                   Chunk *batches, uint32_t *unsorted, EfRec *drecs) {
+                                                   Chunk *batches, uint32_t *unsorted, EfRec *drecs, const uint32_t *abort) {
     __shared__ unsigned long long win[EF_WIN_WORDS];
     __shared__ unsigned long long img[EF_CHUNK + 8];  // low words of the chunk (EF_CHUNK * l / 64 <= EF_CHUNK)
     const uint32_t lane = lane_id();
+    if (*abort) return;  // (k_ef_offsets: the streams allocated ahead of it are too small)
     for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const EfChunkRec rc = recs[c];
         const uint32_t start = rc.start;
@@ -850,9 +858,11 @@ template <int RMAX, bool SMALL, bool WITHFULL = true, bool V2 = false>
 __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *__restrict__ sorted_ids, const EfChunkRec *__restrict__ recs,
                                                      uint64_t nchunks, uint64_t *__restrict__ low, uint64_t *__restrict__ high,
                                                      uint32_t *__restrict__ hrank, Chunk *__restrict__ batches,
-                                                     uint32_t *__restrict__ unsorted, EfRec *__restrict__ drecs) {
+                                                     uint32_t *__restrict__ unsorted, EfRec *__restrict__ drecs,
+                                                     const uint32_t *__restrict__ abort) {
     __shared__ uint32_t win32[EF_WIN_WORDS * 2];
     __shared__ uint32_t img32[(64 * RMAX + 8) * 2];  // low words of the chunk, as 32-bit halves
+    if (*abort) return;  // (k_ef_offsets: the streams allocated ahead of it are too small)
     for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const EfChunkRec rc = recs[c];
         const uint32_t nc = rc.n - rc.start < EF_CHUNK ? rc.n - rc.start : EF_CHUNK;
@@ -1541,6 +1551,10 @@ int ef_mirror(std::vector<T> &dst, const T *d_src, size_t count) {
     if (count) VIDC_HIP(hipMemcpy(dst.data(), d_src, count * sizeof(T), hipMemcpyDeviceToHost));
     return VIDC_OK;
 }
+// words of the two streams (a buffer allocated by a bound is longer than its stream; an empty stream is kept as one word)
+inline uint64_t ef_low_count(const vidc_ef *e) { return e->n_low != ~0ull ? std::max<uint64_t>(e->n_low, 1) : e->d_low.n; }
+inline uint64_t ef_high_count(const vidc_ef *e) { return e->n_high != ~0ull ? std::max<uint64_t>(e->n_high, 1) : e->d_high.n; }
+
 // arena objects (graph rows): every host mirror at once from the per-row {universe, n | l << 8}
 int ef_arena_mirror_locked(const vidc_ef *e) {
     if (e->offsets_host && e->meta_host) return VIDC_OK;
@@ -1802,13 +1816,23 @@ int ef_encode_general(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t
 
 // the single-pass encoder (kernels above); *retry is raised when some list turned out not to be ascending.
 // nchunks: number of EF_CHUNK-sized pieces of all lists (the caller walks the host offsets anyway)
+// spec: the streams are allocated BEFORE the geometry kernels run, by bounds that need only the list lengths and a guess of the
+// largest universe U (ids of an index are 0 .. ntotal-1 unless the caller numbers them himself; the context remembers a larger
+// one it has met):   low  <= sum n_i msb(U / n_i) <= ntotal log2(U nlist / ntotal) bits (n log(U / n) is concave) + 2 words per list,
+//                    high  = (n + 1) + (u >> l) + 1 <= 3 n + 1 bits per list (u >> l < 2 n) whatever U is.
+// Geometry and chunk kernels are then queued back to back and the call waits ONCE, at its end (before: a wait between them for the
+// sizes, 20-25 us of an S1-sized call's 60).  k_ef_offsets checks the exact sizes against the allocation on the device; if they
+// do not fit (a universe beyond the guess, ids >= 2^32) it raises *abort, the chunk kernels return at once, *respec is set and the
+// caller runs the call again the old way.  Cost of the bound: the buffers are up to ~15 % larger than the streams (n_low / n_high
+// hold the exact word counts).
 int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t flags, uint64_t nchunks, uint64_t max_list,
-                   bool *retry) {
+                   bool *retry, bool spec, bool *respec) {
     const uint64_t nlist = e->nlist;
     const uint32_t nl32 = (uint32_t)nlist;
     const uint32_t tile_lists = nl32 <= EF_SINGLE_LISTS ? EF_SINGLE_LISTS : (nl32 <= EF_E1_MAX_LISTS ? 256u : 1024u);
     const uint32_t ntiles = nl32 ? (nl32 + tile_lists - 1u) / tile_lists : 1u;
     VidcPhaseTimer pt(ctx);
+    HostTrace tr("ef encode_fast");
     Scratch s_raw, s_tiles, s_recs, s_big;
     Pinned tail;
     VIDC_TRY(tail.get(ctx, 2 * sizeof(EfSummary)));
@@ -1821,31 +1845,43 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
     VIDC_TRY(s_big.get(ctx, big_cap * sizeof(EfBigList) + 16));
     EfBigList *d_big = (EfBigList *)((char *)s_big.p + 16);
     uint32_t *d_nbig = s_big.as<uint32_t>();
-    if (ntiles != 1u) VIDC_HIP(hipMemsetAsync(d_nbig, 0, 16, ctx->stream));  // (a single tile writes every record itself)
+    uint32_t *d_abort = d_nbig + 1;  // (written by k_ef_offsets whenever there are lists)
+    if (ntiles != 1u || !nlist) VIDC_HIP(hipMemsetAsync(d_nbig, 0, 16, ctx->stream));  // (a single tile writes every record itself)
+    EfLimits lim{~0ull, ~0ull, ~0ull, 1u, 0u};
+    if (spec) {
+        const uint64_t U = std::max<uint64_t>(e->ntotal ? e->ntotal - 1 : 0, ctx->ef_universe_hint);
+        const double ratio = e->ntotal ? (double)U * (double)nlist / (double)e->ntotal : 0.0;
+        const double low_bits = ratio > 1.0 ? (double)e->ntotal * std::log2(ratio) * 1.0001 : 0.0;
+        lim.low_words = (uint64_t)(low_bits / 64.0) + 2 * nlist + 4;
+        lim.high_words = (3 * e->ntotal + nlist) / 64 + nlist + 2;
+        lim.nbatches = lim.high_words / 64 + nlist + 2;
+        lim.wide_ok = 0u;
+    }
     VIDC_TRY(e->d_low_off.alloc(nlist + 1, ctx->dpool)); VIDC_TRY(e->d_high_off.alloc(nlist + 1, ctx->dpool));
     VIDC_TRY(e->d_batch_off.alloc(nlist + 1, ctx->dpool));
     VIDC_TRY(e->d_lbits.alloc(nlist ? nlist : 1, ctx->dpool)); VIDC_TRY(e->d_universe.alloc(nlist ? nlist : 1, ctx->dpool));
     VIDC_TRY(e->d_chunks.alloc(1, ctx->dpool));  // (the chunk table of the three-pass encoder: not needed here)
+    tr.mark("scratch + geometry arrays");
     pt.begin();
     if (ntiles == 1u) {
         hipLaunchKernelGGL((k_ef_offsets<true, 2, 512>), dim3(1), dim3(512), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
                            e->d_lbits.p, e->d_universe.p, (const EfRaw *)nullptr, (const EfTile *)nullptr, 1u,
                            e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
-                           hs, d_big, d_nbig);
+                           hs, d_big, d_nbig, lim, d_abort);
     } else if (tile_lists == 256u) {
         hipLaunchKernelGGL(k_ef_meta<1>, dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
                            e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>());
         hipLaunchKernelGGL((k_ef_offsets<false, 1, 256>), dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p,
                            nl32, e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>(), ntiles,
                            e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
-                           hs, d_big, d_nbig);
+                           hs, d_big, d_nbig, lim, d_abort);
     } else {
         hipLaunchKernelGGL(k_ef_meta<4>, dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
                            e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>());
         hipLaunchKernelGGL((k_ef_offsets<false, 4, 256>), dim3(ntiles), dim3(256), 0, ctx->stream, d_ids, e->d_offsets.p,
                            nl32, e->d_lbits.p, e->d_universe.p, s_raw.as<EfRaw>(), s_tiles.as<EfTile>(), ntiles,
                            e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
-                           hs, d_big, d_nbig);
+                           hs, d_big, d_nbig, lim, d_abort);
     }
     if (ntiles != 1u && max_list > (uint64_t)EF_CHUNK * EF_BIG_CHUNKS)  // (some list is that long)
         hipLaunchKernelGGL(k_ef_big_recs, dim3((uint32_t)std::min<uint64_t>(big_cap, (uint64_t)ctx->num_cu * 32)), dim3(64), 0, ctx->stream,
@@ -1854,18 +1890,24 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
     pt.end();
     // (the geometry kernel stores its summary into the pinned block itself, and the chunk kernels their "not ascending" flag: a copy
     // engine between a kernel and the host's wake-up costs more than these kernels)
-    VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
-    if (hs->nchunks != nchunks) {
-        set_error("elias-fano encoder: chunk count mismatch (%llu vs %llu)", (unsigned long long)hs->nchunks,
-                  (unsigned long long)nchunks);
-        return VIDC_ERR_OVERFLOW;
-    }
-    const uint64_t low_words = hs->low_words, high_words = hs->high_words;
+    tr.mark("geometry kernels queued");
+    uint64_t low_words = lim.low_words, high_words = lim.high_words;  // words to allocate
+    bool wide_ids = false;
     e->nchunks = nchunks;
-    e->nbatches = hs->nbatches;
-    e->total_bits = hs->total_bits;
-    const bool wide_ids = hs->wide != 0;
-    e->narrow = !wide_ids;
+    e->nbatches = lim.nbatches;  // (spec: an upper bound until the call's only wait)
+    if (!spec) {
+        VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
+        if (hs->nchunks != nchunks) {
+            set_error("elias-fano encoder: chunk count mismatch (%llu vs %llu)", (unsigned long long)hs->nchunks,
+                      (unsigned long long)nchunks);
+            return VIDC_ERR_OVERFLOW;
+        }
+        low_words = hs->low_words; high_words = hs->high_words;
+        e->nbatches = hs->nbatches;
+        e->total_bits = hs->total_bits;
+        wide_ids = hs->wide != 0;
+        e->narrow = !wide_ids;
+    }
     VIDC_TRY(e->d_low.alloc(low_words ? low_words : 1, ctx->dpool));
     VIDC_TRY(e->d_high.alloc(high_words ? high_words : 1, ctx->dpool));
     VIDC_TRY(e->d_batches.alloc(e->nbatches ? e->nbatches : 1, ctx->dpool));
@@ -1908,38 +1950,56 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
         if (clear_high) VIDC_HIP(hipMemsetAsync(e->d_high.p, 0, high_words * 8, ctx->stream));
         if (wide_ids)
             hipLaunchKernelGGL(k_ef_lowhigh, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(), nchunks,
-                               e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
+                               e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
         else if (!std::getenv("VIDC_EF_OLD_ENC") && !std::getenv("VIDC_EF_NO_FULL")) {  // the V2 bodies (VIDC_EF_OLD_ENC=1: the round-4 ones below)
             if (max_list <= 256)
                 hipLaunchKernelGGL((k_ef_lowhigh32<4, true, true, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
-                                   nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
+                                   nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
             else if (e->ntotal < 256 * nchunks)
                 hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, true, true, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
-                                   s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
+                                   s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
             else
                 hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false, true, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
-                                   s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
+                                   s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
         } else if (const bool nofull = std::getenv("VIDC_EF_NO_FULL") != nullptr; max_list <= 256) {  // (16 M ids in lists of 256: 65 -> 57 us)
             if (nofull) hipLaunchKernelGGL((k_ef_lowhigh32<4, true, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
-                               nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
+                               nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
             else hipLaunchKernelGGL((k_ef_lowhigh32<4, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
-                               nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
+                               nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
         } else if (e->ntotal < 256 * nchunks) {  // (chunks half full on average: 10 M ids in 65 536 Zipf lists 0.090 -> 0.082 ms)
             if (nofull) hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, true, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
-                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
+                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
             else hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
-                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
+                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
         } else {
             if (nofull) hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
-                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
+                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
             else hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
-                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs);
+                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
         }
         VIDC_HIP(hipGetLastError());
         pt.end();
     }
+    tr.mark("streams allocated, chunk kernels queued");
     VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
+    tr.mark("wait");
     ctx->last_kernel_ms = pt.collect();
+    tr.mark("event times");
+    if (spec) {
+        if (hs->nchunks != nchunks) {
+            set_error("elias-fano encoder: chunk count mismatch (%llu vs %llu)", (unsigned long long)hs->nchunks,
+                      (unsigned long long)nchunks);
+            return VIDC_ERR_OVERFLOW;
+        }
+        if (hs->low_words > lim.low_words || hs->high_words > lim.high_words || hs->nbatches > lim.nbatches || hs->wide) {
+            *respec = true;  // (the chunk kernels saw the same verdict in *abort and wrote nothing)
+            return VIDC_OK;
+        }
+        e->nbatches = hs->nbatches;
+        e->total_bits = hs->total_bits;
+        e->narrow = true;
+        e->n_low = hs->low_words; e->n_high = hs->high_words;
+    }
     if (nchunks && hs[1].unsorted) *retry = true;
     if (enc_recs && !*retry) {
         std::lock_guard<std::mutex> g(e->mu);
@@ -1958,38 +2018,59 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     if (!ctx || !out || (nlist && !offsets)) return VIDC_ERR_INVALID;
     *out = nullptr;
     if (nlist >= 0xffffffffull) return VIDC_ERR_INVALID;
+    HostTrace tr("ef encode");
     VIDC_HIP(hipSetDevice(ctx->device));
     std::unique_ptr<vidc_ef> e(new vidc_ef());
     e->device = ctx->device;
     e->nlist = nlist;
-    e->offsets = vec_pool<uint64_t>().take(nlist + 1);
-    if (nlist) e->offsets.assign(offsets, offsets + nlist + 1);
-    else e->offsets.assign(1, 0);
-    e->offsets_host = true;
-    e->ntotal = e->offsets[nlist];
+    // (the host mirror of the offsets is filled from the device array the first time an entry point needs it: copying 8 bytes per list
+    // here was a sixth of the host side of a 65 536-list call)
+    e->ntotal = nlist ? offsets[nlist] : 0;
     uint64_t nchunks = 0, max_list = 0;
     static_assert((EF_CHUNK & (EF_CHUNK - 1u)) == 0u, "the pass below counts chunks by a shift");
     const LengthsPass lp = lengths_pass(offsets, nlist, (uint32_t)__builtin_ctz(EF_CHUNK), 0u);  // (four lists per instruction where the host can)
     if (!lp.wide && lp.max_n <= 0xfffffff0ull) { nchunks = lp.nchunks; max_list = lp.max_n; }
     else
     for (uint64_t l = 0; l < nlist; l++) {  // (some length of 2^32 or more, or offsets that decrease: list by list, with the message)
-        if (e->offsets[l + 1] < e->offsets[l] || e->offsets[l + 1] - e->offsets[l] > 0xfffffff0ull) {
+        if (offsets[l + 1] < offsets[l] || offsets[l + 1] - offsets[l] > 0xfffffff0ull) {
             set_error("bad offsets at list %llu", (unsigned long long)l);
             return VIDC_ERR_INVALID;
         }
-        nchunks += (e->offsets[l + 1] - e->offsets[l] + EF_CHUNK - 1) / EF_CHUNK;
-        max_list = std::max(max_list, e->offsets[l + 1] - e->offsets[l]);
+        nchunks += (offsets[l + 1] - offsets[l] + EF_CHUNK - 1) / EF_CHUNK;
+        max_list = std::max(max_list, offsets[l + 1] - offsets[l]);
     }
     if (e->ntotal && !d_ids) return VIDC_ERR_INVALID;
+    tr.mark("host offsets pass");
     VIDC_TRY(e->d_offsets.alloc(nlist + 1, ctx->dpool));
     Pinned h_off;
     VIDC_TRY(h_off.get(ctx, (nlist + 1) * 8));
-    std::memcpy(h_off.p, e->offsets.data(), (nlist + 1) * 8);
+    if (nlist) std::memcpy(h_off.p, offsets, (nlist + 1) * 8);
+    else *h_off.as<uint64_t>() = 0;
     VIDC_HIP(hipMemcpyAsync(e->d_offsets.p, h_off.p, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     bool retry = false;
     e->max_list = max_list;
-    VIDC_TRY(ef_encode_fast(ctx, e.get(), d_ids, flags, nchunks, max_list, &retry));
+    tr.mark("offsets staged");
+    static const bool no_spec = std::getenv("VIDC_EF_NO_SPEC") != nullptr;  // (measurement switch: always size the streams after the geometry kernels)
+    bool respec = false;
+    const bool spec = !no_spec && e->ntotal && e->ntotal <= 0xffffffffull;
+    VIDC_TRY(ef_encode_fast(ctx, e.get(), d_ids, flags, nchunks, max_list, &retry, spec, &respec));
+    if (respec) {  // the guess of the universe was too small: size the streams from the ids, and remember how large they are
+        e->d_recs.release();
+        e->recs_ready = false;
+        e->has_perm = false;
+        e->n_low = e->n_high = ~0ull;
+        VIDC_TRY(ef_encode_fast(ctx, e.get(), d_ids, flags, nchunks, max_list, &retry, false, &respec));
+        std::vector<uint64_t> uni(nlist);
+        VIDC_HIP(hipMemcpy(uni.data(), e->d_universe.p, nlist * 8, hipMemcpyDeviceToHost));
+        for (uint64_t u : uni) ctx->ef_universe_hint = std::max(ctx->ef_universe_hint, u);
+    }
+    tr.mark("encode_fast (launches + wait)");
     if (retry) {  // some list is not ascending: general three-pass encoder with the sort
+        e->offsets = vec_pool<uint64_t>().take(nlist + 1);
+        if (nlist) e->offsets.assign(offsets, offsets + nlist + 1);
+        else e->offsets.assign(1, 0);
+        e->offsets_host = true;
+        e->n_low = e->n_high = ~0ull;
         e->total_bits = 0;
         e->has_perm = false;
         e->recs_ready = false;  // (the general encoder's objects build their records on the first bulk decode)
@@ -2402,16 +2483,17 @@ int vidc_ef_stream_words(const vidc_ef *e, uint64_t *low_words, uint64_t *high_w
         if (high_words) *high_words = e->high_off[e->nlist] ? e->high_off[e->nlist] : 1;
         return VIDC_OK;
     }
-    if (low_words) *low_words = e->d_low.n;
-    if (high_words) *high_words = e->d_high.n;
+    if (low_words) *low_words = ef_low_count(e);
+    if (high_words) *high_words = ef_high_count(e);
     return VIDC_OK;
 }
 int vidc_ef_export_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *low, size_t low_cap, uint64_t *high, size_t high_cap) {
     if (!ctx || !e || !low || !high) return VIDC_ERR_INVALID;
     VIDC_TRY(ef_ensure_csr(ctx, e));
-    if (e->d_low.n > low_cap || e->d_high.n > high_cap) { set_error("export buffers too small"); return VIDC_ERR_INVALID; }
-    VIDC_TRY(vidc_copy_d2h(ctx, low, e->d_low.p, e->d_low.n * 8));
-    return vidc_copy_d2h(ctx, high, e->d_high.p, e->d_high.n * 8);
+    const uint64_t nl = ef_low_count(e), nh = ef_high_count(e);
+    if (nl > low_cap || nh > high_cap) { set_error("export buffers too small"); return VIDC_ERR_INVALID; }
+    VIDC_TRY(vidc_copy_d2h(ctx, low, e->d_low.p, nl * 8));
+    return vidc_copy_d2h(ctx, high, e->d_high.p, nh * 8);
 }
 int vidc_ef_import(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const uint32_t *lbits,
                    const uint64_t *universe, const uint64_t *low, uint64_t n_low, const uint64_t *high, uint64_t n_high,

@@ -63,24 +63,6 @@ struct vidc_roc {
 
 namespace {
 
-// VIDC_TRACE=1 prints host-side phase times of encode / decode calls (dev aid)
-struct HostTrace {
-    bool on;
-    std::chrono::steady_clock::time_point t0;
-    const char *what;
-    explicit HostTrace(const char *w) : what(w) {
-        const char *e = getenv("VIDC_TRACE");
-        on = e && e[0] == '1';
-        t0 = std::chrono::steady_clock::now();
-    }
-    void mark(const char *phase) {
-        if (!on) return;
-        auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[vidc] %s: %-28s %8.3f ms\n", what, phase, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    }
-};
-
 constexpr uint32_t TINY_MAX = 64;
 constexpr uint32_t GEN_SMALL_MAX = 4096;   // decoder: fb <= 9 -> 2 KiB of LDS (full occupancy)
 // Lists longer than this go to the bitmap kernels (one wave per CU, lowest step latency: they are the critical
