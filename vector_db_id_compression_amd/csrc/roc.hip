@@ -352,40 +352,28 @@ int finish_enqueue(vidc_ctx *ctx, vidc_roc *r, EncodeTail &e, Scratch &d_status_
     unsigned long long *t = e.t = e.tail.as<unsigned long long>();
     t[0] = ~0ull; t[1] = 0; t[2] = 0; t[3] = 0; t[4] = 0; t[5] = 0; t[6] = 0; t[7] = 0;
     VIDC_TRY(r->d_word_off.alloc(nlist + 1, ctx->dpool));
-    if (nlist && !r->rows) {  // summary + word offsets + total in one launch; its last workgroup stores the results into `t`
+    if (nlist) {  // summary + word offsets (+ CSR offsets of graph rows) + totals in one launch; its last workgroup stores the results into `t`
         const uint32_t ntiles = (uint32_t)(nlist / VIDC_TAIL_TILE + 1u);
+        const size_t state_bytes = ((size_t)ntiles * (r->rows ? 2u : 1u) + 10) * 8;
         if (!e.state_zeroed) {
-            VIDC_TRY(e.s_state.get(ctx, ((size_t)ntiles + 10) * 8));
-            VIDC_HIP(hipMemsetAsync(e.s_state.p, 0, ((size_t)ntiles + 10) * 8, ctx->stream));
+            VIDC_TRY(e.s_state.get(ctx, state_bytes));
+            VIDC_HIP(hipMemsetAsync(e.s_state.p, 0, state_bytes, ctx->stream));
         }
         e.state_zeroed = false;  // (used up)
-        hipLaunchKernelGGL(k_roc_tail, dim3(ntiles), dim3(256), 0, ctx->stream, r->d_nwords.p, (uint32_t)nlist, r->d_word_off.p,
-                           d_status_buf.as<uint32_t>(), e.s_state.as<unsigned long long>(), t);
+        if (r->rows) {
+            VIDC_TRY(r->d_offsets.alloc(nlist + 1, ctx->dpool));
+            hipLaunchKernelGGL(k_roc_tail<true>, dim3(ntiles), dim3(256), 0, ctx->stream, r->d_nwords.p, (uint32_t)nlist, r->d_word_off.p,
+                               d_status_buf.as<uint32_t>(), e.s_state.as<unsigned long long>(), t, d_sizes, r->d_offsets.p);
+        } else
+            hipLaunchKernelGGL(k_roc_tail<false>, dim3(ntiles), dim3(256), 0, ctx->stream, r->d_nwords.p, (uint32_t)nlist, r->d_word_off.p,
+                               d_status_buf.as<uint32_t>(), e.s_state.as<unsigned long long>(), t, (const uint32_t *)nullptr,
+                               (uint64_t *)nullptr);
         VIDC_HIP(hipGetLastError());
         return VIDC_OK;
     }
-    VIDC_TRY(e.s_sum.get(ctx, 64));
-    VIDC_HIP(hipMemcpyAsync(e.s_sum.p, t, 64, hipMemcpyHostToDevice, ctx->stream));
-    if (nlist) {
-        hipLaunchKernelGGL(k_roc_status_summary, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 1024)), dim3(256),
-                           0, ctx->stream, d_status_buf.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t)nlist,
-                           e.s_sum.as<unsigned long long>());
-        VIDC_TRY(device_exscan(ctx, r->d_nwords.p, (uint32_t)nlist, r->d_word_off.p, e.s_tmp));
-        if (r->rows) {
-            VIDC_TRY(r->d_offsets.alloc(nlist + 1, ctx->dpool));
-            VIDC_TRY(device_exscan(ctx, d_sizes, (uint32_t)nlist, r->d_offsets.p, e.s_tmp2));
-            hipLaunchKernelGGL(k_count_nonzero, dim3((uint32_t)std::min<uint64_t>((nlist + 255) / 256, 64)), dim3(256), 0,
-                               ctx->stream, d_sizes, (uint32_t)nlist, e.s_sum.as<unsigned long long>() + 6);
-            VIDC_HIP(hipMemcpyAsync(t + 5, r->d_offsets.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
-        }
-        VIDC_HIP(hipGetLastError());
-        VIDC_HIP(hipMemcpyAsync(t + 4, r->d_word_off.p + nlist, 8, hipMemcpyDeviceToHost, ctx->stream));
-    } else {
-        VIDC_HIP(hipMemsetAsync(r->d_word_off.p, 0, 8, ctx->stream));
-        if (r->rows) { VIDC_TRY(r->d_offsets.alloc(1, ctx->dpool)); VIDC_HIP(hipMemsetAsync(r->d_offsets.p, 0, 8, ctx->stream)); }
-    }
-    VIDC_HIP(hipMemcpyAsync(t, e.s_sum.p, 32, hipMemcpyDeviceToHost, ctx->stream));
-    if (r->rows) VIDC_HIP(hipMemcpyAsync(t + 6, e.s_sum.as<unsigned long long>() + 6, 8, hipMemcpyDeviceToHost, ctx->stream));
+    // no lists: the offsets of an empty object
+    VIDC_HIP(hipMemsetAsync(r->d_word_off.p, 0, 8, ctx->stream));
+    if (r->rows) { VIDC_TRY(r->d_offsets.alloc(1, ctx->dpool)); VIDC_HIP(hipMemsetAsync(r->d_offsets.p, 0, 8, ctx->stream)); }
     return VIDC_OK;
 }
 int finish_complete(vidc_ctx *ctx, vidc_roc *r, EncodeTail &e, const uint32_t *d_arena, uint32_t arena_stride, Scratch &d_status_buf,

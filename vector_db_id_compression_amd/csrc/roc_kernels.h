@@ -620,10 +620,12 @@ __global__ void k_roc_status_summary_host(const uint32_t *status, const uint32_t
                 if (k < retry_cap) host[8 + k] = l;  // (pinned memory: each slot has one writer)
             }
     }
-    __threadfence();
+    // (Everything the last workgroup reads was written by device-scope atomics, which are performed at the memory side of the XCDs' L2s:
+    // waiting for this wavefront's own outstanding operations orders them before the counter.  A __threadfence() here is a release
+    // at device scope -- a write-back of the XCD's L2, full of the decode kernels' output: 67 us for the 4096 wavefronts of a 10^6-row call.)
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (threadIdx.x == 0 && atomicAdd(&acc[4], 1ull) == (unsigned long long)gridDim.x - 1ull) {
-        __threadfence();
         const unsigned long long b = atomicAdd(&acc[0], 0ull);
         host[0] = b ? ~b : ~0ull;
         host[1] = atomicAdd(&acc[1], 0ull);
@@ -643,26 +645,39 @@ __global__ void k_roc_status_summary_host(const uint32_t *status, const uint32_t
 // sum[2] / [3] = retries / pending sorts, sum[4] = total words.  The last tile to finish stores {first bad list or ~0, 0, retries,
 // pending, total} into `host` (pinned host memory: no copy engine between this kernel and the host's wake-up).
 #define VIDC_TAIL_TILE 4096u
+// ROWS (graph objects, round 6): the same launch also scans the edge counts into the CSR offsets and counts the non-empty rows
+// (host[5] = edges, host[6] = non-empty rows; their tile sums live behind the summary: state[gridDim.x + 10 ..]).  Before, the tail of a
+// graph encode was seven launches -- status summary, two three-launch scans, a count -- ~130 us of latency-bound kernels behind a
+// 300 us encode kernel.
+template <bool ROWS>
 __global__ void __launch_bounds__(256) k_roc_tail(const uint32_t *__restrict__ nwords, uint32_t n, uint64_t *__restrict__ word_off,
                                                   const uint32_t *__restrict__ status, unsigned long long *state,
-                                                  unsigned long long *host) {
+                                                  unsigned long long *host, const uint32_t *__restrict__ sizes,
+                                                  uint64_t *__restrict__ offsets) {
     unsigned long long *const sum = state + gridDim.x + 2;
+    unsigned long long *const state2 = state + gridDim.x + 10;
     __shared__ uint64_t sh[256];
-    __shared__ uint64_t tile_off_s;
+    __shared__ uint64_t sh2[ROWS ? 256 : 1];
+    __shared__ uint64_t tile_off_s, tile_off2_s;
     __shared__ uint32_t tile_s;
     const uint32_t t = threadIdx.x;
     if (t == 0) tile_s = (uint32_t)atomicAdd(&state[gridDim.x], 1ull);
     __syncthreads();
     const uint32_t tile = tile_s;
     const uint32_t base = tile * VIDC_TAIL_TILE + t * 16u;
-    uint32_t v[16];
-    uint64_t s = 0;
-    unsigned long long bad = ~0ull, retry = 0, pending = 0;
+    uint32_t v[16], v2[ROWS ? 16 : 1];
+    uint64_t s = 0, s2 = 0;
+    unsigned long long bad = ~0ull, retry = 0, pending = 0, nonzero = 0;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const uint32_t l = base + j;
         v[j] = l < n ? nwords[l] : 0u;
         s += v[j];
+        if (ROWS) {
+            v2[j] = l < n ? sizes[l] : 0u;
+            s2 += v2[j];
+            nonzero += v2[j] != 0u;
+        }
         if (l < n) {
             const uint32_t st = status[l];
             if (st == 5u) retry++;  // VIDC_ST_RETRY (roc_lane.h)
@@ -671,53 +686,86 @@ __global__ void __launch_bounds__(256) k_roc_tail(const uint32_t *__restrict__ n
         }
     }
     sh[t] = s;
+    if (ROWS) sh2[t] = s2;
     __syncthreads();
     for (uint32_t o = 1; o < 256; o <<= 1) {
         const uint64_t x = t >= o ? sh[t - o] : 0;
+        const uint64_t x2 = (ROWS && t >= o) ? sh2[t - o] : 0;
         __syncthreads();
         sh[t] += x;
+        if (ROWS) sh2[t] += x2;
         __syncthreads();
     }
     const uint64_t incl = sh[t], tile_sum = sh[255];
+    const uint64_t incl2 = ROWS ? sh2[t] : 0, tile_sum2 = ROWS ? sh2[255] : 0;
     // (no fence in front: the published value is the exchange's own operand, and a device-scope release writes back the XCD's whole L2)
-    if (t == 0) atomicExch(&state[tile], (1ull << 63) | tile_sum);
+    if (t == 0) {
+        atomicExch(&state[tile], (1ull << 63) | tile_sum);
+        if (ROWS) atomicExch(&state2[tile], (1ull << 63) | tile_sum2);
+    }
     // sums of the tiles before this one (they were dispatched earlier: every wait ends)
-    uint64_t before = 0;
+    uint64_t before = 0, before2 = 0;
     for (uint32_t k = t; k < tile; k += 256u) {
         unsigned long long x;
-        do { x = atomicAdd(&state[k], 0ull); } while (!(x >> 63));
+        // (device-scope atomic LOADS: read-modify-write polls of 245 tiles on the same few cache lines serialise in the memory system)
+        do { x = __hip_atomic_load(&state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(x >> 63));
         before += x & ~(1ull << 63);
+        if (ROWS) {
+            do { x = __hip_atomic_load(&state2[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(x >> 63));
+            before2 += x & ~(1ull << 63);
+        }
     }
     __syncthreads();  // (sh is read above by every thread before it is reused)
     sh[t] = before;
+    if (ROWS) sh2[t] = before2;
     __syncthreads();
     for (uint32_t o = 128; o > 0; o >>= 1) {
-        if (t < o) sh[t] += sh[t + o];
+        if (t < o) {
+            sh[t] += sh[t + o];
+            if (ROWS) sh2[t] += sh2[t + o];
+        }
         __syncthreads();
     }
-    if (t == 0) tile_off_s = sh[0];
+    if (t == 0) {
+        tile_off_s = sh[0];
+        if (ROWS) tile_off2_s = sh2[0];
+    }
     __syncthreads();
     uint64_t acc = tile_off_s + incl - s;
+    uint64_t acc2 = ROWS ? tile_off2_s + incl2 - s2 : 0;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         if (base + j <= n) word_off[base + j] = acc;  // (index n receives the total)
-        if (base + j == n) sum[4] = acc;
+        if (base + j == n) atomicExch(&sum[4], acc);
         acc += v[j];
+        if (ROWS) {
+            if (base + j <= n) offsets[base + j] = acc2;
+            if (base + j == n) atomicExch(&sum[5], acc2);
+            acc2 += v2[j];
+        }
     }
     // status summary: few lists ever report anything
     if (bad != ~0ull) atomicMax(&sum[0], ~bad);
     if (retry) atomicAdd(&sum[2], retry);
     if (pending) atomicAdd(&sum[3], pending);
-    __threadfence();
+    if (ROWS) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nonzero += __shfl_xor(nonzero, o, 64);
+        if ((t & 63u) == 0u && nonzero) atomicAdd(&sum[6], nonzero);
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // (see k_roc_status_summary_host: atomics only, no device-scope release)
     __syncthreads();
     if (t == 0 && atomicAdd(&state[gridDim.x + 1], 1ull) == (unsigned long long)gridDim.x - 1ull) {
-        __threadfence();
         const unsigned long long b = atomicAdd(&sum[0], 0ull);
         host[0] = b ? ~b : ~0ull;
         host[1] = 0ull;
         host[2] = atomicAdd(&sum[2], 0ull);
         host[3] = atomicAdd(&sum[3], 0ull);
         host[4] = atomicAdd(&sum[4], 0ull);
+        if (ROWS) {
+            host[5] = atomicAdd(&sum[5], 0ull);
+            host[6] = atomicAdd(&sum[6], 0ull);
+        }
     }
 }
 
@@ -788,14 +836,29 @@ __global__ void __launch_bounds__(64) k_roc_compact_groups(const uint32_t *arena
         if (lane == 0) wo[cnt] = word_off[g0 + cnt];
         __syncthreads();
         const uint64_t w_begin = wo[0], total = wo[cnt] - w_begin;
-        for (uint64_t k = lane; k < total; k += 64) {
-            const uint64_t g = w_begin + k;
-            uint32_t lo = 0, hi = cnt;  // largest r with wo[r] <= g
-            while (hi - lo > 1u) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (wo[mid] <= g) lo = mid; else hi = mid;
+        // eight words per lane and trip, every load issued before the first store (round 6: one load per trip -- load, wait, store --
+        // was ~25 memory round trips in a row per group: 78 us for 10^6 graph rows, the kernel's wavefronts waiting 83 % of the time)
+        for (uint64_t k0 = 0; k0 < total; k0 += 512u) {
+            uint32_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint64_t k = k0 + (uint64_t)j * 64u + lane;
+                v[j] = 0u;
+                if (k < total) {
+                    const uint64_t g = w_begin + k;
+                    uint32_t lo = 0, hi = cnt;  // largest r with wo[r] <= g
+                    while (hi - lo > 1u) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (wo[mid] <= g) lo = mid; else hi = mid;
+                    }
+                    v[j] = arena[ao[lo] + (g - wo[lo])];
+                }
             }
-            words[g] = arena[ao[lo] + (g - wo[lo])];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint64_t k = k0 + (uint64_t)j * 64u + lane;
+                if (k < total) words[w_begin + k] = v[j];
+            }
         }
         __syncthreads();
     }

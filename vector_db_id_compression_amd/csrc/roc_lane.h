@@ -999,12 +999,21 @@ __global__ void __launch_bounds__(64) k_roc_encode_tiny_lane(RocEncArgs a, const
     }
 }
 
-#define VIDC_TINY_STRIP 84u  // LDS words per lane of the tiny decoder: >= n + 2 + slack for n <= 64, P <= 32
+#define VIDC_TINY_STRIP 48u  // LDS words per lane of the tiny decoder: a window over the top of the list's stream (word w at slot w mod 48)
 #define VIDC_TINY_LD 65u     // word w of lane t at buf[w * 65 + t]: conflict-free per lane AND per row (output phase)
 
+// Round 6: the stream words come in eight loads at a time (the loop that loaded one word, waited and stored it made ~40 memory round
+// trips in a row per wavefront -- most of the kernel's 53 us of residence on 10^6 graph rows), the step's divisor constant comes from a
+// register (it was a scalar load per step), the decoded ids live ONLY in the lane's registers during the loop (the strip holds nothing
+// but the stream: 12.4 instead of 21.3 KiB per wavefront, 12 instead of 7 wavefronts per CU) and go through the strip's LDS 32
+// positions at a time on the way out, where a lane stores 16 bytes of a row (graph flavour, K % 4 == 0).
+// The strip is a WINDOW of 48 words over the top of the stream (a list of 64 ids at P <= 20 has ~41 words; at P = 32 up to 74): the
+// decoder consumes the stream from its top, and a lane that reaches the bottom of its window with words left below it loads them
+// (all of them fit: <= 74 - 48) in the branch that also serves the empty stack.
 template <bool ROWS>
 __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const LaneDiv *__restrict__ dtab) {
-    __shared__ uint32_t buf[VIDC_TINY_STRIP * VIDC_TINY_LD];
+    __shared__ __attribute__((aligned(16))) uint32_t buf[VIDC_TINY_STRIP * VIDC_TINY_LD];
+    __shared__ uint32_t rown[64];
     const uint32_t lane = lane_id();
     const uint32_t wi = blockIdx.x * 64u + lane;
     const bool have = wi < a.nwork;
@@ -1015,12 +1024,24 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
     const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
     const uint32_t W = have ? a.nwords[l] : 0u;
     const uint32_t *orig = a.words + (have ? a.word_off[l] : 0ull);
-    uint32_t err = (W > VIDC_TINY_STRIP) ? 1u : 0u;
+    const uint32_t lqv = dtab[lane + 1u].w;  // lane i: floor(2^31 / (i + 1)), the constant of step i
+    uint32_t err = (W > 2u * VIDC_TINY_STRIP - 2u) ? 1u : 0u;
     const uint32_t Wc = err ? 0u : W;
+    uint32_t base = Wc > VIDC_TINY_STRIP ? Wc - VIDC_TINY_STRIP : 0u;  // words [base, sp) are in the window
+    auto slot = [&](uint32_t w) -> uint32_t {  // w mod 48 for w < 96
+        const uint32_t v = w - VIDC_TINY_STRIP;
+        return (w < v ? w : v) * VIDC_TINY_LD + lane;
+    };
     {
-        const uint32_t wmax = wave_max_u32(Wc);
-        for (uint32_t w = 0; w < wmax; w++)
-            if (w < Wc) buf[w * VIDC_TINY_LD + lane] = orig[w];
+        const uint32_t wmax = wave_max_u32(Wc - base);
+        for (uint32_t w0 = 0; w0 < wmax; w0 += 8u) {
+            uint32_t t[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) t[j] = base + w0 + (uint32_t)j < Wc ? orig[base + w0 + (uint32_t)j] : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (base + w0 + (uint32_t)j < Wc) buf[slot(base + w0 + (uint32_t)j)] = t[j];
+        }
     }
     uint32_t sp = Wc;
     uint32_t draws = have ? a.draws[l] : 0u;
@@ -1030,14 +1051,18 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
     const uint32_t nsteps = wave_max_u32(n_eff);
 
     auto pop = [&]() -> uint32_t {  // codec.h:32-40
-        if (__builtin_expect(sp == 0u, 0)) {
-            uint32_t w = 0;
-            if (draws < VIDC_MT_TABLE) w = a.mt[draws]; else err |= 2u;
-            draws++;
-            return w;
+        if (__builtin_expect(sp == base, 0)) {
+            if (base == 0u) {
+                uint32_t w = 0;
+                if (draws < VIDC_MT_TABLE) w = a.mt[draws]; else err |= 2u;
+                draws++;
+                return w;
+            }
+            for (uint32_t w = 0; w < base; w++) buf[slot(w)] = orig[w];  // (once per list at most: base <= 46 after this)
+            base = 0u;
         }
         sp--;
-        return buf[sp * VIDC_TINY_LD + lane];
+        return buf[slot(sp)];
     };
     auto u_pop = [&](uint32_t p) -> uint32_t {  // codec.cpp:78-90
         const uint32_t sym = (uint32_t)head & ((1u << p) - 1u);
@@ -1046,15 +1071,15 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
         return sym;
     };
 
-    // the ids decoded so far also sit in 64 registers of the lane (slot i = step i, 0x7fffffff while empty): the rank
-    // is roc_lane_reg_asm.h's sign-bit count over the blocks of 16 slots in use instead of a scan of the LDS strip
-    // (one ds_read + three instructions per id)
+    // the ids decoded so far sit in 64 registers of the lane (slot i = step i, 0x7fffffff while empty): the rank
+    // is roc_lane_reg_asm.h's sign-bit count over the blocks of 16 slots in use (two instructions per id)
     v32u e0, e1;
 #pragma unroll
     for (int k = 0; k < 32; k++) e0[k] = e1[k] = 0x7fffffffu;
-    for (uint32_t i = 0; i < nsteps; i++) {
-        const uint32_t lq = dtab[i + 1u].w;  // uniform: floor(2^31 / (i + 1))
-        uint32_t xs = 0;
+    for (uint32_t ii = 0; ii < nsteps; ii++) {
+        const uint32_t i = rfl(ii);      // (kept in a scalar register: it indexes registers below)
+        const uint32_t lq = rl(lqv, i);  // uniform: floor(2^31 / (i + 1))
+        uint32_t xs = 0x7fffffffu;
         if (i < n_eff) {
             if (__builtin_expect(l_lt_2p31(head), 0)) {
                 (void)u_pop(0u);
@@ -1080,7 +1105,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
             {
                 uint64_t h0 = head;
                 if (__builtin_expect((uint32_t)(h0 >> 32) >= lq, 0)) {
-                    if (sp + i + 1u < VIDC_TINY_STRIP) buf[sp * VIDC_TINY_LD + lane] = (uint32_t)h0; else err |= 1u;
+                    if (sp - base < VIDC_TINY_STRIP) buf[slot(sp)] = (uint32_t)h0; else err |= 1u;
                     sp++;
                     h0 >>= 32;
                 }
@@ -1088,36 +1113,63 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
                 if (__builtin_expect(l_lt_2p31(h), 0)) h = (uint64_t)pop() | (h << 32);
                 head = h;
             }
-            if (sp + i < VIDC_TINY_STRIP) buf[(VIDC_TINY_STRIP - 1u - i) * VIDC_TINY_LD + lane] = x; else err |= 1u;
         }
-        // slot i = x (uniform register index; lanes past their list write an empty slot they never read)
+        // slot i = x (uniform register index; lanes past their list keep the empty value)
         asm volatile("s_set_gpr_idx_on %[i], gpr_idx(DST)\n\ts_nop 0\n\tv_mov_b32 v64, %[x]\n\ts_set_gpr_idx_off"
                      : "+{v[64:95]}"(e0), "+{v[96:127]}"(e1)
                      : [x] "v"(xs), [i] "s"(i));
-    }
-    __syncthreads();
-    // output, one list per iteration so that the stores are contiguous: decoded order == sampling order, the id
-    // of step i goes to position n-1-i (codec.cpp:150); graph rows are padded with -1 (the reference leaves
-    // slots >= n untouched, altid_impl.cpp:153-165)
-    for (uint32_t rr = 0; rr < 64u; rr++) {
-        const uint32_t n_r = rl(n_eff, rr);
-        const uint32_t have_r = rl(have ? 1u : 0u, rr);
-        if (!have_r) break;  // work items fill the lanes from 0
-        const uint64_t o_r = rl64((uint32_t)ooff, (uint32_t)(ooff >> 32), rr);
-        // position p holds the id of step n-1-p, stored at strip word STRIP-1-(n-1-p) = STRIP-n+p
-        if (ROWS) {
-            if (lane < a.K) {
-                const int32_t v = lane < n_r ? (int32_t)buf[(VIDC_TINY_STRIP - n_r + lane) * VIDC_TINY_LD + rr] : -1;
-                a.out_rows[o_r + lane] = v;
-            }
-        } else if (lane < n_r) {
-            a.out[o_r + lane] = (uint64_t)buf[(VIDC_TINY_STRIP - n_r + lane) * VIDC_TINY_LD + rr];
-        }
     }
     if (have) {
         const bool clean = (head == VIDC_RANS_L) && (sp == draws - draws0);
         a.end_state[l] = (clean || n == 0u) ? 0u : 1u;
         a.status[l] = err ? ((err & 1u) ? VIDC_ST_OVERFLOW : VIDC_ST_MT) : VIDC_ST_OK;
+    }
+    // output: decoded order == sampling order, the id of step i goes to position n-1-i (codec.cpp:150); graph rows are padded
+    // with -1 (the reference leaves slots >= n untouched, altid_impl.cpp:153-165).  32 positions at a time through the strip's
+    // LDS (position p of lane t at buf[(p & 31) * 65 + t]), then row-wise stores.
+    rown[lane] = n_eff | (have ? 0x100u : 0u);
+    const bool quad = ROWS && (a.K & 3u) == 0u && (((uintptr_t)a.out_rows | (ooff * 4u)) & 15u) == 0u && !a.out_off;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if (rfl((uint32_t)h * 32u) >= nsteps && !ROWS) break;  // (nothing in the upper half)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+            const uint32_t p = n_eff - 1u - (uint32_t)i;  // (wraps for i >= n: fails the range test)
+            if ((p >> 5) == (uint32_t)h && p < n_eff) buf[(p & 31u) * VIDC_TINY_LD + lane] = i < 32 ? e0[i & 31] : e1[i & 31];
+        }
+        __syncthreads();
+        if (ROWS && ballot(quad) == ~0ull) {
+            // lane = (row of a group of eight, four consecutive positions of this half): 16-byte stores
+            const uint32_t g = lane >> 3, q4 = (lane & 7u) * 4u, c0 = (uint32_t)h * 32u + q4;
+            for (uint32_t r0 = 0; r0 < 64u; r0 += 8u) {
+                const uint32_t rr = r0 + g;
+                const uint32_t rm = rown[rr];
+                if (!(rm & 0x100u) || c0 >= a.K) continue;
+                const uint32_t n_r = rm & 0xffu;
+                int4 o;
+                o.x = c0 + 0u < n_r ? (int32_t)buf[(q4 + 0u) * VIDC_TINY_LD + rr] : -1;
+                o.y = c0 + 1u < n_r ? (int32_t)buf[(q4 + 1u) * VIDC_TINY_LD + rr] : -1;
+                o.z = c0 + 2u < n_r ? (int32_t)buf[(q4 + 2u) * VIDC_TINY_LD + rr] : -1;
+                o.w = c0 + 3u < n_r ? (int32_t)buf[(q4 + 3u) * VIDC_TINY_LD + rr] : -1;
+                *(int4 *)(a.out_rows + ((uint64_t)blockIdx.x * 64u + rr) * a.K + c0) = o;
+            }
+        } else {
+            for (uint32_t rr = 0; rr < 64u; rr++) {
+                const uint32_t rm = rl(rown[lane], rr);
+                if (!(rm & 0x100u)) break;  // work items fill the lanes from 0
+                const uint32_t n_r = rm & 0xffu;
+                const uint64_t o_r = rl64((uint32_t)ooff, (uint32_t)(ooff >> 32), rr);
+                const uint32_t c = (uint32_t)h * 32u + lane;
+                if (lane < 32u) {
+                    if (ROWS) {
+                        if (c < a.K) a.out_rows[o_r + c] = c < n_r ? (int32_t)buf[lane * VIDC_TINY_LD + rr] : -1;
+                    } else if (c < n_r) {
+                        a.out[o_r + c] = (uint64_t)buf[lane * VIDC_TINY_LD + rr];
+                    }
+                }
+            }
+        }
     }
 }
 
