@@ -26,6 +26,7 @@ pass-through stand-in for the codec; it prints `"dry_run": true` and `"value": n
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -75,6 +76,9 @@ def compact(r2):
         c["traffic_x"] = r2["traffic_over_algorithmic"]
     if "chain_floor" in r2:
         c["chain_ms"] = [r2["chain_floor"]["encode_ms"], r2["chain_floor"]["decode_ms"]]
+    if r2.get("issue"):
+        c["issue"] = {"valu_floor_ms": r2["issue"]["valu_floor_ms"], "frac": r2["issue"]["frac"],
+                      "class_alone_ms": r2["issue"].get("class_alone_ms")}
     return c
 
 
@@ -157,6 +161,39 @@ def committed_traffic(tag, alg_bytes):
         return None
 
 
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # MI355X: 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
+
+
+def committed_issue(tag, kernel_ms):
+    """The bound ROC is actually near: instruction issue.  Sum of SQ_INSTS_VALU (wave instructions) over the kernels of one step, from
+    the committed counter passes of this very workload (tools/pmc_issue.sh -> profiles/pmc_issue_<tag>.json; offline, like
+    committed_traffic), x 4 cycles / (1024 SIMDs x 2.4 GHz) = the time the step's vector instructions need with every SIMD issuing
+    one every cycle-slot: `valu_floor_ms`; `frac` = that floor over the measured kernel time.  S2 additionally carries what its two
+    chain kernel classes take with the machine to themselves (profiles/r06_s2_timeline_serial.txt, VIDC_SERIAL=1)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"pmc_issue_{tag}.json")) as f:
+            pk = json.load(f)["per_kernel_per_step"]
+        valu = sum(v.get("SQ_INSTS_VALU", 0.0) for v in pk.values())
+        salu = sum(v.get("SQ_INSTS_SALU", 0.0) for v in pk.values())
+        floor_ms = 1e3 * valu * 4.0 / (SIMDS * CLOCK_HZ)
+        out = {"bound": "valu issue", "valu_wave_insts_per_step": valu, "salu_wave_insts_per_step": salu, "valu_floor_ms": floor_ms,
+               "frac": floor_ms / kernel_ms if kernel_ms else None,
+               "source": f"profiles/pmc_issue_{tag}.json (rocprofv3 --pmc SQ_INSTS_VALU ..., offline passes of this command)"}
+        top = sorted(pk.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0.0))[:3]
+        out["top_kernels_valu_share"] = {k: v.get("SQ_INSTS_VALU", 0.0) / valu for k, v in top} if valu else {}
+        if tag.startswith("s2"):
+            alone = {}
+            with open(os.path.join(ROOT, "profiles", "r06_s2_timeline_serial.txt")) as f:
+                for line in f:
+                    m = re.match(r"^(k_roc_encode_r2|k_roc_decode_b2)\b.*start ([\d.]+) end ([\d.]+)", line)
+                    if m:
+                        alone[m.group(1)] = alone.get(m.group(1), 0.0) + float(m.group(3)) - float(m.group(2))
+            out["class_alone_ms"] = alone
+        return out
+    except Exception:
+        return None
+
+
 def per_list_multisets_equal(offsets, got, want, chunk=1 << 27):
     """Every list of `got` holds the same multiset of ids as the same list of `want` (both device int64, CSR `offsets`):
     keyed sort (list number, id) of both sides, in chunks cut on list boundaries.  A list-boundary bug fails this; a
@@ -180,7 +217,7 @@ def per_list_multisets_equal(offsets, got, want, chunk=1 << 27):
     return True
 
 
-def sharded_measure(args, ctx, dist, rank, world, steps, warmup, workload="c5", device="cuda"):
+def sharded_measure(args, ctx, dist, rank, world, steps, warmup, workload="c5", device="cuda", codec="roc"):
     """Strong scaling of one index (BASELINE configs[4] shape): shard, encode + decode per rank, search-shaped gather.
     -> the result dict on rank 0, None elsewhere.  `ctx` None = --dry-run (DryLists stands in for the codec, device cpu)."""
     import torch
@@ -193,7 +230,7 @@ def sharded_measure(args, ctx, dist, rank, world, steps, warmup, workload="c5", 
     want_perm = not args.no_perm
     dry = ctx is None
     if not dry:
-        from vector_db_id_compression_amd.codecs import RocLists
+        from vector_db_id_compression_amd.codecs import EfLists, PackedLists, RocLists
 
     def sync():
         if not dry:
@@ -214,11 +251,18 @@ def sharded_measure(args, ctx, dist, rank, world, steps, warmup, workload="c5", 
             sh.codec = DryLists(loc_off, loc_ids)
             sh.codec.decode_all(out)
             return 0.0, 0.0
-        sh.codec = RocLists.encode(loc_off, loc_ids, ctx=ctx, want_perm=want_perm)
-        ke = ctx.phase_ms(0) + ctx.phase_ms(1)
+        if codec == "roc":
+            sh.codec = RocLists.encode(loc_off, loc_ids, ctx=ctx, want_perm=want_perm)
+            ke = ctx.phase_ms(0) + ctx.phase_ms(1)
+            sh.codec.decode_all(out)
+            return ke, ctx.phase_ms(2)
+        sh.codec = (EfLists if codec == "ef" else PackedLists).encode(loc_off, loc_ids, ctx=ctx)
+        ke = ctx.last_kernel_ms()
         sh.codec.decode_all(out)
-        return ke, ctx.phase_ms(2)
+        return ke, ctx.last_kernel_ms()
 
+    if dist is not None:
+        dist.barrier()  # (a collective before the first gather: batched send / recv must not be a group's first operation)
     for _ in range(max(warmup, 1)):
         step()
         sh.gather_ids(req, dst=0)
@@ -261,13 +305,19 @@ def sharded_measure(args, ctx, dist, rank, world, steps, warmup, workload="c5", 
         ok = ok and np.array_equal(a, np.sort(np.asarray(ids_host[int(offsets[l]):int(offsets[l + 1])]).astype(np.uint64)))
     rows = [x.cpu().numpy() for x in allr]
     codec_ms = [1e3 * float(x[0]) for x in rows]
+    # what strong scaling can reach at most: the ranks work in parallel, a list does not -- ROC's longest list is one serial chain
+    # (sum of ids / (G x longest list)); the bandwidth codecs split a list over wavefronts and have no such bound
+    strong_bound = float(wl["ntotal"]) / (world * max(1, wl["max_list"])) if codec == "roc" else None
     return {
-        "metric": "IDs encoded+decoded / sec (ROC/ANS, bit-exact vs codec.cpp), one index sharded over the GPUs",
+        "metric": ("IDs encoded+decoded / sec (ROC/ANS, bit-exact vs codec.cpp), one index sharded over the GPUs" if codec == "roc"
+                   else f"IDs encoded+decoded / sec ({codec}), one index sharded over the GPUs"),
+        "strong_bound": strong_bound,
         "value": None if dry else wl["ntotal"] * steps / elapsed, "unit": "IDs/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": wl["describe"], "codec": "roc", "nlist": wl["nlist"], "max_list": wl["max_list"],
-                   "median_list": wl["median_list"], "container_path": "stream + sampling permutation" if want_perm else "stream only",
+        "config": {"workload": wl["describe"], "codec": codec, "nlist": wl["nlist"], "max_list": wl["max_list"],
+                   "median_list": wl["median_list"],
+                   "container_path": ("stream + sampling permutation" if want_perm else "stream only") if codec == "roc" else "streams",
                    "parallelism": f"{wl['nlist']} lists partitioned over {world} GPU(s) by total length (LPT); per step: "
                                   f"encode + decode of the shard, then the {nq * nprobe} lists of {nq} searches x nprobe {nprobe} "
                                   f"decoded by their owners and gathered on rank 0 (send/recv)"},
@@ -580,6 +630,8 @@ def main():
                           "schedule of this batch runs faster than this chain (under load its steps are slower: its one "
                           "global load per step misses L2)")
             res2["chain_floor"] = cf
+        if traffic_tag and codec == "roc":
+            res2["issue"] = committed_issue(traffic_tag, (ke + kd) / steps)
         return res2
 
     def secondary_graph(N=1_000_000, K=64, steps=5):
@@ -650,13 +702,18 @@ def main():
         per_rank_ms = [float(x.item()) for x in allr]
 
     # one launch answers both multi-GPU questions: behind the weak steps the SAME ranks shard ONE index (strong form)
-    sharded = None
+    sharded = sharded_ef = None
     if world > 1 and not args.no_sharded_extra and args.codec == "roc":
         try:
             sharded = sharded_measure(args, ctx, dist, rank, world, steps=min(args.steps, 5), warmup=1,
                                       workload=args.sharded_workload, device=device)
         except Exception as e:  # (every rank takes the same path: a failure here is reported, not fatal for `value`)
             sharded = {"error": str(e)}
+        try:  # the same index through a codec without a serial chain: the form the ">= 6x at 8 GPUs" of north_star can show on
+            sharded_ef = sharded_measure(args, ctx, dist, rank, world, steps=min(args.steps, 5), warmup=1,
+                                         workload=args.sharded_workload, device=device, codec="ef")
+        except Exception as e:
+            sharded_ef = {"error": str(e)}
     info = rccl_info(dist, world, device) if dist is not None else None
 
     if rank == 0:
@@ -733,17 +790,21 @@ def main():
                 res["extra_legend"] = EXTRA_LEGEND
             except Exception as e:
                 res["extra"] = {"error": str(e), **{k: compact(v) for k, v in full.items()}}
-        if sharded is not None:
-            res.setdefault("extra", {})["sharded_c5"] = (sharded if "error" in sharded else {
-                "workload": sharded["config"]["workload"], "ids_per_s": sharded["value"], "ms": sharded["ms_per_step"],
-                "steps": sharded["steps"], "per_rank": sharded["per_rank"], "gather_bytes": sharded["gather_bytes"],
-                "gather_lists": sharded["gather_lists"], "gather_verified": sharded["gather_verified"], "scaling": "strong"})
+        for key, shd in (("sharded_c5", sharded), ("sharded_c5_ef", sharded_ef)):
+            if shd is not None:
+                res.setdefault("extra", {})[key] = (shd if "error" in shd else {
+                    "workload": shd["config"]["workload"], "codec": shd["config"]["codec"], "ids_per_s": shd["value"], "ms": shd["ms_per_step"],
+                    "steps": shd["steps"], "per_rank": shd["per_rank"], "gather_bytes": shd["gather_bytes"],
+                    "gather_lists": shd["gather_lists"], "gather_verified": shd["gather_verified"], "scaling": "strong",
+                    "strong_bound": shd["strong_bound"]})
         if world == 1 and args.codec == "roc" and not args.no_extra and not dry:
             try:
                 cf = chain_floor(wl, d_ids)
                 cf["chain_floor_ms"] = cf["encode_ms"] + cf["decode_ms"]
                 cf["share_of_kernel_time"] = cf["chain_floor_ms"] / (1e3 * kern_s)
                 res["roofline"]["chain_floor"] = cf
+                if args.workload == "s1":
+                    res["roofline"]["issue"] = committed_issue("s1_roc", 1e3 * kern_s)
                 res["roofline"]["note"] = "latency bound: the batch cannot finish before its longest list's chain of dependent codec steps (chain_floor)"
             except Exception as e:
                 res["roofline"]["chain_floor"] = {"error": str(e)}

@@ -113,4 +113,10 @@ def test_two_rank_line_carries_the_weak_aggregate_the_sharded_index_and_what_the
         assert len(pr[key]) == 2, key
     assert sum(pr["ids"]) == 1_000_000 and abs(pr["ids"][0] - pr["ids"][1]) <= 52114  # LPT: within the longest list
     assert pr["codec_ms_spread"] >= 0 and sh["gather_lists"] == 16000 and sh["gather_bytes"] > 0
-    assert len(lines[0]) < 7000  # the driver keeps the last ~8000 characters of stdout
+    # ROC's strong scaling is bounded by its longest list (one serial chain): sum of ids / (G x longest list), printed beside it
+    assert sh["codec"] == "roc" and abs(sh["strong_bound"] - 1_000_000 / (2 * 52114)) < 1e-3
+    # the same index through a codec without that chain: the form north_star's ">= 6x at 8 GPUs" can show on
+    ef = d["extra"]["sharded_c5_ef"]
+    assert ef["codec"] == "ef" and ef["scaling"] == "strong" and ef["gather_verified"] is True and ef["strong_bound"] is None
+    assert sum(ef["per_rank"]["ids"]) == 1_000_000 and ef["gather_lists"] == 16000
+    assert len(lines[0]) < 7500  # the driver keeps the last ~8000 characters of stdout

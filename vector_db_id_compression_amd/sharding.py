@@ -85,6 +85,20 @@ class ShardedInvLists:
             local_ids = ids[_segment_index(st, sz, torch)] if loc_sizes.size else ids[:0]
         self.codec = encode_fn(self.local_offsets, local_ids)
         self.load = np.bincount(self.owner, weights=self.sizes, minlength=world).astype(np.int64)
+        self._p2p_ready = False
+
+    def _ensure_p2p(self):
+        """The first operation of a process group must not be a batch of point-to-point operations: PyTorch documents batched
+        send / recv as undefined when they are a group's first call (the NCCL / RCCL communicators of the pairs are created
+        lazily and at different moments on the two sides).  One collective brings every rank's communicator up first."""
+        if self._p2p_ready or self.world <= 1:
+            return
+        import torch
+        import torch.distributed as dist
+
+        t = torch.zeros(1, dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, group=self.group)
+        self._p2p_ready = True
 
     def decode_local(self, list_nos):
         """Decode the requested GLOBAL list numbers this rank owns (request order, repeats kept)
@@ -106,9 +120,11 @@ class ShardedInvLists:
         owners = self.owner[ln]
         _, ids, _ = self.decode_local(ln)
         ids = ids.to(self.device).view(torch.int64) if ids.numel() else torch.zeros(0, dtype=torch.int64, device=self.device)
+        self._ensure_p2p()
         if self.world > 1 and self.rank != dst:
-            if ids.numel():
-                dist.send(ids.contiguous(), dst=dst, group=self.group)
+            if ids.numel():  # (the same batched form as the receiving side: one group call per rank and gather)
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, ids.contiguous(), dst, self.group)]):
+                    w.wait()
             return None, None
         out = torch.empty(int(req_off[-1]), dtype=torch.int64, device=self.device)
         bufs = {self.rank: ids}
