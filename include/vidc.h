@@ -69,6 +69,9 @@ int vidc_ctx_synchronize(vidc_ctx *ctx);
  * (kept so that the next 10^6-list encode does not page-fault ~50 MB in again; bounded at 256 MB per element type) is
  * released as well. */
 int vidc_ctx_trim(vidc_ctx *ctx, uint64_t *freed_bytes);
+/* Test aid: fill every device block the context's cache hands out with 0xFF first (also: VIDC_POOL_POISON=1 in the environment when the
+ * context is created).  Streams must not depend on what a block held before. */
+int vidc_ctx_debug_pool_poison(vidc_ctx *ctx, int on);
 /* Streams the kernel classes of one large ROC call are spread over: 8 when the PROCESS was started with the ROCm runtime
  * variable GPU_MAX_HW_QUEUES >= 8 (HIP multiplexes a process's streams onto that many hardware queues, default 4, and reads
  * the variable when it initialises: export it before the process starts -- for a Faiss-hosted process in the environment of
@@ -139,7 +142,8 @@ int vidc_roc_decode_lists(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const ui
 /* The decode section of the deferred search in ONE call (custom_invlists_impl.cpp:508-525: `ids = get_ids(list_no)` per touched
  * list, then `labels[r] = ids[lo_offset(labels[r])]`): the m touched lists are decoded into device staging owned by the
  * context, the n_items requested ids are picked ON THE DEVICE (item i = list_nos[item_slot[i]][item_off[i]]) and only those
- * cross PCIe: 8 * n_items bytes into ids_out (host int64[n_items]).  Items outside their list -> VIDC_ERR_INVALID.
+ * cross PCIe: 8 * n_items bytes into ids_out (host int64[n_items]).  Items outside their list -> VIDC_ERR_INVALID, reported before
+ * anything is decoded.  list_nos should name every touched list ONCE (a repeated list is decoded and staged once per mention).
  * Same signature for the four containers (vidc_ef_decode_gather, vidc_packed_decode_gather, vidc_wt_decode_gather). */
 int vidc_roc_decode_gather(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *list_nos, uint64_t n_items,
                            const uint64_t *item_slot, const uint64_t *item_off, int64_t *ids_out);

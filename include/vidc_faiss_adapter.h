@@ -52,6 +52,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -126,13 +127,24 @@ struct DeviceArray {
 struct CompressedInvertedLists : faiss::ReadOnlyInvertedLists {
 #ifndef SWIG
     struct Prefetch { /* one announcement of IndexIVF::search_preassigned */
-        std::vector<uint64_t> lists;
+        std::thread::id owner;                  /* the thread that announced it */
+        std::vector<uint64_t> lists;            /* distinct non-empty lists */
         std::unordered_map<uint64_t, size_t> slot;
+        std::atomic<long> remaining{0};         /* announced visits not served yet: the cache is dropped when it reaches 0 */
+        size_t total_ids = 0;
         std::once_flag once; /* the first get_ids of an announced list decodes them all */
         std::vector<faiss::idx_t> ids;
         std::vector<uint64_t> off;
     };
-    mutable std::shared_ptr<Prefetch> prefetch_; /* (std::atomic_load / atomic_store: searches may run concurrently) */
+    /* Announcements that are being served.  IndexIVF::search cuts a batch into one slice per OpenMP thread and every slice announces
+     * its own lists from its own thread, concurrently (round 5 kept ONE slot per container: the slices overwrote each other and a
+     * stale announcement pinned up to 128 MB of decoded ids until the next search).  Now: one announcement per announcing thread
+     * (a new one from the same thread replaces it), found first by the calling thread's own, then by any that holds the list (a
+     * batch too small to be sliced announces from the main thread and scans from the workers); every visit served counts the
+     * announcement down and the last one frees its cache; the cached ids of all live announcements stay below
+     * VIDC_FAISS_PREFETCH_MAX_IDS, beyond that an announcement is not recorded and its lists take the per-list path. */
+    mutable std::mutex pf_mu_;
+    mutable std::vector<std::shared_ptr<Prefetch>> pf_active_;
 #endif
     std::vector<uint64_t> offsets;                /* [nlist + 1] */
     std::vector<std::vector<uint8_t>> codes_all;  /* per list, in the container's order */
@@ -198,32 +210,60 @@ struct CompressedInvertedLists : faiss::ReadOnlyInvertedLists {
         std::shared_ptr<Prefetch> st;
         if (n > 1) {
             st = std::make_shared<Prefetch>();
-            size_t total = 0;
-            for (int i = 0; i < n && total <= VIDC_FAISS_PREFETCH_MAX_IDS; i++) {
+            st->owner = std::this_thread::get_id();
+            long visits = 0;
+            for (int i = 0; i < n && st->total_ids <= VIDC_FAISS_PREFETCH_MAX_IDS; i++) {
                 if (list_nos[i] < 0 || (size_t)list_nos[i] >= nlist || !list_size(list_nos[i])) continue;
+                visits++;
                 if (st->slot.emplace((uint64_t)list_nos[i], st->lists.size()).second) {
                     st->lists.push_back((uint64_t)list_nos[i]);
-                    total += list_size(list_nos[i]);
+                    st->total_ids += list_size(list_nos[i]);
                 }
             }
-            if (total > VIDC_FAISS_PREFETCH_MAX_IDS || st->lists.size() < 2) st.reset();
+            st->remaining.store(visits);
+            if (st->total_ids > VIDC_FAISS_PREFETCH_MAX_IDS || st->lists.size() < 2) st.reset();
         }
-        std::atomic_store(&prefetch_, st);
+        std::lock_guard<std::mutex> g(pf_mu_);
+        size_t live = 0;
+        for (size_t i = 0; i < pf_active_.size();) {  /* this thread's previous announcement is over */
+            if (pf_active_[i]->owner == std::this_thread::get_id()) pf_active_.erase(pf_active_.begin() + i);
+            else live += pf_active_[i++]->total_ids;
+        }
+        if (st && live + st->total_ids <= VIDC_FAISS_PREFETCH_MAX_IDS) pf_active_.push_back(st);
     }
-    void clear_prefetch() const { std::atomic_store(&prefetch_, std::shared_ptr<Prefetch>()); }
+    void clear_prefetch() const {
+        std::lock_guard<std::mutex> g(pf_mu_);
+        pf_active_.clear();
+    }
+    size_t prefetch_live_announcements() const {
+        std::lock_guard<std::mutex> g(pf_mu_);
+        return pf_active_.size();
+    }
 
     /* get_ids: new idx_t[list_size], nullptr for an empty list (:212-214,294-296) */
     const faiss::idx_t* get_ids(size_t l) const override {
         size_t n = list_size(l);
         if (n == 0) return nullptr;
         std::unique_ptr<faiss::idx_t[]> out(new faiss::idx_t[n]);
-        if (std::shared_ptr<Prefetch> st = std::atomic_load(&prefetch_)) {
-            auto it = st->slot.find((uint64_t)l);
-            if (it != st->slot.end()) {
-                std::call_once(st->once, [&] { decode_lists_host(st->lists.size(), st->lists.data(), st->ids, st->off); });
-                std::memcpy(out.get(), st->ids.data() + st->off[it->second], n * sizeof(faiss::idx_t));
-                return out.release();
+        std::shared_ptr<Prefetch> st;
+        {
+            std::lock_guard<std::mutex> g(pf_mu_);
+            const std::thread::id me = std::this_thread::get_id();
+            for (auto& a : pf_active_)  /* (a handful: one per announcing thread) */
+                if (a->slot.count((uint64_t)l) && (!st || a->owner == me)) {
+                    st = a;
+                    if (a->owner == me) break;
+                }
+        }
+        if (st) {
+            std::call_once(st->once, [&] { decode_lists_host(st->lists.size(), st->lists.data(), st->ids, st->off); });
+            std::memcpy(out.get(), st->ids.data() + st->off[st->slot.find((uint64_t)l)->second], n * sizeof(faiss::idx_t));
+            if (st->remaining.fetch_sub(1) <= 1) {  /* the last announced visit: the search this announcement belonged to is over */
+                std::lock_guard<std::mutex> g(pf_mu_);
+                for (size_t i = 0; i < pf_active_.size(); i++)
+                    if (pf_active_[i] == st) { pf_active_.erase(pf_active_.begin() + i); break; }
             }
+            return out.release();
         }
         ThreadCtx& t = thread_ctx();
         uint64_t off[2], ln = l;

@@ -9,6 +9,8 @@
 #include <random>
 #include <set>
 #include <vector>
+#include <thread>
+#include <atomic>
 
 #define VIDC_FAISS_REFERENCE_NAMES  // the reference's class names at global scope (bench_invlists.py:19-25 runs unchanged)
 #include "vidc_faiss_adapter.h"
@@ -64,6 +66,49 @@ static int check_container(faiss::IndexIVF& index, const faiss::ArrayInvertedLis
         const idx_t* ids = comp.get_ids(l0);
         REQUIRE(vidc_faiss::thread_ctx().device_calls - calls1 == 1);
         comp.release_ids(l0, ids);
+    }
+    {
+        // IndexIVF::search cuts a batch into one slice per thread and every slice announces its own lists, concurrently: the
+        // announcements must not overwrite each other (each slice: ONE library call for its lists), the ids must be right, and when
+        // the slices are done nothing stays cached
+        REQUIRE(comp.prefetch_live_announcements() == 0);
+        std::vector<size_t> nonempty;
+        for (size_t l = 0; l < ref.nlist; l++)
+            if (ref.list_size(l)) nonempty.push_back(l);
+        const int T = 4;
+        std::vector<int> bad(T, 0);
+        std::vector<size_t> calls(T, 0);
+        std::atomic<int> announced{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t] {
+                std::vector<idx_t> mine;  // overlapping subsets, with repeats and a -1 like a real probe list
+                for (size_t i = (size_t)t; i < nonempty.size(); i += 2) mine.push_back((idx_t)nonempty[i]);
+                for (size_t i = 0; i < std::min<size_t>(5, nonempty.size()); i++) mine.push_back((idx_t)nonempty[i]);
+                mine.push_back(-1);
+                const size_t c0 = vidc_faiss::thread_ctx().device_calls;
+                comp.prefetch_lists(mine.data(), (int)mine.size());
+                announced++;
+                while (announced.load() < T) std::this_thread::yield();  // every slice has announced before any of them scans
+                for (idx_t l : mine) {
+                    if (l < 0) continue;
+                    const idx_t* ids = comp.get_ids((size_t)l);
+                    const idx_t* want = ref.get_ids((size_t)l);
+                    std::vector<idx_t> a(ids, ids + ref.list_size(l)), b(want, want + ref.list_size(l));
+                    std::sort(a.begin(), a.end());
+                    std::sort(b.begin(), b.end());
+                    if (a != b) bad[t]++;
+                    comp.release_ids((size_t)l, ids);
+                    ref.release_ids((size_t)l, want);
+                }
+                calls[t] = vidc_faiss::thread_ctx().device_calls - c0;
+            });
+        for (auto& x : th) x.join();
+        for (int t = 0; t < T; t++) {
+            REQUIRE(bad[t] == 0);
+            REQUIRE(calls[t] <= 1);  // (a slice whose lists another slice's cache already held makes no call at all)
+        }
+        REQUIRE(comp.prefetch_live_announcements() == 0);
     }
     for (int one_by_one = 0; one_by_one < 2; one_by_one++) {  // test_compressed_ivfs.py:128-156
         std::fill(I.begin(), I.end(), -7);

@@ -334,7 +334,7 @@ def test_save_load_roundtrip(tmp_path):
 def test_streams_from_dirty_pool_blocks_equal_streams_from_fresh_ones(monkeypatch, tmp_path):
     """The high stream of an Elias-Fano object up to 64 MB is not cleared before the chunk kernels write it (every high word has ONE
     owning chunk, empty words included), the encoder writes the decode records, packed bits writes its own padding words, ROC its
-    arenas: all into blocks from the context's pool, which hold whatever an earlier call left there.  VIDC_POOL_POISON=1 fills every
+    arenas: all into blocks from the context's pool, which hold whatever an earlier call left there.  the context's pool-poison switch (vidc_ctx_debug_pool_poison; VIDC_POOL_POISON=1 at start-up) fills every
     block handed out with 0xFF; the word images (Elias-Fano low / high, packed words, ROC stack words) and the decoded ids must be
     the ones a cleared stream (VIDC_EF_MEMSET=1) / a fresh block gives.  Zipf lists, empty lists, lists whose high stream spans
     more than a chunk's LDS window, a sparse tail, 64-bit ids."""
@@ -374,13 +374,19 @@ def test_streams_from_dirty_pool_blocks_equal_streams_from_fresh_ones(monkeypatc
                 out[name, "roc"] = (r.all_words().copy(), r.info()["heads"].copy(), r.perm().copy(), r.decode_all().cpu().numpy().copy())
         return out
 
-    monkeypatch.delenv("VIDC_POOL_POISON", raising=False)
+    from vector_db_id_compression_amd import _lib
+
+    ctx = _lib.default_context()
+    ctx.set_pool_poison(False)
     monkeypatch.setenv("VIDC_EF_MEMSET", "1")
     clean = images("clean")
     monkeypatch.delenv("VIDC_EF_MEMSET", raising=False)
-    monkeypatch.setenv("VIDC_POOL_POISON", "1")
-    dirty = images("dirty")
-    dirty2 = images("dirty2")  # (blocks released by the first poisoned pass, poisoned again)
+    ctx.set_pool_poison(True)
+    try:
+        dirty = images("dirty")
+        dirty2 = images("dirty2")  # (blocks released by the first poisoned pass, poisoned again)
+    finally:
+        ctx.set_pool_poison(False)
     assert clean.keys() == dirty.keys()
     for key in clean:
         for i, (a, b, c) in enumerate(zip(clean[key], dirty[key], dirty2[key])):

@@ -45,6 +45,7 @@ def _declare(lib):
     f("vidc_ctx_reset_stream", C.c_int, _vp)
     f("vidc_ctx_synchronize", C.c_int, _vp)
     f("vidc_ctx_trim", C.c_int, _vp, C.POINTER(C.c_uint64))
+    f("vidc_ctx_debug_pool_poison", C.c_int, _vp, C.c_int)
     f("vidc_ctx_class_streams", C.c_int, _vp)
     f("vidc_dev_alloc", C.c_int, _vp, C.c_size_t, _P(_vp))
     f("vidc_dev_free", C.c_int, _vp, _vp)
@@ -125,7 +126,7 @@ def _declare(lib):
 #: every symbol include/vidc.h declares (checked by the CPU test-suite against the built library)
 EXPORTED_SYMBOLS = [
     "vidc_last_error", "vidc_version", "vidc_ctx_create", "vidc_ctx_destroy", "vidc_ctx_set_stream", "vidc_ctx_reset_stream",
-    "vidc_ctx_synchronize", "vidc_ctx_trim", "vidc_ctx_class_streams", "vidc_dev_alloc", "vidc_dev_free", "vidc_copy_h2d", "vidc_copy_d2h", "vidc_ctx_d2h_bytes",
+    "vidc_ctx_synchronize", "vidc_ctx_trim", "vidc_ctx_debug_pool_poison", "vidc_ctx_class_streams", "vidc_dev_alloc", "vidc_dev_free", "vidc_copy_h2d", "vidc_copy_d2h", "vidc_ctx_d2h_bytes",
     "vidc_ctx_last_kernel_ms", "vidc_ctx_phase_ms", "vidc_ctx_chain_info",
     "vidc_roc_encode", "vidc_roc_encode_rows", "vidc_roc_destroy", "vidc_roc_nlist", "vidc_roc_ntotal",
     "vidc_roc_compressed_bytes", "vidc_roc_total_words", "vidc_roc_list_info", "vidc_roc_export_words", "vidc_roc_export_all_words",
@@ -206,6 +207,10 @@ class Context:
         freed = C.c_uint64(0)
         check(lib().vidc_ctx_trim(self.h, C.byref(freed)))
         return int(freed.value)
+
+    def set_pool_poison(self, on):
+        """Test aid: every cached device block is filled with 0xFF before it is handed out (vidc_ctx_debug_pool_poison)."""
+        check(lib().vidc_ctx_debug_pool_poison(self.h, 1 if on else 0))
 
     def class_streams(self):
         """Streams the kernel classes of a large ROC call are spread over: 8 if the process started with GPU_MAX_HW_QUEUES >= 8, else 4."""

@@ -34,44 +34,10 @@ void set_error(const char *fmt, ...);
         }                                                                                     \
     } while (0)
 
-// Waiting for a stream / an event.  hipStreamSynchronize spins on the completion signal for 100 us and then sleeps until the
-// interrupt.  VIDC_SPIN_US=n makes these poll the state for up to n us before they block (measurements: 3000 us did not move a
-// 1 ms encode + decode call of 65 536 lists -- 1.076 against 1.054 ms, inside the box-to-box spread -- so the default is 0: the
-// runtime's wait at once).
-inline long vidc_spin_us() {
-    static const long us = [] { const char *e = std::getenv("VIDC_SPIN_US"); return e ? std::atol(e) : 0L; }();
-    return us;
-}
-template <typename Query>
-inline bool vidc_spin_until_done(Query &&q, hipError_t *err) {
-    const long limit = vidc_spin_us();
-    if (limit <= 0) return false;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned it = 0;; it++) {
-        const hipError_t e = q();
-        if (e != hipErrorNotReady) {
-            if (it) (void)hipGetLastError();  // ("not ready" must not be what the next launch check reads)
-            *err = e;
-            return true;
-        }
-        __builtin_ia32_pause();
-        if ((it & 15u) == 15u &&
-            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > limit) {
-            (void)hipGetLastError();
-            return false;
-        }
-    }
-}
-inline hipError_t vidc_stream_wait(hipStream_t s) {
-    hipError_t e = hipSuccess;
-    if (vidc_spin_until_done([&] { return hipStreamQuery(s); }, &e)) return e;
-    return hipStreamSynchronize(s);
-}
-inline hipError_t vidc_event_wait(hipEvent_t ev) {
-    hipError_t e = hipSuccess;
-    if (vidc_spin_until_done([&] { return hipEventQuery(ev); }, &e)) return e;
-    return hipEventSynchronize(ev);
-}
+// Waiting for a stream / an event: the runtime's own wait (it spins on the completion signal for ~100 us, then sleeps until the
+// interrupt).  Polling the state for longer before blocking was measured in round 4 and did not move a 1 ms call: HISTORY.md.
+inline hipError_t vidc_stream_wait(hipStream_t s) { return hipStreamSynchronize(s); }
+inline hipError_t vidc_event_wait(hipEvent_t ev) { return hipEventSynchronize(ev); }
 
 #define VIDC_TRY(expr)              \
     do {                            \
@@ -144,6 +110,9 @@ struct DevPool {
     std::mutex m;
     std::vector<PoolBlockD> blocks;
     int device = 0;
+    // tests: every block handed out is filled with 0xFF first (VIDC_POOL_POISON=1 when the pool is created, or
+    // vidc_ctx_debug_pool_poison)
+    bool poison_on = [] { const char *e = std::getenv("VIDC_POOL_POISON"); return e && e[0] == '1'; }();
     ~DevPool();
     int get(size_t nbytes, void **p, size_t *bytes);
     int get_raw(size_t nbytes, void **p, size_t *bytes);
@@ -300,10 +269,19 @@ inline int vidc_decode_gather_impl(vidc_ctx *ctx, uint64_t nlist, uint64_t m, co
     if (!n_items) return VIDC_OK;
     if (!m || !list_nos || !item_slot || !item_off || !ids_out) return VIDC_ERR_INVALID;
     uint64_t total = 0;
+    std::vector<uint64_t> sizes(m);
     for (uint64_t i = 0; i < m; i++) {
         if (list_nos[i] >= nlist) { vidc::set_error("decode_gather: list number %llu out of range", (unsigned long long)list_nos[i]); return VIDC_ERR_INVALID; }
-        total += size_of(list_nos[i]);
+        sizes[i] = size_of(list_nos[i]);
+        total += sizes[i];
     }
+    // (the request is checked BEFORE anything is decoded: an invalid item must not cost the decode of every touched list)
+    for (uint64_t i = 0; i < n_items; i++)
+        if (item_slot[i] >= m || item_off[i] >= sizes[item_slot[i]]) {
+            vidc::set_error("decode_gather: item %llu = (slot %llu, offset %llu) is outside its list", (unsigned long long)i,
+                            (unsigned long long)item_slot[i], (unsigned long long)item_off[i]);
+            return VIDC_ERR_INVALID;
+        }
     vidc::Scratch staging;
     VIDC_TRY(staging.get(ctx, (total ? total : 1) * 8));
     std::vector<uint64_t> list_off(m + 1, 0);

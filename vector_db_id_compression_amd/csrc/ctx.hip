@@ -22,9 +22,9 @@ DevPool::~DevPool() {
 // supposed to write (Elias-Fano high words without a memset, packed-bits padding words, encoder-written decode records, ROC
 // arenas) must produce the same bits from dirty blocks as from fresh ones; stale data from an earlier call is what a pooled
 // block normally holds.
+// (The switch is a member of the pool, read from the environment when the pool is created and settable through
+// vidc_ctx_debug_pool_poison: round 5 called getenv on every block handed out.)
 static int poison(void *p, size_t bytes) {
-    const char *e = std::getenv("VIDC_POOL_POISON");
-    if (!e || e[0] != '1') return VIDC_OK;
     VIDC_HIP(hipDeviceSynchronize());
     VIDC_HIP(hipMemset(p, 0xFF, bytes));
     VIDC_HIP(hipDeviceSynchronize());
@@ -32,7 +32,7 @@ static int poison(void *p, size_t bytes) {
 }
 int DevPool::get(size_t nbytes, void **out, size_t *out_bytes) {
     VIDC_TRY(get_raw(nbytes, out, out_bytes));
-    return poison(*out, *out_bytes);
+    return poison_on ? poison(*out, *out_bytes) : VIDC_OK;
 }
 int DevPool::get_raw(size_t nbytes, void **out, size_t *out_bytes) {
     std::lock_guard<std::mutex> g(m);
@@ -290,6 +290,11 @@ int vidc_ctx_synchronize(vidc_ctx *c) {
     return VIDC_OK;
 }
 
+int vidc_ctx_debug_pool_poison(vidc_ctx *c, int on) {
+    if (!c || !c->dpool) return VIDC_ERR_INVALID;
+    c->dpool->poison_on = on != 0;
+    return VIDC_OK;
+}
 int vidc_ctx_trim(vidc_ctx *c, uint64_t *freed_bytes) {
     if (!c) return VIDC_ERR_INVALID;
     VIDC_HIP(hipSetDevice(c->device));

@@ -84,6 +84,7 @@ struct EfRec {
 };
 // (the record array ends with one unused record: a wavefront loads its record and the next one together)
 #define EF_CLEAR_HIGH_BYTES (64ull << 20)  // high streams beyond this are cleared ahead of the chunk kernels (comment at the memset)
+#define EF_SINGLE_MAX_CHUNKS 16384u  // chunk records the single-tile geometry kernel writes itself (S1: 2.4 k)
 #define EF_ENC_RECS_MAX (1u << 18)  // objects of fewer batches: records written by the encoder, LDS table sized by the longest list
 
 namespace {
@@ -1829,7 +1830,10 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
                    bool *retry, bool spec, bool *respec) {
     const uint64_t nlist = e->nlist;
     const uint32_t nl32 = (uint32_t)nlist;
-    const uint32_t tile_lists = nl32 <= EF_SINGLE_LISTS ? EF_SINGLE_LISTS : (nl32 <= EF_E1_MAX_LISTS ? 256u : 1024u);
+    // (one tile only for objects whose chunk records one workgroup can write: 1024 lists of a million ids each are two million records,
+    // and spreading those over the GPU is what k_ef_big_recs is for)
+    const bool single = nl32 <= EF_SINGLE_LISTS && nchunks <= EF_SINGLE_MAX_CHUNKS;  // (one tile, the geometry kernel alone)
+    const uint32_t tile_lists = single ? EF_SINGLE_LISTS : (nl32 <= EF_E1_MAX_LISTS ? 256u : 1024u);
     const uint32_t ntiles = nl32 ? (nl32 + tile_lists - 1u) / tile_lists : 1u;
     VidcPhaseTimer pt(ctx);
     HostTrace tr("ef encode_fast");
@@ -1846,7 +1850,7 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
     EfBigList *d_big = (EfBigList *)((char *)s_big.p + 16);
     uint32_t *d_nbig = s_big.as<uint32_t>();
     uint32_t *d_abort = d_nbig + 1;  // (written by k_ef_offsets whenever there are lists)
-    if (ntiles != 1u || !nlist) VIDC_HIP(hipMemsetAsync(d_nbig, 0, 16, ctx->stream));  // (a single tile writes every record itself)
+    if (!single || !nlist) VIDC_HIP(hipMemsetAsync(d_nbig, 0, 16, ctx->stream));  // (a single tile writes every record itself)
     EfLimits lim{~0ull, ~0ull, ~0ull, 1u, 0u};
     if (spec) {
         const uint64_t U = std::max<uint64_t>(e->ntotal ? e->ntotal - 1 : 0, ctx->ef_universe_hint);
@@ -1863,7 +1867,7 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
     VIDC_TRY(e->d_chunks.alloc(1, ctx->dpool));  // (the chunk table of the three-pass encoder: not needed here)
     tr.mark("scratch + geometry arrays");
     pt.begin();
-    if (ntiles == 1u) {
+    if (single) {
         hipLaunchKernelGGL((k_ef_offsets<true, 2, 512>), dim3(1), dim3(512), 0, ctx->stream, d_ids, e->d_offsets.p, nl32,
                            e->d_lbits.p, e->d_universe.p, (const EfRaw *)nullptr, (const EfTile *)nullptr, 1u,
                            e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
@@ -1883,7 +1887,7 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
                            e->d_low_off.p, e->d_high_off.p, e->d_batch_off.p, s_recs.as<EfChunkRec>(),
                            hs, d_big, d_nbig, lim, d_abort);
     }
-    if (ntiles != 1u && max_list > (uint64_t)EF_CHUNK * EF_BIG_CHUNKS)  // (some list is that long)
+    if (!single && max_list > (uint64_t)EF_CHUNK * EF_BIG_CHUNKS)  // (some list is that long)
         hipLaunchKernelGGL(k_ef_big_recs, dim3((uint32_t)std::min<uint64_t>(big_cap, (uint64_t)ctx->num_cu * 32)), dim3(64), 0, ctx->stream,
                            d_big, d_nbig, s_recs.as<EfChunkRec>());
     VIDC_HIP(hipGetLastError());
@@ -1951,32 +1955,15 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
         if (wide_ids)
             hipLaunchKernelGGL(k_ef_lowhigh, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(), nchunks,
                                e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
-        else if (!std::getenv("VIDC_EF_OLD_ENC") && !std::getenv("VIDC_EF_NO_FULL")) {  // the V2 bodies (VIDC_EF_OLD_ENC=1: the round-4 ones below)
-            if (max_list <= 256)
-                hipLaunchKernelGGL((k_ef_lowhigh32<4, true, true, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
-                                   nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
-            else if (e->ntotal < 256 * nchunks)
-                hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, true, true, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
-                                   s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
-            else
-                hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false, true, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
-                                   s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
-        } else if (const bool nofull = std::getenv("VIDC_EF_NO_FULL") != nullptr; max_list <= 256) {  // (16 M ids in lists of 256: 65 -> 57 us)
-            if (nofull) hipLaunchKernelGGL((k_ef_lowhigh32<4, true, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
+        else if (max_list <= 256)
+            hipLaunchKernelGGL((k_ef_lowhigh32<4, true, true, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
                                nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
-            else hipLaunchKernelGGL((k_ef_lowhigh32<4, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(),
-                               nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
-        } else if (e->ntotal < 256 * nchunks) {  // (chunks half full on average: 10 M ids in 65 536 Zipf lists 0.090 -> 0.082 ms)
-            if (nofull) hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, true, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
+        else if (e->ntotal < 256 * nchunks)  // (chunks half full on average)
+            hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, true, true, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
                                s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
-            else hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
+        else
+            hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false, true, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
                                s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
-        } else {
-            if (nofull) hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
-                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
-            else hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
-                               s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
-        }
         VIDC_HIP(hipGetLastError());
         pt.end();
     }
@@ -2153,14 +2140,7 @@ int vidc_ef_decode_all(vidc_ctx *ctx, const vidc_ef *e, uint64_t *d_out) {
         const uint32_t max_cnt = publish_after_sync ? pending_max_cnt : e->recs_max_cnt;
         const uint32_t lds = std::min<uint32_t>(EF_BATCH_BITS, (max_cnt + 63u) & ~63u) * 2;
         const bool small = max_cnt <= 256;
-        const bool dec_v1 = std::getenv("VIDC_EF_DEC_V1") != nullptr;
-        if (e->narrow && small && dec_v1)
-            hipLaunchKernelGGL((k_ef_decode_rec<uint32_t, 4, false>), grid, dim3(64), lds, ctx->stream, e->d_low.p, e->d_high.p,
-                               e->d_recs.p, (uint32_t)e->nbatches, d_out);
-        else if (e->narrow && dec_v1)
-            hipLaunchKernelGGL((k_ef_decode_rec<uint32_t, 8, false>), grid, dim3(64), lds, ctx->stream, e->d_low.p, e->d_high.p,
-                               e->d_recs.p, (uint32_t)e->nbatches, d_out);
-        else if (e->narrow && small)
+        if (e->narrow && small)
             hipLaunchKernelGGL((k_ef_decode_rec<uint32_t, 4>), grid, dim3(64), lds, ctx->stream, e->d_low.p, e->d_high.p,
                                e->d_recs.p, (uint32_t)e->nbatches, d_out);
         else if (e->narrow)

@@ -764,10 +764,8 @@ static int packed_setup(vidc_ctx *ctx, vidc_packed *p, uint64_t nlist, const uin
     // lists per thread of k_packed_table (256 threads per tile): an object of up to 4095 lists is ONE tile (no chained scan, no cleared
     // state), larger ones aim at ~1024 tiles -- 65 536 lists ran as 17 tiles of 4096 on 17 of the 256 CUs (16.3 us of a 102 us
     // encode + decode of 16 M ids), 2^20 lists as 257
-    // (VIDC_PACKED_TILE16=1, comparisons: tiles of 4096 lists whatever the object)
     const uint32_t per = nlist + 1 <= 4096u ? (uint32_t)((nlist + 1 + 255u) / 256u)
-                         : (std::getenv("VIDC_PACKED_TILE16") ? 16u
-                            : (uint32_t)std::min<uint64_t>(16u, std::max<uint64_t>(1u, (nlist + 1 + 262143u) / 262144u)));
+                                            : (uint32_t)std::min<uint64_t>(16u, std::max<uint64_t>(1u, (nlist + 1 + 262143u) / 262144u));
     const uint32_t ntiles = (uint32_t)((nlist + 1 + 256u * per - 1u) / (256u * per));
     VIDC_TRY(keep.s_state.get(ctx, ((size_t)2 * ntiles + 1) * 8));
     VIDC_HIP(hipMemcpyAsync(p->d_offsets.p, h64, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));

@@ -99,30 +99,22 @@ inline bool env_on(const char *name) {  // set, not empty, not "0"
 // throughput kernels -- a step costs about as many instructions as a wave-per-list step but advances four lists -- and
 // every list pays a longer step (LDS round trips instead of v_readlane), so they only pay once a call has more such
 // lists than the wave-per-list kernels keep resident.  Test hooks: VIDC_NO_GRP=1 (never), VIDC_FORCE_GRP=1 (every list
-// of 65 .. 131 072 ids), VIDC_GRP_MIN=<lists>, VIDC_GRP_MAXN=<ids> (measurements).
+// of 65 .. 131 072 ids).
 constexpr uint64_t GRP_MIN_LISTS = 8192;
 struct GrpPolicy { uint64_t min_lists, min_n, max_n, dec_max_n, dec_min_n; };
 inline GrpPolicy grp_policy() {
     // (lists beyond 32 768 ids are chains of >= 40 ms at this family's 1.2 us per step: they keep the lower-latency
-    // wave-per-list kernels unless VIDC_GRP_MAXN / VIDC_FORCE_GRP say otherwise)
+    // wave-per-list kernels unless VIDC_FORCE_GRP says otherwise)
     // Decode: up to 16 384 ids -- the 16 385..32 768-id lists are the longest chains next to the b2 / general-kernel lists of a
     // big call, and their step under load is 1.7-2.6 us here against ~1 us on the general decoder (S2: 53-85 ms against 32).
     GrpPolicy g{GRP_MIN_LISTS, VIDC_LANE_MAX64 + 1u, 32768u, 16384u, VIDC_LANE_MAX64 + 1u};
     if (env_on("VIDC_NO_GRP") || env_on("VIDC_FORCE_GENERAL") || env_on("VIDC_OLD_U")) { g.min_lists = ~0ull; return g; }
     if (env_on("VIDC_FORCE_GRP")) { g.min_lists = 0; g.min_n = g.dec_min_n = VIDC_GRP_MIN_LIST; g.max_n = g.dec_max_n = VIDC_GRP_MAX_LIST; }
-    if (const char *e = std::getenv("VIDC_GRP_MINN")) g.min_n = std::max<uint64_t>((uint64_t)std::atoll(e), VIDC_GRP_MIN_LIST);
-    if (const char *e = std::getenv("VIDC_GRP_DEC_MINN")) g.dec_min_n = std::max<uint64_t>((uint64_t)std::atoll(e), VIDC_GRP_MIN_LIST);
-    if (const char *e = std::getenv("VIDC_GRP_MIN")) g.min_lists = (uint64_t)std::atoll(e);
-    if (const char *e = std::getenv("VIDC_GRP_MAXN")) g.max_n = std::min<uint64_t>((uint64_t)std::atoll(e), VIDC_GRP_MAX_LIST);
-    if (const char *e = std::getenv("VIDC_GRP_DEC_MAXN")) g.dec_max_n = std::min<uint64_t>((uint64_t)std::atoll(e), VIDC_GRP_MAX_LIST);
     return g;
 }
 
-// wavefronts of a bucket-row lane decoder launch (VIDC_LANE_GRID=<n>: at most n, the rest of the groups by grid stride)
-inline uint32_t lane_grid(uint32_t groups) {
-    static const uint32_t cap = [] { const char *e = std::getenv("VIDC_LANE_GRID"); return e ? (uint32_t)std::atoi(e) : 0u; }();
-    return cap && groups > cap ? cap : groups;
-}
+// wavefronts of a bucket-row lane decoder launch: one per group of lists
+inline uint32_t lane_grid(uint32_t groups) { return groups; }
 
 // test hook: VIDC_OLD_U=1 keeps the round-1 bitmap kernels (roc_u.h) instead of the hand-scheduled ones (roc_u2.h)
 // Lists per wavefront of a lane-per-list launch (VIDC_LPW=8|16|32, measurements only; default 64).  Every list of a
@@ -398,7 +390,7 @@ int finish_complete(vidc_ctx *ctx, vidc_roc *r, EncodeTail &e, const uint32_t *d
             const uint32_t grid = (uint32_t)std::min<uint64_t>((nlist + 63) / 64, (uint64_t)ctx->num_cu * 64);
             hipLaunchKernelGGL(k_roc_compact_groups, dim3(grid), dim3(64), 0, ctx->stream, d_arena, d_off, arena_stride,
                                r->d_word_off.p, r->d_words.p, (uint32_t)nlist);
-        } else if (r->total_words / nlist < 200 && !env_on("VIDC_COMPACT_BLOCKS")) {  // a wavefront per four lists (k_roc_compact_waves)
+        } else if (r->total_words / nlist < 200 ){  // a wavefront per four lists (k_roc_compact_waves)
             const uint32_t grid = (uint32_t)std::min<uint64_t>((nlist + 15) / 16, (uint64_t)ctx->num_cu * 8);
             hipLaunchKernelGGL(k_roc_compact_waves, dim3(grid), dim3(256), 0, ctx->stream, d_arena, d_off, arena_stride,
                                r->d_word_off.p, r->d_words.p, (uint32_t)nlist);
@@ -655,7 +647,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         use_lane64 = lane_wanted(lpol, n_mid64_lists, LANE_MIN_LISTS64);
         use_lane_tiny = lane_wanted(lpol, n_tiny_lists, LANE_MIN_TINY);
         // (the octaves of a call must overlap: without spare hardware queues they would run one after the other)
-        use_grp = n_grp_lists && n_grp_lists >= gpol.min_lists && (ctx->wide || gpol.min_lists == 0 || std::getenv("VIDC_GRP_MIN"));
+        use_grp = n_grp_lists && n_grp_lists >= gpol.min_lists && (ctx->wide || gpol.min_lists == 0);
         // classification prepass (one workgroup per list): max id -> precision, sortedness, domain
         const uint32_t *maxid = nullptr, *pflags = nullptr;
         if (any_big) {
@@ -673,7 +665,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
             // classifies by length alone and reads the maxima back when it needs them -- for the decode plan, while the
             // encode kernels run -- instead of waiting for the prepass here (0.1 ms per call at 65 536 lists).  A last id
             // outside the domain is then reported by the kernel that takes the list, like one in the middle of a list.
-            pre_deferred = light_prepass && max_n < u_min && !env_on("VIDC_NO_DEFER_PREPASS");
+            pre_deferred = light_prepass && max_n < u_min;
             if (pre_deferred) {
                 VIDC_HIP(hipEventRecord(ctx->ev_pre[0], ctx->stream));
                 hipLaunchKernelGGL(k_roc_prepass_last, dim3((uint32_t)((nlist + 255) / 256)), dim3(256), 0, ctx->stream, d_ids,
@@ -892,16 +884,15 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                     take(wl_c3);
                     if (wl_c3.empty()) take(wl_c2);
                     if (wl_c3.empty() && wl_c2.empty()) take(wl_c1);
-                } else if (n_top <= 65536 && !wl_c3.empty() && !env_on("VIDC_NO_R2_TOP")) {
+                } else if (n_top <= 65536 && !wl_c3.empty()) {
                     // More long chains than that (S2: 1754 lists of 32 769..65 536 ids): the `cap` longest ones -- one per SIMD --
                     // still decide the call (65 536 steps at 0.9 us on the general kernel under load against ~0.7 here) and, with
                     // the bitmap sized for 65 536 positions (8 KiB instead of 32), no longer take the LDS the other classes need;
                     // the rest of the class (<= ~45 000 ids on S2) finishes earlier on the general kernel anyway.
                     // Half as many again queue behind the resident ones in the same launch: each starts when one of the longest
                     // chains has finished, still ends before the launch's longest chain would have on the general kernel, and
-                    // leaves that kernel ~500 fewer chains (S2 encode 59-62 -> 55-57 ms; all 1754: 59).  VIDC_R2_TAKE=<n>: measurements.
+                    // leaves that kernel ~500 fewer chains (S2 encode 59-62 -> 55-57 ms; all 1754: 59).
                     take_cap = cap + cap / 2;
-                    if (const char *e = std::getenv("VIDC_R2_TAKE")) take_cap = (size_t)std::atoll(e);
                     take(wl_c3);
                 }
             }
@@ -1035,7 +1026,7 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 if (enc_prio & 4) b.lpw = 0x80000000u;
                 const U2Div *dt = (const U2Div *)ctx->d_u2tab;
                 // (the bitmap of a launch whose longest list -- the first of the work list -- has at most 65 536 positions: 8 KiB)
-                const bool small = r->offsets[wl_r2[0] + 1] - r->offsets[wl_r2[0]] <= 65536 && !env_on("VIDC_R2_BIG");
+                const bool small = r->offsets[wl_r2[0] + 1] - r->offsets[wl_r2[0]] <= 65536;
                 if (small && want_perm) hipLaunchKernelGGL((k_roc_encode_r2<true, 10>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(10), st_r2, b, dt);
                 else if (small) hipLaunchKernelGGL((k_roc_encode_r2<false, 10>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(10), st_r2, b, dt);
                 else if (want_perm) hipLaunchKernelGGL((k_roc_encode_r2<true, 12>), dim3(b.nwork), dim3(64), VIDC_R2_LDS_BYTES(12), st_r2, b, dt);
@@ -1064,10 +1055,8 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         {
             // Every launch is latency-bound (its duration is its longest list's chain) and light on issue slots, so the octaves
             // must overlap: they alternate between the first and the third auxiliary stream (the lane classes own the second).
-            // VIDC_GRP_STREAMS="1313": stream digit per segment (0 = main, 1..3 = auxiliary), measurements.
-            const char *gmap = std::getenv("VIDC_GRP_STREAMS");
-            // (wide: the last auxiliary stream is the plan upload's: ADVICE round 4)
-            if (!gmap || !*gmap) gmap = ctx->wide ? "456" : "13";
+            // stream digit per segment (0 = main, 1.. = auxiliary; wide: the last auxiliary stream is the plan upload's: ADVICE round 4)
+            const char *gmap = ctx->wide ? "456" : "13";
             const size_t gmap_n = std::strlen(gmap);
             size_t seg_no = 0;
             auto add_grp = [&](const std::vector<uint32_t> &w, size_t wbase, bool lev3) {
@@ -1442,13 +1431,13 @@ struct DecEnv {
     bool nb256, pair, quad;
     bool nb128, mid128;
     uint64_t pair_min = VIDC_LANE_REG_MAX;  // lists of more than this many ids (up to 512) decode on a PAIR of lanes
-    DecEnv() : nb256(env_on("VIDC_LANE_NB256")),  // measurements: 256 buckets for the 257..1024-id lists too
+    DecEnv() : nb256(false),  // (256 buckets for the 257..1024-id lists too: measured no better, HISTORY.md)
                pair(!env_on("VIDC_NO_LANE_PAIR") && !env_on("VIDC_NO_LANE_REG")),
                // (quads of lanes for 513..1024 ids: opt-in.  Measured slower than the bucket rows: 65 536 x 1024 ids decode in 5.6
                // instead of 4.1 ms -- 16 lists per 256-VGPR wavefront means two rounds of wavefronts per SIMD --, S2 84 instead of 78 ms)
                quad(env_on("VIDC_LANE_QUAD") && !env_on("VIDC_NO_LANE_PAIR") && !env_on("VIDC_NO_LANE_REG")) {
         nb128 = !env_on("VIDC_NO_LANE128");  // lists of 1025..2048 ids on 128 buckets (VIDC_NO_LANE128=1: 256, as before round 4)
-        mid128 = env_on("VIDC_LANE_MID128");  // measurements: the bucket-row lists of up to 1024 ids on 128 buckets
+        mid128 = false;  // (the bucket-row lists of up to 1024 ids on 128 buckets: measured no better, HISTORY.md)
         // VIDC_PAIR_MIN=n (64 .. 256): lists of n+1 .. 256 ids on lane pairs too -- 32 lists per wavefront, i.e. two wavefronts
         // per SIMD where a call of 65 536 lists has one (measurements: DESIGN section 12)
         if (const char *e = std::getenv("VIDC_PAIR_MIN")) pair_min = std::min<uint64_t>(VIDC_LANE_REG_MAX, std::max<uint64_t>(TINY_MAX, (uint64_t)std::atoll(e)));
@@ -1563,7 +1552,7 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             n_grp += n >= gpol.dec_min_n && n <= gpol.dec_max_n;
         }
         use_grp = allow_b2 && !f_general && !rows_flavour && n_grp && n_grp >= gpol.min_lists &&
-                  (wide || gpol.min_lists == 0 || std::getenv("VIDC_GRP_MIN"));
+                  (wide || gpol.min_lists == 0);
         allow_lane = lane_wanted(lpol, n_mid, LANE_MIN_LISTS);
         allow_lane64 = lane_wanted(lpol, n_mid64, LANE_MIN_LISTS64);
         p.tiny_lane = lane_wanted(lpol, rows_flavour ? lists.size() : n_tiny, LANE_MIN_TINY);
@@ -1614,20 +1603,16 @@ void plan_decode(const vidc_roc *r, const std::vector<uint32_t> &lists, bool row
             if (stop) break;
         }
         size_t b2_cap = B2_CAP;
-        if (const char *e = std::getenv("VIDC_B2_CAP")) {  // measurements: take up to this many chains whatever the rule says
-            b2_cap = (size_t)std::atoll(e);
-            n_long = 0;
-        }
         // More long chains than the cap (S2: 1754 lists of 32 769..65 536 ids and 2666 of 16 385..32 768): round 3 gave the `cap`
         // longest ones to this kernel and left the rest on the general decoder, whose step under load is ~1.1 us against ~0.65
         // here.  Measured in round 4 (S2 decode, kernels): 1024 chains 77-79 ms, all 1754 lists beyond 32 768 ids 74, these and
         // the 2666 lists of 16 385..32 768 ids 71-73; the lists of 8193..16 384 ids too (instead of the row-per-list kernel): 80-90.
         // So every list beyond 16 384 ids takes it, up to B2_TOP_CAP chains (20 per CU of an MI355X: 8 KiB of LDS each).
-        const bool top_only = n_top && n_long > b2_cap && !env_on("VIDC_NO_R2_TOP");
-        if (top_only && !std::getenv("VIDC_B2_CAP")) b2_cap = env_on("VIDC_B2_TOP_OLD") ? B2_CAP : B2_TOP_CAP;
+        const bool top_only = n_top && n_long > b2_cap;
+        if (top_only) b2_cap = B2_TOP_CAP;
         if (n_top && (n_long <= b2_cap || top_only))
             for (int c : order_) {  // longest first; a list that does not qualify stays where it is
-                if (top_only && c != DC_GHUGE && (c != DC_GMID || env_on("VIDC_B2_TOP_OLD"))) break;
+                if (top_only && c != DC_GHUGE && c != DC_GMID) break;
                 std::vector<uint32_t> keep;
                 for (uint32_t i : cls[c]) {
                     const uint32_t P = r->prec[lists[i]];
@@ -1832,7 +1817,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     // space -- 6 ms alone on S2's 217 M ids, 73 ms as the tail of the call when everything starts at once.
     // (measured on S2: 92-95 ms of decode against 86-87 with everything started at once -- the other classes take their ~85 ms
     // whether or not these lists are among them; opt-in for measurements)
-    const bool pair_first = p.count[DC_LANEP] && p.wl.size() > 4 * p.count[DC_LANEP] / 3 && env_on("VIDC_PAIR_FIRST");
+    const bool pair_first = p.count[DC_LANEP] && false;  // (the pair class first: measured no better, HISTORY.md)
     // Stream assignment: a class's kernel lasts about max(its longest chain, its share of the machine); classes are
     // taken longest first and each goes to the stream that frees up first (LPT over 3 streams).  A fixed
     // assignment left three general classes back to back on one stream on S2 (70 + 45 + 18 ms) while the
@@ -1963,20 +1948,13 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
                                    (const LaneDiv *)ctx->d_ltab);
                 break;
             case DC_B2: {
-                // VIDC_B2_PF=1 (measurement switch, off by default): the next step's candidate rows requested one step ahead
-                // (roc_u2.h, U2B_DEC_PF).  Measured on S2 (4420 chains): 45.7 against 47.5 ms with the class alone, 72.9 against
-                // 72.2 ms for the whole decode -- the candidates are right (100 % in the host-side replay), the demand load behind
-                // an in-flight prefetch of its line still takes a memory round trip.
-                const char *pfe = std::getenv("VIDC_B2_PF");
-                const bool pf = pfe && pfe[0] == '1';
-                // VIDC_CHAIN_PRIO=1: s_setprio by chain length (roc_u2.h)
-                if (env_on("VIDC_CHAIN_PRIO")) b.lpw = (uint32_t)p.max_n[DC_B2];
+                // (round 5 measured and dropped: the next step's candidate rows requested one step ahead -- 45.7 against 47.5 ms with
+                // the class alone, 72.9 against 72.2 ms for the whole S2 decode: HISTORY.md)
                 // VIDC_B2_MASK=1 / 0: the row load under exec = lanes below the bucket's member count (roc_u2.h, U2B_DEC_IDX_MC: a third
                 // of the sectors, a later load) / the whole row at once.  Default: calls of many chains, whose rows come from HBM.
                 const char *mke = std::getenv("VIDC_B2_MASK");
                 const bool mk = mke ? mke[0] == '1' : b.nwork >= B2_MASK_MIN_CHAINS;
-                if (pf) hipLaunchKernelGGL((k_roc_decode_b2<0, 1>), dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
-                else if (mk) hipLaunchKernelGGL((k_roc_decode_b2<0, 2>), dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
+                if (mk) hipLaunchKernelGGL((k_roc_decode_b2<0, 2>), dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
                 else hipLaunchKernelGGL(k_roc_decode_b2<0>, dim3(b.nwork), dim3(64), VIDC_B2_LDS_BYTES, st_, b, (const U2Div *)ctx->d_u2tab);
                 break;
             }
