@@ -55,63 +55,219 @@ struct vidc_wt {
 namespace {
 
 constexpr uint32_t BLK_WORDS = 8;  // 512-bit rank blocks
+__host__ __device__ inline uint64_t wt_nrank_base(uint32_t level) { return ((uint64_t)1 << level) - 1u + level; }  // sum of (2^j + 1), j < level
 
-// list_nos[id] = list number; validates the reference's asserts (ids ascending inside a list, < ntotal)
-__global__ void k_wt_scatter_syms(const uint64_t *ids, const uint64_t *offsets, uint32_t nlist, uint64_t ntotal,
-                                  uint32_t *syms, uint32_t *err) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ntotal; g += stride) {
-        const uint32_t l = find_list(offsets, nlist, g);
-        const uint64_t id = ids[g];
-        bool bad = id >= ntotal;
-        if (g > offsets[l]) bad |= ids[g - 1] >= id;  // assert(ids_data[i] > prev_id), :359
-        if (bad) { atomicOr(err, 1u); continue; }
-        if (atomicExch(&syms[id], l) != 0xffffffffu) atomicOr(err, 2u);  // id present twice
+// list_nos[id] = list number; validates the reference's asserts (ids ascending inside a list, < ntotal).
+// A workgroup takes 4096 consecutive positions: two searches of the whole offset table find the lists of its first and last position,
+// every position then searches only between them; the symbol goes out with a plain store and k_wt_check_syms looks for slots nobody
+// wrote (ntotal ids below ntotal without a gap are a permutation).  Round 5: a 16-step search per id and an atomic exchange per
+// id -- 0.69 ms for 16.8 M ids.
+__global__ void __launch_bounds__(256) k_wt_scatter_syms(const uint64_t *__restrict__ ids, const uint64_t *__restrict__ offsets, uint32_t nlist,
+                                                         uint64_t ntotal, uint32_t *__restrict__ syms, uint32_t *err) {
+    __shared__ uint32_t lo_s, hi_s;
+    bool bad = false;
+    for (uint64_t base = (uint64_t)blockIdx.x * 4096u; base < ntotal; base += (uint64_t)gridDim.x * 4096u) {
+        const uint64_t end = base + 4096u < ntotal ? base + 4096u : ntotal;
+        if (threadIdx.x == 0) lo_s = find_list(offsets, nlist, base);
+        if (threadIdx.x == 64) hi_s = find_list(offsets, nlist, end - 1);
+        __syncthreads();
+        const uint32_t llo = lo_s, lhi = hi_s;
+        for (uint64_t g = base + threadIdx.x; g < end; g += 256u) {
+            uint32_t lo = llo, hi = lhi + 1u;  // invariant: offsets[lo] <= g < offsets[hi]
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (offsets[mid] <= g) lo = mid; else hi = mid;
+            }
+            const uint64_t id = ids[g];
+            bool b = id >= ntotal;
+            if (g > offsets[lo]) b |= ids[g - 1] >= id;  // assert(ids_data[i] > prev_id), :359
+            if (!b) syms[id] = lo;
+            bad |= b;
+        }
+        __syncthreads();
     }
+    if (bad) atomicOr(err, 1u);
+}
+// a slot nobody wrote = an id that is missing = another one present twice
+__global__ void k_wt_check_syms(const uint32_t *syms, uint64_t ntotal, uint32_t *err) {
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ntotal; i += (uint64_t)gridDim.x * blockDim.x) bad |= syms[i] == 0xffffffffu;
+    if (bad) atomicOr(err, 2u);
 }
 
-// one thread per 64-bit word of the level bitvector
-__global__ void k_wt_bits(const uint32_t *syms_in_order, uint64_t ntotal, uint32_t shift, uint64_t *bits,
-                          uint64_t nwords) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += stride) {
-        uint64_t out = 0;
-        const uint64_t base = w * 64;
-        for (uint32_t b = 0; b < 64 && base + b < ntotal; b++)
-            out |= (uint64_t)((syms_in_order[base + b] >> shift) & 1u) << b;
-        bits[w] = out;
-    }
-}
-
-// rank directory: rank[j] = ones in blocks [0, j); single workgroup, chunked scan
-__global__ void __launch_bounds__(1024) k_wt_rankdir(const uint64_t *bits, uint64_t nwords, uint64_t nblocks,
-                                                     uint32_t *rank) {
-    __shared__ uint32_t sh[1024];
-    __shared__ uint32_t carry;
+// ---- one level of the tree in ONE pass over its symbols (round 6).  Before: four launches per level -- a thread per 64-bit word gathering 64
+// symbols 4 bytes at a time, a SINGLE workgroup scanning the whole rank directory, a node-rank kernel, and a partition whose every element
+// asked the fresh rank directory three times -- 0.4 ms per level on 16.8 M ids, 6.4 ms for the 16 levels of a 65 536-list tree.
+// Now a tile of 4096 consecutive positions per workgroup: the symbols come in coalesced, a wavefront's ballot IS the bit-vector word of its
+// 64 positions, the ones before the tile come from a chained scan over the tiles (decoupled look-back: a tile publishes its own count, then
+// its inclusive prefix; a successor adds counts until it meets a prefix; tiles take their numbers from a counter in start order, so every
+// wait ends), and an element's slot in the next level follows from its rank and from tables that need only the symbol start table C: the
+// ones before every node start (k_wt_node_ranks_from_C, all levels in one launch before the first pass).
+#define VIDC_WT_TILE 4096u
+struct WtScanState {  // per tile: bit 63 = inclusive prefix, bit 62 = the tile's own count; 0 = nothing yet.  [ntiles] | ticket
+    unsigned long long v;
+};
+// nrank[(level, p)] = ones before the start of node p of the level (p = 0 .. 2^level; entry 2^level = the level's ones): the elements of the
+// right children of the nodes before p, i.e. sums of symbol counts.  One workgroup per level.
+// dstab[2 (level, p) + b] (build only): what an element of node p with bit b adds its zero-rank / one-rank to for its slot in the next level:
+// slot = b ? (node start + zeros of the node - ones before the node) + ones before the element
+//          : (ones before the node) + zeros before the element        -- ONE table entry per element instead of four (two C, two nrank).
+__global__ void __launch_bounds__(1024) k_wt_node_ranks_from_C(const uint64_t *C, uint32_t nlist, uint32_t L, uint32_t *nrank, uint32_t *dstab) {
+    __shared__ uint64_t sh[1024];
+    __shared__ uint64_t carry;
+    const uint32_t level = blockIdx.x, shn = L - level;  // a node of this level spans 2^shn symbols
+    uint32_t *out = nrank + wt_nrank_base(level);
+    const uint64_t nodes = 1ull << level;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (uint64_t b0 = 0; b0 < nblocks; b0 += 1024) {
-        const uint64_t b = b0 + threadIdx.x;
-        uint32_t c = 0;
-        if (b < nblocks)
-            for (uint32_t j = 0; j < BLK_WORDS; j++) {
-                uint64_t w = b * BLK_WORDS + j;
-                if (w < nwords) c += (uint32_t)__builtin_popcountll(bits[w]);
-            }
-        sh[threadIdx.x] = c;
+    for (uint64_t p0 = 0; p0 < nodes; p0 += 1024) {
+        const uint64_t p = p0 + threadIdx.x;
+        uint64_t rs = 0;  // size of the node's right child: symbols [mid, hi)
+        if (p < nodes) {
+            uint64_t mid = ((2 * p + 1) << (shn - 1)), hi = ((2 * p + 2) << (shn - 1));
+            mid = mid > nlist ? nlist : mid;
+            hi = hi > nlist ? nlist : hi;
+            rs = C[hi] - C[mid];
+        }
+        sh[threadIdx.x] = rs;
         __syncthreads();
         for (uint32_t o = 1; o < 1024; o <<= 1) {
-            uint32_t v = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+            const uint64_t v = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
             __syncthreads();
             sh[threadIdx.x] += v;
             __syncthreads();
         }
-        if (b < nblocks) rank[b] = carry + sh[threadIdx.x] - c;
+        if (p < nodes) {
+            const uint64_t r_ns = carry + sh[threadIdx.x] - rs;
+            out[p] = (uint32_t)r_ns;
+            uint64_t lo = p << shn, hi = (p + 1) << shn;
+            lo = lo > nlist ? nlist : lo;
+            hi = hi > nlist ? nlist : hi;
+            const uint64_t ns = C[lo], zeros = (C[hi] - ns) - rs;
+            dstab[2 * (wt_nrank_base(level) + p)] = (uint32_t)r_ns;
+            dstab[2 * (wt_nrank_base(level) + p) + 1] = (uint32_t)(ns + zeros - r_ns);
+        }
         __syncthreads();
         if (threadIdx.x == 1023) carry += sh[1023];
         __syncthreads();
     }
-    if (threadIdx.x == 0) rank[nblocks] = carry;
+    if (threadIdx.x == 0) out[nodes] = (uint32_t)carry;
+}
+
+// syms_in: the level's order.  bits / rank: the level's bit vector (nwords words, zero padded) and its directory of ones before every
+// 512-bit block (nblocks + 1 entries).  syms_out (nullptr on the last level): the next level's order.  state: zeroed, ntiles + 1 entries.
+__global__ void __launch_bounds__(256) k_wt_level(const uint32_t *__restrict__ syms_in, uint32_t *__restrict__ syms_out, uint64_t ntotal,
+                                                  uint32_t nlist, uint32_t L, uint32_t level,
+                                                  const uint32_t *__restrict__ dstab_l, uint64_t *__restrict__ bits, uint64_t nwords,
+                                                  uint32_t *__restrict__ rank, uint64_t nblocks, unsigned long long *state, uint32_t ntiles) {
+    __shared__ uint64_t words[64];
+    __shared__ uint32_t wpre[65];  // ones before every word of the tile
+    __shared__ uint32_t tile_s;
+    __shared__ unsigned long long before_s;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    if (t == 0) tile_s = (uint32_t)atomicAdd(&state[ntiles], 1ull);
+    __syncthreads();
+    const uint32_t tile = tile_s;
+    const uint64_t base = (uint64_t)tile * VIDC_WT_TILE;
+    const uint32_t bsh = L - 1u - level;  // the symbol bit this level stores
+    uint32_t sym[16];
+    uint32_t inword[16];  // ones before the element inside its word
+    uint32_t mybits = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint64_t i = base + (uint64_t)j * 256u + t;
+        sym[j] = i < ntotal ? syms_in[i] : 0u;
+        const bool b = i < ntotal && ((sym[j] >> bsh) & 1u);
+        const uint64_t m = __ballot(b);
+        inword[j] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        mybits |= b ? 1u << j : 0u;
+        if (lane == 0) words[j * 4 + wave] = m;
+    }
+    __syncthreads();
+    // ones before every word of the tile (64 words: the first wavefront scans their popcounts)
+    if (wave == 0) {
+        const uint32_t c = (uint32_t)__builtin_popcountll(words[lane]);
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
+            if (lane >= (uint32_t)o) incl += v;
+        }
+        wpre[lane] = incl - c;
+        if (lane == 63) wpre[64] = incl;
+        // the bit-vector words of the tile: one coalesced store
+        const uint64_t w = (uint64_t)tile * 64u + lane;
+        if (w < nwords) bits[w] = words[lane];
+    }
+    __syncthreads();
+    const uint32_t tile_ones = wpre[64];
+    // chained scan: publish the tile's count, look back for the ones before the tile, publish the inclusive prefix.  The look-back reads 256
+    // predecessors per round trip (one per thread): the first tiles of a launch all start together and none of them holds a prefix
+    // yet, so the tile numbered k makes k / 256 rounds -- with 64 per round the 2048 resident tiles of a 16.8 M-id level finished their
+    // look-backs at 2 us x k / 64, and the level took 100 us for 30 us of traffic.
+    {
+        __shared__ unsigned long long w_all[4], w_upto[4];
+        __shared__ uint32_t w_stop[4], done_s;
+        if (t == 0) {
+            atomicExch(&state[tile], (1ull << 62) | tile_ones);
+            before_s = 0;
+            done_s = tile == 0u ? 1u : 0u;
+        }
+        __syncthreads();
+        int64_t k0 = (int64_t)tile - 1;
+        while (!done_s) {
+            const int64_t k = k0 - (int64_t)t;
+            unsigned long long x = 0;
+            if (k >= 0) {
+                do { x = __hip_atomic_load(&state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(x >> 62));
+            }
+            const uint64_t pm = __ballot(k >= 0 && (x >> 63));  // predecessors that hold an inclusive prefix
+            const uint32_t stop = pm ? (uint32_t)__builtin_ctzll(pm) : 64u;  // the nearest of this wavefront's
+            const unsigned long long v = k >= 0 ? (x & ((1ull << 62) - 1ull)) : 0ull;
+            unsigned long long all = v, upto = lane <= stop ? v : 0ull;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                all += __shfl_xor(all, o, 64);
+                upto += __shfl_xor(upto, o, 64);
+            }
+            if (lane == 0) { w_all[wave] = all; w_upto[wave] = upto; w_stop[wave] = stop; }
+            __syncthreads();
+            if (t == 0) {
+                unsigned long long acc = before_s;
+                bool found = false;
+                for (int w = 0; w < 4 && !found; w++) {  // wavefront w holds predecessors k0 - 64 w .. k0 - 64 w - 63
+                    found = w_stop[w] < 64u;
+                    acc += found ? w_upto[w] : w_all[w];
+                }
+                before_s = acc;
+                if (found || k0 - 256 < 0) done_s = 1u;
+            }
+            __syncthreads();
+            k0 -= 256;
+        }
+        if (t == 0) atomicExch(&state[tile], (1ull << 63) | (before_s + tile_ones));
+    }
+    const uint64_t before = before_s;
+    // rank directory: ones before every 512-bit block (8 words) of the tile; the entry behind the last block = the level's ones
+    if (t < 8u) {
+        const uint64_t blk = (uint64_t)tile * 8u + t;
+        if (blk < nblocks) rank[blk] = (uint32_t)(before + wpre[t * 8u]);
+    }
+    if (tile + 1u == ntiles && t == 0) rank[nblocks] = (uint32_t)(before + tile_ones);
+    if (!syms_out) return;
+    // the next level's order: zeros of a node keep their order in its left child, ones in its right child
+    const uint32_t shn = L - level;  // a node of this level spans 2^shn symbols
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint64_t i = base + (uint64_t)j * 256u + t;
+        if (i >= ntotal) continue;
+        const uint32_t s = sym[j];
+        const uint32_t p = shn >= 32u ? 0u : s >> shn;
+        const uint32_t bit = (mybits >> j) & 1u;
+        const uint64_t r_i = before + wpre[j * 4 + wave] + inword[j];  // ones before the element
+        const uint64_t dst = (uint64_t)dstab_l[2u * p + bit] + (bit ? r_i : i - r_i);
+        syms_out[dst] = s;
+    }
 }
 
 __device__ __forceinline__ uint64_t rank1(const uint64_t *bits, const uint32_t *rank, uint64_t i) {
@@ -402,19 +558,6 @@ __global__ void k_rrr_samples(const uint64_t *bits, const uint32_t *rank, uint64
     }
 }
 
-__host__ __device__ inline uint64_t wt_nrank_base(uint32_t level) { return ((uint64_t)1 << level) - 1u + level; }  // sum of (2^j + 1), j < level
-// ones before the start of every node of a level (and the level's total), from the level's plain bits
-__global__ void k_wt_node_ranks(const uint64_t *bits, const uint32_t *rank, const uint64_t *C, uint32_t nlist, uint32_t L, uint32_t level,
-                                uint32_t *nrank) {
-    const uint32_t sh = L - level;
-    const uint64_t nodes = (uint64_t)1 << level;
-    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p <= nodes; p += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t s_lo = sh >= 32 ? (p ? nlist : 0) : (p << sh);
-        if (s_lo > nlist) s_lo = nlist;
-        nrank[p] = (uint32_t)rank1(bits, rank, C[s_lo]);
-    }
-}
-
 // Bulk decode of a compressed tree: a level is turned back into plain bits ONCE -- a thread per 63-bit block: the sample before
 // it, the classes up to it, one unranking -- with the 512-bit rank directory the plain kernels use (a thread per entry, from
 // the samples and classes), and the level's partition then runs on the plain view.  The per-element form unranked a block for
@@ -437,25 +580,6 @@ __global__ void k_rrr_rankdir(BvRrr bv, uint64_t nblocks, uint32_t *rank) {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j <= nblocks; j += stride) {
         const uint64_t pos = j * 64 * BLK_WORDS;
         rank[j] = (uint32_t)bv.rank_1(pos < bv.nbits ? pos : bv.nbits);
-    }
-}
-
-// stable partition of every node of the level by its bit -> order of the next level
-__global__ void k_wt_partition(const uint32_t *syms_in, uint32_t *syms_out, const uint64_t *bits, const uint32_t *rank,
-                               const uint64_t *C, uint64_t ntotal, uint32_t nlist, uint32_t L, uint32_t level) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint32_t sh = L - level;  // symbols of one node share their top `level` bits
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ntotal; i += stride) {
-        const uint32_t s = syms_in[i];
-        const uint64_t p = sh >= 32 ? 0 : (uint64_t)(s >> sh);
-        uint64_t s_lo = sh >= 32 ? 0 : (p << sh), s_hi = sh >= 32 ? nlist : ((p + 1) << sh);
-        if (s_hi > nlist) s_hi = nlist;
-        const uint64_t ns = C[s_lo], ne = C[s_hi];
-        const uint64_t r_ns = rank1(bits, rank, ns), r_i = rank1(bits, rank, i), r_ne = rank1(bits, rank, ne);
-        const bool bit = (bits[i >> 6] >> (i & 63)) & 1ull;
-        const uint64_t zeros_in_node = (ne - ns) - (r_ne - r_ns);
-        const uint64_t dst = bit ? ns + zeros_in_node + (r_i - r_ns) : ns + ((i - ns) - (r_i - r_ns));
-        syms_out[dst] = s;
     }
 }
 
@@ -689,8 +813,9 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
     const uint32_t grid = (uint32_t)std::min<uint64_t>((nt + 255) / 256 + 1, (uint64_t)ctx->num_cu * 32);
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     if (nt) {
-        hipLaunchKernelGGL(k_wt_scatter_syms, dim3(grid), dim3(256), 0, ctx->stream, d_ids, w->d_C.p, (uint32_t)nlist, nt,
-                           s_a.as<uint32_t>(), s_err.as<uint32_t>());
+        hipLaunchKernelGGL(k_wt_scatter_syms, dim3((uint32_t)std::min<uint64_t>((nt + 4095) / 4096, (uint64_t)ctx->num_cu * 32)), dim3(256), 0,
+                           ctx->stream, d_ids, w->d_C.p, (uint32_t)nlist, nt, s_a.as<uint32_t>(), s_err.as<uint32_t>());
+        hipLaunchKernelGGL(k_wt_check_syms, dim3(grid), dim3(256), 0, ctx->stream, s_a.as<uint32_t>(), nt, s_err.as<uint32_t>());
         VIDC_HIP(hipGetLastError());
     }
     uint32_t err = 0;
@@ -703,21 +828,27 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
     }
     uint32_t *cur = s_a.as<uint32_t>(), *nxt = s_b.as<uint32_t>();
     std::vector<uint64_t> lvl_bits(L, 0);  // wt_type 1: bits of every level's offset stream
+    // scan states of every level's pass (zeroed once) and the ones before every node start of every level (from C alone)
+    Scratch s_state, s_dstab;
+    {
+        VIDC_TRY(s_dstab.get(ctx, 2 * (wt_nrank_base(L) + 1) * 4));
+        const size_t per_level = (size_t)((w->words_per_level + 63) / 64) + 1;
+        VIDC_TRY(s_state.get(ctx, (size_t)L * per_level * 8));
+        VIDC_HIP(hipMemsetAsync(s_state.p, 0, (size_t)L * per_level * 8, ctx->stream));
+        hipLaunchKernelGGL(k_wt_node_ranks_from_C, dim3(L), dim3(1024), 0, ctx->stream, w->d_C.p, (uint32_t)nlist, L, w->d_nrank.p,
+                           s_dstab.as<uint32_t>());
+        VIDC_HIP(hipGetLastError());
+    }
     for (uint32_t level = 0; level < L && nt; level++) {
         uint64_t *bits = rrr ? s_lvl_bits.as<uint64_t>() : w->d_bits.p + (uint64_t)level * w->words_per_level;
         uint32_t *rank = rrr ? s_lvl_rank.as<uint32_t>() : w->d_rank.p + (uint64_t)level * (w->blocks_per_level + 1);
         if (rrr) VIDC_HIP(hipMemsetAsync(bits, 0, w->words_per_level * 8, ctx->stream));
-        hipLaunchKernelGGL(k_wt_bits, dim3(grid), dim3(256), 0, ctx->stream, cur, nt, L - 1 - level, bits,
-                           (nt + 63) / 64);
-        hipLaunchKernelGGL(k_wt_rankdir, dim3(1), dim3(1024), 0, ctx->stream, bits, w->words_per_level,
-                           w->blocks_per_level, rank);
-        hipLaunchKernelGGL(k_wt_node_ranks, dim3((uint32_t)std::min<uint64_t>((((uint64_t)1 << level) + 256) / 256, 1024)), dim3(256), 0,
-                           ctx->stream, bits, rank, w->d_C.p, (uint32_t)nlist, L, level, w->d_nrank.p + wt_nrank_base(level));
-        if (level + 1 < L) {
-            hipLaunchKernelGGL(k_wt_partition, dim3(grid), dim3(256), 0, ctx->stream, cur, nxt, bits, rank, w->d_C.p, nt,
-                               (uint32_t)nlist, L, level);
-            std::swap(cur, nxt);
-        }
+        const uint32_t ntiles = (uint32_t)((w->words_per_level + 63) / 64);
+        unsigned long long *st = s_state.as<unsigned long long>() + (size_t)level * (ntiles + 1);
+        hipLaunchKernelGGL(k_wt_level, dim3(ntiles), dim3(256), 0, ctx->stream, cur, level + 1 < L ? nxt : (uint32_t *)nullptr, nt,
+                           (uint32_t)nlist, L, level, s_dstab.as<uint32_t>() + 2 * wt_nrank_base(level), bits, w->words_per_level, rank,
+                           w->blocks_per_level, st, ntiles);
+        if (level + 1 < L) std::swap(cur, nxt);
         VIDC_HIP(hipGetLastError());
         if (rrr) {  // code this level: classes -> offset widths -> bit positions (scan) -> offsets, samples
             const uint32_t bgrid = (uint32_t)std::min<uint64_t>((nblk + 255) / 256 + 1, (uint64_t)ctx->num_cu * 32);
