@@ -673,6 +673,48 @@ def main():
             del g, dec
         return res
 
+    def secondary_wavelet(steps=5):
+        """the wavelet-tree container (custom_invlists_impl.cpp:346-397) on 16 M ids in 65 536 lists, plain bit vectors
+        (wt_type 0) and RRR-coded ones (wt_type 1): build, decode_all, random selects (get_single_id).  `frac` = (16 + 2c) B/id over
+        the build + decode_all kernel time, c = the object's size per id; `ok` = every list decodes to its ids."""
+        from vector_db_id_compression_amd.codecs import WaveletTreeLists
+        w = synth.workload("uniform_16m", seed=1046 + rank)
+        ids = w["ids"]
+        if isinstance(ids, np.ndarray):
+            ids = torch.from_numpy(ids.view(np.int64)).cuda()
+        off, n = w["offsets"], w["ntotal"]
+        rng = np.random.default_rng(3)
+        ln = rng.integers(0, w["nlist"], 100000).astype(np.uint64)
+        sizes = (off[1:] - off[:-1])[ln.astype(np.int64)]
+        ln, sizes = ln[sizes > 0], sizes[sizes > 0]
+        of = (rng.random(ln.size) * sizes).astype(np.uint64)
+        res = {"workload": w["describe"]}
+        for wt_type in (0, 1):
+            tb = td = kb = kd = ts = 0.0
+            for it in range(steps + 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                wt = WaveletTreeLists.build(off, ids, wt_type=wt_type, ctx=ctx)
+                t1 = time.perf_counter()
+                k1 = ctx.last_kernel_ms()
+                dec = wt.decode_all()
+                t2 = time.perf_counter()
+                k2 = ctx.last_kernel_ms()
+                got = wt.select(ln, of)
+                t3 = time.perf_counter()
+                if it:
+                    tb += t1 - t0; td += t2 - t1; kb += k1; kd += k2; ts += t3 - t2
+            ok = bool(torch.equal(dec, ids)) and bool(np.array_equal(got, ids[torch.from_numpy((off[ln.astype(np.int64)] + of).astype(np.int64)).cuda()].cpu().numpy()))
+            c = wt.size_in_bytes / n
+            alg = (16.0 + 2.0 * c) * n
+            res[f"wt_type_{wt_type}"] = {"build_ms": 1e3 * tb / steps, "decode_all_ms": 1e3 * td / steps,
+                                          "kernel_ms": {"build": kb / steps, "decode_all": kd / steps},
+                                          "selects_per_s": ln.size * steps / ts, "bits_per_id": 8.0 * c,
+                                          "frac": alg / ((kb + kd) / steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "frac_wall": alg / ((tb + td) / steps) / 1e9 / HBM_PEAK_GBS, "ok": ok}
+            del wt, dec
+        return res
+
     comp_bytes = r.compressed_bytes
     c = comp_bytes / ntotal  # compressed bytes per id
     # SURVEY 8(d): enc 8 B read + c written, dec c read + 8 B written = 16 + 2c B/id: that is `roofline.achieved` / `frac`.
@@ -780,6 +822,7 @@ def main():
                 full["s1_packed_bits"] = secondary(wl, "packed")
                 full["c5"] = secondary("c5", "roc", floor=True)
                 full["graph_rows"] = secondary_graph()
+                full["wavelet_tree"] = secondary_wavelet()
                 res["extra"] = {k: compact(v) for k, v in full.items()}
                 g = full["graph_rows"]
                 res["extra"]["graph_rows"] = {"workload": g["workload"], **{
@@ -787,6 +830,11 @@ def main():
                         "k_ms": [g[n]["kernel_ms"]["encode"], g[n]["kernel_ms"]["decode"]], "host_ms": g[n]["host_ms_per_step"],
                         "bits": g[n]["bits_per_edge"], "frac": g[n]["frac"], "frac_wall": g[n]["frac_wall"],
                         "ok": g[n]["roundtrip_ok"]} for n in ("roc", "elias_fano", "compact")}}
+                wv = full["wavelet_tree"]
+                res["extra"]["wavelet_tree"] = {"workload": wv["workload"], **{
+                    k: {"build_ms": wv[k]["build_ms"], "decode_all_ms": wv[k]["decode_all_ms"],
+                        "k_ms": [wv[k]["kernel_ms"]["build"], wv[k]["kernel_ms"]["decode_all"]], "selects_per_s": wv[k]["selects_per_s"],
+                        "bits": wv[k]["bits_per_id"], "frac": wv[k]["frac"], "ok": wv[k]["ok"]} for k in ("wt_type_0", "wt_type_1")}}
                 res["extra_legend"] = EXTRA_LEGEND
             except Exception as e:
                 res["extra"] = {"error": str(e), **{k: compact(v) for k, v in full.items()}}

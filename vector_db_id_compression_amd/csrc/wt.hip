@@ -49,6 +49,8 @@ struct vidc_wt {
     // ones before the start of every node of every level -- level l has 2^l nodes, entry (l, p) at wt_nrank_base(l) + p,
     // entry (l, 2^l) = the level's total --, what every step of a select / decode walk asked the level's rank structure for.
     DevBuf<uint32_t> d_nrank;
+    // two entries per node of every level (k_wt_node_ranks_from_C): what the build and the bulk decode add an element's rank to
+    DevBuf<uint32_t> d_dstab;
     DevBuf<uint64_t> d_binom;           // C(n, k), n, k < 64 (row n at 64 n); behind it (d_binom + 4096) the 64 offset widths as bytes
 };
 
@@ -103,7 +105,8 @@ __global__ void k_wt_check_syms(const uint32_t *syms, uint64_t ntotal, uint32_t 
 // its inclusive prefix; a successor adds counts until it meets a prefix; tiles take their numbers from a counter in start order, so every
 // wait ends), and an element's slot in the next level follows from its rank and from tables that need only the symbol start table C: the
 // ones before every node start (k_wt_node_ranks_from_C, all levels in one launch before the first pass).
-#define VIDC_WT_TILE 4096u
+#define VIDC_WT_EPT 64u                    // elements per thread
+#define VIDC_WT_TILE (256u * VIDC_WT_EPT)  // 16 384 positions = 256 bit-vector words = 32 rank blocks per workgroup
 struct WtScanState {  // per tile: bit 63 = inclusive prefix, bit 62 = the tile's own count; 0 = nothing yet.  [ntiles] | ticket
     unsigned long long v;
 };
@@ -160,8 +163,9 @@ __global__ void __launch_bounds__(256) k_wt_level(const uint32_t *__restrict__ s
                                                   uint32_t nlist, uint32_t L, uint32_t level,
                                                   const uint32_t *__restrict__ dstab_l, uint64_t *__restrict__ bits, uint64_t nwords,
                                                   uint32_t *__restrict__ rank, uint64_t nblocks, unsigned long long *state, uint32_t ntiles) {
-    __shared__ uint64_t words[64];
-    __shared__ uint32_t wpre[65];  // ones before every word of the tile
+    __shared__ uint64_t words[VIDC_WT_EPT * 4];
+    __shared__ uint32_t wpre[VIDC_WT_EPT * 4 + 1];  // ones before every word of the tile
+    __shared__ uint32_t wsum[4];
     __shared__ uint32_t tile_s;
     __shared__ unsigned long long before_s;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -170,37 +174,49 @@ __global__ void __launch_bounds__(256) k_wt_level(const uint32_t *__restrict__ s
     const uint32_t tile = tile_s;
     const uint64_t base = (uint64_t)tile * VIDC_WT_TILE;
     const uint32_t bsh = L - 1u - level;  // the symbol bit this level stores
-    uint32_t sym[16];
-    uint32_t inword[16];  // ones before the element inside its word
-    uint32_t mybits = 0;
+    uint32_t sym[VIDC_WT_EPT];
+    uint32_t inword[VIDC_WT_EPT / 4];  // ones before the element inside its word (< 64): four per register
+    uint64_t mybits = 0;
+    // (every load of the tile is issued before the first ballot: a predicated load inside the ballot loop made the compiler wait for each
+    // of the 64 loads in turn -- 63 us of a level's 100 were this loop)
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < (int)VIDC_WT_EPT; j++) {
         const uint64_t i = base + (uint64_t)j * 256u + t;
-        sym[j] = i < ntotal ? syms_in[i] : 0u;
+        sym[j] = syms_in[i < ntotal ? i : ntotal - 1u];
+    }
+#pragma unroll
+    for (int j = 0; j < (int)VIDC_WT_EPT; j++) {
+        const uint64_t i = base + (uint64_t)j * 256u + t;
         const bool b = i < ntotal && ((sym[j] >> bsh) & 1u);
         const uint64_t m = __ballot(b);
-        inword[j] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        mybits |= b ? 1u << j : 0u;
+        const uint32_t iw = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if ((j & 3) == 0) inword[j >> 2] = iw; else inword[j >> 2] |= iw << (8 * (j & 3));
+        mybits |= b ? 1ull << j : 0ull;
         if (lane == 0) words[j * 4 + wave] = m;
     }
     __syncthreads();
-    // ones before every word of the tile (64 words: the first wavefront scans their popcounts)
-    if (wave == 0) {
-        const uint32_t c = (uint32_t)__builtin_popcountll(words[lane]);
+    // ones before every word of the tile (256 words: a thread each, scan inside the wavefronts, then across the four)
+    {
+        const uint32_t c = (uint32_t)__builtin_popcountll(words[t]);
         uint32_t incl = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64);
             if (lane >= (uint32_t)o) incl += v;
         }
-        wpre[lane] = incl - c;
-        if (lane == 63) wpre[64] = incl;
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t wbefore = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) wbefore += k < wave ? wsum[k] : 0u;
+        wpre[t] = wbefore + incl - c;
+        if (t == 255) wpre[256] = wbefore + incl;
         // the bit-vector words of the tile: one coalesced store
-        const uint64_t w = (uint64_t)tile * 64u + lane;
-        if (w < nwords) bits[w] = words[lane];
+        const uint64_t w = (uint64_t)tile * (VIDC_WT_EPT * 4) + t;
+        if (w < nwords) bits[w] = words[t];
     }
     __syncthreads();
-    const uint32_t tile_ones = wpre[64];
+    const uint32_t tile_ones = wpre[VIDC_WT_EPT * 4];
     // chained scan: publish the tile's count, look back for the ones before the tile, publish the inclusive prefix.  The look-back reads 256
     // predecessors per round trip (one per thread): the first tiles of a launch all start together and none of them holds a prefix
     // yet, so the tile numbered k makes k / 256 rounds -- with 64 per round the 2048 resident tiles of a 16.8 M-id level finished their
@@ -249,8 +265,8 @@ __global__ void __launch_bounds__(256) k_wt_level(const uint32_t *__restrict__ s
     }
     const uint64_t before = before_s;
     // rank directory: ones before every 512-bit block (8 words) of the tile; the entry behind the last block = the level's ones
-    if (t < 8u) {
-        const uint64_t blk = (uint64_t)tile * 8u + t;
+    if (t < VIDC_WT_EPT / 2) {
+        const uint64_t blk = (uint64_t)tile * (VIDC_WT_EPT / 2) + t;
         if (blk < nblocks) rank[blk] = (uint32_t)(before + wpre[t * 8u]);
     }
     if (tile + 1u == ntiles && t == 0) rank[nblocks] = (uint32_t)(before + tile_ones);
@@ -258,15 +274,23 @@ __global__ void __launch_bounds__(256) k_wt_level(const uint32_t *__restrict__ s
     // the next level's order: zeros of a node keep their order in its left child, ones in its right child
     const uint32_t shn = L - level;  // a node of this level spans 2^shn symbols
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const uint64_t i = base + (uint64_t)j * 256u + t;
-        if (i >= ntotal) continue;
-        const uint32_t s = sym[j];
-        const uint32_t p = shn >= 32u ? 0u : s >> shn;
-        const uint32_t bit = (mybits >> j) & 1u;
-        const uint64_t r_i = before + wpre[j * 4 + wave] + inword[j];  // ones before the element
-        const uint64_t dst = (uint64_t)dstab_l[2u * p + bit] + (bit ? r_i : i - r_i);
-        syms_out[dst] = s;
+    for (int j0 = 0; j0 < (int)VIDC_WT_EPT; j0 += 16) {
+        uint32_t tb[16];  // sixteen table entries in flight, then sixteen stores
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) {
+            const int j = j0 + jj;
+            const uint32_t p = shn >= 32u ? 0u : sym[j] >> shn;
+            tb[jj] = dstab_l[2u * p + ((uint32_t)(mybits >> j) & 1u)];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) {
+            const int j = j0 + jj;
+            const uint64_t i = base + (uint64_t)j * 256u + t;
+            const uint32_t bit = (uint32_t)(mybits >> j) & 1u;
+            const uint64_t r_i = before + wpre[j * 4 + wave] + ((inword[j >> 2] >> (8 * (j & 3))) & 0xffu);  // ones before the element
+            const uint64_t dst = (uint64_t)tb[jj] + (bit ? r_i : i - r_i);
+            if (i < ntotal) syms_out[dst] = sym[j];
+        }
     }
 }
 
@@ -720,6 +744,65 @@ __global__ void k_wt_decode_level(const WtItem *in, WtItem *out, uint64_t *out_i
     }
 }
 
+// The same pass over tiles of 8192 consecutive positions (round 6): the tile's 128 bit-vector words and 16 rank-directory entries give
+// every position its bit and rank (v_mbcnt inside the word) -- the per-element form above asked the rank directory and up to eight words
+// per element --, the destination is one table entry (d_dstab) plus that rank, and all of a thread's 32 items are requested before any
+// of them is used.
+#define VIDC_WTD_EPT 32u
+template <bool LAST>
+__global__ void __launch_bounds__(256) k_wt_decode_tile(const WtItem *__restrict__ in, WtItem *__restrict__ out, uint64_t *__restrict__ out_ids,
+                                                        const uint64_t *__restrict__ bits, uint64_t nwords, const uint32_t *__restrict__ rank,
+                                                        const uint32_t *__restrict__ dstab_l, uint64_t ntotal) {
+    __shared__ uint64_t words[VIDC_WTD_EPT * 4];
+    __shared__ uint32_t wpre[VIDC_WTD_EPT * 4];  // ones before every word of the tile, from the start of the level
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * (256u * VIDC_WTD_EPT);
+    WtItem it[VIDC_WTD_EPT];
+#pragma unroll
+    for (int j = 0; j < (int)VIDC_WTD_EPT; j++) {
+        const uint64_t i = base + (uint64_t)j * 256u + t;
+        if (in) it[j] = in[i < ntotal ? i : ntotal - 1u];
+        else it[j] = WtItem{(uint32_t)i, 0u};  // level 0: position i holds id i, prefix 0
+    }
+    if (t < VIDC_WTD_EPT * 4) {
+        const uint64_t w = (uint64_t)blockIdx.x * (VIDC_WTD_EPT * 4) + t;
+        words[t] = w < nwords ? bits[w] : 0ull;
+    }
+    __syncthreads();
+    if (t < VIDC_WTD_EPT * 4) {
+        const uint64_t blk = (uint64_t)blockIdx.x * (VIDC_WTD_EPT / 2) + (t >> 3);
+        uint32_t c = blk * 8u < nwords ? rank[blk] : 0u;
+        for (uint32_t k = t & ~7u; k < t; k++) c += (uint32_t)__builtin_popcountll(words[k]);
+        wpre[t] = c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j0 = 0; j0 < (int)VIDC_WTD_EPT; j0 += 16) {
+        uint32_t tb[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) {
+            const int j = j0 + jj;
+            const uint64_t wd = words[j * 4 + wave];
+            const uint32_t bit = (uint32_t)(wd >> lane) & 1u;
+            tb[jj] = dstab_l[2u * it[j].pref + bit];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) {
+            const int j = j0 + jj;
+            const uint64_t i = base + (uint64_t)j * 256u + t;
+            const uint64_t wd = words[j * 4 + wave];
+            const uint32_t bit = (uint32_t)(wd >> lane) & 1u;
+            const uint64_t r_i = (uint64_t)wpre[j * 4 + wave] +
+                                 __builtin_amdgcn_mbcnt_hi((uint32_t)(wd >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wd, 0u));
+            const uint64_t dst = (uint64_t)tb[jj] + (bit ? r_i : i - r_i);
+            if (i < ntotal) {
+                if (LAST) out_ids[dst] = it[j].id;
+                else out[dst] = WtItem{it[j].id, (it[j].pref << 1) | bit};
+            }
+        }
+    }
+}
+
 WtPlainView plain_view(const vidc_wt *w) { return WtPlainView{w->d_bits.p, w->d_rank.p, w->words_per_level, w->blocks_per_level}; }
 RrrTab rrr_tab() {
     RrrTab t;
@@ -829,24 +912,24 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
     uint32_t *cur = s_a.as<uint32_t>(), *nxt = s_b.as<uint32_t>();
     std::vector<uint64_t> lvl_bits(L, 0);  // wt_type 1: bits of every level's offset stream
     // scan states of every level's pass (zeroed once) and the ones before every node start of every level (from C alone)
-    Scratch s_state, s_dstab;
+    Scratch s_state;
     {
-        VIDC_TRY(s_dstab.get(ctx, 2 * (wt_nrank_base(L) + 1) * 4));
-        const size_t per_level = (size_t)((w->words_per_level + 63) / 64) + 1;
+        VIDC_TRY(w->d_dstab.alloc(2 * (wt_nrank_base(L) + 1)));
+        const size_t per_level = (size_t)((w->words_per_level + VIDC_WT_EPT * 4 - 1) / (VIDC_WT_EPT * 4)) + 1;
         VIDC_TRY(s_state.get(ctx, (size_t)L * per_level * 8));
         VIDC_HIP(hipMemsetAsync(s_state.p, 0, (size_t)L * per_level * 8, ctx->stream));
         hipLaunchKernelGGL(k_wt_node_ranks_from_C, dim3(L), dim3(1024), 0, ctx->stream, w->d_C.p, (uint32_t)nlist, L, w->d_nrank.p,
-                           s_dstab.as<uint32_t>());
+                           w->d_dstab.p);
         VIDC_HIP(hipGetLastError());
     }
     for (uint32_t level = 0; level < L && nt; level++) {
         uint64_t *bits = rrr ? s_lvl_bits.as<uint64_t>() : w->d_bits.p + (uint64_t)level * w->words_per_level;
         uint32_t *rank = rrr ? s_lvl_rank.as<uint32_t>() : w->d_rank.p + (uint64_t)level * (w->blocks_per_level + 1);
         if (rrr) VIDC_HIP(hipMemsetAsync(bits, 0, w->words_per_level * 8, ctx->stream));
-        const uint32_t ntiles = (uint32_t)((w->words_per_level + 63) / 64);
+        const uint32_t ntiles = (uint32_t)((w->words_per_level + VIDC_WT_EPT * 4 - 1) / (VIDC_WT_EPT * 4));
         unsigned long long *st = s_state.as<unsigned long long>() + (size_t)level * (ntiles + 1);
         hipLaunchKernelGGL(k_wt_level, dim3(ntiles), dim3(256), 0, ctx->stream, cur, level + 1 < L ? nxt : (uint32_t *)nullptr, nt,
-                           (uint32_t)nlist, L, level, s_dstab.as<uint32_t>() + 2 * wt_nrank_base(level), bits, w->words_per_level, rank,
+                           (uint32_t)nlist, L, level, w->d_dstab.p + 2 * wt_nrank_base(level), bits, w->words_per_level, rank,
                            w->blocks_per_level, st, ntiles);
         if (level + 1 < L) std::swap(cur, nxt);
         VIDC_HIP(hipGetLastError());
@@ -1007,10 +1090,13 @@ int vidc_wt_decode_all(vidc_ctx *ctx, const vidc_wt *w, uint64_t *d_out) {
                                    0, ctx->stream, rv, w->blocks_per_level, s_rank.as<uint32_t>());
                 bv = BvPlain{s_bits.as<uint64_t>(), s_rank.as<uint32_t>(), w->blocks_per_level, w->words_per_level};
             }
-            if (last) hipLaunchKernelGGL((k_wt_decode_level<true, BvPlain>), dim3(grid), dim3(256), 0, ctx->stream, in, out, oid, bv,
-                                         w->d_C.p, nr, w->ntotal, (uint32_t)w->nlist, w->L, level);
-            else hipLaunchKernelGGL((k_wt_decode_level<false, BvPlain>), dim3(grid), dim3(256), 0, ctx->stream, in, out, oid, bv,
-                                    w->d_C.p, nr, w->ntotal, (uint32_t)w->nlist, w->L, level);
+            const dim3 tgrid((uint32_t)((w->ntotal + 256u * VIDC_WTD_EPT - 1) / (256u * VIDC_WTD_EPT)));
+            const uint32_t *dt = w->d_dstab.p + 2 * wt_nrank_base(level);
+            if (last) hipLaunchKernelGGL(k_wt_decode_tile<true>, tgrid, dim3(256), 0, ctx->stream, in, out, oid, bv.bits, w->words_per_level, bv.rank,
+                                         dt, w->ntotal);
+            else hipLaunchKernelGGL(k_wt_decode_tile<false>, tgrid, dim3(256), 0, ctx->stream, in, out, oid, bv.bits, w->words_per_level, bv.rank,
+                                    dt, w->ntotal);
+            (void)nr;
             in = out;
         }
         VIDC_HIP(hipGetLastError());
