@@ -785,7 +785,7 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
     if (V2) bad |= hi_or != 0u;
     if (ballot(bad) || (V2 && xlast > u)) {
         if (lane == 0) *(volatile uint32_t *)unsorted = 1u;  // (pinned host memory: every writer stores the same value)
-        __syncthreads();
+        wave_lds_sync();
         return;  // the object is rebuilt by the general path
     }
     const uint32_t wl = last >> 6;
@@ -801,7 +801,7 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
         if (xn <= u && (pn >> 6) == wl) pnext = pn;
     }
     if (b) {  // low stream: the l low bits of every id into the LDS image, 32-bit halves
-        __syncthreads();
+        wave_lds_sync();
         const uint32_t keep = b >= 32u ? 0xffffffffu : ((1u << b) - 1u);
         const uint32_t lane_b = __umul24(lane, b);  // (V2)
 #pragma unroll
@@ -814,7 +814,7 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
                 if (sh + b > 32u) atomicOr(&img32[(p >> 5) + 1u], x >> (32u - sh));
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         const uint32_t nlw = (nc * b + 63u) >> 6;
         uint64_t *ldst = low + rc.low_word + (((uint64_t)start * b) >> 6);
         const uint64_t *img = (const uint64_t *)img32;
@@ -823,7 +823,7 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
     const uint64_t *win = (const uint64_t *)win32;
     for (uint32_t wbase = wlo; wbase <= whi; wbase += EF_WIN_WORDS) {
         win32[lane] = 0; win32[lane + 64] = 0; win32[lane + 128] = 0; win32[lane + 192] = 0;
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (uint32_t r = 0; r < R; r++) {
             if (FULL || r < nr) {
@@ -836,14 +836,14 @@ __device__ __forceinline__ void ef_lowhigh32_chunk(const EfChunkRec &rc, const u
             const uint32_t rel = pnext - wbase * 64u;
             atomicOr(&win32[rel >> 5], 1u << (rel & 31u));
         }
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (uint32_t t = 0; t < 2; t++) {
             const uint32_t k = lane + 64 * t;
             const uint32_t w = wbase + k;
             if (w <= whi) dst[w] = win[k];  // (empty words too: nothing zeroes the stream beforehand)
         }
-        __syncthreads();
+        wave_lds_sync();
     }
     ef_chunk_directory<uint32_t>(rc, src + start, nc, pos, start ? (before >> b) + (start - 1u) : 0u, last,
                                  low, hrank, batches, drecs);
@@ -864,6 +864,9 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *__restrict_
     __shared__ uint32_t win32[EF_WIN_WORDS * 2];
     __shared__ uint32_t img32[(64 * RMAX + 8) * 2];  // low words of the chunk, as 32-bit halves
     if (*abort) return;  // (k_ef_offsets: the streams allocated ahead of it are too small)
+    // (Round 6, measured and dropped: the record and the ids of the wavefront's NEXT chunk requested before the current one is worked
+    // on -- 16 more registers, S2 encode 3.15-3.22 ms against 3.10: with 18 wavefronts per CU the loads of other wavefronts already
+    // fill the time a wavefront waits, and the kernel sits at its issue limit.  HISTORY.md.)
     for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const EfChunkRec rc = recs[c];
         const uint32_t nc = rc.n - rc.start < EF_CHUNK ? rc.n - rc.start : EF_CHUNK;
@@ -877,7 +880,7 @@ __global__ void __launch_bounds__(64) k_ef_lowhigh32(const uint64_t *__restrict_
             ef_lowhigh32_chunk<4, false, V2>(rc, sorted_ids, low, high, hrank, batches, unsorted, drecs, win32, img32);
         else
             ef_lowhigh32_chunk<1, false, V2>(rc, sorted_ids, low, high, hrank, batches, unsorted, drecs, win32, img32);
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 
@@ -1140,7 +1143,7 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
                 h1 &= h1 - 1u;
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         const LW pbase = (LW)bt * EF_BATCH_BITS;
         for (uint32_t r0 = 0; r0 < tot; r0 += 64 * R) {
             if (r0) {
@@ -1176,7 +1179,7 @@ __global__ void __launch_bounds__(64) k_ef_decode_rec(const uint64_t *low, const
                 }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 
@@ -1240,7 +1243,7 @@ __global__ void __launch_bounds__(64) k_ef_rows_encode_tile(const int32_t *__res
             const uint32_t nz = (64u * SDW + 3u) / 4u;
             for (uint32_t f = lane; f < nz; f += 64u) z[f] = make_uint4(0u, 0u, 0u, 0u);
         }
-        __syncthreads();
+        wave_lds_sync();
         {
             // Branch-free: an element that is not one (e >= n, or a row that is reported as bad) ORs zeros, which is harmless anywhere
             // inside the LDS image (bit e * l <= 63 * 30: dword 60 of the lane's record at most, and the host adds 64 dwords behind the records).
@@ -1264,7 +1267,7 @@ __global__ void __launch_bounds__(64) k_ef_rows_encode_tile(const int32_t *__res
                 bp += l;
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         {
             uint64_t *dst = arena + row0 * S;
             const uint32_t total = nrows * S;  // S <= 32 words per row: at most 32 per lane
@@ -1363,7 +1366,7 @@ __global__ void __launch_bounds__(64) k_ef_rows_decode_tile(const uint64_t *__re
                 mt = lane < nr ? meta[nt * 64u + lane] : make_uint2(0u, 0u);
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         {
             uint32_t hd[2 * HWC];
 #pragma unroll
@@ -1391,7 +1394,7 @@ __global__ void __launch_bounds__(64) k_ef_rows_decode_tile(const uint64_t *__re
                 off += 32u;
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         if (QUAD) {  // K % 4 == 0, out 16-byte aligned
             const uint32_t g = lane >> 4, q4 = (lane & 15u) * 4u;
             const uint32_t qs = q4 < (uint32_t)KP ? q4 : 0u;
@@ -1431,7 +1434,7 @@ __global__ void __launch_bounds__(64) k_ef_rows_decode_tile(const uint64_t *__re
             }
         }
         if (counts && have) counts[w0 + lane] = n;
-        __syncthreads();  // (the next tile's records go to the same LDS)
+        wave_lds_sync();  // (the next tile's records go to the same LDS)
     }
 }
 

@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(64) k_packed_encode(const uint64_t *ids, const
             v[r] = i < nc ? src[i] : 0ull;
         }
         for (uint32_t w = lane; w < nw + 1u; w += 64) img[w] = 0;
-        __syncthreads();
+        wave_lds_sync();
         bool bad = false;
 #pragma unroll
         for (uint32_t r = 0; r < R; r++) {
@@ -77,10 +77,10 @@ __global__ void __launch_bounds__(64) k_packed_encode(const uint64_t *ids, const
             }
         }
         if (__ballot(bad) && lane == 0) *(volatile uint32_t *)err = 1u;  // (every writer stores the same value: device or pinned host memory)
-        __syncthreads();
+        wave_lds_sync();
         uint64_t *dst = words + word_off[ch.list] + w0;
         for (uint32_t w = lane; w < nw; w += 64) dst[w] = img[w];
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 
@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(64) k_compact_rows_encode_tile(const int32_t *
         }
         if (fill) rec[wofs] = lo;
         anybad = anybad || (bad && lane < nrows);
-        __syncthreads();
+        wave_lds_sync();
         uint32_t *dst = out + row0 * SD;
         if ((SD & 3u) == 0u) {  // 16-byte pieces never straddle two rows; SD <= 64: at most 16 pieces per lane
             const uint32_t CPR = SD >> 2, total = nrows * CPR;
@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(64) k_compact_rows_decode_tile(const uint32_t 
                 tile_advance(c, SD, step_rows, step_w);
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         if (QUAD) {
             const uint32_t g = lane >> 4, q4 = (lane & 15u) * 4u, gsh = g * 16u;
             uint32_t dw[4], sh[4];
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(64) k_compact_rows_decode_tile(const uint32_t 
             }
             if (counts && lane < nrows) counts[w0 + lane] = my_n;
         }
-        __syncthreads();  // (the next tile's records go to the same LDS)
+        wave_lds_sync();  // (the next tile's records go to the same LDS)
     }
 }
 

@@ -68,7 +68,7 @@ __device__ __forceinline__ void tile_commit_rows(const int32_t *__restrict__ row
         constexpr int NC = KP / 4, HALVES = KP / 32, LDH = 33;
 #pragma unroll
         for (int h = 0; h < HALVES; h++) {
-            if (h) __syncthreads();
+            if (h) wave_lds_sync();
 #pragma unroll
             for (int i = 0; i < NC; i++) {
                 const uint32_t c = (uint32_t)i * 64u + lane;  // piece c: row c / NC, columns 4 (c % NC) ..
@@ -78,11 +78,11 @@ __device__ __forceinline__ void tile_commit_rows(const int32_t *__restrict__ row
                     d[0] = (uint32_t)t.v[i].x; d[1] = (uint32_t)t.v[i].y; d[2] = (uint32_t)t.v[i].z; d[3] = (uint32_t)t.v[i].w;
                 }
             }
-            __syncthreads();
+            wave_lds_sync();
 #pragma unroll
             for (int e = 0; e < 32; e++) r[h * 32 + e] = lds[lane * LDH + (uint32_t)e];
         }
-        __syncthreads();
+        wave_lds_sync();
         return;
     } else {
         const int32_t *src = rows + row0 * K;
@@ -96,14 +96,14 @@ __device__ __forceinline__ void tile_commit_rows(const int32_t *__restrict__ row
             }
         }
     }
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int e = 0; e < KP; e++) r[e] = lds[lane * LD + (uint32_t)e];
     if (!FULL) {
 #pragma unroll
         for (int e = 0; e < KP; e++) r[e] = (uint32_t)e < K ? r[e] : 0xffffffffu;
     }
-    __syncthreads();
+    wave_lds_sync();
 }
 
 // edges of a row = entries before the first -1 (altid_impl.cpp:61-68,110-117); entries from there on become 0xffffffff.

@@ -82,6 +82,11 @@ __device__ __forceinline__ void lane_sort(uint32_t (&r)[KP]) {
 
 // single-wave workgroup: orders LDS / global accesses between lanes of the wave
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// single-wave workgroup, LDS only: the wavefront's LDS operations execute in order, so lanes see each other's LDS writes without a
+// barrier; what has to be stopped is the COMPILER moving LDS accesses across this point.  __syncthreads() also waits for every
+// outstanding global load and store of the wavefront (s_waitcnt vmcnt(0)): a block requested for the NEXT tile would be waited for at the
+// first barrier of the current one.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
