@@ -20,4 +20,6 @@ for c in ef packed; do for w in s2 uniform_16m s1; do cp $S/${c}_${w}_kernel_sta
 [ -f $S/search_paths.txt ] && cp $S/search_paths.txt $D/${R}_search_paths.txt
 [ -f $S/trace_u16.txt ] && grep -v amdgpu.ids $S/trace_u16.txt > $D/${R}_trace_uniform16m_host.txt
 [ -f $S/hw_gpr_idx_probe.txt ] && cp $S/hw_gpr_idx_probe.txt $D/${R}_hw_gpr_idx_probe.txt
+for f in bench_graph_kernel_stats.csv pmc_traffic_graph_ef.json pmc_traffic_graph_compact.json pmc_traffic_graph_roc.json pmc_graph.json pmc_wt.json pmc_ef_s2.json; do [ -f $S/$f ] && cp $S/$f $D/${R}_$f; done
+for f in pmc_issue_s1_roc.json pmc_issue_s2_roc.json; do [ -f $S/$f ] && cp $S/$f $D/$f && cp $S/$f $D/${R}_$f; done
 ls $D | grep "^${R}_" | wc -l

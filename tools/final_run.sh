@@ -16,8 +16,8 @@ VIDC_NO_LANE_PAIR=1 VIDC_FORCE_LANE=1 timeout 900 python -m pytest tests/test_gp
 VIDC_LANE_LOOP=1 VIDC_NO_LANE128=1 VIDC_FORCE_LANE=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_lane_loop.txt
 VIDC_NO_AVX2=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_packed_ef.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_no_avx2.txt
 VIDC_NO_LENGTH_CLASSES=1 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_containers.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_no_length_classes.txt
-# round 5: the measurement switches of DESIGN section 12 must not change a bit (look-ahead rows, chain priority, 65..256-id lists on lane pairs)
-VIDC_B2_PF=1 VIDC_CHAIN_PRIO=1 VIDC_PAIR_MIN=64 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_r5_switches.txt
+# round 5: 65..256-id lists on lane pairs must not change a bit (the look-ahead / chain-priority switches of that round are gone: HISTORY.md)
+VIDC_PAIR_MIN=64 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_r5_switches.txt
 # round 5, last session: the forms the new defaults replaced (whole-row b2 loads, lane-decoder rows on 16-byte boundaries, no class priority) and
 # the sized row load forced for every b2 launch must not change a bit either
 VIDC_B2_MASK=0 VIDC_LANE_ALIGN=4 VIDC_ENC_PRIO=0 timeout 900 python -m pytest tests/test_gpu_roc.py tests/test_gpu_full_configs.py -m gpu -q 2>&1 | tail -3 > gpurun_out/$R/pytest_r5_old_defaults.txt
@@ -40,7 +40,11 @@ done
 for c in packed ef; do for w in s1 uniform_16m uniform_64m_1k; do
   timeout 600 python bench.py --workload $w --codec $c --no-cpu-baseline --no-extra --steps 10 --warmup 3 2>/dev/null >> gpurun_out/$R/bench_other.jsonl
 done; done
-timeout 600 python tools/bench_graph.py 1000000 2>/dev/null | tail -1 > gpurun_out/$R/bench_graph.json
+# round 6: BASELINE configs[3] evidence (line, rocprofv3 kernel stats, FETCH_SIZE / WRITE_SIZE per kernel) + issue / wait counters per kernel
+bash tools/prof_graph.sh $R > gpurun_out/$R/prof_graph.log 2>&1
+bash tools/pmc_cmd.sh $R graph python tools/bench_graph.py 1000000 64 2 > gpurun_out/$R/pmc_graph.log 2>&1
+bash tools/pmc_cmd.sh $R wt python tools/bench_wt.py uniform_16m > gpurun_out/$R/pmc_wt.log 2>&1
+bash tools/pmc_cmd.sh $R ef_s2 python bench.py --workload s2 --codec ef --steps 1 --warmup 1 --no-cpu-baseline --no-extra --no-verify > gpurun_out/$R/pmc_ef_s2.log 2>&1
 export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/$R/prof_s1 -o s1 -- python bench.py --no-cpu-baseline --no-extra > /dev/null 2> gpurun_out/$R/prof.err
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/$R/prof_u16 -o u16 -- python bench.py --workload uniform_16m --no-cpu-baseline --no-extra --steps 5 --warmup 2 > /dev/null 2>> gpurun_out/$R/prof.err
