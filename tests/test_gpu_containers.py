@@ -370,6 +370,69 @@ def test_graph_rows_edge_shapes(K, monkeypatch, oracle):
                 assert np.array_equal(got[i, :d].astype(np.uint64), ref), (cls.__name__, i)
 
 
+@pytest.mark.parametrize("K", [32, 64])
+def test_graph_tile_kernels_off_their_fast_paths(K, oracle):
+    """The 64-row tile kernels (rows_tile.h) away from the shape the bench exercises: a row array that is only 4-byte aligned
+    (no 16-byte block loads), a node count that is not a multiple of 64, neighbour ids far beyond the node count (the Elias-Fano
+    arena is sized for ids < N first and must size itself again from the largest id it met), requests by node list, and the
+    Elias-Fano words of sampled rows against the oracle's streams."""
+    import torch
+    from vector_db_id_compression_amd.codecs import CompactRows, EfLists, RocLists
+
+    rng = np.random.default_rng(100 + K)
+    N = 70000 + 37  # (>= 65 536: the whole-graph ROC decode takes the rows ordered by edge count)
+    deg = rng.integers(0, K + 1, size=N)
+    deg[::1000] = K
+    deg[1::1000] = 0
+    flat = torch.full((N * K + 1,), -1, dtype=torch.int32)
+    rows_np = np.full((N, K), -1, dtype=np.int32)
+    big_ids = rng.integers(0, 1 << 30, size=(N, K)).astype(np.int64)
+    for i in range(0, N, 1):
+        d = int(deg[i])
+        if d:
+            # distinct ids; every 7th row from a universe of 2^30, the others below N
+            src = np.unique(big_ids[i]) if i % 7 == 0 else np.unique(rng.integers(0, N, size=2 * K))
+            if src.size < d:
+                d = deg[i] = src.size
+            rows_np[i, :d] = rng.permutation(src)[:d].astype(np.int32)
+    flat[1:] = torch.from_numpy(rows_np.reshape(-1))
+    rows = flat.cuda()[1:].view(N, K)  # 4 bytes off a 16-byte boundary
+    assert rows.data_ptr() % 16 != 0
+    big = np.iinfo(np.int32).max
+    want = np.sort(np.where(rows_np >= 0, rows_np, big), axis=1)
+    nodes = rng.integers(0, N, size=3000).astype(np.uint64)
+    for cls in (EfLists, RocLists):  # (compact bits stores ids < N only: further down)
+        g = cls.encode_rows(rows)
+        every, cnt = g.decode_rows(None, K)
+        got = every.cpu().numpy()
+        assert np.array_equal(cnt, deg), cls.__name__
+        if cls is EfLists:
+            assert np.array_equal(np.sort(np.where(got >= 0, got, big), axis=1), want)
+            assert np.array_equal(got[:, :1][deg > 0, 0], want[deg > 0, 0])  # Elias-Fano decodes ascending
+        else:
+            ok = (rows_np.max(axis=1) & (rows_np.max(axis=1) - 1)) != 0  # (ROC is lossy for a power-of-two maximum, SURVEY Q3)
+            assert np.array_equal(np.sort(np.where(got >= 0, got, big), axis=1)[ok], want[ok])
+        sub, c2 = g.decode_rows(nodes, K)
+        assert np.array_equal(sub.cpu().numpy(), got[nodes.astype(np.int64)]) and np.array_equal(c2, deg[nodes.astype(np.int64)])
+        if cls is EfLists:
+            for i in (0, 7, 14, 1000, 1001, N - 1, N - 2):
+                d = int(deg[i])
+                if not d:
+                    continue
+                e = oracle.ef_build(np.sort(rows_np[i, :d]).astype(np.uint64))
+                low, high, lb, hb = g.export(i)
+                assert (lb, hb) == (e["low_nbits"], e["high_nbits"]), i
+                assert np.array_equal(low, e["low"]) and np.array_equal(high, e["high"]), i
+    small = np.where(rows_np >= N, rows_np % N, rows_np)  # compact bits: ids below N (duplicates inside a row are fine for it)
+    flat[1:] = torch.from_numpy(small.reshape(-1))
+    rows_c = flat.cuda()[1:].view(N, K)
+    c = CompactRows.encode_rows(rows_c)
+    dec, cnt = c.decode_rows(None, K)
+    assert np.array_equal(dec.cpu().numpy(), small) and np.array_equal(cnt, deg)
+    sub, c2 = c.decode_rows(nodes, K)
+    assert np.array_equal(sub.cpu().numpy(), small[nodes.astype(np.int64)])
+
+
 def test_empty_graph_and_list_objects():
     """Zero nodes / zero lists / all-empty rows through every codec (scan kernels with n = 0, zero-sized streams)."""
     from vector_db_id_compression_amd.codecs import CompactRows, EfLists, PackedLists, RocLists

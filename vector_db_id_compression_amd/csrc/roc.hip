@@ -50,6 +50,9 @@ struct vidc_roc {
     DevBuf<uint64_t> d_offsets, d_heads, d_word_off;
     DevBuf<uint32_t> d_prec, d_nwords, d_draws, d_words, d_perm;
     mutable uint64_t last_nonclean = 0;
+    // graph objects: the rows ordered by edge count (k_rows_order_*), built by the first whole-graph decode_rows (guarded by mu)
+    mutable DevBuf<uint32_t> d_row_order;
+    mutable bool row_order_ready = false;
     // decode_all plan, built on first use (depends only on the immutable metadata)
     mutable std::shared_ptr<struct DecPlanCache> plan_all;
     // the same plan without its device arrays, built by the encoder while its kernels run (the host would only wait)
@@ -321,20 +324,28 @@ void sort_desc(std::vector<uint32_t> &wl, const std::vector<uint64_t> &offsets) 
 // End of an encode call: status check + word offsets + sizes + compaction, all on the device.  Two halves so that the first
 // can be queued right behind the encode kernels -- while the host still plans the decode -- and ONE synchronisation serves the
 // kernels, the status summary (errors / lists waiting for the sorting pass) and the size read-back:
-//   finish_enqueue: status summary, exclusive scan of the word counts (and of the edge counts of graph rows), copies to `t`
-//   finish_complete (after a synchronisation of the stream): checks, allocation of the stream, compaction, final synchronisation
+//   finish_enqueue: status summary + totals into `t`; the exclusive scan of the word counts (IVF lists: k_roc_tail)
+//   finish_complete (after a synchronisation of the stream): checks, allocation of the stream, compaction (graph rows: with the scans
+//                   of the word and edge counts inside, k_roc_rows_compact), final synchronisation
 struct EncodeTail {
     Scratch s_sum, s_tmp, s_tmp2, s_state;
     bool state_zeroed = false;  // the tile states of k_roc_tail were cleared ahead of the encode kernels
+    const uint32_t *d_sizes = nullptr;  // graph rows: the edge counts, for the scan inside the compaction
     Pinned tail;
     unsigned long long *t = nullptr;  // [0..3] status summary (first bad list, -, retries, pending sorts), [4] total words, [5] ntotal, [6] non-empty rows
 };
 // (ahead of the encode kernels: the tile states of the tail kernel, so that clearing them is not part of the tail)
+inline uint32_t rows_tiles(uint64_t nlist) { return (uint32_t)((nlist + 63) / 64); }  // tiles of k_roc_rows_compact
+inline uint32_t rows_chunks(uint64_t nlist) { return (uint32_t)((nlist + VIDC_ROWS_CHUNK - 1) / VIDC_ROWS_CHUNK); }  // workgroups of k_roc_rows_totals
+inline size_t rows_state_bytes(uint64_t nlist) {  // tile sums (words, edges) | chunk sums | counter | chunk prefixes
+    return ((size_t)rows_tiles(nlist) * 2 + (size_t)rows_chunks(nlist) * 10 + 1) * 8;
+}
 int finish_prepare(vidc_ctx *ctx, const vidc_roc *r, EncodeTail &e) {
-    if (r->rows || !r->nlist) return VIDC_OK;
-    const uint32_t ntiles = (uint32_t)(r->nlist / VIDC_TAIL_TILE + 1u);
-    VIDC_TRY(e.s_state.get(ctx, ((size_t)ntiles + 10) * 8));  // (+ the tile counter, the tiles-done counter, the summary)
-    VIDC_HIP(hipMemsetAsync(e.s_state.p, 0, ((size_t)ntiles + 10) * 8, ctx->stream));
+    if (!r->nlist) return VIDC_OK;
+    // graph rows: [word scan | edge scan | tile counter | sum[8]] of k_roc_rows_totals / k_roc_rows_compact
+    const size_t bytes = r->rows ? rows_state_bytes(r->nlist) : ((size_t)(r->nlist / VIDC_TAIL_TILE + 1u) + 10) * 8;
+    VIDC_TRY(e.s_state.get(ctx, bytes));
+    VIDC_HIP(hipMemsetAsync(e.s_state.p, 0, bytes, ctx->stream));
     e.state_zeroed = true;
     return VIDC_OK;
 }
@@ -344,22 +355,30 @@ int finish_enqueue(vidc_ctx *ctx, vidc_roc *r, EncodeTail &e, Scratch &d_status_
     unsigned long long *t = e.t = e.tail.as<unsigned long long>();
     t[0] = ~0ull; t[1] = 0; t[2] = 0; t[3] = 0; t[4] = 0; t[5] = 0; t[6] = 0; t[7] = 0;
     VIDC_TRY(r->d_word_off.alloc(nlist + 1, ctx->dpool));
-    if (nlist) {  // summary + word offsets (+ CSR offsets of graph rows) + totals in one launch; its last workgroup stores the results into `t`
+    if (nlist && r->rows) {  // totals only: the scans ride on the compaction (k_roc_rows_compact)
+        const uint32_t nt = rows_tiles(nlist);
+        if (!e.state_zeroed) {
+            VIDC_TRY(e.s_state.get(ctx, rows_state_bytes(nlist)));
+            VIDC_HIP(hipMemsetAsync(e.s_state.p, 0, rows_state_bytes(nlist), ctx->stream));
+        }
+        e.state_zeroed = false;  // (used up)
+        e.d_sizes = d_sizes;
+        VIDC_TRY(r->d_offsets.alloc(nlist + 1, ctx->dpool));
+        hipLaunchKernelGGL(k_roc_rows_totals, dim3(rows_chunks(nlist)), dim3(256), 0, ctx->stream, r->d_nwords.p, d_sizes, d_status_buf.as<uint32_t>(),
+                           (uint32_t)nlist, e.s_state.as<unsigned long long>() + 2ull * nt, t);
+        VIDC_HIP(hipGetLastError());
+        return VIDC_OK;
+    }
+    if (nlist) {  // summary + word offsets + totals in one launch; its last workgroup stores the results into `t`
         const uint32_t ntiles = (uint32_t)(nlist / VIDC_TAIL_TILE + 1u);
-        const size_t state_bytes = ((size_t)ntiles * (r->rows ? 2u : 1u) + 10) * 8;
+        const size_t state_bytes = ((size_t)ntiles + 10) * 8;
         if (!e.state_zeroed) {
             VIDC_TRY(e.s_state.get(ctx, state_bytes));
             VIDC_HIP(hipMemsetAsync(e.s_state.p, 0, state_bytes, ctx->stream));
         }
         e.state_zeroed = false;  // (used up)
-        if (r->rows) {
-            VIDC_TRY(r->d_offsets.alloc(nlist + 1, ctx->dpool));
-            hipLaunchKernelGGL(k_roc_tail<true>, dim3(ntiles), dim3(256), 0, ctx->stream, r->d_nwords.p, (uint32_t)nlist, r->d_word_off.p,
-                               d_status_buf.as<uint32_t>(), e.s_state.as<unsigned long long>(), t, d_sizes, r->d_offsets.p);
-        } else
-            hipLaunchKernelGGL(k_roc_tail<false>, dim3(ntiles), dim3(256), 0, ctx->stream, r->d_nwords.p, (uint32_t)nlist, r->d_word_off.p,
-                               d_status_buf.as<uint32_t>(), e.s_state.as<unsigned long long>(), t, (const uint32_t *)nullptr,
-                               (uint64_t *)nullptr);
+        hipLaunchKernelGGL(k_roc_tail, dim3(ntiles), dim3(256), 0, ctx->stream, r->d_nwords.p, (uint32_t)nlist, r->d_word_off.p,
+                           d_status_buf.as<uint32_t>(), e.s_state.as<unsigned long long>(), t);
         VIDC_HIP(hipGetLastError());
         return VIDC_OK;
     }
@@ -386,7 +405,15 @@ int finish_complete(vidc_ctx *ctx, vidc_roc *r, EncodeTail &e, const uint32_t *d
     if (nlist) {
         EventTimer tm(ctx);
         const uint64_t *d_off = r->rows ? (const uint64_t *)nullptr : (const uint64_t *)r->d_offsets.p;
-        if (r->total_words / nlist < 64) {  // graph rows / tiny lists (a few dozen words each): one wavefront per 64 lists
+        if (r->rows) {  // 64 rows per wavefront; word offsets and CSR offsets are scanned on the way
+            const uint32_t nt = rows_tiles(nlist);
+            // (every wavefront resident at once: 64 threads, 260 bytes of LDS -> at least 8 per SIMD)
+            const uint32_t grid = std::min<uint32_t>(nt, (uint32_t)ctx->num_cu * 16u);
+            hipLaunchKernelGGL(k_roc_rows_compact, dim3(grid), dim3(64), 0, ctx->stream, d_arena, arena_stride, r->d_nwords.p, e.d_sizes,
+                               (uint32_t)nlist, e.s_state.as<unsigned long long>(), nt,
+                               e.s_state.as<unsigned long long>() + 2ull * nt + 8ull * rows_chunks(nlist) + 1, r->d_word_off.p, r->d_offsets.p,
+                               r->d_words.p);
+        } else if (r->total_words / nlist < 64) {  // tiny lists (a few dozen words each): one wavefront per 64 lists
             const uint32_t grid = (uint32_t)std::min<uint64_t>((nlist + 63) / 64, (uint64_t)ctx->num_cu * 64);
             hipLaunchKernelGGL(k_roc_compact_groups, dim3(grid), dim3(64), 0, ctx->stream, d_arena, d_off, arena_stride,
                                r->d_word_off.p, r->d_words.p, (uint32_t)nlist);
@@ -434,6 +461,7 @@ struct DecPlan {
     bool gsmall_lrows = false;       // DC_GSMALL items keep their member rows in LDS (33 KiB each: only for few lists)
     uint32_t lane_align = 4;         // slots a bucket row of the lane decoders is aligned / padded to (roc_lane_cap_nb)
     uint64_t implicit = 0;           // lean plan without a work list: items are rows 0..implicit-1
+    const uint32_t *order_dev = nullptr;  // ... or every row of the object in this device-resident order, each to its OWN output row
     DecPlan() = default;
     DecPlan(const DecPlan &) = default;
     DecPlan(DecPlan &&) = default;
@@ -1757,7 +1785,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     if (cache) {
         d_wl = cache->d_wl.p; d_scr_off = cache->d_scratch_off.p; d_slots_off = cache->d_slots_off.p;
     } else if (p.implicit) {
-        d_wl = nullptr;
+        d_wl = p.order_dev;
     } else {
         // one pinned staging block for everything that goes up: work list | scratch offsets | slot offsets | out offsets
         const size_t n8 = p.lean ? 0 : nwork;
@@ -1800,6 +1828,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     a.heads = r->d_heads.p; a.prec = r->d_prec.p; a.nwords = r->d_nwords.p; a.draws = r->d_draws.p;
     a.words = r->d_words.p; a.word_off = r->d_word_off.p;
     a.out = d_out; a.out_rows = d_out_rows; a.K = K;
+    a.out_by_list = (p.implicit && p.order_dev) ? 1u : 0u;
     a.scratch_words = s_scr.as<uint32_t>();
     a.slots = s_slots.as<uint32_t>();
     a.end_state = s_end.as<uint32_t>(); a.status = d_status;
@@ -2402,6 +2431,22 @@ int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uin
         DecPlan p;
         p.lean = true; p.tiny_lane = true; p.implicit = m;
         p.count[DC_TINY] = m;
+        if (m == r->nlist && m >= 65536) {  // the whole graph: rows of equal edge count share a wavefront (k_rows_order_*)
+            std::lock_guard<std::mutex> g(r->mu);
+            if (!r->row_order_ready) {
+                VIDC_HIP(hipSetDevice(ctx->device));
+                // (the per-workgroup histograms live behind the order in the object's own buffer: no scratch to hand back, no wait here)
+                const uint32_t nb = VIDC_ORDER_BLOCKS;
+                VIDC_TRY(r->d_row_order.alloc(m + (uint64_t)nb * 65, ctx->dpool));
+                uint32_t *part = r->d_row_order.p + m;
+                hipLaunchKernelGGL(k_rows_order_hist, dim3(nb), dim3(256), 0, ctx->stream, r->d_offsets.p, (uint32_t)m, part);
+                hipLaunchKernelGGL(k_rows_order_starts, dim3(1), dim3(128), 0, ctx->stream, part);
+                hipLaunchKernelGGL(k_rows_order_scatter, dim3(nb), dim3(256), 0, ctx->stream, r->d_offsets.p, (uint32_t)m, part, r->d_row_order.p);
+                VIDC_HIP(hipGetLastError());
+                r->row_order_ready = true;
+            }
+            p.order_dev = r->d_row_order.p;
+        }
         VIDC_TRY(decode_impl(ctx, r, p, nullptr, nullptr, d_out, K));
         if (counts) VIDC_TRY(fetch_sizes<uint32_t>(ctx, r->d_offsets.p, (const uint32_t *)nullptr, m, counts));
         return VIDC_OK;

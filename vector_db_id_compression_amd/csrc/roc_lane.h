@@ -1013,13 +1013,14 @@ __global__ void __launch_bounds__(64) k_roc_encode_tiny_lane(RocEncArgs a, const
 template <bool ROWS>
 __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const LaneDiv *__restrict__ dtab) {
     __shared__ __attribute__((aligned(16))) uint32_t buf[VIDC_TINY_STRIP * VIDC_TINY_LD];
-    __shared__ uint32_t rown[64];
+    __shared__ uint32_t rown[64], rowix[64];
     const uint32_t lane = lane_id();
     const uint32_t wi = blockIdx.x * 64u + lane;
     const bool have = wi < a.nwork;
     const uint32_t l = have ? (a.worklist ? a.worklist[wi] : wi) : 0u;
     const uint32_t n = have ? (uint32_t)(a.offsets[l + 1] - a.offsets[l]) : 0u;
-    const uint64_t ooff = have ? (a.out_off ? a.out_off[wi] : (ROWS ? (uint64_t)wi * a.K : a.offsets[l])) : 0ull;
+    const uint32_t orow = (ROWS && a.out_by_list) ? l : wi;  // output row of a graph decode: the item's number, or the row's own (ordered work list)
+    const uint64_t ooff = have ? (a.out_off ? a.out_off[wi] : (ROWS ? (uint64_t)orow * a.K : a.offsets[l])) : 0ull;
     const uint32_t P = have ? a.prec[l] : 0u;
     const uint32_t p0 = P < 16u ? P : 16u, p1 = P > 16u ? (P - 16u > 16u ? 16u : P - 16u) : 0u;
     const uint32_t W = have ? a.nwords[l] : 0u;
@@ -1128,6 +1129,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
     // with -1 (the reference leaves slots >= n untouched, altid_impl.cpp:153-165).  32 positions at a time through the strip's
     // LDS (position p of lane t at buf[(p & 31) * 65 + t]), then row-wise stores.
     rown[lane] = n_eff | (have ? 0x100u : 0u);
+    rowix[lane] = orow;
     const bool quad = ROWS && (a.K & 3u) == 0u && (((uintptr_t)a.out_rows | (ooff * 4u)) & 15u) == 0u && !a.out_off;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -1152,7 +1154,7 @@ __global__ void __launch_bounds__(64) k_roc_decode_tiny_lane(RocDecArgs a, const
                 o.y = c0 + 1u < n_r ? (int32_t)buf[(q4 + 1u) * VIDC_TINY_LD + rr] : -1;
                 o.z = c0 + 2u < n_r ? (int32_t)buf[(q4 + 2u) * VIDC_TINY_LD + rr] : -1;
                 o.w = c0 + 3u < n_r ? (int32_t)buf[(q4 + 3u) * VIDC_TINY_LD + rr] : -1;
-                *(int4 *)(a.out_rows + ((uint64_t)blockIdx.x * 64u + rr) * a.K + c0) = o;
+                *(int4 *)(a.out_rows + (uint64_t)rowix[rr] * a.K + c0) = o;
             }
         } else {
             for (uint32_t rr = 0; rr < 64u; rr++) {

@@ -2,13 +2,14 @@
 // HBM and the "one row per LANE" kernels in TILES of 64 consecutive rows.
 //
 // A wavefront owns 64 rows.  Their 64*K int32 are ONE contiguous block of the row array: the wavefront reads it with
-// fully coalesced 16-byte loads (lane j takes chunk i*64 + j, 1 KiB per instruction) and transposes it through LDS
-// (row t, entry e at lds[t * (KP + 1) + e]: odd leading dimension, so both the row-major fill and the per-lane
-// column read are free of bank conflicts), after which lane t holds row t in registers.  Decoders go the other
-// way.  Before (rounds 1-5) every lane read its own row with 16-byte loads 4*K bytes apart: 64 sectors per wave
-// instruction, rows fetched twice.
+// fully coalesced 16-byte loads (lane j takes chunk i*64 + j, 1 KiB per instruction) and transposes it through LDS,
+// 32 columns at a time (row t, column e at lds[t * 33 + (e & 31)]: odd leading dimension, so both the row-major
+// fill and the per-lane column read are free of bank conflicts), after which lane t holds row t in registers.
+// Decoders go the other way.  Before (rounds 1-5) every lane read its own row with 16-byte loads 4*K bytes apart:
+// 64 sectors per wave instruction, rows fetched twice.
 //
-// A workgroup is ONE wavefront (blockDim.x == 64): __syncthreads() only orders the wavefront's own LDS accesses.
+// A workgroup is ONE wavefront (blockDim.x == 64): wave_lds_sync() (wave.h) orders the wavefront's own LDS accesses
+// without waiting for its outstanding global loads and stores, which __syncthreads() would.
 #pragma once
 #include "wave.h"
 
@@ -32,10 +33,11 @@ inline uint32_t tile_grid(int num_cu, uint64_t ntiles, uint32_t per_cu) {
 inline __host__ __device__ uint32_t tile_magic(uint32_t d) { return d > 1u ? (uint32_t)((0x100000000ull + d - 1u) / d) : 0u; }
 __device__ __forceinline__ uint32_t tile_div(uint32_t f, uint32_t d, uint32_t magic) { return d > 1u ? __umulhi(f, magic) : f; }
 
-// The kernels are PERSISTENT: a wavefront walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and requests the block of its NEXT
-// tile (tile_issue_rows: 16-byte loads into registers, nothing waits) before it works on the current one, so the HBM round trip of
-// a tile hides behind the arithmetic of the previous tile instead of behind other wavefronts (the LDS image of a tile allows only
-// 9 wavefronts per CU, and one-shot wavefronts also pay their launch and kernel-argument loads per tile).
+// The DECODERS are persistent: a wavefront walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and requests the records of its
+// NEXT tile (tile_fetch16: 16-byte loads into registers, nothing waits) before it works on the current one, so the HBM round trip
+// of a tile hides behind the arithmetic of the previous tile.  The ENCODERS take one tile per wavefront: holding a second tile's
+// rows in registers across the encode costs them 254 VGPRs and a store-acknowledge wait at every commit (measured, round 6).
+// tile_issue_rows requests a tile's block of rows, every load ahead of the first use.
 template <int KP>
 struct TileRegs {
     int4 v[KP / 4];
