@@ -1894,7 +1894,7 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
         hipLaunchKernelGGL(k_ef_big_recs, dim3((uint32_t)std::min<uint64_t>(big_cap, (uint64_t)ctx->num_cu * 32)), dim3(64), 0, ctx->stream,
                            d_big, d_nbig, s_recs.as<EfChunkRec>());
     VIDC_HIP(hipGetLastError());
-    pt.end();
+    // (ONE pair of timing events around the call's kernels: every record is a packet the queue processes between two kernels)
     // (the geometry kernel stores its summary into the pinned block itself, and the chunk kernels their "not ascending" flag: a copy
     // engine between a kernel and the host's wake-up costs more than these kernels)
     tr.mark("geometry kernels queued");
@@ -1943,17 +1943,14 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
         e->has_perm = true;
         if (e->ntotal) {
             const uint32_t grid = (uint32_t)std::min<uint64_t>((e->ntotal + 255) / 256, (uint64_t)ctx->num_cu * 32);
-            pt.begin();
             hipLaunchKernelGGL(k_iota_perm, dim3(grid), dim3(256), 0, ctx->stream, e->d_offsets.p, nl32, e->ntotal,
                                e->d_perm.p);
-            pt.end();
         }
     }
     if (nchunks) {
         const uint32_t cgrid = (uint32_t)std::min<uint64_t>(nchunks, (uint64_t)ctx->num_cu * 256);
         hs[1].unsorted = 0u;
         uint32_t *d_flag = &hs[1].unsorted;
-        pt.begin();
         if (clear_high) VIDC_HIP(hipMemsetAsync(e->d_high.p, 0, high_words * 8, ctx->stream));
         if (wide_ids)
             hipLaunchKernelGGL(k_ef_lowhigh, dim3(cgrid), dim3(64), 0, ctx->stream, d_ids, s_recs.as<EfChunkRec>(), nchunks,
@@ -1968,8 +1965,8 @@ int ef_encode_fast(vidc_ctx *ctx, vidc_ef *e, const uint64_t *d_ids, uint32_t fl
             hipLaunchKernelGGL((k_ef_lowhigh32<EF_CHUNK / 64, false, true, true>), dim3(cgrid), dim3(64), 0, ctx->stream, d_ids,
                                s_recs.as<EfChunkRec>(), nchunks, e->d_low.p, e->d_high.p, e->d_hrank.p, e->d_batches.p, d_flag, d_drecs, d_abort);
         VIDC_HIP(hipGetLastError());
-        pt.end();
     }
+    pt.end();
     tr.mark("streams allocated, chunk kernels queued");
     VIDC_HIP(vidc::vidc_stream_wait(ctx->stream));
     tr.mark("wait");
@@ -2016,6 +2013,19 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     // (the host mirror of the offsets is filled from the device array the first time an entry point needs it: copying 8 bytes per list
     // here was a sixth of the host side of a 65 536-list call)
     e->ntotal = nlist ? offsets[nlist] : 0;
+    // the offsets go to the device first (pinned staging block, asynchronous copy); the host's pass over them runs while they cross PCIe
+    VIDC_TRY(e->d_offsets.alloc(nlist + 1, ctx->dpool));
+    Pinned h_off;
+    VIDC_TRY(h_off.get(ctx, (nlist + 1) * 8));
+    struct SyncOnExit {  // (an early return must not release the staging block of a copy in flight)
+        vidc_ctx *c;
+        bool armed = true;
+        ~SyncOnExit() { if (armed) (void)vidc::vidc_stream_wait(c->stream); }
+    } guard{ctx};
+    if (nlist) std::memcpy(h_off.p, offsets, (nlist + 1) * 8);
+    else *h_off.as<uint64_t>() = 0;
+    VIDC_HIP(hipMemcpyAsync(e->d_offsets.p, h_off.p, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    tr.mark("offsets staged");
     uint64_t nchunks = 0, max_list = 0;
     static_assert((EF_CHUNK & (EF_CHUNK - 1u)) == 0u, "the pass below counts chunks by a shift");
     const LengthsPass lp = lengths_pass(offsets, nlist, (uint32_t)__builtin_ctz(EF_CHUNK), 0u);  // (four lists per instruction where the host can)
@@ -2031,12 +2041,6 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
     }
     if (e->ntotal && !d_ids) return VIDC_ERR_INVALID;
     tr.mark("host offsets pass");
-    VIDC_TRY(e->d_offsets.alloc(nlist + 1, ctx->dpool));
-    Pinned h_off;
-    VIDC_TRY(h_off.get(ctx, (nlist + 1) * 8));
-    if (nlist) std::memcpy(h_off.p, offsets, (nlist + 1) * 8);
-    else *h_off.as<uint64_t>() = 0;
-    VIDC_HIP(hipMemcpyAsync(e->d_offsets.p, h_off.p, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     bool retry = false;
     e->max_list = max_list;
     tr.mark("offsets staged");
@@ -2054,6 +2058,7 @@ int vidc_ef_encode(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const
         VIDC_HIP(hipMemcpy(uni.data(), e->d_universe.p, nlist * 8, hipMemcpyDeviceToHost));
         for (uint64_t u : uni) ctx->ef_universe_hint = std::max(ctx->ef_universe_hint, u);
     }
+    guard.armed = false;  // (ef_encode_fast has waited)
     tr.mark("encode_fast (launches + wait)");
     if (retry) {  // some list is not ascending: general three-pass encoder with the sort
         e->offsets = vec_pool<uint64_t>().take(nlist + 1);

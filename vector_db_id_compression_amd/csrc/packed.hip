@@ -737,9 +737,16 @@ static int packed_setup(vidc_ctx *ctx, vidc_packed *p, uint64_t nlist, const uin
     p->device = ctx->device;
     p->nlist = nlist;
     p->bits = bits;
+    // the offsets go to the device first (pinned staging block, asynchronous copy): the host's own pass over them -- mirror, geometry --
+    // runs while they cross PCIe (round 6: it used to run in front of the copy, 25 us of a 65 536-list call before the GPU saw anything)
+    VIDC_TRY(keep.h_up.get(ctx, (nlist + 1) * 8 + 16));
+    uint64_t *h64 = keep.h_up.as<uint64_t>();
+    if (nlist) std::memcpy(h64, offsets, (nlist + 1) * 8);
+    else h64[0] = 0;
+    VIDC_TRY(p->d_offsets.alloc(nlist + 1, ctx->dpool));
+    VIDC_HIP(hipMemcpyAsync(p->d_offsets.p, h64, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     p->offsets = vec_pool<uint64_t>().take(nlist + 1);
-    if (nlist) p->offsets.assign(offsets, offsets + nlist + 1);
-    else p->offsets.assign(1, 0);
+    p->offsets.assign(h64, h64 + nlist + 1);
     p->ntotal = p->offsets[nlist];
     const LengthsPass lp = lengths_pass(p->offsets.data(), nlist, 9u, (uint32_t)bits);  // (four lists per instruction where the host can)
     static_assert(CHUNK_IDS == 512, "the pass above counts chunks of 2^9 ids");
@@ -753,11 +760,7 @@ static int packed_setup(vidc_ctx *ctx, vidc_packed *p, uint64_t nlist, const uin
         p->nchunks += (n + CHUNK_IDS - 1) / CHUNK_IDS;
         p->max_list = std::max(p->max_list, n);
     }
-    // offsets through pinned staging; word offsets, chunk table and padding words on the device (k_packed_table)
-    VIDC_TRY(keep.h_up.get(ctx, (nlist + 1) * 8 + 16));
-    uint64_t *h64 = keep.h_up.as<uint64_t>();
-    std::memcpy(h64, p->offsets.data(), (nlist + 1) * 8);
-    VIDC_TRY(p->d_offsets.alloc(nlist + 1, ctx->dpool));
+    // word offsets, chunk table and padding words on the device (k_packed_table)
     VIDC_TRY(p->d_word_off.alloc(nlist + 1, ctx->dpool));
     VIDC_TRY(p->d_words.alloc(p->total_words ? p->total_words : 1, ctx->dpool));
     VIDC_TRY(p->d_chunks.alloc(p->nchunks ? p->nchunks : 1, ctx->dpool));
@@ -768,7 +771,6 @@ static int packed_setup(vidc_ctx *ctx, vidc_packed *p, uint64_t nlist, const uin
                                             : (uint32_t)std::min<uint64_t>(16u, std::max<uint64_t>(1u, (nlist + 1 + 262143u) / 262144u));
     const uint32_t ntiles = (uint32_t)((nlist + 1 + 256u * per - 1u) / (256u * per));
     VIDC_TRY(keep.s_state.get(ctx, ((size_t)2 * ntiles + 1) * 8));
-    VIDC_HIP(hipMemcpyAsync(p->d_offsets.p, h64, (nlist + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     // (the device work of the set-up is part of the encode's kernel time: the caller reads ev0 .. ev1)
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     if (ntiles > 1u) VIDC_HIP(hipMemsetAsync(keep.s_state.p, 0, ((size_t)2 * ntiles + 1) * 8, ctx->stream));
