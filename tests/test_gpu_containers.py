@@ -433,6 +433,38 @@ def test_graph_tile_kernels_off_their_fast_paths(K, oracle):
     assert np.array_equal(sub.cpu().numpy(), small[nodes.astype(np.int64)])
 
 
+@pytest.mark.parametrize("N", [300, 70000])
+def test_graph_encoders_refuse_a_negative_id_that_is_not_the_terminator(N):
+    """A row ends at its first -1 (altid_impl.cpp:61-68, 110-117); any other negative entry in front of it is not an id.  The three
+    graph encoders report the row instead of encoding garbage -- through the wave-per-row kernels (N = 300) and the 64-row tile /
+    lane kernels with their device-side totals (N = 70 000); entries BEHIND the terminator are never looked at."""
+    from vector_db_id_compression_amd._lib import VidcError
+    from vector_db_id_compression_amd.codecs import CompactRows, EfLists, RocLists
+
+    rng = np.random.default_rng(N)
+    K = 32
+    rows = np.full((N, K), -1, dtype=np.int32)
+    for i in range(N):
+        d = int(rng.integers(1, K + 1))
+        rows[i, :d] = rng.choice(N, size=d, replace=False)
+    ok = rows.copy()
+    ok[N // 2, K - 1] = -1
+    ok[N // 2, K - 2] = -1
+    ok[N // 2, K - 1] = -9  # behind a terminator: ignored
+    bad = rows.copy()
+    victim = N - 3
+    bad[victim, 0] = -9
+    for cls in (RocLists, EfLists, CompactRows):
+        g = cls.encode_rows(ok)
+        dec = g.decode_rows(None, K)[0].cpu().numpy()
+        assert ((dec >= 0).sum(1) == ((ok >= 0).cumprod(1)).sum(1)).all(), cls.__name__
+        with pytest.raises(VidcError) as ei:
+            cls.encode_rows(bad)
+        assert "status -4" in str(ei.value), (cls.__name__, str(ei.value))  # VIDC_ERR_DOMAIN
+        if cls is RocLists:
+            assert f"list {victim} " in str(ei.value)  # (the first offending row, from the device-side summary)
+
+
 def test_empty_graph_and_list_objects():
     """Zero nodes / zero lists / all-empty rows through every codec (scan kernels with n = 0, zero-sized streams)."""
     from vector_db_id_compression_amd.codecs import CompactRows, EfLists, PackedLists, RocLists

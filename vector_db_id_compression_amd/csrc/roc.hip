@@ -407,8 +407,16 @@ int finish_complete(vidc_ctx *ctx, vidc_roc *r, EncodeTail &e, const uint32_t *d
         const uint64_t *d_off = r->rows ? (const uint64_t *)nullptr : (const uint64_t *)r->d_offsets.p;
         if (r->rows) {  // 64 rows per wavefront; word offsets and CSR offsets are scanned on the way
             const uint32_t nt = rows_tiles(nlist);
-            // (every wavefront resident at once: 64 threads, 260 bytes of LDS -> at least 8 per SIMD)
-            const uint32_t grid = std::min<uint32_t>(nt, (uint32_t)ctx->num_cu * 16u);
+            // Every wavefront of the launch resident at once (what the runtime says fits, not a guess: a tile waits for the tiles in
+            // front of it in its chunk), and a multiple of 64 of them: the 64 tiles of a chunk are then 64 consecutive workgroups
+            // in the same trip of their loops, so a tile only ever waits for workgroups with smaller numbers.
+            static const int occ = [] {
+                int o = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_roc_rows_compact, 64, 0) != hipSuccess || o < 1) o = 1;
+                return o;
+            }();
+            const uint32_t cap = std::max<uint32_t>(64u, (uint32_t)ctx->num_cu * (uint32_t)occ / 64u * 64u);
+            const uint32_t grid = std::min<uint32_t>(nt, cap);
             hipLaunchKernelGGL(k_roc_rows_compact, dim3(grid), dim3(64), 0, ctx->stream, d_arena, arena_stride, r->d_nwords.p, e.d_sizes,
                                (uint32_t)nlist, e.s_state.as<unsigned long long>(), nt,
                                e.s_state.as<unsigned long long>() + 2ull * nt + 8ull * rows_chunks(nlist) + 1, r->d_word_off.p, r->d_offsets.p,
@@ -2126,7 +2134,7 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
     unsigned long long *sum = h_sum.as<unsigned long long>();
     sum[0] = ~0ull; sum[1] = 0; sum[2] = 0; sum[3] = 0;
     // (the kernel's last workgroup stores the summary into the pinned block itself: no copy up, no copy down)
-    hipLaunchKernelGGL(k_roc_status_summary_host, dim3((uint32_t)std::min<uint64_t>((r->nlist + 255) / 256, 1024)), dim3(256),
+    hipLaunchKernelGGL(k_roc_status_summary_host, dim3((uint32_t)std::min<uint64_t>((r->nlist + 1023) / 1024, 256)), dim3(256),
                        0, ctx->stream, d_status, s_end.as<uint32_t>(), (uint32_t)r->nlist,
                        (unsigned long long *)(s_end.as<uint32_t>() + 2 * r->nlist), sum, (out_off_host || r->rows) ? 0u : RETRY_SLOTS);
     VIDC_HIP(hipGetLastError());

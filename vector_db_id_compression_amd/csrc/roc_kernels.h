@@ -603,22 +603,38 @@ __global__ void k_roc_status_summary(const uint32_t *status, const uint32_t *end
 __global__ void k_roc_status_summary_host(const uint32_t *status, const uint32_t *end_state, uint32_t nlist,
                                           unsigned long long *acc, unsigned long long *host, uint32_t retry_cap) {
     unsigned long long bad = ~0ull, nonclean = 0, retry = 0, pending = 0;
-    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x) {
-        const uint32_t s = status[l];
-        if (s == 5u) retry++;  // VIDC_ST_RETRY (roc_lane.h)
-        else if (s != VIDC_ST_OK && (unsigned long long)l < bad) bad = l;
-        if (s == VIDC_ST_PENDING_SORT) pending++;
-        if (end_state) nonclean += end_state[l];
+    // (four lists per thread and trip, every load ahead of the first use; at most 256 workgroups: each of them ends with an atomic on the
+    // one "workgroups done" counter, and same-address atomics of different workgroups take ~10 ns each, one after the other)
+    for (uint32_t l0 = blockIdx.x * blockDim.x * 4u; l0 < nlist; l0 += gridDim.x * blockDim.x * 4u) {
+        uint32_t sv[4], ev[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t l = l0 + (uint32_t)j * blockDim.x + threadIdx.x;
+            sv[j] = l < nlist ? status[l] : (uint32_t)VIDC_ST_OK;
+            ev[j] = (end_state && l < nlist) ? end_state[l] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long l = l0 + (uint32_t)j * blockDim.x + threadIdx.x;
+            const uint32_t s = sv[j];
+            if (s == 5u) retry++;  // VIDC_ST_RETRY (roc_lane.h)
+            else if (s != VIDC_ST_OK && l < bad) bad = l;
+            if (s == VIDC_ST_PENDING_SORT) pending++;
+            nonclean += ev[j];
+        }
     }
     if (bad != ~0ull) atomicMax(&acc[0], ~bad);
     if (nonclean) atomicAdd(&acc[1], nonclean);
     if (retry) atomicAdd(&acc[2], retry);
     if (pending) atomicAdd(&acc[3], pending);
     if (retry && retry_cap) {  // the handed-back lists themselves (a handful per 10^6): the host redoes them without fetching nlist statuses
-        for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < nlist; l += gridDim.x * blockDim.x)
-            if (status[l] == 5u) {
-                const unsigned long long k = atomicAdd(&acc[5], 1ull);
-                if (k < retry_cap) host[8 + k] = l;  // (pinned memory: each slot has one writer)
+        for (uint32_t l0 = blockIdx.x * blockDim.x * 4u; l0 < nlist; l0 += gridDim.x * blockDim.x * 4u)  // (this thread's lists again)
+            for (uint32_t j = 0; j < 4u; j++) {
+                const uint32_t l = l0 + j * blockDim.x + threadIdx.x;
+                if (l < nlist && status[l] == 5u) {
+                    const unsigned long long k = atomicAdd(&acc[5], 1ull);
+                    if (k < retry_cap) host[8 + k] = l;  // (pinned memory: each slot has one writer)
+                }
             }
     }
     // (Everything the last workgroup reads was written by device-scope atomics, which are performed at the memory side of the XCDs' L2s:
@@ -964,8 +980,8 @@ __global__ void __launch_bounds__(64) k_roc_rows_compact(const uint32_t *__restr
     __shared__ uint32_t lp[65];
     const uint32_t lane = threadIdx.x;
     unsigned long long *const state_w = state, *const state_e = state + ntiles;
-    // Tiles blockIdx.x, blockIdx.x + gridDim.x, ...: every wavefront of the launch is resident at once (the host sizes the grid for
-    // that), so a tile only ever waits for wavefronts that are running.
+    // Tiles blockIdx.x, blockIdx.x + gridDim.x, ...: every wavefront of the launch is resident at once (the host sizes the grid by the
+    // runtime's occupancy figure) and gridDim.x is a multiple of 64, so a tile waits only for running wavefronts with smaller numbers.
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t l = tile * 64u + lane;
         const bool in = l < n;
