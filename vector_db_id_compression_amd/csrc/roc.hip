@@ -470,6 +470,7 @@ struct DecPlan {
     uint32_t lane_align = 4;         // slots a bucket row of the lane decoders is aligned / padded to (roc_lane_cap_nb)
     uint64_t implicit = 0;           // lean plan without a work list: items are rows 0..implicit-1
     const uint32_t *order_dev = nullptr;  // ... or every row of the object in this device-resident order, each to its OWN output row
+    bool order_build = false;        // ... which this call builds first (k_rows_order_*, inside the call's timed region)
     DecPlan() = default;
     DecPlan(const DecPlan &) = default;
     DecPlan(DecPlan &&) = default;
@@ -1848,6 +1849,14 @@ int decode_impl(vidc_ctx *ctx, const vidc_roc *r, const DecPlan &p, const uint64
         for (int c = 0; c < DC_COUNT; c++) { base[c] = acc; acc += p.count[c]; }
     }
     EventTimer t(ctx);
+    if (p.order_build) {  // rows by edge count, most edges first: histogram per workgroup, segment starts, scatter
+        uint32_t *part = const_cast<uint32_t *>(p.order_dev) + nwork;
+        hipLaunchKernelGGL(k_rows_order_hist, dim3(VIDC_ORDER_BLOCKS), dim3(256), 0, ctx->stream, r->d_offsets.p, (uint32_t)nwork, part);
+        hipLaunchKernelGGL(k_rows_order_starts, dim3(1), dim3(128), 0, ctx->stream, part);
+        hipLaunchKernelGGL(k_rows_order_scatter, dim3(VIDC_ORDER_BLOCKS), dim3(256), 0, ctx->stream, r->d_offsets.p, (uint32_t)nwork, part,
+                           const_cast<uint32_t *>(p.order_dev));
+        VIDC_HIP(hipGetLastError());
+    }
     // classes run concurrently: the longest chains on the caller's stream, the rest on the auxiliary streams (fork below)
     // The lane-pair register decoder goes FIRST and alone when the call has other work for the whole machine: its wavefronts
     // need 256 VGPRs, and next to memory-bound classes that fill the SIMDs with small wavefronts they wait for register
@@ -2439,23 +2448,22 @@ int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uin
         DecPlan p;
         p.lean = true; p.tiny_lane = true; p.implicit = m;
         p.count[DC_TINY] = m;
+        std::unique_lock<std::mutex> g(r->mu, std::defer_lock);
         if (m == r->nlist && m >= 65536) {  // the whole graph: rows of equal edge count share a wavefront (k_rows_order_*)
-            std::lock_guard<std::mutex> g(r->mu);
+            g.lock();
             if (!r->row_order_ready) {
-                VIDC_HIP(hipSetDevice(ctx->device));
-                // (the per-workgroup histograms live behind the order in the object's own buffer: no scratch to hand back, no wait here)
-                const uint32_t nb = VIDC_ORDER_BLOCKS;
-                VIDC_TRY(r->d_row_order.alloc(m + (uint64_t)nb * 65, ctx->dpool));
-                uint32_t *part = r->d_row_order.p + m;
-                hipLaunchKernelGGL(k_rows_order_hist, dim3(nb), dim3(256), 0, ctx->stream, r->d_offsets.p, (uint32_t)m, part);
-                hipLaunchKernelGGL(k_rows_order_starts, dim3(1), dim3(128), 0, ctx->stream, part);
-                hipLaunchKernelGGL(k_rows_order_scatter, dim3(nb), dim3(256), 0, ctx->stream, r->d_offsets.p, (uint32_t)m, part, r->d_row_order.p);
-                VIDC_HIP(hipGetLastError());
-                r->row_order_ready = true;
+                // the first whole-graph decode of the object builds the order inside its own timed region (decode_impl) and publishes
+                // it -- other contexts may use it -- once this call has synchronised; until then the object's lock stays with this call
+                // (the per-workgroup histograms live behind the order in the object's own buffer: no scratch to hand back)
+                VIDC_TRY(r->d_row_order.alloc(m + (uint64_t)VIDC_ORDER_BLOCKS * 65, ctx->dpool));
+                p.order_build = true;
+            } else {
+                g.unlock();
             }
             p.order_dev = r->d_row_order.p;
         }
-        VIDC_TRY(decode_impl(ctx, r, p, nullptr, nullptr, d_out, K));
+        VIDC_TRY(decode_impl(ctx, r, p, nullptr, nullptr, d_out, K));  // (ends with a synchronisation of the stream)
+        if (p.order_build) { r->row_order_ready = true; g.unlock(); }
         if (counts) VIDC_TRY(fetch_sizes<uint32_t>(ctx, r->d_offsets.p, (const uint32_t *)nullptr, m, counts));
         return VIDC_OK;
     }
