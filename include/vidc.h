@@ -148,7 +148,9 @@ int vidc_roc_decode_lists(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const ui
 int vidc_roc_decode_gather(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *list_nos, uint64_t n_items,
                            const uint64_t *item_slot, const uint64_t *item_off, int64_t *ids_out);
 /* Graph flavour: d_out device int32[m*K]; rows padded with -1; counts (host, m, may be NULL) = num edges.
- * nodes == NULL selects nodes 0..m-1 (no index array is built or uploaded). */
+ * nodes == NULL selects nodes 0..m-1 (no index array is built or uploaded).  The first such call for every node of a graph of
+ * 65 536 nodes or more also sorts the node numbers by edge count inside the object (4 bytes per node of device memory, 0.02 ms
+ * at 10^6 nodes): rows of equal length then share a wavefront of the decoder; the output is the same rows in the same places. */
 int vidc_roc_decode_rows(vidc_ctx *ctx, const vidc_roc *r, uint64_t m, const uint64_t *nodes, uint32_t K,
                          int32_t *d_out, uint32_t *counts);
 /* End-state self check of the last decode_all: number of lists whose final ANS state is not the

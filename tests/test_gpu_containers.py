@@ -384,6 +384,7 @@ def test_graph_tile_kernels_off_their_fast_paths(K, oracle):
     deg = rng.integers(0, K + 1, size=N)
     deg[::1000] = K
     deg[1::1000] = 0
+    deg[1280:1408] = K  # two whole tiles of full rows with 30-bit ids: more stream words than the compaction requests in one pass
     flat = torch.full((N * K + 1,), -1, dtype=torch.int32)
     rows_np = np.full((N, K), -1, dtype=np.int32)
     big_ids = rng.integers(0, 1 << 30, size=(N, K)).astype(np.int64)
@@ -391,7 +392,7 @@ def test_graph_tile_kernels_off_their_fast_paths(K, oracle):
         d = int(deg[i])
         if d:
             # distinct ids; every 7th row from a universe of 2^30, the others below N
-            src = np.unique(big_ids[i]) if i % 7 == 0 else np.unique(rng.integers(0, N, size=2 * K))
+            src = np.unique(big_ids[i]) if (i % 7 == 0 or 1280 <= i < 1408) else np.unique(rng.integers(0, N, size=2 * K))
             if src.size < d:
                 d = deg[i] = src.size
             rows_np[i, :d] = rng.permutation(src)[:d].astype(np.int32)
