@@ -1222,7 +1222,9 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
                 if (use_lane_tiny) {  // one list per lane (roc_lane.h)
                     const dim3 grid((b.nwork + 63u) / 64u);
                     const LaneDiv *dt = (const LaneDiv *)ctx->d_ltab;
-                    if (rows && K <= 32) hipLaunchKernelGGL((k_roc_encode_tiny_lane<32, true>), grid, dim3(64), 0, st_, b, dt);
+                    if (rows && K == 32) hipLaunchKernelGGL((k_roc_encode_tiny_lane<32, true, true>), grid, dim3(64), 0, st_, b, dt);
+                    else if (rows && K == 64) hipLaunchKernelGGL((k_roc_encode_tiny_lane<64, true, true>), grid, dim3(64), 0, st_, b, dt);
+                    else if (rows && K < 32) hipLaunchKernelGGL((k_roc_encode_tiny_lane<32, true>), grid, dim3(64), 0, st_, b, dt);
                     else if (rows) hipLaunchKernelGGL((k_roc_encode_tiny_lane<64, true>), grid, dim3(64), 0, st_, b, dt);
                     else hipLaunchKernelGGL((k_roc_encode_tiny_lane<64, false>), grid, dim3(64), 0, st_, b, dt);
                 } else if (rows) hipLaunchKernelGGL(k_roc_encode_tiny<true>, dim3(b.nwork), dim3(64), 0, st_, b);

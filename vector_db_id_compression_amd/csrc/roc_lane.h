@@ -20,6 +20,7 @@
 #pragma once
 #include "roc_kernels.h"
 #include "roc_lane_reg_asm.h"
+#include "rows_tile.h"
 
 namespace vidc {
 namespace dev {
@@ -880,9 +881,14 @@ __global__ void __launch_bounds__(64) k_roc_decode_lane_reg(RocDecArgs a, const 
 //            ids grow down from the end of the same strip), rank = linear scan over the decoded ids
 // No global load sits on the serial chain (the divisor table is copied to LDS), so a step never waits on memory.
 // ===============================================================================================================
-template <int KP, bool ROWS>
+// Graph rows arrive as a TILE (rows_tile.h): the wavefront's 64 rows are one contiguous block, read with coalesced 16-byte loads and
+// transposed through the strip's LDS (FULL: K == KP).  Every lane reading its own row 256 bytes from its neighbour's -- 16 KiB of cache
+// lines per wavefront, nine wavefronts on a 32 KiB L1 -- made everything in front of the step loop 98 us on 10^6 x 64 rows; as a tile
+// 79 (44 load + edges + strip, 27 sort, 8 results).  The whole kernel stays at ~305 us: one wavefront's prologue runs under the
+// loops of the others, and the loop is the vector-issue bound of DESIGN section 5.
+template <int KP, bool ROWS, bool FULL = false>
 __global__ void __launch_bounds__(64) k_roc_encode_tiny_lane(RocEncArgs a, const LaneDiv *__restrict__ dtab) {
-    __shared__ uint32_t sid[KP * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t sid[KP * 64 + (ROWS ? 64 : 0)];  // (+ 64: the tile image of rows narrower than KP has a leading dimension of KP + 1)
     __shared__ LaneDiv dt[KP + 1];
     const uint32_t lane = lane_id();
     const uint32_t wi = blockIdx.x * 64u + lane;
@@ -895,28 +901,19 @@ __global__ void __launch_bounds__(64) k_roc_encode_tiny_lane(RocEncArgs a, const
     uint64_t off = 0;
     bool bad = false, unsorted = false;
     if (ROWS) {
-        // altid_impl.cpp:110-117: edges up to the first -1
+        // altid_impl.cpp:110-117: edges up to the first -1 (rows are never on a work list: lane t = row blockIdx.x * 64 + t)
         off = (uint64_t)l * a.K;
-        const int32_t *row = a.rows + off;
-        if ((a.K & 3u) == 0u) {
-#pragma unroll
-            for (int e = 0; e < KP; e += 4) {
-                int4 v = make_int4(-1, -1, -1, -1);
-                if (have && (uint32_t)e < a.K) v = *(const int4 *)(row + e);
-                r[e] = (uint32_t)v.x; r[e + 1] = (uint32_t)v.y; r[e + 2] = (uint32_t)v.z; r[e + 3] = (uint32_t)v.w;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < KP; e++) r[e] = (have && (uint32_t)e < a.K) ? (uint32_t)row[e] : 0xffffffffu;
+        const uint64_t row0 = (uint64_t)blockIdx.x * 64u;
+        const uint32_t nrows = a.nwork - (uint32_t)row0 < 64u ? a.nwork - (uint32_t)row0 : 64u;
+        const bool pf = FULL && (((uintptr_t)a.rows) & 15u) == 0u;
+        {
+            TileRegs<KP> pre;
+            if (pf) tile_issue_rows<KP>(a.rows, row0, nrows, pre);
+            tile_commit_rows<KP, FULL>(a.rows, row0, nrows, a.K, tile_magic(a.K), pf, pre, sid, r);
         }
-        n = have ? a.K : 0u;
-#pragma unroll
-        for (int e = KP - 1; e >= 0; e--) n = (r[e] == 0xffffffffu && (uint32_t)e < n) ? (uint32_t)e : n;
-#pragma unroll
-        for (int e = 0; e < KP; e++) {
-            bad |= (uint32_t)e < n && (int32_t)r[e] < 0;
-            r[e] = (uint32_t)e < n ? r[e] : 0xffffffffu;
-        }
+        uint32_t row_max;
+        n = tile_row_edges<KP>(r, bad, row_max);
+        if (!have) { n = 0; bad = false; }  // (lanes behind the last row of the last tile hold whatever the LDS held)
     } else {
         off = have ? a.offsets[l] : 0ull;
         n = have ? (uint32_t)(a.offsets[l + 1] - off) : 0u;
