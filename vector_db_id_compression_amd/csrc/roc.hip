@@ -543,7 +543,8 @@ int encode_impl(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const ui
         bool armed = false;
         ~SyncOnExit() { if (armed) (void)vidc::vidc_stream_wait(c->stream); }
     } pre_guard{ctx};
-    const uint32_t arena_stride = rows ? (uint32_t)arena_words_for(K) : 0u;
+    // (graph rows: slots of whole 64-byte sectors -- a row's ~100 bytes of stream then lie in two sectors, not in two and a half)
+    const uint32_t arena_stride = rows ? (uint32_t)((arena_words_for(K) + 15u) & ~15ull) : 0u;
     uint64_t arena_words = 0, nonempty = 0, ntiny = 0;
     if (rows) {
         if (K == 0 || K > TINY_MAX) {
