@@ -169,6 +169,48 @@ def test_wavelet_tree_select_and_asserts(oracle):
         WaveletTreeLists.build(np.array([0, 3], dtype=np.uint64), np.array([0, 1, 7], dtype=np.uint64))
 
 
+@pytest.mark.parametrize("nlist,ntotal", [(700, 300_001), (65536, 1 << 20), (3, 262_144)])
+def test_wavelet_tree_built_through_the_partitioned_scatter(nlist, ntotal, monkeypatch):
+    """From 2^18 ids on list_nos[id] is built in two streaming passes (partition by id >> 14, place per bucket: wt.hip) instead of
+    one random scatter: same tree as the direct scatter (VIDC_WT_SCATTER=1) down to the last word, and the same refusals --
+    an id twice (so another one missing), an id >= ntotal, a list that does not ascend (custom_invlists_impl.cpp:359-360)."""
+    from vector_db_id_compression_amd import VidcError
+    from vector_db_id_compression_amd.codecs import WaveletTreeLists
+
+    rng = np.random.default_rng(nlist)
+    assign = rng.integers(0, nlist, ntotal)
+    order = np.argsort(assign, kind="stable")
+    counts = np.bincount(assign, minlength=nlist)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    ids = order.astype(np.uint64)
+    wt = WaveletTreeLists.build(off, ids)
+    assert np.array_equal(wt.decode_all().cpu().numpy().view(np.uint64), ids)
+    ql = rng.integers(0, nlist, 500)
+    ql = ql[counts[ql] > 0]
+    qo = (rng.random(ql.size) * counts[ql]).astype(np.int64)
+    got = wt.select(ql, qo)
+    assert np.array_equal(got, ids[off[ql].astype(np.int64) + qo].astype(np.int64))
+    monkeypatch.setenv("VIDC_WT_SCATTER", "1")
+    ref = WaveletTreeLists.build(off, ids)
+    monkeypatch.delenv("VIDC_WT_SCATTER")
+    assert ref.size_in_bytes == wt.size_in_bytes and np.array_equal(ref.select(ql, qo), got)
+    assert np.array_equal(ref.decode_all().cpu().numpy(), wt.decode_all().cpu().numpy())
+    big = int(np.argmax(counts))
+    a, b = int(off[big]), int(off[big + 1])
+    assert b - a >= 3
+    for what in ("twice", "too large", "descending"):
+        bad = ids.copy()
+        if what == "twice":
+            bad[a + 1] = bad[a]  # (also breaks the order inside the list; the missing id is what the placement pass sees)
+            bad[b - 1] = ids[a + 1] if ids[a + 1] > bad[b - 2] else bad[b - 1]
+        elif what == "too large":
+            bad[b - 1] = ntotal + 5
+        else:
+            bad[a], bad[a + 1] = ids[a + 1], ids[a]
+        with pytest.raises(VidcError):
+            WaveletTreeLists.build(off, bad)
+
+
 def _rrr_wt_size(list_nos, nlist):
     """Bytes of a levelwise wavelet tree whose levels are RRR coded with 63-bit blocks and one sample per 32 blocks:
     6-bit class + ceil(log2 C(63, class)) offset bits per block, (32-bit stream pointer + 32-bit rank) per sample

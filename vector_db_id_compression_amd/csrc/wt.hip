@@ -97,6 +97,177 @@ __global__ void k_wt_check_syms(const uint32_t *syms, uint64_t ntotal, uint32_t 
     if (bad) atomicOr(err, 2u);
 }
 
+// ---- the same in two streaming passes (round 6, second half; 2^18 <= ntotal <= 2^24 ids, <= 2^18 lists).  The direct scatter writes 4 bytes
+// at 16.8 M random places: 32-byte partial writes, 0.48 ms at 92 % of its wavefronts' cycles waiting (profiles/r06_pmc_wt.json).  Here the
+// (id, list) pairs are first PARTITIONED by id >> 14 into <= 1024 buckets -- 256 workgroups over consecutive positions, per-workgroup
+// histograms, no global atomic (rule 3) -- as one packed dword each (14 low id bits | list number), then one workgroup
+// per bucket places its pairs in a 64 KiB LDS image of the bucket's 16 384 ids and writes the image out with 16-byte stores; a slot nobody
+// wrote is found on the way (k_wt_check_syms and the 0xff fill of the array are not needed).
+#define VIDC_WTP_BSH 14u
+#define VIDC_WTP_BUCKET (1u << VIDC_WTP_BSH)
+#define VIDC_WTP_MAXB 1024u  // buckets
+#define VIDC_WTP_LOFF 4224u  // lists a 4096-position tile may touch with their starts in LDS (more -- thousands of empty lists -- : searched in memory)
+#define VIDC_WTP_NBLK 1024u  // workgroups of the two passes over the positions (16 384 positions each at 16.8 M ids)
+__host__ __device__ inline uint64_t wtp_chunk(uint64_t ntotal) {  // positions per workgroup: whole 4096-position tiles
+    return ((ntotal + VIDC_WTP_NBLK - 1u) / VIDC_WTP_NBLK + 4095u) & ~4095ull;
+}
+__global__ void __launch_bounds__(256) k_wt_part_hist(const uint64_t *__restrict__ ids, uint64_t ntotal, uint32_t *__restrict__ part) {
+    __shared__ uint32_t h[VIDC_WTP_MAXB];
+    for (uint32_t k = threadIdx.x; k < VIDC_WTP_MAXB; k += 256u) h[k] = 0u;
+    __syncthreads();
+    const uint64_t chunk = wtp_chunk(ntotal), lo = blockIdx.x * chunk, hi = lo + chunk < ntotal ? lo + chunk : ntotal;
+    for (uint64_t g0 = lo; g0 < hi; g0 += 1024u) {
+        uint64_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t g = g0 + (uint32_t)j * 256u + threadIdx.x;
+            v[j] = g < hi ? ids[g] : ~0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (v[j] < ntotal) atomicAdd(&h[v[j] >> VIDC_WTP_BSH], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < VIDC_WTP_MAXB; k += 256u) part[blockIdx.x * VIDC_WTP_MAXB + k] = h[k];
+}
+// thread = bucket: its per-workgroup counts 128 at a time in registers -> exclusive prefix over the workgroups in place, the bucket's total to tot
+// (64 threads per workgroup: 2048 memory instructions per wavefront go through ONE CU's address unit, so sixteen CUs share them)
+__global__ void __launch_bounds__(64) k_wt_part_scan(uint32_t *part, uint32_t *tot) {
+    const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+    uint32_t run = 0;
+    for (uint32_t b0 = 0; b0 < VIDC_WTP_NBLK; b0 += 128u) {
+        uint32_t c[128];
+#pragma unroll
+        for (uint32_t b = 0; b < 128u; b++) c[b] = part[(b0 + b) * VIDC_WTP_MAXB + k];
+        asm volatile("" ::: "memory");  // (all 128 loads in flight before the first add: scheduled in groups of ~32 they were 32 round trips)
+#pragma unroll
+        for (uint32_t b = 0; b < 128u; b++) {
+            const uint32_t t = c[b];
+            c[b] = run;
+            run += t;
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < 128u; b++) part[(b0 + b) * VIDC_WTP_MAXB + k] = c[b];
+    }
+    tot[k] = run;
+}
+__global__ void __launch_bounds__(256) k_wt_part_scatter(const uint64_t *__restrict__ ids, const uint64_t *__restrict__ offsets, uint32_t nlist,
+                                                         uint64_t ntotal, const uint32_t *__restrict__ part, const uint32_t *__restrict__ tot,
+                                                         uint32_t *__restrict__ bstart, uint32_t *__restrict__ pairs, uint32_t *err) {
+    __shared__ uint32_t cur[VIDC_WTP_MAXB];
+    __shared__ uint32_t tsum[256];
+    __shared__ uint32_t loff[VIDC_WTP_LOFF];  // starts of the lists a tile touches, relative to the first of them
+    __shared__ uint32_t lo_s, hi_s;
+    {   // bucket starts = exclusive scan of the 1024 totals: four per thread + a scan over the threads
+        uint32_t t4[4], s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { t4[j] = tot[threadIdx.x * 4u + (uint32_t)j]; s += t4[j]; }
+        tsum[threadIdx.x] = s;
+        __syncthreads();
+        for (uint32_t o = 1; o < 256u; o <<= 1) {
+            const uint32_t v = threadIdx.x >= o ? tsum[threadIdx.x - o] : 0u;
+            __syncthreads();
+            tsum[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t run = tsum[threadIdx.x] - s;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t k = threadIdx.x * 4u + (uint32_t)j;
+            cur[k] = run + part[blockIdx.x * VIDC_WTP_MAXB + k];
+            if (blockIdx.x == 0) bstart[k] = run;
+            run += t4[j];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 255u) bstart[VIDC_WTP_MAXB] = run;
+    }
+    __syncthreads();
+    bool bad = false;
+    const uint64_t chunk = wtp_chunk(ntotal), c_lo = blockIdx.x * chunk, c_hi = c_lo + chunk < ntotal ? c_lo + chunk : ntotal;
+    for (uint64_t base = c_lo; base < c_hi; base += 4096u) {
+        const uint64_t end = base + 4096u < c_hi ? base + 4096u : c_hi;
+        // the tile's 16 ids per thread (and the id in front of each: the order check) are requested before anything waits; the starts of
+        // the lists the tile touches go to LDS, so that a position finds its list without a chain of global loads (five dependent round
+        // trips per position for lists of 256 ids: 0.23 ms of this kernel's first version)
+        uint64_t idv[16], prv[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint64_t g = base + (uint32_t)j * 256u + threadIdx.x;
+            idv[j] = g < end ? ids[g] : ~0ull;
+            prv[j] = (g < end && g) ? ids[g - 1] : 0ull;
+        }
+        if (threadIdx.x == 0) lo_s = find_list(offsets, nlist, base);
+        if (threadIdx.x == 64) hi_s = find_list(offsets, nlist, end - 1);
+        __syncthreads();
+        const uint32_t llo = lo_s, lhi = hi_s, nl = lhi - llo + 1u;  // lists llo .. lhi
+        const bool in_lds = nl <= VIDC_WTP_LOFF;
+        const uint64_t o0 = offsets[llo];
+        if (in_lds)
+            for (uint32_t k = threadIdx.x; k < nl; k += 256u) loff[k] = (uint32_t)(offsets[llo + k] - o0);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint64_t g = base + (uint32_t)j * 256u + threadIdx.x;
+            if (g >= end) continue;
+            uint32_t lo = 0, hi = nl;  // invariant: start of list llo + lo <= g < start of list llo + hi
+            uint64_t lstart;
+            if (in_lds) {
+                const uint32_t rel = (uint32_t)(g - o0);
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (loff[mid] <= rel) lo = mid; else hi = mid;
+                }
+                lstart = o0 + loff[lo];
+            } else {
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (offsets[llo + mid] <= g) lo = mid; else hi = mid;
+                }
+                lstart = offsets[llo + lo];
+            }
+            const uint64_t id = idv[j];
+            if (id < ntotal) {  // (counted by k_wt_part_hist: takes its slot whatever else is wrong with it)
+                if (g > lstart) bad |= prv[j] >= id;  // assert(ids_data[i] > prev_id), :359
+                const uint32_t slot = atomicAdd(&cur[id >> VIDC_WTP_BSH], 1u);
+                pairs[slot] = ((uint32_t)id & (VIDC_WTP_BUCKET - 1u)) | ((llo + lo) << VIDC_WTP_BSH);
+            } else {
+                bad = true;
+            }
+        }
+        __syncthreads();
+    }
+    if (bad) atomicOr(err, 1u);
+}
+__global__ void __launch_bounds__(256) k_wt_part_place(const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ bstart, uint64_t ntotal,
+                                                       uint32_t *__restrict__ syms, uint32_t *err) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t img[];  // VIDC_WTP_BUCKET dwords
+    for (uint32_t i = threadIdx.x; i < VIDC_WTP_BUCKET / 4u; i += 256u) ((uint4 *)img)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    __syncthreads();
+    const uint32_t j0 = bstart[blockIdx.x], j1 = bstart[blockIdx.x + 1u];
+    for (uint32_t j = j0 + threadIdx.x; j < j1; j += 1024u) {
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = j + (uint32_t)q * 256u < j1 ? pairs[j + (uint32_t)q * 256u] : ~0u;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (j + (uint32_t)q * 256u < j1) img[v[q] & (VIDC_WTP_BUCKET - 1u)] = v[q] >> VIDC_WTP_BSH;
+    }
+    __syncthreads();
+    const uint64_t first = (uint64_t)blockIdx.x << VIDC_WTP_BSH;
+    const uint32_t cnt = ntotal - first < VIDC_WTP_BUCKET ? (uint32_t)(ntotal - first) : VIDC_WTP_BUCKET;
+    bool bad = false;
+    for (uint32_t i = threadIdx.x * 4u; i < cnt; i += 1024u) {
+        const uint4 v = *(const uint4 *)(img + i);
+        if (i + 4u <= cnt) {
+            bad |= v.x == ~0u || v.y == ~0u || v.z == ~0u || v.w == ~0u;
+            *(uint4 *)(syms + first + i) = v;  // (the array and the bucket's first id are 16-byte aligned)
+        } else {
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+            for (uint32_t q = 0; i + q < cnt; q++) { bad |= e[q] == ~0u; syms[first + i + q] = e[q]; }
+        }
+    }
+    if (bad) atomicOr(err, 2u);  // a slot nobody wrote = an id that is missing = another one present twice
+}
+
 // ---- one level of the tree in ONE pass over its symbols (round 6).  Before: four launches per level -- a thread per 64-bit word gathering 64
 // symbols 4 bytes at a time, a SINGLE workgroup scanning the whole rank directory, a node-rank kernel, and a partition whose every element
 // asked the fresh rank directory three times -- 0.4 ms per level on 16.8 M ids, 6.4 ms for the 16 levels of a 65 536-list tree.
@@ -115,46 +286,69 @@ struct WtScanState {  // per tile: bit 63 = inclusive prefix, bit 62 = the tile'
 // dstab[2 (level, p) + b] (build only): what an element of node p with bit b adds its zero-rank / one-rank to for its slot in the next level:
 // slot = b ? (node start + zeros of the node - ones before the node) + ones before the element
 //          : (ones before the node) + zeros before the element        -- ONE table entry per element instead of four (two C, two nrank).
-__global__ void __launch_bounds__(1024) k_wt_node_ranks_from_C(const uint64_t *C, uint32_t nlist, uint32_t L, uint32_t *nrank, uint32_t *dstab) {
-    __shared__ uint64_t sh[1024];
-    __shared__ uint64_t carry;
-    const uint32_t level = blockIdx.x, shn = L - level;  // a node of this level spans 2^shn symbols
+// VIDC_WT_NR_G workgroups per level: workgroup g owns a run of nodes, adds up the right children of every node in FRONT of its run itself
+// (coalesced, independent loads: redundant work, 128 loads per thread at most for a 65 536-list tree) and then scans its run 256 nodes
+// per trip.  One workgroup per level -- 64 trips for the last level, or a run of 128 nodes per thread with every access 2 KiB from its
+// neighbour's -- kept the whole last level on ONE CU's address unit: 92-98 us whatever the loop looked like.
+#define VIDC_WT_NR_G 16u
+__global__ void __launch_bounds__(256) k_wt_node_ranks_from_C(const uint64_t *__restrict__ C, uint32_t nlist, uint32_t L, uint32_t *__restrict__ nrank,
+                                                              uint32_t *__restrict__ dstab) {
+    __shared__ uint64_t wsum[4];
+    const uint32_t level = blockIdx.x / VIDC_WT_NR_G, g = blockIdx.x % VIDC_WT_NR_G, shn = L - level;  // a node of this level spans 2^shn symbols
     uint32_t *out = nrank + wt_nrank_base(level);
+    uint32_t *dst = dstab + 2 * wt_nrank_base(level);
     const uint64_t nodes = 1ull << level;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint64_t p0 = 0; p0 < nodes; p0 += 1024) {
-        const uint64_t p = p0 + threadIdx.x;
-        uint64_t rs = 0;  // size of the node's right child: symbols [mid, hi)
-        if (p < nodes) {
-            uint64_t mid = ((2 * p + 1) << (shn - 1)), hi = ((2 * p + 2) << (shn - 1));
-            mid = mid > nlist ? nlist : mid;
-            hi = hi > nlist ? nlist : hi;
-            rs = C[hi] - C[mid];
-        }
-        sh[threadIdx.x] = rs;
+    const uint64_t B = ((nodes + VIDC_WT_NR_G - 1u) / VIDC_WT_NR_G + 255u) & ~255ull;
+    const uint64_t first = g * B, last = first + B < nodes ? first + B : nodes;
+    if (first >= nodes) return;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    auto csym = [&](uint64_t sym) -> uint64_t { return C[sym > nlist ? nlist : sym]; };
+    auto block_sum = [&](uint64_t v) -> uint64_t {  // every thread gets the sum over the workgroup
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         __syncthreads();
-        for (uint32_t o = 1; o < 1024; o <<= 1) {
-            const uint64_t v = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += v;
-            __syncthreads();
-        }
-        if (p < nodes) {
-            const uint64_t r_ns = carry + sh[threadIdx.x] - rs;
-            out[p] = (uint32_t)r_ns;
-            uint64_t lo = p << shn, hi = (p + 1) << shn;
-            lo = lo > nlist ? nlist : lo;
-            hi = hi > nlist ? nlist : hi;
-            const uint64_t ns = C[lo], zeros = (C[hi] - ns) - rs;
-            dstab[2 * (wt_nrank_base(level) + p)] = (uint32_t)r_ns;
-            dstab[2 * (wt_nrank_base(level) + p) + 1] = (uint32_t)(ns + zeros - r_ns);
-        }
+        if (lane == 0) wsum[wave] = v;
         __syncthreads();
-        if (threadIdx.x == 1023) carry += sh[1023];
-        __syncthreads();
+        return wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    };
+    uint64_t acc = 0;  // right children of the nodes in front of the run
+    for (uint64_t q0 = 0; q0 < first; q0 += 1024u) {
+        uint64_t m[4], h[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t q = q0 + (uint32_t)j * 256u + t;
+            m[j] = q < first ? csym((2 * q + 1) << (shn - 1)) : 0;
+            h[j] = q < first ? csym((2 * q + 2) << (shn - 1)) : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc += h[j] - m[j];
     }
-    if (threadIdx.x == 0) out[nodes] = (uint32_t)carry;
+    uint64_t carry = block_sum(acc);
+    for (uint64_t p0 = first; p0 < last; p0 += 256u) {
+        const uint64_t p = p0 + t;
+        const bool in = p < last;
+        const uint64_t ns = in ? csym(p << shn) : 0, mid = in ? csym((2 * p + 1) << (shn - 1)) : 0, hi = in ? csym((p + 1) << shn) : 0;
+        const uint64_t rs = hi - mid;  // size of the node's right child
+        uint64_t incl = rs;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t u = __shfl_up(incl, o, 64);
+            if (lane >= (uint32_t)o) incl += u;
+        }
+        __syncthreads();
+        if (lane == 63u) wsum[wave] = incl;
+        __syncthreads();
+        uint64_t before = carry;
+        for (uint32_t w2 = 0; w2 < wave; w2++) before += wsum[w2];
+        if (in) {
+            const uint64_t r_ns = before + incl - rs, zeros = mid - ns;
+            out[p] = (uint32_t)r_ns;
+            dst[2 * p] = (uint32_t)r_ns;
+            dst[2 * p + 1] = (uint32_t)(ns + zeros - r_ns);
+        }
+        carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+    if (last == nodes && t == 0) out[nodes] = (uint32_t)carry;
 }
 
 // syms_in: the level's order.  bits / rank: the level's bit vector (nwords words, zero padded) and its directory of ones before every
@@ -892,13 +1086,40 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
     VIDC_TRY(s_b.get(ctx, (nt ? nt : 1) * 4));
     VIDC_TRY(s_err.get(ctx, 4));
     VIDC_HIP(hipMemsetAsync(s_err.p, 0, 4, ctx->stream));
-    VIDC_HIP(hipMemsetAsync(s_a.p, 0xff, (nt ? nt : 1) * 4, ctx->stream));
+    // list_nos[id]: partition + place (two streaming passes) for the sizes it is built for, the direct scatter otherwise
+    const bool part2 = nt >= (1ull << 18) && nt <= (1ull << 24) && nlist <= (1ull << 18) && !std::getenv("VIDC_WT_SCATTER");
+    Scratch s_part;
+    if (!part2) VIDC_HIP(hipMemsetAsync(s_a.p, 0xff, (nt ? nt : 1) * 4, ctx->stream));
     const uint32_t grid = (uint32_t)std::min<uint64_t>((nt + 255) / 256 + 1, (uint64_t)ctx->num_cu * 32);
+    if (part2) VIDC_TRY(s_part.get(ctx, ((size_t)VIDC_WTP_NBLK * VIDC_WTP_MAXB + 2 * VIDC_WTP_MAXB + 8) * 4));
     VIDC_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    if (nt) {
+    if (part2) {
+        uint32_t *part = s_part.as<uint32_t>(), *tot = part + (size_t)VIDC_WTP_NBLK * VIDC_WTP_MAXB, *bstart = tot + VIDC_WTP_MAXB;
+        uint32_t *pairs = s_b.as<uint32_t>();  // (the second symbol array is free until the first level has run)
+        const uint32_t nbuckets = (uint32_t)((nt + VIDC_WTP_BUCKET - 1) >> VIDC_WTP_BSH);
+        hipLaunchKernelGGL(k_wt_part_hist, dim3(VIDC_WTP_NBLK), dim3(256), 0, ctx->stream, d_ids, nt, part);
+        hipLaunchKernelGGL(k_wt_part_scan, dim3(VIDC_WTP_MAXB / 64), dim3(64), 0, ctx->stream, part, tot);
+        hipLaunchKernelGGL(k_wt_part_scatter, dim3(VIDC_WTP_NBLK), dim3(256), 0, ctx->stream, d_ids, w->d_C.p, (uint32_t)nlist, nt, part, tot,
+                           bstart, pairs, s_err.as<uint32_t>());
+        hipLaunchKernelGGL(k_wt_part_place, dim3(nbuckets), dim3(256), VIDC_WTP_BUCKET * 4, ctx->stream, pairs, bstart, nt, s_a.as<uint32_t>(),
+                           s_err.as<uint32_t>());
+        VIDC_HIP(hipGetLastError());
+    } else if (nt) {
         hipLaunchKernelGGL(k_wt_scatter_syms, dim3((uint32_t)std::min<uint64_t>((nt + 4095) / 4096, (uint64_t)ctx->num_cu * 32)), dim3(256), 0,
                            ctx->stream, d_ids, w->d_C.p, (uint32_t)nlist, nt, s_a.as<uint32_t>(), s_err.as<uint32_t>());
         hipLaunchKernelGGL(k_wt_check_syms, dim3(grid), dim3(256), 0, ctx->stream, s_a.as<uint32_t>(), nt, s_err.as<uint32_t>());
+        VIDC_HIP(hipGetLastError());
+    }
+    // scan states of every level's pass (zeroed once) and the ones before every node start of every level (from C alone): queued in front
+    // of the wait for the verdict on the ids, which they do not depend on
+    Scratch s_state;
+    {
+        VIDC_TRY(w->d_dstab.alloc(2 * (wt_nrank_base(L) + 1)));
+        const size_t per_level = (size_t)((w->words_per_level + VIDC_WT_EPT * 4 - 1) / (VIDC_WT_EPT * 4)) + 1;
+        VIDC_TRY(s_state.get(ctx, (size_t)L * per_level * 8));
+        VIDC_HIP(hipMemsetAsync(s_state.p, 0, (size_t)L * per_level * 8, ctx->stream));
+        hipLaunchKernelGGL(k_wt_node_ranks_from_C, dim3(L * VIDC_WT_NR_G), dim3(256), 0, ctx->stream, w->d_C.p, (uint32_t)nlist, L, w->d_nrank.p,
+                           w->d_dstab.p);
         VIDC_HIP(hipGetLastError());
     }
     uint32_t err = 0;
@@ -911,17 +1132,6 @@ int vidc_wt_build(vidc_ctx *ctx, uint64_t nlist, const uint64_t *offsets, const 
     }
     uint32_t *cur = s_a.as<uint32_t>(), *nxt = s_b.as<uint32_t>();
     std::vector<uint64_t> lvl_bits(L, 0);  // wt_type 1: bits of every level's offset stream
-    // scan states of every level's pass (zeroed once) and the ones before every node start of every level (from C alone)
-    Scratch s_state;
-    {
-        VIDC_TRY(w->d_dstab.alloc(2 * (wt_nrank_base(L) + 1)));
-        const size_t per_level = (size_t)((w->words_per_level + VIDC_WT_EPT * 4 - 1) / (VIDC_WT_EPT * 4)) + 1;
-        VIDC_TRY(s_state.get(ctx, (size_t)L * per_level * 8));
-        VIDC_HIP(hipMemsetAsync(s_state.p, 0, (size_t)L * per_level * 8, ctx->stream));
-        hipLaunchKernelGGL(k_wt_node_ranks_from_C, dim3(L), dim3(1024), 0, ctx->stream, w->d_C.p, (uint32_t)nlist, L, w->d_nrank.p,
-                           w->d_dstab.p);
-        VIDC_HIP(hipGetLastError());
-    }
     for (uint32_t level = 0; level < L && nt; level++) {
         uint64_t *bits = rrr ? s_lvl_bits.as<uint64_t>() : w->d_bits.p + (uint64_t)level * w->words_per_level;
         uint32_t *rank = rrr ? s_lvl_rank.as<uint32_t>() : w->d_rank.p + (uint64_t)level * (w->blocks_per_level + 1);
