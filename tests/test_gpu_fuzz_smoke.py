@@ -10,7 +10,8 @@ Each fuzzer runs in its own process for a few seconds with a fixed seed:
   kernels, the general kernels and the oracle on lists of 4 097..150 000 ids (duplicates, unsorted input, the lossy regime);
 * fuzz_ef_packed.py: Elias-Fano / packed-bits streams against the oracle's words;
 * fuzz_graph_roc.py: ROC graph objects (random widths, node counts on both sides of the edge-count ordering, unaligned row arrays): the
-  64-row tile / lane kernels against the wave-per-row kernels and the oracle.
+  64-row tile / lane kernels against the wave-per-row kernels and the oracle;
+* fuzz_wt.py: wavelet trees built through the partitioned scatter against the direct scatter and the input.
 The long runs (minutes, other seeds) stay in tools/final_run.sh; their logs are profiles/r05*_long_fuzz.txt.
 """
 import os
@@ -27,6 +28,7 @@ CASES = [
     ("fuzz_chain.py", ["6", "8", "wide"], "fuzz_chain ok"),
     ("fuzz_ef_packed.py", ["5", "6"], "fuzz ok"),
     ("fuzz_graph_roc.py", ["5", "8"], "fuzz ok"),
+    ("fuzz_wt.py", ["5", "6"], "fuzz ok"),
 ]
 
 

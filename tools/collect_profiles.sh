@@ -16,7 +16,7 @@ cp $S/bench_graph.json $D/${R}_bench_graph_1M_x_64.json
 cp $S/probe_grp.txt $D/${R}_probe_grp.txt
 for c in ef packed; do for w in s2 uniform_16m s1; do cp $S/${c}_${w}_kernel_stats.csv $D/${R}_bench_${c}_${w}_kernel_stats.csv; done; done
 (for f in pytest_gpu pytest_force_general pytest_no_lane pytest_force_lane pytest_old_u pytest_full_prepass_no_lane_reg pytest_force_grp pytest_wide pytest_no_lane_pair pytest_lane_loop pytest_no_length_classes pytest_no_avx2 pytest_r5_switches pytest_r5_old_defaults pytest_r5_mask_prio pytest_pool_poison; do echo "== $f"; cat $S/$f.txt; done
- for f in fuzz_chain fuzz_chain_wide fuzz_families fuzz_ef_packed fuzz_graph_roc chain_probe bench_wt smoke; do echo "== $f"; cat $S/$f.txt; done) | grep -v "amdgpu.ids" > $D/${R}_tests_all_modes.txt
+ for f in fuzz_chain fuzz_chain_wide fuzz_families fuzz_ef_packed fuzz_graph_roc fuzz_wt chain_probe bench_wt smoke; do echo "== $f"; cat $S/$f.txt; done) | grep -v "amdgpu.ids" > $D/${R}_tests_all_modes.txt
 [ -f $S/search_paths.txt ] && cp $S/search_paths.txt $D/${R}_search_paths.txt
 [ -f $S/trace_u16.txt ] && grep -v amdgpu.ids $S/trace_u16.txt > $D/${R}_trace_uniform16m_host.txt
 [ -f $S/hw_gpr_idx_probe.txt ] && cp $S/hw_gpr_idx_probe.txt $D/${R}_hw_gpr_idx_probe.txt

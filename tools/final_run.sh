@@ -32,6 +32,7 @@ timeout 300 python tools/chain_probe.py 2>&1 | tail -6 > gpurun_out/$R/chain_pro
 timeout 300 python tools/fuzz_families.py 31 90 2>&1 | tail -1 > gpurun_out/$R/fuzz_families.txt
 timeout 300 python tools/fuzz_ef_packed.py 31 40 2>&1 | tail -1 > gpurun_out/$R/fuzz_ef_packed.txt
 timeout 300 python tools/fuzz_graph_roc.py 31 40 2>&1 | tail -1 > gpurun_out/$R/fuzz_graph_roc.txt
+timeout 300 python tools/fuzz_wt.py 31 30 2>&1 | tail -1 > gpurun_out/$R/fuzz_wt.txt
 timeout 300 python tools/bench_wt.py 2>&1 | tail -4 > gpurun_out/$R/bench_wt.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/$R/smoke.txt 2>&1
 timeout 600 python bench.py > gpurun_out/$R/bench.json 2> gpurun_out/$R/bench.err
