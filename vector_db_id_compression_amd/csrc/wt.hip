@@ -100,13 +100,13 @@ __global__ void k_wt_check_syms(const uint32_t *syms, uint64_t ntotal, uint32_t 
 // ---- the same in two streaming passes (round 6, second half; 2^18 <= ntotal <= 2^24 ids, <= 2^18 lists).  The direct scatter writes 4 bytes
 // at 16.8 M random places: 32-byte partial writes, 0.48 ms at 92 % of its wavefronts' cycles waiting (profiles/r06_pmc_wt.json).  Here the
 // (id, list) pairs are first PARTITIONED by id >> 14 into <= 1024 buckets -- 256 workgroups over consecutive positions, per-workgroup
-// histograms, no global atomic (rule 3) -- as one packed dword each (14 low id bits | list number), then one workgroup
+// histograms, no global atomic (rule 3) -- as one packed dword each (14 low id bits | list number; the list of a position from the list starts marked in a tile's LDS image and a scan,
+// not from a search per position), then one workgroup
 // per bucket places its pairs in a 64 KiB LDS image of the bucket's 16 384 ids and writes the image out with 16-byte stores; a slot nobody
 // wrote is found on the way (k_wt_check_syms and the 0xff fill of the array are not needed).
 #define VIDC_WTP_BSH 14u
 #define VIDC_WTP_BUCKET (1u << VIDC_WTP_BSH)
 #define VIDC_WTP_MAXB 1024u  // buckets
-#define VIDC_WTP_LOFF 4224u  // lists a 4096-position tile may touch with their starts in LDS (more -- thousands of empty lists -- : searched in memory)
 #define VIDC_WTP_NBLK 1024u  // workgroups of the two passes over the positions (16 384 positions each at 16.8 M ids)
 __host__ __device__ inline uint64_t wtp_chunk(uint64_t ntotal) {  // positions per workgroup: whole 4096-position tiles
     return ((ntotal + VIDC_WTP_NBLK - 1u) / VIDC_WTP_NBLK + 4095u) & ~4095ull;
@@ -156,8 +156,9 @@ __global__ void __launch_bounds__(256) k_wt_part_scatter(const uint64_t *__restr
                                                          uint32_t *__restrict__ bstart, uint32_t *__restrict__ pairs, uint32_t *err) {
     __shared__ uint32_t cur[VIDC_WTP_MAXB];
     __shared__ uint32_t tsum[256];
-    __shared__ uint32_t loff[VIDC_WTP_LOFF];  // starts of the lists a tile touches, relative to the first of them
+    __shared__ uint32_t lidx[4096 + 256];       // per position of a tile: list starts marked, then the number of the position's list
     __shared__ uint32_t lo_s, hi_s;
+    uint32_t bs4[4];  // starts of this thread's four buckets
     {   // bucket starts = exclusive scan of the 1024 totals: four per thread + a scan over the threads
         uint32_t t4[4], s = 0;
 #pragma unroll
@@ -174,20 +175,27 @@ __global__ void __launch_bounds__(256) k_wt_part_scatter(const uint64_t *__restr
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t k = threadIdx.x * 4u + (uint32_t)j;
-            cur[k] = run + part[blockIdx.x * VIDC_WTP_MAXB + k];
+            bs4[j] = run;
             if (blockIdx.x == 0) bstart[k] = run;
             run += t4[j];
         }
         if (blockIdx.x == 0 && threadIdx.x == 255u) bstart[VIDC_WTP_MAXB] = run;
     }
-    __syncthreads();
     bool bad = false;
-    const uint64_t chunk = wtp_chunk(ntotal), c_lo = blockIdx.x * chunk, c_hi = c_lo + chunk < ntotal ? c_lo + chunk : ntotal;
+    // chunks blockIdx.x, blockIdx.x + gridDim.x, ... (the launch has one workgroup per chunk; fewer, each walking several chunks -- so that
+    // fewer of the 64-byte bucket runs are open at once and their lines fill up in the L2 -- measured no faster: 143 / 221 us with 512 / 256)
+    for (uint32_t cb = blockIdx.x; cb < VIDC_WTP_NBLK; cb += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t k = threadIdx.x * 4u + (uint32_t)j;
+        cur[k] = bs4[j] + part[cb * VIDC_WTP_MAXB + k];
+    }
+    __syncthreads();
+    const uint64_t chunk = wtp_chunk(ntotal), c_lo = cb * chunk, c_hi = c_lo + chunk < ntotal ? c_lo + chunk : ntotal;
     for (uint64_t base = c_lo; base < c_hi; base += 4096u) {
         const uint64_t end = base + 4096u < c_hi ? base + 4096u : c_hi;
-        // the tile's 16 ids per thread (and the id in front of each: the order check) are requested before anything waits; the starts of
-        // the lists the tile touches go to LDS, so that a position finds its list without a chain of global loads (five dependent round
-        // trips per position for lists of 256 ids: 0.23 ms of this kernel's first version)
+        // the tile's 16 ids per thread (and the id in front of each: the order check) are requested before anything waits
         uint64_t idv[16], prv[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
@@ -197,43 +205,58 @@ __global__ void __launch_bounds__(256) k_wt_part_scatter(const uint64_t *__restr
         }
         if (threadIdx.x == 0) lo_s = find_list(offsets, nlist, base);
         if (threadIdx.x == 64) hi_s = find_list(offsets, nlist, end - 1);
+#pragma unroll
+        for (int j = 0; j < 17; j++) lidx[(uint32_t)j * 256u + threadIdx.x] = 0u;
         __syncthreads();
         const uint32_t llo = lo_s, lhi = hi_s, nl = lhi - llo + 1u;  // lists llo .. lhi
-        const bool in_lds = nl <= VIDC_WTP_LOFF;
-        const uint64_t o0 = offsets[llo];
-        if (in_lds)
-            for (uint32_t k = threadIdx.x; k < nl; k += 256u) loff[k] = (uint32_t)(offsets[llo + k] - o0);
+        const bool first_starts = offsets[llo] == base;  // (the tile's first position opens list llo: no id in front of it to compare with)
+        // list of a position = llo + the number of lists llo + 1 .. lhi that start at or in front of it: every such list marks its start
+        // (all of them lie inside the tile), a scan over the tile's 4096 positions does the rest -- no search per position (a binary search
+        // in LDS per position, a chain of dependent reads sixteen times in a row per thread, was most of this kernel's 0.2 ms)
+        for (uint32_t k = 1u + threadIdx.x; k < nl; k += 256u) {
+            const uint32_t rel = (uint32_t)(offsets[llo + k] - base);
+            atomicAdd(&lidx[rel + (rel >> 4)], 1u);  // (entry p at p + p / 16: thread t's sixteen entries of the scan below are conflict-free)
+        }
+        __syncthreads();
+        {
+            uint32_t f[16], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { f[j] = lidx[threadIdx.x * 17u + (uint32_t)j]; sum += f[j]; }
+            uint32_t incl = sum;
+            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = (uint32_t)__shfl_up((int)incl, o, 64);
+                if (lane >= (uint32_t)o) incl += u;
+            }
+            if (lane == 63u) tsum[wave] = incl;
+            __syncthreads();
+            uint32_t run = incl - sum;
+            for (uint32_t w2 = 0; w2 < wave; w2++) run += tsum[w2];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                run += f[j];
+                lidx[threadIdx.x * 17u + (uint32_t)j] = run | (f[j] ? 0x80000000u : 0u);  // bit 31: a list starts here
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            const uint64_t g = base + (uint32_t)j * 256u + threadIdx.x;
+            const uint32_t rel = (uint32_t)j * 256u + threadIdx.x;
+            const uint64_t g = base + rel;
             if (g >= end) continue;
-            uint32_t lo = 0, hi = nl;  // invariant: start of list llo + lo <= g < start of list llo + hi
-            uint64_t lstart;
-            if (in_lds) {
-                const uint32_t rel = (uint32_t)(g - o0);
-                while (hi - lo > 1u) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (loff[mid] <= rel) lo = mid; else hi = mid;
-                }
-                lstart = o0 + loff[lo];
-            } else {
-                while (hi - lo > 1u) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (offsets[llo + mid] <= g) lo = mid; else hi = mid;
-                }
-                lstart = offsets[llo + lo];
-            }
+            const uint32_t v = lidx[rel + (rel >> 4)];
             const uint64_t id = idv[j];
             if (id < ntotal) {  // (counted by k_wt_part_hist: takes its slot whatever else is wrong with it)
-                if (g > lstart) bad |= prv[j] >= id;  // assert(ids_data[i] > prev_id), :359
+                if (!(v >> 31) && !(rel == 0u && first_starts)) bad |= prv[j] >= id;  // assert(ids_data[i] > prev_id), :359 (not for the first id of a list)
                 const uint32_t slot = atomicAdd(&cur[id >> VIDC_WTP_BSH], 1u);
-                pairs[slot] = ((uint32_t)id & (VIDC_WTP_BUCKET - 1u)) | ((llo + lo) << VIDC_WTP_BSH);
+                pairs[slot] = ((uint32_t)id & (VIDC_WTP_BUCKET - 1u)) | ((llo + (v & 0x7fffffffu)) << VIDC_WTP_BSH);
             } else {
                 bad = true;
             }
         }
         __syncthreads();
+    }
     }
     if (bad) atomicOr(err, 1u);
 }
